@@ -1,0 +1,205 @@
+/*
+ * mjpc_hip.h — C ABI of the MI355X-native Predictive-Sampling rollout engine.
+ *
+ * This is the drop-in boundary for ONE path of hartikainen/mujoco_mpc:
+ *   mjpc/planners/sampling/planner.cc:342-380  (SamplingPlanner::Rollouts, the ThreadPool fan-out)
+ *   mjpc/trajectory.cc:100-210                 (Trajectory::NoisyRollout, the horizon loop)
+ *   mjpc/trajectory.cc:312-326                 (Trajectory::UpdateReturn)
+ *   mjpc/planners/sampling/planner.cc:168-181  (partial_sort -> winner)
+ *
+ * Plain C, plain pointers and sizes, no C++/torch types.  Every array is fp64
+ * (mjtNum == double in the reference) or int32.
+ *
+ * MjpcHipModel mirrors the fields of MuJoCo's `mjModel` the path reads (same names, same
+ * layout, same units) so that the reference-side shim is a field-by-field pointer copy
+ * from the `mjModel*` handed to `SamplingPlanner::Initialize`
+ * (mjpc/planners/sampling/planner.cc:40-76).  See INTEGRATION.md.
+ */
+#ifndef MJPC_HIP_H_
+#define MJPC_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- enums (numeric values identical to MuJoCo 3.1.4 / MJPC) ------------------------- */
+enum { MJPC_JNT_FREE = 0, MJPC_JNT_BALL = 1, MJPC_JNT_SLIDE = 2, MJPC_JNT_HINGE = 3 };
+enum {
+  MJPC_GEOM_PLANE = 0, MJPC_GEOM_HFIELD = 1, MJPC_GEOM_SPHERE = 2, MJPC_GEOM_CAPSULE = 3,
+  MJPC_GEOM_ELLIPSOID = 4, MJPC_GEOM_CYLINDER = 5, MJPC_GEOM_BOX = 6, MJPC_GEOM_MESH = 7
+};
+enum { MJPC_CONE_PYRAMIDAL = 0, MJPC_CONE_ELLIPTIC = 1 };
+enum { MJPC_DSBL_CONTACT = 1 << 4 };            /* mjDSBL_CONTACT */
+enum { MJPC_BIAS_NONE = 0, MJPC_BIAS_AFFINE = 1 };
+/* spline interpolation, mjpc/spline/spline.h:30-34 */
+enum { MJPC_SPLINE_ZERO = 0, MJPC_SPLINE_LINEAR = 1, MJPC_SPLINE_CUBIC = 2 };
+/* norm types, mjpc/norm.h:27-38 */
+enum {
+  MJPC_NORM_NULL = -1, MJPC_NORM_QUADRATIC = 0, MJPC_NORM_L22 = 1, MJPC_NORM_L2 = 2,
+  MJPC_NORM_COSH = 3, MJPC_NORM_POWER = 5, MJPC_NORM_SMOOTHABS = 6, MJPC_NORM_SMOOTHABS2 = 7,
+  MJPC_NORM_RECTIFY = 8
+};
+/* built-in device residuals (the reference dispatches through the global mjcb_sensor
+ * callback, mjpc/app.cc:110-126; a GPU cannot call back into host C++) */
+enum {
+  MJPC_TASK_PARTICLE = 0,   /* mjpc/test/testdata/particle_residual.h:33-43 */
+  MJPC_TASK_CARTPOLE = 1,   /* mjpc/tasks/cartpole/cartpole.cc:36-49 */
+  MJPC_TASK_QUADRUPED = 2,  /* mjpc/tasks/quadruped/quadruped.cc:33-221 */
+  MJPC_TASK_COPYSTATE = 3   /* residual = [qpos,qvel] (mjpc/test/agent/rollout_test.cc:40-60) */
+};
+enum { MJPC_OBJ_BODY = 1, MJPC_OBJ_XBODY = 2, MJPC_OBJ_GEOM = 5, MJPC_OBJ_SITE = 6 };
+
+#define MJPC_MINVAL 1e-15           /* mjMINVAL */
+#define MJPC_MAX_RETURN 1.0e6       /* kMaxReturnValue, mjpc/trajectory.cc:29 */
+#define MJPC_MAX_COST_TERMS 128     /* kMaxCostTerms, mjpc/task.h */
+#define MJPC_MAX_HORIZON 512        /* kMaxTrajectoryHorizon, mjpc/trajectory.h:27 */
+
+/* ---- model: the subset of mjModel the path reads ------------------------------------- */
+typedef struct MjpcHipModel {
+  /* sizes */
+  int nq, nv, nu, na, nbody, njnt, ngeom, nsite, nmocap, nuserdata, nkey, nexclude;
+  /* mjOption */
+  double timestep;
+  double gravity[3];
+  double impratio;
+  double tolerance;        /* solver tolerance (1e-8) */
+  double ls_tolerance;     /* line-search tolerance (0.01) */
+  int cone;                /* MJPC_CONE_* */
+  int iterations;          /* max Newton iterations (100) */
+  int ls_iterations;       /* max line-search iterations (50) */
+  int disableflags;        /* mjDSBL_* bits; only MJPC_DSBL_CONTACT is honoured */
+  /* mjStatistic */
+  double meaninertia;
+  /* engine capacities (0 = default); overflow => candidate failure, like MuJoCo's
+   * "contact/constraint buffer full" warnings -> mjpc CheckWarnings (utilities.cc:787-799) */
+  int nconmax, nefcmax;
+  /* bodies */
+  const int *body_parentid, *body_rootid, *body_weldid, *body_mocapid;
+  const int *body_jntnum, *body_jntadr, *body_dofnum, *body_dofadr;
+  const double *body_pos, *body_quat, *body_ipos, *body_iquat;
+  const double *body_mass, *body_subtreemass, *body_inertia, *body_invweight0;
+  /* joints */
+  const int *jnt_type, *jnt_qposadr, *jnt_dofadr, *jnt_bodyid, *jnt_limited;
+  const double *jnt_pos, *jnt_axis, *jnt_stiffness, *jnt_range, *jnt_margin;
+  const double *jnt_solref, *jnt_solimp;      /* limit solver params: 2 / 5 per joint */
+  const double *qpos0, *qpos_spring;
+  /* dofs */
+  const int *dof_bodyid, *dof_jntid, *dof_parentid;
+  const double *dof_armature, *dof_damping, *dof_frictionloss, *dof_invweight0;
+  const double *dof_solref, *dof_solimp;      /* friction-loss solver params */
+  /* geoms */
+  const int *geom_type, *geom_contype, *geom_conaffinity, *geom_condim, *geom_bodyid;
+  const int *geom_group, *geom_priority;
+  const double *geom_size, *geom_pos, *geom_quat, *geom_friction, *geom_solmix;
+  const double *geom_solref, *geom_solimp, *geom_margin, *geom_gap, *geom_rbound;
+  /* <contact><exclude>: (body1 << 16) + body2, as mjModel.exclude_signature */
+  const int *exclude_signature;
+  /* sites */
+  const int *site_bodyid;
+  const double *site_pos, *site_quat;
+  /* actuators (joint transmission only; gain fixed; bias none/affine) */
+  const int *actuator_trnid;        /* joint id (first of the 2 mjModel ints) */
+  const int *actuator_ctrllimited, *actuator_forcelimited, *actuator_biastype;
+  const double *actuator_gainprm;   /* 3 per actuator (first 3 of mjNGAIN) */
+  const double *actuator_biasprm;   /* 3 per actuator (first 3 of mjNBIAS) */
+  const double *actuator_gear;      /* 1 per actuator (first of 6) */
+  const double *actuator_ctrlrange, *actuator_forcerange;
+  /* keyframes */
+  const double *key_qpos;           /* nkey * nq */
+} MjpcHipModel;
+
+/* ---- task: cost table (mjpc/task.cc:147-245) + frozen ResidualFn state --------------- */
+typedef struct MjpcHipTask {
+  int task_id;                      /* MJPC_TASK_* */
+  int num_residual, num_term, num_trace;
+  const int *dim_norm_residual;     /* [num_term] */
+  const int *norm;                  /* [num_term] MJPC_NORM_* */
+  const int *num_norm_parameter;    /* [num_term] */
+  const double *weight;             /* [num_term] */
+  const double *norm_parameter;     /* [sum num_norm_parameter] */
+  double risk;
+  int num_parameter;
+  const double *parameters;         /* residual_* numerics, select values bit-cast (task.cc:38-64) */
+  const int *trace_objtype;         /* [num_trace] MJPC_OBJ_SITE / BODY / GEOM (framepos sensors "trace%i") */
+  const int *trace_objid;           /* [num_trace] */
+  int num_int;  const int *int_data;      /* task-specific frozen ids  (layout: mjpc_hip_tasks.md / DESIGN.md) */
+  int num_dbl;  const double *dbl_data;   /* task-specific frozen state */
+} MjpcHipTask;
+
+/* ---- one plan step ------------------------------------------------------------------- */
+typedef struct MjpcHipPlanInput {
+  /* State snapshot, mjpc/planners/sampling/planner.cc:146-149 */
+  const double *state;      /* [nq+nv+na] */
+  const double *mocap;      /* [7*nmocap] pos3+quat4 per mocap body */
+  const double *userdata;   /* [nuserdata] */
+  double time;
+  /* nominal spline policy after UpdateNominalPolicy (planner.cc:236-310) */
+  const double *knot_times;   /* [num_spline_points] */
+  const double *knot_values;  /* [num_spline_points*nu] */
+  int num_spline_points;
+  int interpolation;          /* MJPC_SPLINE_* */
+  /* sampling */
+  int num_trajectory;         /* N: GLOBAL candidate count */
+  int horizon;                /* H (steps, <= MJPC_MAX_HORIZON) */
+  int candidate_offset;       /* first global candidate index owned by this engine (multi-GPU shard) */
+  int num_local;              /* candidates rolled out by this engine: [offset, offset+num_local) */
+  double noise_exploration[2];/* sigma; [1] used with prob. 0.2 when > 0 (planner.cc:320-325) */
+  /* noise: explicit standard-normal tensor, or NULL -> Philox4x32-10(seed, stream) on device */
+  const double *noise_eps;    /* [num_trajectory*P*nu] (global indexing) or NULL */
+  const int *noise_sel;       /* [num_trajectory] 1 = use noise_exploration[1]; or NULL */
+  uint64_t seed;
+  uint64_t stream;            /* plan iteration counter */
+} MjpcHipPlanInput;
+
+typedef struct MjpcHipPlanOutput {
+  /* all host buffers, caller-owned; any pointer may be NULL to skip the copy */
+  double *returns;        /* [num_local] total_return per local candidate */
+  int *failure;           /* [num_local] */
+  int winner;             /* OUT: global index of local argmin (lowest index on ties) */
+  double winner_return;   /* OUT */
+  /* winner trajectory, same layout as mjpc::Trajectory (trajectory.h:74-86) */
+  double *states;         /* [H*(nq+nv+na)] */
+  double *actions;        /* [H*nu] */
+  double *times;          /* [H] */
+  double *residual;       /* [H*num_residual] */
+  double *costs;          /* [H] */
+  double *trace;          /* [H*3*num_trace] */
+  double *winner_knots;   /* [P*nu] candidate_policy[winner].plan values */
+  /* device timings of the last plan step, microseconds (fields mirror
+   * noise_compute_time / rollouts_compute_time, planner.h:149-152) */
+  double noise_compute_time_us;
+  double rollouts_compute_time_us;
+} MjpcHipPlanOutput;
+
+typedef struct MjpcHipEngine MjpcHipEngine;
+
+/* Create an engine on HIP device `device`.  Copies model+task to HBM.  max_local = largest
+ * num_local that will be planned on this device.  Returns NULL on error (see last_error). */
+MjpcHipEngine *mjpc_hip_create(const MjpcHipModel *model, const MjpcHipTask *task,
+                               int max_local, int max_horizon, int device);
+void mjpc_hip_destroy(MjpcHipEngine *e);
+/* Re-upload cost weights / norm params / residual parameters / frozen task state
+ * (Agent::PlanIteration takes a fresh ResidualFn copy every plan step, agent.cc:290). */
+int mjpc_hip_set_task(MjpcHipEngine *e, const MjpcHipTask *task);
+/* One plan step: noise -> N rollouts -> costs -> argmin; blocking. 0 on success. */
+int mjpc_hip_plan(MjpcHipEngine *e, const MjpcHipPlanInput *in, MjpcHipPlanOutput *out);
+/* Split form used by bench.py / multi-GPU: enqueue on the engine's stream, then fetch. */
+int mjpc_hip_plan_async(MjpcHipEngine *e, const MjpcHipPlanInput *in);
+int mjpc_hip_plan_fetch(MjpcHipEngine *e, MjpcHipPlanOutput *out);
+/* Copy any local candidate's trajectory / knots to host (GUI traces, RankedPlanner). */
+int mjpc_hip_get_candidate(MjpcHipEngine *e, int local_index, MjpcHipPlanOutput *out);
+/* Average device time of the rollout kernel over the launches since the last call,
+ * measured with hipEvents on the engine's stream; returns launches counted. */
+int mjpc_hip_kernel_time(MjpcHipEngine *e, double *avg_rollout_us, double *avg_total_us);
+/* Device pointers of the last plan's result arrays (for zero-copy consumers / tests). */
+int mjpc_hip_device_ptrs(MjpcHipEngine *e, void **returns, void **states, void **residual);
+const char *mjpc_hip_last_error(void);
+int mjpc_hip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif  /* MJPC_HIP_H_ */

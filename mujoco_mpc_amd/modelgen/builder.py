@@ -1,0 +1,525 @@
+"""Minimal MJCF-like model compiler (numpy) -> flat arrays mirroring `mjModel` field names.
+
+The reference loads its models with MuJoCo's MJCF compiler (`mj_loadXML`, mjpc/agent.cc:242), which
+is a third-party dependency absent from this image.  The engine's ABI (include/mjpc_hip.h) takes the
+*compiled* model, so in a real MJPC checkout the shim copies pointers out of `mjModel`.  This module
+exists so that tests / bench can author the BASELINE models without MuJoCo: it restates the parts of
+the compiler those models need (frames, fromto, inertia from geoms, inertial-frame diagonalisation,
+dof tree, qpos0, rbound, invweight0, meaninertia).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+
+import numpy as np
+
+FREE, BALL, SLIDE, HINGE = 0, 1, 2, 3
+PLANE, HFIELD, SPHERE, CAPSULE, ELLIPSOID, CYLINDER, BOX, MESH = range(8)
+MINVAL = 1e-15
+
+
+# ---------------------------------------------------------------------------- quaternion helpers
+def quat_mul(a, b):
+    a = np.asarray(a, float); b = np.asarray(b, float)
+    return np.array([
+        a[0]*b[0] - a[1]*b[1] - a[2]*b[2] - a[3]*b[3],
+        a[0]*b[1] + a[1]*b[0] + a[2]*b[3] - a[3]*b[2],
+        a[0]*b[2] - a[1]*b[3] + a[2]*b[0] + a[3]*b[1],
+        a[0]*b[3] + a[1]*b[2] - a[2]*b[1] + a[3]*b[0]])
+
+
+def quat2mat(q):
+    q = np.asarray(q, float)
+    w, x, y, z = q
+    return np.array([
+        [w*w + x*x - y*y - z*z, 2*(x*y - w*z), 2*(x*z + w*y)],
+        [2*(x*y + w*z), w*w - x*x + y*y - z*z, 2*(y*z - w*x)],
+        [2*(x*z - w*y), 2*(y*z + w*x), w*w - x*x - y*y + z*z]])
+
+
+def mat2quat(m):
+    m = np.asarray(m, float)
+    tr = m[0, 0] + m[1, 1] + m[2, 2]
+    if tr > 0:
+        s = math.sqrt(tr + 1.0) * 2
+        q = [0.25 * s, (m[2, 1] - m[1, 2]) / s, (m[0, 2] - m[2, 0]) / s, (m[1, 0] - m[0, 1]) / s]
+    elif m[0, 0] > m[1, 1] and m[0, 0] > m[2, 2]:
+        s = math.sqrt(1.0 + m[0, 0] - m[1, 1] - m[2, 2]) * 2
+        q = [(m[2, 1] - m[1, 2]) / s, 0.25 * s, (m[0, 1] + m[1, 0]) / s, (m[0, 2] + m[2, 0]) / s]
+    elif m[1, 1] > m[2, 2]:
+        s = math.sqrt(1.0 + m[1, 1] - m[0, 0] - m[2, 2]) * 2
+        q = [(m[0, 2] - m[2, 0]) / s, (m[0, 1] + m[1, 0]) / s, 0.25 * s, (m[1, 2] + m[2, 1]) / s]
+    else:
+        s = math.sqrt(1.0 + m[2, 2] - m[0, 0] - m[1, 1]) * 2
+        q = [(m[1, 0] - m[0, 1]) / s, (m[0, 2] + m[2, 0]) / s, (m[1, 2] + m[2, 1]) / s, 0.25 * s]
+    q = np.array(q)
+    return q / np.linalg.norm(q)
+
+
+def axisangle2quat(axis, angle):
+    axis = np.asarray(axis, float)
+    return np.concatenate([[math.cos(angle / 2)], axis * math.sin(angle / 2)])
+
+
+def z2quat(vec):
+    """quaternion rotating the z axis onto `vec` (MJCF fromto / zaxis)."""
+    v = np.asarray(vec, float)
+    v = v / np.linalg.norm(v)
+    z = np.array([0.0, 0.0, 1.0])
+    axis = np.cross(z, v)
+    s = np.linalg.norm(axis)
+    if s < 1e-10:
+        return np.array([1.0, 0, 0, 0]) if v[2] > 0 else np.array([0.0, 1.0, 0, 0])
+    axis /= s
+    ang = math.atan2(s, v[2])
+    return axisangle2quat(axis, ang)
+
+
+def euler2quat(e):
+    """MJCF default eulerseq 'xyz' (intrinsic)."""
+    q = np.array([1.0, 0, 0, 0])
+    for i, a in enumerate(e):
+        ax = np.zeros(3); ax[i] = 1
+        q = quat_mul(q, axisangle2quat(ax, a))
+    return q
+
+
+def normq(q):
+    q = np.asarray(q, float)
+    return q / np.linalg.norm(q)
+
+
+# ---------------------------------------------------------------------------- spec records
+DEF_SOLREF = (0.02, 1.0)
+DEF_SOLIMP = (0.9, 0.95, 0.001, 0.5, 2.0)
+
+
+@dataclass
+class _Joint:
+    name: str; body: int; type: int; axis: np.ndarray; pos: np.ndarray
+    limited: bool; range: tuple; damping: float; armature: float; frictionloss: float
+    stiffness: float; ref: float; springref: float; margin: float
+    solreflimit: tuple; solimplimit: tuple; solreffriction: tuple; solimpfriction: tuple
+
+
+@dataclass
+class _Geom:
+    name: str; body: int; type: int; size: np.ndarray; pos: np.ndarray; quat: np.ndarray
+    mass: float | None; density: float; contype: int; conaffinity: int; condim: int
+    friction: tuple; priority: int; margin: float; gap: float; solmix: float
+    solref: tuple; solimp: tuple; group: int
+
+
+@dataclass
+class _Body:
+    name: str; parent: int; pos: np.ndarray; quat: np.ndarray; mocap: bool
+    inertial: dict | None = None
+    joints: list = field(default_factory=list)
+    geoms: list = field(default_factory=list)
+
+
+class ModelBuilder:
+    def __init__(self, timestep=0.002, gravity=(0, 0, -9.81), cone=0, impratio=1.0,
+                 contact=True, tolerance=1e-8, iterations=100, ls_iterations=50, ls_tolerance=0.01):
+        self.opt = dict(timestep=timestep, gravity=np.array(gravity, float), cone=cone, impratio=impratio,
+                        contact=contact, tolerance=tolerance, iterations=iterations,
+                        ls_iterations=ls_iterations, ls_tolerance=ls_tolerance)
+        self.bodies = [_Body("world", 0, np.zeros(3), np.array([1.0, 0, 0, 0]), False)]
+        self.joints: list[_Joint] = []
+        self.geoms: list[_Geom] = []
+        self.sites: list[tuple] = []
+        self.actuators: list[dict] = []
+        self.keys: list[tuple] = []
+        self.excludes: list[tuple] = []
+        self.nuserdata = 0
+        self.nconmax = 0
+        self.nefcmax = 0
+
+    # ---- authoring API
+    def body(self, name, parent=0, pos=(0, 0, 0), quat=(1, 0, 0, 0), mocap=False, inertial=None):
+        if isinstance(parent, str):
+            parent = self.body_id(parent)
+        self.bodies.append(_Body(name, parent, np.array(pos, float), normq(quat), mocap, inertial))
+        return len(self.bodies) - 1
+
+    def body_id(self, name):
+        for i, b in enumerate(self.bodies):
+            if b.name == name:
+                return i
+        raise KeyError(name)
+
+    def joint(self, body, name, type=HINGE, axis=(0, 0, 1), pos=(0, 0, 0), limited=False, range=(0, 0),
+              damping=0.0, armature=0.0, frictionloss=0.0, stiffness=0.0, ref=0.0, springref=0.0, margin=0.0,
+              solreflimit=DEF_SOLREF, solimplimit=DEF_SOLIMP, solreffriction=DEF_SOLREF, solimpfriction=DEF_SOLIMP):
+        ax = np.array(axis, float)
+        if type in (HINGE, SLIDE):
+            ax = ax / np.linalg.norm(ax)
+        j = _Joint(name, body, type, ax, np.array(pos, float), limited, tuple(range), damping, armature,
+                   frictionloss, stiffness, ref, springref, margin, tuple(solreflimit), tuple(solimplimit),
+                   tuple(solreffriction), tuple(solimpfriction))
+        # joints of a body must be contiguous: insert after the last joint of this body
+        self.joints.append(j)
+        self.bodies[body].joints.append(len(self.joints) - 1)
+        return len(self.joints) - 1
+
+    def geom(self, body, name="", type=SPHERE, size=(0, 0, 0), pos=(0, 0, 0), quat=(1, 0, 0, 0), fromto=None,
+             mass=None, density=1000.0, contype=1, conaffinity=1, condim=3, friction=(1, 0.005, 0.0001),
+             priority=0, margin=0.0, gap=0.0, solmix=1.0, solref=DEF_SOLREF, solimp=DEF_SOLIMP, group=0,
+             zaxis=None, euler=None):
+        size = list(size) + [0.0] * (3 - len(size))
+        pos = np.array(pos, float); quat = normq(quat)
+        if zaxis is not None:
+            quat = z2quat(zaxis)
+        if euler is not None:
+            quat = euler2quat(euler)
+        if fromto is not None:
+            a = np.array(fromto[:3], float); b = np.array(fromto[3:], float)
+            pos = 0.5 * (a + b)
+            quat = z2quat(b - a)
+            size[1] = 0.5 * np.linalg.norm(b - a)
+        g = _Geom(name, body, type, np.array(size, float), pos, quat, mass, density, contype, conaffinity, condim,
+                  tuple(friction), priority, margin, gap, solmix, tuple(solref), tuple(solimp), group)
+        self.geoms.append(g)
+        self.bodies[body].geoms.append(len(self.geoms) - 1)
+        return len(self.geoms) - 1
+
+    def site(self, body, name, pos=(0, 0, 0), quat=(1, 0, 0, 0)):
+        self.sites.append((name, body, np.array(pos, float), normq(quat)))
+        return len(self.sites) - 1
+
+    def actuator(self, name, joint, gainprm=(1, 0, 0), biastype=0, biasprm=(0, 0, 0), gear=1.0,
+                 ctrllimited=True, ctrlrange=(-1, 1), forcelimited=False, forcerange=(0, 0)):
+        self.actuators.append(dict(name=name, joint=joint, gainprm=tuple(gainprm), biastype=biastype,
+                                   biasprm=tuple(biasprm), gear=gear, ctrllimited=ctrllimited,
+                                   ctrlrange=tuple(ctrlrange), forcelimited=forcelimited, forcerange=tuple(forcerange)))
+
+    def key(self, name, qpos):
+        self.keys.append((name, np.array(qpos, float)))
+
+    def exclude(self, body1, body2):
+        self.excludes.append((body1, body2))
+
+    # ---- geometry helpers
+    @staticmethod
+    def _geom_volume_inertia(g: _Geom):
+        s = g.size
+        t = g.type
+        if t == SPHERE:
+            vol = 4.0 / 3.0 * math.pi * s[0] ** 3
+            unit = np.array([2 / 5 * s[0] ** 2] * 3)          # per unit mass
+        elif t == CAPSULE:
+            h = 2 * s[1]; r = s[0]
+            vol = math.pi * r * r * (4 * r / 3 + h)
+            ms = 4 * r / (4 * r + 3 * h); mc = 1 - ms
+            ixx = mc * (3 * r * r + h * h) / 12 + 2 * ms * r * r / 5 + ms * h * (3 * r + 2 * h) / 8
+            izz = mc * r * r / 2 + 2 * ms * r * r / 5
+            unit = np.array([ixx, ixx, izz])
+        elif t == CYLINDER:
+            h = 2 * s[1]; r = s[0]
+            vol = math.pi * r * r * h
+            unit = np.array([(3 * r * r + h * h) / 12, (3 * r * r + h * h) / 12, r * r / 2])
+        elif t == BOX:
+            vol = 8 * s[0] * s[1] * s[2]
+            unit = np.array([(s[1] ** 2 + s[2] ** 2) / 3, (s[0] ** 2 + s[2] ** 2) / 3, (s[0] ** 2 + s[1] ** 2) / 3])
+        elif t == ELLIPSOID:
+            vol = 4.0 / 3.0 * math.pi * s[0] * s[1] * s[2]
+            unit = np.array([(s[1] ** 2 + s[2] ** 2) / 5, (s[0] ** 2 + s[2] ** 2) / 5, (s[0] ** 2 + s[1] ** 2) / 5])
+        else:
+            vol = 0.0; unit = np.zeros(3)
+        mass = g.mass if g.mass is not None else g.density * vol
+        return mass, unit * mass
+
+    @staticmethod
+    def _rbound(g: _Geom):
+        s = g.size
+        return {PLANE: 0.0, SPHERE: s[0], CAPSULE: s[0] + s[1], CYLINDER: math.hypot(s[0], s[1]),
+                BOX: float(np.linalg.norm(s)), ELLIPSOID: float(max(s))}.get(g.type, 0.0)
+
+    # ---- compile
+    def compile(self):
+        nb = len(self.bodies)
+        # joints must be ordered by body (MuJoCo orders joints in body order)
+        order = [j for b in self.bodies for j in b.joints]
+        remap = {old: new for new, old in enumerate(order)}
+        joints = [self.joints[j] for j in order]
+        for b in self.bodies:
+            b.joints = [remap[j] for j in b.joints]
+        for a in self.actuators:
+            if isinstance(a["joint"], str):
+                a["joint"] = [j.name for j in joints].index(a["joint"])
+            else:
+                a["joint"] = remap[a["joint"]]
+        self.joints = joints
+        nj = len(joints)
+        M = {}
+        # ---- bodies
+        parent = np.array([b.parent for b in self.bodies], np.int32)
+        M["body_parentid"] = parent
+        rootid = np.zeros(nb, np.int32); weldid = np.zeros(nb, np.int32)
+        for i in range(1, nb):
+            rootid[i] = i if parent[i] == 0 else rootid[parent[i]]
+            weldid[i] = i if self.bodies[i].joints else weldid[parent[i]]
+        M["body_rootid"] = rootid; M["body_weldid"] = weldid
+        mocapid = -np.ones(nb, np.int32); nmocap = 0
+        for i, b in enumerate(self.bodies):
+            if b.mocap:
+                mocapid[i] = nmocap; nmocap += 1
+        M["body_mocapid"] = mocapid
+        M["body_pos"] = np.array([b.pos for b in self.bodies]); M["body_quat"] = np.array([b.quat for b in self.bodies])
+        # joints / dofs
+        qadr = 0; dadr = 0
+        jnt_qposadr = np.zeros(nj, np.int32); jnt_dofadr = np.zeros(nj, np.int32)
+        body_jntnum = np.zeros(nb, np.int32); body_jntadr = -np.ones(nb, np.int32)
+        body_dofnum = np.zeros(nb, np.int32); body_dofadr = -np.ones(nb, np.int32)
+        dof_bodyid = []; dof_jntid = []; dof_parentid = []
+        qpos0 = []; qpos_spring = []
+        last_dof_of_body = -np.ones(nb, np.int32)
+        for bi, b in enumerate(self.bodies):
+            body_jntnum[bi] = len(b.joints)
+            if b.joints:
+                body_jntadr[bi] = b.joints[0]; body_dofadr[bi] = dadr
+            # nearest ancestor dof
+            anc = parent[bi] if bi > 0 else 0
+            prev = -1
+            a = anc
+            while bi > 0 and True:
+                if last_dof_of_body[a] >= 0:
+                    prev = last_dof_of_body[a]; break
+                if a == 0:
+                    break
+                a = parent[a]
+            for j in b.joints:
+                jt = joints[j]
+                jnt_qposadr[j] = qadr; jnt_dofadr[j] = dadr
+                nqj, nvj = {FREE: (7, 6), BALL: (4, 3), SLIDE: (1, 1), HINGE: (1, 1)}[jt.type]
+                if jt.type == FREE:
+                    qpos0 += list(b.pos) + list(b.quat); qpos_spring += list(b.pos) + list(b.quat)
+                elif jt.type == BALL:
+                    qpos0 += [1, 0, 0, 0]; qpos_spring += [1, 0, 0, 0]
+                else:
+                    qpos0.append(jt.ref); qpos_spring.append(jt.springref)
+                for k in range(nvj):
+                    dof_bodyid.append(bi); dof_jntid.append(j); dof_parentid.append(prev)
+                    prev = dadr + k
+                qadr += nqj; dadr += nvj
+            if b.joints:
+                body_dofnum[bi] = dadr - body_dofadr[bi]
+                last_dof_of_body[bi] = dadr - 1
+        nq, nv = qadr, dadr
+        M.update(body_jntnum=body_jntnum, body_jntadr=body_jntadr, body_dofnum=body_dofnum, body_dofadr=body_dofadr)
+        M["jnt_type"] = np.array([j.type for j in joints], np.int32)
+        M["jnt_qposadr"] = jnt_qposadr; M["jnt_dofadr"] = jnt_dofadr
+        M["jnt_bodyid"] = np.array([j.body for j in joints], np.int32)
+        M["jnt_limited"] = np.array([int(j.limited) for j in joints], np.int32)
+        M["jnt_pos"] = np.array([j.pos for j in joints]).reshape(nj, 3)
+        M["jnt_axis"] = np.array([j.axis for j in joints]).reshape(nj, 3)
+        M["jnt_stiffness"] = np.array([j.stiffness for j in joints], float)
+        M["jnt_range"] = np.array([j.range for j in joints], float).reshape(nj, 2)
+        M["jnt_margin"] = np.array([j.margin for j in joints], float)
+        M["jnt_solref"] = np.array([j.solreflimit for j in joints], float).reshape(nj, 2)
+        M["jnt_solimp"] = np.array([j.solimplimit for j in joints], float).reshape(nj, 5)
+        M["qpos0"] = np.array(qpos0, float); M["qpos_spring"] = np.array(qpos_spring, float)
+        M["dof_bodyid"] = np.array(dof_bodyid, np.int32); M["dof_jntid"] = np.array(dof_jntid, np.int32)
+        M["dof_parentid"] = np.array(dof_parentid, np.int32)
+        dj = [joints[j] for j in dof_jntid]
+        M["dof_armature"] = np.array([j.armature for j in dj], float)
+        M["dof_damping"] = np.array([j.damping for j in dj], float)
+        M["dof_frictionloss"] = np.array([j.frictionloss for j in dj], float)
+        M["dof_solref"] = np.array([j.solreffriction for j in dj], float).reshape(nv, 2)
+        M["dof_solimp"] = np.array([j.solimpfriction for j in dj], float).reshape(nv, 5)
+        # ---- geoms
+        ng = len(self.geoms)
+        G = self.geoms
+        M["geom_type"] = np.array([g.type for g in G], np.int32)
+        M["geom_contype"] = np.array([g.contype for g in G], np.int32)
+        M["geom_conaffinity"] = np.array([g.conaffinity for g in G], np.int32)
+        M["geom_condim"] = np.array([g.condim for g in G], np.int32)
+        M["geom_bodyid"] = np.array([g.body for g in G], np.int32)
+        M["geom_group"] = np.array([g.group for g in G], np.int32)
+        M["geom_priority"] = np.array([g.priority for g in G], np.int32)
+        M["geom_size"] = np.array([g.size for g in G], float).reshape(ng, 3)
+        M["geom_pos"] = np.array([g.pos for g in G], float).reshape(ng, 3)
+        M["geom_quat"] = np.array([g.quat for g in G], float).reshape(ng, 4)
+        M["geom_friction"] = np.array([g.friction for g in G], float).reshape(ng, 3)
+        M["geom_solmix"] = np.array([g.solmix for g in G], float)
+        M["geom_solref"] = np.array([g.solref for g in G], float).reshape(ng, 2)
+        M["geom_solimp"] = np.array([g.solimp for g in G], float).reshape(ng, 5)
+        M["geom_margin"] = np.array([g.margin for g in G], float)
+        M["geom_gap"] = np.array([g.gap for g in G], float)
+        M["geom_rbound"] = np.array([self._rbound(g) for g in G], float)
+        # ---- inertial frames
+        body_mass = np.zeros(nb); body_ipos = np.zeros((nb, 3)); body_iquat = np.tile([1.0, 0, 0, 0], (nb, 1))
+        body_inertia = np.zeros((nb, 3))
+        for bi, b in enumerate(self.bodies):
+            if bi == 0:
+                continue
+            if b.inertial is not None:
+                ine = b.inertial
+                body_mass[bi] = ine["mass"]; body_ipos[bi] = np.array(ine.get("pos", (0, 0, 0)), float)
+                if "fullinertia" in ine:
+                    f = ine["fullinertia"]
+                    I = np.array([[f[0], f[3], f[4]], [f[3], f[1], f[5]], [f[4], f[5], f[2]]], float)
+                    body_inertia[bi], body_iquat[bi] = self._diagonalize(I)
+                else:
+                    body_inertia[bi] = np.array(ine["diaginertia"], float)
+                    body_iquat[bi] = normq(ine.get("quat", (1, 0, 0, 0)))
+                continue
+            masses = []; coms = []; tensors = []
+            for gi in b.geoms:
+                g = G[gi]
+                m_, diag = self._geom_volume_inertia(g)
+                if m_ <= 0:
+                    continue
+                R = quat2mat(g.quat)
+                masses.append(m_); coms.append(g.pos); tensors.append(R @ np.diag(diag) @ R.T)
+            if not masses:
+                continue
+            mt = sum(masses)
+            com = sum(m_ * c for m_, c in zip(masses, coms)) / mt
+            I = np.zeros((3, 3))
+            for m_, c, T in zip(masses, coms, tensors):
+                dlt = c - com
+                I += T + m_ * (dlt @ dlt * np.eye(3) - np.outer(dlt, dlt))
+            body_mass[bi] = mt; body_ipos[bi] = com
+            body_inertia[bi], body_iquat[bi] = self._diagonalize(I)
+        M.update(body_mass=body_mass, body_ipos=body_ipos, body_iquat=body_iquat, body_inertia=body_inertia)
+        sub = body_mass.copy()
+        for i in range(nb - 1, 0, -1):
+            sub[parent[i]] += sub[i]
+        M["body_subtreemass"] = sub
+        # ---- sites, actuators, keys, excludes
+        ns = len(self.sites)
+        M["site_bodyid"] = np.array([s[1] for s in self.sites], np.int32)
+        M["site_pos"] = np.array([s[2] for s in self.sites], float).reshape(ns, 3)
+        M["site_quat"] = np.array([s[3] for s in self.sites], float).reshape(ns, 4)
+        nu = len(self.actuators); A = self.actuators
+        M["actuator_trnid"] = np.array([a["joint"] for a in A], np.int32)
+        M["actuator_ctrllimited"] = np.array([int(a["ctrllimited"]) for a in A], np.int32)
+        M["actuator_forcelimited"] = np.array([int(a["forcelimited"]) for a in A], np.int32)
+        M["actuator_biastype"] = np.array([a["biastype"] for a in A], np.int32)
+        M["actuator_gainprm"] = np.array([a["gainprm"] for a in A], float).reshape(nu, 3)
+        M["actuator_biasprm"] = np.array([a["biasprm"] for a in A], float).reshape(nu, 3)
+        M["actuator_gear"] = np.array([a["gear"] for a in A], float)
+        M["actuator_ctrlrange"] = np.array([a["ctrlrange"] for a in A], float).reshape(nu, 2)
+        M["actuator_forcerange"] = np.array([a["forcerange"] for a in A], float).reshape(nu, 2)
+        nkey = len(self.keys)
+        kq = np.tile(M["qpos0"], (max(nkey, 1), 1))
+        for k, (_, qp) in enumerate(self.keys):
+            kq[k, :len(qp)] = qp
+        M["key_qpos"] = kq[:nkey].reshape(nkey, nq) if nkey else np.zeros((0, nq))
+        M["exclude_signature"] = np.array([(min(a, b) << 16) + max(a, b) for a, b in self.excludes], np.int32)
+        sizes = dict(nq=nq, nv=nv, nu=nu, na=0, nbody=nb, njnt=nj, ngeom=ng, nsite=ns, nmocap=nmocap,
+                     nuserdata=self.nuserdata, nkey=nkey, nexclude=len(self.excludes))
+        M.update(sizes)
+        o = self.opt
+        M.update(timestep=o["timestep"], gravity=o["gravity"], impratio=o["impratio"], tolerance=o["tolerance"],
+                 ls_tolerance=o["ls_tolerance"], cone=o["cone"], iterations=o["iterations"],
+                 ls_iterations=o["ls_iterations"], disableflags=0 if o["contact"] else (1 << 4),
+                 nconmax=self.nconmax, nefcmax=self.nefcmax)
+        # ---- quantities evaluated at qpos0 (mjModel "set0")
+        Mq, Jp, Jr = mass_matrix(M, M["qpos0"])
+        Minv = np.linalg.inv(Mq) if nv else np.zeros((0, 0))
+        binv = np.zeros((nb, 2))
+        for bi in range(1, nb):
+            if nv == 0:
+                break
+            At = Jp[bi] @ Minv @ Jp[bi].T; Ar = Jr[bi] @ Minv @ Jr[bi].T
+            binv[bi] = [np.trace(At) / 3, np.trace(Ar) / 3]
+        dinv = np.zeros(nv)
+        for j, jt in enumerate(joints):
+            da = jnt_dofadr[j]
+            if jt.type == FREE:
+                dinv[da:da + 3] = np.mean(np.diag(Minv)[da:da + 3]); dinv[da + 3:da + 6] = np.mean(np.diag(Minv)[da + 3:da + 6])
+            elif jt.type == BALL:
+                dinv[da:da + 3] = np.mean(np.diag(Minv)[da:da + 3])
+            else:
+                dinv[da] = Minv[da, da]
+        M["body_invweight0"] = binv; M["dof_invweight0"] = dinv
+        M["meaninertia"] = max(float(np.mean(np.diag(Mq))) if nv else 1.0, MINVAL)
+        # names
+        M["names"] = dict(
+            body={b.name: i for i, b in enumerate(self.bodies)},
+            joint={j.name: i for i, j in enumerate(joints)},
+            geom={g.name: i for i, g in enumerate(G) if g.name},
+            site={s[0]: i for i, s in enumerate(self.sites)},
+            actuator={a["name"]: i for i, a in enumerate(A)},
+            key={k[0]: i for i, k in enumerate(self.keys)})
+        return M
+
+    @staticmethod
+    def _diagonalize(I):
+        w, V = np.linalg.eigh(I)
+        idx = np.argsort(-w)              # decreasing, like mju_eig3
+        w = w[idx]; V = V[:, idx]
+        if np.linalg.det(V) < 0:
+            V[:, 2] = -V[:, 2]
+        return w, mat2quat(V)
+
+
+# ---------------------------------------------------------------------------- numpy kinematics (qpos0 quantities + test cross-check)
+def kinematics(M, qpos):
+    nb = M["nbody"]
+    xpos = np.zeros((nb, 3)); xquat = np.tile([1.0, 0, 0, 0], (nb, 1)); xmat = np.tile(np.eye(3), (nb, 1, 1))
+    nj = M["njnt"]
+    xanchor = np.zeros((nj, 3)); xaxis = np.zeros((nj, 3))
+    for i in range(1, nb):
+        p = M["body_parentid"][i]
+        jn, ja = M["body_jntnum"][i], M["body_jntadr"][i]
+        if jn == 1 and M["jnt_type"][ja] == FREE:
+            qa = M["jnt_qposadr"][ja]
+            pos = qpos[qa:qa + 3].copy(); quat = normq(qpos[qa + 3:qa + 7])
+            xanchor[ja] = pos; xaxis[ja] = M["jnt_axis"][ja]
+        else:
+            pos = xpos[p] + xmat[p] @ M["body_pos"][i]
+            quat = quat_mul(xquat[p], M["body_quat"][i])
+            for j in range(ja, ja + jn):
+                qa = M["jnt_qposadr"][j]
+                R = quat2mat(quat)
+                xaxis[j] = R @ M["jnt_axis"][j]
+                xanchor[j] = R @ M["jnt_pos"][j] + pos
+                t = M["jnt_type"][j]
+                if t == SLIDE:
+                    pos = pos + xaxis[j] * (qpos[qa] - M["qpos0"][qa])
+                else:
+                    qloc = normq(qpos[qa:qa + 4]) if t == BALL else axisangle2quat(M["jnt_axis"][j], qpos[qa] - M["qpos0"][qa])
+                    quat = quat_mul(quat, qloc)
+                    pos = xanchor[j] - quat2mat(quat) @ M["jnt_pos"][j]
+        quat = normq(quat)
+        xpos[i] = pos; xquat[i] = quat; xmat[i] = quat2mat(quat)
+    return xpos, xquat, xmat, xanchor, xaxis
+
+
+def mass_matrix(M, qpos):
+    """Dense joint-space inertia by summing J^T I J over bodies; also per-body COM Jacobians."""
+    nb, nv = M["nbody"], M["nv"]
+    xpos, xquat, xmat, xanchor, xaxis = kinematics(M, qpos)
+    Jp = np.zeros((nb, 3, nv)); Jr = np.zeros((nb, 3, nv))
+    Mq = np.diag(M["dof_armature"].astype(float)) if nv else np.zeros((0, 0))
+    for b in range(1, nb):
+        com = xpos[b] + xmat[b] @ M["body_ipos"][b]
+        # chain of dofs
+        a = b
+        while a > 0:
+            for j in range(M["body_jntadr"][a], M["body_jntadr"][a] + M["body_jntnum"][a]):
+                t = M["jnt_type"][j]; da = M["jnt_dofadr"][j]
+                if t == FREE:
+                    for k in range(3):
+                        Jp[b, k, da + k] = 1.0
+                    for k in range(3):
+                        ax = xmat[a][:, k]
+                        Jr[b, :, da + 3 + k] = ax; Jp[b, :, da + 3 + k] = np.cross(ax, com - xpos[a])
+                elif t == BALL:
+                    for k in range(3):
+                        ax = xmat[a][:, k]
+                        Jr[b, :, da + k] = ax; Jp[b, :, da + k] = np.cross(ax, com - xanchor[j])
+                elif t == SLIDE:
+                    Jp[b, :, da] = xaxis[j]
+                else:
+                    Jr[b, :, da] = xaxis[j]; Jp[b, :, da] = np.cross(xaxis[j], com - xanchor[j])
+            a = M["body_parentid"][a]
+        if nv:
+            R = xmat[b] @ quat2mat(M["body_iquat"][b])
+            Iw = R @ np.diag(M["body_inertia"][b]) @ R.T
+            Mq = Mq + M["body_mass"][b] * Jp[b].T @ Jp[b] + Jr[b].T @ Iw @ Jr[b]
+    return Mq, Jp, Jr

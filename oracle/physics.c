@@ -1,0 +1,918 @@
+/*
+ * oracle/physics.c — TEST INFRASTRUCTURE ONLY (CPU oracle).
+ *
+ * Sequential fp64 restatement of what the reference's rollout executes inside
+ * `mj_step(model, data)` (mjpc/trajectory.cc:158) and `mj_forward` (mjpc/trajectory.cc:198).
+ * The arithmetic lives in MuJoCo 3.1.4 (third-party, pinned by /root/reference/CMakeLists.txt:58-61,
+ * absent from /root/reference and from this image): this file restates MuJoCo's published
+ * computation pipeline stage by stage:
+ *   position: kinematics, com-based inertias, CRBA, factorisation, collision, constraint rows
+ *   velocity: com velocities, passive forces, reference acceleration, RNE bias
+ *   actuation, smooth acceleration, primal Newton constraint solve (soft constraints,
+ *   friction-loss, limits, frictionless / elliptic contacts), Euler with implicit damping.
+ * PARITY UNPINNED at this boundary; analytic checks live in tests/.
+ */
+#include <stdlib.h>
+#include <stdio.h>
+#include "oracle.h"
+#include "omath.h"
+
+int oracle_collide_pair(const OModel *om, OData *d, int g1, int g2, double margin, OContact *out, int *unsupported);
+
+/* ------------------------------------------------------------------------------------ */
+static void *dalloc(OData *d, size_t bytes) {
+  void *p = calloc(1, bytes ? bytes : 8);
+  d->blocks[d->nblocks++] = p;
+  return p;
+}
+#define DD(field, n) d->field = (double *)dalloc(d, sizeof(double) * (size_t)(n))
+#define DI(field, n) d->field = (int *)dalloc(d, sizeof(int) * (size_t)(n))
+
+OData *oracle_make_data(const OModel *om) {
+  const MjpcHipModel *m = &om->m;
+  OData *d = (OData *)calloc(1, sizeof(OData));
+  int nv = m->nv, nb = m->nbody, ne = om->nefcmax;
+  DD(qpos, m->nq); DD(qvel, nv); DD(ctrl, m->nu); DD(mocap_pos, 3 * m->nmocap + 3);
+  DD(mocap_quat, 4 * m->nmocap + 4); DD(userdata, m->nuserdata + 1);
+  DD(qacc, nv); DD(qacc_warmstart, nv); DD(qacc_smooth, nv); DD(qfrc_smooth, nv);
+  DD(qfrc_bias, nv); DD(qfrc_passive, nv); DD(qfrc_actuator, nv); DD(qfrc_constraint, nv);
+  DD(actuator_force, m->nu + 1);
+  DD(xpos, 3 * nb); DD(xquat, 4 * nb); DD(xmat, 9 * nb); DD(xipos, 3 * nb); DD(ximat, 9 * nb);
+  DD(xanchor, 3 * m->njnt + 3); DD(xaxis, 3 * m->njnt + 3);
+  DD(geom_xpos, 3 * m->ngeom + 3); DD(geom_xmat, 9 * m->ngeom + 9);
+  DD(site_xpos, 3 * m->nsite + 3); DD(site_xmat, 9 * m->nsite + 9);
+  DD(subtree_com, 3 * nb); DD(cinert, 10 * nb); DD(cdof, 6 * nv + 6); DD(cvel, 6 * nb);
+  DD(cdof_dot, 6 * nv + 6); DD(crb, 10 * nb); DD(subtree_linvel, 3 * nb); DD(cacc, 6 * nb); DD(cfrc, 6 * nb);
+  DD(qM, nv * nv + 1); DD(qL, nv * nv + 1); DD(qH, nv * nv + 1); DD(qLD2, nv * nv + 1);
+  d->contact = (OContact *)dalloc(d, sizeof(OContact) * (size_t)(om->nconmax + 8));
+  DI(efc_type, ne); DI(efc_id, ne); DI(efc_state, ne);
+  DD(efc_J, ne * nv + 1); DD(efc_pos, ne); DD(efc_margin, ne); DD(efc_frictionloss, ne);
+  DD(efc_diagApprox, ne); DD(efc_D, ne); DD(efc_R, ne); DD(efc_vel, ne); DD(efc_aref, ne);
+  DD(efc_force, ne); DD(efc_jar, ne); DD(efc_jv, ne); DD(efc_KBIP, 4 * ne);
+  DD(efc_solref, 2 * ne); DD(efc_solimp, 5 * ne);
+  DD(Ma, nv); DD(grad, nv); DD(Mgrad, nv); DD(search, nv); DD(Mv, nv); DD(work, 16 * nv + 64);
+  DD(sensordata, om->t.num_residual + 1);
+  /* defaults: qpos0, mocap at body pose */
+  o_copy(d->qpos, m->qpos0, m->nq);
+  for (int i = 0; i < nb; i++) if (m->body_mocapid[i] >= 0) {
+    o_copy3(d->mocap_pos + 3 * m->body_mocapid[i], m->body_pos + 3 * i);
+    o_copy(d->mocap_quat + 4 * m->body_mocapid[i], m->body_quat + 4 * i, 4);
+  }
+  return d;
+}
+void oracle_free_data(OData *d) {
+  if (!d) return;
+  for (int i = 0; i < d->nblocks; i++) free(d->blocks[i]);
+  free(d);
+}
+
+/* ---- dense Cholesky helpers (A = L L^T, lower triangle of L stored row-major) -------- */
+static int chol_factor(double *L, const double *A, int n) {
+  int rank = n;
+  for (int i = 0; i < n * n; i++) L[i] = A[i];
+  for (int j = 0; j < n; j++) {
+    double t = L[j * n + j];
+    for (int k = 0; k < j; k++) t -= L[j * n + k] * L[j * n + k];
+    if (t < O_MINVAL) { t = O_MINVAL; rank--; }
+    double dj = sqrt(t);
+    L[j * n + j] = dj;
+    double inv = 1.0 / dj;
+    for (int i = j + 1; i < n; i++) {
+      double s = L[i * n + j];
+      for (int k = 0; k < j; k++) s -= L[i * n + k] * L[j * n + k];
+      L[i * n + j] = s * inv;
+    }
+  }
+  return rank;
+}
+static void chol_solve(double *x, const double *L, const double *b, int n) {
+  for (int i = 0; i < n; i++) {
+    double s = b[i];
+    for (int k = 0; k < i; k++) s -= L[i * n + k] * x[k];
+    x[i] = s / L[i * n + i];
+  }
+  for (int i = n - 1; i >= 0; i--) {
+    double s = x[i];
+    for (int k = i + 1; k < n; k++) s -= L[k * n + i] * x[k];
+    x[i] = s / L[i * n + i];
+  }
+}
+
+/* ---- position stage ------------------------------------------------------------------ */
+static void kinematics(const OModel *om, OData *d) {
+  const MjpcHipModel *m = &om->m;
+  o_zero(d->xpos, 3); o_zero(d->xipos, 3);
+  d->xquat[0] = 1; d->xquat[1] = d->xquat[2] = d->xquat[3] = 0;
+  o_zero(d->xmat, 9); d->xmat[0] = d->xmat[4] = d->xmat[8] = 1;
+  o_copy(d->ximat, d->xmat, 9);
+  for (int i = 1; i < m->nbody; i++) {
+    double xpos[3], xquat[4];
+    int pid = m->body_parentid[i];
+    int jntnum = m->body_jntnum[i], jntadr = m->body_jntadr[i];
+    if (m->body_mocapid[i] >= 0) {
+      int id = m->body_mocapid[i];
+      o_copy3(xpos, d->mocap_pos + 3 * id);
+      o_copy(xquat, d->mocap_quat + 4 * id, 4);
+      o_normalize4(xquat);
+    } else if (jntnum == 1 && m->jnt_type[jntadr] == MJPC_JNT_FREE) {
+      int qa = m->jnt_qposadr[jntadr];
+      o_normalize4(d->qpos + qa + 3);
+      o_copy3(xpos, d->qpos + qa);
+      o_copy(xquat, d->qpos + qa + 3, 4);
+      o_copy3(d->xanchor + 3 * jntadr, xpos);
+      o_copy3(d->xaxis + 3 * jntadr, m->jnt_axis + 3 * jntadr);
+    } else {
+      if (pid) {
+        o_mulmatvec3(xpos, d->xmat + 9 * pid, m->body_pos + 3 * i);
+        o_add3(xpos, xpos, d->xpos + 3 * pid);
+        o_mulquat(xquat, d->xquat + 4 * pid, m->body_quat + 4 * i);
+      } else {
+        o_copy3(xpos, m->body_pos + 3 * i);
+        o_copy(xquat, m->body_quat + 4 * i, 4);
+      }
+      for (int j = jntadr; j < jntadr + jntnum; j++) {
+        int qa = m->jnt_qposadr[j];
+        double vec[3];
+        o_rotvecquat(d->xaxis + 3 * j, m->jnt_axis + 3 * j, xquat);
+        o_rotvecquat(vec, m->jnt_pos + 3 * j, xquat);
+        o_add3(d->xanchor + 3 * j, vec, xpos);
+        if (m->jnt_type[j] == MJPC_JNT_SLIDE) {
+          o_addtoscl3(xpos, d->xaxis + 3 * j, d->qpos[qa] - m->qpos0[qa]);
+        } else if (m->jnt_type[j] == MJPC_JNT_BALL || m->jnt_type[j] == MJPC_JNT_HINGE) {
+          double qloc[4], t[4];
+          if (m->jnt_type[j] == MJPC_JNT_BALL) {
+            o_normalize4(d->qpos + qa);
+            o_copy(qloc, d->qpos + qa, 4);
+          } else {
+            o_axisangle2quat(qloc, m->jnt_axis + 3 * j, d->qpos[qa] - m->qpos0[qa]);
+          }
+          o_mulquat(t, xquat, qloc);
+          o_copy(xquat, t, 4);
+          o_rotvecquat(vec, m->jnt_pos + 3 * j, xquat);
+          o_sub3(xpos, d->xanchor + 3 * j, vec);
+        }
+      }
+    }
+    o_normalize4(xquat);
+    o_copy3(d->xpos + 3 * i, xpos);
+    o_copy(d->xquat + 4 * i, xquat, 4);
+    o_quat2mat(d->xmat + 9 * i, xquat);
+    /* inertial frame */
+    double v[3], q[4];
+    o_mulmatvec3(v, d->xmat + 9 * i, m->body_ipos + 3 * i);
+    o_add3(d->xipos + 3 * i, v, xpos);
+    o_mulquat(q, xquat, m->body_iquat + 4 * i);
+    o_quat2mat(d->ximat + 9 * i, q);
+  }
+  for (int g = 0; g < m->ngeom; g++) {
+    int b = m->geom_bodyid[g];
+    double v[3], q[4];
+    o_mulmatvec3(v, d->xmat + 9 * b, m->geom_pos + 3 * g);
+    o_add3(d->geom_xpos + 3 * g, v, d->xpos + 3 * b);
+    o_mulquat(q, d->xquat + 4 * b, m->geom_quat + 4 * g);
+    o_quat2mat(d->geom_xmat + 9 * g, q);
+  }
+  for (int s = 0; s < m->nsite; s++) {
+    int b = m->site_bodyid[s];
+    double v[3], q[4];
+    o_mulmatvec3(v, d->xmat + 9 * b, m->site_pos + 3 * s);
+    o_add3(d->site_xpos + 3 * s, v, d->xpos + 3 * b);
+    o_mulquat(q, d->xquat + 4 * b, m->site_quat + 4 * s);
+    o_quat2mat(d->site_xmat + 9 * s, q);
+  }
+}
+
+static void com_pos(const OModel *om, OData *d) {
+  const MjpcHipModel *m = &om->m;
+  for (int i = 0; i < m->nbody; i++) o_scl3(d->subtree_com + 3 * i, d->xipos + 3 * i, m->body_mass[i]);
+  for (int i = m->nbody - 1; i > 0; i--) {
+    int p = m->body_parentid[i];
+    o_add3(d->subtree_com + 3 * p, d->subtree_com + 3 * p, d->subtree_com + 3 * i);
+  }
+  for (int i = 0; i < m->nbody; i++) {
+    if (m->body_subtreemass[i] < O_MINVAL) o_copy3(d->subtree_com + 3 * i, d->xipos + 3 * i);
+    else o_scl3(d->subtree_com + 3 * i, d->subtree_com + 3 * i, 1.0 / m->body_subtreemass[i]);
+  }
+  o_zero(d->cinert, 10);
+  for (int i = 1; i < m->nbody; i++) {
+    double off[3];
+    o_sub3(off, d->xipos + 3 * i, d->subtree_com + 3 * m->body_rootid[i]);
+    o_inertcom(d->cinert + 10 * i, m->body_inertia + 3 * i, d->ximat + 9 * i, off, m->body_mass[i]);
+  }
+  for (int j = 0; j < m->njnt; j++) {
+    int b = m->jnt_bodyid[j], da = m->jnt_dofadr[j];
+    double off[3];
+    o_sub3(off, d->subtree_com + 3 * m->body_rootid[b], d->xanchor + 3 * j);
+    int skip = 0;
+    switch (m->jnt_type[j]) {
+      case MJPC_JNT_FREE:
+        o_zero(d->cdof + 6 * da, 18);
+        for (int k = 0; k < 3; k++) d->cdof[6 * (da + k) + 3 + k] = 1;
+        skip = 3;
+        /* fallthrough */
+      case MJPC_JNT_BALL:
+        for (int k = 0; k < 3; k++) {
+          const double *xm = d->xmat + 9 * b;
+          double ax[3] = {xm[k], xm[k + 3], xm[k + 6]};
+          double *c = d->cdof + 6 * (da + k + skip);
+          o_copy3(c, ax); o_cross(c + 3, ax, off);
+        }
+        break;
+      case MJPC_JNT_SLIDE:
+        o_zero(d->cdof + 6 * da, 3);
+        o_copy3(d->cdof + 6 * da + 3, d->xaxis + 3 * j);
+        break;
+      default: /* hinge */
+        o_copy3(d->cdof + 6 * da, d->xaxis + 3 * j);
+        o_cross(d->cdof + 6 * da + 3, d->xaxis + 3 * j, off);
+    }
+  }
+}
+
+static void crb_and_factor(const OModel *om, OData *d) {
+  const MjpcHipModel *m = &om->m;
+  int nv = m->nv;
+  o_copy(d->crb, d->cinert, 10 * m->nbody);
+  for (int i = m->nbody - 1; i > 0; i--) {
+    int p = m->body_parentid[i];
+    if (p > 0) for (int k = 0; k < 10; k++) d->crb[10 * p + k] += d->crb[10 * i + k];
+  }
+  o_zero(d->qM, nv * nv);
+  for (int i = 0; i < nv; i++) {
+    double buf[6];
+    o_mulinertvec(buf, d->crb + 10 * m->dof_bodyid[i], d->cdof + 6 * i);
+    d->qM[i * nv + i] = m->dof_armature[i];
+    for (int j = i; j >= 0; j = m->dof_parentid[j]) {
+      double v = o_dot(d->cdof + 6 * j, buf, 6);
+      d->qM[i * nv + j] += v;
+      if (j != i) d->qM[j * nv + i] = d->qM[i * nv + j];
+    }
+  }
+  chol_factor(d->qL, d->qM, nv);
+}
+
+/* jacobian of point `p` attached to body b: jacp[3*nv], jacr[3*nv] (either may be NULL) */
+static void jac_point(const OModel *om, const OData *d, double *jacp, double *jacr, const double *p, int b) {
+  const MjpcHipModel *m = &om->m;
+  int nv = m->nv;
+  if (jacp) o_zero(jacp, 3 * nv);
+  if (jacr) o_zero(jacr, 3 * nv);
+  if (b <= 0) return;
+  double off[3];
+  o_sub3(off, p, d->subtree_com + 3 * m->body_rootid[b]);
+  /* find last dof of the chain: walk up until a body with dofs */
+  while (b > 0 && m->body_dofnum[b] == 0) b = m->body_parentid[b];
+  if (b <= 0) return;
+  int i = m->body_dofadr[b] + m->body_dofnum[b] - 1;
+  for (; i >= 0; i = m->dof_parentid[i]) {
+    const double *c = d->cdof + 6 * i;
+    if (jacr) { jacr[i] = c[0]; jacr[nv + i] = c[1]; jacr[2 * nv + i] = c[2]; }
+    if (jacp) {
+      double t[3]; o_cross(t, c, off);
+      jacp[i] = c[3] + t[0]; jacp[nv + i] = c[4] + t[1]; jacp[2 * nv + i] = c[5] + t[2];
+    }
+  }
+}
+
+/* mj_contactParam-style mixing */
+static void contact_param(const MjpcHipModel *m, int g1, int g2, OContact *c, double *margin, double *gap) {
+  int p1 = m->geom_priority[g1], p2 = m->geom_priority[g2];
+  *margin = fmax(m->geom_margin[g1], m->geom_margin[g2]);
+  *gap = fmax(m->geom_gap[g1], m->geom_gap[g2]);
+  double fri[3];
+  if (p1 != p2) {
+    int g = p1 > p2 ? g1 : g2;
+    c->dim = m->geom_condim[g];
+    o_copy(c->solref, m->geom_solref + 2 * g, 2);
+    o_copy(c->solimp, m->geom_solimp + 5 * g, 5);
+    o_copy3(fri, m->geom_friction + 3 * g);
+  } else {
+    c->dim = m->geom_condim[g1] > m->geom_condim[g2] ? m->geom_condim[g1] : m->geom_condim[g2];
+    double s1 = m->geom_solmix[g1], s2 = m->geom_solmix[g2], mix;
+    if (s1 >= O_MINVAL && s2 >= O_MINVAL) mix = s1 / (s1 + s2);
+    else if (s1 < O_MINVAL && s2 < O_MINVAL) mix = 0.5;
+    else if (s1 < O_MINVAL) mix = 0.0;
+    else mix = 1.0;
+    const double *r1 = m->geom_solref + 2 * g1, *r2 = m->geom_solref + 2 * g2;
+    if (r1[0] > 0 && r2[0] > 0) for (int i = 0; i < 2; i++) c->solref[i] = mix * r1[i] + (1 - mix) * r2[i];
+    else for (int i = 0; i < 2; i++) c->solref[i] = fmin(r1[i], r2[i]);
+    for (int i = 0; i < 5; i++) c->solimp[i] = mix * m->geom_solimp[5 * g1 + i] + (1 - mix) * m->geom_solimp[5 * g2 + i];
+    for (int i = 0; i < 3; i++) fri[i] = fmax(m->geom_friction[3 * g1 + i], m->geom_friction[3 * g2 + i]);
+  }
+  c->friction[0] = fri[0]; c->friction[1] = fri[0]; c->friction[2] = fri[1];
+  c->friction[3] = fri[2]; c->friction[4] = fri[2];
+}
+
+static void collision(const OModel *om, OData *d) {
+  const MjpcHipModel *m = &om->m;
+  d->ncon = 0;
+  if (m->disableflags & MJPC_DSBL_CONTACT) return;
+  for (int p = 0; p < om->npair; p++) {
+    int g1 = om->pair_g1[p], g2 = om->pair_g2[p];
+    OContact proto;
+    double margin, gap;
+    memset(&proto, 0, sizeof(proto));
+    contact_param(m, g1, g2, &proto, &margin, &gap);
+    /* bounding-sphere / plane-sphere filter */
+    double r1 = m->geom_rbound[g1], r2 = m->geom_rbound[g2];
+    const double *p1 = d->geom_xpos + 3 * g1, *p2 = d->geom_xpos + 3 * g2;
+    if (m->geom_type[g1] == MJPC_GEOM_PLANE) {
+      const double *mat = d->geom_xmat + 9 * g1;
+      double n[3] = {mat[2], mat[5], mat[8]}, dif[3];
+      o_sub3(dif, p2, p1);
+      if (o_dot3(dif, n) > margin + r2) continue;
+    } else if (r1 > 0 && r2 > 0) {
+      double dif[3]; o_sub3(dif, p2, p1);
+      double bound = r1 + r2 + margin;
+      if (o_dot3(dif, dif) > bound * bound) continue;
+    }
+    OContact con[8];
+    int n = oracle_collide_pair(om, d, g1, g2, margin, con, &d->unsupported);
+    for (int k = 0; k < n; k++) {
+      if (d->ncon >= om->nconmax) { d->warning = 1; return; }   /* contact buffer full */
+      OContact *c = d->contact + d->ncon++;
+      *c = proto;
+      c->dist = con[k].dist;
+      o_copy3(c->pos, con[k].pos);
+      o_copy(c->frame, con[k].frame, 9);
+      o_makeframe(c->frame);
+      c->includemargin = margin - gap;
+      c->geom1 = g1; c->geom2 = g2;
+    }
+  }
+}
+
+/* impedance d(r) and derived K,B  (MuJoCo "solref/solimp" soft-constraint model) */
+static double impedance(const double *solimp_in, double pos, double margin) {
+  double si[5]; o_copy(si, solimp_in, 5);
+  const double MINIMP = 0.0001, MAXIMP = 0.9999;
+  si[0] = o_clip(si[0], MINIMP, MAXIMP); si[1] = o_clip(si[1], MINIMP, MAXIMP);
+  si[2] = fmax(0, si[2]); si[3] = o_clip(si[3], MINIMP, MAXIMP); si[4] = fmax(1, si[4]);
+  if (si[0] == si[1] || si[2] <= O_MINVAL) return 0.5 * (si[0] + si[1]);
+  double x = (pos - margin) / si[2];
+  if (x < 0) x = -x;
+  if (x >= 1) return si[1];
+  if (x == 0) return si[0];
+  double y;
+  if (si[4] == 1) y = x;
+  else if (x <= si[3]) { double a = 1 / pow(si[3], si[4] - 1); y = a * pow(x, si[4]); }
+  else { double b = 1 / pow(1 - si[3], si[4] - 1); y = 1 - b * pow(1 - x, si[4]); }
+  return si[0] + y * (si[1] - si[0]);
+}
+
+static int add_row(const OModel *om, OData *d, int type, int id) {
+  if (d->nefc >= om->nefcmax) { d->warning = 1; return -1; }   /* constraint buffer full */
+  int r = d->nefc++;
+  o_zero(d->efc_J + r * om->m.nv, om->m.nv);
+  d->efc_type[r] = type; d->efc_id[r] = id;
+  d->efc_pos[r] = 0; d->efc_margin[r] = 0; d->efc_frictionloss[r] = 0;
+  return r;
+}
+
+static void make_constraint(const OModel *om, OData *d) {
+  const MjpcHipModel *m = &om->m;
+  int nv = m->nv;
+  d->nefc = 0; d->nf = 0; d->nl = 0;
+  /* friction loss */
+  for (int i = 0; i < nv; i++) if (m->dof_frictionloss[i] > 0) {
+    int r = add_row(om, d, O_CNSTR_FRICTION_DOF, i); if (r < 0) return;
+    d->efc_J[r * nv + i] = 1;
+    d->efc_frictionloss[r] = m->dof_frictionloss[i];
+    o_copy(d->efc_solref + 2 * r, m->dof_solref + 2 * i, 2);
+    o_copy(d->efc_solimp + 5 * r, m->dof_solimp + 5 * i, 5);
+    d->efc_diagApprox[r] = m->dof_invweight0[i];
+    d->nf++;
+  }
+  /* joint limits */
+  for (int j = 0; j < m->njnt; j++) if (m->jnt_limited[j] &&
+      (m->jnt_type[j] == MJPC_JNT_SLIDE || m->jnt_type[j] == MJPC_JNT_HINGE)) {
+    double value = d->qpos[m->jnt_qposadr[j]], margin = m->jnt_margin[j];
+    for (int side = -1; side <= 1; side += 2) {
+      double dist = side * (m->jnt_range[2 * j + (side + 1) / 2] - value);
+      if (dist < margin) {
+        int r = add_row(om, d, O_CNSTR_LIMIT_JOINT, j); if (r < 0) return;
+        d->efc_J[r * nv + m->jnt_dofadr[j]] = -side;
+        d->efc_pos[r] = dist; d->efc_margin[r] = margin;
+        o_copy(d->efc_solref + 2 * r, m->jnt_solref + 2 * j, 2);
+        o_copy(d->efc_solimp + 5 * r, m->jnt_solimp + 5 * j, 5);
+        d->efc_diagApprox[r] = m->dof_invweight0[m->jnt_dofadr[j]];
+        d->nl++;
+      }
+    }
+  }
+  /* contacts */
+  double *jp1 = d->work, *jp2 = jp1 + 3 * nv, *jr1 = jp2 + 3 * nv, *jr2 = jr1 + 3 * nv;
+  for (int ci = 0; ci < d->ncon; ci++) {
+    OContact *c = d->contact + ci;
+    int b1 = m->geom_bodyid[c->geom1], b2 = m->geom_bodyid[c->geom2];
+    int dim = c->dim;
+    int elliptic = (dim > 1 && m->cone == MJPC_CONE_ELLIPTIC);
+    if (dim > 1 && !elliptic) { d->unsupported++; dim = 1; }   /* pyramidal cones: not in round 1 */
+    jac_point(om, d, jp1, dim > 3 ? jr1 : NULL, c->pos, b1);
+    jac_point(om, d, jp2, dim > 3 ? jr2 : NULL, c->pos, b2);
+    double tran = m->body_invweight0[2 * b1] + m->body_invweight0[2 * b2];
+    double rot = m->body_invweight0[2 * b1 + 1] + m->body_invweight0[2 * b2 + 1];
+    c->efc_address = d->nefc;
+    for (int k = 0; k < dim; k++) {
+      int r = add_row(om, d, dim == 1 ? O_CNSTR_CONTACT_FRICTIONLESS : O_CNSTR_CONTACT_ELLIPTIC, ci);
+      if (r < 0) return;
+      const double *ax = c->frame + 3 * (k % 3);
+      const double *ja = k < 3 ? jp1 : jr1, *jb = k < 3 ? jp2 : jr2;
+      for (int i = 0; i < nv; i++)
+        d->efc_J[r * nv + i] = ax[0] * (jb[i] - ja[i]) + ax[1] * (jb[nv + i] - ja[nv + i]) + ax[2] * (jb[2 * nv + i] - ja[2 * nv + i]);
+      d->efc_pos[r] = c->dist; d->efc_margin[r] = c->includemargin;
+      o_copy(d->efc_solref + 2 * r, c->solref, 2);
+      o_copy(d->efc_solimp + 5 * r, c->solimp, 5);
+      d->efc_diagApprox[r] = k < 3 ? tran : rot;
+    }
+  }
+}
+
+/* efc_vel, KBIP, R, D, aref */
+static void make_impedance(const OModel *om, OData *d) {
+  const MjpcHipModel *m = &om->m;
+  int nv = m->nv;
+  for (int r = 0; r < d->nefc; r++) d->efc_vel[r] = o_dot(d->efc_J + r * nv, d->qvel, nv);
+  for (int r = 0; r < d->nefc; r++) {
+    int dim = 1;
+    if (d->efc_type[r] == O_CNSTR_CONTACT_ELLIPTIC) dim = d->contact[d->efc_id[r]].dim;
+    const double *solref = d->efc_solref + 2 * r, *solimp = d->efc_solimp + 5 * r;
+    double imp = impedance(solimp, d->efc_pos[r], d->efc_margin[r]);
+    double dmax = o_clip(solimp[1], 0.0001, 0.9999);
+    double K, B;
+    if (solref[0] > 0) {
+      double tc = fmax(solref[0], 2 * m->timestep);   /* refsafe */
+      double dr = solref[1];
+      K = 1 / fmax(O_MINVAL, dmax * dmax * tc * tc * dr * dr);
+      B = 2 / fmax(O_MINVAL, dmax * tc);
+    } else {
+      K = -solref[0] / fmax(O_MINVAL, dmax * dmax);
+      B = -solref[1] / fmax(O_MINVAL, dmax);
+    }
+    for (int k = 0; k < dim; k++) {
+      int q = r + k;
+      int friction_row = (d->efc_type[q] == O_CNSTR_FRICTION_DOF) || (k > 0);
+      double Kq = friction_row ? 0 : K;
+      d->efc_KBIP[4 * q] = Kq; d->efc_KBIP[4 * q + 1] = B; d->efc_KBIP[4 * q + 2] = imp; d->efc_KBIP[4 * q + 3] = 0;
+      d->efc_R[q] = fmax(O_MINVAL, (1 - imp) / imp * d->efc_diagApprox[q]);
+      d->efc_aref[q] = -B * d->efc_vel[q] - Kq * imp * (d->efc_pos[q] - d->efc_margin[q]);
+    }
+    if (dim > 1) {   /* elliptic cone: friction regularisation from impratio, regularised mu */
+      OContact *c = d->contact + d->efc_id[r];
+      double *R = d->efc_R + r;
+      R[1] = R[0] / fmax(O_MINVAL, m->impratio);
+      c->mu = c->friction[0] * sqrt(R[1] / R[0]);
+      for (int k = 2; k < dim; k++)
+        R[k] = R[1] * c->friction[0] * c->friction[0] / (c->friction[k - 1] * c->friction[k - 1]);
+    }
+    for (int k = 0; k < dim; k++) d->efc_D[r + k] = 1 / d->efc_R[r + k];
+    r += dim - 1;
+  }
+}
+
+/* ---- velocity stage ------------------------------------------------------------------ */
+static void com_vel(const OModel *om, OData *d) {
+  const MjpcHipModel *m = &om->m;
+  o_zero(d->cvel, 6);
+  for (int i = 1; i < m->nbody; i++) {
+    double cvel[6];
+    o_copy(cvel, d->cvel + 6 * m->body_parentid[i], 6);
+    int bda = m->body_dofadr[i];
+    for (int j = m->body_jntadr[i]; j < m->body_jntadr[i] + m->body_jntnum[i]; j++) {
+      int type = m->jnt_type[j];
+      if (type == MJPC_JNT_FREE) {
+        o_zero(d->cdof_dot + 6 * bda, 18);
+        for (int k = 0; k < 3; k++) for (int c = 0; c < 6; c++) cvel[c] += d->cdof[6 * (bda + k) + c] * d->qvel[bda + k];
+        bda += 3;
+      }
+      if (type == MJPC_JNT_FREE || type == MJPC_JNT_BALL) {
+        for (int k = 0; k < 3; k++) o_crossmotion(d->cdof_dot + 6 * (bda + k), cvel, d->cdof + 6 * (bda + k));
+        for (int k = 0; k < 3; k++) for (int c = 0; c < 6; c++) cvel[c] += d->cdof[6 * (bda + k) + c] * d->qvel[bda + k];
+        bda += 3;
+      } else {
+        o_crossmotion(d->cdof_dot + 6 * bda, cvel, d->cdof + 6 * bda);
+        for (int c = 0; c < 6; c++) cvel[c] += d->cdof[6 * bda + c] * d->qvel[bda];
+        bda++;
+      }
+    }
+    o_copy(d->cvel + 6 * i, cvel, 6);
+  }
+  /* subtree linear velocity (mj_subtreeVel, linear part) */
+  for (int i = 0; i < m->nbody; i++) {
+    double off[3], v[3];
+    o_sub3(off, d->xipos + 3 * i, d->subtree_com + 3 * m->body_rootid[i]);
+    o_cross(v, d->cvel + 6 * i, off);
+    o_add3(v, v, d->cvel + 6 * i + 3);
+    o_scl3(d->subtree_linvel + 3 * i, v, m->body_mass[i]);
+  }
+  for (int i = m->nbody - 1; i > 0; i--) {
+    int p = m->body_parentid[i];
+    o_add3(d->subtree_linvel + 3 * p, d->subtree_linvel + 3 * p, d->subtree_linvel + 3 * i);
+  }
+  for (int i = 0; i < m->nbody; i++) {
+    double s = 1.0 / fmax(O_MINVAL, m->body_subtreemass[i]);
+    o_scl3(d->subtree_linvel + 3 * i, d->subtree_linvel + 3 * i, s);
+  }
+}
+
+static void passive(const OModel *om, OData *d) {
+  const MjpcHipModel *m = &om->m;
+  o_zero(d->qfrc_passive, m->nv);
+  for (int j = 0; j < m->njnt; j++) {
+    double k = m->jnt_stiffness[j];
+    if (k == 0) continue;
+    if (m->jnt_type[j] == MJPC_JNT_SLIDE || m->jnt_type[j] == MJPC_JNT_HINGE) {
+      int qa = m->jnt_qposadr[j];
+      d->qfrc_passive[m->jnt_dofadr[j]] -= k * (d->qpos[qa] - m->qpos_spring[qa]);
+    }
+  }
+  for (int i = 0; i < m->nv; i++) d->qfrc_passive[i] -= m->dof_damping[i] * d->qvel[i];
+}
+
+static void rne_bias(const OModel *om, OData *d) {
+  const MjpcHipModel *m = &om->m;
+  o_zero(d->cacc, 6);
+  for (int k = 0; k < 3; k++) d->cacc[3 + k] = -m->gravity[k];
+  o_zero(d->cfrc, 6);
+  for (int i = 1; i < m->nbody; i++) {
+    double *a = d->cacc + 6 * i;
+    o_copy(a, d->cacc + 6 * m->body_parentid[i], 6);
+    int bda = m->body_dofadr[i];
+    for (int k = 0; k < m->body_dofnum[i]; k++)
+      for (int c = 0; c < 6; c++) a[c] += d->cdof_dot[6 * (bda + k) + c] * d->qvel[bda + k];
+    double t1[6], t2[6], t3[6];
+    o_mulinertvec(t1, d->cinert + 10 * i, a);
+    o_mulinertvec(t2, d->cinert + 10 * i, d->cvel + 6 * i);
+    o_crossforce(t3, d->cvel + 6 * i, t2);
+    for (int c = 0; c < 6; c++) d->cfrc[6 * i + c] = t1[c] + t3[c];
+  }
+  for (int i = m->nbody - 1; i > 0; i--) {
+    int p = m->body_parentid[i];
+    if (p > 0) for (int c = 0; c < 6; c++) d->cfrc[6 * p + c] += d->cfrc[6 * i + c];
+  }
+  for (int i = 0; i < m->nv; i++) d->qfrc_bias[i] = o_dot(d->cdof + 6 * i, d->cfrc + 6 * m->dof_bodyid[i], 6);
+}
+
+static void actuation(const OModel *om, OData *d) {
+  const MjpcHipModel *m = &om->m;
+  o_zero(d->qfrc_actuator, m->nv);
+  for (int i = 0; i < m->nu; i++) {
+    double ctrl = d->ctrl[i];
+    if (m->actuator_ctrllimited[i]) ctrl = o_clip(ctrl, m->actuator_ctrlrange[2 * i], m->actuator_ctrlrange[2 * i + 1]);
+    int j = m->actuator_trnid[i];
+    int qa = m->jnt_qposadr[j], da = m->jnt_dofadr[j];
+    double gear = m->actuator_gear[i];
+    double force = m->actuator_gainprm[3 * i] * ctrl;
+    if (m->actuator_biastype[i] == MJPC_BIAS_AFFINE)
+      force += m->actuator_biasprm[3 * i] + m->actuator_biasprm[3 * i + 1] * (gear * d->qpos[qa]) +
+               m->actuator_biasprm[3 * i + 2] * (gear * d->qvel[da]);
+    if (m->actuator_forcelimited[i]) force = o_clip(force, m->actuator_forcerange[2 * i], m->actuator_forcerange[2 * i + 1]);
+    d->actuator_force[i] = force;
+    d->qfrc_actuator[da] += gear * force;
+  }
+}
+
+/* ---- primal constraint solver (Newton) ------------------------------------------------ */
+/* cost of constraints at jar; fills force/state; optionally cone Hessians */
+static double constraint_update(const OModel *om, OData *d, const double *jar, double *force, int *state, int hess) {
+  double cost = 0;
+  for (int i = 0; i < d->nefc; i++) {
+    double D = d->efc_D[i], R = d->efc_R[i], x = jar[i];
+    int type = d->efc_type[i];
+    if (type == O_CNSTR_FRICTION_DOF) {
+      double f = d->efc_frictionloss[i];
+      if (x <= -R * f) { cost += -0.5 * R * f * f - f * x; force[i] = f; state[i] = O_STATE_LINEARNEG; }
+      else if (x >= R * f) { cost += -0.5 * R * f * f + f * x; force[i] = -f; state[i] = O_STATE_LINEARPOS; }
+      else { cost += 0.5 * D * x * x; force[i] = -D * x; state[i] = O_STATE_QUADRATIC; }
+    } else if (type != O_CNSTR_CONTACT_ELLIPTIC) {
+      if (x >= 0) { force[i] = 0; state[i] = O_STATE_SATISFIED; }
+      else { cost += 0.5 * D * x * x; force[i] = -D * x; state[i] = O_STATE_QUADRATIC; }
+    } else {
+      OContact *c = d->contact + d->efc_id[i];
+      int dim = c->dim;
+      double mu = c->mu, U[6];
+      U[0] = jar[i] * mu;
+      for (int j = 1; j < dim; j++) U[j] = jar[i + j] * c->friction[j - 1];
+      double N = U[0], T = o_norm(U + 1, dim - 1);
+      if (N >= mu * T || (T <= 0 && N >= 0)) {
+        for (int j = 0; j < dim; j++) force[i + j] = 0;
+        state[i] = O_STATE_SATISFIED;
+      } else if (mu * N + T <= 0 || (T <= 0 && N < 0)) {
+        for (int j = 0; j < dim; j++) { cost += 0.5 * d->efc_D[i + j] * jar[i + j] * jar[i + j]; force[i + j] = -d->efc_D[i + j] * jar[i + j]; }
+        state[i] = O_STATE_QUADRATIC;
+      } else {
+        double Dm = d->efc_D[i] / (mu * mu * (1 + mu * mu));
+        double NmT = N - mu * T;
+        cost += 0.5 * Dm * NmT * NmT;
+        force[i] = -Dm * NmT * mu;
+        for (int j = 1; j < dim; j++) force[i + j] = -force[i] / T * U[j] * c->friction[j - 1];
+        state[i] = O_STATE_CONE;
+        if (hess) {
+          /* H = S * d2s/dU2 * S, S = diag(mu, friction);  s = 0.5*Dm*(N - mu*T)^2 */
+          double g[6], S[6];
+          S[0] = mu; g[0] = 1;
+          for (int j = 1; j < dim; j++) { S[j] = c->friction[j - 1]; g[j] = -mu * U[j] / T; }
+          for (int a = 0; a < dim; a++) for (int b = 0; b < dim; b++) {
+            double h = g[a] * g[b];
+            if (a > 0 && b > 0) h += NmT * (-mu) * ((a == b ? 1.0 / T : 0.0) - U[a] * U[b] / (T * T * T));
+            c->H[a * 6 + b] = Dm * h * S[a] * S[b];
+          }
+        }
+      }
+      for (int j = 1; j < dim; j++) state[i + j] = state[i];
+      i += dim - 1;
+    }
+  }
+  return cost;
+}
+
+typedef struct { double cost, d1, d2; } LSPoint;
+
+/* exact 1-D evaluation of phi(alpha) = Gauss(alpha) + sum_i s_i(jar + alpha*jv) */
+static LSPoint ls_eval(const OModel *om, const OData *d, const double *jar, const double *jv, const double quad[3], double a) {
+  LSPoint p;
+  p.cost = quad[0] + a * quad[1] + a * a * quad[2];
+  p.d1 = quad[1] + 2 * a * quad[2];
+  p.d2 = 2 * quad[2];
+  for (int i = 0; i < d->nefc; i++) {
+    double D = d->efc_D[i], R = d->efc_R[i], x = jar[i] + a * jv[i], v = jv[i];
+    int type = d->efc_type[i];
+    if (type == O_CNSTR_FRICTION_DOF) {
+      double f = d->efc_frictionloss[i];
+      if (x <= -R * f) { p.cost += -0.5 * R * f * f - f * x; p.d1 += -f * v; }
+      else if (x >= R * f) { p.cost += -0.5 * R * f * f + f * x; p.d1 += f * v; }
+      else { p.cost += 0.5 * D * x * x; p.d1 += D * x * v; p.d2 += D * v * v; }
+    } else if (type != O_CNSTR_CONTACT_ELLIPTIC) {
+      if (x < 0) { p.cost += 0.5 * D * x * x; p.d1 += D * x * v; p.d2 += D * v * v; }
+    } else {
+      const OContact *c = d->contact + d->efc_id[i];
+      int dim = c->dim;
+      double mu = c->mu, U[6], V[6];
+      U[0] = x * mu; V[0] = v * mu;
+      for (int j = 1; j < dim; j++) { U[j] = (jar[i + j] + a * jv[i + j]) * c->friction[j - 1]; V[j] = jv[i + j] * c->friction[j - 1]; }
+      double N = U[0], T = o_norm(U + 1, dim - 1);
+      if (N >= mu * T || (T <= 0 && N >= 0)) {
+        /* satisfied */
+      } else if (mu * N + T <= 0 || (T <= 0 && N < 0)) {
+        for (int j = 0; j < dim; j++) {
+          double xj = jar[i + j] + a * jv[i + j], Dj = d->efc_D[i + j];
+          p.cost += 0.5 * Dj * xj * xj; p.d1 += Dj * xj * jv[i + j]; p.d2 += Dj * jv[i + j] * jv[i + j];
+        }
+      } else {
+        double Dm = d->efc_D[i] / (mu * mu * (1 + mu * mu));
+        double NmT = N - mu * T;
+        double UV = o_dot(U + 1, V + 1, dim - 1), VV = o_dot(V + 1, V + 1, dim - 1);
+        double T1 = UV / T;
+        double T2 = (VV - UV * UV / (T * T)) / T;
+        double g1 = V[0] - mu * T1;
+        p.cost += 0.5 * Dm * NmT * NmT;
+        p.d1 += Dm * NmT * g1;
+        p.d2 += Dm * (g1 * g1 - NmT * mu * T2);
+      }
+      i += dim - 1;
+    }
+  }
+  return p;
+}
+
+/* safeguarded Newton on phi'(alpha); phi convex, C1 */
+static double line_search(const OModel *om, OData *d, double cost0_gauss) {
+  const MjpcHipModel *m = &om->m;
+  int nv = m->nv;
+  double snorm = o_norm(d->search, nv);
+  double scale = 1.0 / (m->meaninertia * (nv > 1 ? nv : 1));
+  if (snorm < O_MINVAL) return 0;
+  double gtol = m->tolerance * m->ls_tolerance * snorm / scale;
+  /* Mv, jv, Gauss quadratic */
+  for (int i = 0; i < nv; i++) d->Mv[i] = o_dot(d->qM + i * nv, d->search, nv);
+  for (int r = 0; r < d->nefc; r++) d->efc_jv[r] = o_dot(d->efc_J + r * nv, d->search, nv);
+  double quad[3];
+  quad[0] = cost0_gauss;
+  quad[1] = 0; for (int i = 0; i < nv; i++) quad[1] += d->search[i] * (d->Ma[i] - d->qfrc_smooth[i]);
+  quad[2] = 0.5 * o_dot(d->search, d->Mv, nv);
+  LSPoint p0 = ls_eval(om, d, d->efc_jar, d->efc_jv, quad, 0);
+  if (!(p0.d2 > 0) || p0.d1 >= 0) return 0;
+  double lo = 0, hi = -1;   /* hi < 0: no upper bracket yet */
+  double a = -p0.d1 / p0.d2;
+  for (int it = 0; it < m->ls_iterations; it++) {
+    LSPoint p = ls_eval(om, d, d->efc_jar, d->efc_jv, quad, a);
+    if (fabs(p.d1) < gtol) break;
+    if (p.d1 < 0) lo = a; else hi = a;
+    double an = (p.d2 > 0) ? a - p.d1 / p.d2 : -1;
+    if (hi >= 0) { if (!(an > lo && an < hi)) an = 0.5 * (lo + hi); }
+    else if (!(an > lo)) an = 2 * a;
+    if (an == a) break;
+    a = an;
+  }
+  return a;
+}
+
+static void newton_gradient(const OModel *om, OData *d) {
+  const MjpcHipModel *m = &om->m;
+  int nv = m->nv;
+  /* grad = Ma - qfrc_smooth - J^T force */
+  for (int i = 0; i < nv; i++) d->grad[i] = d->Ma[i] - d->qfrc_smooth[i];
+  for (int r = 0; r < d->nefc; r++) {
+    double f = d->efc_force[r];
+    if (f == 0) continue;
+    for (int i = 0; i < nv; i++) d->grad[i] -= d->efc_J[r * nv + i] * f;
+  }
+  /* H = M + J^T diag(D*active) J + cone blocks */
+  o_copy(d->qH, d->qM, nv * nv);
+  for (int r = 0; r < d->nefc; r++) {
+    if (d->efc_state[r] == O_STATE_QUADRATIC) {
+      const double *J = d->efc_J + r * nv;
+      double D = d->efc_D[r];
+      for (int i = 0; i < nv; i++) { if (J[i] == 0) continue; double s = D * J[i]; for (int j = 0; j < nv; j++) d->qH[i * nv + j] += s * J[j]; }
+    } else if (d->efc_state[r] == O_STATE_CONE) {
+      const OContact *c = d->contact + d->efc_id[r];
+      int dim = c->dim;
+      for (int a = 0; a < dim; a++) for (int b = 0; b < dim; b++) {
+        double h = c->H[a * 6 + b];
+        const double *Ja = d->efc_J + (r + a) * nv, *Jb = d->efc_J + (r + b) * nv;
+        for (int i = 0; i < nv; i++) { if (Ja[i] == 0) continue; double s = h * Ja[i]; for (int j = 0; j < nv; j++) d->qH[i * nv + j] += s * Jb[j]; }
+      }
+      r += dim - 1;
+    }
+  }
+  chol_factor(d->qLD2, d->qH, nv);
+  chol_solve(d->Mgrad, d->qLD2, d->grad, nv);
+}
+
+static double total_cost(const OModel *om, OData *d, const double *qacc, double *gauss_out) {
+  int nv = om->m.nv;
+  for (int i = 0; i < nv; i++) d->Ma[i] = o_dot(d->qM + i * nv, qacc, nv);
+  for (int r = 0; r < d->nefc; r++) d->efc_jar[r] = o_dot(d->efc_J + r * nv, qacc, nv) - d->efc_aref[r];
+  double gauss = 0;
+  for (int i = 0; i < nv; i++) gauss += 0.5 * (d->Ma[i] - d->qfrc_smooth[i]) * (qacc[i] - d->qacc_smooth[i]);
+  if (gauss_out) *gauss_out = gauss;
+  return gauss + constraint_update(om, d, d->efc_jar, d->efc_force, d->efc_state, 1);
+}
+
+static void solve_constraints(const OModel *om, OData *d) {
+  const MjpcHipModel *m = &om->m;
+  int nv = m->nv;
+  d->solver_iter = 0;
+  if (d->nefc == 0) {
+    o_copy(d->qacc, d->qacc_smooth, nv);
+    o_zero(d->qfrc_constraint, nv);
+    return;
+  }
+  /* warm start: better of qacc_warmstart and qacc_smooth */
+  double cost_ws = total_cost(om, d, d->qacc_warmstart, NULL);
+  double cost_sm = total_cost(om, d, d->qacc_smooth, NULL);
+  if (cost_ws > cost_sm) o_copy(d->qacc, d->qacc_smooth, nv); else o_copy(d->qacc, d->qacc_warmstart, nv);
+  double gauss;
+  double cost = total_cost(om, d, d->qacc, &gauss);
+  newton_gradient(om, d);
+  for (int i = 0; i < nv; i++) d->search[i] = -d->Mgrad[i];
+  double scale = 1.0 / (m->meaninertia * (nv > 1 ? nv : 1));
+  for (int iter = 0; iter < m->iterations; iter++) {
+    double alpha = line_search(om, d, gauss);
+    if (alpha == 0) break;
+    for (int i = 0; i < nv; i++) d->qacc[i] += alpha * d->search[i];
+    double oldcost = cost;
+    cost = total_cost(om, d, d->qacc, &gauss);   /* recomputes Ma, jar exactly */
+    newton_gradient(om, d);
+    d->solver_iter++;
+    double improvement = scale * (oldcost - cost);
+    double gradient = scale * o_norm(d->grad, nv);
+    if (improvement < m->tolerance || gradient < m->tolerance) break;
+    for (int i = 0; i < nv; i++) d->search[i] = -d->Mgrad[i];
+  }
+  o_zero(d->qfrc_constraint, nv);
+  for (int r = 0; r < d->nefc; r++) {
+    double f = d->efc_force[r];
+    if (f == 0) continue;
+    for (int i = 0; i < nv; i++) d->qfrc_constraint[i] += d->efc_J[r * nv + i] * f;
+  }
+}
+
+/* ---- pipeline ------------------------------------------------------------------------ */
+static int bad(const double *x, int n) {
+  for (int i = 0; i < n; i++) if (!(x[i] == x[i]) || x[i] > 1e10 || x[i] < -1e10) return 1;
+  return 0;
+}
+
+void oracle_forward(const OModel *om, OData *d) {
+  const MjpcHipModel *m = &om->m;
+  int nv = m->nv;
+  kinematics(om, d);
+  com_pos(om, d);
+  crb_and_factor(om, d);
+  collision(om, d);
+  make_constraint(om, d);
+  com_vel(om, d);
+  passive(om, d);
+  make_impedance(om, d);
+  rne_bias(om, d);
+  actuation(om, d);
+  for (int i = 0; i < nv; i++) d->qfrc_smooth[i] = d->qfrc_passive[i] - d->qfrc_bias[i] + d->qfrc_actuator[i];
+  chol_solve(d->qacc_smooth, d->qL, d->qfrc_smooth, nv);
+  solve_constraints(om, d);
+  oracle_residual(om, d, d->sensordata);
+}
+
+static void integrate_pos(const OModel *om, OData *d, double h) {
+  const MjpcHipModel *m = &om->m;
+  for (int j = 0; j < m->njnt; j++) {
+    int qa = m->jnt_qposadr[j], da = m->jnt_dofadr[j];
+    switch (m->jnt_type[j]) {
+      case MJPC_JNT_FREE:
+        for (int k = 0; k < 3; k++) d->qpos[qa + k] += h * d->qvel[da + k];
+        o_quatintegrate(d->qpos + qa + 3, d->qvel + da + 3, h);
+        break;
+      case MJPC_JNT_BALL:
+        o_quatintegrate(d->qpos + qa, d->qvel + da, h);
+        break;
+      default:
+        d->qpos[qa] += h * d->qvel[da];
+    }
+  }
+}
+
+void oracle_step(const OModel *om, OData *d) {
+  const MjpcHipModel *m = &om->m;
+  int nv = m->nv;
+  double h = m->timestep;
+  if (bad(d->qpos, m->nq) || bad(d->qvel, nv)) { d->warning = 1; return; }
+  oracle_forward(om, d);
+  if (bad(d->qacc, nv)) { d->warning = 1; return; }
+  /* Euler, implicit in joint damping */
+  int damped = 0;
+  for (int i = 0; i < nv; i++) if (m->dof_damping[i] > 0) damped = 1;
+  double *qacc = d->qacc;
+  if (damped) {
+    o_copy(d->qH, d->qM, nv * nv);
+    for (int i = 0; i < nv; i++) d->qH[i * nv + i] += h * m->dof_damping[i];
+    chol_factor(d->qLD2, d->qH, nv);
+    double *rhs = d->work, *sol = d->work + nv;
+    for (int i = 0; i < nv; i++) rhs[i] = d->qfrc_smooth[i] + d->qfrc_constraint[i];
+    chol_solve(sol, d->qLD2, rhs, nv);
+    qacc = sol;
+  }
+  for (int i = 0; i < nv; i++) d->qvel[i] += h * qacc[i];
+  integrate_pos(om, d, h);
+  d->time += h;
+  o_copy(d->qacc_warmstart, d->qacc, nv);
+}
+
+/* ---- debug accessors for unit tests --------------------------------------------------- */
+int oracle_debug_forward(const OModel *om, const double *qpos, const double *qvel,
+                         const double *ctrl, const double *mocap, double time,
+                         double *qacc, double *qM, double *xpos, double *sensordata,
+                         double *contact_dist, int *ncon, int *nefc, double *efc_force,
+                         double *geom_xpos, double *extra) {
+  const MjpcHipModel *m = &om->m;
+  OData *d = oracle_make_data(om);
+  o_copy(d->qpos, qpos, m->nq);
+  if (qvel) o_copy(d->qvel, qvel, m->nv);
+  if (ctrl) o_copy(d->ctrl, ctrl, m->nu);
+  if (mocap) for (int i = 0; i < m->nmocap; i++) { o_copy3(d->mocap_pos + 3 * i, mocap + 7 * i); o_copy(d->mocap_quat + 4 * i, mocap + 7 * i + 3, 4); }
+  d->time = time;
+  oracle_forward(om, d);
+  if (qacc) o_copy(qacc, d->qacc, m->nv);
+  if (qM) o_copy(qM, d->qM, m->nv * m->nv);
+  if (xpos) o_copy(xpos, d->xpos, 3 * m->nbody);
+  if (sensordata) o_copy(sensordata, d->sensordata, om->t.num_residual);
+  if (contact_dist) for (int i = 0; i < d->ncon; i++) contact_dist[i] = d->contact[i].dist;
+  if (ncon) *ncon = d->ncon;
+  if (nefc) *nefc = d->nefc;
+  if (efc_force) o_copy(efc_force, d->efc_force, d->nefc);
+  if (geom_xpos) o_copy(geom_xpos, d->geom_xpos, 3 * m->ngeom);
+  if (extra) {   /* [0:nv] qacc_smooth, [nv:2nv] qfrc_bias, [2nv:3nv] qfrc_constraint, then solver_iter, unsupported, 3*nbody subtree_com, 3*nbody subtree_linvel */
+    int nv = m->nv;
+    o_copy(extra, d->qacc_smooth, nv); o_copy(extra + nv, d->qfrc_bias, nv); o_copy(extra + 2 * nv, d->qfrc_constraint, nv);
+    extra[3 * nv] = d->solver_iter; extra[3 * nv + 1] = d->unsupported;
+    o_copy(extra + 3 * nv + 2, d->subtree_com, 3 * m->nbody);
+    o_copy(extra + 3 * nv + 2 + 3 * m->nbody, d->subtree_linvel, 3 * m->nbody);
+  }
+  int w = d->warning;
+  oracle_free_data(d);
+  return w;
+}
+
+int oracle_debug_step(const OModel *om, double *qpos, double *qvel, const double *ctrl,
+                      const double *mocap, double *time, int nstep, double *energy) {
+  const MjpcHipModel *m = &om->m;
+  OData *d = oracle_make_data(om);
+  o_copy(d->qpos, qpos, m->nq); o_copy(d->qvel, qvel, m->nv);
+  if (ctrl) o_copy(d->ctrl, ctrl, m->nu);
+  if (mocap) for (int i = 0; i < m->nmocap; i++) { o_copy3(d->mocap_pos + 3 * i, mocap + 7 * i); o_copy(d->mocap_quat + 4 * i, mocap + 7 * i + 3, 4); }
+  d->time = *time;
+  for (int s = 0; s < nstep && !d->warning; s++) {
+    oracle_step(om, d);
+    if (energy) {   /* energy of the state the forward pass saw */
+      int nv = m->nv;
+      double ke = 0, pe = 0;
+      for (int i = 0; i < nv; i++) ke += 0.5 * d->qvel[i] * o_dot(d->qM + i * nv, d->qvel, nv);
+      for (int b = 1; b < m->nbody; b++) pe -= m->body_mass[b] * o_dot3(m->gravity, d->xipos + 3 * b);
+      energy[2 * s] = ke; energy[2 * s + 1] = pe;
+    }
+  }
+  o_copy(qpos, d->qpos, m->nq); o_copy(qvel, d->qvel, m->nv);
+  *time = d->time;
+  int w = d->warning;
+  oracle_free_data(d);
+  return w;
+}

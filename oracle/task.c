@@ -1,0 +1,363 @@
+/*
+ * oracle/task.c — TEST INFRASTRUCTURE ONLY (CPU oracle).
+ *
+ * Cost (norms, risk), task residuals and the Ground() ray cast, restated from:
+ *   mjpc/norm.cc:25-210            NormParameterDimension, Norm
+ *   mjpc/task.cc:71-110            BaseResidualFn::CostTerms / CostValue
+ *   mjpc/tasks/cartpole/cartpole.cc:36-49
+ *   mjpc/test/testdata/particle_residual.h:33-43
+ *   mjpc/tasks/quadruped/quadruped.cc:33-221,602-714 (+ constants quadruped.h:68-140)
+ *   mjpc/utilities.cc:538-556      Ground (mj_ray straight down, geom group 0)
+ */
+#include <stdio.h>
+#include "oracle.h"
+#include "omath.h"
+
+int oracle_norm_parameter_dimension(int type) {   /* norm.cc:25-47 */
+  switch (type) {
+    case MJPC_NORM_NULL: return 0;
+    case MJPC_NORM_QUADRATIC: return 0;
+    case MJPC_NORM_L22: return 2;
+    case MJPC_NORM_L2: return 1;
+    case MJPC_NORM_COSH: return 1;
+    case MJPC_NORM_POWER: return 1;
+    case MJPC_NORM_SMOOTHABS: return 1;
+    case MJPC_NORM_SMOOTHABS2: return 2;
+    case MJPC_NORM_RECTIFY: return 1;
+  }
+  return 0;
+}
+
+double oracle_norm(const double *x, const double *params, int n, int type) {   /* norm.cc:50-210, value only */
+  double y = 0;
+  double p = params ? params[0] : 0, q = params ? params[1] : 0;
+  switch (type) {
+    case MJPC_NORM_NULL: y = x[0]; break;
+    case MJPC_NORM_QUADRATIC:
+      for (int i = 0; i < n; i++) y += x[i] * x[i];
+      y *= 0.5;
+      break;
+    case MJPC_NORM_L22: {
+      double c = 0;
+      for (int i = 0; i < n; i++) c += x[i] * x[i];
+      double a = pow(c, q / 2) + pow(p, q);
+      double s = pow(a, 1 / q);
+      y = s - p;
+      break;
+    }
+    case MJPC_NORM_L2: {
+      double s = sqrt(o_dot(x, x, n) + p * p);
+      y = s - p;
+      break;
+    }
+    case MJPC_NORM_COSH:
+      for (int i = 0; i < n; i++) y += p * p * (cosh(x[i] / p) - 1.0);
+      break;
+    case MJPC_NORM_POWER:
+      for (int i = 0; i < n; i++) y += pow(fabs(x[i]), p);
+      break;
+    case MJPC_NORM_SMOOTHABS:
+      for (int i = 0; i < n; i++) { double s = sqrt(x[i] * x[i] + p * p); y += s - p; }
+      break;
+    case MJPC_NORM_SMOOTHABS2:
+      for (int i = 0; i < n; i++) {
+        double a = fabs(x[i]);
+        double d = pow(a, q);
+        double e = d + pow(p, q);
+        double s = pow(e, 1 / q);
+        y += s - p;
+      }
+      break;
+    case MJPC_NORM_RECTIFY:
+      for (int i = 0; i < n; i++) {
+        if (p > 0) { double s = exp(x[i] / p); y += p * log(1 + s); }
+        else y += x[i] > 0 ? x[i] : 0;
+      }
+      break;
+    default: break;
+  }
+  return y;
+}
+
+double oracle_cost_value(const MjpcHipTask *t, const double *residual, double *terms_out) {   /* task.cc:71-110 */
+  double terms[MJPC_MAX_COST_TERMS];
+  int f_shift = 0, p_shift = 0;
+  for (int k = 0; k < t->num_term; k++) {
+    terms[k] = t->weight[k] * oracle_norm(residual + f_shift, t->norm_parameter + p_shift,
+                                          t->dim_norm_residual[k], t->norm[k]);
+    f_shift += t->dim_norm_residual[k];
+    p_shift += t->num_norm_parameter[k];
+  }
+  double cost = 0;
+  for (int i = 0; i < t->num_term; i++) cost += terms[i];
+  if (terms_out) for (int i = 0; i < t->num_term; i++) terms_out[i] = terms[i];
+  if (fabs(t->risk) < 1e-6) return cost;                 /* kRiskNeutralTolerance */
+  return (exp(t->risk * cost) - 1.0) / t->risk;
+}
+
+/* ---- ray casting against plane / sphere / box (mju_rayGeom semantics) ----------------- */
+static double ray_geom(const double *pos, const double *mat, const double *size, const double *pnt, const double *vec, int type) {
+  double dif[3], lp[3], lv[3];
+  o_sub3(dif, pnt, pos);
+  o_mulmattvec3(lp, mat, dif);
+  o_mulmattvec3(lv, mat, vec);
+  if (type == MJPC_GEOM_PLANE) {
+    if (lv[2] > -O_MINVAL) return -1;
+    double x = -lp[2] / lv[2];
+    if (x < 0) return -1;
+    double p0 = lp[0] + x * lv[0], p1 = lp[1] + x * lv[1];
+    if ((size[0] <= 0 || fabs(p0) <= size[0]) && (size[1] <= 0 || fabs(p1) <= size[1])) return x;
+    return -1;
+  }
+  if (type == MJPC_GEOM_SPHERE) {
+    double a = o_dot3(lv, lv), b = o_dot3(lv, lp), c = o_dot3(lp, lp) - size[0] * size[0];
+    double det = b * b - a * c;
+    if (det < O_MINVAL || a < O_MINVAL) return -1;
+    det = sqrt(det);
+    double x0 = (-b - det) / a, x1 = (-b + det) / a;
+    if (x0 >= 0) return x0;
+    if (x1 >= 0) return x1;
+    return -1;
+  }
+  if (type == MJPC_GEOM_BOX) {
+    double best = -1;
+    for (int i = 0; i < 3; i++) {
+      if (fabs(lv[i]) <= O_MINVAL) continue;
+      for (int side = -1; side <= 1; side += 2) {
+        double x = (side * size[i] - lp[i]) / lv[i];
+        if (x < 0) continue;
+        int j = (i + 1) % 3, k = (i + 2) % 3;
+        double pj = lp[j] + x * lv[j], pk = lp[k] + x * lv[k];
+        if (fabs(pj) <= size[j] && fabs(pk) <= size[k]) if (best < 0 || x < best) best = x;
+      }
+    }
+    return best;
+  }
+  return -1;
+}
+
+double oracle_ray_ground(const OModel *om, const OData *d, const double pos[3]) {   /* utilities.cc:538-556 */
+  const MjpcHipModel *m = &om->m;
+  double down[3] = {0, 0, -1};
+  double query[3] = {pos[0], pos[1], pos[2] + 0.5};
+  double dist = -1;
+  for (int r = 0; r < om->nray; r++) {
+    int g = om->ray_geom[r];
+    double x = ray_geom(d->geom_xpos + 3 * g, d->geom_xmat + 9 * g, m->geom_size + 3 * g, query, down, m->geom_type[g]);
+    if (x >= 0 && (dist < 0 || x < dist)) dist = x;
+  }
+  return pos[2] + 0.5 - dist;
+}
+
+/* ---- quadruped ------------------------------------------------------------------------ */
+enum { QI_TORSO = 0, QI_HEAD = 1, QI_GOAL = 2, QI_FOOT = 3, QI_GAIT = 7, QI_GAIT_SWITCH = 8, QI_FLIP_DIR = 9,
+       QI_BIPED_TYPE = 10, QI_CADENCE = 11, QI_AMPLITUDE = 12, QI_DUTY = 13, QI_HEADING = 14, QI_HOME = 15,
+       QI_CROUCH = 16, QI_MODE = 17 };
+enum { QD_MODE_START = 0, QD_POSITION = 1, QD_HEADING = 4, QD_SPEED = 6, QD_ANGVEL = 7, QD_GROUND = 8,
+       QD_ORIENT = 9, QD_GAIT = 13, QD_PHASE_START = 14, QD_PHASE_START_TIME = 15, QD_PHASE_VEL = 16,
+       QD_GRAVITY = 17, QD_JUMP_VEL = 18, QD_FLIGHT_TIME = 19, QD_JUMP_ACC = 20, QD_CROUCH_TIME = 21,
+       QD_LEAP_TIME = 22, QD_JUMP_TIME = 23, QD_CROUCH_VEL = 24, QD_LAND_TIME = 25, QD_LAND_ACC = 26,
+       QD_FLIGHT_ROT_VEL = 27, QD_JUMP_ROT_VEL = 28, QD_JUMP_ROT_ACC = 29, QD_LAND_ROT_ACC = 30 };
+enum { kModeQuadruped = 0, kModeBiped, kModeWalk, kModeScramble, kModeFlip };
+enum { kFootFL = 0, kFootHL, kFootFR, kFootHR };
+static const double kGaitPhase[5][4] = {   /* quadruped.h:77-85 */
+  {0, 0, 0, 0}, {0, 0.75, 0.5, 0.25}, {0, 0.5, 0.5, 0}, {0, 0.33, 0.33, 0.66}, {0, 0.4, 0.05, 0.35}};
+static const double kHeightQuadruped = 0.25, kHeightBiped = 0.6, kFootRadius = 0.02, kMinAngvel = 0.01;
+static const double kJointPostureGain[3] = {2, 1, 1};
+static const double kLeapHeight = 0.5;
+
+static int reinterpret_int(double v) { int i; memcpy(&i, &v, sizeof(int)); return i; }   /* utilities.cc:100-102 */
+
+static double q_step_height(double time, double footphase, double duty_ratio) {   /* quadruped.cc:650-659 */
+  double angle = fmod(time + O_PI - footphase, 2 * O_PI) - O_PI;
+  double value = 0;
+  if (duty_ratio < 1) {
+    angle *= 0.5 / (1 - duty_ratio);
+    value = cos(o_clip(angle, -O_PI / 2, O_PI / 2));
+  }
+  return fabs(value) < 1e-6 ? 0.0 : value;
+}
+static double q_flip_height(const double *D, double time) {   /* quadruped.cc:674-690 */
+  double jump_time = D[QD_JUMP_TIME], flight_time = D[QD_FLIGHT_TIME], land_time = D[QD_LAND_TIME];
+  if (time >= jump_time + flight_time + land_time) return kHeightQuadruped + D[QD_GROUND];
+  double h = 0;
+  if (time < jump_time) h = kHeightQuadruped + time * D[QD_CROUCH_VEL] + 0.5 * time * time * D[QD_JUMP_ACC];
+  else if (time >= jump_time && time < jump_time + flight_time) { time -= jump_time; h = kLeapHeight + D[QD_JUMP_VEL] * time - 0.5 * 9.81 * time * time; }
+  else if (time >= jump_time + flight_time) { time -= jump_time + flight_time; h = kLeapHeight - D[QD_JUMP_VEL] * time + 0.5 * D[QD_LAND_ACC] * time * time; }
+  return h + D[QD_GROUND];
+}
+static void q_flip_quat(const double *D, const double *params, const int *I, double quat[4], double time) {   /* quadruped.cc:695-714 */
+  double angle = 0;
+  double jump_time = D[QD_JUMP_TIME], flight_time = D[QD_FLIGHT_TIME], land_time = D[QD_LAND_TIME], crouch_time = D[QD_CROUCH_TIME];
+  if (time >= jump_time + flight_time + land_time) angle = 2 * O_PI;
+  else if (time >= crouch_time && time < jump_time) { time -= crouch_time; angle = 0.5 * D[QD_JUMP_ROT_ACC] * time * time + D[QD_JUMP_ROT_VEL] * time; }
+  else if (time >= jump_time && time < jump_time + flight_time) { time -= jump_time; angle = O_PI / 2 + D[QD_FLIGHT_ROT_VEL] * time; }
+  else if (time >= jump_time + flight_time) { time -= jump_time + flight_time; angle = 1.75 * O_PI + D[QD_FLIGHT_ROT_VEL] * time - 0.5 * D[QD_LAND_ROT_ACC] * time * time; }
+  int flip_dir = reinterpret_int(params[I[QI_FLIP_DIR]]);
+  double axis[3] = {0, flip_dir ? 1.0 : -1.0, 0}, q[4];
+  o_axisangle2quat(q, axis, angle);
+  o_mulquat(quat, D + QD_ORIENT, q);
+}
+static void q_walk(const double *D, double pos[2], double time) {   /* quadruped.cc:619-636 */
+  if (fabs(D[QD_ANGVEL]) < kMinAngvel) {
+    double fwd[2] = {D[QD_HEADING], D[QD_HEADING + 1]};
+    o_normalize(fwd, 2);
+    pos[0] = D[QD_POSITION] + D[QD_HEADING] + time * D[QD_SPEED] * fwd[0];
+    pos[1] = D[QD_POSITION + 1] + D[QD_HEADING + 1] + time * D[QD_SPEED] * fwd[1];
+  } else {
+    double angle = time * D[QD_ANGVEL];
+    double c = cos(angle), s = sin(angle);
+    pos[0] = c * D[QD_HEADING] - s * D[QD_HEADING + 1] + D[QD_POSITION];
+    pos[1] = s * D[QD_HEADING] + c * D[QD_HEADING + 1] + D[QD_POSITION + 1];
+  }
+}
+
+static void residual_quadruped(const OModel *om, OData *d, double *residual) {   /* quadruped.cc:33-221 */
+  const MjpcHipModel *m = &om->m;
+  const MjpcHipTask *t = &om->t;
+  const int *I = t->int_data;
+  const double *D = t->dbl_data, *P = t->parameters;
+  int mode = I[QI_MODE], torso = I[QI_TORSO];
+  int counter = 0;
+  const double *foot_pos[4];
+  for (int f = 0; f < 4; f++) foot_pos[f] = d->geom_xpos + 3 * I[QI_FOOT + f];
+  /* average foot position (quadruped.cc:602-616) */
+  double avg[3];
+  if (mode == kModeBiped) {
+    int handstand = reinterpret_int(P[I[QI_BIPED_TYPE]]);
+    if (handstand) o_add3(avg, foot_pos[kFootFL], foot_pos[kFootFR]);
+    else o_add3(avg, foot_pos[kFootHL], foot_pos[kFootHR]);
+    o_scl3(avg, avg, 0.5);
+  } else {
+    o_add3(avg, foot_pos[kFootHL], foot_pos[kFootHR]);
+    o_add3(avg, avg, foot_pos[kFootFL]);
+    o_add3(avg, avg, foot_pos[kFootFR]);
+    o_scl3(avg, avg, 0.25);
+  }
+  const double *torso_xmat = d->xmat + 9 * torso;
+  const double *goal_pos = d->mocap_pos + 3 * I[QI_GOAL];
+  const double *compos = d->subtree_com + 3 * torso;
+  /* Upright */
+  if (mode != kModeFlip) {
+    if (mode == kModeBiped) {
+      int handstand = reinterpret_int(P[I[QI_BIPED_TYPE]]) ? -1 : 1;
+      residual[counter++] = torso_xmat[6] - handstand;
+    } else residual[counter++] = torso_xmat[8] - 1;
+    residual[counter++] = 0;
+    residual[counter++] = 0;
+  } else {
+    double quat[4];
+    q_flip_quat(D, P, I, quat, d->time - D[QD_MODE_START]);
+    o_subquat(residual + counter, d->xquat + 4 * torso, quat);
+    counter += 3;
+  }
+  /* Height */
+  const double *torso_pos = d->xipos + 3 * torso;
+  int is_biped = mode == kModeBiped;
+  double height_goal = is_biped ? kHeightBiped : kHeightQuadruped;
+  if (mode == kModeScramble) residual[counter++] = 0;
+  else if (mode == kModeFlip) residual[counter++] = torso_pos[2] - q_flip_height(D, d->time - D[QD_MODE_START]);
+  else residual[counter++] = (torso_pos[2] - avg[2]) - height_goal;
+  /* Position */
+  const double *head = d->site_xpos + 3 * I[QI_HEAD];
+  double target[3];
+  if (mode == kModeWalk) { q_walk(D, target, d->time - D[QD_MODE_START]); target[2] = 0; }
+  else o_copy3(target, goal_pos);
+  residual[counter++] = head[0] - target[0];
+  residual[counter++] = head[1] - target[1];
+  residual[counter++] = mode == kModeScramble ? 2 * (head[2] - target[2]) : 0;
+  /* Gait */
+  int gait = mode == kModeBiped ? 2 : reinterpret_int(D[QD_GAIT]);
+  double phase = D[QD_PHASE_START] + (d->time - D[QD_PHASE_START_TIME]) * D[QD_PHASE_VEL];
+  double amplitude = P[I[QI_AMPLITUDE]], duty = P[I[QI_DUTY]];
+  double step[4];
+  for (int f = 0; f < 4; f++) step[f] = amplitude * q_step_height(phase, 2 * O_PI * kGaitPhase[gait][f], duty);
+  for (int f = 0; f < 4; f++) {
+    if (is_biped) {
+      int handstand = reinterpret_int(P[I[QI_BIPED_TYPE]]) != 0;
+      int front_hand = !handstand && (f == kFootFL || f == kFootFR);
+      int back_hand = handstand && (f == kFootHL || f == kFootHR);
+      if (front_hand || back_hand) { residual[counter++] = 0; continue; }
+    }
+    double query[3] = {foot_pos[f][0], foot_pos[f][1], foot_pos[f][2]};
+    if (mode == kModeScramble) {
+      double v[3];
+      o_sub3(v, goal_pos, torso_pos); o_normalize3(v);
+      o_sub3(v, goal_pos, foot_pos[f]);
+      v[2] = 0; o_normalize3(v);
+      o_addtoscl3(query, v, 0.15);
+    }
+    double ground_height = oracle_ray_ground(om, d, query);
+    double height_target = ground_height + kFootRadius + step[f];
+    double height_difference = foot_pos[f][2] - height_target;
+    if (mode == kModeScramble) height_difference = fmin(0, height_difference);
+    residual[counter++] = step[f] ? height_difference : 0;
+  }
+  /* Balance */
+  const double *comvel = d->subtree_linvel + 3 * torso;
+  double fall_time = sqrt(2 * height_goal / 9.81), capture[3];
+  o_addscl3(capture, compos, comvel, fall_time);
+  residual[counter++] = capture[0] - avg[0];
+  residual[counter++] = capture[1] - avg[1];
+  /* Effort */
+  for (int i = 0; i < m->nu; i++) residual[counter + i] = d->actuator_force[i] * 2e-2;
+  counter += m->nu;
+  /* Posture */
+  const double *home = m->key_qpos + I[QI_HOME] * m->nq;
+  for (int i = 0; i < m->nu; i++) residual[counter + i] = d->qpos[7 + i] - home[7 + i];
+  if (mode == kModeFlip) {
+    double flip_time = d->time - D[QD_MODE_START];
+    if (flip_time < D[QD_CROUCH_TIME]) {
+      const double *crouch = m->key_qpos + I[QI_CROUCH] * m->nq;
+      for (int i = 0; i < m->nu; i++) residual[counter + i] = d->qpos[7 + i] - crouch[7 + i];
+    } else if (flip_time >= D[QD_CROUCH_TIME] && flip_time < D[QD_JUMP_TIME] + D[QD_FLIGHT_TIME]) {
+      for (int i = 0; i < m->nu; i++) residual[counter + i] = 0;
+    }
+  }
+  for (int f = 0; f < 4; f++) for (int j = 0; j < 3; j++) residual[counter + 3 * f + j] *= kJointPostureGain[j];
+  if (mode == kModeBiped) {
+    int handstand = reinterpret_int(P[I[QI_BIPED_TYPE]]) != 0;
+    if (handstand) { residual[counter + 4] *= 0.03; residual[counter + 5] *= 0.03; residual[counter + 10] *= 0.03; residual[counter + 11] *= 0.03; }
+    else { residual[counter + 1] *= 0.03; residual[counter + 2] *= 0.03; residual[counter + 7] *= 0.03; residual[counter + 8] *= 0.03; }
+  }
+  counter += m->nu;
+  /* Yaw */
+  double th[2] = {torso_xmat[0], torso_xmat[3]};
+  if (mode == kModeBiped) {
+    int handstand = reinterpret_int(P[I[QI_BIPED_TYPE]]) ? 1 : -1;
+    th[0] = handstand * torso_xmat[2]; th[1] = handstand * torso_xmat[5];
+  }
+  o_normalize(th, 2);
+  double heading_goal = P[I[QI_HEADING]];
+  residual[counter++] = th[0] - cos(heading_goal);
+  residual[counter++] = th[1] - sin(heading_goal);
+  /* "Angmom": declared as a second subtreelinvel sensor (task_flat.xml:143) */
+  o_copy3(residual + counter, d->subtree_linvel + 3 * torso);
+  counter += 3;
+}
+
+void oracle_residual(const OModel *om, OData *d, double *residual) {
+  const MjpcHipModel *m = &om->m;
+  switch (om->t.task_id) {
+    case MJPC_TASK_PARTICLE:   /* particle_residual.h:33-43 */
+      o_copy(residual, d->qpos, m->nq);
+      residual[0] -= d->mocap_pos[0];
+      residual[1] -= d->mocap_pos[1];
+      o_copy(residual + 2, d->qvel, m->nv);
+      break;
+    case MJPC_TASK_CARTPOLE:   /* cartpole.cc:36-49 */
+      residual[0] = cos(d->qpos[1]) - 1;
+      residual[1] = d->qpos[0] - om->t.parameters[0];
+      residual[2] = d->qvel[1];
+      residual[3] = d->ctrl[0];
+      break;
+    case MJPC_TASK_COPYSTATE:
+      o_copy(residual, d->qpos, m->nq);
+      o_copy(residual + m->nq, d->qvel, m->nv);
+      break;
+    case MJPC_TASK_QUADRUPED:
+      residual_quadruped(om, d, residual);
+      break;
+    default: break;
+  }
+}

@@ -1,0 +1,228 @@
+"""Analytic / invariant checks of the oracle's physics restatement (CPU only).
+
+MuJoCo is not available here (parity unpinned at the mj_step boundary); these tests
+pin the restatement against closed forms and conservation laws instead.
+"""
+import math
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from mujoco_mpc_amd.modelgen import ModelBuilder, cartpole, mass_matrix, particle, quadruped
+from mujoco_mpc_amd.modelgen.builder import BOX, CAPSULE, FREE, HINGE, PLANE, SLIDE, SPHERE
+from mujoco_mpc_amd.modelgen.tasks import TASK_COPYSTATE, make_task
+
+
+def _copy_task(m):
+    n = m["nq"] + m["nv"]
+    return make_task(TASK_COPYSTATE, [(n, 0, 1.0)])
+
+
+def test_particle_implicit_damped_integrator_closed_form():
+    m, task, _ = particle(timestep=0.01)
+    o = ol.Oracle(m, task)
+    h, mass, b = 0.01, 0.3, 1.0
+    x = np.array([0.05, -0.1]); v = np.array([0.2, 0.1]); u = np.array([0.7, -0.4])
+    q, qd, t, _, w = o.step(x, v, ctrl=u, nstep=25)
+    for _ in range(25):
+        v = v + h * (u - b * v) / (mass + h * b)           # Euler, implicit in damping
+        x = x + h * v
+    assert w == 0 and abs(t - 0.25) < 1e-12
+    assert np.allclose(q, x, rtol=0, atol=1e-13) and np.allclose(qd, v, rtol=0, atol=1e-13)
+
+
+def test_mass_matrix_matches_independent_numpy_for_all_models():
+    rng = np.random.default_rng(1)
+    for f in (particle, cartpole, quadruped):
+        m, task, d = f()
+        o = ol.Oracle(m, task)
+        q = d["state"][:m["nq"]].copy()
+        q[-min(m["nq"], 12):] += rng.uniform(-0.3, 0.3, min(m["nq"], 12))
+        if m["nq"] == 19:
+            q[3:7] = rng.normal(size=4); q[3:7] /= np.linalg.norm(q[3:7])
+        r = o.forward(q, mocap=d["mocap"] if len(d["mocap"]) else None)
+        Mq, _, _ = mass_matrix(m, q)
+        assert np.abs(Mq - r["qM"]).max() < 1e-13
+        assert np.all(np.linalg.eigvalsh(r["qM"]) > 0)
+
+
+def test_cartpole_equations_of_motion_textbook():
+    m, task, _ = cartpole()
+    o = ol.Oracle(m, task)
+    mc = 1.0; mp = 0.1
+    # pole capsule: COM at l=0.5 from the hinge; inertia about COM from the compiled model (axis y)
+    l = 0.5
+    pole = m["names"]["body"]["pole_1"]
+    Mq, _, _ = mass_matrix(m, np.zeros(2))
+    I_hinge = Mq[1, 1]                                    # Ic + mp l^2 at theta=0
+    g = 9.81
+    for th, x_d, th_d, u in [(0.3, 0.1, -0.5, 0.4), (2.5, -0.3, 1.2, -1.0), (-1.0, 0.0, 0.0, 0.0)]:
+        r = o.forward([0.2, th], [x_d, th_d], [u])
+        # generalized coords (x, theta), theta=0 upright, rotation about +y: pole tip at (sin th, cos th)
+        Mt = np.array([[mc + mp, mp * l * math.cos(th)], [mp * l * math.cos(th), I_hinge]])
+        bias = np.array([-mp * l * math.sin(th) * th_d ** 2, -mp * g * l * math.sin(th)])
+        tau = np.array([10.0 * u - 1e-4 * x_d, -1e-4 * th_d])
+        acc = np.linalg.solve(Mt, tau - bias)
+        assert np.allclose(r["qM"], Mt, atol=1e-12)
+        assert np.allclose(r["qacc"], acc, rtol=1e-10, atol=1e-10)
+
+
+def test_free_flight_momentum_quadruped():
+    """Internal forces (actuators, damping, friction loss, Coriolis) cannot accelerate the COM: as h -> 0 the
+    COM acceleration of the free-flying robot is exactly gravity (Euler's O(h) error shrinks with h)."""
+    errs = []
+    for h in (1e-4, 1e-5):
+        m, task, d = quadruped(timestep=h)
+        o = ol.Oracle(m, task)
+        rng = np.random.default_rng(3)
+        q = d["state"][:19].copy(); q[2] = 2.0             # far above the floor: no contacts
+        q[7:] += rng.uniform(-0.2, 0.2, 12)
+        v = rng.normal(size=18) * 0.5
+        trunk = m["names"]["body"]["trunk"]
+        r0 = o.forward(q, v, mocap=d["mocap"])
+        assert r0["ncon"] == 0
+        q1, v1, _, _, w = o.step(q, v, ctrl=rng.uniform(-1, 1, 12), mocap=d["mocap"], nstep=1)
+        r1 = o.forward(q1, v1, mocap=d["mocap"])
+        acc = (r1["subtree_linvel"][trunk] - r0["subtree_linvel"][trunk]) / h
+        assert w == 0
+        errs.append(np.abs(acc - [0, 0, -9.81]).max())
+    assert errs[1] < 5e-4 and errs[1] < 0.2 * errs[0]      # first-order convergence to exactly g
+
+
+def _ball_on_plane(tilt=0.0, friction=1.0, condim=3, cone=1, r=0.1, mass=1.0, margin=0.0):
+    b = ModelBuilder(timestep=0.002, cone=cone, impratio=1.0)
+    b.geom(0, "floor", PLANE, size=(0, 0, 1), friction=(friction, 0.005, 0.0001), condim=condim, margin=margin,
+           quat=(math.cos(tilt / 2), 0, math.sin(tilt / 2), 0))
+    ball = b.body("ball", 0, pos=(0, 0, r))
+    b.joint(ball, "root", FREE)
+    b.geom(ball, "ball", SPHERE, size=(r,), mass=mass, friction=(friction, 0.005, 0.0001), condim=condim)
+    m = b.compile()
+    return m, _copy_task(m)
+
+
+def test_sphere_rests_on_plane_with_weight_as_contact_force():
+    m, task = _ball_on_plane(condim=1)
+    o = ol.Oracle(m, task)
+    q = np.array([0, 0, 0.1, 1, 0, 0, 0.0]); v = np.zeros(6)
+    q, v, _, _, w = o.step(q, v, nstep=1500)
+    r = o.forward(q, v)
+    assert w == 0 and r["ncon"] == 1 and r["nefc"] == 1
+    assert abs(v[2]) < 1e-6 and 0.09 < q[2] < 0.1          # small static penetration
+    assert r["efc_force"][0] == pytest.approx(9.81, rel=1e-4)
+    assert np.abs(r["qacc"]).max() < 1e-4
+
+
+@pytest.mark.parametrize("condim", [3, 6])
+def test_elliptic_friction_slide_vs_stick_on_incline(condim):
+    mu = 0.5
+    # gentle slope: sticks (friction angle atan(0.5)=26.6deg)
+    m, task = _ball_on_plane(tilt=0.2, friction=mu, condim=condim)
+    o = ol.Oracle(m, task)
+    nrm = np.array([math.sin(0.2), 0, math.cos(0.2)])
+    q = np.concatenate([nrm * 0.0995, [1, 0, 0, 0.0]]); v = np.zeros(6)
+    q1, v1, _, _, w = o.step(q, v, nstep=400)
+    r = o.forward(q1, v1)
+    assert w == 0 and r["nefc"] == condim
+    # a sphere on an incline rolls; the contact point must not slip: v_contact ~ 0
+    R = 0.1
+    # world angular velocity = xmat * local; near-identity orientation change handled by using speeds
+    speed = np.linalg.norm(v1[:3]); omega = np.linalg.norm(v1[3:])
+    assert speed > 0.05                                     # it does move (rolls downhill)
+    assert abs(speed - omega * R) / speed < 0.05           # rolling without slipping
+    # steep slope, small mu: slips.  Evaluate the forward dynamics at a sliding, penetrating state.
+    m, task = _ball_on_plane(tilt=1.2, friction=0.1, condim=condim)
+    o = ol.Oracle(m, task)
+    nrm = np.array([math.sin(1.2), 0, math.cos(1.2)])
+    tangent = np.array([math.cos(1.2), 0, -math.sin(1.2)])
+    q = np.concatenate([nrm * 0.0995, [1, 0, 0, 0.0]])
+    v = np.concatenate([0.5 * tangent, np.zeros(3)])
+    r = o.forward(q, v)
+    f = r["efc_force"]
+    assert r["nefc"] == condim and f[0] > 0
+    assert math.hypot(f[1], f[2]) == pytest.approx(0.1 * f[0], rel=1e-6)   # on the cone boundary: |ft| = mu*fn
+    # Newton's law on the ball: m*a_t = m*g*sin(theta) - mu*fn ; m*a_n = fn - m*g*cos(theta)
+    assert r["qacc"][:3] @ tangent == pytest.approx(9.81 * math.sin(1.2) - 0.1 * f[0], rel=1e-6)
+    assert r["qacc"][:3] @ nrm == pytest.approx(f[0] - 9.81 * math.cos(1.2), rel=1e-6)
+
+
+def test_joint_limit_balances_applied_force():
+    m, task, _ = particle(timestep=0.01)
+    o = ol.Oracle(m, task)
+    q, v, _, _, w = o.step([0.28, 0.0], [0.0, 0.0], ctrl=[1.0, 0.0], nstep=600)
+    r = o.forward(q, v, ctrl=[1.0, 0.0])
+    assert w == 0 and r["nefc"] == 1
+    assert 0.29 < q[0] < 0.30 and abs(v[0]) < 1e-6
+    assert r["efc_force"][0] == pytest.approx(1.0, rel=1e-4)    # limit force = motor force (gear 1)
+
+
+def test_frictionloss_stick_and_slip():
+    def build(torque):
+        b = ModelBuilder(timestep=0.002, gravity=(0, 0, 0))
+        arm = b.body("arm", 0)
+        b.joint(arm, "h", HINGE, axis=(0, 0, 1), frictionloss=0.5)
+        b.geom(arm, "g", BOX, size=(0.1, 0.1, 0.1), mass=1.0)
+        b.actuator("a", "h", gear=1.0, ctrlrange=(-2, 2))
+        m = b.compile()
+        return m, _copy_task(m)
+    m, task = build(0)
+    o = ol.Oracle(m, task)
+    I = m["body_inertia"][1][0]
+    r = o.forward([0.0], [0.0], [0.3])
+    assert abs(r["qacc"][0]) < 0.3 / I * 0.2                # below the loss: (almost) stuck
+    q, v, _, _, _ = o.step([0.0], [0.0], ctrl=[0.3], nstep=500)
+    # soft friction: steady creep where -D*(0 - aref) = tau, aref = -B*v, R = (1-d0)/d0 * invweight0
+    R = (1 - 0.9) / 0.9 / I; B = 2 / (0.95 * 0.02)
+    assert v[0] == pytest.approx(0.3 * R / B, rel=1e-6)
+    r = o.forward([0.0], [1.0], [1.5])                      # sliding: tau - f
+    assert r["qacc"][0] == pytest.approx((1.5 - 0.5) / I, rel=1e-6)
+
+
+def test_energy_drift_small_for_undamped_pendulum_chain():
+    b = ModelBuilder(timestep=0.0005)
+    l1 = b.body("l1", 0, pos=(0, 0, 2))
+    b.joint(l1, "j1", HINGE, axis=(0, 1, 0))
+    b.geom(l1, "g1", CAPSULE, size=(0.03, 0), fromto=(0, 0, 0, 0, 0, -0.5))
+    l2 = b.body("l2", l1, pos=(0, 0, -0.5))
+    b.joint(l2, "j2", HINGE, axis=(1, 0, 0))
+    b.geom(l2, "g2", CAPSULE, size=(0.03, 0), fromto=(0, 0, 0, 0, 0.1, -0.4))
+    l3 = b.body("l3", l2, pos=(0, 0.1, -0.4))
+    b.joint(l3, "j3", SLIDE, axis=(0, 0, 1), stiffness=50.0)
+    b.geom(l3, "g3", SPHERE, size=(0.05,))
+    m = b.compile()
+    o = ol.Oracle(m, _copy_task(m))
+
+    def energy(q, v):
+        r = o.forward(q, v)
+        ke = 0.5 * v @ r["qM"] @ v
+        xp, _, xm, _, _ = __import__("mujoco_mpc_amd.modelgen.builder", fromlist=["kinematics"]).kinematics(m, np.asarray(q, float))
+        pe = sum(m["body_mass"][i] * 9.81 * (xp[i] + xm[i] @ m["body_ipos"][i])[2] for i in range(1, m["nbody"]))
+        pe += 0.5 * 50.0 * q[2] ** 2
+        return ke + pe
+    q = np.array([1.0, 0.5, 0.02]); v = np.array([0.3, -0.8, 0.1])
+    e0 = energy(q, v)
+    q1, v1, _, _, w = o.step(q, v, nstep=2000)
+    e1 = energy(q1, v1)
+    assert w == 0 and abs(e1 - e0) / abs(e0) < 2e-3          # semi-implicit Euler: O(h) drift only
+
+
+def test_quadruped_stands_on_four_feet_and_ground_raycast():
+    m, task, d = quadruped()
+    o = ol.Oracle(m, task)
+    q = d["state"][:19].copy(); v = np.zeros(18)
+    q1, v1, _, _, w = o.step(q, v, mocap=d["mocap"], nstep=100)   # 1 s, zero torque, settles on the legs
+    r = o.forward(q1, v1, mocap=d["mocap"])
+    assert w == 0
+    assert r["ncon"] >= 4
+    total_mass = m["body_subtreemass"][m["names"]["body"]["trunk"]]
+    # Gait residual (indices 7..10) uses Ground(): foot z - (ground + 0.02 + step); ground = floor at -0.01
+    feet = [m["names"]["geom"][n] for n in ("FL", "HL", "FR", "HR")]
+    from mujoco_mpc_amd.modelgen.tasks import select_value
+    gz = r["geom_xpos"][feet, 2]
+    step_h = 0.06 * 1.0                                      # amplitude * StepHeight(phase 0) with duty 0
+    assert np.allclose(r["sensordata"][7:11], gz - (-0.01 + 0.02 + step_h), atol=1e-12)
+    # vertical force balance when (nearly) at rest: sum of normal forces ~ weight
+    if np.abs(v1).max() < 1e-2:
+        fn = sum(r["efc_force"][12 + 6 * k] for k in range(4)) if r["ncon"] == 4 else None
+        if fn is not None:
+            assert fn == pytest.approx(total_mass * 9.81, rel=0.05)

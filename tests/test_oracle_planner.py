@@ -1,0 +1,110 @@
+"""Rollout / planner level checks of the oracle against what the reference's tests pin (CPU only)."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from oracle_backend import OracleBackend
+from mujoco_mpc_amd.modelgen import cartpole, particle, quadruped
+from mujoco_mpc_amd.planner import SamplingPlanner, kCubicSpline, kZeroSpline
+
+
+def test_rollout_particle_pd_reaches_goal():
+    """mjpc/test/agent/rollout_test.cc:69-138: PD feedback, horizon 100, dt 0.01."""
+    m, task, _ = particle(timestep=0.01, copystate=True)
+    o = ol.Oracle(m, task)
+    goal = np.array([0.1, 0.1])
+    q = np.zeros(2); v = np.zeros(2); t = 0.0
+    for _ in range(99):
+        u = -10.0 * (q - goal) - 2.5 * v
+        q, v, t, _, w = o.step(q, v, ctrl=u, time=t, nstep=1)
+        assert w == 0
+    assert np.abs(q - goal).sum() < 0.1 and np.abs(v).sum() < 0.1
+
+
+def test_rollout_residual_is_aligned_with_state():
+    """rollout_test.cc:141-145: with a copy-state residual, ||states - residual||_1 < 1e-5 over 400 entries, i.e.
+    residual[t] is evaluated at state[t] (before integration) and the terminal mj_forward fills row H-1."""
+    m, task, d = particle(timestep=0.01, copystate=True)
+    o = ol.Oracle(m, task)
+    H = 100
+    kt = np.linspace(0, 0.99, 6); kv = np.random.default_rng(0).uniform(-1, 1, (6, 2))
+    r = o.plan(np.zeros(4), d["mocap"], 0.0, kt, kv, kCubicSpline, 3, H, sigma=(0.3, 0.0), seed=3)
+    for i in range(3):
+        assert np.abs(r["states"][i] - r["residual"][i]).sum() < 1e-5
+        assert np.array_equal(r["states"][i], r["residual"][i])
+        assert np.array_equal(r["actions"][i, H - 1], r["actions"][i, H - 2])     # trajectory.cc:190-195
+        assert np.allclose(np.diff(r["times"][i]), 0.01, atol=1e-12)
+    assert np.array_equal(r["knots"][0], kv)                                     # candidate 0 is un-noised
+    assert not np.array_equal(r["knots"][1], kv)
+    assert np.all(np.abs(r["knots"]) <= 1.0)                                     # clamped to ctrlrange
+    assert r["trace"].shape == (3, H, 3)
+    assert np.allclose(r["trace"][0, :, :2], r["states"][0, :, :2])              # trace0 = tip site = particle pos
+
+
+def test_returns_are_mean_of_costs_and_winner_is_first_min():
+    m, task, d = cartpole()
+    o = ol.Oracle(m, task)
+    kt = np.linspace(0, 0.49, 10); kv = np.zeros((10, 1))
+    r = o.plan(d["state"], None, 0.0, kt, kv, kCubicSpline, 16, 50, sigma=(0.5, 0.0), seed=11, nthreads=4)
+    for i in range(16):
+        tot = 0.0
+        for t in range(50):
+            c, _ = o.cost(r["residual"][i, t]); assert c == r["costs"][i, t]; tot += c
+        assert r["returns"][i] == tot / 50
+    assert r["winner"] == int(np.argmin(r["returns"]))
+    r1 = o.plan(d["state"], None, 0.0, kt, kv, kCubicSpline, 16, 50, sigma=(0.5, 0.0), seed=11, nthreads=1)
+    assert np.array_equal(r["returns"], r1["returns"])                          # scheduling-independent
+    # sharded evaluation == the corresponding slice of the global one
+    r2 = o.plan(d["state"], None, 0.0, kt, kv, kCubicSpline, 16, 50, sigma=(0.5, 0.0), seed=11, candidate_offset=8, num_local=8)
+    assert np.array_equal(r2["returns"], r["returns"][8:])
+    assert r2["winner"] == 8 + int(np.argmin(r["returns"][8:]))
+
+
+def test_injected_noise_equals_philox_noise():
+    m, task, d = cartpole()
+    o = ol.Oracle(m, task)
+    kt = np.linspace(0, 0.49, 10); kv = np.zeros((10, 1))
+    eps, sel = ol.noise(7, 2, 0, 8, 10, 1)
+    a = o.plan(d["state"], None, 0.0, kt, kv, kCubicSpline, 8, 30, sigma=(0.5, 0.0), seed=7, stream=2)
+    b = o.plan(d["state"], None, 0.0, kt, kv, kCubicSpline, 8, 30, sigma=(0.5, 0.0), noise_eps=eps, noise_sel=sel)
+    assert np.array_equal(a["returns"], b["returns"]) and np.array_equal(a["knots"], b["knots"])
+    scale = 0.5 * 2.0
+    expect = np.clip(kv[None] + scale * 0.5 * eps, -1, 1); expect[0] = kv
+    assert np.allclose(a["knots"], expect, atol=1e-15)
+
+
+def test_sampling_planner_particle_converges():
+    """mjpc/test/sampling_planner/sampling_planner_test.cc:40-108 (1000 iterations, 1 thread, N=10 default, timestep 0.1, H=26)."""
+    m, task, d = particle(timestep=0.1)
+    backend = OracleBackend(m, task)
+    planner = SamplingPlanner(backend)
+    planner.Initialize(m, task, dict(sampling_spline_points=11, sampling_exploration=0.01))
+    planner.Allocate()
+    planner.Reset(11)
+    planner.noise_exploration[0] = 0.01
+    planner.SetState(np.zeros(4), d["mocap"], None, 0.0)
+    H = 26
+    for _ in range(1000):
+        planner.OptimizePolicy(H)
+    best = planner.BestTrajectory()
+    final = best.states[H - 1]
+    assert np.abs(final[:2] - d["mocap"][:2]).sum() < 0.1        # sampling_planner_test.cc:89-98
+    assert np.abs(final[2:]).sum() < 0.1
+    assert np.all(best.actions >= -1.0) and np.all(best.actions <= 1.0)   # :101-108
+    # use_previous returns the pre-update policy (agent_test.cc:204-266)
+    before = planner.policy.plan.copy()
+    planner.OptimizePolicy(H)
+    for t in (0.0, 0.35, 1.2):
+        prev = planner.ActionFromPolicy(t, use_previous=True)
+        expect = np.clip(before.Sample(t), -1, 1)
+        assert np.array_equal(prev, expect)
+
+
+def test_quadruped_plan_smoke_and_improvement():
+    m, task, d = quadruped()
+    o = ol.Oracle(m, task)
+    kt = np.array([0.0, 0.175, 0.35]); kv = np.zeros((3, 12))
+    r = o.plan(d["state"], d["mocap"], 0.0, kt, kv, kCubicSpline, 12, 36, sigma=(0.04, 0.0), seed=5, nthreads=4)
+    assert r["failure"].sum() == 0 and np.all(np.isfinite(r["returns"]))
+    assert r["returns"][r["winner"]] <= r["returns"][0]
+    assert r["residual"].shape == (12, 36, 42)

@@ -194,6 +194,8 @@ def load_engine():
     lib.mjpc_hip_get_candidate.argtypes = [C.c_void_p, C.c_int, C.POINTER(MjpcHipPlanOutput)]
     lib.mjpc_hip_kernel_time.argtypes = [C.c_void_p, c_double_p, c_double_p]
     lib.mjpc_hip_device_ptrs.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+    lib.mjpc_hip_debug_fetch_all.argtypes = [C.c_void_p] + [c_double_p] * 7 + [c_int_p]
+    lib.mjpc_hip_lds_bytes.argtypes = [C.c_void_p]
     lib.mjpc_hip_last_error.restype = C.c_char_p
     lib.mjpc_hip_version.restype = C.c_int
     _engine = lib

@@ -1,0 +1,1565 @@
+// core.h — one candidate rollout, written SPMD over the lanes of ONE wavefront.
+//
+// Replaces (for every candidate i in parallel) what a ThreadPool worker runs in the reference:
+//   mjpc/planners/sampling/planner.cc:355-376   copy nominal policy, AddNoiseToPolicy, Rollout
+//   mjpc/trajectory.cc:100-210                  NoisyRollout: policy -> ctrl -> mj_step -> record
+//   mjpc/trajectory.cc:312-326                  UpdateReturn
+// mj_step / mj_forward (MuJoCo 3.1.4, third-party) are re-designed here as lane-parallel phases over
+// LDS-resident state: tree-level kinematics, subtree reductions, pairwise mass-matrix entries,
+// scan-compacted collision + constraint rows, a primal Newton solver with wave reductions in the
+// exact line search, and Euler with implicit joint damping.
+#pragma once
+#include "dmath.h"
+#include "model.h"
+
+struct Ctx {
+  const DevModel *M;
+  const KParams *K;
+  double *qpos, *qvel, *ctrl, *qacc, *qacc_ws, *qacc_smooth, *qfrc_smooth, *qfrc_bias, *qfrc_constraint, *actuator_force;
+  double *mocap_pos, *mocap_quat;
+  double *xpos, *xquat, *xmat, *xipos, *ximat, *xanchor, *xaxis, *geom_xpos, *geom_xmat, *site_xpos;
+  double *subtree_com, *cinert, *crb, *cdof, *cvel, *cdof_dot, *cacc, *cfrc, *cfrc_sub, *subtree_linvel, *bodytmp;
+  double *qM, *qL, *qH, *Linv, *Hinv;
+  double *efc_J, *efc_D, *efc_R, *efc_aref, *efc_force, *efc_jar, *efc_jv, *efc_floss, *efc_pos, *efc_margin, *efc_diag;
+  double *contact;
+  double *Ma, *grad, *Mgrad, *search, *Mv, *vtmp;
+  double *knot_times, *knot_values, *residual, *terms, *red;
+  int *efc_type, *efc_id, *efc_state, *con_i, *active, *misc;
+  double time;
+  int ncon, nefc, warning, solver_iter;
+};
+
+DEV void ctx_init(Ctx &c, const KParams *K, double *base) {
+  const Lay &L = K->L;
+  c.M = &K->M; c.K = K;
+#define P_(f) c.f = base + L.f
+  P_(qpos); P_(qvel); P_(ctrl); P_(qacc); P_(qacc_ws); P_(qacc_smooth); P_(qfrc_smooth); P_(qfrc_bias);
+  P_(qfrc_constraint); P_(actuator_force); P_(mocap_pos); P_(mocap_quat);
+  P_(xpos); P_(xquat); P_(xmat); P_(xipos); P_(ximat); P_(xanchor); P_(xaxis); P_(geom_xpos); P_(geom_xmat); P_(site_xpos);
+  P_(subtree_com); P_(cinert); P_(crb); P_(cdof); P_(cvel); P_(cdof_dot); P_(cacc); P_(cfrc); P_(cfrc_sub);
+  P_(subtree_linvel); P_(bodytmp); P_(qM); P_(qL); P_(qH); P_(Linv); P_(Hinv);
+  P_(efc_J); P_(efc_D); P_(efc_R); P_(efc_aref); P_(efc_force); P_(efc_jar); P_(efc_jv); P_(efc_floss);
+  P_(efc_pos); P_(efc_margin); P_(efc_diag); P_(contact);
+  P_(Ma); P_(grad); P_(Mgrad); P_(search); P_(Mv); P_(vtmp);
+  P_(knot_times); P_(knot_values); P_(residual); P_(terms); P_(red);
+#undef P_
+  int *ib = (int *)(base + L.ints);
+  c.efc_type = ib + L.i_efc_type; c.efc_id = ib + L.i_efc_id; c.efc_state = ib + L.i_efc_state;
+  c.con_i = ib + L.i_con; c.active = ib + L.i_active; c.misc = ib + L.i_misc;
+  c.time = 0; c.ncon = 0; c.nefc = 0; c.warning = 0; c.solver_iter = 0;
+}
+
+// ======================================================================================
+// spline policy: TimeSpline::Sample (mjpc/spline/spline.cc:103-156,240-277), one component
+// ======================================================================================
+DEV double spline_slope(const double *times, const double *values, int P, int dim, int node, int k) {
+  if (node == 0) return (values[dim + k] - values[k]) / (times[1] - times[0]);
+  if (node == P - 1) return (values[node * dim + k] - values[(node - 1) * dim + k]) / (times[node] - times[node - 1]);
+  return 0.5 * (values[(node + 1) * dim + k] - values[node * dim + k]) / (times[node + 1] - times[node]) +
+         0.5 * (values[node * dim + k] - values[(node - 1) * dim + k]) / (times[node] - times[node - 1]);
+}
+DEV double spline_sample(const double *times, const double *values, int P, int dim, int interp, double time, int k) {
+  if (P == 0) return 0.0;
+  int upper = 0;
+  while (upper < P && !(time < times[upper])) upper++;
+  if (upper == P) return values[(P - 1) * dim + k];
+  if (upper == 0) return values[k];
+  int lower = upper - 1;
+  double lo = times[lower], up = times[upper];
+  double t = (time - lo) / (up - lo);
+  if (interp == 0) return values[lower * dim + k];
+  if (interp == 1) return values[lower * dim + k] * (1 - t) + values[upper * dim + k] * t;
+  double c0 = 2.0 * t*t*t - 3.0 * t*t + 1.0;
+  double c1 = (t*t*t - 2.0 * t*t + t) * (up - lo);
+  double c2 = -2.0 * t*t*t + 3 * t*t;
+  double c3 = (t*t*t - t*t) * (up - lo);
+  double p0 = values[lower * dim + k], p1 = values[upper * dim + k];
+  double m0 = spline_slope(times, values, P, dim, lower, k);
+  double m1 = spline_slope(times, values, P, dim, upper, k);
+  return c0 * p0 + c1 * m0 + c2 * p1 + c3 * m1;
+}
+
+// ======================================================================================
+// position stage
+// ======================================================================================
+DEV void kin_body(Ctx &c, int i) {
+  const DevModel &M = *c.M;
+  double xpos[3], xquat[4];
+  int pid = M.body_parentid[i];
+  int jntnum = M.body_jntnum[i], jntadr = M.body_jntadr[i];
+  int mid = M.body_mocapid[i];
+  if (mid >= 0) {
+    d_copy3(xpos, c.mocap_pos + 3 * mid);
+    d_copy4(xquat, c.mocap_quat + 4 * mid);
+    d_normalize4(xquat);
+  } else if (jntnum == 1 && M.jnt_type[jntadr] == 0) {
+    int qa = M.jnt_qposadr[jntadr];
+    d_normalize4(c.qpos + qa + 3);
+    d_copy3(xpos, c.qpos + qa);
+    d_copy4(xquat, c.qpos + qa + 3);
+    d_copy3(c.xanchor + 3 * jntadr, xpos);
+    d_copy3(c.xaxis + 3 * jntadr, M.jnt_axis + 3 * jntadr);
+  } else {
+    if (pid) {
+      d_mulmatvec3(xpos, c.xmat + 9 * pid, M.body_pos + 3 * i);
+      d_add3(xpos, xpos, c.xpos + 3 * pid);
+      d_mulquat(xquat, c.xquat + 4 * pid, M.body_quat + 4 * i);
+    } else {
+      d_copy3(xpos, M.body_pos + 3 * i);
+      d_copy4(xquat, M.body_quat + 4 * i);
+    }
+    for (int j = jntadr; j < jntadr + jntnum; j++) {
+      int qa = M.jnt_qposadr[j], type = M.jnt_type[j];
+      double vec[3], ax[3], jp[3];
+      d_copy3(ax, M.jnt_axis + 3 * j); d_copy3(jp, M.jnt_pos + 3 * j);
+      d_rotvecquat(c.xaxis + 3 * j, ax, xquat);
+      d_rotvecquat(vec, jp, xquat);
+      d_add3(c.xanchor + 3 * j, vec, xpos);
+      if (type == 2) {
+        d_addtoscl3(xpos, c.xaxis + 3 * j, c.qpos[qa] - M.qpos0[qa]);
+      } else {
+        double qloc[4], t[4];
+        if (type == 1) { d_normalize4(c.qpos + qa); d_copy4(qloc, c.qpos + qa); }
+        else d_axisangle2quat(qloc, ax, c.qpos[qa] - M.qpos0[qa]);
+        d_mulquat(t, xquat, qloc);
+        d_copy4(xquat, t);
+        d_rotvecquat(vec, jp, xquat);
+        d_sub3(xpos, c.xanchor + 3 * j, vec);
+      }
+    }
+  }
+  d_normalize4(xquat);
+  d_copy3(c.xpos + 3 * i, xpos);
+  d_copy4(c.xquat + 4 * i, xquat);
+  double xm[9];
+  d_quat2mat(xm, xquat);
+  for (int k = 0; k < 9; k++) c.xmat[9 * i + k] = xm[k];
+  double v[3], q[4], ip[3], iq[4];
+  d_copy3(ip, M.body_ipos + 3 * i); d_copy4(iq, M.body_iquat + 4 * i);
+  d_mulmatvec3(v, xm, ip);
+  d_add3(c.xipos + 3 * i, v, xpos);
+  d_mulquat(q, xquat, iq);
+  d_quat2mat(xm, q);
+  for (int k = 0; k < 9; k++) c.ximat[9 * i + k] = xm[k];
+}
+
+DEV void kinematics(Ctx &c) {
+  const DevModel &M = *c.M;
+  for (int l = 0; l < M.nlevel; l++) {
+    int a = M.level_adr[l], n = M.level_adr[l + 1] - a;
+    PFOR(k, n) kin_body(c, M.level_body[a + k]);
+    SYNC();
+  }
+  PFOR(g, M.ngeom) {
+    int b = M.geom_bodyid[g];
+    double v[3], q[4], gp[3], gq[4], xm[9];
+    d_copy3(gp, M.geom_pos + 3 * g); d_copy4(gq, M.geom_quat + 4 * g);
+    d_mulmatvec3(v, c.xmat + 9 * b, gp);
+    d_add3(c.geom_xpos + 3 * g, v, c.xpos + 3 * b);
+    d_mulquat(q, c.xquat + 4 * b, gq);
+    d_quat2mat(xm, q);
+    for (int k = 0; k < 9; k++) c.geom_xmat[9 * g + k] = xm[k];
+  }
+  PFOR(s, M.nsite) {
+    int b = M.site_bodyid[s];
+    double v[3], sp[3];
+    d_copy3(sp, M.site_pos + 3 * s);
+    d_mulmatvec3(v, c.xmat + 9 * b, sp);
+    d_add3(c.site_xpos + 3 * s, v, c.xpos + 3 * b);
+  }
+  SYNC();
+}
+
+DEV void com_pos(Ctx &c) {
+  const DevModel &M = *c.M;
+  PFOR(b, M.nbody) {
+    double s[3] = {0, 0, 0};
+    for (int k = M.subtree_adr[b]; k < M.subtree_adr[b + 1]; k++) {
+      int cb = M.subtree_list[k];
+      d_addtoscl3(s, c.xipos + 3 * cb, M.body_mass[cb]);
+    }
+    double sm = M.body_subtreemass[b];
+    if (sm < D_MINVAL) d_copy3(c.subtree_com + 3 * b, c.xipos + 3 * b);
+    else d_scl3(c.subtree_com + 3 * b, s, 1.0 / sm);
+  }
+  SYNC();
+  PFOR(b, M.nbody) {
+    if (b == 0) { for (int k = 0; k < 10; k++) c.cinert[k] = 0; continue; }
+    double off[3], ine[3], r[10];
+    d_sub3(off, c.xipos + 3 * b, c.subtree_com + 3 * M.body_rootid[b]);
+    d_copy3(ine, M.body_inertia + 3 * b);
+    d_inertcom(r, ine, c.ximat + 9 * b, off, M.body_mass[b]);
+    for (int k = 0; k < 10; k++) c.cinert[10 * b + k] = r[k];
+  }
+  PFOR(j, M.njnt) {
+    int b = M.jnt_bodyid[j], da = M.jnt_dofadr[j], type = M.jnt_type[j];
+    double off[3];
+    d_sub3(off, c.subtree_com + 3 * M.body_rootid[b], c.xanchor + 3 * j);
+    int skip = 0;
+    if (type == 0) {
+      for (int k = 0; k < 18; k++) c.cdof[6 * da + k] = 0;
+      for (int k = 0; k < 3; k++) c.cdof[6 * (da + k) + 3 + k] = 1;
+      skip = 3;
+    }
+    if (type == 0 || type == 1) {
+      const double *xm = c.xmat + 9 * b;
+      for (int k = 0; k < 3; k++) {
+        double ax[3] = {xm[k], xm[k + 3], xm[k + 6]}, cr[3];
+        double *cd = c.cdof + 6 * (da + k + skip);
+        d_cross(cr, ax, off);
+        d_copy3(cd, ax); d_copy3(cd + 3, cr);
+      }
+    } else if (type == 2) {
+      c.cdof[6 * da] = 0; c.cdof[6 * da + 1] = 0; c.cdof[6 * da + 2] = 0;
+      d_copy3(c.cdof + 6 * da + 3, c.xaxis + 3 * j);
+    } else {
+      double cr[3];
+      d_cross(cr, c.xaxis + 3 * j, off);
+      d_copy3(c.cdof + 6 * da, c.xaxis + 3 * j);
+      d_copy3(c.cdof + 6 * da + 3, cr);
+    }
+  }
+  SYNC();
+}
+
+// dense Cholesky A = L L^T in place (lower triangle), row stride nvp; Linv[j] = 1/L[j][j]
+DEV void chol_factor(Ctx &c, double *A, double *Linv, int n, int nvp) {
+  for (int j = 0; j < n; j++) {
+    SYNC();
+    PFOR(ii, n - j) {
+      int i = j + ii;
+      double s = A[i * nvp + j];
+      for (int k = 0; k < j; k++) s -= A[i * nvp + k] * A[j * nvp + k];
+      c.vtmp[i] = s;
+    }
+    SYNC();
+    double t = c.vtmp[j];
+    if (t < D_MINVAL) t = D_MINVAL;
+    double dj = sqrt(t), inv = 1.0 / dj;
+    PFOR(ii, n - j) {
+      int i = j + ii;
+      A[i * nvp + j] = (i == j) ? dj : c.vtmp[i] * inv;
+    }
+    if (LANE == 0) Linv[j] = inv;
+  }
+  SYNC();
+}
+// x <- (L L^T)^-1 x, x in LDS
+DEV void chol_solve(Ctx &c, const double *L, const double *Linv, double *x, int n, int nvp) {
+  for (int i = 0; i < n; i++) {
+    SYNC();
+    double xi = x[i] * Linv[i];
+    SYNC();
+    PFOR(kk, n - i - 1) { int k = i + 1 + kk; x[k] -= L[k * nvp + i] * xi; }
+    if (LANE == 0) x[i] = xi;
+  }
+  for (int i = n - 1; i >= 0; i--) {
+    SYNC();
+    double xi = x[i] * Linv[i];
+    SYNC();
+    PFOR(k, i) x[k] -= L[i * nvp + k] * xi;
+    if (LANE == 0) x[i] = xi;
+  }
+  SYNC();
+}
+
+DEV void crb_and_factor(Ctx &c) {
+  const DevModel &M = *c.M;
+  int nv = M.nv, nvp = M.nvp;
+  PFOR(e, M.nbody * 10) {
+    int b = e / 10, k = e - 10 * b;
+    double s = 0;
+    if (b > 0) for (int q = M.subtree_adr[b]; q < M.subtree_adr[b + 1]; q++) s += c.cinert[10 * M.subtree_list[q] + k];
+    c.crb[e] = s;
+  }
+  SYNC();
+  PFOR(p, M.nmpair) {
+    int i = M.mpair_i[p], j = M.mpair_j[p];
+    double buf[6];
+    d_mulinertvec(buf, c.crb + 10 * M.dof_bodyid[i], c.cdof + 6 * i);
+    const double *cj = c.cdof + 6 * j;
+    double v = cj[0]*buf[0] + cj[1]*buf[1] + cj[2]*buf[2] + cj[3]*buf[3] + cj[4]*buf[4] + cj[5]*buf[5];
+    if (i == j) v += M.dof_armature[i];
+    c.qM[i * nvp + j] = v; c.qM[j * nvp + i] = v;
+  }
+  SYNC();
+  PFOR(e, nv * nvp) c.qL[e] = c.qM[e];
+  chol_factor(c, c.qL, c.Linv, nv, nvp);
+}
+
+// ======================================================================================
+// collision: bounding-sphere filter -> ordered compaction -> analytic narrow phase
+// ======================================================================================
+struct NPCon { double dist, pos[3], frame[6]; };
+
+DEV int np_sphere_sphere(NPCon *con, double margin, const double *p1, double r1, const double *p2, double r2) {
+  double dif[3];
+  d_sub3(dif, p2, p1);
+  double cdist = d_norm3(dif), dist = cdist - r1 - r2;
+  if (dist > margin) return 0;
+  for (int k = 0; k < 6; k++) con->frame[k] = 0;
+  if (cdist < D_MINVAL) con->frame[0] = 1; else d_scl3(con->frame, dif, 1.0 / cdist);
+  con->dist = dist;
+  d_addscl3(con->pos, p1, con->frame, r1 + 0.5 * dist);
+  return 1;
+}
+DEV int np_plane_sphere(NPCon *con, double margin, const double *pp, const double *n, const double *cen, double r) {
+  double dif[3];
+  d_sub3(dif, cen, pp);
+  double dist = d_dot3(dif, n) - r;
+  if (dist > margin) return 0;
+  for (int k = 0; k < 6; k++) con->frame[k] = 0;
+  d_copy3(con->frame, n);
+  con->dist = dist;
+  d_addscl3(con->pos, cen, n, -(r + 0.5 * dist));
+  return 1;
+}
+DEV int np_plane_capsule(NPCon *con, double margin, const double *pp, const double *pm, const double *cp, const double *cm, const double *size) {
+  double n[3] = {pm[2], pm[5], pm[8]}, axis[3] = {cm[2], cm[5], cm[8]}, seg[3], e[3];
+  int cnt = 0;
+  d_scl3(seg, axis, size[1]);
+  d_add3(e, cp, seg);
+  if (np_plane_sphere(con + cnt, margin, pp, n, e, size[0])) { d_copy3(con[cnt].frame + 3, axis); cnt++; }
+  d_sub3(e, cp, seg);
+  if (np_plane_sphere(con + cnt, margin, pp, n, e, size[0])) { d_copy3(con[cnt].frame + 3, axis); cnt++; }
+  return cnt;
+}
+DEV int np_plane_box(NPCon *con, double margin, const double *pp, const double *pm, const double *bp, const double *bm, const double *size) {
+  double n[3] = {pm[2], pm[5], pm[8]}, dif[3];
+  d_sub3(dif, bp, pp);
+  double dist = d_dot3(dif, n);
+  int cnt = 0;
+  for (int i = 0; i < 8; i++) {
+    double vec[3] = {(i & 1) ? size[0] : -size[0], (i & 2) ? size[1] : -size[1], (i & 4) ? size[2] : -size[2]};
+    double corner[3];
+    d_mulmatvec3(corner, bm, vec);
+    double ldist = d_dot3(n, corner);
+    if (dist + ldist > margin || ldist > 0) continue;
+    if (cnt >= 4) break;
+    NPCon *q = con + cnt;
+    q->dist = dist + ldist;
+    for (int k = 0; k < 6; k++) q->frame[k] = 0;
+    d_copy3(q->frame, n);
+    d_add3(corner, corner, bp);
+    d_addscl3(q->pos, corner, n, -0.5 * q->dist);
+    cnt++;
+    if (cnt >= 4) break;
+  }
+  return cnt;
+}
+DEV int np_plane_cylinder(NPCon *con, double margin, const double *pp, const double *pm, const double *cp, const double *cm, const double *size) {
+  double n[3] = {pm[2], pm[5], pm[8]}, axis[3] = {cm[2], cm[5], cm[8]};
+  double prjaxis = d_dot3(n, axis);
+  if (prjaxis > 0) { d_scl3(axis, axis, -1); prjaxis = -prjaxis; }
+  double vec[3];
+  d_sub3(vec, cp, pp);
+  double dist0 = d_dot3(vec, n);
+  d_scl3(vec, axis, prjaxis); d_sub3(vec, vec, n);
+  double len2 = d_dot3(vec, vec);
+  if (len2 >= D_MINVAL) d_scl3(vec, vec, size[0] / sqrt(len2));
+  else { vec[0] = cm[0] * size[0]; vec[1] = cm[3] * size[0]; vec[2] = cm[6] * size[0]; }
+  double prjvec = d_dot3(vec, n);
+  d_scl3(axis, axis, size[1]); prjaxis *= size[1];
+  int cnt = 0;
+  if (dist0 + prjaxis + prjvec <= margin) {
+    NPCon *q = con + cnt++;
+    q->dist = dist0 + prjaxis + prjvec;
+    d_add3(q->pos, cp, vec); d_add3(q->pos, q->pos, axis); d_addtoscl3(q->pos, n, -0.5 * q->dist);
+    for (int k = 0; k < 6; k++) q->frame[k] = 0;
+    d_copy3(q->frame, n);
+  } else return 0;
+  if (dist0 - prjaxis + prjvec <= margin) {
+    NPCon *q = con + cnt++;
+    q->dist = dist0 - prjaxis + prjvec;
+    d_add3(q->pos, cp, vec); d_sub3(q->pos, q->pos, axis); d_addtoscl3(q->pos, n, -0.5 * q->dist);
+    for (int k = 0; k < 6; k++) q->frame[k] = 0;
+    d_copy3(q->frame, n);
+  }
+  double prjvec1 = -0.5 * prjvec;
+  if (dist0 + prjaxis + prjvec1 <= margin) {
+    double vec1[3];
+    d_cross(vec1, vec, axis);
+    d_normalize3(vec1);
+    d_scl3(vec1, vec1, size[0] * sqrt(3.0) / 2);
+    for (int s = -1; s <= 1; s += 2) {
+      NPCon *q = con + cnt++;
+      q->dist = dist0 + prjaxis + prjvec1;
+      d_add3(q->pos, cp, axis); d_addtoscl3(q->pos, vec, -0.5); d_addtoscl3(q->pos, vec1, (double)s);
+      d_addtoscl3(q->pos, n, -0.5 * q->dist);
+      for (int k = 0; k < 6; k++) q->frame[k] = 0;
+      d_copy3(q->frame, n);
+    }
+  }
+  return cnt;
+}
+DEV int np_sphere_capsule(NPCon *con, double margin, const double *sp, double sr, const double *cp, const double *cm, const double *csize) {
+  double axis[3] = {cm[2], cm[5], cm[8]}, vec[3], pt[3];
+  d_sub3(vec, sp, cp);
+  double x = d_clip(d_dot3(axis, vec), -csize[1], csize[1]);
+  d_addscl3(pt, cp, axis, x);
+  return np_sphere_sphere(con, margin, sp, sr, pt, csize[0]);
+}
+DEV int np_capsule_capsule(NPCon *con, double margin, const double *p1, const double *m1, const double *s1,
+                           const double *p2, const double *m2, const double *s2) {
+  double a1[3] = {m1[2], m1[5], m1[8]}, a2[3] = {m2[2], m2[5], m2[8]}, dif[3];
+  d_sub3(dif, p1, p2);
+  double len1 = s1[1], len2 = s2[1];
+  double ma = d_dot3(a1, a1), mb = -d_dot3(a1, a2), mc = d_dot3(a2, a2);
+  double u = -d_dot3(a1, dif), v = d_dot3(a2, dif);
+  double det = ma * mc - mb * mb;
+  if (fabs(det) >= D_MINVAL) {
+    double x1 = (mc * u - mb * v) / det, x2 = (ma * v - mb * u) / det;
+    if (x1 > len1) { x1 = len1; x2 = (v - mb * len1) / mc; }
+    else if (x1 < -len1) { x1 = -len1; x2 = (v + mb * len1) / mc; }
+    if (x2 > len2) { x2 = len2; x1 = d_clip((u - mb * len2) / ma, -len1, len1); }
+    else if (x2 < -len2) { x2 = -len2; x1 = d_clip((u + mb * len2) / ma, -len1, len1); }
+    double v1[3], v2[3];
+    d_addscl3(v1, p1, a1, x1); d_addscl3(v2, p2, a2, x2);
+    return np_sphere_sphere(con, margin, v1, s1[0], v2, s2[0]);
+  }
+  int cnt = 0;
+  for (int s = -1; s <= 1 && cnt < 2; s += 2) {
+    double e[3], w[3], pt[3];
+    d_addscl3(e, p1, a1, s * len1);
+    d_sub3(w, e, p2);
+    double x = d_clip(d_dot3(a2, w), -len2, len2);
+    d_addscl3(pt, p2, a2, x);
+    cnt += np_sphere_sphere(con + cnt, margin, e, s1[0], pt, s2[0]);
+  }
+  return cnt;
+}
+DEV int np_sphere_box(NPCon *con, double margin, const double *sp, double sr, const double *bp, const double *bm, const double *bs) {
+  double dif[3], cc[3], clamped[3];
+  d_sub3(dif, sp, bp);
+  d_mulmattvec3(cc, bm, dif);
+  int inside = 1;
+  for (int i = 0; i < 3; i++) { clamped[i] = d_clip(cc[i], -bs[i], bs[i]); if (clamped[i] != cc[i]) inside = 0; }
+  double nloc[3], dist;
+  if (!inside) {
+    double dd[3]; d_sub3(dd, cc, clamped);
+    double len = d_norm3(dd);
+    dist = len - sr;
+    if (dist > margin) return 0;
+    d_scl3(nloc, dd, 1.0 / len);
+  } else {
+    int k = 0; double best = 1e300;
+    for (int i = 0; i < 3; i++) { double pen = bs[i] - fabs(cc[i]); if (pen < best) { best = pen; k = i; } }
+    nloc[0] = nloc[1] = nloc[2] = 0;
+    double sgn = cc[k] >= 0 ? 1.0 : -1.0;
+    if (k == 0) nloc[0] = sgn; else if (k == 1) nloc[1] = sgn; else nloc[2] = sgn;
+    d_copy3(clamped, cc);
+    if (k == 0) clamped[0] = sgn * bs[0]; else if (k == 1) clamped[1] = sgn * bs[1]; else clamped[2] = sgn * bs[2];
+    dist = -best - sr;
+  }
+  double nw[3], surf[3];
+  d_mulmatvec3(nw, bm, nloc);
+  for (int k = 0; k < 6; k++) con->frame[k] = 0;
+  d_scl3(con->frame, nw, -1);
+  con->dist = dist;
+  d_mulmatvec3(surf, bm, clamped); d_add3(surf, surf, bp);
+  d_addscl3(con->pos, surf, nw, 0.5 * dist);
+  return 1;
+}
+
+DEV int narrow_phase(Ctx &c, int g1, int g2, double margin, NPCon *con) {
+  const DevModel &M = *c.M;
+  int t1 = M.geom_type[g1], t2 = M.geom_type[g2];
+  double p1[3], p2[3], m1[9], m2[9], s1[3], s2[3];
+  d_copy3(p1, c.geom_xpos + 3 * g1); d_copy3(p2, c.geom_xpos + 3 * g2);
+  for (int k = 0; k < 9; k++) { m1[k] = c.geom_xmat[9 * g1 + k]; m2[k] = c.geom_xmat[9 * g2 + k]; }
+  d_copy3(s1, M.geom_size + 3 * g1); d_copy3(s2, M.geom_size + 3 * g2);
+  if (t1 == 0) {
+    double n[3] = {m1[2], m1[5], m1[8]};
+    if (t2 == 2) return np_plane_sphere(con, margin, p1, n, p2, s2[0]);
+    if (t2 == 3) return np_plane_capsule(con, margin, p1, m1, p2, m2, s2);
+    if (t2 == 6) return np_plane_box(con, margin, p1, m1, p2, m2, s2);
+    if (t2 == 5) return np_plane_cylinder(con, margin, p1, m1, p2, m2, s2);
+  } else if (t1 == 2) {
+    if (t2 == 2) return np_sphere_sphere(con, margin, p1, s1[0], p2, s2[0]);
+    if (t2 == 3) return np_sphere_capsule(con, margin, p1, s1[0], p2, m2, s2);
+    if (t2 == 6) return np_sphere_box(con, margin, p1, s1[0], p2, m2, s2);
+  } else if (t1 == 3 && t2 == 3) {
+    return np_capsule_capsule(con, margin, p1, m1, s1, p2, m2, s2);
+  }
+  return 0;   // unsupported pair types produce no contact (known gap)
+}
+
+DEV void contact_param(const DevModel &M, int g1, int g2, double *cc, int *dim) {
+  int p1 = M.geom_priority[g1], p2 = M.geom_priority[g2];
+  double fri[3];
+  if (p1 != p2) {
+    int g = p1 > p2 ? g1 : g2;
+    *dim = M.geom_condim[g];
+    for (int i = 0; i < 2; i++) cc[CON_SOLREF + i] = M.geom_solref[2 * g + i];
+    for (int i = 0; i < 5; i++) cc[CON_SOLIMP + i] = M.geom_solimp[5 * g + i];
+    d_copy3(fri, M.geom_friction + 3 * g);
+  } else {
+    int d1 = M.geom_condim[g1], d2 = M.geom_condim[g2];
+    *dim = d1 > d2 ? d1 : d2;
+    double s1 = M.geom_solmix[g1], s2 = M.geom_solmix[g2], mix;
+    if (s1 >= D_MINVAL && s2 >= D_MINVAL) mix = s1 / (s1 + s2);
+    else if (s1 < D_MINVAL && s2 < D_MINVAL) mix = 0.5;
+    else if (s1 < D_MINVAL) mix = 0.0;
+    else mix = 1.0;
+    double r10 = M.geom_solref[2 * g1], r20 = M.geom_solref[2 * g2];
+    for (int i = 0; i < 2; i++) {
+      double a = M.geom_solref[2 * g1 + i], b = M.geom_solref[2 * g2 + i];
+      cc[CON_SOLREF + i] = (r10 > 0 && r20 > 0) ? mix * a + (1 - mix) * b : fmin(a, b);
+    }
+    for (int i = 0; i < 5; i++) cc[CON_SOLIMP + i] = mix * M.geom_solimp[5 * g1 + i] + (1 - mix) * M.geom_solimp[5 * g2 + i];
+    for (int i = 0; i < 3; i++) fri[i] = fmax(M.geom_friction[3 * g1 + i], M.geom_friction[3 * g2 + i]);
+  }
+  cc[CON_FRICTION] = fri[0]; cc[CON_FRICTION + 1] = fri[0]; cc[CON_FRICTION + 2] = fri[1];
+  cc[CON_FRICTION + 3] = fri[2]; cc[CON_FRICTION + 4] = fri[2];
+}
+
+DEV void collision(Ctx &c) {
+  const DevModel &M = *c.M;
+  c.ncon = 0;
+  if (M.disableflags & (1 << 4)) return;
+  // (1) broad phase: ordered compaction of the pairs whose bounding volumes overlap
+  int nactive = 0;
+  for (int base = 0; base < M.npair; base += NLANE) {
+    int p = base + LANE, pass = 0;
+    if (p < M.npair) {
+      int g1 = M.pair_g1[p], g2 = M.pair_g2[p];
+      double margin = fmax(M.geom_margin[g1], M.geom_margin[g2]);
+      double r1 = M.geom_rbound[g1], r2 = M.geom_rbound[g2];
+      double dif[3];
+      d_sub3(dif, c.geom_xpos + 3 * g2, c.geom_xpos + 3 * g1);
+      pass = 1;
+      if (M.geom_type[g1] == 0) {
+        const double *mat = c.geom_xmat + 9 * g1;
+        double n[3] = {mat[2], mat[5], mat[8]};
+        if (d_dot3(dif, n) > margin + r2) pass = 0;
+      } else if (r1 > 0 && r2 > 0) {
+        double bound = r1 + r2 + margin;
+        if (d_dot3(dif, dif) > bound * bound) pass = 0;
+      }
+    }
+    int tot, off = wave_excl_scan(pass, &tot);
+    if (pass && nactive + off < MAX_ACTIVE_PAIRS) c.active[nactive + off] = p;
+    nactive += tot;
+  }
+  if (nactive > MAX_ACTIVE_PAIRS) { c.warning |= WARN_CONTACTFULL; nactive = MAX_ACTIVE_PAIRS; }
+  SYNC();
+  // (2) narrow phase, one lane per active pair, contacts appended in pair order
+  for (int base = 0; base < nactive; base += NLANE) {
+    int a = base + LANE, n = 0, g1 = 0, g2 = 0;
+    double margin = 0, gap = 0;
+    NPCon con[4];
+    if (a < nactive) {
+      int p = c.active[a];
+      g1 = M.pair_g1[p]; g2 = M.pair_g2[p];
+      margin = fmax(M.geom_margin[g1], M.geom_margin[g2]);
+      gap = fmax(M.geom_gap[g1], M.geom_gap[g2]);
+      n = narrow_phase(c, g1, g2, margin, con);
+    }
+    int tot, off = wave_excl_scan(n, &tot);
+    if (c.ncon + tot > M.nconmax) { c.warning |= WARN_CONTACTFULL; break; }
+    for (int k = 0; k < n; k++) {
+      int ci = c.ncon + off + k;
+      double *cc = c.contact + ci * CON_STRIDE;
+      int dim;
+      contact_param(M, g1, g2, cc, &dim);
+      double fr[9];
+      for (int q = 0; q < 6; q++) fr[q] = con[k].frame[q];
+      d_makeframe(fr);
+      cc[CON_DIST] = con[k].dist;
+      d_copy3(cc + CON_POS, con[k].pos);
+      for (int q = 0; q < 9; q++) cc[CON_FRAME + q] = fr[q];
+      cc[CON_INCLUDEMARGIN] = margin - gap;
+      cc[CON_MU] = 0;
+      int *ci_ = c.con_i + ci * CONI_STRIDE;
+      ci_[0] = dim; ci_[1] = g1; ci_[2] = g2; ci_[3] = 0;
+    }
+    c.ncon += tot;
+  }
+  SYNC();
+}
+
+// ======================================================================================
+// constraint rows
+// ======================================================================================
+DEV double impedance(const double *solimp_in, double pos, double margin) {
+  double si0 = d_clip(solimp_in[0], 0.0001, 0.9999), si1 = d_clip(solimp_in[1], 0.0001, 0.9999);
+  double si2 = fmax(0.0, solimp_in[2]), si3 = d_clip(solimp_in[3], 0.0001, 0.9999), si4 = fmax(1.0, solimp_in[4]);
+  if (si0 == si1 || si2 <= D_MINVAL) return 0.5 * (si0 + si1);
+  double x = (pos - margin) / si2;
+  if (x < 0) x = -x;
+  if (x >= 1) return si1;
+  if (x == 0) return si0;
+  double y;
+  if (si4 == 1) y = x;
+  else if (x <= si3) { double a = 1 / pow(si3, si4 - 1); y = a * pow(x, si4); }
+  else { double b = 1 / pow(1 - si3, si4 - 1); y = 1 - b * pow(1 - x, si4); }
+  return si0 + y * (si1 - si0);
+}
+
+DEV void make_constraint(Ctx &c) {
+  const DevModel &M = *c.M;
+  int nv = M.nv, nvp = M.nvp;
+  int nefc = M.nfric;
+  // friction-loss rows are static: rows [0, nfric)
+  PFOR(r, M.nfric) {
+    int d = M.fric_dof[r];
+    c.efc_type[r] = CNSTR_FRICTION_DOF; c.efc_id[r] = d;
+    c.efc_floss[r] = M.dof_frictionloss[d]; c.efc_pos[r] = 0; c.efc_margin[r] = 0;
+    c.efc_diag[r] = M.dof_invweight0[d];
+  }
+  // joint limits: ordered compaction, lower side before upper side
+  for (int base = 0; base < M.nlimit; base += NLANE) {
+    int q = base + LANE, cnt = 0, j = 0;
+    double dist[2] = {0, 0}; int side[2] = {0, 0};
+    if (q < M.nlimit) {
+      j = M.limit_jnt[q];
+      double value = c.qpos[M.jnt_qposadr[j]], margin = M.jnt_margin[j];
+      for (int s = -1; s <= 1; s += 2) {
+        double dd = s * (M.jnt_range[2 * j + (s + 1) / 2] - value);
+        if (dd < margin) { dist[cnt] = dd; side[cnt] = s; cnt++; }
+      }
+    }
+    int tot, off = wave_excl_scan(cnt, &tot);
+    if (nefc + tot > M.nefcmax) { c.warning |= WARN_CNSTRFULL; break; }
+    for (int k = 0; k < cnt; k++) {
+      int r = nefc + off + k;
+      c.efc_type[r] = CNSTR_LIMIT_JOINT; c.efc_id[r] = j;
+      c.efc_floss[r] = (double)(-side[k]);      // J entry, consumed below
+      c.efc_pos[r] = dist[k]; c.efc_margin[r] = M.jnt_margin[j];
+      c.efc_diag[r] = M.dof_invweight0[M.jnt_dofadr[j]];
+    }
+    nefc += tot;
+  }
+  int nlim_end = nefc;
+  // contacts: dim rows each
+  for (int base = 0; base < c.ncon; base += NLANE) {
+    int ci = base + LANE, dim = 0;
+    if (ci < c.ncon) {
+      dim = c.con_i[ci * CONI_STRIDE];
+      if (dim > 1 && M.cone != 1) dim = 1;       // pyramidal cones not built yet: normal only (DESIGN.md gap)
+      c.con_i[ci * CONI_STRIDE] = dim;
+    }
+    int tot, off = wave_excl_scan(dim, &tot);
+    if (nefc + tot > M.nefcmax) { c.warning |= WARN_CNSTRFULL; c.ncon = base; break; }
+    if (ci < c.ncon) {
+      int r0 = nefc + off;
+      c.con_i[ci * CONI_STRIDE + 3] = r0;
+      int g1 = c.con_i[ci * CONI_STRIDE + 1], g2 = c.con_i[ci * CONI_STRIDE + 2];
+      int b1 = M.geom_bodyid[g1], b2 = M.geom_bodyid[g2];
+      double tran = M.body_invweight0[2 * b1] + M.body_invweight0[2 * b2];
+      double rot = M.body_invweight0[2 * b1 + 1] + M.body_invweight0[2 * b2 + 1];
+      const double *cc = c.contact + ci * CON_STRIDE;
+      for (int k = 0; k < dim; k++) {
+        c.efc_type[r0 + k] = dim == 1 ? CNSTR_CONTACT_FRICTIONLESS : CNSTR_CONTACT_ELLIPTIC;
+        c.efc_id[r0 + k] = ci;
+        c.efc_floss[r0 + k] = 0; c.efc_pos[r0 + k] = cc[CON_DIST]; c.efc_margin[r0 + k] = cc[CON_INCLUDEMARGIN];
+        c.efc_diag[r0 + k] = k < 3 ? tran : rot;
+      }
+    }
+    nefc += tot;
+  }
+  c.nefc = nefc;
+  SYNC();
+  // Jacobian
+  PFOR(e, nefc * nvp) c.efc_J[e] = 0;
+  SYNC();
+  PFOR(r, nlim_end) {
+    if (r < M.nfric) c.efc_J[r * nvp + c.efc_id[r]] = 1;
+    else { c.efc_J[r * nvp + M.jnt_dofadr[c.efc_id[r]]] = c.efc_floss[r]; c.efc_floss[r] = 0; }
+  }
+  PFOR(e, c.ncon * nv) {
+    int ci = e / nv, d = e - ci * nv;
+    const int *cin = c.con_i + ci * CONI_STRIDE;
+    int dim = cin[0], r0 = cin[3];
+    int b1 = M.geom_bodyid[cin[1]], b2 = M.geom_bodyid[cin[2]];
+    unsigned long long bit = 1ull << d;
+    int in1 = (M.body_dofmask[b1] & bit) != 0, in2 = (M.body_dofmask[b2] & bit) != 0;
+    if (!in1 && !in2) continue;
+    const double *cc = c.contact + ci * CON_STRIDE;
+    const double *cd = c.cdof + 6 * d;
+    double jp[3] = {0, 0, 0}, jr[3] = {0, 0, 0};
+    if (in2) {
+      double off[3], t[3];
+      d_sub3(off, cc + CON_POS, c.subtree_com + 3 * M.body_rootid[b2]);
+      d_cross(t, cd, off);
+      jp[0] += cd[3] + t[0]; jp[1] += cd[4] + t[1]; jp[2] += cd[5] + t[2];
+      jr[0] += cd[0]; jr[1] += cd[1]; jr[2] += cd[2];
+    }
+    if (in1) {
+      double off[3], t[3];
+      d_sub3(off, cc + CON_POS, c.subtree_com + 3 * M.body_rootid[b1]);
+      d_cross(t, cd, off);
+      jp[0] -= cd[3] + t[0]; jp[1] -= cd[4] + t[1]; jp[2] -= cd[5] + t[2];
+      jr[0] -= cd[0]; jr[1] -= cd[1]; jr[2] -= cd[2];
+    }
+    for (int k = 0; k < dim; k++) {
+      const double *ax = cc + CON_FRAME + 3 * (k % 3);
+      const double *jj = k < 3 ? jp : jr;
+      c.efc_J[(r0 + k) * nvp + d] = ax[0] * jj[0] + ax[1] * jj[1] + ax[2] * jj[2];
+    }
+  }
+  SYNC();
+}
+
+// efc_vel, impedance, R, D, aref
+DEV void make_impedance(Ctx &c) {
+  const DevModel &M = *c.M;
+  int nv = M.nv, nvp = M.nvp;
+  PFOR(r, c.nefc) {
+    int type = c.efc_type[r], id = c.efc_id[r];
+    double vel = 0;
+    for (int i = 0; i < nv; i++) vel += c.efc_J[r * nvp + i] * c.qvel[i];
+    double solref[2], solimp[5];
+    int first = 1;
+    if (type == CNSTR_FRICTION_DOF) {
+      for (int k = 0; k < 2; k++) solref[k] = M.dof_solref[2 * id + k];
+      for (int k = 0; k < 5; k++) solimp[k] = M.dof_solimp[5 * id + k];
+    } else if (type == CNSTR_LIMIT_JOINT) {
+      for (int k = 0; k < 2; k++) solref[k] = M.jnt_solref[2 * id + k];
+      for (int k = 0; k < 5; k++) solimp[k] = M.jnt_solimp[5 * id + k];
+    } else {
+      const double *cc = c.contact + id * CON_STRIDE;
+      for (int k = 0; k < 2; k++) solref[k] = cc[CON_SOLREF + k];
+      for (int k = 0; k < 5; k++) solimp[k] = cc[CON_SOLIMP + k];
+      first = (r == c.con_i[id * CONI_STRIDE + 3]);
+    }
+    double imp = impedance(solimp, c.efc_pos[r], c.efc_margin[r]);
+    double dmax = d_clip(solimp[1], 0.0001, 0.9999);
+    double K, B;
+    if (solref[0] > 0) {
+      double tc = fmax(solref[0], 2 * M.timestep), dr = solref[1];
+      K = 1 / fmax(D_MINVAL, dmax * dmax * tc * tc * dr * dr);
+      B = 2 / fmax(D_MINVAL, dmax * tc);
+    } else {
+      K = -solref[0] / fmax(D_MINVAL, dmax * dmax);
+      B = -solref[1] / fmax(D_MINVAL, dmax);
+    }
+    if (type == CNSTR_FRICTION_DOF || !first) K = 0;
+    c.efc_R[r] = fmax(D_MINVAL, (1 - imp) / imp * c.efc_diag[r]);
+    c.efc_aref[r] = -B * vel - K * imp * (c.efc_pos[r] - c.efc_margin[r]);
+  }
+  SYNC();
+  PFOR(ci, c.ncon) {
+    int dim = c.con_i[ci * CONI_STRIDE];
+    if (dim > 1) {
+      double *cc = c.contact + ci * CON_STRIDE;
+      double *R = c.efc_R + c.con_i[ci * CONI_STRIDE + 3];
+      R[1] = R[0] / fmax(D_MINVAL, M.impratio);
+      cc[CON_MU] = cc[CON_FRICTION] * sqrt(R[1] / R[0]);
+      for (int k = 2; k < dim; k++)
+        R[k] = R[1] * cc[CON_FRICTION] * cc[CON_FRICTION] / (cc[CON_FRICTION + k - 1] * cc[CON_FRICTION + k - 1]);
+    }
+  }
+  SYNC();
+  PFOR(r, c.nefc) c.efc_D[r] = 1 / c.efc_R[r];
+  SYNC();
+}
+
+// ======================================================================================
+// velocity stage: com velocities, subtree momentum, RNE bias, passive, actuation
+// ======================================================================================
+DEV void vel_body(Ctx &c, int i) {
+  const DevModel &M = *c.M;
+  double cvel[6];
+  for (int k = 0; k < 6; k++) cvel[k] = c.cvel[6 * M.body_parentid[i] + k];
+  int bda = M.body_dofadr[i];
+  for (int j = M.body_jntadr[i]; j < M.body_jntadr[i] + M.body_jntnum[i]; j++) {
+    int type = M.jnt_type[j];
+    if (type == 0) {
+      for (int k = 0; k < 18; k++) c.cdof_dot[6 * bda + k] = 0;
+      for (int k = 0; k < 3; k++) for (int q = 0; q < 6; q++) cvel[q] += c.cdof[6 * (bda + k) + q] * c.qvel[bda + k];
+      bda += 3;
+    }
+    if (type == 0 || type == 1) {
+      for (int k = 0; k < 3; k++) {
+        double r[6];
+        d_crossmotion(r, cvel, c.cdof + 6 * (bda + k));
+        for (int q = 0; q < 6; q++) c.cdof_dot[6 * (bda + k) + q] = r[q];
+      }
+      for (int k = 0; k < 3; k++) for (int q = 0; q < 6; q++) cvel[q] += c.cdof[6 * (bda + k) + q] * c.qvel[bda + k];
+      bda += 3;
+    } else {
+      double r[6];
+      d_crossmotion(r, cvel, c.cdof + 6 * bda);
+      for (int q = 0; q < 6; q++) c.cdof_dot[6 * bda + q] = r[q];
+      for (int q = 0; q < 6; q++) cvel[q] += c.cdof[6 * bda + q] * c.qvel[bda];
+      bda++;
+    }
+  }
+  for (int k = 0; k < 6; k++) c.cvel[6 * i + k] = cvel[k];
+  // RNE forward part: cacc, cfrc_body
+  double a[6];
+  for (int k = 0; k < 6; k++) a[k] = c.cacc[6 * M.body_parentid[i] + k];
+  bda = M.body_dofadr[i];
+  for (int k = 0; k < M.body_dofnum[i]; k++)
+    for (int q = 0; q < 6; q++) a[q] += c.cdof_dot[6 * (bda + k) + q] * c.qvel[bda + k];
+  for (int k = 0; k < 6; k++) c.cacc[6 * i + k] = a[k];
+  double t1[6], t2[6], t3[6];
+  d_mulinertvec(t1, c.cinert + 10 * i, a);
+  d_mulinertvec(t2, c.cinert + 10 * i, cvel);
+  d_crossforce(t3, cvel, t2);
+  for (int k = 0; k < 6; k++) c.cfrc[6 * i + k] = t1[k] + t3[k];
+  // body momentum for subtree_linvel
+  double off[3], v[3];
+  d_sub3(off, c.xipos + 3 * i, c.subtree_com + 3 * M.body_rootid[i]);
+  d_cross(v, cvel, off);
+  d_add3(v, v, cvel + 3);
+  d_scl3(c.bodytmp + 3 * i, v, M.body_mass[i]);
+}
+
+DEV void velocity_stage(Ctx &c) {
+  const DevModel &M = *c.M;
+  int nv = M.nv;
+  for (int l = 0; l < M.nlevel; l++) {
+    int a = M.level_adr[l], n = M.level_adr[l + 1] - a;
+    PFOR(k, n) vel_body(c, M.level_body[a + k]);
+    SYNC();
+  }
+  PFOR(e, M.nbody * 9) {
+    int b = e / 9, k = e - 9 * b;
+    if (k < 6) {
+      double s = 0;
+      if (b > 0) for (int q = M.subtree_adr[b]; q < M.subtree_adr[b + 1]; q++) s += c.cfrc[6 * M.subtree_list[q] + k];
+      c.cfrc_sub[6 * b + k] = s;
+    } else {
+      int kk = k - 6;
+      double s = 0;
+      for (int q = M.subtree_adr[b]; q < M.subtree_adr[b + 1]; q++) s += c.bodytmp[3 * M.subtree_list[q] + kk];
+      c.subtree_linvel[3 * b + kk] = s / fmax(D_MINVAL, M.body_subtreemass[b]);
+    }
+  }
+  // actuator forces
+  PFOR(i, M.nu) {
+    double ctrl = c.ctrl[i];
+    if (M.actuator_ctrllimited[i]) ctrl = d_clip(ctrl, M.actuator_ctrlrange[2 * i], M.actuator_ctrlrange[2 * i + 1]);
+    double gear = M.actuator_gear[i];
+    double force = M.actuator_gainprm[3 * i] * ctrl;
+    if (M.actuator_biastype[i] == 1)
+      force += M.actuator_biasprm[3 * i] + M.actuator_biasprm[3 * i + 1] * (gear * c.qpos[M.actuator_qposadr[i]]) +
+               M.actuator_biasprm[3 * i + 2] * (gear * c.qvel[M.actuator_dofadr[i]]);
+    if (M.actuator_forcelimited[i]) force = d_clip(force, M.actuator_forcerange[2 * i], M.actuator_forcerange[2 * i + 1]);
+    c.actuator_force[i] = force;
+  }
+  SYNC();
+  PFOR(d, nv) {
+    const double *cd = c.cdof + 6 * d, *cf = c.cfrc_sub + 6 * M.dof_bodyid[d];
+    double bias = cd[0]*cf[0] + cd[1]*cf[1] + cd[2]*cf[2] + cd[3]*cf[3] + cd[4]*cf[4] + cd[5]*cf[5];
+    c.qfrc_bias[d] = bias;
+    double act = 0;
+    for (int i = 0; i < M.nu; i++) if (M.actuator_dofadr[i] == d) act += M.actuator_gear[i] * c.actuator_force[i];
+    c.qfrc_smooth[d] = act - bias - M.dof_damping[d] * c.qvel[d];   // joint springs are added below
+  }
+  SYNC();
+  PFOR(j, M.njnt) {
+    double k = M.jnt_stiffness[j];
+    int type = M.jnt_type[j];
+    if (k != 0 && (type == 2 || type == 3)) {
+      int qa = M.jnt_qposadr[j];
+      c.qfrc_smooth[M.jnt_dofadr[j]] -= k * (c.qpos[qa] - M.qpos_spring[qa]);
+    }
+  }
+  SYNC();
+  PFOR(d, nv) c.qacc_smooth[d] = c.qfrc_smooth[d];
+  chol_solve(c, c.qL, c.Linv, c.qacc_smooth, nv, M.nvp);
+}
+
+// ======================================================================================
+// primal Newton solver
+// ======================================================================================
+// constraint cost at efc_jar; fills force/state (and cone Hessians); returns this lane's partial cost
+DEV double constraint_update(Ctx &c, int hess) {
+  const DevModel &M = *c.M;
+  double cost = 0;
+  PFOR(i, c.nefc) {
+    int type = c.efc_type[i];
+    if (type == CNSTR_CONTACT_ELLIPTIC) continue;
+    double D = c.efc_D[i], R = c.efc_R[i], x = c.efc_jar[i];
+    if (type == CNSTR_FRICTION_DOF) {
+      double f = c.efc_floss[i];
+      if (x <= -R * f) { cost += -0.5 * R * f * f - f * x; c.efc_force[i] = f; c.efc_state[i] = STATE_LINEARNEG; }
+      else if (x >= R * f) { cost += -0.5 * R * f * f + f * x; c.efc_force[i] = -f; c.efc_state[i] = STATE_LINEARPOS; }
+      else { cost += 0.5 * D * x * x; c.efc_force[i] = -D * x; c.efc_state[i] = STATE_QUADRATIC; }
+    } else {
+      if (x >= 0) { c.efc_force[i] = 0; c.efc_state[i] = STATE_SATISFIED; }
+      else { cost += 0.5 * D * x * x; c.efc_force[i] = -D * x; c.efc_state[i] = STATE_QUADRATIC; }
+    }
+  }
+  PFOR(ci, c.ncon) {
+    int dim = c.con_i[ci * CONI_STRIDE];
+    if (dim <= 1) continue;
+    int i = c.con_i[ci * CONI_STRIDE + 3];
+    double *cc = c.contact + ci * CON_STRIDE;
+    double mu = cc[CON_MU], U[6], fr[6];
+    fr[0] = mu;
+    for (int j = 1; j < 6; j++) fr[j] = j < dim ? cc[CON_FRICTION + j - 1] : 0;
+    double T2 = 0;
+    for (int j = 0; j < 6; j++) { U[j] = j < dim ? c.efc_jar[i + j] * fr[j] : 0; if (j > 0) T2 += U[j] * U[j]; }
+    double N = U[0], T = sqrt(T2);
+    int st;
+    if (N >= mu * T || (T <= 0 && N >= 0)) {
+      for (int j = 0; j < dim; j++) c.efc_force[i + j] = 0;
+      st = STATE_SATISFIED;
+    } else if (mu * N + T <= 0 || (T <= 0 && N < 0)) {
+      for (int j = 0; j < dim; j++) { double xj = c.efc_jar[i + j], Dj = c.efc_D[i + j]; cost += 0.5 * Dj * xj * xj; c.efc_force[i + j] = -Dj * xj; }
+      st = STATE_QUADRATIC;
+    } else {
+      double Dm = c.efc_D[i] / (mu * mu * (1 + mu * mu));
+      double NmT = N - mu * T;
+      cost += 0.5 * Dm * NmT * NmT;
+      double f0 = -Dm * NmT * mu;
+      c.efc_force[i] = f0;
+      for (int j = 1; j < dim; j++) c.efc_force[i + j] = -f0 / T * U[j] * fr[j];
+      st = STATE_CONE;
+      if (hess) {
+        double g[6];
+        g[0] = 1;
+        for (int j = 1; j < 6; j++) g[j] = -mu * U[j] / T;
+        for (int a = 0; a < dim; a++) for (int b = 0; b < dim; b++) {
+          double h = g[a] * g[b];
+          if (a > 0 && b > 0) h += NmT * (-mu) * ((a == b ? 1.0 / T : 0.0) - U[a] * U[b] / (T * T * T));
+          cc[CON_H + a * 6 + b] = Dm * h * fr[a] * fr[b];
+        }
+      }
+    }
+    for (int j = 0; j < dim; j++) c.efc_state[i + j] = st;
+  }
+  (void)M;
+  return cost;
+}
+
+// Ma = M qacc, jar = J qacc - aref, cost = Gauss + constraints; returns total cost (uniform), Gauss via out
+DEV double solver_eval(Ctx &c, const double *qacc, double *gauss_out) {
+  const DevModel &M = *c.M;
+  int nv = M.nv, nvp = M.nvp;
+  double part = 0;
+  PFOR(i, nv) {
+    double s = 0;
+    for (int j = 0; j < nv; j++) s += c.qM[i * nvp + j] * qacc[j];
+    c.Ma[i] = s;
+    part += 0.5 * (s - c.qfrc_smooth[i]) * (qacc[i] - c.qacc_smooth[i]);
+  }
+  PFOR(r, c.nefc) {
+    double s = 0;
+    for (int j = 0; j < nv; j++) s += c.efc_J[r * nvp + j] * qacc[j];
+    c.efc_jar[r] = s - c.efc_aref[r];
+  }
+  SYNC();
+  double gauss = wave_sum(part);
+  double cc = wave_sum(constraint_update(c, 1));
+  SYNC();
+  if (gauss_out) *gauss_out = gauss;
+  return gauss + cc;
+}
+
+DEV void newton_gradient(Ctx &c) {
+  const DevModel &M = *c.M;
+  int nv = M.nv, nvp = M.nvp, nefc = c.nefc;
+  PFOR(i, nv) {
+    double g = c.Ma[i] - c.qfrc_smooth[i];
+    for (int r = 0; r < nefc; r++) g -= c.efc_J[r * nvp + i] * c.efc_force[r];
+    c.grad[i] = g;
+    c.Mgrad[i] = g;
+  }
+  // H = M + J^T diag(D * quadratic) J + cone blocks; lower triangle, one entry per lane-iteration
+  int ntri = nv * (nv + 1) / 2;
+  PFOR(e, ntri) {
+    int i = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
+    while ((i + 1) * (i + 2) / 2 <= e) i++;
+    while (i * (i + 1) / 2 > e) i--;
+    int j = e - i * (i + 1) / 2;
+    double h = c.qM[i * nvp + j];
+    for (int r = 0; r < nefc; r++) {
+      int st = c.efc_state[r];
+      if (st == STATE_QUADRATIC) h += c.efc_D[r] * c.efc_J[r * nvp + i] * c.efc_J[r * nvp + j];
+      else if (st == STATE_CONE) {
+        int ci = c.efc_id[r];
+        int dim = c.con_i[ci * CONI_STRIDE];
+        const double *Hc = c.contact + ci * CON_STRIDE + CON_H;
+        for (int a = 0; a < dim; a++) {
+          double Jai = c.efc_J[(r + a) * nvp + i];
+          if (Jai == 0) continue;
+          for (int b = 0; b < dim; b++) h += Hc[a * 6 + b] * Jai * c.efc_J[(r + b) * nvp + j];
+        }
+        r += dim - 1;
+      }
+    }
+    c.qH[i * nvp + j] = h;
+  }
+  chol_factor(c, c.qH, c.Hinv, nv, nvp);
+  chol_solve(c, c.qH, c.Hinv, c.Mgrad, nv, nvp);
+}
+
+// exact 1-D line search along `search`: safeguarded Newton on phi'(alpha)
+struct LSPoint { double cost, d1, d2; };
+
+DEV LSPoint ls_eval(Ctx &c, double q0, double q1, double q2, double a) {
+  LSPoint p; p.cost = 0; p.d1 = 0; p.d2 = 0;
+  PFOR(i, c.nefc) {
+    int type = c.efc_type[i];
+    if (type == CNSTR_CONTACT_ELLIPTIC) continue;
+    double D = c.efc_D[i], R = c.efc_R[i], v = c.efc_jv[i], x = c.efc_jar[i] + a * v;
+    if (type == CNSTR_FRICTION_DOF) {
+      double f = c.efc_floss[i];
+      if (x <= -R * f) { p.cost += -0.5 * R * f * f - f * x; p.d1 += -f * v; }
+      else if (x >= R * f) { p.cost += -0.5 * R * f * f + f * x; p.d1 += f * v; }
+      else { p.cost += 0.5 * D * x * x; p.d1 += D * x * v; p.d2 += D * v * v; }
+    } else if (x < 0) { p.cost += 0.5 * D * x * x; p.d1 += D * x * v; p.d2 += D * v * v; }
+  }
+  PFOR(ci, c.ncon) {
+    int dim = c.con_i[ci * CONI_STRIDE];
+    if (dim <= 1) continue;
+    int i = c.con_i[ci * CONI_STRIDE + 3];
+    const double *cc = c.contact + ci * CON_STRIDE;
+    double mu = cc[CON_MU], U[6], V[6];
+    double T2 = 0, UV = 0, VV = 0;
+    for (int j = 0; j < 6; j++) {
+      double fr = j == 0 ? mu : (j < dim ? cc[CON_FRICTION + j - 1] : 0);
+      U[j] = j < dim ? (c.efc_jar[i + j] + a * c.efc_jv[i + j]) * fr : 0;
+      V[j] = j < dim ? c.efc_jv[i + j] * fr : 0;
+      if (j > 0) { T2 += U[j] * U[j]; UV += U[j] * V[j]; VV += V[j] * V[j]; }
+    }
+    double N = U[0], T = sqrt(T2);
+    if (N >= mu * T || (T <= 0 && N >= 0)) {
+    } else if (mu * N + T <= 0 || (T <= 0 && N < 0)) {
+      for (int j = 0; j < dim; j++) {
+        double vj = c.efc_jv[i + j], xj = c.efc_jar[i + j] + a * vj, Dj = c.efc_D[i + j];
+        p.cost += 0.5 * Dj * xj * xj; p.d1 += Dj * xj * vj; p.d2 += Dj * vj * vj;
+      }
+    } else {
+      double Dm = c.efc_D[i] / (mu * mu * (1 + mu * mu));
+      double NmT = N - mu * T;
+      double T1 = UV / T, T2d = (VV - UV * UV / (T * T)) / T;
+      double g1 = V[0] - mu * T1;
+      p.cost += 0.5 * Dm * NmT * NmT; p.d1 += Dm * NmT * g1; p.d2 += Dm * (g1 * g1 - NmT * mu * T2d);
+    }
+  }
+  p.cost = wave_sum(p.cost) + q0 + a * q1 + a * a * q2;
+  p.d1 = wave_sum(p.d1) + q1 + 2 * a * q2;
+  p.d2 = wave_sum(p.d2) + 2 * q2;
+  return p;
+}
+
+DEV double line_search(Ctx &c, double gauss) {
+  const DevModel &M = *c.M;
+  int nv = M.nv, nvp = M.nvp;
+  double p_sn = 0, p_q1 = 0, p_q2 = 0;
+  PFOR(i, nv) {
+    double s = 0;
+    for (int j = 0; j < nv; j++) s += c.qM[i * nvp + j] * c.search[j];
+    c.Mv[i] = s;
+    double si = c.search[i];
+    p_sn += si * si; p_q1 += si * (c.Ma[i] - c.qfrc_smooth[i]); p_q2 += 0.5 * si * s;
+  }
+  PFOR(r, c.nefc) {
+    double s = 0;
+    for (int j = 0; j < nv; j++) s += c.efc_J[r * nvp + j] * c.search[j];
+    c.efc_jv[r] = s;
+  }
+  SYNC();
+  double snorm = sqrt(wave_sum(p_sn)), q1 = wave_sum(p_q1), q2 = wave_sum(p_q2);
+  double scale = 1.0 / (M.meaninertia * (nv > 1 ? nv : 1));
+  if (snorm < D_MINVAL) return 0;
+  double gtol = M.tolerance * M.ls_tolerance * snorm / scale;
+  LSPoint p0 = ls_eval(c, gauss, q1, q2, 0.0);
+  if (!(p0.d2 > 0) || p0.d1 >= 0) return 0;
+  // safeguarded Newton on phi'(alpha) (rtsafe): expand until phi' changes sign, then Newton steps that stay
+  // inside the bracket and at least halve the previous step, else bisection; return the best point seen
+  double lo = 0, hi = -1, a = -p0.d1 / p0.d2;
+  double best_a = 0, best_cost = p0.cost, dxold = a, dx = a;
+  for (int it = 0; it < M.ls_iterations; it++) {
+    LSPoint p = ls_eval(c, gauss, q1, q2, a);
+    if (p.cost < best_cost) { best_cost = p.cost; best_a = a; }
+    if (fabs(p.d1) < gtol) break;
+    if (p.d1 < 0) lo = a; else hi = a;
+    double an;
+    if (hi < 0) {
+      an = (p.d2 > 0) ? a - p.d1 / p.d2 : 2 * a;
+      if (!(an > a)) an = 2 * a;
+      dxold = dx; dx = an - a;
+    } else {
+      double nw = (p.d2 > 0) ? a - p.d1 / p.d2 : lo - 1;
+      int ok = (nw > lo) && (nw < hi) && (fabs(2 * p.d1) <= fabs(dxold * p.d2));
+      dxold = dx;
+      if (ok) { dx = fabs(nw - a); an = nw; }
+      else { dx = 0.5 * (hi - lo); an = lo + dx; }
+    }
+    if (an == a) break;
+    a = an;
+  }
+  return best_a;
+}
+
+DEV void solve_constraints(Ctx &c) {
+  const DevModel &M = *c.M;
+  int nv = M.nv, nvp = M.nvp;
+  c.solver_iter = 0;
+  if (c.nefc == 0) {
+    PFOR(i, nv) { c.qacc[i] = c.qacc_smooth[i]; c.qfrc_constraint[i] = 0; }
+    SYNC();
+    return;
+  }
+  double cost_ws = solver_eval(c, c.qacc_ws, 0);
+  double cost_sm = solver_eval(c, c.qacc_smooth, 0);
+  PFOR(i, nv) c.qacc[i] = (cost_ws > cost_sm) ? c.qacc_smooth[i] : c.qacc_ws[i];
+  SYNC();
+  double gauss;
+  double cost = solver_eval(c, c.qacc, &gauss);
+  newton_gradient(c);
+  PFOR(i, nv) c.search[i] = -c.Mgrad[i];
+  SYNC();
+  double scale = 1.0 / (M.meaninertia * (nv > 1 ? nv : 1));
+  for (int iter = 0; iter < M.iterations; iter++) {
+    double alpha = line_search(c, gauss);
+    if (alpha == 0) break;
+    PFOR(i, nv) c.qacc[i] += alpha * c.search[i];
+    SYNC();
+    double oldcost = cost;
+    cost = solver_eval(c, c.qacc, &gauss);
+    newton_gradient(c);
+    c.solver_iter++;
+    double pg = 0;
+    PFOR(i, nv) pg += c.grad[i] * c.grad[i];
+    double gradient = scale * sqrt(wave_sum(pg));
+    double improvement = scale * (oldcost - cost);
+    if (improvement < M.tolerance || gradient < M.tolerance) break;
+    PFOR(i, nv) c.search[i] = -c.Mgrad[i];
+    SYNC();
+  }
+  PFOR(i, nv) {
+    double s = 0;
+    for (int r = 0; r < c.nefc; r++) s += c.efc_J[r * nvp + i] * c.efc_force[r];
+    c.qfrc_constraint[i] = s;
+  }
+  SYNC();
+}
+
+// ======================================================================================
+// task residuals (device restatement of the reference's ResidualFn::Residual)
+// ======================================================================================
+DEV double ray_geom(const double *pos, const double *mat, const double *size, const double *pnt, const double *vec, int type) {
+  double dif[3], lp[3], lv[3];
+  d_sub3(dif, pnt, pos);
+  d_mulmattvec3(lp, mat, dif);
+  d_mulmattvec3(lv, mat, vec);
+  if (type == 0) {
+    if (lv[2] > -D_MINVAL) return -1;
+    double x = -lp[2] / lv[2];
+    if (x < 0) return -1;
+    double p0 = lp[0] + x * lv[0], p1 = lp[1] + x * lv[1];
+    if ((size[0] <= 0 || fabs(p0) <= size[0]) && (size[1] <= 0 || fabs(p1) <= size[1])) return x;
+    return -1;
+  }
+  if (type == 2) {
+    double a = d_dot3(lv, lv), b = d_dot3(lv, lp), cq = d_dot3(lp, lp) - size[0] * size[0];
+    double det = b * b - a * cq;
+    if (det < D_MINVAL || a < D_MINVAL) return -1;
+    det = sqrt(det);
+    double x0 = (-b - det) / a, x1 = (-b + det) / a;
+    if (x0 >= 0) return x0;
+    if (x1 >= 0) return x1;
+    return -1;
+  }
+  if (type == 6) {
+    double best = -1;
+    for (int i = 0; i < 3; i++) {
+      double lvi = i == 0 ? lv[0] : (i == 1 ? lv[1] : lv[2]);
+      double lpi = i == 0 ? lp[0] : (i == 1 ? lp[1] : lp[2]);
+      double szi = i == 0 ? size[0] : (i == 1 ? size[1] : size[2]);
+      if (fabs(lvi) <= D_MINVAL) continue;
+      int j = (i + 1) % 3, k = (i + 2) % 3;
+      double lvj = j == 0 ? lv[0] : (j == 1 ? lv[1] : lv[2]), lpj = j == 0 ? lp[0] : (j == 1 ? lp[1] : lp[2]);
+      double lvk = k == 0 ? lv[0] : (k == 1 ? lv[1] : lv[2]), lpk = k == 0 ? lp[0] : (k == 1 ? lp[1] : lp[2]);
+      double szj = j == 0 ? size[0] : (j == 1 ? size[1] : size[2]), szk = k == 0 ? size[0] : (k == 1 ? size[1] : size[2]);
+      for (int side = -1; side <= 1; side += 2) {
+        double x = (side * szi - lpi) / lvi;
+        if (x < 0) continue;
+        double pj = lpj + x * lvj, pk = lpk + x * lvk;
+        if (fabs(pj) <= szj && fabs(pk) <= szk) if (best < 0 || x < best) best = x;
+      }
+    }
+    return best;
+  }
+  return -1;
+}
+
+// mjpc/utilities.cc:538-556 Ground(): mj_ray straight down from 0.5 m above, geom group 0
+DEV double ray_ground(Ctx &c, const double *pos) {
+  const DevModel &M = *c.M;
+  double down[3] = {0, 0, -1}, query[3] = {pos[0], pos[1], pos[2] + 0.5};
+  double dist = -1;
+  for (int r = 0; r < M.nray; r++) {
+    int g = M.ray_geom[r];
+    double gp[3], gm[9], gs[3];
+    d_copy3(gp, c.geom_xpos + 3 * g); d_copy3(gs, M.geom_size + 3 * g);
+    for (int k = 0; k < 9; k++) gm[k] = c.geom_xmat[9 * g + k];
+    double x = ray_geom(gp, gm, gs, query, down, M.geom_type[g]);
+    if (x >= 0 && (dist < 0 || x < dist)) dist = x;
+  }
+  return pos[2] + 0.5 - dist;
+}
+
+DEV int reinterpret_int(double v) { union { double d; int i[2]; } u; u.d = v; return u.i[0]; }
+
+enum { QI_TORSO = 0, QI_HEAD = 1, QI_GOAL = 2, QI_FOOT = 3, QI_GAIT = 7, QI_GAIT_SWITCH = 8, QI_FLIP_DIR = 9,
+       QI_BIPED_TYPE = 10, QI_CADENCE = 11, QI_AMPLITUDE = 12, QI_DUTY = 13, QI_HEADING = 14, QI_HOME = 15,
+       QI_CROUCH = 16, QI_MODE = 17 };
+enum { QD_MODE_START = 0, QD_POSITION = 1, QD_HEADING = 4, QD_SPEED = 6, QD_ANGVEL = 7, QD_GROUND = 8,
+       QD_ORIENT = 9, QD_GAIT = 13, QD_PHASE_START = 14, QD_PHASE_START_TIME = 15, QD_PHASE_VEL = 16,
+       QD_GRAVITY = 17, QD_JUMP_VEL = 18, QD_FLIGHT_TIME = 19, QD_JUMP_ACC = 20, QD_CROUCH_TIME = 21,
+       QD_LEAP_TIME = 22, QD_JUMP_TIME = 23, QD_CROUCH_VEL = 24, QD_LAND_TIME = 25, QD_LAND_ACC = 26,
+       QD_FLIGHT_ROT_VEL = 27, QD_JUMP_ROT_VEL = 28, QD_JUMP_ROT_ACC = 29, QD_LAND_ROT_ACC = 30 };
+
+DEV double q_gait_phase(int gait, int foot) {   // quadruped.h:77-85
+  const double tab[20] = {0, 0, 0, 0, 0, 0.75, 0.5, 0.25, 0, 0.5, 0.5, 0, 0, 0.33, 0.33, 0.66, 0, 0.4, 0.05, 0.35};
+  return tab[4 * gait + foot];
+}
+DEV double q_step_height(double time, double footphase, double duty_ratio) {   // quadruped.cc:650-659
+  double angle = fmod(time + D_PI - footphase, 2 * D_PI) - D_PI;
+  double value = 0;
+  if (duty_ratio < 1) { angle *= 0.5 / (1 - duty_ratio); value = cos(d_clip(angle, -D_PI / 2, D_PI / 2)); }
+  return fabs(value) < 1e-6 ? 0.0 : value;
+}
+DEV double q_flip_height(const double *D, double time) {   // quadruped.cc:674-690
+  double jt = D[QD_JUMP_TIME], ft = D[QD_FLIGHT_TIME], lt = D[QD_LAND_TIME];
+  if (time >= jt + ft + lt) return 0.25 + D[QD_GROUND];
+  double h = 0;
+  if (time < jt) h = 0.25 + time * D[QD_CROUCH_VEL] + 0.5 * time * time * D[QD_JUMP_ACC];
+  else if (time >= jt && time < jt + ft) { time -= jt; h = 0.5 + D[QD_JUMP_VEL] * time - 0.5 * 9.81 * time * time; }
+  else if (time >= jt + ft) { time -= jt + ft; h = 0.5 - D[QD_JUMP_VEL] * time + 0.5 * D[QD_LAND_ACC] * time * time; }
+  return h + D[QD_GROUND];
+}
+DEV void q_flip_quat(const double *D, const double *P, const int *I, double *quat, double time) {   // quadruped.cc:695-714
+  double angle = 0, jt = D[QD_JUMP_TIME], ft = D[QD_FLIGHT_TIME], lt = D[QD_LAND_TIME], ct = D[QD_CROUCH_TIME];
+  if (time >= jt + ft + lt) angle = 2 * D_PI;
+  else if (time >= ct && time < jt) { time -= ct; angle = 0.5 * D[QD_JUMP_ROT_ACC] * time * time + D[QD_JUMP_ROT_VEL] * time; }
+  else if (time >= jt && time < jt + ft) { time -= jt; angle = D_PI / 2 + D[QD_FLIGHT_ROT_VEL] * time; }
+  else if (time >= jt + ft) { time -= jt + ft; angle = 1.75 * D_PI + D[QD_FLIGHT_ROT_VEL] * time - 0.5 * D[QD_LAND_ROT_ACC] * time * time; }
+  int flip_dir = reinterpret_int(P[I[QI_FLIP_DIR]]);
+  double axis[3] = {0, flip_dir ? 1.0 : -1.0, 0}, q[4], o[4];
+  d_axisangle2quat(q, axis, angle);
+  d_copy4(o, D + QD_ORIENT);
+  d_mulquat(quat, o, q);
+}
+
+// mjpc/tasks/quadruped/quadruped.cc:33-221
+DEV void residual_quadruped(Ctx &c, double *residual) {
+  const DevModel &M = *c.M;
+  const int *I = M.task.int_data;
+  const double *D = M.task.dbl_data, *P = M.task.parameters;
+  int mode = I[QI_MODE], torso = I[QI_TORSO], nu = M.nu;
+  int is_biped = mode == 1;
+  double height_goal = is_biped ? 0.6 : 0.25;
+  double avg[3];
+  {
+    const double *fFL = c.geom_xpos + 3 * I[QI_FOOT + 0], *fHL = c.geom_xpos + 3 * I[QI_FOOT + 1];
+    const double *fFR = c.geom_xpos + 3 * I[QI_FOOT + 2], *fHR = c.geom_xpos + 3 * I[QI_FOOT + 3];
+    if (mode == 1) {
+      int handstand = reinterpret_int(P[I[QI_BIPED_TYPE]]);
+      if (handstand) d_add3(avg, fFL, fFR); else d_add3(avg, fHL, fHR);
+      d_scl3(avg, avg, 0.5);
+    } else {
+      d_add3(avg, fHL, fHR); d_add3(avg, avg, fFL); d_add3(avg, avg, fFR); d_scl3(avg, avg, 0.25);
+    }
+  }
+  const double *torso_pos = c.xipos + 3 * torso;
+  const double *goal_pos = c.mocap_pos + 3 * I[QI_GOAL];
+  // ---- Gait (4 residuals at offset 7): one lane per foot, each casts its own ray
+  PFOR(f, 4) {
+    double r = 0;
+    int skip = 0;
+    if (is_biped) {
+      int handstand = reinterpret_int(P[I[QI_BIPED_TYPE]]) != 0;
+      int front_hand = !handstand && (f == 0 || f == 2);
+      int back_hand = handstand && (f == 1 || f == 3);
+      skip = front_hand || back_hand;
+    }
+    if (!skip) {
+      int gait = is_biped ? 2 : reinterpret_int(D[QD_GAIT]);
+      double phase = D[QD_PHASE_START] + (c.time - D[QD_PHASE_START_TIME]) * D[QD_PHASE_VEL];
+      double step = P[I[QI_AMPLITUDE]] * q_step_height(phase, 2 * D_PI * q_gait_phase(gait, f), P[I[QI_DUTY]]);
+      double fp[3], query[3];
+      d_copy3(fp, c.geom_xpos + 3 * I[QI_FOOT + f]);
+      d_copy3(query, fp);
+      if (mode == 3) {
+        double v[3];
+        d_sub3(v, goal_pos, fp); v[2] = 0; d_normalize3(v);
+        d_addtoscl3(query, v, 0.15);
+      }
+      double ground_height = ray_ground(c, query);
+      double height_difference = fp[2] - (ground_height + 0.02 + step);
+      if (mode == 3) height_difference = fmin(0.0, height_difference);
+      r = step ? height_difference : 0;
+    }
+    residual[7 + f] = r;
+  }
+  // ---- Effort (12 at 13) and Posture (12 at 25)
+  PFOR(i, nu) {
+    residual[13 + i] = c.actuator_force[i] * 2e-2;
+    const double *home = M.key_qpos + I[QI_HOME] * M.nq;
+    double p = c.qpos[7 + i] - home[7 + i];
+    if (mode == 4) {
+      double flip_time = c.time - D[QD_MODE_START];
+      if (flip_time < D[QD_CROUCH_TIME]) p = c.qpos[7 + i] - M.key_qpos[I[QI_CROUCH] * M.nq + 7 + i];
+      else if (flip_time >= D[QD_CROUCH_TIME] && flip_time < D[QD_JUMP_TIME] + D[QD_FLIGHT_TIME]) p = 0;
+    }
+    int j = i % 3;
+    p *= (j == 0) ? 2.0 : 1.0;
+    if (mode == 1) {
+      int handstand = reinterpret_int(P[I[QI_BIPED_TYPE]]) != 0;
+      if (handstand) { if (i == 4 || i == 5 || i == 10 || i == 11) p *= 0.03; }
+      else { if (i == 1 || i == 2 || i == 7 || i == 8) p *= 0.03; }
+    }
+    residual[13 + nu + i] = p;
+  }
+  // ---- everything else: lane 0
+  if (LANE == 0) {
+    const double *xm = c.xmat + 9 * torso;
+    int k = 0;
+    if (mode != 4) {
+      if (mode == 1) { int hs = reinterpret_int(P[I[QI_BIPED_TYPE]]) ? -1 : 1; residual[k++] = xm[6] - hs; }
+      else residual[k++] = xm[8] - 1;
+      residual[k++] = 0; residual[k++] = 0;
+    } else {
+      double quat[4], r3[3];
+      q_flip_quat(D, P, I, quat, c.time - D[QD_MODE_START]);
+      d_subquat(r3, c.xquat + 4 * torso, quat);
+      residual[0] = r3[0]; residual[1] = r3[1]; residual[2] = r3[2]; k = 3;
+    }
+    if (mode == 3) residual[k++] = 0;
+    else if (mode == 4) residual[k++] = torso_pos[2] - q_flip_height(D, c.time - D[QD_MODE_START]);
+    else residual[k++] = (torso_pos[2] - avg[2]) - height_goal;
+    const double *head = c.site_xpos + 3 * I[QI_HEAD];
+    double target[3] = {goal_pos[0], goal_pos[1], goal_pos[2]};
+    if (mode == 2) {   // Walk(), quadruped.cc:619-636
+      double tm = c.time - D[QD_MODE_START];
+      if (fabs(D[QD_ANGVEL]) < 0.01) {
+        double fwd[2] = {D[QD_HEADING], D[QD_HEADING + 1]};
+        d_normalize2(fwd);
+        target[0] = D[QD_POSITION] + D[QD_HEADING] + tm * D[QD_SPEED] * fwd[0];
+        target[1] = D[QD_POSITION + 1] + D[QD_HEADING + 1] + tm * D[QD_SPEED] * fwd[1];
+      } else {
+        double angle = tm * D[QD_ANGVEL], cs = cos(angle), sn = sin(angle);
+        target[0] = cs * D[QD_HEADING] - sn * D[QD_HEADING + 1] + D[QD_POSITION];
+        target[1] = sn * D[QD_HEADING] + cs * D[QD_HEADING + 1] + D[QD_POSITION + 1];
+      }
+    }
+    residual[k++] = head[0] - target[0];
+    residual[k++] = head[1] - target[1];
+    residual[k++] = mode == 3 ? 2 * (head[2] - target[2]) : 0;
+    // Balance (2 at 11)
+    const double *compos = c.subtree_com + 3 * torso, *comvel = c.subtree_linvel + 3 * torso;
+    double fall_time = sqrt(2 * height_goal / 9.81);
+    residual[11] = compos[0] + comvel[0] * fall_time - avg[0];
+    residual[12] = compos[1] + comvel[1] * fall_time - avg[1];
+    // Yaw (2) and "Angmom" (3) after effort + posture
+    int o = 13 + 2 * nu;
+    double th[2] = {xm[0], xm[3]};
+    if (mode == 1) { int hs = reinterpret_int(P[I[QI_BIPED_TYPE]]) ? 1 : -1; th[0] = hs * xm[2]; th[1] = hs * xm[5]; }
+    d_normalize2(th);
+    double heading_goal = P[I[QI_HEADING]];
+    residual[o] = th[0] - cos(heading_goal);
+    residual[o + 1] = th[1] - sin(heading_goal);
+    residual[o + 2] = comvel[0]; residual[o + 3] = comvel[1]; residual[o + 4] = comvel[2];
+  }
+}
+
+DEV void task_residual(Ctx &c, double *residual) {
+  const DevModel &M = *c.M;
+  int id = M.task.task_id;
+  if (id == 0) {          // particle_residual.h:33-43
+    PFOR(i, M.nq) residual[i] = c.qpos[i] - (i < 2 ? c.mocap_pos[i] : 0.0);
+    PFOR(i, M.nv) residual[2 + i] = c.qvel[i];
+  } else if (id == 1) {   // cartpole.cc:36-49
+    if (LANE == 0) {
+      residual[0] = cos(c.qpos[1]) - 1;
+      residual[1] = c.qpos[0] - M.task.parameters[0];
+      residual[2] = c.qvel[1];
+      residual[3] = c.ctrl[0];
+    }
+  } else if (id == 3) {   // copy state (rollout_test.cc:40-60)
+    PFOR(i, M.nq) residual[i] = c.qpos[i];
+    PFOR(i, M.nv) residual[M.nq + i] = c.qvel[i];
+  } else if (id == 2) {
+    residual_quadruped(c, residual);
+  }
+  SYNC();
+}
+
+// ======================================================================================
+// cost: Norm (mjpc/norm.cc:50-210, value only) and CostValue (mjpc/task.cc:71-110)
+// ======================================================================================
+DEV double norm_value(const double *x, const double *params, int n, int type) {
+  double y = 0, p = params[0], q = params[1];
+  switch (type) {
+    case -1: y = x[0]; break;
+    case 0: for (int i = 0; i < n; i++) y += x[i] * x[i]; y *= 0.5; break;
+    case 1: { double cq = 0; for (int i = 0; i < n; i++) cq += x[i] * x[i];
+              double a = pow(cq, q / 2) + pow(p, q); y = pow(a, 1 / q) - p; break; }
+    case 2: { double s = 0; for (int i = 0; i < n; i++) s += x[i] * x[i]; y = sqrt(s + p * p) - p; break; }
+    case 3: for (int i = 0; i < n; i++) y += p * p * (cosh(x[i] / p) - 1.0); break;
+    case 5: for (int i = 0; i < n; i++) y += pow(fabs(x[i]), p); break;
+    case 6: for (int i = 0; i < n; i++) { double s = sqrt(x[i] * x[i] + p * p); y += s - p; } break;
+    case 7: for (int i = 0; i < n; i++) { double a = fabs(x[i]); double d = pow(a, q); double e = d + pow(p, q); y += pow(e, 1 / q) - p; } break;
+    case 8: for (int i = 0; i < n; i++) { if (p > 0) { double s = exp(x[i] / p); y += p * log(1 + s); } else y += x[i] > 0 ? x[i] : 0; } break;
+    default: break;
+  }
+  return y;
+}
+DEV double cost_value(Ctx &c, const double *residual) {
+  const DevTask &T = c.M->task;
+  PFOR(k, T.num_term) {
+    int fs = 0, ps = 0;
+    for (int j = 0; j < k; j++) { fs += T.dim_norm_residual[j]; ps += T.num_norm_parameter[j]; }
+    double prm[2] = {0, 0};
+    for (int j = 0; j < T.num_norm_parameter[k] && j < 2; j++) prm[j] = T.norm_parameter[ps + j];
+    c.terms[k] = T.weight[k] * norm_value(residual + fs, prm, T.dim_norm_residual[k], T.norm[k]);
+  }
+  SYNC();
+  double cost = 0;
+  for (int k = 0; k < T.num_term; k++) cost += c.terms[k];     // ascending k, like task.cc:99-102
+  SYNC();
+  if (fabs(T.risk) < 1e-6) return cost;
+  return (exp(T.risk * cost) - 1.0) / T.risk;
+}
+
+// ======================================================================================
+// mj_forward / mj_step
+// ======================================================================================
+DEV void forward(Ctx &c) {
+  kinematics(c);
+  com_pos(c);
+  crb_and_factor(c);
+  collision(c);
+  make_constraint(c);
+  velocity_stage(c);
+  make_impedance(c);
+  solve_constraints(c);
+  task_residual(c, c.residual);
+}
+
+DEV int bad_values(const double *x, int n) {
+  int b = 0;
+  PFOR(i, n) { double v = x[i]; if (!(v == v) || v > 1e10 || v < -1e10) b = 1; }
+  return wave_or_i(b);
+}
+
+DEV void integrate(Ctx &c) {
+  const DevModel &M = *c.M;
+  int nv = M.nv, nvp = M.nvp;
+  double h = M.timestep;
+  PFOR(i, nv) c.qacc_ws[i] = c.qacc[i];
+  if (M.any_damping) {
+    PFOR(e, nv * nvp) { int i = e / nvp, j = e - i * nvp; c.qH[e] = c.qM[e] + ((i == j) ? h * M.dof_damping[i] : 0.0); }
+    PFOR(i, nv) c.Mgrad[i] = c.qfrc_smooth[i] + c.qfrc_constraint[i];
+    chol_factor(c, c.qH, c.Hinv, nv, nvp);
+    chol_solve(c, c.qH, c.Hinv, c.Mgrad, nv, nvp);
+    PFOR(i, nv) c.qvel[i] += h * c.Mgrad[i];
+  } else {
+    PFOR(i, nv) c.qvel[i] += h * c.qacc[i];
+  }
+  SYNC();
+  PFOR(j, M.njnt) {
+    int qa = M.jnt_qposadr[j], da = M.jnt_dofadr[j], type = M.jnt_type[j];
+    if (type == 0) {
+      for (int k = 0; k < 3; k++) c.qpos[qa + k] += h * c.qvel[da + k];
+      d_quatintegrate(c.qpos + qa + 3, c.qvel + da + 3, h);
+    } else if (type == 1) {
+      d_quatintegrate(c.qpos + qa, c.qvel + da, h);
+    } else c.qpos[qa] += h * c.qvel[da];
+  }
+  c.time += h;
+  SYNC();
+}
+
+// ======================================================================================
+// the whole rollout of local candidate r  (trajectory.cc:100-210 + 312-326)
+// ======================================================================================
+DEV void rollout(const KParams *K, double *lds, int r) {
+  Ctx c;
+  ctx_init(c, K, lds);
+  const DevModel &M = K->M;
+  const DevTask &T = M.task;
+  int nq = M.nq, nv = M.nv, nu = M.nu, H = K->H, P = K->P;
+  int ds = nq + nv, nr = T.num_residual, ntr = 3 * T.num_trace;
+  int gi = K->offset + r;                     // global candidate index
+  double *states = K->states + (size_t)r * H * ds, *actions = K->actions + (size_t)r * H * nu;
+  double *times = K->times + (size_t)r * H, *residual = K->residual + (size_t)r * H * nr;
+  double *costs = K->costs + (size_t)r * H, *trace = K->trace + (size_t)r * H * ntr;
+  // ---- candidate policy: nominal knots + noise, clamped (planner.cc:313-339)
+  PFOR(p, P) c.knot_times[p] = K->knot_times[p];
+  double std = K->sigma0;
+  if (K->sigma1 > 0 && K->noise_sel[r]) std = K->sigma1;
+  PFOR(e, P * nu) {
+    int k = e % nu;
+    double v = K->knot_values[e];
+    double lo = M.actuator_ctrlrange[2 * k], hi = M.actuator_ctrlrange[2 * k + 1];
+    if (gi != 0) {
+      double scale = 0.5 * (hi - lo);
+      v = add_mul3_rn(v, scale, std, K->noise_eps[(size_t)r * P * nu + e]);   // bit-exact candidate policy
+      v = d_clip(v, lo, hi);
+    }
+    c.knot_values[e] = v;
+    K->knots[(size_t)r * P * nu + e] = v;
+  }
+  // ---- initial state (trajectory.cc:120-137)
+  PFOR(i, M.nmocap) {
+    d_copy3(c.mocap_pos + 3 * i, K->mocap + 7 * i);
+    d_copy4(c.mocap_quat + 4 * i, K->mocap + 7 * i + 3);
+  }
+  PFOR(i, nq) { c.qpos[i] = K->state[i]; states[i] = K->state[i]; }
+  PFOR(i, nv) { c.qvel[i] = K->state[nq + i]; states[nq + i] = K->state[nq + i]; c.qacc_ws[i] = 0; }
+  PFOR(e, nv * M.nvp) c.qM[e] = 0;
+  PFOR(k, nu) c.ctrl[k] = 0;      // data->ctrl after Reset (planner.cc:124-130); only visible when H == 1
+  if (LANE == 0) {
+    times[0] = K->time;
+    for (int k = 0; k < 3; k++) { c.xpos[k] = 0; c.xipos[k] = 0; c.subtree_linvel[k] = 0; }
+    c.xquat[0] = 1; c.xquat[1] = 0; c.xquat[2] = 0; c.xquat[3] = 0;
+    for (int k = 0; k < 9; k++) { c.xmat[k] = (k % 4 == 0) ? 1.0 : 0.0; c.ximat[k] = c.xmat[k]; }
+    for (int k = 0; k < 6; k++) { c.cvel[k] = 0; c.cfrc[k] = 0; c.cacc[k] = (k >= 3) ? -M.gravity[k - 3] : 0.0; }
+  }
+  c.time = K->time;
+  SYNC();
+  double total = 0;
+  int failure = 0, diag_iter = 0, diag_ncon = 0, diag_nefc = 0;
+  for (int t = 0; t < H; t++) {
+    int last = (t == H - 1);
+    if (!last) {
+      PFOR(k, nu) {
+        double a = spline_sample(c.knot_times, c.knot_values, P, nu, K->interp, c.time, k);
+        a = d_clip(a, M.actuator_ctrlrange[2 * k], M.actuator_ctrlrange[2 * k + 1]);
+        c.ctrl[k] = a; actions[t * nu + k] = a;
+      }
+      SYNC();
+      if (bad_values(c.qpos, nq)) c.warning |= WARN_BADQPOS;
+      if (bad_values(c.qvel, nv)) c.warning |= WARN_BADQVEL;
+      if (c.warning) { failure = 1; break; }
+    } else {
+      PFOR(k, nu) actions[t * nu + k] = (H > 1) ? c.ctrl[k] : 0.0;     // trajectory.cc:190-195
+    }
+    forward(c);
+    diag_iter += c.solver_iter; if (c.ncon > diag_ncon) diag_ncon = c.ncon; if (c.nefc > diag_nefc) diag_nefc = c.nefc;
+    PFOR(i, nr) residual[t * nr + i] = c.residual[i];
+    PFOR(i, T.num_trace) {
+      int id = T.trace_objid[i], ty = T.trace_objtype[i];
+      const double *src = ty == 6 ? c.site_xpos + 3 * id : (ty == 5 ? c.geom_xpos + 3 * id : (ty == 1 ? c.xipos + 3 * id : c.xpos + 3 * id));
+      d_copy3(trace + t * ntr + 3 * i, src);
+    }
+    if (!last) {
+      if (bad_values(c.qacc, nv)) c.warning |= WARN_BADQACC;
+      if (c.warning) { failure = 1; break; }
+      integrate(c);
+      PFOR(i, nq) states[(t + 1) * ds + i] = c.qpos[i];
+      PFOR(i, nv) states[(t + 1) * ds + nq + i] = c.qvel[i];
+      if (LANE == 0) times[t + 1] = c.time;
+    } else if (c.warning) { failure = 1; break; }
+    // UpdateReturn (trajectory.cc:312-326) folded into the loop: same left-to-right sum over t
+    double ct = cost_value(c, c.residual);
+    if (LANE == 0) costs[t] = ct;
+    total += ct;
+  }
+  if (LANE == 0) {
+    K->returns[r] = failure ? 1.0e6 : total / (H > 1 ? H : 1);
+    K->failure[r] = failure ? (c.warning ? c.warning : 1) : 0;
+    if (K->diag) { K->diag[4 * r] = diag_iter; K->diag[4 * r + 1] = diag_ncon; K->diag[4 * r + 2] = diag_nefc; K->diag[4 * r + 3] = c.warning; }
+  }
+}

@@ -1,0 +1,333 @@
+// engine.hip — HIP kernels + C ABI (include/mjpc_hip.h) of the Predictive-Sampling rollout engine.
+//
+// Kernels (gfx950, wave64):
+//   noise_kernel    Philox4x32-10 + Box-Muller standard normals  eps[nlocal, P, nu]
+//   rollout_kernel  ONE WAVEFRONT PER CANDIDATE (grid = nlocal blocks x 64 threads); the candidate's
+//                   whole mjData-equivalent lives in dynamic LDS for all H steps; HBM traffic is only
+//                   the Trajectory record (coalesced row writes by the owning wave) + model reads
+//                   that hit L2 / the scalar cache.  Replaces planner.cc:342-380 + trajectory.cc:100-210.
+//   argmin_kernel   wavefront (value, index) min-reduction, lowest index wins ties
+//                   (planner.cc:168-181 partial_sort -> trajectory_order[0]).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "core.h"
+#include "host.h"
+
+// ------------------------------------------------------------------------------ kernels
+extern "C" __global__ void __launch_bounds__(64) rollout_kernel(const KParams K) {
+  extern __shared__ __align__(16) double lds[];
+  int r = blockIdx.x;
+  if (r >= K.nlocal) return;
+  rollout(&K, lds, r);
+}
+
+__device__ inline void philox4x32_10(unsigned long long seed, unsigned long long stream, unsigned c0, unsigned c1, unsigned out[4]) {
+  unsigned c[4] = {c0, c1, (unsigned)stream, (unsigned)(stream >> 32)};
+  unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+  for (int r = 0; r < 10; r++) {
+    unsigned long long p0 = (unsigned long long)0xD2511F53u * c[0], p1 = (unsigned long long)0xCD9E8D57u * c[2];
+    unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k0, n1 = (unsigned)p1;
+    unsigned n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k1, n3 = (unsigned)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
+}
+
+// eps[r, e] for global candidate (offset + r), element e = p*nu + k; sel[r] = second-std choice
+extern "C" __global__ void noise_kernel(double *eps, int *sel, unsigned long long seed, unsigned long long stream,
+                                        int offset, int nlocal, int PN, double sigma1) {
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t total = (size_t)nlocal * PN;
+  if (idx < total) {
+    int r = (int)(idx / PN), e = (int)(idx - (size_t)r * PN);
+    unsigned o[4];
+    philox4x32_10(seed, stream, (unsigned)(offset + r), (unsigned)e, o);
+    unsigned long long x1 = ((unsigned long long)o[0] << 32) | o[1], x2 = ((unsigned long long)o[2] << 32) | o[3];
+    double u1 = (double)((x1 >> 11) + 1) * (1.0 / 9007199254740992.0);
+    double u2 = (double)(x2 >> 11) * (1.0 / 9007199254740992.0);
+    eps[idx] = sqrt(-2.0 * log(u1)) * cos(2.0 * 3.14159265358979323846 * u2);
+  }
+  if (idx < (size_t)nlocal) {
+    unsigned o[4];
+    philox4x32_10(seed, stream, (unsigned)(offset + (int)idx), 0xFFFFFFFFu, o);
+    unsigned long long x = ((unsigned long long)o[0] << 32) | o[1];
+    double u = (double)(x >> 11) * (1.0 / 9007199254740992.0);
+    sel[idx] = (sigma1 > 0 && u < 0.2) ? 1 : 0;
+  }
+}
+
+// winner[0] = local index of the first minimum of returns[0..n), winner_val[0] = its value
+extern "C" __global__ void __launch_bounds__(64) argmin_kernel(const double *returns, int n, int *winner, double *winner_val) {
+  int lane = threadIdx.x;
+  double best = 1.0e300; int bi = 0x7fffffff;
+  for (int i = lane; i < n; i += 64) { double v = returns[i]; if (v < best) { best = v; bi = i; } }   // strict <: keeps the lowest index per lane
+  for (int o = 32; o > 0; o >>= 1) {
+    double ov = __shfl_xor(best, o, 64); int oi = __shfl_xor(bi, o, 64);
+    if (ov < best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+  }
+  if (lane == 0) { winner[0] = bi; winner_val[0] = best; }
+}
+
+// ------------------------------------------------------------------------------ host side
+static thread_local std::string g_error;
+static void set_error(const std::string &s) { g_error = s; }
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error(std::string(#x) + ": " + hipGetErrorString(e_)); return -2; } } while (0)
+#define HIPCHKP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error(std::string(#x) + ": " + hipGetErrorString(e_)); return nullptr; } } while (0)
+
+struct MjpcHipEngine {
+  int device = 0;
+  PackedModel pm;
+  int *d_ib = nullptr; double *d_db = nullptr;
+  KParams K;
+  int max_local = 0, max_horizon = 0, P_max = 0;
+  int nq = 0, nv = 0, nu = 0, nmocap = 0, nr = 0, ntr = 0, ds = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  // device buffers
+  double *d_state = nullptr, *d_mocap = nullptr, *d_kt = nullptr, *d_kv = nullptr, *d_eps = nullptr;
+  int *d_sel = nullptr;
+  size_t eps_cap = 0;
+  double *d_states = nullptr, *d_actions = nullptr, *d_times = nullptr, *d_residual = nullptr, *d_costs = nullptr,
+         *d_trace = nullptr, *d_knots = nullptr, *d_returns = nullptr, *d_winner_val = nullptr;
+  size_t knots_cap = 0;
+  int *d_failure = nullptr, *d_diag = nullptr, *d_winner = nullptr;
+  // pinned host staging
+  double *h_small = nullptr;   // state | mocap | knot_times | knot_values
+  // last plan
+  int last_H = 0, last_P = 0, last_nlocal = 0, last_offset = 0, pending = 0;
+  // kernel timing accumulation
+  double acc_rollout_us = 0, acc_total_us = 0; int acc_n = 0;
+  size_t lds_bytes = 0;
+};
+
+static int upload_model(MjpcHipEngine *e) {
+  HIPCHK(hipMemcpy(e->d_ib, e->pm.ib.data(), e->pm.ib.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(e->d_db, e->pm.db.data(), e->pm.db.size() * sizeof(double), hipMemcpyHostToDevice));
+  e->K.M = mjpc_host::relocate(e->pm, e->d_ib, e->d_db);
+  e->K.L = e->pm.L;
+  return 0;
+}
+
+extern "C" {
+
+const char *mjpc_hip_last_error(void) { return g_error.c_str(); }
+int mjpc_hip_version(void) { return 1; }
+
+MjpcHipEngine *mjpc_hip_create(const MjpcHipModel *model, const MjpcHipTask *task, int max_local, int max_horizon, int device) {
+  if (!model || !task || max_local < 1 || max_horizon < 1 || max_horizon > MJPC_MAX_HORIZON) { set_error("mjpc_hip_create: invalid argument"); return nullptr; }
+  int ndev = 0;
+  HIPCHKP(hipGetDeviceCount(&ndev));
+  if (ndev < 1 || device < 0 || device >= ndev) { set_error("mjpc_hip_create: no such HIP device"); return nullptr; }
+  HIPCHKP(hipSetDevice(device));
+  MjpcHipEngine *e = new MjpcHipEngine();
+  e->device = device;
+  e->P_max = 64;     // MaxSamplingSplinePoints is 36 (mjpc/planners/sampling/planner.h:35-36)
+  if (!mjpc_host::build(e->pm, model, task, e->P_max)) { set_error("mjpc_hip_create: " + e->pm.error); delete e; return nullptr; }
+  memset(&e->K, 0, sizeof(e->K));
+  e->max_local = max_local; e->max_horizon = max_horizon;
+  e->nq = model->nq; e->nv = model->nv; e->nu = model->nu; e->nmocap = model->nmocap;
+  e->nr = task->num_residual; e->ntr = 3 * task->num_trace; e->ds = model->nq + model->nv;
+  e->lds_bytes = (size_t)e->pm.L.total_doubles * sizeof(double);
+  if (e->lds_bytes > 160 * 1024) { set_error("mjpc_hip_create: per-candidate state exceeds 160 KiB of LDS; lower nconmax/nefcmax"); delete e; return nullptr; }
+  HIPCHKP(hipMalloc(&e->d_ib, e->pm.ib.size() * sizeof(int)));
+  HIPCHKP(hipMalloc(&e->d_db, e->pm.db.size() * sizeof(double)));
+  if (upload_model(e) != 0) { delete e; return nullptr; }
+  HIPCHKP(hipStreamCreate(&e->stream));
+  for (int i = 0; i < 4; i++) HIPCHKP(hipEventCreate(&e->ev[i]));
+  size_t NL = (size_t)max_local, H = (size_t)max_horizon;
+  HIPCHKP(hipMalloc(&e->d_state, sizeof(double) * (e->ds + 1)));
+  HIPCHKP(hipMalloc(&e->d_mocap, sizeof(double) * (7 * e->nmocap + 7)));
+  HIPCHKP(hipMalloc(&e->d_kt, sizeof(double) * e->P_max));
+  HIPCHKP(hipMalloc(&e->d_kv, sizeof(double) * (e->P_max * e->nu + 1)));
+  HIPCHKP(hipMalloc(&e->d_sel, sizeof(int) * NL));
+  HIPCHKP(hipMalloc(&e->d_states, sizeof(double) * NL * H * e->ds));
+  HIPCHKP(hipMalloc(&e->d_actions, sizeof(double) * NL * H * (e->nu + 1)));
+  HIPCHKP(hipMalloc(&e->d_times, sizeof(double) * NL * H));
+  HIPCHKP(hipMalloc(&e->d_residual, sizeof(double) * NL * H * (e->nr + 1)));
+  HIPCHKP(hipMalloc(&e->d_costs, sizeof(double) * NL * H));
+  HIPCHKP(hipMalloc(&e->d_trace, sizeof(double) * NL * H * (e->ntr + 1)));
+  HIPCHKP(hipMalloc(&e->d_returns, sizeof(double) * NL));
+  HIPCHKP(hipMalloc(&e->d_failure, sizeof(int) * NL));
+  HIPCHKP(hipMalloc(&e->d_diag, sizeof(int) * NL * 4));
+  HIPCHKP(hipMalloc(&e->d_winner, sizeof(int) * 2));
+  HIPCHKP(hipMalloc(&e->d_winner_val, sizeof(double) * 2));
+  HIPCHKP(hipHostMalloc(&e->h_small, sizeof(double) * (e->ds + 7 * e->nmocap + e->P_max * (e->nu + 1) + 16)));
+  HIPCHKP(hipFuncSetAttribute((const void *)rollout_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_bytes));
+  return e;
+}
+
+void mjpc_hip_destroy(MjpcHipEngine *e) {
+  if (!e) return;
+  hipSetDevice(e->device);
+  if (e->stream) hipStreamSynchronize(e->stream);
+  void *bufs[] = {e->d_ib, e->d_db, e->d_state, e->d_mocap, e->d_kt, e->d_kv, e->d_eps, e->d_sel, e->d_states, e->d_actions,
+                  e->d_times, e->d_residual, e->d_costs, e->d_trace, e->d_knots, e->d_returns, e->d_failure, e->d_diag,
+                  e->d_winner, e->d_winner_val};
+  for (void *b : bufs) if (b) hipFree(b);
+  if (e->h_small) hipHostFree(e->h_small);
+  for (int i = 0; i < 4; i++) if (e->ev[i]) hipEventDestroy(e->ev[i]);
+  if (e->stream) hipStreamDestroy(e->stream);
+  delete e;
+}
+
+int mjpc_hip_set_task(MjpcHipEngine *e, const MjpcHipTask *task) {
+  if (!e || !task) { set_error("mjpc_hip_set_task: invalid argument"); return -1; }
+  HIPCHK(hipSetDevice(e->device));
+  if (task->num_residual != e->nr || 3 * task->num_trace != e->ntr) { set_error("mjpc_hip_set_task: residual/trace dimensions changed"); return -1; }
+  if (!mjpc_host::repack_task(e->pm, task)) { set_error("mjpc_hip_set_task: " + e->pm.error); return -1; }
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return upload_model(e);
+}
+
+int mjpc_hip_plan_async(MjpcHipEngine *e, const MjpcHipPlanInput *in) {
+  if (!e || !in) { set_error("mjpc_hip_plan: invalid argument"); return -1; }
+  int P = in->num_spline_points, H = in->horizon, nl = in->num_local, nu = e->nu;
+  if (P < 1 || P > e->P_max) { set_error("mjpc_hip_plan: num_spline_points out of range (1..64)"); return -1; }
+  if (H < 1 || H > e->max_horizon) { set_error("mjpc_hip_plan: horizon out of range"); return -1; }
+  if (nl < 1 || nl > e->max_local || in->candidate_offset < 0 || in->candidate_offset + nl > in->num_trajectory) { set_error("mjpc_hip_plan: candidate range out of bounds"); return -1; }
+  if (in->interpolation < 0 || in->interpolation > 2) { set_error("mjpc_hip_plan: unknown interpolation"); return -1; }
+  if (!in->state || !in->knot_times || !in->knot_values || (e->nmocap > 0 && !in->mocap)) { set_error("mjpc_hip_plan: null input"); return -1; }
+  HIPCHK(hipSetDevice(e->device));
+  size_t need = (size_t)nl * P * nu;
+  if (need > e->eps_cap) {
+    if (e->d_eps) HIPCHK(hipFree(e->d_eps));
+    HIPCHK(hipMalloc(&e->d_eps, sizeof(double) * (need + 1)));
+    e->eps_cap = need;
+  }
+  if (need > e->knots_cap) {
+    if (e->d_knots) HIPCHK(hipFree(e->d_knots));
+    HIPCHK(hipMalloc(&e->d_knots, sizeof(double) * ((size_t)e->max_local * P * nu + 1)));
+    e->knots_cap = (size_t)e->max_local * P * nu;
+  }
+  // small inputs through pinned staging
+  double *hs = e->h_small;
+  memcpy(hs, in->state, sizeof(double) * e->ds);
+  if (e->nmocap) memcpy(hs + e->ds, in->mocap, sizeof(double) * 7 * e->nmocap);
+  double *hkt = hs + e->ds + 7 * e->nmocap, *hkv = hkt + e->P_max;
+  memcpy(hkt, in->knot_times, sizeof(double) * P);
+  memcpy(hkv, in->knot_values, sizeof(double) * P * nu);
+  HIPCHK(hipMemcpyAsync(e->d_state, hs, sizeof(double) * e->ds, hipMemcpyHostToDevice, e->stream));
+  if (e->nmocap) HIPCHK(hipMemcpyAsync(e->d_mocap, hs + e->ds, sizeof(double) * 7 * e->nmocap, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipMemcpyAsync(e->d_kt, hkt, sizeof(double) * P, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipMemcpyAsync(e->d_kv, hkv, sizeof(double) * P * nu, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipEventRecord(e->ev[0], e->stream));
+  if (in->noise_eps) {
+    HIPCHK(hipMemcpyAsync(e->d_eps, in->noise_eps + (size_t)in->candidate_offset * P * nu, sizeof(double) * need, hipMemcpyHostToDevice, e->stream));
+    if (in->noise_sel) HIPCHK(hipMemcpyAsync(e->d_sel, in->noise_sel + in->candidate_offset, sizeof(int) * nl, hipMemcpyHostToDevice, e->stream));
+    else HIPCHK(hipMemsetAsync(e->d_sel, 0, sizeof(int) * nl, e->stream));
+  } else {
+    size_t total = need > (size_t)nl ? need : (size_t)nl;
+    int blocks = (int)((total + 255) / 256);
+    hipLaunchKernelGGL(noise_kernel, dim3(blocks), dim3(256), 0, e->stream, e->d_eps, e->d_sel, (unsigned long long)in->seed,
+                       (unsigned long long)in->stream, in->candidate_offset, nl, P * nu, in->noise_exploration[1]);
+  }
+  KParams &K = e->K;
+  K.state = e->d_state; K.mocap = e->d_mocap; K.knot_times = e->d_kt; K.knot_values = e->d_kv; K.noise_eps = e->d_eps; K.noise_sel = e->d_sel;
+  K.time = in->time; K.sigma0 = in->noise_exploration[0]; K.sigma1 = in->noise_exploration[1];
+  K.seed = in->seed; K.stream = in->stream;
+  K.P = P; K.interp = in->interpolation; K.H = H; K.N = in->num_trajectory; K.offset = in->candidate_offset; K.nlocal = nl;
+  K.use_device_noise = in->noise_eps ? 0 : 1;
+  K.states = e->d_states; K.actions = e->d_actions; K.times = e->d_times; K.residual = e->d_residual; K.costs = e->d_costs;
+  K.trace = e->d_trace; K.knots = e->d_knots; K.returns = e->d_returns; K.failure = e->d_failure; K.diag = e->d_diag;
+  HIPCHK(hipEventRecord(e->ev[1], e->stream));
+  hipLaunchKernelGGL(rollout_kernel, dim3(nl), dim3(64), e->lds_bytes, e->stream, K);
+  HIPCHK(hipEventRecord(e->ev[2], e->stream));
+  hipLaunchKernelGGL(argmin_kernel, dim3(1), dim3(64), 0, e->stream, e->d_returns, nl, e->d_winner, e->d_winner_val);
+  HIPCHK(hipEventRecord(e->ev[3], e->stream));
+  HIPCHK(hipGetLastError());
+  e->last_H = H; e->last_P = P; e->last_nlocal = nl; e->last_offset = in->candidate_offset; e->pending = 1;
+  return 0;
+}
+
+static int fetch_rows(MjpcHipEngine *e, int local, MjpcHipPlanOutput *out) {
+  size_t H = (size_t)e->last_H, P = (size_t)e->last_P, r = (size_t)local;
+  if (out->states) HIPCHK(hipMemcpyAsync(out->states, e->d_states + r * H * e->ds, sizeof(double) * H * e->ds, hipMemcpyDeviceToHost, e->stream));
+  if (out->actions) HIPCHK(hipMemcpyAsync(out->actions, e->d_actions + r * H * e->nu, sizeof(double) * H * e->nu, hipMemcpyDeviceToHost, e->stream));
+  if (out->times) HIPCHK(hipMemcpyAsync(out->times, e->d_times + r * H, sizeof(double) * H, hipMemcpyDeviceToHost, e->stream));
+  if (out->residual) HIPCHK(hipMemcpyAsync(out->residual, e->d_residual + r * H * e->nr, sizeof(double) * H * e->nr, hipMemcpyDeviceToHost, e->stream));
+  if (out->costs) HIPCHK(hipMemcpyAsync(out->costs, e->d_costs + r * H, sizeof(double) * H, hipMemcpyDeviceToHost, e->stream));
+  if (out->trace && e->ntr) HIPCHK(hipMemcpyAsync(out->trace, e->d_trace + r * H * e->ntr, sizeof(double) * H * e->ntr, hipMemcpyDeviceToHost, e->stream));
+  if (out->winner_knots) HIPCHK(hipMemcpyAsync(out->winner_knots, e->d_knots + r * P * e->nu, sizeof(double) * P * e->nu, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return 0;
+}
+
+int mjpc_hip_plan_fetch(MjpcHipEngine *e, MjpcHipPlanOutput *out) {
+  if (!e || !out || !e->last_nlocal) { set_error("mjpc_hip_plan_fetch: nothing planned"); return -1; }
+  HIPCHK(hipSetDevice(e->device));
+  int wl = 0; double wv = 0;
+  HIPCHK(hipMemcpyAsync(&wl, e->d_winner, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipMemcpyAsync(&wv, e->d_winner_val, sizeof(double), hipMemcpyDeviceToHost, e->stream));
+  if (out->returns) HIPCHK(hipMemcpyAsync(out->returns, e->d_returns, sizeof(double) * e->last_nlocal, hipMemcpyDeviceToHost, e->stream));
+  if (out->failure) HIPCHK(hipMemcpyAsync(out->failure, e->d_failure, sizeof(int) * e->last_nlocal, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  if (wl < 0 || wl >= e->last_nlocal) { set_error("mjpc_hip_plan_fetch: argmin out of range (all returns non-finite?)"); return -3; }
+  out->winner = e->last_offset + wl; out->winner_return = wv;
+  if (e->pending) {
+    float t01 = 0, t12 = 0, t03 = 0;
+    hipEventElapsedTime(&t01, e->ev[0], e->ev[1]); hipEventElapsedTime(&t12, e->ev[1], e->ev[2]); hipEventElapsedTime(&t03, e->ev[0], e->ev[3]);
+    out->noise_compute_time_us = 1e3 * t01; out->rollouts_compute_time_us = 1e3 * t12;
+    e->acc_rollout_us += 1e3 * t12; e->acc_total_us += 1e3 * t03; e->acc_n++;
+    e->pending = 0;
+  }
+  return fetch_rows(e, wl, out);
+}
+
+int mjpc_hip_plan(MjpcHipEngine *e, const MjpcHipPlanInput *in, MjpcHipPlanOutput *out) {
+  int rc = mjpc_hip_plan_async(e, in);
+  if (rc != 0) return rc;
+  return mjpc_hip_plan_fetch(e, out);
+}
+
+int mjpc_hip_get_candidate(MjpcHipEngine *e, int local_index, MjpcHipPlanOutput *out) {
+  if (!e || !out || local_index < 0 || local_index >= e->last_nlocal) { set_error("mjpc_hip_get_candidate: index out of range"); return -1; }
+  HIPCHK(hipSetDevice(e->device));
+  if (out->returns) HIPCHK(hipMemcpyAsync(out->returns, e->d_returns + local_index, sizeof(double), hipMemcpyDeviceToHost, e->stream));
+  if (out->failure) HIPCHK(hipMemcpyAsync(out->failure, e->d_failure + local_index, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+  out->winner = e->last_offset + local_index;
+  return fetch_rows(e, local_index, out);
+}
+
+int mjpc_hip_kernel_time(MjpcHipEngine *e, double *avg_rollout_us, double *avg_total_us) {
+  if (!e) return 0;
+  int n = e->acc_n;
+  if (avg_rollout_us) *avg_rollout_us = n ? e->acc_rollout_us / n : 0;
+  if (avg_total_us) *avg_total_us = n ? e->acc_total_us / n : 0;
+  e->acc_rollout_us = 0; e->acc_total_us = 0; e->acc_n = 0;
+  return n;
+}
+
+int mjpc_hip_device_ptrs(MjpcHipEngine *e, void **returns, void **states, void **residual) {
+  if (!e) return -1;
+  if (returns) *returns = e->d_returns;
+  if (states) *states = e->d_states;
+  if (residual) *residual = e->d_residual;
+  return 0;
+}
+
+// debug / test hook: copy every local candidate's arrays of the last plan to the host
+int mjpc_hip_debug_fetch_all(MjpcHipEngine *e, double *states, double *actions, double *times, double *residual,
+                             double *costs, double *trace, double *knots, int *diag) {
+  if (!e || !e->last_nlocal) return -1;
+  HIPCHK(hipSetDevice(e->device));
+  size_t n = (size_t)e->last_nlocal, H = (size_t)e->last_H, P = (size_t)e->last_P;
+  HIPCHK(hipStreamSynchronize(e->stream));
+  if (states) HIPCHK(hipMemcpy(states, e->d_states, sizeof(double) * n * H * e->ds, hipMemcpyDeviceToHost));
+  if (actions) HIPCHK(hipMemcpy(actions, e->d_actions, sizeof(double) * n * H * e->nu, hipMemcpyDeviceToHost));
+  if (times) HIPCHK(hipMemcpy(times, e->d_times, sizeof(double) * n * H, hipMemcpyDeviceToHost));
+  if (residual) HIPCHK(hipMemcpy(residual, e->d_residual, sizeof(double) * n * H * e->nr, hipMemcpyDeviceToHost));
+  if (costs) HIPCHK(hipMemcpy(costs, e->d_costs, sizeof(double) * n * H, hipMemcpyDeviceToHost));
+  if (trace && e->ntr) HIPCHK(hipMemcpy(trace, e->d_trace, sizeof(double) * n * H * e->ntr, hipMemcpyDeviceToHost));
+  if (knots) HIPCHK(hipMemcpy(knots, e->d_knots, sizeof(double) * n * P * e->nu, hipMemcpyDeviceToHost));
+  if (diag) HIPCHK(hipMemcpy(diag, e->d_diag, sizeof(int) * n * 4, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int mjpc_hip_lds_bytes(MjpcHipEngine *e) { return e ? (int)e->lds_bytes : 0; }
+
+}  // extern "C"

@@ -1,0 +1,226 @@
+// host.h — host-side model compilation shared by the HIP engine (engine.hip) and the 1-lane
+// emulation build used by the CPU test tier (tests/emu).  Flattens MjpcHipModel/MjpcHipTask into
+// one int32 and one fp64 buffer, derives the static tables the kernel needs, and computes the
+// LDS carve-up.
+#pragma once
+#include <stdint.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include "../../include/mjpc_hip.h"
+#include "model.h"
+
+struct PackedModel {
+  std::vector<int> ib;
+  std::vector<double> db;
+  DevModel M;          // pointer fields hold OFFSETS (as intptr) until relocate()
+  Lay L;
+  size_t task_i0, task_d0, task_i_cap, task_d_cap;   // task region inside ib/db
+  std::string error;
+};
+
+namespace mjpc_host {
+
+template <class T> static inline const T *as_off(size_t off) { return reinterpret_cast<const T *>(off * sizeof(T) + 1); }
+
+static inline size_t put_i(PackedModel &p, const int *src, size_t n) {
+  size_t o = p.ib.size();
+  for (size_t i = 0; i < n; i++) p.ib.push_back(src ? src[i] : 0);
+  if (n == 0) p.ib.push_back(0);
+  return o;
+}
+static inline size_t put_d(PackedModel &p, const double *src, size_t n) {
+  size_t o = p.db.size();
+  for (size_t i = 0; i < n; i++) p.db.push_back(src ? src[i] : 0.0);
+  if (n == 0) p.db.push_back(0.0);
+  return o;
+}
+
+// pack the task tables at the current end of ib/db and fill M.task with offsets
+static inline void pack_task(PackedModel &p, const MjpcHipTask *t) {
+  DevTask &T = p.M.task;
+  T.task_id = t->task_id; T.num_residual = t->num_residual; T.num_term = t->num_term; T.num_trace = t->num_trace;
+  T.num_parameter = t->num_parameter; T.num_int = t->num_int; T.num_dbl = t->num_dbl; T.risk = t->risk;
+  int np = 0;
+  for (int k = 0; k < t->num_term; k++) np += t->num_norm_parameter[k];
+  T.dim_norm_residual = as_off<int>(put_i(p, t->dim_norm_residual, t->num_term));
+  T.norm = as_off<int>(put_i(p, t->norm, t->num_term));
+  T.num_norm_parameter = as_off<int>(put_i(p, t->num_norm_parameter, t->num_term));
+  T.trace_objtype = as_off<int>(put_i(p, t->trace_objtype, t->num_trace));
+  T.trace_objid = as_off<int>(put_i(p, t->trace_objid, t->num_trace));
+  T.int_data = as_off<int>(put_i(p, t->int_data, t->num_int));
+  T.weight = as_off<double>(put_d(p, t->weight, t->num_term));
+  T.norm_parameter = as_off<double>(put_d(p, t->norm_parameter, np));
+  T.parameters = as_off<double>(put_d(p, t->parameters, t->num_parameter));
+  T.dbl_data = as_off<double>(put_d(p, t->dbl_data, t->num_dbl));
+}
+
+static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTask *t, int P_max) {
+  DevModel &M = p.M;
+  memset(&M, 0, sizeof(M));
+  int nb = m->nbody, nj = m->njnt, nv = m->nv, ng = m->ngeom, ns = m->nsite, nu = m->nu;
+  if (nv > 64) { p.error = "nv > 64 not supported (dof bitmask)"; return false; }
+  if (m->na != 0) { p.error = "activation states (na > 0) not supported"; return false; }
+  M.nq = m->nq; M.nv = nv; M.nu = nu; M.nbody = nb; M.njnt = nj; M.ngeom = ng; M.nsite = ns; M.nmocap = m->nmocap;
+  M.nkey = m->nkey; M.nvp = nv | 1;
+  M.cone = m->cone; M.iterations = m->iterations; M.ls_iterations = m->ls_iterations; M.disableflags = m->disableflags;
+  M.timestep = m->timestep; for (int k = 0; k < 3; k++) M.gravity[k] = m->gravity[k];
+  M.impratio = m->impratio; M.tolerance = m->tolerance; M.ls_tolerance = m->ls_tolerance; M.meaninertia = m->meaninertia;
+  M.nconmax = m->nconmax > 0 ? m->nconmax : 32;
+  if (M.nconmax > 64) M.nconmax = 64;
+  M.nefcmax = m->nefcmax > 0 ? m->nefcmax : 128;
+#define PI_(f, n) M.f = as_off<int>(put_i(p, m->f, (size_t)(n)))
+#define PD_(f, n) M.f = as_off<double>(put_d(p, m->f, (size_t)(n)))
+  PI_(body_parentid, nb); PI_(body_rootid, nb); PI_(body_mocapid, nb); PI_(body_jntnum, nb); PI_(body_jntadr, nb);
+  PI_(body_dofnum, nb); PI_(body_dofadr, nb);
+  PD_(body_pos, 3 * nb); PD_(body_quat, 4 * nb); PD_(body_ipos, 3 * nb); PD_(body_iquat, 4 * nb); PD_(body_mass, nb);
+  PD_(body_subtreemass, nb); PD_(body_inertia, 3 * nb); PD_(body_invweight0, 2 * nb);
+  PI_(jnt_type, nj); PI_(jnt_qposadr, nj); PI_(jnt_dofadr, nj); PI_(jnt_bodyid, nj);
+  PD_(jnt_pos, 3 * nj); PD_(jnt_axis, 3 * nj); PD_(jnt_stiffness, nj); PD_(jnt_range, 2 * nj); PD_(jnt_margin, nj);
+  PD_(jnt_solref, 2 * nj); PD_(jnt_solimp, 5 * nj); PD_(qpos0, m->nq); PD_(qpos_spring, m->nq);
+  PI_(dof_bodyid, nv); PI_(dof_parentid, nv);
+  PD_(dof_armature, nv); PD_(dof_damping, nv); PD_(dof_frictionloss, nv); PD_(dof_invweight0, nv);
+  PD_(dof_solref, 2 * nv); PD_(dof_solimp, 5 * nv);
+  PI_(geom_type, ng); PI_(geom_condim, ng); PI_(geom_bodyid, ng); PI_(geom_priority, ng);
+  PD_(geom_size, 3 * ng); PD_(geom_pos, 3 * ng); PD_(geom_quat, 4 * ng); PD_(geom_friction, 3 * ng); PD_(geom_solmix, ng);
+  PD_(geom_solref, 2 * ng); PD_(geom_solimp, 5 * ng); PD_(geom_margin, ng); PD_(geom_gap, ng); PD_(geom_rbound, ng);
+  PI_(site_bodyid, ns); PD_(site_pos, 3 * ns); PD_(site_quat, 4 * ns);
+  PI_(actuator_ctrllimited, nu); PI_(actuator_forcelimited, nu); PI_(actuator_biastype, nu);
+  PD_(actuator_gainprm, 3 * nu); PD_(actuator_biasprm, 3 * nu); PD_(actuator_gear, nu);
+  PD_(actuator_ctrlrange, 2 * nu); PD_(actuator_forcerange, 2 * nu);
+  PD_(key_qpos, (size_t)m->nkey * m->nq);
+#undef PI_
+#undef PD_
+  // actuator -> dof / qpos address (joint transmission)
+  { std::vector<int> da(nu), qa(nu);
+    for (int i = 0; i < nu; i++) { int j = m->actuator_trnid[i]; da[i] = m->jnt_dofadr[j]; qa[i] = m->jnt_qposadr[j]; }
+    M.actuator_dofadr = as_off<int>(put_i(p, da.data(), nu)); M.actuator_qposadr = as_off<int>(put_i(p, qa.data(), nu)); }
+  // bodies by depth
+  { std::vector<int> depth(nb, 0); int maxd = 0;
+    for (int b = 1; b < nb; b++) { depth[b] = depth[m->body_parentid[b]] + 1; if (depth[b] > maxd) maxd = depth[b]; }
+    std::vector<int> adr(maxd + 1, 0), list;
+    for (int l = 1; l <= maxd; l++) { adr[l - 1] = (int)list.size(); for (int b = 1; b < nb; b++) if (depth[b] == l) list.push_back(b); }
+    adr[maxd] = (int)list.size();
+    M.nlevel = maxd;
+    M.level_adr = as_off<int>(put_i(p, adr.data(), adr.size())); M.level_body = as_off<int>(put_i(p, list.data(), list.size())); }
+  // subtree lists
+  { std::vector<int> adr(nb + 1, 0), list;
+    for (int b = 0; b < nb; b++) {
+      adr[b] = (int)list.size();
+      for (int c = b; c < nb; c++) { int a = c; while (a > b) a = m->body_parentid[a]; if (a == b) list.push_back(c); }
+    }
+    adr[nb] = (int)list.size();
+    M.subtree_adr = as_off<int>(put_i(p, adr.data(), adr.size())); M.subtree_list = as_off<int>(put_i(p, list.data(), list.size())); }
+  // non-zeros of the joint-space inertia
+  { std::vector<int> pi, pj;
+    for (int i = 0; i < nv; i++) for (int j = i; j >= 0; j = m->dof_parentid[j]) { pi.push_back(i); pj.push_back(j); }
+    M.nmpair = (int)pi.size();
+    M.mpair_i = as_off<int>(put_i(p, pi.data(), pi.size())); M.mpair_j = as_off<int>(put_i(p, pj.data(), pj.size())); }
+  // dof chain bitmask per body
+  { std::vector<double> masks(nb);
+    for (int b = 0; b < nb; b++) {
+      unsigned long long mask = 0;
+      for (int a = b; a > 0; a = m->body_parentid[a])
+        for (int k = 0; k < m->body_dofnum[a]; k++) mask |= 1ull << (m->body_dofadr[a] + k);
+      memcpy(&masks[b], &mask, 8);
+    }
+    M.body_dofmask = reinterpret_cast<const unsigned long long *>(as_off<double>(put_d(p, masks.data(), nb))); }
+  // static collision filtering (same weld body, parent-child, <exclude>, contype/conaffinity)
+  { std::vector<int> g1s, g2s;
+    for (int a = 0; a < ng; a++) for (int b = a + 1; b < ng; b++) {
+      int g1 = a, g2 = b;
+      if (m->geom_type[g1] > m->geom_type[g2]) { g1 = b; g2 = a; }
+      int b1 = m->geom_bodyid[g1], b2 = m->geom_bodyid[g2];
+      int w1 = m->body_weldid[b1], w2 = m->body_weldid[b2];
+      if (w1 == w2) continue;
+      int pw1 = m->body_weldid[m->body_parentid[w1]], pw2 = m->body_weldid[m->body_parentid[w2]];
+      if (w1 != 0 && w2 != 0 && (w1 == pw2 || w2 == pw1)) continue;
+      bool excl = false;
+      for (int e = 0; e < m->nexclude; e++)
+        if (m->exclude_signature[e] == (b1 << 16) + b2 || m->exclude_signature[e] == (b2 << 16) + b1) excl = true;
+      if (excl) continue;
+      if (!((m->geom_contype[g1] & m->geom_conaffinity[g2]) || (m->geom_contype[g2] & m->geom_conaffinity[g1]))) continue;
+      if (m->geom_type[g1] == MJPC_GEOM_PLANE && m->geom_type[g2] == MJPC_GEOM_PLANE) continue;
+      g1s.push_back(g1); g2s.push_back(g2);
+    }
+    M.npair = (int)g1s.size();
+    M.pair_g1 = as_off<int>(put_i(p, g1s.data(), g1s.size())); M.pair_g2 = as_off<int>(put_i(p, g2s.data(), g2s.size())); }
+  { std::vector<int> fr, lim, ray;
+    for (int i = 0; i < nv; i++) if (m->dof_frictionloss[i] > 0) fr.push_back(i);
+    for (int j = 0; j < nj; j++) if (m->jnt_limited[j] && (m->jnt_type[j] == MJPC_JNT_SLIDE || m->jnt_type[j] == MJPC_JNT_HINGE)) lim.push_back(j);
+    for (int g = 0; g < ng; g++) if (m->geom_group[g] == 0) ray.push_back(g);
+    M.nfric = (int)fr.size(); M.nlimit = (int)lim.size(); M.nray = (int)ray.size();
+    M.fric_dof = as_off<int>(put_i(p, fr.data(), fr.size())); M.limit_jnt = as_off<int>(put_i(p, lim.data(), lim.size()));
+    M.ray_geom = as_off<int>(put_i(p, ray.data(), ray.size())); }
+  M.any_damping = 0;
+  for (int i = 0; i < nv; i++) if (m->dof_damping[i] > 0) M.any_damping = 1;
+  if (M.nefcmax < M.nfric + 2) M.nefcmax = M.nfric + 2;
+  // task region last (re-packable by set_task)
+  p.task_i0 = p.ib.size(); p.task_d0 = p.db.size();
+  pack_task(p, t);
+  p.task_i_cap = p.ib.size() - p.task_i0; p.task_d_cap = p.db.size() - p.task_d0;
+  // ---- LDS layout
+  Lay &L = p.L;
+  int o = 0;
+  int nvp = M.nvp, ne = M.nefcmax, nc = M.nconmax, nr = t->num_residual;
+#define A_(f, n) L.f = o; o += (int)(n)
+  A_(qpos, m->nq); A_(qvel, nv); A_(ctrl, nu + 1); A_(qacc, nv); A_(qacc_ws, nv); A_(qacc_smooth, nv); A_(qfrc_smooth, nv);
+  A_(qfrc_bias, nv); A_(qfrc_constraint, nv); A_(actuator_force, nu + 1); A_(mocap_pos, 3 * m->nmocap + 3); A_(mocap_quat, 4 * m->nmocap + 4);
+  A_(xpos, 3 * nb); A_(xquat, 4 * nb); A_(xmat, 9 * nb); A_(xipos, 3 * nb); A_(ximat, 9 * nb); A_(xanchor, 3 * nj + 3); A_(xaxis, 3 * nj + 3);
+  A_(geom_xpos, 3 * ng + 3); A_(geom_xmat, 9 * ng + 9); A_(site_xpos, 3 * ns + 3);
+  A_(subtree_com, 3 * nb); A_(cinert, 10 * nb); A_(crb, 10 * nb); A_(cdof, 6 * nv + 18); A_(cvel, 6 * nb); A_(cdof_dot, 6 * nv + 18);
+  A_(cacc, 6 * nb); A_(cfrc, 6 * nb); A_(cfrc_sub, 6 * nb); A_(subtree_linvel, 3 * nb); A_(bodytmp, 3 * nb);
+  A_(qM, nv * nvp + 1); A_(qL, nv * nvp + 1); A_(qH, nv * nvp + 1); A_(Linv, nv + 1); A_(Hinv, nv + 1);
+  A_(efc_J, ne * nvp + 1); A_(efc_D, ne); A_(efc_R, ne); A_(efc_aref, ne); A_(efc_force, ne); A_(efc_jar, ne); A_(efc_jv, ne);
+  A_(efc_floss, ne); A_(efc_pos, ne); A_(efc_margin, ne); A_(efc_diag, ne);
+  A_(contact, nc * CON_STRIDE + 1);
+  A_(Ma, nv + 1); A_(grad, nv + 1); A_(Mgrad, nv + 1); A_(search, nv + 1); A_(Mv, nv + 1); A_(vtmp, nv + 1);
+  A_(knot_times, P_max); A_(knot_values, P_max * nu + 1); A_(residual, nr + 1); A_(terms, t->num_term + 1); A_(red, 8);
+  L.ints = o;
+#undef A_
+  int io = 0;
+  L.i_efc_type = io; io += ne; L.i_efc_id = io; io += ne; L.i_efc_state = io; io += ne;
+  L.i_con = io; io += nc * CONI_STRIDE; L.i_active = io; io += MAX_ACTIVE_PAIRS; L.i_misc = io; io += 8;
+  L.total_doubles = o + (io + 1) / 2;
+  return true;
+}
+
+// turn offsets into real pointers for buffers living at (ibase, dbase)
+static inline DevModel relocate(const PackedModel &p, const int *ibase, const double *dbase) {
+  DevModel M = p.M;
+  auto fi = [&](const int *&q) { size_t off = (reinterpret_cast<size_t>(q) - 1) / sizeof(int); q = ibase + off; };
+  auto fd = [&](const double *&q) { size_t off = (reinterpret_cast<size_t>(q) - 1) / sizeof(double); q = dbase + off; };
+  fi(M.body_parentid); fi(M.body_rootid); fi(M.body_mocapid); fi(M.body_jntnum); fi(M.body_jntadr); fi(M.body_dofnum); fi(M.body_dofadr);
+  fd(M.body_pos); fd(M.body_quat); fd(M.body_ipos); fd(M.body_iquat); fd(M.body_mass); fd(M.body_subtreemass); fd(M.body_inertia); fd(M.body_invweight0);
+  fi(M.jnt_type); fi(M.jnt_qposadr); fi(M.jnt_dofadr); fi(M.jnt_bodyid);
+  fd(M.jnt_pos); fd(M.jnt_axis); fd(M.jnt_stiffness); fd(M.jnt_range); fd(M.jnt_margin); fd(M.jnt_solref); fd(M.jnt_solimp); fd(M.qpos0); fd(M.qpos_spring);
+  fi(M.dof_bodyid); fi(M.dof_parentid);
+  fd(M.dof_armature); fd(M.dof_damping); fd(M.dof_frictionloss); fd(M.dof_invweight0); fd(M.dof_solref); fd(M.dof_solimp);
+  fi(M.geom_type); fi(M.geom_condim); fi(M.geom_bodyid); fi(M.geom_priority);
+  fd(M.geom_size); fd(M.geom_pos); fd(M.geom_quat); fd(M.geom_friction); fd(M.geom_solmix); fd(M.geom_solref); fd(M.geom_solimp);
+  fd(M.geom_margin); fd(M.geom_gap); fd(M.geom_rbound);
+  fi(M.site_bodyid); fd(M.site_pos); fd(M.site_quat);
+  fi(M.actuator_dofadr); fi(M.actuator_qposadr); fi(M.actuator_ctrllimited); fi(M.actuator_forcelimited); fi(M.actuator_biastype);
+  fd(M.actuator_gainprm); fd(M.actuator_biasprm); fd(M.actuator_gear); fd(M.actuator_ctrlrange); fd(M.actuator_forcerange);
+  fd(M.key_qpos);
+  fi(M.level_adr); fi(M.level_body); fi(M.subtree_adr); fi(M.subtree_list); fi(M.mpair_i); fi(M.mpair_j);
+  { const double *q = reinterpret_cast<const double *>(M.body_dofmask); fd(q); M.body_dofmask = reinterpret_cast<const unsigned long long *>(q); }
+  fi(M.pair_g1); fi(M.pair_g2); fi(M.fric_dof); fi(M.limit_jnt); fi(M.ray_geom);
+  DevTask &T = M.task;
+  fi(T.dim_norm_residual); fi(T.norm); fi(T.num_norm_parameter); fi(T.trace_objtype); fi(T.trace_objid); fi(T.int_data);
+  fd(T.weight); fd(T.norm_parameter); fd(T.parameters); fd(T.dbl_data);
+  return M;
+}
+
+// re-pack the task into the reserved region (sizes must not exceed the initial ones)
+static inline bool repack_task(PackedModel &p, const MjpcHipTask *t) {
+  std::vector<int> ib_save(p.ib.begin(), p.ib.begin() + p.task_i0);
+  std::vector<double> db_save(p.db.begin(), p.db.begin() + p.task_d0);
+  p.ib.resize(p.task_i0); p.db.resize(p.task_d0);
+  pack_task(p, t);
+  if (p.ib.size() - p.task_i0 > p.task_i_cap || p.db.size() - p.task_d0 > p.task_d_cap) { p.error = "task grew beyond the size given at create()"; return false; }
+  p.ib.resize(p.task_i0 + p.task_i_cap, 0); p.db.resize(p.task_d0 + p.task_d_cap, 0.0);
+  return true;
+}
+
+}  // namespace mjpc_host

@@ -1,0 +1,91 @@
+// model.h — device-side model / task description, LDS layout and kernel parameter block.
+//
+// HBM layout: the model is two flat device buffers (one int32, one fp64) plus this struct of
+// pointers into them; it is read-only, shared by every candidate and stays L2/scalar-cache
+// resident.  Per-candidate mutable state ("mjData") is NOT in HBM: it lives in LDS for the whole
+// horizon (Lay gives the carve-up); only the Trajectory record (states/actions/times/residual/
+// costs/trace per step, mjpc/trajectory.h:74-86) is streamed out, row-major per candidate.
+#pragma once
+#include <stdint.h>
+
+#define CON_STRIDE 63          // doubles per contact in LDS (odd: conflict-free field access)
+#define CON_DIST 0
+#define CON_POS 1
+#define CON_FRAME 4
+#define CON_INCLUDEMARGIN 13
+#define CON_FRICTION 14
+#define CON_SOLREF 19
+#define CON_SOLIMP 21
+#define CON_MU 26
+#define CON_H 27
+#define CONI_STRIDE 4          // ints per contact: dim, geom1, geom2, efc_address
+#define MAX_ACTIVE_PAIRS 192
+
+enum { CNSTR_FRICTION_DOF = 1, CNSTR_LIMIT_JOINT = 3, CNSTR_CONTACT_FRICTIONLESS = 5, CNSTR_CONTACT_ELLIPTIC = 7 };
+enum { STATE_SATISFIED = 0, STATE_QUADRATIC = 1, STATE_LINEARNEG = 2, STATE_LINEARPOS = 3, STATE_CONE = 4 };
+enum { WARN_BADQPOS = 1, WARN_BADQVEL = 2, WARN_BADQACC = 4, WARN_CONTACTFULL = 8, WARN_CNSTRFULL = 16, WARN_RAY = 32 };
+
+struct DevTask {
+  int task_id, num_residual, num_term, num_trace, num_parameter, num_int, num_dbl;
+  double risk;
+  const int *dim_norm_residual, *norm, *num_norm_parameter, *trace_objtype, *trace_objid, *int_data;
+  const double *weight, *norm_parameter, *parameters, *dbl_data;
+};
+
+struct DevModel {
+  int nq, nv, nu, nbody, njnt, ngeom, nsite, nmocap, nkey, nvp;
+  int nlevel, npair, nfric, nlimit, nray, nmpair, nconmax, nefcmax, any_damping;
+  int cone, iterations, ls_iterations, disableflags;
+  double timestep, gravity[3], impratio, tolerance, ls_tolerance, meaninertia;
+  const int *body_parentid, *body_rootid, *body_mocapid, *body_jntnum, *body_jntadr, *body_dofnum, *body_dofadr;
+  const double *body_pos, *body_quat, *body_ipos, *body_iquat, *body_mass, *body_subtreemass, *body_inertia, *body_invweight0;
+  const int *jnt_type, *jnt_qposadr, *jnt_dofadr, *jnt_bodyid;
+  const double *jnt_pos, *jnt_axis, *jnt_stiffness, *jnt_range, *jnt_margin, *jnt_solref, *jnt_solimp, *qpos0, *qpos_spring;
+  const int *dof_bodyid, *dof_parentid;
+  const double *dof_armature, *dof_damping, *dof_frictionloss, *dof_invweight0, *dof_solref, *dof_solimp;
+  const int *geom_type, *geom_condim, *geom_bodyid, *geom_priority;
+  const double *geom_size, *geom_pos, *geom_quat, *geom_friction, *geom_solmix, *geom_solref, *geom_solimp, *geom_margin, *geom_gap, *geom_rbound;
+  const int *site_bodyid;
+  const double *site_pos, *site_quat;
+  const int *actuator_dofadr, *actuator_qposadr, *actuator_ctrllimited, *actuator_forcelimited, *actuator_biastype;
+  const double *actuator_gainprm, *actuator_biasprm, *actuator_gear, *actuator_ctrlrange, *actuator_forcerange;
+  const double *key_qpos;
+  // derived on the host at create()
+  const int *level_adr, *level_body;        // bodies grouped by tree depth (depth >= 1)
+  const int *subtree_adr, *subtree_list;    // bodies of each subtree, self first, ascending ids
+  const int *mpair_i, *mpair_j;             // (dof i, ancestor-or-self dof j): the non-zeros of M
+  const unsigned long long *body_dofmask;   // bit d set <=> dof d moves body
+  const int *pair_g1, *pair_g2;             // statically filtered geom pairs (type1 <= type2)
+  const int *fric_dof, *limit_jnt, *ray_geom;
+  DevTask task;
+};
+
+// LDS carve-up, offsets in doubles (ints live behind `ints`, offsets in ints)
+struct Lay {
+  int qpos, qvel, ctrl, qacc, qacc_ws, qacc_smooth, qfrc_smooth, qfrc_bias, qfrc_constraint, actuator_force;
+  int mocap_pos, mocap_quat;
+  int xpos, xquat, xmat, xipos, ximat, xanchor, xaxis, geom_xpos, geom_xmat, site_xpos;
+  int subtree_com, cinert, crb, cdof, cvel, cdof_dot, cacc, cfrc, cfrc_sub, subtree_linvel, bodytmp;
+  int qM, qL, qH, Linv, Hinv;
+  int efc_J, efc_D, efc_R, efc_aref, efc_force, efc_jar, efc_jv, efc_floss, efc_pos, efc_margin, efc_diag;
+  int contact;
+  int Ma, grad, Mgrad, search, Mv, vtmp;
+  int knot_times, knot_values, residual, terms, red;
+  int ints;            // start of the int region (in doubles)
+  int i_efc_type, i_efc_id, i_efc_state, i_con, i_active, i_misc;
+  int total_doubles;   // LDS bytes = 8 * total_doubles
+};
+
+struct KParams {
+  DevModel M;
+  Lay L;
+  // plan inputs (device pointers)
+  const double *state, *mocap, *knot_times, *knot_values, *noise_eps;
+  const int *noise_sel;
+  double time, sigma0, sigma1;
+  unsigned long long seed, stream;
+  int P, interp, H, N, offset, nlocal, use_device_noise;
+  // outputs (device), row-major per local candidate
+  double *states, *actions, *times, *residual, *costs, *trace, *knots, *returns;
+  int *failure, *diag;
+};

@@ -223,6 +223,24 @@ class HipBackend:
         o["trace"] = o["trace"][:, :ntr]
         return o
 
+    def fetch_all(self, nl, H, P):
+        """Every local candidate's Trajectory arrays of the last plan (tests / GUI traces)."""
+        m, t = self.model, self.task
+        ds = m["nq"] + m["nv"] + m["na"]; nu = m["nu"]; nr = t["num_residual"]; ntr = 3 * t["num_trace"]
+        o = dict(states=np.zeros((nl, H, ds)), actions=np.zeros((nl, H, nu)), times=np.zeros((nl, H)),
+                 residual=np.zeros((nl, H, nr)), costs=np.zeros((nl, H)), trace=np.zeros((nl, H, max(ntr, 1))),
+                 knots=np.zeros((nl, P, nu)), diag=np.zeros((nl, 4), np.int32))
+        rc = self.lib.mjpc_hip_debug_fetch_all(self.h, *[o[k].ctypes.data_as(capi.c_double_p) for k in
+                                                         ["states", "actions", "times", "residual", "costs", "trace", "knots"]],
+                                               o["diag"].ctypes.data_as(capi.c_int_p))
+        if rc != 0:
+            raise RuntimeError(self.lib.mjpc_hip_last_error().decode())
+        o["trace"] = o["trace"][:, :, :ntr]
+        return o
+
+    def lds_bytes(self):
+        return self.lib.mjpc_hip_lds_bytes(self.h)
+
     def kernel_time(self):
         a = C.c_double(0); b = C.c_double(0)
         n = self.lib.mjpc_hip_kernel_time(self.h, C.byref(a), C.byref(b))

@@ -692,19 +692,33 @@ static double line_search(const OModel *om, OData *d, double cost0_gauss) {
   quad[2] = 0.5 * o_dot(d->search, d->Mv, nv);
   LSPoint p0 = ls_eval(om, d, d->efc_jar, d->efc_jv, quad, 0);
   if (!(p0.d2 > 0) || p0.d1 >= 0) return 0;
+  /* safeguarded Newton on phi'(alpha) (rtsafe): expand until phi' changes sign, then Newton steps that
+   * stay inside the bracket and at least halve the previous step, else bisection; return the best point */
   double lo = 0, hi = -1;   /* hi < 0: no upper bracket yet */
   double a = -p0.d1 / p0.d2;
+  double best_a = 0, best_cost = p0.cost, dxold = a, dx = a;
   for (int it = 0; it < m->ls_iterations; it++) {
     LSPoint p = ls_eval(om, d, d->efc_jar, d->efc_jv, quad, a);
+    if (p.cost < best_cost) { best_cost = p.cost; best_a = a; }
     if (fabs(p.d1) < gtol) break;
     if (p.d1 < 0) lo = a; else hi = a;
-    double an = (p.d2 > 0) ? a - p.d1 / p.d2 : -1;
-    if (hi >= 0) { if (!(an > lo && an < hi)) an = 0.5 * (lo + hi); }
-    else if (!(an > lo)) an = 2 * a;
+    double an;
+    if (hi < 0) {
+      an = (p.d2 > 0) ? a - p.d1 / p.d2 : 2 * a;
+      if (!(an > a)) an = 2 * a;
+      dxold = dx; dx = an - a;
+    } else {
+      double nw = (p.d2 > 0) ? a - p.d1 / p.d2 : lo - 1;
+      int ok = (nw > lo) && (nw < hi) && (fabs(2 * p.d1) <= fabs(dxold * p.d2));
+      dxold = dx;
+      if (ok) { dx = fabs(nw - a); an = nw; }
+      else { dx = 0.5 * (hi - lo); an = lo + dx; }
+    }
     if (an == a) break;
     a = an;
   }
-  return a;
+  if (getenv("ORACLE_DEBUG_SOLVER")) fprintf(stderr, "    ls: p0 cost %.10g d1 %.4g | best a %.6g cost %.10g lo %.4g hi %.4g\n", p0.cost, p0.d1, best_a, best_cost, lo, hi);
+  return best_a;
 }
 
 static void newton_gradient(const OModel *om, OData *d) {
@@ -777,6 +791,7 @@ static void solve_constraints(const OModel *om, OData *d) {
     d->solver_iter++;
     double improvement = scale * (oldcost - cost);
     double gradient = scale * o_norm(d->grad, nv);
+    if (getenv("ORACLE_DEBUG_SOLVER")) fprintf(stderr, "  iter %d alpha %.6g cost %.12g improvement %.3g gradient %.3g\n", iter, alpha, cost, improvement, gradient);
     if (improvement < m->tolerance || gradient < m->tolerance) break;
     for (int i = 0; i < nv; i++) d->search[i] = -d->Mgrad[i];
   }

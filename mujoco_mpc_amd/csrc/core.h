@@ -12,7 +12,17 @@
 #include "dmath.h"
 #include "model.h"
 
+#if defined(MJPC_PROFILE) && !defined(MJPC_EMU)
+#define NPROF 24
+#define PROF(c, i) do { long long t_ = (long long)__builtin_amdgcn_s_memtime(); (c).prof[i] += t_ - (c).tlast; (c).tlast = t_; } while (0)
+#else
+#define PROF(c, i) ((void)0)
+#endif
+
 struct Ctx {
+#if defined(MJPC_PROFILE) && !defined(MJPC_EMU)
+  long long prof[NPROF]; long long tlast;
+#endif
   const DevModel *M;
   const KParams *K;
   double *qpos, *qvel, *ctrl, *qacc, *qacc_ws, *qacc_smooth, *qfrc_smooth, *qfrc_bias, *qfrc_constraint, *actuator_force;
@@ -985,8 +995,11 @@ DEV void newton_gradient(Ctx &c) {
     }
     c.qH[i * nvp + j] = h;
   }
+  PROF(c, 15);
   chol_factor(c, c.qH, c.Hinv, nv, nvp);
+  PROF(c, 16);
   chol_solve(c, c.qH, c.Hinv, c.Mgrad, nv, nvp);
+  PROF(c, 17);
 }
 
 // exact 1-D line search along `search`: safeguarded Newton on phi'(alpha)
@@ -1098,23 +1111,28 @@ DEV void solve_constraints(Ctx &c) {
     SYNC();
     return;
   }
+  PROF(c, 7);
   double cost_ws = solver_eval(c, c.qacc_ws, 0);
   double cost_sm = solver_eval(c, c.qacc_smooth, 0);
   PFOR(i, nv) c.qacc[i] = (cost_ws > cost_sm) ? c.qacc_smooth[i] : c.qacc_ws[i];
   SYNC();
   double gauss;
   double cost = solver_eval(c, c.qacc, &gauss);
+  PROF(c, 12);
   newton_gradient(c);
   PFOR(i, nv) c.search[i] = -c.Mgrad[i];
   SYNC();
   double scale = 1.0 / (M.meaninertia * (nv > 1 ? nv : 1));
   for (int iter = 0; iter < M.iterations; iter++) {
+    PROF(c, 13);
     double alpha = line_search(c, gauss);
+    PROF(c, 14);
     if (alpha == 0) break;
     PFOR(i, nv) c.qacc[i] += alpha * c.search[i];
     SYNC();
     double oldcost = cost;
     cost = solver_eval(c, c.qacc, &gauss);
+    PROF(c, 12);
     newton_gradient(c);
     c.solver_iter++;
     double pg = 0;
@@ -1426,15 +1444,16 @@ DEV double cost_value(Ctx &c, const double *residual) {
 // mj_forward / mj_step
 // ======================================================================================
 DEV void forward(Ctx &c) {
-  kinematics(c);
-  com_pos(c);
-  crb_and_factor(c);
-  collision(c);
-  make_constraint(c);
-  velocity_stage(c);
-  make_impedance(c);
-  solve_constraints(c);
-  task_residual(c, c.residual);
+  PROF(c, 0);
+  kinematics(c); PROF(c, 1);
+  com_pos(c); PROF(c, 2);
+  crb_and_factor(c); PROF(c, 3);
+  collision(c); PROF(c, 4);
+  make_constraint(c); PROF(c, 5);
+  velocity_stage(c); PROF(c, 6);
+  make_impedance(c); PROF(c, 7);
+  solve_constraints(c); PROF(c, 8);
+  task_residual(c, c.residual); PROF(c, 9);
 }
 
 DEV int bad_values(const double *x, int n) {
@@ -1521,6 +1540,10 @@ DEV void rollout(const KParams *K, double *lds, int r) {
   SYNC();
   double total = 0;
   int failure = 0, diag_iter = 0, diag_ncon = 0, diag_nefc = 0;
+#if defined(MJPC_PROFILE) && !defined(MJPC_EMU)
+  for (int q = 0; q < NPROF; q++) c.prof[q] = 0;
+  c.tlast = (long long)__builtin_amdgcn_s_memtime();
+#endif
   for (int t = 0; t < H; t++) {
     int last = (t == H - 1);
     if (!last) {
@@ -1547,7 +1570,9 @@ DEV void rollout(const KParams *K, double *lds, int r) {
     if (!last) {
       if (bad_values(c.qacc, nv)) c.warning |= WARN_BADQACC;
       if (c.warning) { failure = 1; break; }
+      PROF(c, 10);
       integrate(c);
+      PROF(c, 11);
       PFOR(i, nq) states[(t + 1) * ds + i] = c.qpos[i];
       PFOR(i, nv) states[(t + 1) * ds + nq + i] = c.qvel[i];
       if (LANE == 0) times[t + 1] = c.time;
@@ -1560,6 +1585,9 @@ DEV void rollout(const KParams *K, double *lds, int r) {
   if (LANE == 0) {
     K->returns[r] = failure ? 1.0e6 : total / (H > 1 ? H : 1);
     K->failure[r] = failure ? (c.warning ? c.warning : 1) : 0;
+#if defined(MJPC_PROFILE) && !defined(MJPC_EMU)
+    if (K->prof) for (int q = 0; q < NPROF; q++) K->prof[(size_t)r * NPROF + q] = c.prof[q];
+#endif
     if (K->diag) { K->diag[4 * r] = diag_iter; K->diag[4 * r + 1] = diag_ncon; K->diag[4 * r + 2] = diag_nefc; K->diag[4 * r + 3] = c.warning; }
   }
 }

@@ -96,6 +96,7 @@ struct MjpcHipEngine {
          *d_trace = nullptr, *d_knots = nullptr, *d_returns = nullptr, *d_winner_val = nullptr;
   size_t knots_cap = 0;
   int *d_failure = nullptr, *d_diag = nullptr, *d_winner = nullptr;
+  long long *d_prof = nullptr;
   // pinned host staging
   double *h_small = nullptr;   // state | mocap | knot_times | knot_values
   // last plan
@@ -155,6 +156,8 @@ MjpcHipEngine *mjpc_hip_create(const MjpcHipModel *model, const MjpcHipTask *tas
   HIPCHKP(hipMalloc(&e->d_failure, sizeof(int) * NL));
   HIPCHKP(hipMalloc(&e->d_diag, sizeof(int) * NL * 4));
   HIPCHKP(hipMalloc(&e->d_winner, sizeof(int) * 2));
+  HIPCHKP(hipMalloc(&e->d_prof, sizeof(long long) * NL * 24));
+  HIPCHKP(hipMemset(e->d_prof, 0, sizeof(long long) * NL * 24));
   HIPCHKP(hipMalloc(&e->d_winner_val, sizeof(double) * 2));
   HIPCHKP(hipHostMalloc(&e->h_small, sizeof(double) * (e->ds + 7 * e->nmocap + e->P_max * (e->nu + 1) + 16)));
   HIPCHKP(hipFuncSetAttribute((const void *)rollout_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_bytes));
@@ -167,7 +170,7 @@ void mjpc_hip_destroy(MjpcHipEngine *e) {
   if (e->stream) hipStreamSynchronize(e->stream);
   void *bufs[] = {e->d_ib, e->d_db, e->d_state, e->d_mocap, e->d_kt, e->d_kv, e->d_eps, e->d_sel, e->d_states, e->d_actions,
                   e->d_times, e->d_residual, e->d_costs, e->d_trace, e->d_knots, e->d_returns, e->d_failure, e->d_diag,
-                  e->d_winner, e->d_winner_val};
+                  e->d_winner, e->d_winner_val, e->d_prof};
   for (void *b : bufs) if (b) hipFree(b);
   if (e->h_small) hipHostFree(e->h_small);
   for (int i = 0; i < 4; i++) if (e->ev[i]) hipEventDestroy(e->ev[i]);
@@ -233,7 +236,7 @@ int mjpc_hip_plan_async(MjpcHipEngine *e, const MjpcHipPlanInput *in) {
   K.P = P; K.interp = in->interpolation; K.H = H; K.N = in->num_trajectory; K.offset = in->candidate_offset; K.nlocal = nl;
   K.use_device_noise = in->noise_eps ? 0 : 1;
   K.states = e->d_states; K.actions = e->d_actions; K.times = e->d_times; K.residual = e->d_residual; K.costs = e->d_costs;
-  K.trace = e->d_trace; K.knots = e->d_knots; K.returns = e->d_returns; K.failure = e->d_failure; K.diag = e->d_diag;
+  K.trace = e->d_trace; K.knots = e->d_knots; K.returns = e->d_returns; K.failure = e->d_failure; K.diag = e->d_diag; K.prof = e->d_prof;
   HIPCHK(hipEventRecord(e->ev[1], e->stream));
   hipLaunchKernelGGL(rollout_kernel, dim3(nl), dim3(64), e->lds_bytes, e->stream, K);
   HIPCHK(hipEventRecord(e->ev[2], e->stream));
@@ -329,5 +332,14 @@ int mjpc_hip_debug_fetch_all(MjpcHipEngine *e, double *states, double *actions, 
 }
 
 int mjpc_hip_lds_bytes(MjpcHipEngine *e) { return e ? (int)e->lds_bytes : 0; }
+
+// MJPC_PROFILE builds: per-candidate phase cycle counters of the last plan ([nlocal][24] int64)
+int mjpc_hip_debug_fetch_prof(MjpcHipEngine *e, long long *prof) {
+  if (!e || !e->last_nlocal) return -1;
+  HIPCHK(hipSetDevice(e->device));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  HIPCHK(hipMemcpy(prof, e->d_prof, sizeof(long long) * (size_t)e->last_nlocal * 24, hipMemcpyDeviceToHost));
+  return 0;
+}
 
 }  // extern "C"

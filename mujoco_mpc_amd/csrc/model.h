@@ -88,4 +88,5 @@ struct KParams {
   // outputs (device), row-major per local candidate
   double *states, *actions, *times, *residual, *costs, *trace, *knots, *returns;
   int *failure, *diag;
+  long long *prof;     // optional per-candidate phase cycle counters (MJPC_PROFILE builds)
 };

@@ -1,0 +1,32 @@
+"""Diagnostic: build the engine with in-kernel phase stamps (MJPC_PROFILE) and print where a step's cycles go.
+Never used for timing claims (stamps perturb the schedule); only the shares matter."""
+import ctypes as C, os, subprocess, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.abspath(__file__)); sys.path.insert(0, ROOT)
+CSRC = os.path.join(ROOT, "mujoco_mpc_amd", "csrc")
+so = os.path.join(ROOT, "gpurun_out", "libmjpc_hip_prof.so")
+os.makedirs(os.path.dirname(so), exist_ok=True)
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DMJPC_PROFILE=1",
+                       "-Wno-unused-value", "-o", so, os.path.join(CSRC, "engine.hip")])
+from mujoco_mpc_amd import capi
+capi.ENGINE_PATH = so
+from mujoco_mpc_amd.modelgen import quadruped
+from mujoco_mpc_amd.planner import HipBackend
+m, task, d = quadruped()
+N, H, P = int(sys.argv[1]) if len(sys.argv) > 1 else 256, 100, 3
+kt = np.linspace(0, 0.99, P); kv = np.zeros((P, 12))
+be = HipBackend(m, task, max_samples=N, max_horizon=H)
+for i in range(2):
+    out = be.plan(state=d["state"], mocap=d["mocap"], time=0.0, knot_times=kt, knot_values=kv, interpolation=2, num_trajectory=N,
+                  horizon=H, sigma=(0.04, 0.0), seed=0x5EED, stream=i)
+prof = np.zeros((N, 24), np.int64)
+be.lib.mjpc_hip_debug_fetch_prof.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
+be.lib.mjpc_hip_debug_fetch_prof(be.h, prof.ctypes.data_as(C.POINTER(C.c_longlong)))
+allc = be.fetch_all(N, H, P)
+names = ["(loop overhead/record)", "kinematics", "com_pos", "crb+factorM", "collision", "make_constraint", "velocity+smooth", "impedance(+warm)",
+         "solver tail", "residual", "cost+record", "integrate", "solver_eval", "newton tail/iter", "line_search", "grad+H build", "chol_factor(H)", "chol_solve(H)"]
+tot = prof.sum(1).mean()
+print(f"rollout us {out['rollouts_compute_time_us']:.0f}; mean stamped ticks/candidate {tot:.3e} (s_memtime ticks @100MHz => {tot/100:.0f} us)")
+for i, n in enumerate(names):
+    print(f"  {n:26s} {100*prof[:, i].mean()/tot:6.2f} %   {prof[:, i].mean()/100/H:8.2f} us/step")
+print("newton iters per step (mean)", allc["diag"][:, 0].mean() / H, "max ncon", allc["diag"][:, 1].max(), "max nefc", allc["diag"][:, 2].max())

@@ -11,17 +11,49 @@
 #pragma once
 #include "dmath.h"
 #include "model.h"
+#include "linalg.h"
+
+// ---- where the kernel parameters, the LDS block and the candidate index come from ---------------------
+// Phases are __noinline__ (each gets its own register allocation; a fully inlined rollout needs all 512
+// registers and serialises every LDS load).  They re-derive what they need from three ambient sources:
+// the kernarg segment pointer argument (scalar loads), the workgroup's dynamic LDS symbol, and blockIdx.
+#ifdef MJPC_EMU
+static thread_local double *g_emu_lds = nullptr;
+static thread_local int g_emu_r = 0;
+typedef const KParams *KP;
+DEV const KParams *kp_generic(KP k) { return k; }
+DEV double *lds_base() { return g_emu_lds; }
+DEV int cand_index() { return g_emu_r; }
+DEV int uniform_i(int v) { return v; }
+#else
+extern __shared__ __align__(16) double g_lds[];
+// The kernarg segment pointer is taken in the kernel and handed to every phase as a constant-address-space
+// (4) argument, so K->... stays scalar loads.  (__builtin_amdgcn_kernarg_segment_ptr() inside a
+// __noinline__ callee returns null on gfx950 / ROCm 7.2 — measured.)
+typedef const __attribute__((address_space(4))) KParams *KP;
+DEV const KParams *kp_generic(KP k) {
+  // arguments of callable functions arrive in VGPRs: make the pointer provably wave-uniform again
+  unsigned long long v = (unsigned long long)k;
+  unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  KP u = (KP)(((unsigned long long)hi << 32) | lo);
+  return (const KParams *)u;
+}
+DEV double *lds_base() { return g_lds; }
+DEV int cand_index() { return (int)blockIdx.x; }
+DEV int uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+#endif
 
 #if defined(MJPC_PROFILE) && !defined(MJPC_EMU)
 #define NPROF 24
-#define PROF(c, i) do { long long t_ = (long long)__builtin_amdgcn_s_memtime(); (c).prof[i] += t_ - (c).tlast; (c).tlast = t_; } while (0)
+// diagnostic builds only: lane 0 accumulates s_memtime deltas per phase slot in LDS
+#define PROF(c, i) do { if (LANE == 0) { long long t_ = (long long)__builtin_amdgcn_s_memtime(); (c).prof[i] += t_ - (c).prof[NPROF]; (c).prof[NPROF] = t_; } } while (0)
 #else
 #define PROF(c, i) ((void)0)
 #endif
 
 struct Ctx {
 #if defined(MJPC_PROFILE) && !defined(MJPC_EMU)
-  long long prof[NPROF]; long long tlast;
+  long long *prof;
 #endif
   const DevModel *M;
   const KParams *K;
@@ -30,13 +62,13 @@ struct Ctx {
   double *xpos, *xquat, *xmat, *xipos, *ximat, *xanchor, *xaxis, *geom_xpos, *geom_xmat, *site_xpos;
   double *subtree_com, *cinert, *crb, *cdof, *cvel, *cdof_dot, *cacc, *cfrc, *cfrc_sub, *subtree_linvel, *bodytmp;
   double *qM, *qL, *qH, *Linv, *Hinv;
-  double *efc_J, *efc_D, *efc_R, *efc_aref, *efc_force, *efc_jar, *efc_jv, *efc_floss, *efc_pos, *efc_margin, *efc_diag;
+  double *efc_J, *efc_WJ, *efc_D, *efc_R, *efc_aref, *efc_force, *efc_jar, *efc_jv, *efc_floss, *efc_pos, *efc_margin, *efc_diag;
   double *contact;
-  double *Ma, *grad, *Mgrad, *search, *Mv, *vtmp;
+  double *Ma, *grad, *Mgrad, *search, *Mv, *vtmp, *sgl;
   double *knot_times, *knot_values, *residual, *terms, *red;
-  int *efc_type, *efc_id, *efc_state, *con_i, *active, *misc;
+  int *efc_type, *efc_id, *efc_state, *efc_dof, *con_i, *active, *misc;
   double time;
-  int ncon, nefc, warning, solver_iter;
+  int ncon, nefc, nsingle, warning, solver_iter;
 };
 
 DEV void ctx_init(Ctx &c, const KParams *K, double *base) {
@@ -48,15 +80,34 @@ DEV void ctx_init(Ctx &c, const KParams *K, double *base) {
   P_(xpos); P_(xquat); P_(xmat); P_(xipos); P_(ximat); P_(xanchor); P_(xaxis); P_(geom_xpos); P_(geom_xmat); P_(site_xpos);
   P_(subtree_com); P_(cinert); P_(crb); P_(cdof); P_(cvel); P_(cdof_dot); P_(cacc); P_(cfrc); P_(cfrc_sub);
   P_(subtree_linvel); P_(bodytmp); P_(qM); P_(qL); P_(qH); P_(Linv); P_(Hinv);
-  P_(efc_J); P_(efc_D); P_(efc_R); P_(efc_aref); P_(efc_force); P_(efc_jar); P_(efc_jv); P_(efc_floss);
+  P_(efc_J); P_(efc_WJ); P_(efc_D); P_(efc_R); P_(efc_aref); P_(efc_force); P_(efc_jar); P_(efc_jv); P_(efc_floss);
   P_(efc_pos); P_(efc_margin); P_(efc_diag); P_(contact);
-  P_(Ma); P_(grad); P_(Mgrad); P_(search); P_(Mv); P_(vtmp);
+  P_(Ma); P_(grad); P_(Mgrad); P_(search); P_(Mv); P_(vtmp); P_(sgl);
   P_(knot_times); P_(knot_values); P_(residual); P_(terms); P_(red);
 #undef P_
   int *ib = (int *)(base + L.ints);
-  c.efc_type = ib + L.i_efc_type; c.efc_id = ib + L.i_efc_id; c.efc_state = ib + L.i_efc_state;
+  c.efc_type = ib + L.i_efc_type; c.efc_id = ib + L.i_efc_id; c.efc_state = ib + L.i_efc_state; c.efc_dof = ib + L.i_efc_dof;
   c.con_i = ib + L.i_con; c.active = ib + L.i_active; c.misc = ib + L.i_misc;
-  c.time = 0; c.ncon = 0; c.nefc = 0; c.warning = 0; c.solver_iter = 0;
+  c.time = 0; c.ncon = 0; c.nefc = 0; c.nsingle = 0; c.warning = 0; c.solver_iter = 0;
+#if defined(MJPC_PROFILE) && !defined(MJPC_EMU)
+  c.prof = (long long *)(base + L.prof);
+#endif
+}
+
+// rollout scalars shared between phases live in LDS: misc[0..4] = ncon, nefc, nsingle, warning, solver_iter; red[0] = time
+DEV void ctx_open(Ctx &c, KP Kc) {
+  ctx_init(c, kp_generic(Kc), lds_base());
+  c.ncon = uniform_i(c.misc[0]); c.nefc = uniform_i(c.misc[1]); c.nsingle = uniform_i(c.misc[2]);
+  c.warning = uniform_i(c.misc[3]); c.solver_iter = uniform_i(c.misc[4]);
+  c.time = c.red[0];
+}
+DEV void ctx_close(Ctx &c) {
+  SYNC();
+  if (LANE == 0) {
+    c.misc[0] = c.ncon; c.misc[1] = c.nefc; c.misc[2] = c.nsingle; c.misc[3] = c.warning; c.misc[4] = c.solver_iter;
+    c.red[0] = c.time;
+  }
+  SYNC();
 }
 
 // ======================================================================================
@@ -232,47 +283,7 @@ DEV void com_pos(Ctx &c) {
   SYNC();
 }
 
-// dense Cholesky A = L L^T in place (lower triangle), row stride nvp; Linv[j] = 1/L[j][j]
-DEV void chol_factor(Ctx &c, double *A, double *Linv, int n, int nvp) {
-  for (int j = 0; j < n; j++) {
-    SYNC();
-    PFOR(ii, n - j) {
-      int i = j + ii;
-      double s = A[i * nvp + j];
-      for (int k = 0; k < j; k++) s -= A[i * nvp + k] * A[j * nvp + k];
-      c.vtmp[i] = s;
-    }
-    SYNC();
-    double t = c.vtmp[j];
-    if (t < D_MINVAL) t = D_MINVAL;
-    double dj = sqrt(t), inv = 1.0 / dj;
-    PFOR(ii, n - j) {
-      int i = j + ii;
-      A[i * nvp + j] = (i == j) ? dj : c.vtmp[i] * inv;
-    }
-    if (LANE == 0) Linv[j] = inv;
-  }
-  SYNC();
-}
-// x <- (L L^T)^-1 x, x in LDS
-DEV void chol_solve(Ctx &c, const double *L, const double *Linv, double *x, int n, int nvp) {
-  for (int i = 0; i < n; i++) {
-    SYNC();
-    double xi = x[i] * Linv[i];
-    SYNC();
-    PFOR(kk, n - i - 1) { int k = i + 1 + kk; x[k] -= L[k * nvp + i] * xi; }
-    if (LANE == 0) x[i] = xi;
-  }
-  for (int i = n - 1; i >= 0; i--) {
-    SYNC();
-    double xi = x[i] * Linv[i];
-    SYNC();
-    PFOR(k, i) x[k] -= L[i * nvp + k] * xi;
-    if (LANE == 0) x[i] = xi;
-  }
-  SYNC();
-}
-
+template <int NVT>
 DEV void crb_and_factor(Ctx &c) {
   const DevModel &M = *c.M;
   int nv = M.nv, nvp = M.nvp;
@@ -294,7 +305,7 @@ DEV void crb_and_factor(Ctx &c) {
   }
   SYNC();
   PFOR(e, nv * nvp) c.qL[e] = c.qM[e];
-  chol_factor(c, c.qL, c.Linv, nv, nvp);
+  chol_factor<NVT>(c.qL, c.Linv, c.vtmp, nv, nvp);
 }
 
 // ======================================================================================
@@ -610,10 +621,11 @@ DEV void make_constraint(Ctx &c) {
   const DevModel &M = *c.M;
   int nv = M.nv, nvp = M.nvp;
   int nefc = M.nfric;
+  PFOR(e, 4 * nv) c.sgl[e] = 0;
   // friction-loss rows are static: rows [0, nfric)
   PFOR(r, M.nfric) {
     int d = M.fric_dof[r];
-    c.efc_type[r] = CNSTR_FRICTION_DOF; c.efc_id[r] = d;
+    c.efc_type[r] = CNSTR_FRICTION_DOF; c.efc_id[r] = d; c.efc_dof[r] = d;
     c.efc_floss[r] = M.dof_frictionloss[d]; c.efc_pos[r] = 0; c.efc_margin[r] = 0;
     c.efc_diag[r] = M.dof_invweight0[d];
   }
@@ -633,7 +645,7 @@ DEV void make_constraint(Ctx &c) {
     if (nefc + tot > M.nefcmax) { c.warning |= WARN_CNSTRFULL; break; }
     for (int k = 0; k < cnt; k++) {
       int r = nefc + off + k;
-      c.efc_type[r] = CNSTR_LIMIT_JOINT; c.efc_id[r] = j;
+      c.efc_type[r] = CNSTR_LIMIT_JOINT; c.efc_id[r] = j; c.efc_dof[r] = M.jnt_dofadr[j];
       c.efc_floss[r] = (double)(-side[k]);      // J entry, consumed below
       c.efc_pos[r] = dist[k]; c.efc_margin[r] = M.jnt_margin[j];
       c.efc_diag[r] = M.dof_invweight0[M.jnt_dofadr[j]];
@@ -641,6 +653,7 @@ DEV void make_constraint(Ctx &c) {
     nefc += tot;
   }
   int nlim_end = nefc;
+  c.nsingle = nlim_end;
   // contacts: dim rows each
   for (int base = 0; base < c.ncon; base += NLANE) {
     int ci = base + LANE, dim = 0;
@@ -817,6 +830,7 @@ DEV void vel_body(Ctx &c, int i) {
   d_scl3(c.bodytmp + 3 * i, v, M.body_mass[i]);
 }
 
+template <int NVT>
 DEV void velocity_stage(Ctx &c) {
   const DevModel &M = *c.M;
   int nv = M.nv;
@@ -870,286 +884,10 @@ DEV void velocity_stage(Ctx &c) {
   }
   SYNC();
   PFOR(d, nv) c.qacc_smooth[d] = c.qfrc_smooth[d];
-  chol_solve(c, c.qL, c.Linv, c.qacc_smooth, nv, M.nvp);
+  chol_solve<NVT>(c.qL, c.Linv, c.qacc_smooth, nv, M.nvp);
 }
 
-// ======================================================================================
-// primal Newton solver
-// ======================================================================================
-// constraint cost at efc_jar; fills force/state (and cone Hessians); returns this lane's partial cost
-DEV double constraint_update(Ctx &c, int hess) {
-  const DevModel &M = *c.M;
-  double cost = 0;
-  PFOR(i, c.nefc) {
-    int type = c.efc_type[i];
-    if (type == CNSTR_CONTACT_ELLIPTIC) continue;
-    double D = c.efc_D[i], R = c.efc_R[i], x = c.efc_jar[i];
-    if (type == CNSTR_FRICTION_DOF) {
-      double f = c.efc_floss[i];
-      if (x <= -R * f) { cost += -0.5 * R * f * f - f * x; c.efc_force[i] = f; c.efc_state[i] = STATE_LINEARNEG; }
-      else if (x >= R * f) { cost += -0.5 * R * f * f + f * x; c.efc_force[i] = -f; c.efc_state[i] = STATE_LINEARPOS; }
-      else { cost += 0.5 * D * x * x; c.efc_force[i] = -D * x; c.efc_state[i] = STATE_QUADRATIC; }
-    } else {
-      if (x >= 0) { c.efc_force[i] = 0; c.efc_state[i] = STATE_SATISFIED; }
-      else { cost += 0.5 * D * x * x; c.efc_force[i] = -D * x; c.efc_state[i] = STATE_QUADRATIC; }
-    }
-  }
-  PFOR(ci, c.ncon) {
-    int dim = c.con_i[ci * CONI_STRIDE];
-    if (dim <= 1) continue;
-    int i = c.con_i[ci * CONI_STRIDE + 3];
-    double *cc = c.contact + ci * CON_STRIDE;
-    double mu = cc[CON_MU], U[6], fr[6];
-    fr[0] = mu;
-    for (int j = 1; j < 6; j++) fr[j] = j < dim ? cc[CON_FRICTION + j - 1] : 0;
-    double T2 = 0;
-    for (int j = 0; j < 6; j++) { U[j] = j < dim ? c.efc_jar[i + j] * fr[j] : 0; if (j > 0) T2 += U[j] * U[j]; }
-    double N = U[0], T = sqrt(T2);
-    int st;
-    if (N >= mu * T || (T <= 0 && N >= 0)) {
-      for (int j = 0; j < dim; j++) c.efc_force[i + j] = 0;
-      st = STATE_SATISFIED;
-    } else if (mu * N + T <= 0 || (T <= 0 && N < 0)) {
-      for (int j = 0; j < dim; j++) { double xj = c.efc_jar[i + j], Dj = c.efc_D[i + j]; cost += 0.5 * Dj * xj * xj; c.efc_force[i + j] = -Dj * xj; }
-      st = STATE_QUADRATIC;
-    } else {
-      double Dm = c.efc_D[i] / (mu * mu * (1 + mu * mu));
-      double NmT = N - mu * T;
-      cost += 0.5 * Dm * NmT * NmT;
-      double f0 = -Dm * NmT * mu;
-      c.efc_force[i] = f0;
-      for (int j = 1; j < dim; j++) c.efc_force[i + j] = -f0 / T * U[j] * fr[j];
-      st = STATE_CONE;
-      if (hess) {
-        double g[6];
-        g[0] = 1;
-        for (int j = 1; j < 6; j++) g[j] = -mu * U[j] / T;
-        for (int a = 0; a < dim; a++) for (int b = 0; b < dim; b++) {
-          double h = g[a] * g[b];
-          if (a > 0 && b > 0) h += NmT * (-mu) * ((a == b ? 1.0 / T : 0.0) - U[a] * U[b] / (T * T * T));
-          cc[CON_H + a * 6 + b] = Dm * h * fr[a] * fr[b];
-        }
-      }
-    }
-    for (int j = 0; j < dim; j++) c.efc_state[i + j] = st;
-  }
-  (void)M;
-  return cost;
-}
-
-// Ma = M qacc, jar = J qacc - aref, cost = Gauss + constraints; returns total cost (uniform), Gauss via out
-DEV double solver_eval(Ctx &c, const double *qacc, double *gauss_out) {
-  const DevModel &M = *c.M;
-  int nv = M.nv, nvp = M.nvp;
-  double part = 0;
-  PFOR(i, nv) {
-    double s = 0;
-    for (int j = 0; j < nv; j++) s += c.qM[i * nvp + j] * qacc[j];
-    c.Ma[i] = s;
-    part += 0.5 * (s - c.qfrc_smooth[i]) * (qacc[i] - c.qacc_smooth[i]);
-  }
-  PFOR(r, c.nefc) {
-    double s = 0;
-    for (int j = 0; j < nv; j++) s += c.efc_J[r * nvp + j] * qacc[j];
-    c.efc_jar[r] = s - c.efc_aref[r];
-  }
-  SYNC();
-  double gauss = wave_sum(part);
-  double cc = wave_sum(constraint_update(c, 1));
-  SYNC();
-  if (gauss_out) *gauss_out = gauss;
-  return gauss + cc;
-}
-
-DEV void newton_gradient(Ctx &c) {
-  const DevModel &M = *c.M;
-  int nv = M.nv, nvp = M.nvp, nefc = c.nefc;
-  PFOR(i, nv) {
-    double g = c.Ma[i] - c.qfrc_smooth[i];
-    for (int r = 0; r < nefc; r++) g -= c.efc_J[r * nvp + i] * c.efc_force[r];
-    c.grad[i] = g;
-    c.Mgrad[i] = g;
-  }
-  // H = M + J^T diag(D * quadratic) J + cone blocks; lower triangle, one entry per lane-iteration
-  int ntri = nv * (nv + 1) / 2;
-  PFOR(e, ntri) {
-    int i = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
-    while ((i + 1) * (i + 2) / 2 <= e) i++;
-    while (i * (i + 1) / 2 > e) i--;
-    int j = e - i * (i + 1) / 2;
-    double h = c.qM[i * nvp + j];
-    for (int r = 0; r < nefc; r++) {
-      int st = c.efc_state[r];
-      if (st == STATE_QUADRATIC) h += c.efc_D[r] * c.efc_J[r * nvp + i] * c.efc_J[r * nvp + j];
-      else if (st == STATE_CONE) {
-        int ci = c.efc_id[r];
-        int dim = c.con_i[ci * CONI_STRIDE];
-        const double *Hc = c.contact + ci * CON_STRIDE + CON_H;
-        for (int a = 0; a < dim; a++) {
-          double Jai = c.efc_J[(r + a) * nvp + i];
-          if (Jai == 0) continue;
-          for (int b = 0; b < dim; b++) h += Hc[a * 6 + b] * Jai * c.efc_J[(r + b) * nvp + j];
-        }
-        r += dim - 1;
-      }
-    }
-    c.qH[i * nvp + j] = h;
-  }
-  PROF(c, 15);
-  chol_factor(c, c.qH, c.Hinv, nv, nvp);
-  PROF(c, 16);
-  chol_solve(c, c.qH, c.Hinv, c.Mgrad, nv, nvp);
-  PROF(c, 17);
-}
-
-// exact 1-D line search along `search`: safeguarded Newton on phi'(alpha)
-struct LSPoint { double cost, d1, d2; };
-
-DEV LSPoint ls_eval(Ctx &c, double q0, double q1, double q2, double a) {
-  LSPoint p; p.cost = 0; p.d1 = 0; p.d2 = 0;
-  PFOR(i, c.nefc) {
-    int type = c.efc_type[i];
-    if (type == CNSTR_CONTACT_ELLIPTIC) continue;
-    double D = c.efc_D[i], R = c.efc_R[i], v = c.efc_jv[i], x = c.efc_jar[i] + a * v;
-    if (type == CNSTR_FRICTION_DOF) {
-      double f = c.efc_floss[i];
-      if (x <= -R * f) { p.cost += -0.5 * R * f * f - f * x; p.d1 += -f * v; }
-      else if (x >= R * f) { p.cost += -0.5 * R * f * f + f * x; p.d1 += f * v; }
-      else { p.cost += 0.5 * D * x * x; p.d1 += D * x * v; p.d2 += D * v * v; }
-    } else if (x < 0) { p.cost += 0.5 * D * x * x; p.d1 += D * x * v; p.d2 += D * v * v; }
-  }
-  PFOR(ci, c.ncon) {
-    int dim = c.con_i[ci * CONI_STRIDE];
-    if (dim <= 1) continue;
-    int i = c.con_i[ci * CONI_STRIDE + 3];
-    const double *cc = c.contact + ci * CON_STRIDE;
-    double mu = cc[CON_MU], U[6], V[6];
-    double T2 = 0, UV = 0, VV = 0;
-    for (int j = 0; j < 6; j++) {
-      double fr = j == 0 ? mu : (j < dim ? cc[CON_FRICTION + j - 1] : 0);
-      U[j] = j < dim ? (c.efc_jar[i + j] + a * c.efc_jv[i + j]) * fr : 0;
-      V[j] = j < dim ? c.efc_jv[i + j] * fr : 0;
-      if (j > 0) { T2 += U[j] * U[j]; UV += U[j] * V[j]; VV += V[j] * V[j]; }
-    }
-    double N = U[0], T = sqrt(T2);
-    if (N >= mu * T || (T <= 0 && N >= 0)) {
-    } else if (mu * N + T <= 0 || (T <= 0 && N < 0)) {
-      for (int j = 0; j < dim; j++) {
-        double vj = c.efc_jv[i + j], xj = c.efc_jar[i + j] + a * vj, Dj = c.efc_D[i + j];
-        p.cost += 0.5 * Dj * xj * xj; p.d1 += Dj * xj * vj; p.d2 += Dj * vj * vj;
-      }
-    } else {
-      double Dm = c.efc_D[i] / (mu * mu * (1 + mu * mu));
-      double NmT = N - mu * T;
-      double T1 = UV / T, T2d = (VV - UV * UV / (T * T)) / T;
-      double g1 = V[0] - mu * T1;
-      p.cost += 0.5 * Dm * NmT * NmT; p.d1 += Dm * NmT * g1; p.d2 += Dm * (g1 * g1 - NmT * mu * T2d);
-    }
-  }
-  p.cost = wave_sum(p.cost) + q0 + a * q1 + a * a * q2;
-  p.d1 = wave_sum(p.d1) + q1 + 2 * a * q2;
-  p.d2 = wave_sum(p.d2) + 2 * q2;
-  return p;
-}
-
-DEV double line_search(Ctx &c, double gauss) {
-  const DevModel &M = *c.M;
-  int nv = M.nv, nvp = M.nvp;
-  double p_sn = 0, p_q1 = 0, p_q2 = 0;
-  PFOR(i, nv) {
-    double s = 0;
-    for (int j = 0; j < nv; j++) s += c.qM[i * nvp + j] * c.search[j];
-    c.Mv[i] = s;
-    double si = c.search[i];
-    p_sn += si * si; p_q1 += si * (c.Ma[i] - c.qfrc_smooth[i]); p_q2 += 0.5 * si * s;
-  }
-  PFOR(r, c.nefc) {
-    double s = 0;
-    for (int j = 0; j < nv; j++) s += c.efc_J[r * nvp + j] * c.search[j];
-    c.efc_jv[r] = s;
-  }
-  SYNC();
-  double snorm = sqrt(wave_sum(p_sn)), q1 = wave_sum(p_q1), q2 = wave_sum(p_q2);
-  double scale = 1.0 / (M.meaninertia * (nv > 1 ? nv : 1));
-  if (snorm < D_MINVAL) return 0;
-  double gtol = M.tolerance * M.ls_tolerance * snorm / scale;
-  LSPoint p0 = ls_eval(c, gauss, q1, q2, 0.0);
-  if (!(p0.d2 > 0) || p0.d1 >= 0) return 0;
-  // safeguarded Newton on phi'(alpha) (rtsafe): expand until phi' changes sign, then Newton steps that stay
-  // inside the bracket and at least halve the previous step, else bisection; return the best point seen
-  double lo = 0, hi = -1, a = -p0.d1 / p0.d2;
-  double best_a = 0, best_cost = p0.cost, dxold = a, dx = a;
-  for (int it = 0; it < M.ls_iterations; it++) {
-    LSPoint p = ls_eval(c, gauss, q1, q2, a);
-    if (p.cost < best_cost) { best_cost = p.cost; best_a = a; }
-    if (fabs(p.d1) < gtol) break;
-    if (p.d1 < 0) lo = a; else hi = a;
-    double an;
-    if (hi < 0) {
-      an = (p.d2 > 0) ? a - p.d1 / p.d2 : 2 * a;
-      if (!(an > a)) an = 2 * a;
-      dxold = dx; dx = an - a;
-    } else {
-      double nw = (p.d2 > 0) ? a - p.d1 / p.d2 : lo - 1;
-      int ok = (nw > lo) && (nw < hi) && (fabs(2 * p.d1) <= fabs(dxold * p.d2));
-      dxold = dx;
-      if (ok) { dx = fabs(nw - a); an = nw; }
-      else { dx = 0.5 * (hi - lo); an = lo + dx; }
-    }
-    if (an == a) break;
-    a = an;
-  }
-  return best_a;
-}
-
-DEV void solve_constraints(Ctx &c) {
-  const DevModel &M = *c.M;
-  int nv = M.nv, nvp = M.nvp;
-  c.solver_iter = 0;
-  if (c.nefc == 0) {
-    PFOR(i, nv) { c.qacc[i] = c.qacc_smooth[i]; c.qfrc_constraint[i] = 0; }
-    SYNC();
-    return;
-  }
-  PROF(c, 7);
-  double cost_ws = solver_eval(c, c.qacc_ws, 0);
-  double cost_sm = solver_eval(c, c.qacc_smooth, 0);
-  PFOR(i, nv) c.qacc[i] = (cost_ws > cost_sm) ? c.qacc_smooth[i] : c.qacc_ws[i];
-  SYNC();
-  double gauss;
-  double cost = solver_eval(c, c.qacc, &gauss);
-  PROF(c, 12);
-  newton_gradient(c);
-  PFOR(i, nv) c.search[i] = -c.Mgrad[i];
-  SYNC();
-  double scale = 1.0 / (M.meaninertia * (nv > 1 ? nv : 1));
-  for (int iter = 0; iter < M.iterations; iter++) {
-    PROF(c, 13);
-    double alpha = line_search(c, gauss);
-    PROF(c, 14);
-    if (alpha == 0) break;
-    PFOR(i, nv) c.qacc[i] += alpha * c.search[i];
-    SYNC();
-    double oldcost = cost;
-    cost = solver_eval(c, c.qacc, &gauss);
-    PROF(c, 12);
-    newton_gradient(c);
-    c.solver_iter++;
-    double pg = 0;
-    PFOR(i, nv) pg += c.grad[i] * c.grad[i];
-    double gradient = scale * sqrt(wave_sum(pg));
-    double improvement = scale * (oldcost - cost);
-    if (improvement < M.tolerance || gradient < M.tolerance) break;
-    PFOR(i, nv) c.search[i] = -c.Mgrad[i];
-    SYNC();
-  }
-  PFOR(i, nv) {
-    double s = 0;
-    for (int r = 0; r < c.nefc; r++) s += c.efc_J[r * nvp + i] * c.efc_force[r];
-    c.qfrc_constraint[i] = s;
-  }
-  SYNC();
-}
+#include "solver.h"
 
 // ======================================================================================
 // task residuals (device restatement of the reference's ResidualFn::Residual)
@@ -1441,37 +1179,159 @@ DEV double cost_value(Ctx &c, const double *residual) {
 }
 
 // ======================================================================================
-// mj_forward / mj_step
+// phases of one step (mj_step = position, velocity, solve, [residual], integrate) — all __noinline__
 // ======================================================================================
-DEV void forward(Ctx &c) {
-  PROF(c, 0);
-  kinematics(c); PROF(c, 1);
-  com_pos(c); PROF(c, 2);
-  crb_and_factor(c); PROF(c, 3);
-  collision(c); PROF(c, 4);
-  make_constraint(c); PROF(c, 5);
-  velocity_stage(c); PROF(c, 6);
-  make_impedance(c); PROF(c, 7);
-  solve_constraints(c); PROF(c, 8);
-  task_residual(c, c.residual); PROF(c, 9);
-}
-
 DEV int bad_values(const double *x, int n) {
   int b = 0;
   PFOR(i, n) { double v = x[i]; if (!(v == v) || v > 1e10 || v < -1e10) b = 1; }
   return wave_or_i(b);
 }
 
-DEV void integrate(Ctx &c) {
+struct Rows { double *states, *actions, *times, *residual, *costs, *trace; int ds, nr, ntr; };
+DEV Rows out_rows(const KParams *K) {
+  const DevModel &M = K->M;
+  Rows R;
+  size_t r = (size_t)cand_index(), H = (size_t)K->H;
+  R.ds = M.nq + M.nv; R.nr = M.task.num_residual; R.ntr = 3 * M.task.num_trace;
+  R.states = K->states + r * H * R.ds; R.actions = K->actions + r * H * M.nu; R.times = K->times + r * H;
+  R.residual = K->residual + r * H * R.nr; R.costs = K->costs + r * H; R.trace = K->trace + r * H * R.ntr;
+  return R;
+}
+
+// candidate policy (planner.cc:313-339) + initial state (trajectory.cc:120-137)
+DEV_NOINLINE void ph_init(KP Kc) {
+  Ctx c;
+  const KParams *K = kp_generic(Kc);
+  ctx_init(c, K, lds_base());
+  const DevModel &M = K->M;
+  Rows R = out_rows(K);
+  int nq = M.nq, nv = M.nv, nu = M.nu, P = K->P, r = cand_index();
+  int gi = K->offset + r;
+  PFOR(p, P) c.knot_times[p] = K->knot_times[p];
+  double std = K->sigma0;
+  if (K->sigma1 > 0 && K->noise_sel[r]) std = K->sigma1;
+  PFOR(e, P * nu) {
+    int k = e % nu;
+    double v = K->knot_values[e];
+    double lo = M.actuator_ctrlrange[2 * k], hi = M.actuator_ctrlrange[2 * k + 1];
+    if (gi != 0) {
+      double scale = 0.5 * (hi - lo);
+      v = add_mul3_rn(v, scale, std, K->noise_eps[(size_t)r * P * nu + e]);   // bit-exact candidate policy
+      v = d_clip(v, lo, hi);
+    }
+    c.knot_values[e] = v;
+    K->knots[(size_t)r * P * nu + e] = v;
+  }
+  PFOR(i, M.nmocap) {
+    d_copy3(c.mocap_pos + 3 * i, K->mocap + 7 * i);
+    d_copy4(c.mocap_quat + 4 * i, K->mocap + 7 * i + 3);
+  }
+  PFOR(i, nq) { c.qpos[i] = K->state[i]; R.states[i] = K->state[i]; }
+  PFOR(i, nv) { c.qvel[i] = K->state[nq + i]; R.states[nq + i] = K->state[nq + i]; c.qacc_ws[i] = 0; }
+  PFOR(e, nv * M.nvp) c.qM[e] = 0;
+  PFOR(k, nu) c.ctrl[k] = 0;      // data->ctrl after Reset (planner.cc:124-130); only visible when H == 1
+  if (LANE == 0) {
+    R.times[0] = K->time;
+    for (int k = 0; k < 3; k++) { c.xpos[k] = 0; c.xipos[k] = 0; c.subtree_linvel[k] = 0; }
+    c.xquat[0] = 1; c.xquat[1] = 0; c.xquat[2] = 0; c.xquat[3] = 0;
+    for (int k = 0; k < 9; k++) { c.xmat[k] = (k % 4 == 0) ? 1.0 : 0.0; c.ximat[k] = c.xmat[k]; }
+    for (int k = 0; k < 6; k++) { c.cvel[k] = 0; c.cfrc[k] = 0; c.cacc[k] = (k >= 3) ? -M.gravity[k - 3] : 0.0; }
+    for (int k = 0; k < 8; k++) c.misc[k] = 0;
+#if defined(MJPC_PROFILE) && !defined(MJPC_EMU)
+    for (int q = 0; q < NPROF; q++) c.prof[q] = 0;
+    c.prof[NPROF] = (long long)__builtin_amdgcn_s_memtime();
+#endif
+  }
+  c.time = K->time;
+  ctx_close(c);
+}
+
+// policy -> ctrl (policy.cc:52-59), mj_checkPos / mj_checkVel; returns the warning mask
+DEV_NOINLINE int ph_action(KP Kc, int t) {
+  Ctx c; ctx_open(c, Kc);
+  const KParams *K = c.K;
   const DevModel &M = *c.M;
-  int nv = M.nv, nvp = M.nvp;
+  Rows R = out_rows(K);
+  int nu = M.nu;
+  PFOR(k, nu) {
+    double a = spline_sample(c.knot_times, c.knot_values, K->P, nu, K->interp, c.time, k);
+    a = d_clip(a, M.actuator_ctrlrange[2 * k], M.actuator_ctrlrange[2 * k + 1]);
+    c.ctrl[k] = a; R.actions[t * nu + k] = a;
+  }
+  SYNC();
+  if (bad_values(c.qpos, M.nq)) c.warning |= WARN_BADQPOS;
+  if (bad_values(c.qvel, M.nv)) c.warning |= WARN_BADQVEL;
+  int w = c.warning;
+  ctx_close(c);
+  return w;
+}
+
+template <int NVT>
+DEV_NOINLINE void ph_position(KP Kc) {
+  Ctx c; ctx_open(c, Kc);
+  PROF(c, 0);
+  kinematics(c); PROF(c, 1);
+  com_pos(c); PROF(c, 2);
+  crb_and_factor<NVT>(c); PROF(c, 3);
+  collision(c); PROF(c, 4);
+  make_constraint(c); PROF(c, 5);
+  ctx_close(c);
+}
+template <int NVT>
+DEV_NOINLINE void ph_velocity(KP Kc) {
+  Ctx c; ctx_open(c, Kc);
+  velocity_stage<NVT>(c); PROF(c, 6);
+  make_impedance(c); PROF(c, 7);
+  ctx_close(c);
+}
+template <int NVT>
+DEV_NOINLINE void ph_solve(KP Kc) {
+  Ctx c; ctx_open(c, Kc);
+  solve_constraints<NVT>(c); PROF(c, 8);
+  ctx_close(c);
+}
+
+// residual (sensor callback at mjSTAGE_ACC), trace, cost; returns (cost, warning)
+struct CostOut { double cost; int warning; };
+DEV_NOINLINE CostOut ph_residual_cost(KP Kc, int t, int last) {
+  Ctx c; ctx_open(c, Kc);
+  const KParams *K = c.K;
+  const DevModel &M = *c.M;
+  const DevTask &T = M.task;
+  Rows R = out_rows(K);
+  if (last) PFOR(k, M.nu) R.actions[t * M.nu + k] = (K->H > 1) ? c.ctrl[k] : 0.0;     // trajectory.cc:190-195
+  task_residual(c, c.residual); PROF(c, 9);
+  PFOR(i, R.nr) R.residual[t * R.nr + i] = c.residual[i];
+  PFOR(i, T.num_trace) {
+    int id = T.trace_objid[i], ty = T.trace_objtype[i];
+    const double *src = ty == 6 ? c.site_xpos + 3 * id : (ty == 5 ? c.geom_xpos + 3 * id : (ty == 1 ? c.xipos + 3 * id : c.xpos + 3 * id));
+    d_copy3(R.trace + t * R.ntr + 3 * i, src);
+  }
+  if (!last && bad_values(c.qacc, M.nv)) c.warning |= WARN_BADQACC;
+  CostOut o;
+  o.cost = cost_value(c, c.residual);      // UpdateReturn (trajectory.cc:312-326) folded into the loop
+  if (LANE == 0) R.costs[t] = o.cost;
+  o.warning = c.warning;
+  PROF(c, 10);
+  ctx_close(c);
+  return o;
+}
+
+// mj_Euler with implicit joint damping, then record state[t+1]
+template <int NVT>
+DEV_NOINLINE void ph_integrate(KP Kc, int t) {
+  Ctx c; ctx_open(c, Kc);
+  const KParams *K = c.K;
+  const DevModel &M = *c.M;
+  Rows R = out_rows(K);
+  int nq = M.nq, nv = M.nv, nvp = M.nvp;
   double h = M.timestep;
   PFOR(i, nv) c.qacc_ws[i] = c.qacc[i];
   if (M.any_damping) {
     PFOR(e, nv * nvp) { int i = e / nvp, j = e - i * nvp; c.qH[e] = c.qM[e] + ((i == j) ? h * M.dof_damping[i] : 0.0); }
     PFOR(i, nv) c.Mgrad[i] = c.qfrc_smooth[i] + c.qfrc_constraint[i];
-    chol_factor(c, c.qH, c.Hinv, nv, nvp);
-    chol_solve(c, c.qH, c.Hinv, c.Mgrad, nv, nvp);
+    chol_factor<NVT>(c.qH, c.Hinv, c.vtmp, nv, nvp);
+    chol_solve<NVT>(c.qH, c.Hinv, c.Mgrad, nv, nvp);
     PFOR(i, nv) c.qvel[i] += h * c.Mgrad[i];
   } else {
     PFOR(i, nv) c.qvel[i] += h * c.qacc[i];
@@ -1488,106 +1348,46 @@ DEV void integrate(Ctx &c) {
   }
   c.time += h;
   SYNC();
+  PFOR(i, nq) R.states[(t + 1) * R.ds + i] = c.qpos[i];
+  PFOR(i, nv) R.states[(t + 1) * R.ds + nq + i] = c.qvel[i];
+  if (LANE == 0) R.times[t + 1] = c.time;
+  PROF(c, 11);
+  ctx_close(c);
 }
 
-// ======================================================================================
-// the whole rollout of local candidate r  (trajectory.cc:100-210 + 312-326)
-// ======================================================================================
-DEV void rollout(const KParams *K, double *lds, int r) {
-  Ctx c;
-  ctx_init(c, K, lds);
-  const DevModel &M = K->M;
-  const DevTask &T = M.task;
-  int nq = M.nq, nv = M.nv, nu = M.nu, H = K->H, P = K->P;
-  int ds = nq + nv, nr = T.num_residual, ntr = 3 * T.num_trace;
-  int gi = K->offset + r;                     // global candidate index
-  double *states = K->states + (size_t)r * H * ds, *actions = K->actions + (size_t)r * H * nu;
-  double *times = K->times + (size_t)r * H, *residual = K->residual + (size_t)r * H * nr;
-  double *costs = K->costs + (size_t)r * H, *trace = K->trace + (size_t)r * H * ntr;
-  // ---- candidate policy: nominal knots + noise, clamped (planner.cc:313-339)
-  PFOR(p, P) c.knot_times[p] = K->knot_times[p];
-  double std = K->sigma0;
-  if (K->sigma1 > 0 && K->noise_sel[r]) std = K->sigma1;
-  PFOR(e, P * nu) {
-    int k = e % nu;
-    double v = K->knot_values[e];
-    double lo = M.actuator_ctrlrange[2 * k], hi = M.actuator_ctrlrange[2 * k + 1];
-    if (gi != 0) {
-      double scale = 0.5 * (hi - lo);
-      v = add_mul3_rn(v, scale, std, K->noise_eps[(size_t)r * P * nu + e]);   // bit-exact candidate policy
-      v = d_clip(v, lo, hi);
-    }
-    c.knot_values[e] = v;
-    K->knots[(size_t)r * P * nu + e] = v;
-  }
-  // ---- initial state (trajectory.cc:120-137)
-  PFOR(i, M.nmocap) {
-    d_copy3(c.mocap_pos + 3 * i, K->mocap + 7 * i);
-    d_copy4(c.mocap_quat + 4 * i, K->mocap + 7 * i + 3);
-  }
-  PFOR(i, nq) { c.qpos[i] = K->state[i]; states[i] = K->state[i]; }
-  PFOR(i, nv) { c.qvel[i] = K->state[nq + i]; states[nq + i] = K->state[nq + i]; c.qacc_ws[i] = 0; }
-  PFOR(e, nv * M.nvp) c.qM[e] = 0;
-  PFOR(k, nu) c.ctrl[k] = 0;      // data->ctrl after Reset (planner.cc:124-130); only visible when H == 1
-  if (LANE == 0) {
-    times[0] = K->time;
-    for (int k = 0; k < 3; k++) { c.xpos[k] = 0; c.xipos[k] = 0; c.subtree_linvel[k] = 0; }
-    c.xquat[0] = 1; c.xquat[1] = 0; c.xquat[2] = 0; c.xquat[3] = 0;
-    for (int k = 0; k < 9; k++) { c.xmat[k] = (k % 4 == 0) ? 1.0 : 0.0; c.ximat[k] = c.xmat[k]; }
-    for (int k = 0; k < 6; k++) { c.cvel[k] = 0; c.cfrc[k] = 0; c.cacc[k] = (k >= 3) ? -M.gravity[k - 3] : 0.0; }
-  }
-  c.time = K->time;
-  SYNC();
-  double total = 0;
-  int failure = 0, diag_iter = 0, diag_ncon = 0, diag_nefc = 0;
-#if defined(MJPC_PROFILE) && !defined(MJPC_EMU)
-  for (int q = 0; q < NPROF; q++) c.prof[q] = 0;
-  c.tlast = (long long)__builtin_amdgcn_s_memtime();
-#endif
-  for (int t = 0; t < H; t++) {
-    int last = (t == H - 1);
-    if (!last) {
-      PFOR(k, nu) {
-        double a = spline_sample(c.knot_times, c.knot_values, P, nu, K->interp, c.time, k);
-        a = d_clip(a, M.actuator_ctrlrange[2 * k], M.actuator_ctrlrange[2 * k + 1]);
-        c.ctrl[k] = a; actions[t * nu + k] = a;
-      }
-      SYNC();
-      if (bad_values(c.qpos, nq)) c.warning |= WARN_BADQPOS;
-      if (bad_values(c.qvel, nv)) c.warning |= WARN_BADQVEL;
-      if (c.warning) { failure = 1; break; }
-    } else {
-      PFOR(k, nu) actions[t * nu + k] = (H > 1) ? c.ctrl[k] : 0.0;     // trajectory.cc:190-195
-    }
-    forward(c);
-    diag_iter += c.solver_iter; if (c.ncon > diag_ncon) diag_ncon = c.ncon; if (c.nefc > diag_nefc) diag_nefc = c.nefc;
-    PFOR(i, nr) residual[t * nr + i] = c.residual[i];
-    PFOR(i, T.num_trace) {
-      int id = T.trace_objid[i], ty = T.trace_objtype[i];
-      const double *src = ty == 6 ? c.site_xpos + 3 * id : (ty == 5 ? c.geom_xpos + 3 * id : (ty == 1 ? c.xipos + 3 * id : c.xpos + 3 * id));
-      d_copy3(trace + t * ntr + 3 * i, src);
-    }
-    if (!last) {
-      if (bad_values(c.qacc, nv)) c.warning |= WARN_BADQACC;
-      if (c.warning) { failure = 1; break; }
-      PROF(c, 10);
-      integrate(c);
-      PROF(c, 11);
-      PFOR(i, nq) states[(t + 1) * ds + i] = c.qpos[i];
-      PFOR(i, nv) states[(t + 1) * ds + nq + i] = c.qvel[i];
-      if (LANE == 0) times[t + 1] = c.time;
-    } else if (c.warning) { failure = 1; break; }
-    // UpdateReturn (trajectory.cc:312-326) folded into the loop: same left-to-right sum over t
-    double ct = cost_value(c, c.residual);
-    if (LANE == 0) costs[t] = ct;
-    total += ct;
-  }
+DEV_NOINLINE void ph_finish(KP Kc, double total, int failure) {
+  Ctx c; ctx_open(c, Kc);
+  const KParams *K = c.K;
+  int r = cand_index(), H = K->H;
   if (LANE == 0) {
     K->returns[r] = failure ? 1.0e6 : total / (H > 1 ? H : 1);
     K->failure[r] = failure ? (c.warning ? c.warning : 1) : 0;
 #if defined(MJPC_PROFILE) && !defined(MJPC_EMU)
     if (K->prof) for (int q = 0; q < NPROF; q++) K->prof[(size_t)r * NPROF + q] = c.prof[q];
 #endif
-    if (K->diag) { K->diag[4 * r] = diag_iter; K->diag[4 * r + 1] = diag_ncon; K->diag[4 * r + 2] = diag_nefc; K->diag[4 * r + 3] = c.warning; }
+    if (K->diag) { K->diag[4 * r] = c.misc[5]; K->diag[4 * r + 1] = c.misc[6]; K->diag[4 * r + 2] = c.misc[7]; K->diag[4 * r + 3] = c.warning; }
   }
+}
+
+// ======================================================================================
+// the whole rollout of the workgroup's candidate  (trajectory.cc:100-210 + 312-326)
+// ======================================================================================
+template <int NVT>
+DEV void rollout(KP Kc) {
+  int H = Kc->H;
+  ph_init(Kc);
+  double total = 0;
+  int failure = 0;
+  for (int t = 0; t < H; t++) {
+    int last = (t == H - 1);
+    if (!last && ph_action(Kc, t)) { failure = 1; break; }
+    ph_position<NVT>(Kc);
+    ph_velocity<NVT>(Kc);
+    ph_solve<NVT>(Kc);
+    CostOut o = ph_residual_cost(Kc, t, last);
+    if (o.warning) { failure = 1; break; }
+    if (!last) ph_integrate<NVT>(Kc, t);
+    total += o.cost;
+  }
+  ph_finish(Kc, total, failure);
 }

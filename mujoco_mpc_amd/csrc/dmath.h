@@ -7,6 +7,18 @@
 #define D_MINVAL 1e-15
 #define D_PI 3.14159265358979323846
 
+// 1/sqrt(x) to full fp64 accuracy without the IEEE sqrt/divide sequences (0 -> 0 so that T = x*rsqrt(x) = 0)
+DEV double fast_rsqrt(double x) {
+  if (!(x > 0)) return 0.0;
+#ifdef MJPC_EMU
+  return 1.0 / sqrt(x);
+#else
+  double y = __builtin_amdgcn_rsq(x);
+  y = y * (1.5 - 0.5 * x * y * y);
+  y = y * (1.5 - 0.5 * x * y * y);
+  return y;
+#endif
+}
 DEV double d_dot3(const double *a, const double *b) { return a[0]*b[0] + a[1]*b[1] + a[2]*b[2]; }
 DEV double d_norm3(const double *a) { return sqrt(a[0]*a[0] + a[1]*a[1] + a[2]*a[2]); }
 DEV void d_copy3(double *r, const double *a) { r[0]=a[0]; r[1]=a[1]; r[2]=a[2]; }

@@ -18,11 +18,19 @@
 #include "host.h"
 
 // ------------------------------------------------------------------------------ kernels
-extern "C" __global__ void __launch_bounds__(64) rollout_kernel(const KParams K) {
-  extern __shared__ __align__(16) double lds[];
-  int r = blockIdx.x;
-  if (r >= K.nlocal) return;
-  rollout(&K, lds, r);
+// NVT = number of dofs known at compile time (register-resident factorisations), 0 = generic
+template <int NVT>
+__global__ void __launch_bounds__(64) rollout_kernel(const KParams K) {
+  if ((int)blockIdx.x >= K.nlocal) return;
+  rollout<NVT>((KP)__builtin_amdgcn_kernarg_segment_ptr());
+}
+typedef void (*RolloutFn)(const KParams);
+static RolloutFn pick_rollout_kernel(int nv) {
+  switch (nv) {
+    case 2: return rollout_kernel<2>;
+    case 18: return rollout_kernel<18>;
+    default: return rollout_kernel<0>;
+  }
 }
 
 __device__ inline void philox4x32_10(unsigned long long seed, unsigned long long stream, unsigned c0, unsigned c1, unsigned out[4]) {
@@ -104,6 +112,7 @@ struct MjpcHipEngine {
   // kernel timing accumulation
   double acc_rollout_us = 0, acc_total_us = 0; int acc_n = 0;
   size_t lds_bytes = 0;
+  RolloutFn kernel = nullptr;
 };
 
 static int upload_model(MjpcHipEngine *e) {
@@ -160,7 +169,8 @@ MjpcHipEngine *mjpc_hip_create(const MjpcHipModel *model, const MjpcHipTask *tas
   HIPCHKP(hipMemset(e->d_prof, 0, sizeof(long long) * NL * 24));
   HIPCHKP(hipMalloc(&e->d_winner_val, sizeof(double) * 2));
   HIPCHKP(hipHostMalloc(&e->h_small, sizeof(double) * (e->ds + 7 * e->nmocap + e->P_max * (e->nu + 1) + 16)));
-  HIPCHKP(hipFuncSetAttribute((const void *)rollout_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_bytes));
+  e->kernel = pick_rollout_kernel(e->nv);
+  HIPCHKP(hipFuncSetAttribute((const void *)e->kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_bytes));
   return e;
 }
 
@@ -238,7 +248,7 @@ int mjpc_hip_plan_async(MjpcHipEngine *e, const MjpcHipPlanInput *in) {
   K.states = e->d_states; K.actions = e->d_actions; K.times = e->d_times; K.residual = e->d_residual; K.costs = e->d_costs;
   K.trace = e->d_trace; K.knots = e->d_knots; K.returns = e->d_returns; K.failure = e->d_failure; K.diag = e->d_diag; K.prof = e->d_prof;
   HIPCHK(hipEventRecord(e->ev[1], e->stream));
-  hipLaunchKernelGGL(rollout_kernel, dim3(nl), dim3(64), e->lds_bytes, e->stream, K);
+  hipLaunchKernelGGL(e->kernel, dim3(nl), dim3(64), e->lds_bytes, e->stream, K);
   HIPCHK(hipEventRecord(e->ev[2], e->stream));
   hipLaunchKernelGGL(argmin_kernel, dim3(1), dim3(64), 0, e->stream, e->d_returns, nl, e->d_winner, e->d_winner_val);
   HIPCHK(hipEventRecord(e->ev[3], e->stream));

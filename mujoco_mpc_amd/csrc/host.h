@@ -61,6 +61,7 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
   int nb = m->nbody, nj = m->njnt, nv = m->nv, ng = m->ngeom, ns = m->nsite, nu = m->nu;
   if (nv > 64) { p.error = "nv > 64 not supported (dof bitmask)"; return false; }
   if (m->na != 0) { p.error = "activation states (na > 0) not supported"; return false; }
+  if (m->nefcmax > 192) { p.error = "nefcmax > 192 not supported (line-search rows per lane)"; return false; }
   M.nq = m->nq; M.nv = nv; M.nu = nu; M.nbody = nb; M.njnt = nj; M.ngeom = ng; M.nsite = ns; M.nmocap = m->nmocap;
   M.nkey = m->nkey; M.nvp = nv | 1;
   M.cone = m->cone; M.iterations = m->iterations; M.ls_iterations = m->ls_iterations; M.disableflags = m->disableflags;
@@ -171,15 +172,15 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
   A_(subtree_com, 3 * nb); A_(cinert, 10 * nb); A_(crb, 10 * nb); A_(cdof, 6 * nv + 18); A_(cvel, 6 * nb); A_(cdof_dot, 6 * nv + 18);
   A_(cacc, 6 * nb); A_(cfrc, 6 * nb); A_(cfrc_sub, 6 * nb); A_(subtree_linvel, 3 * nb); A_(bodytmp, 3 * nb);
   A_(qM, nv * nvp + 1); A_(qL, nv * nvp + 1); A_(qH, nv * nvp + 1); A_(Linv, nv + 1); A_(Hinv, nv + 1);
-  A_(efc_J, ne * nvp + 1); A_(efc_D, ne); A_(efc_R, ne); A_(efc_aref, ne); A_(efc_force, ne); A_(efc_jar, ne); A_(efc_jv, ne);
+  A_(efc_J, ne * nvp + 1); A_(efc_WJ, (ne - M.nfric) * nvp + 1); A_(efc_D, ne); A_(efc_R, ne); A_(efc_aref, ne); A_(efc_force, ne); A_(efc_jar, ne); A_(efc_jv, ne);
   A_(efc_floss, ne); A_(efc_pos, ne); A_(efc_margin, ne); A_(efc_diag, ne);
   A_(contact, nc * CON_STRIDE + 1);
-  A_(Ma, nv + 1); A_(grad, nv + 1); A_(Mgrad, nv + 1); A_(search, nv + 1); A_(Mv, nv + 1); A_(vtmp, nv + 1);
-  A_(knot_times, P_max); A_(knot_values, P_max * nu + 1); A_(residual, nr + 1); A_(terms, t->num_term + 1); A_(red, 8);
+  A_(Ma, nv + 1); A_(grad, nv + 1); A_(Mgrad, nv + 1); A_(search, nv + 1); A_(Mv, nv + 1); A_(vtmp, nv + 1); A_(sgl, 4 * nv + 1);
+  A_(knot_times, P_max); A_(knot_values, P_max * nu + 1); A_(residual, nr + 1); A_(terms, t->num_term + 1); A_(red, 8); A_(prof, 26);
   L.ints = o;
 #undef A_
   int io = 0;
-  L.i_efc_type = io; io += ne; L.i_efc_id = io; io += ne; L.i_efc_state = io; io += ne;
+  L.i_efc_type = io; io += ne; L.i_efc_id = io; io += ne; L.i_efc_state = io; io += ne; L.i_efc_dof = io; io += ne;
   L.i_con = io; io += nc * CONI_STRIDE; L.i_active = io; io += MAX_ACTIVE_PAIRS; L.i_misc = io; io += 8;
   L.total_doubles = o + (io + 1) / 2;
   return true;

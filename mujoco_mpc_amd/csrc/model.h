@@ -67,12 +67,12 @@ struct Lay {
   int xpos, xquat, xmat, xipos, ximat, xanchor, xaxis, geom_xpos, geom_xmat, site_xpos;
   int subtree_com, cinert, crb, cdof, cvel, cdof_dot, cacc, cfrc, cfrc_sub, subtree_linvel, bodytmp;
   int qM, qL, qH, Linv, Hinv;
-  int efc_J, efc_D, efc_R, efc_aref, efc_force, efc_jar, efc_jv, efc_floss, efc_pos, efc_margin, efc_diag;
+  int efc_J, efc_WJ, efc_D, efc_R, efc_aref, efc_force, efc_jar, efc_jv, efc_floss, efc_pos, efc_margin, efc_diag;
   int contact;
-  int Ma, grad, Mgrad, search, Mv, vtmp;
-  int knot_times, knot_values, residual, terms, red;
+  int Ma, grad, Mgrad, search, Mv, vtmp, sgl;
+  int knot_times, knot_values, residual, terms, red, prof;
   int ints;            // start of the int region (in doubles)
-  int i_efc_type, i_efc_id, i_efc_state, i_con, i_active, i_misc;
+  int i_efc_type, i_efc_id, i_efc_state, i_efc_dof, i_con, i_active, i_misc;
   int total_doubles;   // LDS bytes = 8 * total_doubles
 };
 

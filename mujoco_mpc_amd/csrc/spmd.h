@@ -13,6 +13,7 @@
 
 #ifdef MJPC_EMU
 #define DEV static inline
+#define DEV_NOINLINE static
 #define LANE 0
 #define NLANE 1
 #define SYNC() ((void)0)
@@ -27,6 +28,7 @@ DEV int wave_excl_scan(int v, int *total) { *total = v; return 0; }
 #else
 #include <hip/hip_runtime.h>
 #define DEV static __device__ __forceinline__
+#define DEV_NOINLINE static __device__ __noinline__
 #define LANE ((int)threadIdx.x)
 #define NLANE 64
 #define SYNC() __syncthreads()

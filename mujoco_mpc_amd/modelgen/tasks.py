@@ -121,8 +121,8 @@ _CALF_INERTIAL = dict(mass=0.226, pos=(0.00472659, 0, -0.131975), quat=(0.706886
 
 def quadruped(timestep=0.01, transitioned=True):
     b = ModelBuilder(timestep=timestep, cone=1, impratio=10.0, contact=True)
-    b.nconmax = 48
-    b.nefcmax = 160
+    b.nconmax = 32
+    b.nefcmax = 128
     # world geoms (task_flat.xml:52-61)
     b.geom(0, "floor", PLANE, pos=(0, 0, -0.01), size=(0, 0, 0.1))
     b.geom(0, "ramp", BOX, pos=(3.13, 2.5, -0.18), size=(1.6, 1, 0.5), euler=(0, -0.2, 0))

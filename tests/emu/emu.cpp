@@ -34,7 +34,8 @@ extern "C" int emu_plan(const MjpcHipModel *m, const MjpcHipTask *t, const MjpcH
   std::vector<double> lds((size_t)pm.L.total_doubles + 16);
   for (int r = 0; r < nl; r++) {
     for (auto &v : lds) v = 0.0 / 0.0;      // poison: catches reads of uninitialised LDS
-    rollout(&K, lds.data(), r);
+    g_emu_lds = lds.data(); g_emu_r = r;
+    rollout<0>(&K);
   }
   return pm.L.total_doubles;
 }

@@ -25,6 +25,18 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md)
 
 
+def measured_traffic(N, H):
+    """HBM bytes per rollout_kernel launch from the committed rocprofv3 PMC passes (profiles/r1/b_traffic.json:
+    FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE); only valid for the workload it was measured on."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "r1", "b_traffic.json")))
+        if t.get("workload") == f"C2 quadruped {N}x{H}":
+            return t["traffic_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
+
+
 def algorithmic_bytes_per_candidate_step(model, task):
     """the Trajectory I/O contract in fp64: state + action + residual + trace + time + cost."""
     ds = model["nq"] + model["nv"] + model["na"]
@@ -139,7 +151,7 @@ def main():
                        "lds_bytes_per_candidate": be.lds_bytes(),
                        "winner": res["winner"], "winner_return": res["winner_return"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(N, H),
                          "kernel": "rollout_kernel", "avg_launch_us": rollout_us, "launches": nlaunch,
                          "algorithmic_bytes_per_launch": bytes_per_launch, "bytes_per_candidate_step": b_step,
                          "plan_device_us": total_us},

@@ -49,6 +49,7 @@ def cpu_baseline(model, task, d, kt, kv, N, H, seconds_target=12.0):
     import __graft_entry__ as g
     g.build_oracle()
     import oracle_lib as ol
+    ol.FAST = True                           # -O3 -march=native build of the oracle, compiled on this box
     ncpu = os.cpu_count() or 1
     threads = max(1, ncpu - 5)               # testspeed default: hw_threads - 5 (mjpc/testspeed_app.cc:24)
     o = ol.Oracle(model, task)
@@ -64,7 +65,7 @@ def cpu_baseline(model, task, d, kt, kv, N, H, seconds_target=12.0):
         o.plan(d["state"], d["mocap"], 0.0, kt, kv, 2, N, H, sigma=(0.04, 0.0), seed=0x5EED, stream=r, nthreads=threads)
     dt = time.perf_counter() - t0
     return dict(value=N * reps / dt, unit="rollouts/s", cores=threads, kind="port",
-                sample=f"{reps} plan step(s) of the same workload (N={N}, H={H}) on the CPU oracle's FIFO pool, "
+                sample=f"{reps} plan step(s) of the same workload (N={N}, H={H}) on the CPU oracle's FIFO pool (gcc -O3 -march=native), "
                        f"{threads} threads of {ncpu} host cpus; plan-step {1e3 * dt / reps:.1f} ms")
 
 

@@ -62,13 +62,13 @@ struct Ctx {
   double *xpos, *xquat, *xmat, *xipos, *ximat, *xanchor, *xaxis, *geom_xpos, *geom_xmat, *site_xpos;
   double *subtree_com, *cinert, *crb, *cdof, *cvel, *cdof_dot, *cacc, *cfrc, *cfrc_sub, *subtree_linvel, *bodytmp;
   double *qM, *qL, *qH, *Linv, *Hinv;
-  double *efc_J, *efc_WJ, *efc_D, *efc_R, *efc_aref, *efc_force, *efc_jar, *efc_jv, *efc_floss, *efc_pos, *efc_margin, *efc_diag;
+  double *efc_J, *efc_WJ, *efc_JA, *efc_D, *efc_R, *efc_aref, *efc_force, *efc_jar, *efc_jv, *efc_floss, *efc_pos, *efc_margin, *efc_diag;
   double *contact;
   double *Ma, *grad, *Mgrad, *search, *Mv, *vtmp, *sgl;
   double *knot_times, *knot_values, *residual, *terms, *red;
   int *efc_type, *efc_id, *efc_state, *efc_dof, *con_i, *active, *misc;
   double time;
-  int ncon, nefc, nsingle, warning, solver_iter;
+  int ncon, nefc, nsingle, warning, solver_iter, cross;
 };
 
 DEV void ctx_init(Ctx &c, const KParams *K, double *base) {
@@ -80,7 +80,7 @@ DEV void ctx_init(Ctx &c, const KParams *K, double *base) {
   P_(xpos); P_(xquat); P_(xmat); P_(xipos); P_(ximat); P_(xanchor); P_(xaxis); P_(geom_xpos); P_(geom_xmat); P_(site_xpos);
   P_(subtree_com); P_(cinert); P_(crb); P_(cdof); P_(cvel); P_(cdof_dot); P_(cacc); P_(cfrc); P_(cfrc_sub);
   P_(subtree_linvel); P_(bodytmp); P_(qM); P_(qL); P_(qH); P_(Linv); P_(Hinv);
-  P_(efc_J); P_(efc_WJ); P_(efc_D); P_(efc_R); P_(efc_aref); P_(efc_force); P_(efc_jar); P_(efc_jv); P_(efc_floss);
+  P_(efc_J); P_(efc_WJ); P_(efc_JA); P_(efc_D); P_(efc_R); P_(efc_aref); P_(efc_force); P_(efc_jar); P_(efc_jv); P_(efc_floss);
   P_(efc_pos); P_(efc_margin); P_(efc_diag); P_(contact);
   P_(Ma); P_(grad); P_(Mgrad); P_(search); P_(Mv); P_(vtmp); P_(sgl);
   P_(knot_times); P_(knot_values); P_(residual); P_(terms); P_(red);
@@ -88,7 +88,7 @@ DEV void ctx_init(Ctx &c, const KParams *K, double *base) {
   int *ib = (int *)(base + L.ints);
   c.efc_type = ib + L.i_efc_type; c.efc_id = ib + L.i_efc_id; c.efc_state = ib + L.i_efc_state; c.efc_dof = ib + L.i_efc_dof;
   c.con_i = ib + L.i_con; c.active = ib + L.i_active; c.misc = ib + L.i_misc;
-  c.time = 0; c.ncon = 0; c.nefc = 0; c.nsingle = 0; c.warning = 0; c.solver_iter = 0;
+  c.time = 0; c.ncon = 0; c.nefc = 0; c.nsingle = 0; c.warning = 0; c.solver_iter = 0; c.cross = 0;
 #if defined(MJPC_PROFILE) && !defined(MJPC_EMU)
   c.prof = (long long *)(base + L.prof);
 #endif
@@ -98,13 +98,13 @@ DEV void ctx_init(Ctx &c, const KParams *K, double *base) {
 DEV void ctx_open(Ctx &c, KP Kc) {
   ctx_init(c, kp_generic(Kc), lds_base());
   c.ncon = uniform_i(c.misc[0]); c.nefc = uniform_i(c.misc[1]); c.nsingle = uniform_i(c.misc[2]);
-  c.warning = uniform_i(c.misc[3]); c.solver_iter = uniform_i(c.misc[4]);
+  c.warning = uniform_i(c.misc[3]); c.solver_iter = uniform_i(c.misc[4]); c.cross = uniform_i(c.misc[8]);
   c.time = c.red[0];
 }
 DEV void ctx_close(Ctx &c) {
   SYNC();
   if (LANE == 0) {
-    c.misc[0] = c.ncon; c.misc[1] = c.nefc; c.misc[2] = c.nsingle; c.misc[3] = c.warning; c.misc[4] = c.solver_iter;
+    c.misc[0] = c.ncon; c.misc[1] = c.nefc; c.misc[2] = c.nsingle; c.misc[3] = c.warning; c.misc[4] = c.solver_iter; c.misc[8] = c.cross;
     c.red[0] = c.time;
   }
   SYNC();
@@ -682,6 +682,15 @@ DEV void make_constraint(Ctx &c) {
     nefc += tot;
   }
   c.nefc = nefc;
+  // cross-branch contacts (both bodies movable, neither dof chain contains the other) break M's sparsity pattern in H
+  int crossflag = 0;
+  PFOR(ci, c.ncon) {
+    unsigned long long m1 = M.body_dofmask[M.geom_bodyid[c.con_i[ci * CONI_STRIDE + 1]]];
+    unsigned long long m2 = M.body_dofmask[M.geom_bodyid[c.con_i[ci * CONI_STRIDE + 2]]];
+    unsigned long long u = m1 | m2;
+    if (u != m1 && u != m2) crossflag = 1;
+  }
+  c.cross = wave_or_i(crossflag);
   SYNC();
   // Jacobian
   PFOR(e, nefc * nvp) c.efc_J[e] = 0;
@@ -1236,7 +1245,7 @@ DEV_NOINLINE void ph_init(KP Kc) {
     c.xquat[0] = 1; c.xquat[1] = 0; c.xquat[2] = 0; c.xquat[3] = 0;
     for (int k = 0; k < 9; k++) { c.xmat[k] = (k % 4 == 0) ? 1.0 : 0.0; c.ximat[k] = c.xmat[k]; }
     for (int k = 0; k < 6; k++) { c.cvel[k] = 0; c.cfrc[k] = 0; c.cacc[k] = (k >= 3) ? -M.gravity[k - 3] : 0.0; }
-    for (int k = 0; k < 8; k++) c.misc[k] = 0;
+    for (int k = 0; k < 12; k++) c.misc[k] = 0;
 #if defined(MJPC_PROFILE) && !defined(MJPC_EMU)
     for (int q = 0; q < NPROF; q++) c.prof[q] = 0;
     c.prof[NPROF] = (long long)__builtin_amdgcn_s_memtime();

@@ -116,7 +116,16 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
   { std::vector<int> pi, pj;
     for (int i = 0; i < nv; i++) for (int j = i; j >= 0; j = m->dof_parentid[j]) { pi.push_back(i); pj.push_back(j); }
     M.nmpair = (int)pi.size();
-    M.mpair_i = as_off<int>(put_i(p, pi.data(), pi.size())); M.mpair_j = as_off<int>(put_i(p, pj.data(), pj.size())); }
+    M.mpair_i = as_off<int>(put_i(p, pi.data(), pi.size())); M.mpair_j = as_off<int>(put_i(p, pj.data(), pj.size()));
+    // the structurally-zero part of the lower triangle (dof pairs on different branches)
+    std::vector<int> zi, zj;
+    for (int i = 0; i < nv; i++) for (int j = 0; j < i; j++) {
+      bool anc = false;
+      for (int a = i; a >= 0; a = m->dof_parentid[a]) if (a == j) anc = true;
+      if (!anc) { zi.push_back(i); zj.push_back(j); }
+    }
+    M.nzpair = (int)zi.size();
+    M.zpair_i = as_off<int>(put_i(p, zi.data(), zi.size())); M.zpair_j = as_off<int>(put_i(p, zj.data(), zj.size())); }
   // dof chain bitmask per body
   { std::vector<double> masks(nb);
     for (int b = 0; b < nb; b++) {
@@ -172,7 +181,7 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
   A_(subtree_com, 3 * nb); A_(cinert, 10 * nb); A_(crb, 10 * nb); A_(cdof, 6 * nv + 18); A_(cvel, 6 * nb); A_(cdof_dot, 6 * nv + 18);
   A_(cacc, 6 * nb); A_(cfrc, 6 * nb); A_(cfrc_sub, 6 * nb); A_(subtree_linvel, 3 * nb); A_(bodytmp, 3 * nb);
   A_(qM, nv * nvp + 1); A_(qL, nv * nvp + 1); A_(qH, nv * nvp + 1); A_(Linv, nv + 1); A_(Hinv, nv + 1);
-  A_(efc_J, ne * nvp + 1); A_(efc_WJ, (ne - M.nfric) * nvp + 1); A_(efc_D, ne); A_(efc_R, ne); A_(efc_aref, ne); A_(efc_force, ne); A_(efc_jar, ne); A_(efc_jv, ne);
+  A_(efc_J, ne * nvp + 1); A_(efc_WJ, (ne - M.nfric) * nvp + 1); A_(efc_JA, (ne - M.nfric) * nvp + 1); A_(efc_D, ne); A_(efc_R, ne); A_(efc_aref, ne); A_(efc_force, ne); A_(efc_jar, ne); A_(efc_jv, ne);
   A_(efc_floss, ne); A_(efc_pos, ne); A_(efc_margin, ne); A_(efc_diag, ne);
   A_(contact, nc * CON_STRIDE + 1);
   A_(Ma, nv + 1); A_(grad, nv + 1); A_(Mgrad, nv + 1); A_(search, nv + 1); A_(Mv, nv + 1); A_(vtmp, nv + 1); A_(sgl, 4 * nv + 1);
@@ -181,7 +190,7 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
 #undef A_
   int io = 0;
   L.i_efc_type = io; io += ne; L.i_efc_id = io; io += ne; L.i_efc_state = io; io += ne; L.i_efc_dof = io; io += ne;
-  L.i_con = io; io += nc * CONI_STRIDE; L.i_active = io; io += MAX_ACTIVE_PAIRS; L.i_misc = io; io += 8;
+  L.i_con = io; io += nc * CONI_STRIDE; L.i_active = io; io += MAX_ACTIVE_PAIRS; L.i_misc = io; io += 16;
   L.total_doubles = o + (io + 1) / 2;
   return true;
 }
@@ -204,7 +213,7 @@ static inline DevModel relocate(const PackedModel &p, const int *ibase, const do
   fi(M.actuator_dofadr); fi(M.actuator_qposadr); fi(M.actuator_ctrllimited); fi(M.actuator_forcelimited); fi(M.actuator_biastype);
   fd(M.actuator_gainprm); fd(M.actuator_biasprm); fd(M.actuator_gear); fd(M.actuator_ctrlrange); fd(M.actuator_forcerange);
   fd(M.key_qpos);
-  fi(M.level_adr); fi(M.level_body); fi(M.subtree_adr); fi(M.subtree_list); fi(M.mpair_i); fi(M.mpair_j);
+  fi(M.level_adr); fi(M.level_body); fi(M.subtree_adr); fi(M.subtree_list); fi(M.mpair_i); fi(M.mpair_j); fi(M.zpair_i); fi(M.zpair_j);
   { const double *q = reinterpret_cast<const double *>(M.body_dofmask); fd(q); M.body_dofmask = reinterpret_cast<const unsigned long long *>(q); }
   fi(M.pair_g1); fi(M.pair_g2); fi(M.fric_dof); fi(M.limit_jnt); fi(M.ray_geom);
   DevTask &T = M.task;

@@ -63,7 +63,7 @@ DEV void chol_solve_lds(const double *L, const double *Linv, double *x, int n, i
 // ---- register versions (compile-time n) -----------------------------------------------------
 #ifndef MJPC_EMU
 template <int N>
-DEV void chol_factor_reg(double *A, double *Linv, int nvp) {
+DEV void chol_factor_reg(double *A, double *Linv, double *colbuf, int nvp) {
   static_assert(N >= 1 && N <= 64, "one matrix row per lane");
   SYNC();
   const int i = LANE;
@@ -78,8 +78,15 @@ DEV void chol_factor_reg(double *A, double *Linv, int nvp) {
     double inv = fast_rsqrt(ajj), dj = ajj * inv;       // pivot without IEEE sqrt + divide on the column chain
     double lij = (i == j) ? dj : a[j] * inv;
     a[j] = lij;
+    if (j + 1 < N) {
+      // column j of L goes through an LDS line; every lane then reads L[k][j] as a broadcast with an
+      // immediate offset (2 instructions per trailing update instead of 2 readlanes + FMA)
+      if (act) colbuf[i] = lij;
+      SYNC();
 #pragma unroll
-    for (int k = j + 1; k < N; k++) a[k] -= lij * readlane_d(lij, k);   // A[i][k] -= L[i][j] * L[k][j]
+      for (int k = j + 1; k < N; k++) a[k] -= lij * colbuf[k];   // A[i][k] -= L[i][j] * L[k][j]
+      SYNC();
+    }
     if (i == 0) Linv[j] = inv;
   }
 #pragma unroll
@@ -114,14 +121,14 @@ DEV void chol_solve_reg(const double *L, const double *Linv, double *x, int nvp)
 template <int NVT>
 DEV void chol_factor(double *A, double *Linv, double *tmp, int n, int nvp) {
 #ifndef MJPC_EMU
-  if constexpr (NVT > 0) { chol_factor_reg<NVT>(A, Linv, nvp); return; }
+  if constexpr (NVT > 0) { chol_factor_reg<NVT>(A, Linv, tmp, NVT | 1); return; }
 #endif
   chol_factor_lds(A, Linv, tmp, n, nvp);
 }
 template <int NVT>
 DEV void chol_solve(const double *L, const double *Linv, double *x, int n, int nvp) {
 #ifndef MJPC_EMU
-  if constexpr (NVT > 0) { chol_solve_reg<NVT>(L, Linv, x, nvp); return; }
+  if constexpr (NVT > 0) { chol_solve_reg<NVT>(L, Linv, x, NVT | 1); return; }
 #endif
   chol_solve_lds(L, Linv, x, n, nvp);
 }

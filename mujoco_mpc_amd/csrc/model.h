@@ -34,7 +34,7 @@ struct DevTask {
 
 struct DevModel {
   int nq, nv, nu, nbody, njnt, ngeom, nsite, nmocap, nkey, nvp;
-  int nlevel, npair, nfric, nlimit, nray, nmpair, nconmax, nefcmax, any_damping;
+  int nlevel, npair, nfric, nlimit, nray, nmpair, nzpair, nconmax, nefcmax, any_damping;
   int cone, iterations, ls_iterations, disableflags;
   double timestep, gravity[3], impratio, tolerance, ls_tolerance, meaninertia;
   const int *body_parentid, *body_rootid, *body_mocapid, *body_jntnum, *body_jntadr, *body_dofnum, *body_dofadr;
@@ -54,6 +54,7 @@ struct DevModel {
   const int *level_adr, *level_body;        // bodies grouped by tree depth (depth >= 1)
   const int *subtree_adr, *subtree_list;    // bodies of each subtree, self first, ascending ids
   const int *mpair_i, *mpair_j;             // (dof i, ancestor-or-self dof j): the non-zeros of M
+  const int *zpair_i, *zpair_j;             // the rest of the lower triangle (structural zeros of M)
   const unsigned long long *body_dofmask;   // bit d set <=> dof d moves body
   const int *pair_g1, *pair_g2;             // statically filtered geom pairs (type1 <= type2)
   const int *fric_dof, *limit_jnt, *ray_geom;
@@ -67,7 +68,7 @@ struct Lay {
   int xpos, xquat, xmat, xipos, ximat, xanchor, xaxis, geom_xpos, geom_xmat, site_xpos;
   int subtree_com, cinert, crb, cdof, cvel, cdof_dot, cacc, cfrc, cfrc_sub, subtree_linvel, bodytmp;
   int qM, qL, qH, Linv, Hinv;
-  int efc_J, efc_WJ, efc_D, efc_R, efc_aref, efc_force, efc_jar, efc_jv, efc_floss, efc_pos, efc_margin, efc_diag;
+  int efc_J, efc_WJ, efc_JA, efc_D, efc_R, efc_aref, efc_force, efc_jar, efc_jv, efc_floss, efc_pos, efc_margin, efc_diag;
   int contact;
   int Ma, grad, Mgrad, search, Mv, vtmp, sgl;
   int knot_times, knot_values, residual, terms, red, prof;

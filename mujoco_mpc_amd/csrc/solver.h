@@ -133,20 +133,32 @@ DEV double solver_eval(Ctx &c, const double *qacc, double *gauss_out) {
 template <int NVT>
 DEV void newton_gradient(Ctx &c) {
   const DevModel &M = *c.M;
-  int nv = M.nv, nvp = M.nvp, nefc = c.nefc, ns = c.nsingle;
+  const int nv = NVT > 0 ? NVT : M.nv, nvp = NVT > 0 ? (NVT | 1) : M.nvp;     // compile-time strides => immediate LDS offsets
+  int nefc = c.nefc, ns = c.nsingle;
   int ncrow = nefc - ns;
   PROF(c, 13);
-  // WJ = blockdiag(W) J over contact rows: one lane per row, all columns (independent, pipelined loads)
-  PFOR(rr, ncrow) {
-    int r = ns + rr;
+  // ordered compaction of the ACTIVE contact rows (quadratic or cone state): satisfied rows contribute nothing
+  int nact = 0;
+  for (int base = 0; base < ncrow; base += NLANE) {
+    int rr = base + LANE;
+    int flag = (rr < ncrow) && (c.efc_state[ns + rr] != STATE_SATISFIED);
+    int tot, off = wave_excl_scan(flag, &tot);
+    if (flag) c.active[nact + off] = ns + rr;
+    nact += tot;
+  }
+  SYNC();
+  // JA = J rows, WJ = blockdiag(W) J rows of the active set: one lane per row, all columns
+  PFOR(a, nact) {
+    int r = c.active[a];
     int st = c.efc_state[r];
-    double *W = c.efc_WJ + rr * nvp;
+    double *W = c.efc_WJ + a * nvp, *JA = c.efc_JA + a * nvp;
     const double *Jr = c.efc_J + r * nvp;
+    c.efc_jv[a] = c.efc_force[r];                 // compact forces (jv is free between line searches)
     if (st == STATE_QUADRATIC) {
       double D = c.efc_D[r];
 #pragma unroll 6
-      for (int j = 0; j < nv; j++) W[j] = D * Jr[j];
-    } else if (st == STATE_CONE) {
+      for (int j = 0; j < nv; j++) { double v = Jr[j]; JA[j] = v; W[j] = D * v; }
+    } else {
       int ci = c.efc_id[r];
       int dim = c.con_i[ci * CONI_STRIDE], r0 = c.con_i[ci * CONI_STRIDE + 3];
       const double *Hc = c.contact + ci * CON_STRIDE + CON_H + (r - r0) * 6;
@@ -161,39 +173,43 @@ DEV void newton_gradient(Ctx &c) {
         double w = 0;
 #pragma unroll
         for (int b = 0; b < 6; b++) w += hc[b] * c.efc_J[rb[b] + j];
-        W[j] = w;
+        W[j] = w; JA[j] = Jr[j];
       }
-    } else {
-#pragma unroll 6
-      for (int j = 0; j < nv; j++) W[j] = 0;
     }
   }
   PROF(c, 19);
+  SYNC();
   // gradient: Ma - qfrc_smooth - J^T force; diagonal Hessian terms of the single-entry rows
   PFOR(i, nv) {
     double g = c.Ma[i] - c.qfrc_smooth[i] - (c.sgl[i] + c.sgl[2 * nv + i]);
     double hd = c.sgl[nv + i] + c.sgl[3 * nv + i];
 #pragma unroll 8
-    for (int r = ns; r < nefc; r++) g -= c.efc_J[r * nvp + i] * c.efc_force[r];
+    for (int a = 0; a < nact; a++) g -= c.efc_JA[a * nvp + i] * c.efc_jv[a];
     c.grad[i] = g;
     c.Mgrad[i] = g;
     c.vtmp[i] = hd;
   }
   SYNC();
   PROF(c, 15);
-  int ntri = nv * (nv + 1) / 2;
-  PFOR(e, ntri) {
-    int i = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
-    while ((i + 1) * (i + 2) / 2 <= e) i++;
-    while (i * (i + 1) / 2 > e) i--;
-    int j = e - i * (i + 1) / 2;
+  // H = M + diag + JA^T WJ on the lower triangle; without cross-branch contacts only M's sparsity pattern is non-zero
+  int nent = c.cross ? nv * (nv + 1) / 2 : M.nmpair;
+  PFOR(e, nent) {
+    int i, j;
+    if (c.cross) {
+      i = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+      while ((i + 1) * (i + 2) / 2 <= e) i++;
+      while (i * (i + 1) / 2 > e) i--;
+      j = e - i * (i + 1) / 2;
+    } else { i = M.mpair_i[e]; j = M.mpair_j[e]; }
     double h = c.qM[i * nvp + j];
     if (i == j) h += c.vtmp[i];
-    const double *Ji = c.efc_J + ns * nvp + i, *Wj = c.efc_WJ + j;
+    const double *Ji = c.efc_JA + i, *Wj = c.efc_WJ + j;
 #pragma unroll 8
-    for (int rr = 0; rr < ncrow; rr++) h += Ji[rr * nvp] * Wj[rr * nvp];
+    for (int a = 0; a < nact; a++) h += Ji[a * nvp] * Wj[a * nvp];
     c.qH[i * nvp + j] = h;
   }
+  // the in-place factor of the previous iteration filled the structural zeros: clear them again
+  if (!c.cross) PFOR(e, M.nzpair) c.qH[M.zpair_i[e] * nvp + M.zpair_j[e]] = 0;
   PROF(c, 16);
   chol_factor<NVT>(c.qH, c.Hinv, c.vtmp, nv, nvp);
   PROF(c, 17);
@@ -315,11 +331,13 @@ DEV double line_search(Ctx &c, double gauss, double *q1_out, double *q2_out) {
   SYNC();
   double snorm = sqrt(wave_sum(p_sn)), q1 = wave_sum(p_q1), q2 = wave_sum(p_q2);
   *q1_out = q1; *q2_out = q2;
+  PROF(c, 20);
   double scale = 1.0 / (M.meaninertia * (nv > 1 ? nv : 1));
   if (snorm < D_MINVAL) return 0;
   double gtol = M.tolerance * M.ls_tolerance * snorm / scale;
   LSData d;
   ls_load(c, d);
+  PROF(c, 21);
   LSPoint p0 = ls_eval(d, gauss, q1, q2, 0.0);
   if (!(p0.d2 > 0) || p0.d1 >= 0) return 0;
   // safeguarded Newton on phi'(alpha) (rtsafe): expand until phi' changes sign, then Newton steps that stay
@@ -328,6 +346,9 @@ DEV double line_search(Ctx &c, double gauss, double *q1_out, double *q2_out) {
   double best_a = 0, best_cost = p0.cost, dxold = a, dx = a;
   for (int it = 0; it < M.ls_iterations; it++) {
     LSPoint p = ls_eval(d, gauss, q1, q2, a);
+#if defined(MJPC_PROFILE) && !defined(MJPC_EMU)
+    if (LANE == 0) c.prof[23] += 1;
+#endif
     if (p.cost < best_cost) { best_cost = p.cost; best_a = a; }
     if (fabs(p.d1) < gtol) break;
     if (p.d1 < 0) lo = a; else hi = a;
@@ -346,6 +367,7 @@ DEV double line_search(Ctx &c, double gauss, double *q1_out, double *q2_out) {
     if (an == a) break;
     a = an;
   }
+  PROF(c, 22);
   return best_a;
 }
 

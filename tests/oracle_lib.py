@@ -24,6 +24,7 @@ class OPlanOutput(C.Structure):
 
 
 _lib = None
+FAST = False      # bench.py's cpu_baseline sets this before the first use: -O3 -march=native build, rebuilt locally
 
 
 def lib():
@@ -32,9 +33,13 @@ def lib():
         return _lib
     srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith((".c", ".h"))]
     srcs.append(os.path.join(ROOT, "include", "mjpc_hip.h"))
-    if (not os.path.exists(ORACLE_SO)) or any(os.path.getmtime(s) > os.path.getmtime(ORACLE_SO) for s in srcs):
+    so = ORACLE_SO
+    if FAST:
+        so = os.path.join(ORACLE_DIR, "_build", "liboracle_fast.so")
+        subprocess.check_call(["make", "-B", "-C", ORACLE_DIR, "fast"], stdout=subprocess.DEVNULL)   # -march=native: build where it runs
+    elif (not os.path.exists(ORACLE_SO)) or any(os.path.getmtime(s) > os.path.getmtime(ORACLE_SO) for s in srcs):
         subprocess.check_call(["make", "-C", ORACLE_DIR], stdout=subprocess.DEVNULL)
-    L = C.CDLL(ORACLE_SO)
+    L = C.CDLL(so)
     L.oracle_create.restype = C.c_void_p
     L.oracle_create.argtypes = [C.POINTER(capi.MjpcHipModel), C.POINTER(capi.MjpcHipTask)]
     L.oracle_destroy.argtypes = [C.c_void_p]

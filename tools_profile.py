@@ -24,9 +24,10 @@ be.lib.mjpc_hip_debug_fetch_prof.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)
 be.lib.mjpc_hip_debug_fetch_prof(be.h, prof.ctypes.data_as(C.POINTER(C.c_longlong)))
 allc = be.fetch_all(N, H, P)
 names = ["(loop overhead/record)", "kinematics", "com_pos", "crb+factorM", "collision", "make_constraint", "velocity+smooth", "impedance(+warm)",
-         "solver tail", "residual", "cost+record", "integrate", "solver_eval/update", "newton misc", "line_search", "grad", "H build", "chol_factor(H)", "chol_solve(H)", "WJ"]
-tot = prof.sum(1).mean()
+         "solver tail", "residual", "cost+record", "integrate", "solver_eval/update", "newton misc", "line_search", "grad", "H build", "chol_factor(H)", "chol_solve(H)", "WJ", "ls: Mv,jv", "ls: load", "ls: evals"]
+tot = prof[:, :23].sum(1).mean()
 print(f"rollout us {out['rollouts_compute_time_us']:.0f}; mean stamped ticks/candidate {tot:.3e} ")
 for i, n in enumerate(names):
     print(f"  {n:26s} {100*prof[:, i].mean()/tot:6.2f} %   {prof[:, i].mean()/tot*out['rollouts_compute_time_us']/H:8.2f} us/step")
+print("ls evals per step (mean)", prof[:, 23].mean() / H)
 print("newton iters per step (mean)", allc["diag"][:, 0].mean() / H, "max ncon", allc["diag"][:, 1].max(), "max nefc", allc["diag"][:, 2].max())

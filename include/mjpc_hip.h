@@ -48,7 +48,8 @@ enum {
   MJPC_TASK_PARTICLE = 0,   /* mjpc/test/testdata/particle_residual.h:33-43 */
   MJPC_TASK_CARTPOLE = 1,   /* mjpc/tasks/cartpole/cartpole.cc:36-49 */
   MJPC_TASK_QUADRUPED = 2,  /* mjpc/tasks/quadruped/quadruped.cc:33-221 */
-  MJPC_TASK_COPYSTATE = 3   /* residual = [qpos,qvel] (mjpc/test/agent/rollout_test.cc:40-60) */
+  MJPC_TASK_COPYSTATE = 3,  /* residual = [qpos,qvel] (mjpc/test/agent/rollout_test.cc:40-60) */
+  MJPC_TASK_HUMANOID_TRACK = 4  /* mjpc/tasks/humanoid/tracking/tracking.cc:94-216 */
 };
 enum { MJPC_OBJ_BODY = 1, MJPC_OBJ_XBODY = 2, MJPC_OBJ_GEOM = 5, MJPC_OBJ_SITE = 6 };
 
@@ -60,7 +61,7 @@ enum { MJPC_OBJ_BODY = 1, MJPC_OBJ_XBODY = 2, MJPC_OBJ_GEOM = 5, MJPC_OBJ_SITE =
 /* ---- model: the subset of mjModel the path reads ------------------------------------- */
 typedef struct MjpcHipModel {
   /* sizes */
-  int nq, nv, nu, na, nbody, njnt, ngeom, nsite, nmocap, nuserdata, nkey, nexclude;
+  int nq, nv, nu, na, nbody, njnt, ngeom, nsite, nmocap, nuserdata, nkey, nexclude, ntendon, nwrap;
   /* mjOption */
   double timestep;
   double gravity[3];
@@ -107,8 +108,12 @@ typedef struct MjpcHipModel {
   const double *actuator_biasprm;   /* 3 per actuator (first 3 of mjNBIAS) */
   const double *actuator_gear;      /* 1 per actuator (first of 6) */
   const double *actuator_ctrlrange, *actuator_forcerange;
+  /* fixed tendons (wrap objects are joints; wrap_prm = coefficient) */
+  const int *tendon_adr, *tendon_num, *tendon_limited, *wrap_objid;
+  const double *wrap_prm, *tendon_range, *tendon_margin, *tendon_solref_lim, *tendon_solimp_lim, *tendon_invweight0;
   /* keyframes */
   const double *key_qpos;           /* nkey * nq */
+  const double *key_mpos;           /* nkey * 3*nmocap */
 } MjpcHipModel;
 
 /* ---- task: cost table (mjpc/task.cc:147-245) + frozen ResidualFn state --------------- */

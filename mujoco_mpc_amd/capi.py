@@ -16,7 +16,7 @@ ENGINE_PATH = os.path.join(_HERE, "csrc", "libmjpc_hip.so")
 c_double_p = C.POINTER(C.c_double)
 c_int_p = C.POINTER(C.c_int)
 
-_MODEL_INT_SIZES = ["nq", "nv", "nu", "na", "nbody", "njnt", "ngeom", "nsite", "nmocap", "nuserdata", "nkey", "nexclude"]
+_MODEL_INT_SIZES = ["nq", "nv", "nu", "na", "nbody", "njnt", "ngeom", "nsite", "nmocap", "nuserdata", "nkey", "nexclude", "ntendon", "nwrap"]
 _MODEL_INT_ARRAYS_BODY = ["body_parentid", "body_rootid", "body_weldid", "body_mocapid", "body_jntnum", "body_jntadr",
                           "body_dofnum", "body_dofadr"]
 _MODEL_DBL_ARRAYS_BODY = ["body_pos", "body_quat", "body_ipos", "body_iquat", "body_mass", "body_subtreemass",
@@ -46,7 +46,10 @@ class MjpcHipModel(C.Structure):
         + [(n, c_int_p) for n in ["actuator_trnid", "actuator_ctrllimited", "actuator_forcelimited", "actuator_biastype"]]
         + [(n, c_double_p) for n in ["actuator_gainprm", "actuator_biasprm", "actuator_gear", "actuator_ctrlrange",
                                      "actuator_forcerange"]]
-        + [("key_qpos", c_double_p)]
+        + [(n, c_int_p) for n in ["tendon_adr", "tendon_num", "tendon_limited", "wrap_objid"]]
+        + [(n, c_double_p) for n in ["wrap_prm", "tendon_range", "tendon_margin", "tendon_solref_lim", "tendon_solimp_lim",
+                                     "tendon_invweight0"]]
+        + [("key_qpos", c_double_p), ("key_mpos", c_double_p)]
     )
 
 

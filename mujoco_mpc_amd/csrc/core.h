@@ -580,7 +580,7 @@ DEV void collision(Ctx &c) {
     if (c.ncon + tot > M.nconmax) { c.warning |= WARN_CONTACTFULL; break; }
     for (int k = 0; k < n; k++) {
       int ci = c.ncon + off + k;
-      double *cc = c.contact + ci * CON_STRIDE;
+      double *cc = c.contact + ci * c.M->con_stride;
       int dim;
       contact_param(M, g1, g2, cc, &dim);
       double fr[9];
@@ -654,13 +654,37 @@ DEV void make_constraint(Ctx &c) {
   }
   int nlim_end = nefc;
   c.nsingle = nlim_end;
+  // fixed-tendon limits (general rows: several Jacobian entries), lower side before upper side
+  int ntl0 = nefc;
+  for (int base = 0; base < M.ntendon; base += NLANE) {
+    int t = base + LANE, cnt = 0;
+    double dist[2] = {0, 0}; int side[2] = {0, 0};
+    if (t < M.ntendon && M.tendon_limited[t]) {
+      double value = 0, margin = M.tendon_margin[t];
+      for (int w = M.tendon_adr[t]; w < M.tendon_adr[t] + M.tendon_num[t]; w++) value += M.wrap_prm[w] * c.qpos[M.wrap_qposadr[w]];
+      for (int s = -1; s <= 1; s += 2) {
+        double dd = s * (M.tendon_range[2 * t + (s + 1) / 2] - value);
+        if (dd < margin) { dist[cnt] = dd; side[cnt] = s; cnt++; }
+      }
+    }
+    int tot, off = wave_excl_scan(cnt, &tot);
+    if (nefc + tot > M.nefcmax) { c.warning |= WARN_CNSTRFULL; break; }
+    for (int k = 0; k < cnt; k++) {
+      int r = nefc + off + k;
+      c.efc_type[r] = CNSTR_LIMIT_TENDON; c.efc_id[r] = t;
+      c.efc_floss[r] = (double)(-side[k]);      // sign of the Jacobian, consumed below
+      c.efc_pos[r] = dist[k]; c.efc_margin[r] = M.tendon_margin[t];
+      c.efc_diag[r] = M.tendon_invweight0[t];
+    }
+    nefc += tot;
+  }
+  int ntl_end = nefc;
   // contacts: dim rows each
   for (int base = 0; base < c.ncon; base += NLANE) {
     int ci = base + LANE, dim = 0;
     if (ci < c.ncon) {
       dim = c.con_i[ci * CONI_STRIDE];
-      if (dim > 1 && M.cone != 1) dim = 1;       // pyramidal cones not built yet: normal only (DESIGN.md gap)
-      c.con_i[ci * CONI_STRIDE] = dim;
+      if (dim > 1 && M.cone != 1) dim = 2 * (dim - 1);     // pyramidal cone: 2(dim-1) edge rows
     }
     int tot, off = wave_excl_scan(dim, &tot);
     if (nefc + tot > M.nefcmax) { c.warning |= WARN_CNSTRFULL; c.ncon = base; break; }
@@ -671,12 +695,15 @@ DEV void make_constraint(Ctx &c) {
       int b1 = M.geom_bodyid[g1], b2 = M.geom_bodyid[g2];
       double tran = M.body_invweight0[2 * b1] + M.body_invweight0[2 * b2];
       double rot = M.body_invweight0[2 * b1 + 1] + M.body_invweight0[2 * b2 + 1];
-      const double *cc = c.contact + ci * CON_STRIDE;
+      const double *cc = c.contact + ci * c.M->con_stride;
+      int cdim = c.con_i[ci * CONI_STRIDE];
+      int pyr = (cdim > 1 && M.cone != 1);
       for (int k = 0; k < dim; k++) {
-        c.efc_type[r0 + k] = dim == 1 ? CNSTR_CONTACT_FRICTIONLESS : CNSTR_CONTACT_ELLIPTIC;
+        c.efc_type[r0 + k] = cdim == 1 ? CNSTR_CONTACT_FRICTIONLESS : (pyr ? CNSTR_CONTACT_PYRAMIDAL : CNSTR_CONTACT_ELLIPTIC);
         c.efc_id[r0 + k] = ci;
         c.efc_floss[r0 + k] = 0; c.efc_pos[r0 + k] = cc[CON_DIST]; c.efc_margin[r0 + k] = cc[CON_INCLUDEMARGIN];
-        c.efc_diag[r0 + k] = k < 3 ? tran : rot;
+        if (pyr) { double mu = cc[CON_FRICTION + k / 2]; c.efc_diag[r0 + k] = tran + mu * mu * (k < 4 ? tran : rot); }
+        else c.efc_diag[r0 + k] = k < 3 ? tran : rot;
       }
     }
     nefc += tot;
@@ -699,15 +726,22 @@ DEV void make_constraint(Ctx &c) {
     if (r < M.nfric) c.efc_J[r * nvp + c.efc_id[r]] = 1;
     else { c.efc_J[r * nvp + M.jnt_dofadr[c.efc_id[r]]] = c.efc_floss[r]; c.efc_floss[r] = 0; }
   }
+  PFOR(rr, ntl_end - ntl0) {
+    int r = ntl0 + rr, t = c.efc_id[r];
+    double sg = c.efc_floss[r];
+    for (int w = M.tendon_adr[t]; w < M.tendon_adr[t] + M.tendon_num[t]; w++) c.efc_J[r * nvp + M.wrap_dofadr[w]] = sg * M.wrap_prm[w];
+    c.efc_floss[r] = 0;
+  }
   PFOR(e, c.ncon * nv) {
     int ci = e / nv, d = e - ci * nv;
     const int *cin = c.con_i + ci * CONI_STRIDE;
     int dim = cin[0], r0 = cin[3];
+    int pyr = (dim > 1 && M.cone != 1);
     int b1 = M.geom_bodyid[cin[1]], b2 = M.geom_bodyid[cin[2]];
     unsigned long long bit = 1ull << d;
     int in1 = (M.body_dofmask[b1] & bit) != 0, in2 = (M.body_dofmask[b2] & bit) != 0;
     if (!in1 && !in2) continue;
-    const double *cc = c.contact + ci * CON_STRIDE;
+    const double *cc = c.contact + ci * c.M->con_stride;
     const double *cd = c.cdof + 6 * d;
     double jp[3] = {0, 0, 0}, jr[3] = {0, 0, 0};
     if (in2) {
@@ -724,10 +758,21 @@ DEV void make_constraint(Ctx &c) {
       jp[0] -= cd[3] + t[0]; jp[1] -= cd[4] + t[1]; jp[2] -= cd[5] + t[2];
       jr[0] -= cd[0]; jr[1] -= cd[1]; jr[2] -= cd[2];
     }
-    for (int k = 0; k < dim; k++) {
-      const double *ax = cc + CON_FRAME + 3 * (k % 3);
-      const double *jj = k < 3 ? jp : jr;
-      c.efc_J[(r0 + k) * nvp + d] = ax[0] * jj[0] + ax[1] * jj[1] + ax[2] * jj[2];
+    if (pyr) {
+      double jn = cc[CON_FRAME] * jp[0] + cc[CON_FRAME + 1] * jp[1] + cc[CON_FRAME + 2] * jp[2];
+      for (int k = 1; k < dim; k++) {
+        const double *ax = cc + CON_FRAME + 3 * (k % 3);
+        const double *jj = k < 3 ? jp : jr;
+        double jk = ax[0] * jj[0] + ax[1] * jj[1] + ax[2] * jj[2], mu = cc[CON_FRICTION + k - 1];
+        c.efc_J[(r0 + 2 * (k - 1)) * nvp + d] = jn + mu * jk;
+        c.efc_J[(r0 + 2 * (k - 1) + 1) * nvp + d] = jn - mu * jk;
+      }
+    } else {
+      for (int k = 0; k < dim; k++) {
+        const double *ax = cc + CON_FRAME + 3 * (k % 3);
+        const double *jj = k < 3 ? jp : jr;
+        c.efc_J[(r0 + k) * nvp + d] = ax[0] * jj[0] + ax[1] * jj[1] + ax[2] * jj[2];
+      }
     }
   }
   SYNC();
@@ -749,11 +794,14 @@ DEV void make_impedance(Ctx &c) {
     } else if (type == CNSTR_LIMIT_JOINT) {
       for (int k = 0; k < 2; k++) solref[k] = M.jnt_solref[2 * id + k];
       for (int k = 0; k < 5; k++) solimp[k] = M.jnt_solimp[5 * id + k];
+    } else if (type == CNSTR_LIMIT_TENDON) {
+      for (int k = 0; k < 2; k++) solref[k] = M.tendon_solref_lim[2 * id + k];
+      for (int k = 0; k < 5; k++) solimp[k] = M.tendon_solimp_lim[5 * id + k];
     } else {
-      const double *cc = c.contact + id * CON_STRIDE;
+      const double *cc = c.contact + id * c.M->con_stride;
       for (int k = 0; k < 2; k++) solref[k] = cc[CON_SOLREF + k];
       for (int k = 0; k < 5; k++) solimp[k] = cc[CON_SOLIMP + k];
-      first = (r == c.con_i[id * CONI_STRIDE + 3]);
+      first = (r == c.con_i[id * CONI_STRIDE + 3]) || type == CNSTR_CONTACT_PYRAMIDAL;
     }
     double imp = impedance(solimp, c.efc_pos[r], c.efc_margin[r]);
     double dmax = d_clip(solimp[1], 0.0001, 0.9999);
@@ -774,12 +822,18 @@ DEV void make_impedance(Ctx &c) {
   PFOR(ci, c.ncon) {
     int dim = c.con_i[ci * CONI_STRIDE];
     if (dim > 1) {
-      double *cc = c.contact + ci * CON_STRIDE;
+      double *cc = c.contact + ci * c.M->con_stride;
       double *R = c.efc_R + c.con_i[ci * CONI_STRIDE + 3];
-      R[1] = R[0] / fmax(D_MINVAL, M.impratio);
-      cc[CON_MU] = cc[CON_FRICTION] * sqrt(R[1] / R[0]);
-      for (int k = 2; k < dim; k++)
-        R[k] = R[1] * cc[CON_FRICTION] * cc[CON_FRICTION] / (cc[CON_FRICTION + k - 1] * cc[CON_FRICTION + k - 1]);
+      double R1 = R[0] / fmax(D_MINVAL, M.impratio);
+      cc[CON_MU] = cc[CON_FRICTION] * sqrt(R1 / R[0]);
+      if (M.cone != 1) {        // pyramidal: every edge row gets Rpy = 2 mu^2 R0
+        double Rpy = 2 * cc[CON_MU] * cc[CON_MU] * R[0];
+        for (int k = 0; k < 2 * (dim - 1); k++) R[k] = Rpy;
+      } else {
+        R[1] = R1;
+        for (int k = 2; k < dim; k++)
+          R[k] = R[1] * cc[CON_FRICTION] * cc[CON_FRICTION] / (cc[CON_FRICTION + k - 1] * cc[CON_FRICTION + k - 1]);
+      }
     }
   }
   SYNC();
@@ -1128,6 +1182,49 @@ DEV void residual_quadruped(Ctx &c, double *residual) {
   }
 }
 
+// mjpc/tasks/humanoid/tracking/tracking.cc:94-216 (int_data: motion, first key, length, 16 site ids, 16 mocap ids)
+DEV void residual_humanoid_track(Ctx &c, double *residual) {
+  const DevModel &M = *c.M;
+  const int *I = M.task.int_data;
+  const double kFps = 30.0;
+  int start = I[1], length = I[2], nv = M.nv, nu = M.nu;
+  double current_index = (c.time - M.task.dbl_data[0]) * kFps + start;
+  int last_key_index = start + length - 1;
+  double ci = current_index < 0 ? 0 : (current_index > last_key_index ? (double)last_key_index : current_index);
+  int k0 = (int)floor(ci), k1 = k0 + 1 < last_key_index ? k0 + 1 : last_key_index;
+  double w1 = ci - k0, w0 = 1.0 - w1;
+  PFOR(i, nv - 6) residual[i] = c.qvel[6 + i];
+  PFOR(i, nu) residual[nv - 6 + i] = c.ctrl[i];
+  int o = nv - 6 + nu;
+  // interpolated markers (vtmp-free scratch: bodytmp holds 16x3 markers) and averages
+  PFOR(b, 16) {
+    int mid = I[19 + b];
+    const double *p0 = M.key_mpos + M.nmocap * 3 * k0 + 3 * mid, *p1 = M.key_mpos + M.nmocap * 3 * k1 + 3 * mid;
+    double mp[3];
+    d_scl3(mp, p0, w0); d_addtoscl3(mp, p1, w1);
+    d_copy3(c.bodytmp + 3 * b, mp);
+    // velocity residual: finite-difference marker velocity minus framelinvel of the tracking site
+    int sid = I[3 + b], body = M.site_bodyid[sid];
+    double v[3], off[3], lin[3];
+    d_sub3(v, p1, p0); d_scl3(v, v, kFps);
+    d_sub3(off, c.site_xpos + 3 * sid, c.subtree_com + 3 * M.body_rootid[body]);
+    d_cross(lin, c.cvel + 6 * body, off);
+    d_add3(lin, lin, c.cvel + 6 * body + 3);
+    d_sub3(residual + o + 3 + 48 + 3 * b, v, lin);
+  }
+  SYNC();
+  double avg_m[3] = {0, 0, 0}, avg_s[3] = {0, 0, 0};
+  for (int b = 0; b < 16; b++) { d_add3(avg_m, avg_m, c.bodytmp + 3 * b); d_add3(avg_s, avg_s, c.site_xpos + 3 * I[3 + b]); }
+  d_scl3(avg_m, avg_m, 1.0 / 16); d_scl3(avg_s, avg_s, 1.0 / 16);
+  if (LANE == 0) d_sub3(residual + o, avg_m, avg_s);
+  PFOR(b, 16) {
+    double bm[3], bs[3];
+    d_sub3(bm, c.bodytmp + 3 * b, avg_m);
+    d_sub3(bs, c.site_xpos + 3 * I[3 + b], avg_s);
+    d_sub3(residual + o + 3 + 3 * b, bm, bs);
+  }
+}
+
 DEV void task_residual(Ctx &c, double *residual) {
   const DevModel &M = *c.M;
   int id = M.task.task_id;
@@ -1146,6 +1243,8 @@ DEV void task_residual(Ctx &c, double *residual) {
     PFOR(i, M.nv) residual[M.nq + i] = c.qvel[i];
   } else if (id == 2) {
     residual_quadruped(c, residual);
+  } else if (id == 4) {
+    residual_humanoid_track(c, residual);
   }
   SYNC();
 }

@@ -29,6 +29,7 @@ static RolloutFn pick_rollout_kernel(int nv) {
   switch (nv) {
     case 2: return rollout_kernel<2>;
     case 18: return rollout_kernel<18>;
+    case 27: return rollout_kernel<27>;
     default: return rollout_kernel<0>;
   }
 }

@@ -63,10 +63,11 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
   if (m->na != 0) { p.error = "activation states (na > 0) not supported"; return false; }
   if (m->nefcmax > 192) { p.error = "nefcmax > 192 not supported (line-search rows per lane)"; return false; }
   M.nq = m->nq; M.nv = nv; M.nu = nu; M.nbody = nb; M.njnt = nj; M.ngeom = ng; M.nsite = ns; M.nmocap = m->nmocap;
-  M.nkey = m->nkey; M.nvp = nv | 1;
+  M.nkey = m->nkey; M.nvp = nv | 1; M.ntendon = m->ntendon;
   M.cone = m->cone; M.iterations = m->iterations; M.ls_iterations = m->ls_iterations; M.disableflags = m->disableflags;
   M.timestep = m->timestep; for (int k = 0; k < 3; k++) M.gravity[k] = m->gravity[k];
   M.impratio = m->impratio; M.tolerance = m->tolerance; M.ls_tolerance = m->ls_tolerance; M.meaninertia = m->meaninertia;
+  M.con_stride = (m->cone == MJPC_CONE_ELLIPTIC) ? CON_STRIDE_ELLIPTIC : CON_STRIDE_PLAIN;
   M.nconmax = m->nconmax > 0 ? m->nconmax : 32;
   if (M.nconmax > 64) M.nconmax = 64;
   M.nefcmax = m->nefcmax > 0 ? m->nefcmax : 128;
@@ -89,13 +90,19 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
   PI_(actuator_ctrllimited, nu); PI_(actuator_forcelimited, nu); PI_(actuator_biastype, nu);
   PD_(actuator_gainprm, 3 * nu); PD_(actuator_biasprm, 3 * nu); PD_(actuator_gear, nu);
   PD_(actuator_ctrlrange, 2 * nu); PD_(actuator_forcerange, 2 * nu);
-  PD_(key_qpos, (size_t)m->nkey * m->nq);
+  PD_(key_qpos, (size_t)m->nkey * m->nq); PD_(key_mpos, (size_t)m->nkey * 3 * m->nmocap);
+  PI_(tendon_adr, m->ntendon); PI_(tendon_num, m->ntendon); PI_(tendon_limited, m->ntendon);
+  PD_(wrap_prm, m->nwrap); PD_(tendon_range, 2 * m->ntendon); PD_(tendon_margin, m->ntendon);
+  PD_(tendon_solref_lim, 2 * m->ntendon); PD_(tendon_solimp_lim, 5 * m->ntendon); PD_(tendon_invweight0, m->ntendon);
 #undef PI_
 #undef PD_
   // actuator -> dof / qpos address (joint transmission)
   { std::vector<int> da(nu), qa(nu);
     for (int i = 0; i < nu; i++) { int j = m->actuator_trnid[i]; da[i] = m->jnt_dofadr[j]; qa[i] = m->jnt_qposadr[j]; }
     M.actuator_dofadr = as_off<int>(put_i(p, da.data(), nu)); M.actuator_qposadr = as_off<int>(put_i(p, qa.data(), nu)); }
+  { std::vector<int> wd(m->nwrap), wq(m->nwrap);
+    for (int w = 0; w < m->nwrap; w++) { int j = m->wrap_objid[w]; wd[w] = m->jnt_dofadr[j]; wq[w] = m->jnt_qposadr[j]; }
+    M.wrap_dofadr = as_off<int>(put_i(p, wd.data(), wd.size())); M.wrap_qposadr = as_off<int>(put_i(p, wq.data(), wq.size())); }
   // bodies by depth
   { std::vector<int> depth(nb, 0); int maxd = 0;
     for (int b = 1; b < nb; b++) { depth[b] = depth[m->body_parentid[b]] + 1; if (depth[b] > maxd) maxd = depth[b]; }
@@ -183,7 +190,7 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
   A_(qM, nv * nvp + 1); A_(qL, nv * nvp + 1); A_(qH, nv * nvp + 1); A_(Linv, nv + 1); A_(Hinv, nv + 1);
   A_(efc_J, ne * nvp + 1); A_(efc_WJ, (ne - M.nfric) * nvp + 1); A_(efc_JA, (ne - M.nfric) * nvp + 1); A_(efc_D, ne); A_(efc_R, ne); A_(efc_aref, ne); A_(efc_force, ne); A_(efc_jar, ne); A_(efc_jv, ne);
   A_(efc_floss, ne); A_(efc_pos, ne); A_(efc_margin, ne); A_(efc_diag, ne);
-  A_(contact, nc * CON_STRIDE + 1);
+  A_(contact, nc * M.con_stride + 1);
   A_(Ma, nv + 1); A_(grad, nv + 1); A_(Mgrad, nv + 1); A_(search, nv + 1); A_(Mv, nv + 1); A_(vtmp, nv + 1); A_(sgl, 4 * nv + 1);
   A_(knot_times, P_max); A_(knot_values, P_max * nu + 1); A_(residual, nr + 1); A_(terms, t->num_term + 1); A_(red, 8); A_(prof, 26);
   L.ints = o;
@@ -212,7 +219,9 @@ static inline DevModel relocate(const PackedModel &p, const int *ibase, const do
   fi(M.site_bodyid); fd(M.site_pos); fd(M.site_quat);
   fi(M.actuator_dofadr); fi(M.actuator_qposadr); fi(M.actuator_ctrllimited); fi(M.actuator_forcelimited); fi(M.actuator_biastype);
   fd(M.actuator_gainprm); fd(M.actuator_biasprm); fd(M.actuator_gear); fd(M.actuator_ctrlrange); fd(M.actuator_forcerange);
-  fd(M.key_qpos);
+  fd(M.key_qpos); fd(M.key_mpos);
+  fi(M.tendon_adr); fi(M.tendon_num); fi(M.tendon_limited); fi(M.wrap_dofadr); fi(M.wrap_qposadr);
+  fd(M.wrap_prm); fd(M.tendon_range); fd(M.tendon_margin); fd(M.tendon_solref_lim); fd(M.tendon_solimp_lim); fd(M.tendon_invweight0);
   fi(M.level_adr); fi(M.level_body); fi(M.subtree_adr); fi(M.subtree_list); fi(M.mpair_i); fi(M.mpair_j); fi(M.zpair_i); fi(M.zpair_j);
   { const double *q = reinterpret_cast<const double *>(M.body_dofmask); fd(q); M.body_dofmask = reinterpret_cast<const unsigned long long *>(q); }
   fi(M.pair_g1); fi(M.pair_g2); fi(M.fric_dof); fi(M.limit_jnt); fi(M.ray_geom);

@@ -8,7 +8,8 @@
 #pragma once
 #include <stdint.h>
 
-#define CON_STRIDE 63          // doubles per contact in LDS (odd: conflict-free field access)
+#define CON_STRIDE_ELLIPTIC 63  // doubles per contact in LDS incl. the 6x6 cone Hessian (odd: conflict-free field access)
+#define CON_STRIDE_PLAIN 27     // without the cone Hessian (pyramidal / frictionless models)
 #define CON_DIST 0
 #define CON_POS 1
 #define CON_FRAME 4
@@ -21,7 +22,7 @@
 #define CONI_STRIDE 4          // ints per contact: dim, geom1, geom2, efc_address
 #define MAX_ACTIVE_PAIRS 192
 
-enum { CNSTR_FRICTION_DOF = 1, CNSTR_LIMIT_JOINT = 3, CNSTR_CONTACT_FRICTIONLESS = 5, CNSTR_CONTACT_ELLIPTIC = 7 };
+enum { CNSTR_FRICTION_DOF = 1, CNSTR_LIMIT_JOINT = 3, CNSTR_LIMIT_TENDON = 4, CNSTR_CONTACT_FRICTIONLESS = 5, CNSTR_CONTACT_PYRAMIDAL = 6, CNSTR_CONTACT_ELLIPTIC = 7 };
 enum { STATE_SATISFIED = 0, STATE_QUADRATIC = 1, STATE_LINEARNEG = 2, STATE_LINEARPOS = 3, STATE_CONE = 4 };
 enum { WARN_BADQPOS = 1, WARN_BADQVEL = 2, WARN_BADQACC = 4, WARN_CONTACTFULL = 8, WARN_CNSTRFULL = 16, WARN_RAY = 32 };
 
@@ -33,9 +34,9 @@ struct DevTask {
 };
 
 struct DevModel {
-  int nq, nv, nu, nbody, njnt, ngeom, nsite, nmocap, nkey, nvp;
+  int nq, nv, nu, nbody, njnt, ngeom, nsite, nmocap, nkey, nvp, ntendon;
   int nlevel, npair, nfric, nlimit, nray, nmpair, nzpair, nconmax, nefcmax, any_damping;
-  int cone, iterations, ls_iterations, disableflags;
+  int cone, iterations, ls_iterations, disableflags, con_stride;
   double timestep, gravity[3], impratio, tolerance, ls_tolerance, meaninertia;
   const int *body_parentid, *body_rootid, *body_mocapid, *body_jntnum, *body_jntadr, *body_dofnum, *body_dofadr;
   const double *body_pos, *body_quat, *body_ipos, *body_iquat, *body_mass, *body_subtreemass, *body_inertia, *body_invweight0;
@@ -49,7 +50,9 @@ struct DevModel {
   const double *site_pos, *site_quat;
   const int *actuator_dofadr, *actuator_qposadr, *actuator_ctrllimited, *actuator_forcelimited, *actuator_biastype;
   const double *actuator_gainprm, *actuator_biasprm, *actuator_gear, *actuator_ctrlrange, *actuator_forcerange;
-  const double *key_qpos;
+  const int *tendon_adr, *tendon_num, *tendon_limited, *wrap_dofadr, *wrap_qposadr;
+  const double *wrap_prm, *tendon_range, *tendon_margin, *tendon_solref_lim, *tendon_solimp_lim, *tendon_invweight0;
+  const double *key_qpos, *key_mpos;
   // derived on the host at create()
   const int *level_adr, *level_body;        // bodies grouped by tree depth (depth >= 1)
   const int *subtree_adr, *subtree_list;    // bodies of each subtree, self first, ascending ids

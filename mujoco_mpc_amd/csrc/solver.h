@@ -46,9 +46,9 @@ DEV double constraint_update(Ctx &c, int hess) {
   }
   PFOR(ci, c.ncon) {
     int dim = c.con_i[ci * CONI_STRIDE];
-    if (dim <= 1) continue;
     int i = c.con_i[ci * CONI_STRIDE + 3];
-    double *cc = c.contact + ci * CON_STRIDE;
+    if (dim <= 1 || c.efc_type[i] != CNSTR_CONTACT_ELLIPTIC) continue;     // pyramidal edges are plain unilateral rows
+    double *cc = c.contact + ci * c.M->con_stride;
     double mu = cc[CON_MU], U[6], fr[6];
     fr[0] = mu;
 #pragma unroll
@@ -161,7 +161,7 @@ DEV void newton_gradient(Ctx &c) {
     } else {
       int ci = c.efc_id[r];
       int dim = c.con_i[ci * CONI_STRIDE], r0 = c.con_i[ci * CONI_STRIDE + 3];
-      const double *Hc = c.contact + ci * CON_STRIDE + CON_H + (r - r0) * 6;
+      const double *Hc = c.contact + ci * c.M->con_stride + CON_H + (r - r0) * 6;
       double hc[6];
 #pragma unroll
       for (int b = 0; b < 6; b++) hc[b] = b < dim ? Hc[b] : 0.0;
@@ -247,9 +247,9 @@ DEV void ls_load(Ctx &c, LSData &d) {
     for (int j = 0; j < 6; j++) { d.U0[q][j] = 0; d.UV[q][j] = 0; d.E[q][j] = 0; }
     if (ci < c.ncon) {
       int dim = c.con_i[ci * CONI_STRIDE];
-      if (dim > 1) {
-        int i = c.con_i[ci * CONI_STRIDE + 3];
-        const double *cc = c.contact + ci * CON_STRIDE;
+      int i = c.con_i[ci * CONI_STRIDE + 3];
+      if (dim > 1 && c.efc_type[i] == CNSTR_CONTACT_ELLIPTIC) {
+        const double *cc = c.contact + ci * c.M->con_stride;
         double mu = cc[CON_MU];
         d.dim[q] = dim; d.mu[q] = mu;
         d.Dm[q] = c.efc_D[i] / (mu * mu * (1 + mu * mu));

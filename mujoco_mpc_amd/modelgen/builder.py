@@ -131,6 +131,8 @@ class ModelBuilder:
         self.sites: list[tuple] = []
         self.actuators: list[dict] = []
         self.keys: list[tuple] = []
+        self.tendons: list[dict] = []
+        self.key_mpos = None          # optional [nkey, 3*nmocap]
         self.excludes: list[tuple] = []
         self.nuserdata = 0
         self.nconmax = 0
@@ -193,6 +195,11 @@ class ModelBuilder:
         self.actuators.append(dict(name=name, joint=joint, gainprm=tuple(gainprm), biastype=biastype,
                                    biasprm=tuple(biasprm), gear=gear, ctrllimited=ctrllimited,
                                    ctrlrange=tuple(ctrlrange), forcelimited=forcelimited, forcerange=tuple(forcerange)))
+
+    def tendon(self, name, joints, coefs, limited=False, range=(0, 0), margin=0.0, solreflimit=DEF_SOLREF, solimplimit=DEF_SOLIMP):
+        """fixed tendon: length = sum coef * qpos[joint]"""
+        self.tendons.append(dict(name=name, joints=list(joints), coefs=list(coefs), limited=limited, range=tuple(range), margin=margin,
+                                 solref=tuple(solreflimit), solimp=tuple(solimplimit)))
 
     def key(self, name, qpos):
         self.keys.append((name, np.array(qpos, float)))
@@ -409,8 +416,24 @@ class ModelBuilder:
             kq[k, :len(qp)] = qp
         M["key_qpos"] = kq[:nkey].reshape(nkey, nq) if nkey else np.zeros((0, nq))
         M["exclude_signature"] = np.array([(min(a, b) << 16) + max(a, b) for a, b in self.excludes], np.int32)
+        # fixed tendons
+        jnames = [j.name for j in joints]
+        T = self.tendons
+        wrap_objid = []; wrap_prm = []; tadr = []; tnum = []
+        for t in T:
+            tadr.append(len(wrap_objid)); tnum.append(len(t["joints"]))
+            for jn, cf in zip(t["joints"], t["coefs"]):
+                wrap_objid.append(jnames.index(jn) if isinstance(jn, str) else remap[jn]); wrap_prm.append(cf)
+        M["tendon_adr"] = np.array(tadr, np.int32); M["tendon_num"] = np.array(tnum, np.int32)
+        M["tendon_limited"] = np.array([int(t["limited"]) for t in T], np.int32)
+        M["wrap_objid"] = np.array(wrap_objid, np.int32); M["wrap_prm"] = np.array(wrap_prm, float)
+        M["tendon_range"] = np.array([t["range"] for t in T], float).reshape(len(T), 2)
+        M["tendon_margin"] = np.array([t["margin"] for t in T], float)
+        M["tendon_solref_lim"] = np.array([t["solref"] for t in T], float).reshape(len(T), 2)
+        M["tendon_solimp_lim"] = np.array([t["solimp"] for t in T], float).reshape(len(T), 5)
         sizes = dict(nq=nq, nv=nv, nu=nu, na=0, nbody=nb, njnt=nj, ngeom=ng, nsite=ns, nmocap=nmocap,
-                     nuserdata=self.nuserdata, nkey=nkey, nexclude=len(self.excludes))
+                     nuserdata=self.nuserdata, nkey=nkey, nexclude=len(self.excludes), ntendon=len(self.tendons),
+                     nwrap=len(wrap_objid))
         M.update(sizes)
         o = self.opt
         M.update(timestep=o["timestep"], gravity=o["gravity"], impratio=o["impratio"], tolerance=o["tolerance"],
@@ -436,6 +459,15 @@ class ModelBuilder:
             else:
                 dinv[da] = Minv[da, da]
         M["body_invweight0"] = binv; M["dof_invweight0"] = dinv
+        tinv = np.zeros(len(T))
+        for ti, t in enumerate(T):
+            Jt = np.zeros(nv)
+            for k in range(tnum[ti]):
+                Jt[jnt_dofadr[wrap_objid[tadr[ti] + k]]] = wrap_prm[tadr[ti] + k]
+            tinv[ti] = Jt @ Minv @ Jt
+        M["tendon_invweight0"] = tinv
+        km = self.key_mpos if self.key_mpos is not None else np.zeros((nkey, 3 * nmocap))
+        M["key_mpos"] = np.asarray(km, float).reshape(nkey, 3 * nmocap) if nkey else np.zeros((0, 3 * nmocap))
         M["meaninertia"] = max(float(np.mean(np.diag(Mq))) if nv else 1.0, MINVAL)
         # names
         M["names"] = dict(

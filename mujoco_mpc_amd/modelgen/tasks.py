@@ -17,7 +17,7 @@ import numpy as np
 
 from .builder import (BOX, CAPSULE, CYLINDER, FREE, HINGE, PLANE, SLIDE, SPHERE, ModelBuilder)
 
-TASK_PARTICLE, TASK_CARTPOLE, TASK_QUADRUPED, TASK_COPYSTATE = 0, 1, 2, 3
+TASK_PARTICLE, TASK_CARTPOLE, TASK_QUADRUPED, TASK_COPYSTATE, TASK_HUMANOID_TRACK = 0, 1, 2, 3, 4
 OBJ_BODY, OBJ_XBODY, OBJ_GEOM, OBJ_SITE = 1, 2, 5, 6
 NORM_NPARAM = {-1: 0, 0: 0, 1: 2, 2: 1, 3: 1, 5: 1, 6: 1, 7: 2, 8: 1}   # mjpc/norm.cc:25-47
 
@@ -212,4 +212,109 @@ def quadruped(timestep=0.01, transitioned=True):
     return m, task, defaults
 
 
-REGISTRY = {"particle": particle, "cartpole": cartpole, "quadruped": quadruped}
+# ----------------------------------------------------------------------------------- humanoid tracking
+_TRACK_NAMES = ["pelvis", "head", "ltoe", "rtoe", "lheel", "rheel", "lknee", "rknee", "lhand", "rhand", "lelbow", "relbow",
+                "lshoulder", "rshoulder", "lhip", "rhip"]          # tracking.cc:59-63
+
+
+def humanoid_track(timestep=0.005):
+    """mjpc/tasks/humanoid/humanoid.xml.patch (whole-file hunk) + tracking/task.xml; motion 0 ("Jump", 121 keys).
+    MJCF defaults apply: angles in degrees, pyramidal cones, body geoms condim 1 vs floor condim 3 -> condim 3."""
+    import os
+    D = math.pi / 180.0
+    b = ModelBuilder(timestep=timestep, cone=0, impratio=1.0, contact=True)
+    b.nconmax = 24
+    b.nefcmax = 96
+    b.geom(0, "floor", PLANE, size=(50, 50, 0.05))
+    mocap_id = {}
+    for n in _TRACK_NAMES:                      # task.xml:30-77 (mocap bodies carry sites only)
+        mb = b.body(f"mocap[{n}]", 0, mocap=True)
+        b.site(mb, f"mocap[{n}]")
+    G = dict(condim=1, friction=(0.7, 0.005, 0.0001), solimp=(0.9, 0.99, 0.003, 0.5, 2), solref=(0.015, 1))
+    J = dict(damping=0.2, stiffness=1.0, armature=0.01, limited=True, solimplimit=(0, 0.99, 0.01, 0.5, 2))
+    big = {**J, "damping": 5.0, "stiffness": 10.0}
+    stiff = {**big, "stiffness": 20.0}
+
+    def rng(lo, hi):
+        return (lo * D, hi * D)
+    torso = b.body("torso", 0, pos=(0, 0, 1.282))
+    b.joint(torso, "root", FREE)
+    b.geom(torso, "torso", CAPSULE, size=(0.07, 0), fromto=(0, -0.07, 0, 0, 0.07, 0), **G)
+    b.geom(torso, "waist_upper", CAPSULE, size=(0.06, 0), fromto=(-0.01, -0.06, -0.12, -0.01, 0.06, -0.12), **G)
+    head = b.body("head", torso, pos=(0, 0, 0.19))
+    b.geom(head, "head", SPHERE, size=(0.09,), **G)
+    sites = {"head": b.site(head, "tracking[head]", pos=(0.09, 0, 0))}
+    wl = b.body("waist_lower", torso, pos=(-0.01, 0, -0.26))
+    b.geom(wl, "waist_lower", CAPSULE, size=(0.06, 0), fromto=(0, -0.06, 0, 0, 0.06, 0), **G)
+    b.joint(wl, "abdomen_z", HINGE, pos=(0, 0, 0.065), axis=(0, 0, 1), range=rng(-45, 45), **stiff)
+    b.joint(wl, "abdomen_y", HINGE, pos=(0, 0, 0.065), axis=(0, 1, 0), range=rng(-75, 30), **big)
+    pelvis = b.body("pelvis", wl, pos=(0, 0, -0.165))
+    sites["pelvis"] = b.site(pelvis, "tracking[pelvis]", pos=(0, 0, 0.075))
+    b.joint(pelvis, "abdomen_x", HINGE, pos=(0, 0, 0.1), axis=(1, 0, 0), range=rng(-35, 35), **big)
+    b.geom(pelvis, "butt", CAPSULE, size=(0.09, 0), fromto=(-0.02, -0.07, 0, -0.02, 0.07, 0), **G)
+    for side, sg in (("right", -1.0), ("left", 1.0)):
+        s = side[0]
+        th = b.body(f"thigh_{side}", pelvis, pos=(0, 0.1 * sg, -0.04))
+        sites[f"{s}hip"] = b.site(th, f"tracking[{s}hip]", pos=(0, -0.025 * sg, 0.025))
+        b.joint(th, f"hip_x_{side}", HINGE, axis=(-sg, 0, 0), range=rng(-30, 10), **big)
+        b.joint(th, f"hip_z_{side}", HINGE, axis=(0, 0, -sg), range=rng(-60, 35), **big)
+        b.joint(th, f"hip_y_{side}", HINGE, axis=(0, 1, 0), range=rng(-150, 20), **big)
+        b.geom(th, f"thigh_{side}", CAPSULE, size=(0.06, 0), fromto=(0, 0, 0, 0, -0.01 * sg, -0.34), **G)
+        sh = b.body(f"shin_{side}", th, pos=(0, -0.01 * sg, -0.4))
+        b.joint(sh, f"knee_{side}", HINGE, pos=(0, 0, 0.02), axis=(0, -1, 0), range=rng(-160, 2), **J)
+        sites[f"{s}knee"] = b.site(sh, f"tracking[{s}knee]", pos=(0, 0, 0.05))
+        b.geom(sh, f"shin_{side}", CAPSULE, size=(0.049, 0), fromto=(0, 0, 0, 0, 0, -0.3), **G)
+        ft = b.body(f"foot_{side}", sh, pos=(0, 0, -0.39))
+        b.joint(ft, f"ankle_y_{side}", HINGE, pos=(0, 0, 0.08), axis=(0, 1, 0), range=rng(-50, 50), **{**J, "stiffness": 6.0})
+        b.joint(ft, f"ankle_x_{side}", HINGE, pos=(0, 0, 0.04), axis=(-sg, 0, -0.5 * sg), range=rng(-50, 50), **{**J, "stiffness": 3.0})
+        b.geom(ft, f"foot1_{side}", CAPSULE, size=(0.027, 0), fromto=(-0.07, -0.01, 0, 0.14, -0.03, 0), **G)
+        b.geom(ft, f"foot2_{side}", CAPSULE, size=(0.027, 0), fromto=(-0.07, 0.01, 0, 0.14, 0.03, 0), **G)
+        heel = b.body(f"heel_{side}", ft, pos=(-0.05, 0, 0.04))
+        sites[f"{s}heel"] = b.site(heel, f"tracking[{s}heel]")
+        toe = b.body(f"toe_{side}", ft, pos=(0.07, 0, -0.01))
+        sites[f"{s}toe"] = b.site(toe, f"tracking[{s}toe]")
+    for side, sg in (("right", -1.0), ("left", 1.0)):
+        s = side[0]
+        ua = b.body(f"upper_arm_{side}", torso, pos=(0, 0.17 * sg, 0.06))
+        sites[f"{s}shoulder"] = b.site(ua, f"tracking[{s}shoulder]")
+        b.joint(ua, f"shoulder1_{side}", HINGE, axis=(-2 * sg, 1, -sg), range=rng(-85, 60), **J)
+        b.joint(ua, f"shoulder2_{side}", HINGE, axis=(0, -1, -sg), range=rng(-85, 60), **J)
+        b.geom(ua, f"upper_arm_{side}", CAPSULE, size=(0.04, 0), fromto=(0, 0, 0, 0.16, 0.16 * sg, -0.16), **G)
+        la = b.body(f"lower_arm_{side}", ua, pos=(0.18, 0.18 * sg, -0.18))
+        b.joint(la, f"elbow_{side}", HINGE, axis=(0, -1, -sg), range=rng(-100, 50), **{**J, "stiffness": 0.0})
+        sites[f"{s}elbow"] = b.site(la, f"tracking[{s}elbow]")
+        sites[f"{s}hand"] = b.site(la, f"tracking[{s}hand]", pos=(0.13, -0.13 * sg, 0.13))
+        b.geom(la, f"lower_arm_{side}", CAPSULE, size=(0.031, 0), fromto=(0.01, -0.01 * sg, 0.01, 0.17, -0.17 * sg, 0.17), **G)
+        hd = b.body(f"hand_{side}", la, pos=(0.18, -0.18 * sg, 0.18))
+        b.geom(hd, f"hand_{side}", SPHERE, size=(0.04,), **G)
+    b.exclude(b.body_id("waist_lower"), b.body_id("thigh_right"))
+    b.exclude(b.body_id("waist_lower"), b.body_id("thigh_left"))
+    b.tendon("hamstring_right", ["hip_y_right", "knee_right"], [0.5, -0.5], limited=True, range=(-0.3, 2))
+    b.tendon("hamstring_left", ["hip_y_left", "knee_left"], [0.5, -0.5], limited=True, range=(-0.3, 2))
+    for name, gear in [("abdomen_y", 40), ("abdomen_z", 40), ("abdomen_x", 40), ("hip_x_right", 40), ("hip_z_right", 40),
+                       ("hip_y_right", 120), ("knee_right", 100), ("ankle_x_right", 20), ("ankle_y_right", 20),
+                       ("hip_x_left", 40), ("hip_z_left", 40), ("hip_y_left", 120), ("knee_left", 100), ("ankle_x_left", 20),
+                       ("ankle_y_left", 20), ("shoulder1_right", 20), ("shoulder2_right", 20), ("elbow_right", 40),
+                       ("shoulder1_left", 20), ("shoulder2_left", 20), ("elbow_left", 40)]:
+        b.actuator(name, name, gear=float(gear), ctrlrange=(-1, 1))
+    data = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "humanoid_jump_keys.npz"))
+    mpos = data["mpos"]
+    for k in range(mpos.shape[0]):
+        b.key(f"jump_{k + 1}", data["qpos0"] if k == 0 else [])
+    b.key_mpos = mpos
+    m = b.compile()
+    ids_site = [sites[n] for n in _TRACK_NAMES]
+    ids_mocap = [int(m["body_mocapid"][m["names"]["body"][f"mocap[{n}]"]]) for n in _TRACK_NAMES]
+    ints = [0, 0, mpos.shape[0]] + ids_site + ids_mocap
+    terms = [(21, 0, 0.001), (21, 3, 0.1, [0.3]), (3, 6, 100.0, [0.1]), (3, 6, 30.0, [0.1]), (3, 6, 0.0, [0.1]),
+             (6, 7, 30.0, [0.2, 4]), (6, 7, 30.0, [0.2, 4]), (6, 6, 30.0, [0.1]), (6, 6, 30.0, [0.1]), (6, 7, 30.0, [0.2, 4]),
+             (6, 6, 30.0, [0.1]), (6, 6, 30.0, [0.1]),
+             (3, 6, 0.1, [0.3]), (3, 6, 0.0, [0.3])] + [(6, 6, 0.1, [0.3])] * 7
+    task = make_task(TASK_HUMANOID_TRACK, terms, traces=[(OBJ_XBODY, torso)], int_data=ints, dbl_data=[0.0])
+    state = np.concatenate([data["qpos0"], data["qvel0"]])
+    mocap = np.concatenate([np.concatenate([mpos[0, 3 * i:3 * i + 3], [1, 0, 0, 0]]) for i in range(16)])
+    defaults = dict(N=32, P=16, sigma=(0.15, 0.0), interp=2, horizon=101, state=state, mocap=mocap)
+    return m, task, defaults
+
+
+REGISTRY = {"particle": particle, "cartpole": cartpole, "quadruped": quadruped, "humanoid_track": humanoid_track}

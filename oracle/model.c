@@ -57,7 +57,10 @@ OModel *oracle_create(const MjpcHipModel *src, const MjpcHipTask *task) {
   CI(actuator_trnid, nu); CI(actuator_ctrllimited, nu); CI(actuator_forcelimited, nu); CI(actuator_biastype, nu);
   CD(actuator_gainprm, 3 * nu); CD(actuator_biasprm, 3 * nu); CD(actuator_gear, nu);
   CD(actuator_ctrlrange, 2 * nu); CD(actuator_forcerange, 2 * nu);
-  CD(key_qpos, src->nkey * src->nq);
+  CI(tendon_adr, src->ntendon); CI(tendon_num, src->ntendon); CI(tendon_limited, src->ntendon); CI(wrap_objid, src->nwrap);
+  CD(wrap_prm, src->nwrap); CD(tendon_range, 2 * src->ntendon); CD(tendon_margin, src->ntendon);
+  CD(tendon_solref_lim, 2 * src->ntendon); CD(tendon_solimp_lim, 5 * src->ntendon); CD(tendon_invweight0, src->ntendon);
+  CD(key_qpos, src->nkey * src->nq); CD(key_mpos, src->nkey * 3 * src->nmocap);
   copy_task(om, task);
 
   /* static collision filtering */

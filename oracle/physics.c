@@ -400,6 +400,23 @@ static void make_constraint(const OModel *om, OData *d) {
       }
     }
   }
+  /* fixed-tendon limits: length = sum coef*qpos, J = coef at the joints' dofs */
+  for (int t = 0; t < m->ntendon; t++) if (m->tendon_limited[t]) {
+    double value = 0, margin = m->tendon_margin[t];
+    for (int w = m->tendon_adr[t]; w < m->tendon_adr[t] + m->tendon_num[t]; w++) value += m->wrap_prm[w] * d->qpos[m->jnt_qposadr[m->wrap_objid[w]]];
+    for (int side = -1; side <= 1; side += 2) {
+      double dist = side * (m->tendon_range[2 * t + (side + 1) / 2] - value);
+      if (dist < margin) {
+        int r = add_row(om, d, O_CNSTR_LIMIT_TENDON, t); if (r < 0) return;
+        for (int w = m->tendon_adr[t]; w < m->tendon_adr[t] + m->tendon_num[t]; w++) d->efc_J[r * nv + m->jnt_dofadr[m->wrap_objid[w]]] = -side * m->wrap_prm[w];
+        d->efc_pos[r] = dist; d->efc_margin[r] = margin;
+        o_copy(d->efc_solref + 2 * r, m->tendon_solref_lim + 2 * t, 2);
+        o_copy(d->efc_solimp + 5 * r, m->tendon_solimp_lim + 5 * t, 5);
+        d->efc_diagApprox[r] = m->tendon_invweight0[t];
+        d->nl++;
+      }
+    }
+  }
   /* contacts */
   double *jp1 = d->work, *jp2 = jp1 + 3 * nv, *jr1 = jp2 + 3 * nv, *jr2 = jr1 + 3 * nv;
   for (int ci = 0; ci < d->ncon; ci++) {
@@ -407,12 +424,30 @@ static void make_constraint(const OModel *om, OData *d) {
     int b1 = m->geom_bodyid[c->geom1], b2 = m->geom_bodyid[c->geom2];
     int dim = c->dim;
     int elliptic = (dim > 1 && m->cone == MJPC_CONE_ELLIPTIC);
-    if (dim > 1 && !elliptic) { d->unsupported++; dim = 1; }   /* pyramidal cones: not in round 1 */
     jac_point(om, d, jp1, dim > 3 ? jr1 : NULL, c->pos, b1);
     jac_point(om, d, jp2, dim > 3 ? jr2 : NULL, c->pos, b2);
     double tran = m->body_invweight0[2 * b1] + m->body_invweight0[2 * b2];
     double rot = m->body_invweight0[2 * b1 + 1] + m->body_invweight0[2 * b2 + 1];
     c->efc_address = d->nefc;
+    if (dim > 1 && !elliptic) {
+      /* pyramidal cone: 2(dim-1) unilateral rows  Jn +- mu_k * J_k */
+      for (int k = 1; k < dim; k++) for (int sgn = 1; sgn >= -1; sgn -= 2) {
+        int r = add_row(om, d, O_CNSTR_CONTACT_PYRAMIDAL, ci); if (r < 0) return;
+        const double *ax = c->frame + 3 * (k % 3);
+        const double *ja = k < 3 ? jp1 : jr1, *jb = k < 3 ? jp2 : jr2;
+        double mu = c->friction[k - 1];
+        for (int i = 0; i < nv; i++) {
+          double jn = c->frame[0] * (jp2[i] - jp1[i]) + c->frame[1] * (jp2[nv + i] - jp1[nv + i]) + c->frame[2] * (jp2[2 * nv + i] - jp1[2 * nv + i]);
+          double jk = ax[0] * (jb[i] - ja[i]) + ax[1] * (jb[nv + i] - ja[nv + i]) + ax[2] * (jb[2 * nv + i] - ja[2 * nv + i]);
+          d->efc_J[r * nv + i] = jn + sgn * mu * jk;
+        }
+        d->efc_pos[r] = c->dist; d->efc_margin[r] = c->includemargin;
+        o_copy(d->efc_solref + 2 * r, c->solref, 2);
+        o_copy(d->efc_solimp + 5 * r, c->solimp, 5);
+        d->efc_diagApprox[r] = tran + mu * mu * (k < 3 ? tran : rot);
+      }
+      continue;
+    }
     for (int k = 0; k < dim; k++) {
       int r = add_row(om, d, dim == 1 ? O_CNSTR_CONTACT_FRICTIONLESS : O_CNSTR_CONTACT_ELLIPTIC, ci);
       if (r < 0) return;
@@ -434,8 +469,9 @@ static void make_impedance(const OModel *om, OData *d) {
   int nv = m->nv;
   for (int r = 0; r < d->nefc; r++) d->efc_vel[r] = o_dot(d->efc_J + r * nv, d->qvel, nv);
   for (int r = 0; r < d->nefc; r++) {
-    int dim = 1;
+    int dim = 1, pyramidal = d->efc_type[r] == O_CNSTR_CONTACT_PYRAMIDAL;
     if (d->efc_type[r] == O_CNSTR_CONTACT_ELLIPTIC) dim = d->contact[d->efc_id[r]].dim;
+    if (pyramidal) dim = 2 * (d->contact[d->efc_id[r]].dim - 1);
     const double *solref = d->efc_solref + 2 * r, *solimp = d->efc_solimp + 5 * r;
     double imp = impedance(solimp, d->efc_pos[r], d->efc_margin[r]);
     double dmax = o_clip(solimp[1], 0.0001, 0.9999);
@@ -451,13 +487,20 @@ static void make_impedance(const OModel *om, OData *d) {
     }
     for (int k = 0; k < dim; k++) {
       int q = r + k;
-      int friction_row = (d->efc_type[q] == O_CNSTR_FRICTION_DOF) || (k > 0);
+      int friction_row = (d->efc_type[q] == O_CNSTR_FRICTION_DOF) || (k > 0 && !pyramidal);
       double Kq = friction_row ? 0 : K;
       d->efc_KBIP[4 * q] = Kq; d->efc_KBIP[4 * q + 1] = B; d->efc_KBIP[4 * q + 2] = imp; d->efc_KBIP[4 * q + 3] = 0;
       d->efc_R[q] = fmax(O_MINVAL, (1 - imp) / imp * d->efc_diagApprox[q]);
       d->efc_aref[q] = -B * d->efc_vel[q] - Kq * imp * (d->efc_pos[q] - d->efc_margin[q]);
     }
-    if (dim > 1) {   /* elliptic cone: friction regularisation from impratio, regularised mu */
+    if (pyramidal) {   /* all pyramid edges share Rpy = 2 mu^2 R0, mu = friction of the regularised cone */
+      OContact *c = d->contact + d->efc_id[r];
+      double *R = d->efc_R + r;
+      double R1 = R[0] / fmax(O_MINVAL, m->impratio);
+      c->mu = c->friction[0] * sqrt(R1 / R[0]);
+      double Rpy = 2 * c->mu * c->mu * R[0];
+      for (int k = 0; k < dim; k++) R[k] = Rpy;
+    } else if (dim > 1) {   /* elliptic cone: friction regularisation from impratio, regularised mu */
       OContact *c = d->contact + d->efc_id[r];
       double *R = d->efc_R + r;
       R[1] = R[0] / fmax(O_MINVAL, m->impratio);

@@ -336,6 +336,52 @@ static void residual_quadruped(const OModel *om, OData *d, double *residual) {  
   counter += 3;
 }
 
+/* ---- humanoid tracking (mjpc/tasks/humanoid/tracking/tracking.cc:94-216) --------------------------------
+ * int_data: [0] motion id, [1] first key of the motion, [2] motion length, [3..18] tracking site ids,
+ *           [19..34] mocap ids, both in the order of tracking.cc:59-63 body_names; dbl_data: [0] reference_time */
+static void residual_humanoid_track(const OModel *om, OData *d, double *residual) {
+  const MjpcHipModel *m = &om->m;
+  const int *I = om->t.int_data;
+  const double kFps = 30.0;
+  int start = I[1], length = I[2];
+  double current_index = (d->time - om->t.dbl_data[0]) * kFps + start;
+  int last_key_index = start + length - 1;
+  double ci = current_index < 0 ? 0 : (current_index > last_key_index ? (double)last_key_index : current_index);
+  int k0 = (int)floor(ci), k1 = k0 + 1 < last_key_index ? k0 + 1 : last_key_index;
+  double w1 = ci - k0, w0 = 1.0 - w1;
+  int counter = 0;
+  o_copy(residual + counter, d->qvel + 6, m->nv - 6); counter += m->nv - 6;
+  o_copy(residual + counter, d->ctrl, m->nu); counter += m->nu;
+  double avg_m[3] = {0, 0, 0}, avg_s[3] = {0, 0, 0}, mp[16][3];
+  for (int b = 0; b < 16; b++) {
+    int mid = I[19 + b];
+    const double *p0 = m->key_mpos + m->nmocap * 3 * k0 + 3 * mid, *p1 = m->key_mpos + m->nmocap * 3 * k1 + 3 * mid;
+    o_scl3(mp[b], p0, w0);
+    o_addtoscl3(mp[b], p1, w1);
+    o_add3(avg_m, avg_m, mp[b]);
+    o_add3(avg_s, avg_s, d->site_xpos + 3 * I[3 + b]);
+  }
+  o_scl3(avg_m, avg_m, 1.0 / 16); o_scl3(avg_s, avg_s, 1.0 / 16);
+  o_sub3(residual + counter, avg_m, avg_s); counter += 3;
+  for (int b = 0; b < 16; b++) {
+    double bm[3], bs[3];
+    o_sub3(bm, mp[b], avg_m);
+    o_sub3(bs, d->site_xpos + 3 * I[3 + b], avg_s);
+    o_sub3(residual + counter, bm, bs); counter += 3;
+  }
+  for (int b = 0; b < 16; b++) {
+    int mid = I[19 + b], sid = I[3 + b], body = m->site_bodyid[sid];
+    const double *p0 = m->key_mpos + m->nmocap * 3 * k0 + 3 * mid, *p1 = m->key_mpos + m->nmocap * 3 * k1 + 3 * mid;
+    double v[3], off[3], lin[3];
+    o_sub3(v, p1, p0); o_scl3(v, v, kFps);
+    /* framelinvel: velocity of the site point in the world frame */
+    o_sub3(off, d->site_xpos + 3 * sid, d->subtree_com + 3 * m->body_rootid[body]);
+    o_cross(lin, d->cvel + 6 * body, off);
+    o_add3(lin, lin, d->cvel + 6 * body + 3);
+    o_sub3(residual + counter, v, lin); counter += 3;
+  }
+}
+
 void oracle_residual(const OModel *om, OData *d, double *residual) {
   const MjpcHipModel *m = &om->m;
   switch (om->t.task_id) {
@@ -357,6 +403,9 @@ void oracle_residual(const OModel *om, OData *d, double *residual) {
       break;
     case MJPC_TASK_QUADRUPED:
       residual_quadruped(om, d, residual);
+      break;
+    case MJPC_TASK_HUMANOID_TRACK:
+      residual_humanoid_track(om, d, residual);
       break;
     default: break;
   }

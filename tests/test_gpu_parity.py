@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as ol
-from mujoco_mpc_amd.modelgen import cartpole, particle, quadruped
+from mujoco_mpc_amd.modelgen import cartpole, humanoid_track, particle, quadruped
 from mujoco_mpc_amd.planner import HipBackend
 
 pytestmark = pytest.mark.gpu
@@ -84,6 +84,14 @@ def test_quadruped_small():
 def test_quadruped_second_sigma_and_time_offset():
     m, task, d = quadruped()
     _compare(m, task, d, 3, 20, 16, (0.04, 0.2), 2, 1e-5, seed=7, time0=1.23)
+
+
+def test_humanoid_tracking_small():
+    """BASELINE config C3's model/task at a size the oracle finishes in seconds: pyramidal cones, fixed-tendon
+    limits, 21 joint limits, capsule self-collisions, 141 residuals (Cosh / SmoothAbs2 norms)."""
+    m, task, d = humanoid_track()
+    out, ref, allc = _compare(m, task, d, 16, 40, 8, (0.15, 0.0), 2, 1e-5, nominal_scale=0.2)
+    assert allc["diag"][:, 1].max() >= 4
 
 
 def test_device_philox_matches_oracle_noise():

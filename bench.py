@@ -30,7 +30,7 @@ def measured_traffic(N, H):
     FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE); only valid for the workload it was measured on."""
     try:
         t = json.load(open(os.path.join(ROOT, "profiles", "r1", "b_traffic.json")))
-        if t.get("workload") == f"C2 quadruped {N}x{H}":
+        if t.get("workload") == f"C2 quadruped {N}x{H}" and N == 256:
             return t["traffic_bytes_per_launch"]
     except Exception:
         pass
@@ -43,7 +43,7 @@ def algorithmic_bytes_per_candidate_step(model, task):
     return 8 * (ds + model["nu"] + task["num_residual"] + 3 * task["num_trace"] + 2)
 
 
-def cpu_baseline(model, task, d, kt, kv, N, H, seconds_target=12.0):
+def cpu_baseline(model, task, d, kt, kv, N, H, sigma, seconds_target=12.0):
     """Reference-shaped CPU path (oracle = our restatement; the reference cannot be built here: MuJoCo absent)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import __graft_entry__ as g
@@ -55,14 +55,14 @@ def cpu_baseline(model, task, d, kt, kv, N, H, seconds_target=12.0):
     o = ol.Oracle(model, task)
     n = min(N, 4 * threads)
     t0 = time.perf_counter()
-    o.plan(d["state"], d["mocap"], 0.0, kt, kv, 2, n, H, sigma=(0.04, 0.0), seed=0x5EED, stream=0, nthreads=threads)
+    o.plan(d["state"], d["mocap"], 0.0, kt, kv, 2, n, H, sigma=(sigma, 0.0), seed=0x5EED, stream=0, nthreads=threads)
     probe = time.perf_counter() - t0
     per_rollout = probe / n                   # wall seconds per rollout at this thread count
     reps = max(1, int(seconds_target / max(per_rollout * N, 1e-9)))
     reps = min(reps, 20)
     t0 = time.perf_counter()
     for r in range(reps):
-        o.plan(d["state"], d["mocap"], 0.0, kt, kv, 2, N, H, sigma=(0.04, 0.0), seed=0x5EED, stream=r, nthreads=threads)
+        o.plan(d["state"], d["mocap"], 0.0, kt, kv, 2, N, H, sigma=(sigma, 0.0), seed=0x5EED, stream=r, nthreads=threads)
     dt = time.perf_counter() - t0
     return dict(value=N * reps / dt, unit="rollouts/s", cores=threads, kind="port",
                 sample=f"{reps} plan step(s) of the same workload (N={N}, H={H}) on the CPU oracle's FIFO pool (gcc -O3 -march=native), "
@@ -74,8 +74,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--samples", type=int, default=256, help="candidates per GPU")
-    ap.add_argument("--horizon", type=int, default=100)
+    ap.add_argument("--workload", default="quadruped", choices=["quadruped", "humanoid"],
+                    help="quadruped = BASELINE configs[1] (the metric's config, default); humanoid = configs[2]")
+    ap.add_argument("--samples", type=int, default=None, help="candidates per GPU (default 256 / 1024)")
+    ap.add_argument("--horizon", type=int, default=None, help="default 100 / 128")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -89,12 +91,16 @@ def main():
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
-    from mujoco_mpc_amd.modelgen import quadruped
+    from mujoco_mpc_amd.modelgen import humanoid_track, quadruped
     from mujoco_mpc_amd.planner import HipBackend
     from mujoco_mpc_amd.sharded import ShardedSampler
 
-    model, task, d = quadruped()
-    N, H, P = args.samples, args.horizon, 3
+    if args.workload == "quadruped":
+        model, task, d = quadruped()
+        N, H, P, sigma, wname = args.samples or 256, args.horizon or 100, 3, 0.04, "Quadruped flat (A1)"
+    else:
+        model, task, d = humanoid_track()
+        N, H, P, sigma, wname = args.samples or 1024, args.horizon or 128, 16, 0.15, "Humanoid tracking (Jump)"
     dt_model = model["timestep"]
     kt = np.linspace(0.0, (H - 1) * dt_model, P)
     kv = np.zeros((P, model["nu"]))
@@ -103,7 +109,7 @@ def main():
 
     def step(i, knots):
         return sampler.plan(state=d["state"], mocap=d["mocap"], time=0.0, knot_times=kt, knot_values=knots,
-                            interpolation=2, horizon=H, sigma=(0.04, 0.0), seed=0x5EED, stream=i)
+                            interpolation=2, horizon=H, sigma=(sigma, 0.0), seed=0x5EED, stream=i)
 
     def sync():
         if world > 1:
@@ -145,8 +151,9 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"Quadruped flat (A1), SamplingPlanner rollouts, {N} samples/GPU x horizon {H}, "
-                                   f"{P} cubic knots, dt {dt_model}, sigma 0.04, Philox(0x5EED) noise (BASELINE configs[1])",
+            "config": {"workload": f"{wname}, SamplingPlanner rollouts, {N} samples/GPU x horizon {H}, "
+                                   f"{P} cubic knots, dt {dt_model}, sigma {sigma}, Philox(0x5EED) noise "
+                                   f"(BASELINE configs[{1 if args.workload == 'quadruped' else 2}])",
                        "samples_per_gpu": N, "global_samples": N * world, "horizon": H,
                        "candidate_steps_per_s": total_rollouts * H / elapsed,
                        "lds_bytes_per_candidate": be.lds_bytes(),
@@ -158,7 +165,7 @@ def main():
                          "plan_device_us": total_us},
         }
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(model, task, d, kt, kv, N, H)
+            out["cpu_baseline"] = cpu_baseline(model, task, d, kt, kv, N, H, sigma)
         print(json.dumps(out))
     be.close()
     if world > 1:

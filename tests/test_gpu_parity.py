@@ -148,3 +148,38 @@ def test_api_errors():
         be.plan(state=d["state"], mocap=None, time=0.0, knot_times=np.array([0.0]), knot_values=np.zeros((1, 1)),
                 interpolation=0, num_trajectory=4, horizon=11, sigma=(0.1, 0.0))     # beyond max_horizon
     be.close()
+
+
+def test_sampling_planner_on_gpu_reaches_goal_and_matches_oracle_planner():
+    """mjpc/test/sampling_planner/sampling_planner_test.cc:40-108 with the rollouts on the GPU: the host mirror of
+    SamplingPlanner drives the HIP engine (device Philox noise) for 300 plan iterations on the particle task; the
+    same planner on the oracle backend, fed the same Philox stream, must adopt the same winners."""
+    from oracle_backend import OracleBackend
+    from mujoco_mpc_amd.planner import SamplingPlanner
+    m, task, d = particle(timestep=0.1)
+    H = 26
+
+    def make(backend):
+        p = SamplingPlanner(backend)
+        p.Initialize(m, task, dict(sampling_spline_points=11, sampling_exploration=0.01))
+        p.Allocate(); p.Reset(11)
+        p.SetState(np.zeros(4), d["mocap"], None, 0.0)
+        return p
+    gpu = make(HipBackend(m, task, max_samples=16, max_horizon=H))
+    cpu = make(OracleBackend(m, task))
+    same_winner = 0
+    for it in range(300):
+        gpu.OptimizePolicy(H)
+        if it < 40:                      # lock-step comparison while both nominal policies are bit-identical
+            cpu.policy.CopyFrom(gpu.previous_policy); cpu.winner_policy.CopyFrom(gpu.previous_policy); cpu.plan_iter = gpu.plan_iter - 1
+            cpu.OptimizePolicy(H)
+            same_winner += int(cpu.winner == gpu.winner)
+            assert abs(cpu.returns[cpu.winner] - gpu.returns[gpu.winner]) <= 1e-9 * abs(cpu.returns[cpu.winner]) + 1e-12
+    assert same_winner == 40
+    best = gpu.BestTrajectory()
+    final = best.states[H - 1]
+    assert np.abs(final[:2] - d["mocap"][:2]).sum() < 0.1 and np.abs(final[2:]).sum() < 0.1
+    assert np.all(best.actions >= -1.0) and np.all(best.actions <= 1.0)
+    a = gpu.ActionFromPolicy(0.05); b = gpu.ActionFromPolicy(0.05, use_previous=True)
+    assert a.shape == (2,) and b.shape == (2,)
+    gpu.backend.close()

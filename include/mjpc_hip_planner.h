@@ -1,0 +1,150 @@
+// mjpc_hip_planner.h — C++ host side above the C ABI: the reference's SamplingPlanner surface, with the
+// rollouts forwarded to the HIP engine (include/mjpc_hip.h).
+//
+// Mirrors (names, argument meaning, error behaviour):
+//   mjpc/spline/spline.h:41-276              TimeSpline
+//   mjpc/planners/sampling/policy.h,.cc      SamplingPolicy
+//   mjpc/trajectory.h:74-86                  Trajectory (public arrays)
+//   mjpc/planners/sampling/planner.h:51-162  SamplingPlanner (+ RankedPlanner virtuals, planners/planner.h:84-101)
+// Differences forced by the boundary: `mjModel*` / `const Task&` become the ABI's MjpcHipModel / MjpcHipTask views
+// plus the planner's <custom><numeric> settings (Numerics); `ThreadPool&` arguments are gone (the GPU is the pool);
+// `State` is passed as its raw arrays (State::CopyTo, mjpc/states/state.cc:128-135).
+#ifndef MJPC_HIP_PLANNER_H_
+#define MJPC_HIP_PLANNER_H_
+
+#include <array>
+#include <deque>
+#include <shared_mutex>
+#include <vector>
+
+#include "mjpc_hip.h"
+
+namespace mjpc_hip {
+
+inline constexpr int kMaxTrajectoryHorizon = 512;   // mjpc/trajectory.h:27
+inline constexpr int MinSamplingSplinePoints = 1;    // mjpc/planners/sampling/planner.h:35-36
+inline constexpr int MaxSamplingSplinePoints = 36;
+
+enum SplineInterpolation : int { kZeroSpline = 0, kLinearSpline = 1, kCubicSpline = 2 };
+
+// time-indexed spline of `dim`-vectors: zero / linear / cubic-Hermite sampling (spline.cc:103-156,240-277)
+class TimeSpline {
+ public:
+  explicit TimeSpline(int dim = 0, SplineInterpolation interpolation = kZeroSpline, int initial_capacity = 1);
+  std::size_t Size() const { return times_.size(); }
+  int Dim() const { return dim_; }
+  SplineInterpolation Interpolation() const { return interpolation_; }
+  void SetInterpolation(SplineInterpolation interpolation) { interpolation_ = interpolation; }
+  void Reserve(int num_nodes);
+  void Sample(double time, double* values) const;             // values[dim]
+  std::vector<double> Sample(double time) const;
+  int DiscardBefore(double time);
+  void Clear();
+  double* AddNode(double time, const double* values = nullptr);   // returns the node's values; zeros when values == nullptr
+  double NodeTime(int index) const { return times_[index]; }
+  const double* NodeValues(int index) const { return values_[index].data(); }
+  double* NodeValues(int index) { return values_[index].data(); }
+
+ private:
+  double Slope(int node_index, int value_index) const;
+  SplineInterpolation interpolation_;
+  int dim_;
+  std::deque<double> times_;
+  std::deque<std::vector<double>> values_;
+};
+
+// mjpc/planners/sampling/policy.cc:30-78
+class SamplingPolicy {
+ public:
+  void Allocate(const MjpcHipModel* model, int num_spline_points);
+  void Reset(int horizon, const double* initial_repeated_action = nullptr);
+  void Action(double* action, const double* state, double time) const;     // spline sample, clamped to ctrlrange
+  void CopyFrom(const SamplingPolicy& policy, int horizon);
+  TimeSpline plan;
+  int num_spline_points = 0;
+  int nu = 0;
+  std::vector<double> ctrlrange;
+};
+
+// mjpc/trajectory.h:74-86
+struct Trajectory {
+  int horizon = 0, dim_state = 0, dim_action = 0, dim_residual = 0, dim_trace = 0;
+  std::vector<double> states, actions, times, residual, costs, trace;
+  double total_return = 0;
+  bool failure = false;
+};
+
+struct Numerics {                       // the planner's <custom><numeric> entries (planner.cc:53-67, policy.cc:36-37)
+  double sampling_exploration[2] = {0.1, 0.0};
+  int sampling_trajectories = 10;
+  int sampling_representation = kCubicSpline;
+  int sampling_sliding_plan = 0;
+  int sampling_spline_points = kMaxTrajectoryHorizon;
+  int max_samples = 4096;              // kMaxTrajectory is 128 in the reference (planners/planner.h:28); lifted here
+  int max_horizon = kMaxTrajectoryHorizon;   // device trajectory buffers are sized max_samples x max_horizon
+  int device = 0;
+};
+
+class SamplingPlanner {
+ public:
+  SamplingPlanner() = default;
+  ~SamplingPlanner();
+  SamplingPlanner(const SamplingPlanner&) = delete;
+  SamplingPlanner& operator=(const SamplingPlanner&) = delete;
+
+  // ---- Planner virtuals (planners/planner.h:38-80); errors abort like mju_error unless a handler is installed
+  void Initialize(const MjpcHipModel* model, const MjpcHipTask* task, const Numerics& numerics);
+  void Allocate();
+  void Reset(int horizon, const double* initial_repeated_action = nullptr);
+  void SetState(const double* state, const double* mocap, const double* userdata, double time);
+  void OptimizePolicy(int horizon);
+  void NominalTrajectory(int horizon);
+  void ActionFromPolicy(double* action, const double* state, double time, bool use_previous = false);
+  const Trajectory* BestTrajectory();
+  int NumParameters() { return policy.num_spline_points * nu_; }
+  // ---- RankedPlanner virtuals (planners/planner.h:84-101)
+  int OptimizePolicyCandidates(int ncandidates, int horizon);
+  double CandidateScore(int candidate) const;
+  void ActionFromCandidatePolicy(double* action, int candidate, const double* state, double time);
+  void CopyCandidateToPolicy(int candidate);
+  // ---- sampling-specific (planner.h:95-112)
+  void UpdateNominalPolicy(int horizon);
+  void SetTask(const MjpcHipTask* task);               // fresh ResidualFn copy per plan step (agent.cc:290)
+
+  // ---- public members other code reads/writes in the reference (planner.h:115-162)
+  SamplingPolicy policy, previous_policy;
+  std::vector<double> state, mocap, userdata;
+  double time = 0;
+  Trajectory trajectory_winner;                        // trajectory[winner]; other candidates stay on the device
+  std::vector<double> returns;                         // trajectory[i].total_return
+  std::vector<int> failures;
+  std::vector<int> trajectory_order;
+  int winner = 0;
+  double noise_exploration[2] = {0.1, 0.0};
+  int num_trajectory_ = 10;
+  int interpolation_ = kCubicSpline;
+  int sliding_plan_ = 0;
+  double improvement = 0;
+  double noise_compute_time = 0, rollouts_compute_time = 0, policy_update_compute_time = 0;   // microseconds
+  unsigned long long seed = 0x5EED;
+  unsigned long long plan_iter = 0;
+  // reproducible-noise hook (the reference's absl::BitGen is unseedable): optional injected tensors
+  const double* injected_noise_eps = nullptr;   // [num_trajectory * P * nu]
+  const int* injected_noise_sel = nullptr;      // [num_trajectory]
+
+ private:
+  void FetchCandidate(int global_index);
+  MjpcHipEngine* engine_ = nullptr;
+  Numerics numerics_;
+  int nq_ = 0, nv_ = 0, na_ = 0, ns_ = 0, nu_ = 0, nmocap_ = 0, nuserdata_ = 0, nr_ = 0, ntrace_ = 0;
+  double timestep_ = 0;
+  std::vector<double> ctrlrange_;
+  SamplingPolicy winner_policy_;               // candidate_policy[winner]
+  TimeSpline plan_scratch_;
+  std::vector<double> knot_times_, knot_values_, winner_knots_;
+  int last_horizon_ = 0, fetched_ = -1;
+  mutable std::shared_mutex mtx_;
+};
+
+}  // namespace mjpc_hip
+#endif  // MJPC_HIP_PLANNER_H_

@@ -1,0 +1,58 @@
+/* mjpc_hip_planner_c.h — flat C view of the C++ host planner (include/mjpc_hip_planner.h), exported by
+ * libmjpc_hip.so for bindings that cannot take C++ classes (ctypes tests, the Python front end).
+ * Each function forwards to the method of the same name; the reference interface each one stands for:
+ *   mjpc_spline_*   -> mjpc::spline::TimeSpline              (mjpc/spline/spline.h:41-276)
+ *   mjpc_planner_*  -> mjpc::SamplingPlanner / RankedPlanner (mjpc/planners/sampling/planner.h:51-162,
+ *                                                             mjpc/planners/planner.h:38-101)
+ * Handles are opaque; errors go through the installed handler (default: print + abort, like mju_error).
+ */
+#ifndef MJPC_HIP_PLANNER_C_H_
+#define MJPC_HIP_PLANNER_C_H_
+#include "mjpc_hip.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+void mjpc_planner_set_error_handler(void (*handler)(const char *message));
+
+/* TimeSpline */
+void *mjpc_spline_create(int dim, int interpolation);
+void mjpc_spline_destroy(void *spline);
+int mjpc_spline_size(void *spline);
+void mjpc_spline_add_node(void *spline, double time, const double *values /* NULL = zeros */);
+void mjpc_spline_sample(void *spline, double time, double *out /* [dim] */);
+int mjpc_spline_discard_before(void *spline, double time);
+void mjpc_spline_clear(void *spline);
+void mjpc_spline_set_interpolation(void *spline, int interpolation);
+
+/* SamplingPlanner: create = Initialize + Allocate (planner.cc:40-133) */
+void *mjpc_planner_create(const MjpcHipModel *model, const MjpcHipTask *task, const double *exploration /* [2] */,
+                          int trajectories, int representation, int sliding_plan, int spline_points,
+                          int max_samples, int max_horizon, int device);
+void mjpc_planner_destroy(void *planner);
+void mjpc_planner_reset(void *planner, int horizon, const double *initial_repeated_action);
+void mjpc_planner_set_state(void *planner, const double *state, const double *mocap, const double *userdata, double time);
+void mjpc_planner_set_task(void *planner, const MjpcHipTask *task);
+void mjpc_planner_optimize_policy(void *planner, int horizon);
+void mjpc_planner_nominal_trajectory(void *planner, int horizon);
+void mjpc_planner_action_from_policy(void *planner, double *action, double time, int use_previous);
+int mjpc_planner_optimize_policy_candidates(void *planner, int ncandidates, int horizon);
+double mjpc_planner_candidate_score(void *planner, int candidate);
+void mjpc_planner_action_from_candidate_policy(void *planner, double *action, int candidate, double time);
+void mjpc_planner_copy_candidate_to_policy(void *planner, int candidate);
+int mjpc_planner_winner(void *planner);
+double mjpc_planner_improvement(void *planner);
+int mjpc_planner_num_parameters(void *planner);
+void mjpc_planner_set_seed(void *planner, unsigned long long seed, unsigned long long plan_iter);
+void mjpc_planner_set_num_trajectory(void *planner, int num_trajectory);
+void mjpc_planner_set_noise(void *planner, const double *eps, const int *sel);   /* borrowed until the next call */
+void mjpc_planner_returns(void *planner, double *out, int n);
+int mjpc_planner_policy(void *planner, int previous, double *times, double *values);          /* returns P */
+int mjpc_planner_best_trajectory(void *planner, double *states, double *actions, double *times, double *residual,
+                                 double *costs, double *trace, double *total_return, int *failure); /* returns H */
+void mjpc_planner_timings(void *planner, double *noise_us, double *rollouts_us, double *policy_update_us);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MJPC_HIP_PLANNER_C_H_ */

@@ -1,0 +1,243 @@
+"""ctypes view of the C++ host planner (include/mjpc_hip_planner.h via include/mjpc_hip_planner_c.h).
+
+The C++ classes `mjpc_hip::TimeSpline` / `mjpc_hip::SamplingPlanner` in libmjpc_hip.so are the product's host side
+(the reference's planner is compiled C++: mjpc/planners/sampling/planner.cc); this module only lets Python drive
+them.  It never falls back to the Python mirror in planner.py: a missing library raises in capi.load_engine().
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+c_double_p = C.POINTER(C.c_double)
+c_int_p = C.POINTER(C.c_int)
+_ERR_CB = C.CFUNCTYPE(None, C.c_char_p)
+
+PLANNER_C_SYMBOLS = [
+    "mjpc_planner_set_error_handler",
+    "mjpc_spline_create", "mjpc_spline_destroy", "mjpc_spline_size", "mjpc_spline_add_node", "mjpc_spline_sample",
+    "mjpc_spline_discard_before", "mjpc_spline_clear", "mjpc_spline_set_interpolation",
+    "mjpc_planner_create", "mjpc_planner_destroy", "mjpc_planner_reset", "mjpc_planner_set_state", "mjpc_planner_set_task",
+    "mjpc_planner_optimize_policy", "mjpc_planner_nominal_trajectory", "mjpc_planner_action_from_policy",
+    "mjpc_planner_optimize_policy_candidates", "mjpc_planner_candidate_score", "mjpc_planner_action_from_candidate_policy",
+    "mjpc_planner_copy_candidate_to_policy", "mjpc_planner_winner", "mjpc_planner_improvement", "mjpc_planner_num_parameters",
+    "mjpc_planner_set_seed", "mjpc_planner_set_num_trajectory", "mjpc_planner_set_noise", "mjpc_planner_returns",
+    "mjpc_planner_policy", "mjpc_planner_best_trajectory", "mjpc_planner_timings",
+]
+
+
+class PlannerError(RuntimeError):
+    """Raised where the reference would abort through mju_error (planner.cc:69-72, spline.cc:205-208)."""
+
+
+_lib = None
+_pending: list[str] = []
+
+
+@_ERR_CB
+def _on_error(msg):
+    _pending.append(msg.decode() if msg else "unknown")
+
+
+def _check():
+    if _pending:
+        msg = _pending[0]
+        _pending.clear()
+        raise PlannerError(msg)
+
+
+def _dp(a):
+    return None if a is None else a.ctypes.data_as(c_double_p)
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    L = capi.load_engine()
+    vp, d, i = C.c_void_p, C.c_double, C.c_int
+    sig = {
+        "mjpc_planner_set_error_handler": (None, [_ERR_CB]),
+        "mjpc_spline_create": (vp, [i, i]), "mjpc_spline_destroy": (None, [vp]), "mjpc_spline_size": (i, [vp]),
+        "mjpc_spline_add_node": (None, [vp, d, c_double_p]), "mjpc_spline_sample": (None, [vp, d, c_double_p]),
+        "mjpc_spline_discard_before": (i, [vp, d]), "mjpc_spline_clear": (None, [vp]),
+        "mjpc_spline_set_interpolation": (None, [vp, i]),
+        "mjpc_planner_create": (vp, [C.POINTER(capi.MjpcHipModel), C.POINTER(capi.MjpcHipTask), c_double_p, i, i, i, i, i, i, i]),
+        "mjpc_planner_destroy": (None, [vp]), "mjpc_planner_reset": (None, [vp, i, c_double_p]),
+        "mjpc_planner_set_state": (None, [vp, c_double_p, c_double_p, c_double_p, d]),
+        "mjpc_planner_set_task": (None, [vp, C.POINTER(capi.MjpcHipTask)]),
+        "mjpc_planner_optimize_policy": (None, [vp, i]), "mjpc_planner_nominal_trajectory": (None, [vp, i]),
+        "mjpc_planner_action_from_policy": (None, [vp, c_double_p, d, i]),
+        "mjpc_planner_optimize_policy_candidates": (i, [vp, i, i]), "mjpc_planner_candidate_score": (d, [vp, i]),
+        "mjpc_planner_action_from_candidate_policy": (None, [vp, c_double_p, i, d]),
+        "mjpc_planner_copy_candidate_to_policy": (None, [vp, i]), "mjpc_planner_winner": (i, [vp]),
+        "mjpc_planner_improvement": (d, [vp]), "mjpc_planner_num_parameters": (i, [vp]),
+        "mjpc_planner_set_seed": (None, [vp, C.c_ulonglong, C.c_ulonglong]), "mjpc_planner_set_num_trajectory": (None, [vp, i]),
+        "mjpc_planner_set_noise": (None, [vp, c_double_p, c_int_p]), "mjpc_planner_returns": (None, [vp, c_double_p, i]),
+        "mjpc_planner_policy": (i, [vp, i, c_double_p, c_double_p]),
+        "mjpc_planner_best_trajectory": (i, [vp] + [c_double_p] * 7 + [c_int_p]),
+        "mjpc_planner_timings": (None, [vp, c_double_p, c_double_p, c_double_p]),
+    }
+    for name, (res, args) in sig.items():
+        f = getattr(L, name)
+        f.restype = res; f.argtypes = args
+    L.mjpc_planner_set_error_handler(_on_error)
+    _lib = L
+    return L
+
+
+class TimeSpline:
+    """mjpc_hip::TimeSpline (C++) — same surface as mjpc::spline::TimeSpline (spline.h:41-276)."""
+
+    def __init__(self, dim=0, interpolation=0):
+        self._L = lib()
+        self.dim_ = int(dim)
+        self._h = C.c_void_p(self._L.mjpc_spline_create(self.dim_, int(interpolation)))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.mjpc_spline_destroy(self._h); self._h = None
+
+    def Size(self): return self._L.mjpc_spline_size(self._h)
+    def Dim(self): return self.dim_
+    def SetInterpolation(self, interpolation): self._L.mjpc_spline_set_interpolation(self._h, int(interpolation))
+    def Clear(self): self._L.mjpc_spline_clear(self._h)
+
+    def AddNode(self, time, values=None):
+        v = None if values is None else np.ascontiguousarray(values, dtype=np.float64)
+        self._L.mjpc_spline_add_node(self._h, float(time), _dp(v))
+        _check()
+
+    def DiscardBefore(self, time): return self._L.mjpc_spline_discard_before(self._h, float(time))
+
+    def Sample(self, time):
+        out = np.zeros(self.dim_)
+        self._L.mjpc_spline_sample(self._h, float(time), _dp(out))
+        _check()
+        return out
+
+
+class Trajectory:
+    pass
+
+
+class SamplingPlanner:
+    """mjpc_hip::SamplingPlanner (C++) driven from Python; method names follow planners/sampling/planner.h:51-112."""
+
+    def __init__(self):
+        self._L = lib()
+        self._h = None
+        self._noise = None
+
+    def Initialize(self, model: dict, task: dict, numerics: dict | None = None, max_samples=128, max_horizon=512, device=0):
+        numerics = numerics or {}
+        self.cm = capi.CModel(model, task)
+        se = numerics.get("sampling_exploration", 0.1)
+        se = list(se) if isinstance(se, (list, tuple)) else [se]
+        self._expl = np.array([float(se[0]), float(se[1]) if len(se) > 1 else 0.0])
+        self.nu = int(model["nu"]); self.ns = int(model["nq"] + model["nv"] + model["na"])
+        self.nr = int(task["num_residual"]); self.ntrace = int(task["num_trace"])
+        self.max_samples, self.max_horizon = int(max_samples), int(max_horizon)
+        self.close()
+        h = self._L.mjpc_planner_create(C.byref(self.cm.c_model), C.byref(self.cm.c_task), _dp(self._expl),
+                                        int(numerics.get("sampling_trajectories", 10)), int(numerics.get("sampling_representation", 2)),
+                                        int(numerics.get("sampling_sliding_plan", 0)), int(numerics.get("sampling_spline_points", 512)),
+                                        self.max_samples, self.max_horizon, int(device))
+        self._h = C.c_void_p(h)
+        _check()
+
+    def Allocate(self):        # done inside mjpc_planner_create (Initialize + Allocate)
+        pass
+
+    def close(self):
+        if self._h:
+            self._L.mjpc_planner_destroy(self._h); self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def Reset(self, horizon=0, initial_repeated_action=None):
+        a = None if initial_repeated_action is None else np.ascontiguousarray(initial_repeated_action, dtype=np.float64)
+        self._L.mjpc_planner_reset(self._h, int(horizon or 0), _dp(a))
+
+    def SetState(self, state, mocap=None, userdata=None, time=0.0):
+        s = np.ascontiguousarray(state, dtype=np.float64)
+        m = None if mocap is None else np.ascontiguousarray(mocap, dtype=np.float64)
+        u = None if userdata is None else np.ascontiguousarray(userdata, dtype=np.float64)
+        self._L.mjpc_planner_set_state(self._h, _dp(s), _dp(m), _dp(u), float(time))
+
+    def SetTask(self, task: dict):
+        t = self.cm.make_task(task)
+        self._L.mjpc_planner_set_task(self._h, C.byref(t)); _check()
+
+    def set_seed(self, seed, plan_iter=0): self._L.mjpc_planner_set_seed(self._h, int(seed), int(plan_iter))
+    def set_num_trajectory(self, n): self._L.mjpc_planner_set_num_trajectory(self._h, int(n))
+
+    def set_noise(self, eps, sel):
+        if eps is None:
+            self._noise = None
+            self._L.mjpc_planner_set_noise(self._h, None, None)
+            return
+        e = np.ascontiguousarray(eps, dtype=np.float64); s = np.ascontiguousarray(sel, dtype=np.int32)
+        self._noise = (e, s)
+        self._L.mjpc_planner_set_noise(self._h, _dp(e), s.ctypes.data_as(c_int_p))
+
+    def OptimizePolicy(self, horizon): self._L.mjpc_planner_optimize_policy(self._h, int(horizon)); _check()
+    def NominalTrajectory(self, horizon): self._L.mjpc_planner_nominal_trajectory(self._h, int(horizon)); _check()
+
+    def OptimizePolicyCandidates(self, ncandidates, horizon):
+        n = self._L.mjpc_planner_optimize_policy_candidates(self._h, int(ncandidates), int(horizon)); _check()
+        return n
+
+    def CandidateScore(self, candidate): return self._L.mjpc_planner_candidate_score(self._h, int(candidate))
+    def CopyCandidateToPolicy(self, candidate): self._L.mjpc_planner_copy_candidate_to_policy(self._h, int(candidate)); _check()
+
+    def ActionFromCandidatePolicy(self, candidate, time):
+        a = np.zeros(self.nu)
+        self._L.mjpc_planner_action_from_candidate_policy(self._h, _dp(a), int(candidate), float(time)); _check()
+        return a
+
+    def ActionFromPolicy(self, time, use_previous=False):
+        a = np.zeros(self.nu)
+        self._L.mjpc_planner_action_from_policy(self._h, _dp(a), float(time), int(bool(use_previous))); _check()
+        return a
+
+    @property
+    def winner(self): return self._L.mjpc_planner_winner(self._h)
+    @property
+    def improvement(self): return self._L.mjpc_planner_improvement(self._h)
+    def NumParameters(self): return self._L.mjpc_planner_num_parameters(self._h)
+
+    def returns(self, n):
+        out = np.zeros(int(n)); self._L.mjpc_planner_returns(self._h, _dp(out), int(n)); return out
+
+    def policy_knots(self, previous=False):
+        P = self._L.mjpc_planner_policy(self._h, int(previous), None, None)
+        t = np.zeros(max(P, 1)); v = np.zeros((max(P, 1), self.nu))
+        self._L.mjpc_planner_policy(self._h, int(previous), _dp(t), _dp(v))
+        return t[:P], v[:P]
+
+    def timings(self):
+        a, b, c = C.c_double(), C.c_double(), C.c_double()
+        self._L.mjpc_planner_timings(self._h, C.byref(a), C.byref(b), C.byref(c))
+        return dict(noise_us=a.value, rollouts_us=b.value, policy_update_us=c.value)
+
+    def BestTrajectory(self):
+        Hm = self.max_horizon
+        st = np.zeros((Hm, self.ns)); ac = np.zeros((Hm, self.nu)); ti = np.zeros(Hm); re = np.zeros((Hm, max(self.nr, 1)))
+        co = np.zeros(Hm); tr = np.zeros((Hm, 3 * max(self.ntrace, 1))); tot = C.c_double(); fail = C.c_int()
+        H = self._L.mjpc_planner_best_trajectory(self._h, _dp(st), _dp(ac), _dp(ti), _dp(re), _dp(co), _dp(tr), C.byref(tot), C.byref(fail))
+        if H == 0:
+            return None
+        t = Trajectory()
+        t.horizon = H; t.states = st.ravel()[:H * self.ns].reshape(H, self.ns); t.actions = ac.ravel()[:H * self.nu].reshape(H, self.nu)
+        t.times = ti[:H]; t.residual = re.ravel()[:H * self.nr].reshape(H, self.nr); t.costs = co[:H]
+        t.trace = tr.ravel()[:H * 3 * self.ntrace].reshape(H, 3 * self.ntrace)
+        t.total_return = tot.value; t.failure = bool(fail.value)
+        return t

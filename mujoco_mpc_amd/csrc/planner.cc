@@ -1,0 +1,414 @@
+// planner.cc — C++ host side above the C ABI (include/mjpc_hip_planner.h) + a flat C wrapper for the tests.
+// Restates, with the rollouts forwarded to the HIP engine:
+//   mjpc/spline/spline.cc:103-277            TimeSpline::Sample / DiscardBefore / AddNode / Slope
+//   mjpc/planners/sampling/policy.cc:30-78   SamplingPolicy
+//   mjpc/planners/sampling/planner.cc:40-310,525-534   SamplingPlanner host logic
+#include "../../include/mjpc_hip_planner.h"
+#include "../../include/mjpc_hip_planner_c.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <numeric>
+
+namespace mjpc_hip {
+
+// ------------------------------------------------------------------ error convention
+// The reference aborts through mju_error* on configuration errors (planner.cc:69-72); same here, unless a handler
+// is installed (the Python tests install one that records the message instead of killing the interpreter).
+static void (*g_error_handler)(const char*) = nullptr;
+static void Fatal(const char* msg) {
+  if (g_error_handler) { g_error_handler(msg); return; }
+  std::fprintf(stderr, "mjpc_hip planner error: %s\n", msg);
+  std::abort();
+}
+
+// ------------------------------------------------------------------ TimeSpline
+TimeSpline::TimeSpline(int dim, SplineInterpolation interpolation, int) : interpolation_(interpolation), dim_(dim) {}
+void TimeSpline::Reserve(int) {}
+void TimeSpline::Clear() { times_.clear(); values_.clear(); }
+
+double* TimeSpline::AddNode(double time, const double* new_values) {
+  // spline.cc:203-238: only before the first or after the last node
+  if (!(times_.empty() || time > times_.back() || time < times_.front())) {
+    Fatal("Adding nodes to the middle of the spline isn't supported.");
+    return nullptr;
+  }
+  std::vector<double> v(dim_, 0.0);
+  if (new_values) std::copy(new_values, new_values + dim_, v.begin());
+  if (times_.empty() || time > times_.back()) {
+    times_.push_back(time); values_.push_back(std::move(v));
+    return values_.back().data();
+  }
+  times_.push_front(time); values_.push_front(std::move(v));
+  return values_.front().data();
+}
+
+int TimeSpline::DiscardBefore(double time) {   // spline.cc:164-188
+  auto last_node = std::upper_bound(times_.begin(), times_.end(), time);
+  if (last_node == times_.begin()) return 0;
+  int keep_nodes = interpolation_ == kCubicSpline ? 1 : 0;
+  last_node--;
+  while (last_node != times_.begin() && keep_nodes) { last_node--; keep_nodes--; }
+  int nodes_to_remove = (int)(last_node - times_.begin());
+  times_.erase(times_.begin(), last_node);
+  values_.erase(values_.begin(), values_.begin() + nodes_to_remove);
+  return nodes_to_remove;
+}
+
+double TimeSpline::Slope(int node_index, int value_index) const {   // spline.cc:259-277
+  if (node_index == 0)
+    return (values_[1][value_index] - values_[0][value_index]) / (times_[1] - times_[0]);
+  if (node_index == (int)times_.size() - 1)
+    return (values_[node_index][value_index] - values_[node_index - 1][value_index]) / (times_[node_index] - times_[node_index - 1]);
+  return 0.5 * (values_[node_index + 1][value_index] - values_[node_index][value_index]) / (times_[node_index + 1] - times_[node_index]) +
+         0.5 * (values_[node_index][value_index] - values_[node_index - 1][value_index]) / (times_[node_index] - times_[node_index - 1]);
+}
+
+void TimeSpline::Sample(double time, double* values) const {   // spline.cc:103-156
+  if (times_.empty()) { std::fill(values, values + dim_, 0.0); return; }
+  auto upper = std::upper_bound(times_.begin(), times_.end(), time);
+  if (upper == times_.end()) { const auto& n = values_[times_.size() - 1]; std::copy(n.begin(), n.end(), values); return; }
+  if (upper == times_.begin()) { const auto& n = values_[0]; std::copy(n.begin(), n.end(), values); return; }
+  int iu = (int)(upper - times_.begin()), il = iu - 1;
+  double lo = times_[il], up = times_[iu];
+  double t = (time - lo) / (up - lo);
+  const auto& lower_node = values_[il];
+  const auto& upper_node = values_[iu];
+  switch (interpolation_) {
+    case kZeroSpline:
+      std::copy(lower_node.begin(), lower_node.end(), values);
+      return;
+    case kLinearSpline:
+      for (int i = 0; i < dim_; i++) values[i] = lower_node[i] * (1 - t) + upper_node[i] * t;
+      return;
+    case kCubicSpline: {
+      double c0 = 2.0 * t*t*t - 3.0 * t*t + 1.0;
+      double c1 = (t*t*t - 2.0 * t*t + t) * (up - lo);
+      double c2 = -2.0 * t*t*t + 3 * t*t;
+      double c3 = (t*t*t - t*t) * (up - lo);
+      for (int i = 0; i < dim_; i++) {
+        double p0 = lower_node[i], m0 = Slope(il, i), m1 = Slope(iu, i), p1 = upper_node[i];
+        values[i] = c0 * p0 + c1 * m0 + c2 * p1 + c3 * m1;
+      }
+      return;
+    }
+    default:
+      Fatal("Unknown interpolation");
+  }
+}
+std::vector<double> TimeSpline::Sample(double time) const {
+  std::vector<double> v(dim_);
+  Sample(time, v.data());
+  return v;
+}
+
+// ------------------------------------------------------------------ SamplingPolicy
+void SamplingPolicy::Allocate(const MjpcHipModel* model, int nsp) {
+  nu = model->nu;
+  ctrlrange.assign(model->actuator_ctrlrange, model->actuator_ctrlrange + 2 * nu);
+  num_spline_points = nsp;
+  plan = TimeSpline(nu);
+}
+void SamplingPolicy::Reset(int, const double* initial_repeated_action) {
+  plan.Clear();
+  if (initial_repeated_action != nullptr) plan.AddNode(0, initial_repeated_action);
+}
+void SamplingPolicy::Action(double* action, const double*, double time) const {
+  if (action == nullptr) { Fatal("SamplingPolicy::Action: action == nullptr"); return; }
+  plan.Sample(time, action);
+  for (int i = 0; i < nu; i++) action[i] = std::max(ctrlrange[2 * i], std::min(ctrlrange[2 * i + 1], action[i]));   // Clamp
+}
+void SamplingPolicy::CopyFrom(const SamplingPolicy& p, int) {
+  plan = p.plan; num_spline_points = p.num_spline_points; nu = p.nu; ctrlrange = p.ctrlrange;
+}
+
+// ------------------------------------------------------------------ SamplingPlanner
+static double Micros(std::chrono::steady_clock::time_point t0) {
+  return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+}
+
+SamplingPlanner::~SamplingPlanner() { if (engine_) mjpc_hip_destroy(engine_); }
+
+void SamplingPlanner::Initialize(const MjpcHipModel* model, const MjpcHipTask* task, const Numerics& numerics) {
+  numerics_ = numerics;
+  nq_ = model->nq; nv_ = model->nv; na_ = model->na; ns_ = nq_ + nv_ + na_; nu_ = model->nu; nmocap_ = model->nmocap; nuserdata_ = model->nuserdata;
+  nr_ = task->num_residual; ntrace_ = task->num_trace; timestep_ = model->timestep;
+  ctrlrange_.assign(model->actuator_ctrlrange, model->actuator_ctrlrange + 2 * nu_);
+  noise_exploration[0] = numerics.sampling_exploration[0];
+  noise_exploration[1] = numerics.sampling_exploration[1];
+  num_trajectory_ = numerics.sampling_trajectories;
+  interpolation_ = numerics.sampling_representation;
+  sliding_plan_ = numerics.sampling_sliding_plan;
+  if (num_trajectory_ > numerics.max_samples) {
+    char msg[128]; std::snprintf(msg, sizeof(msg), "Too many trajectories, %d is the maximum allowed.", numerics.max_samples);
+    Fatal(msg);
+    return;
+  }
+  if (engine_) { mjpc_hip_destroy(engine_); engine_ = nullptr; }     // the model might have changed
+  engine_ = mjpc_hip_create(model, task, numerics.max_samples, numerics.max_horizon, numerics.device);
+  if (!engine_) { Fatal(mjpc_hip_last_error()); return; }
+  policy.Allocate(model, numerics.sampling_spline_points);
+  previous_policy.Allocate(model, numerics.sampling_spline_points);
+  winner_policy_.Allocate(model, numerics.sampling_spline_points);
+  winner = 0;
+}
+
+void SamplingPlanner::Allocate() {
+  state.assign(ns_, 0.0); mocap.assign(7 * nmocap_, 0.0); userdata.assign(nuserdata_, 0.0);
+  plan_scratch_ = TimeSpline(nu_);
+  trajectory_winner.dim_state = ns_; trajectory_winner.dim_action = nu_;
+  trajectory_winner.dim_residual = nr_; trajectory_winner.dim_trace = 3 * ntrace_;
+  trajectory_winner.states.assign((size_t)numerics_.max_horizon * ns_, 0.0);
+  trajectory_winner.actions.assign((size_t)numerics_.max_horizon * nu_, 0.0);
+  trajectory_winner.times.assign(numerics_.max_horizon, 0.0);
+  trajectory_winner.residual.assign((size_t)numerics_.max_horizon * nr_, 0.0);
+  trajectory_winner.costs.assign(numerics_.max_horizon, 0.0);
+  trajectory_winner.trace.assign((size_t)numerics_.max_horizon * 3 * std::max(ntrace_, 1), 0.0);
+  returns.assign(numerics_.max_samples, 0.0); failures.assign(numerics_.max_samples, 0);
+  winner = -1;
+}
+
+void SamplingPlanner::Reset(int horizon, const double* initial_repeated_action) {
+  std::fill(state.begin(), state.end(), 0.0); std::fill(mocap.begin(), mocap.end(), 0.0);
+  std::fill(userdata.begin(), userdata.end(), 0.0);
+  time = 0.0;
+  policy.Reset(horizon, initial_repeated_action);
+  previous_policy.Reset(horizon, initial_repeated_action);
+  winner_policy_.Reset(horizon, initial_repeated_action);
+  plan_scratch_.Clear();
+  improvement = 0.0;
+  winner = 0;
+  fetched_ = -1;
+}
+
+void SamplingPlanner::SetState(const double* s, const double* m, const double* u, double t) {
+  std::copy(s, s + ns_, state.begin());
+  if (m) std::copy(m, m + 7 * nmocap_, mocap.begin());
+  if (u) std::copy(u, u + nuserdata_, userdata.begin());
+  time = t;
+}
+
+void SamplingPlanner::SetTask(const MjpcHipTask* task) {
+  if (mjpc_hip_set_task(engine_, task) != 0) Fatal(mjpc_hip_last_error());
+}
+
+void SamplingPlanner::UpdateNominalPolicy(int horizon) {   // planner.cc:236-310
+  int num_spline_points = winner_policy_.num_spline_points;
+  double nominal_time = time;
+  double time_horizon = (horizon - 1) * timestep_;
+  if (sliding_plan_) {
+    int extra_points = interpolation_ == kZeroSpline ? 1 : (interpolation_ == kLinearSpline ? 2 : 4);
+    double time_shift;
+    if (num_spline_points > extra_points) time_shift = std::max(time_horizon / (num_spline_points - extra_points), 1.0e-5);
+    else time_shift = time_horizon;
+    const std::unique_lock<std::shared_mutex> lock(mtx_);
+    policy.plan.DiscardBefore(nominal_time);
+    if (policy.plan.Size() == 0) policy.plan.AddNode(time);
+    while ((int)policy.plan.Size() < num_spline_points) {
+      int last = (int)policy.plan.Size() - 1;
+      double new_node_time = policy.plan.NodeTime(last) + time_shift;
+      std::vector<double> copy(policy.plan.NodeValues(last), policy.plan.NodeValues(last) + nu_);
+      policy.plan.AddNode(new_node_time, copy.data());
+    }
+  } else {
+    double time_shift;
+    if (interpolation_ == kZeroSpline) time_shift = std::max(time_horizon / num_spline_points, 1.0e-5);
+    else time_shift = std::max(time_horizon / (num_spline_points - 1), 1.0e-5);
+    plan_scratch_.Clear();
+    plan_scratch_.SetInterpolation((SplineInterpolation)interpolation_);
+    for (int t = 0; t < num_spline_points; t++) {
+      double* node = plan_scratch_.AddNode(nominal_time);
+      winner_policy_.Action(node, nullptr, nominal_time);
+      nominal_time += time_shift;                         // repeated addition, like the reference
+    }
+    const std::unique_lock<std::shared_mutex> lock(mtx_);
+    policy.plan = plan_scratch_;
+  }
+}
+
+int SamplingPlanner::OptimizePolicyCandidates(int ncandidates, int horizon) {   // planner.cc:151-187
+  int num_trajectory = num_trajectory_;
+  ncandidates = std::min(ncandidates, num_trajectory);
+  auto rollouts_start = std::chrono::steady_clock::now();
+  policy.plan.SetInterpolation((SplineInterpolation)interpolation_);
+  int P = (int)policy.plan.Size();
+  knot_times_.resize(std::max(P, 1)); knot_values_.resize((size_t)std::max(P, 1) * nu_);
+  for (int p = 0; p < P; p++) {
+    knot_times_[p] = policy.plan.NodeTime(p);
+    std::copy(policy.plan.NodeValues(p), policy.plan.NodeValues(p) + nu_, knot_values_.begin() + (size_t)p * nu_);
+  }
+  if (P == 0) { P = 1; knot_times_[0] = time; std::fill(knot_values_.begin(), knot_values_.end(), 0.0); }   // empty plan samples zeros
+  winner_knots_.assign((size_t)P * nu_, 0.0);
+  MjpcHipPlanInput in;
+  std::memset(&in, 0, sizeof(in));
+  in.state = state.data(); in.mocap = mocap.data(); in.userdata = userdata.data(); in.time = time;
+  in.knot_times = knot_times_.data(); in.knot_values = knot_values_.data(); in.num_spline_points = P;
+  in.interpolation = interpolation_; in.num_trajectory = num_trajectory; in.horizon = horizon;
+  in.candidate_offset = 0; in.num_local = num_trajectory;
+  in.noise_exploration[0] = noise_exploration[0]; in.noise_exploration[1] = noise_exploration[1];
+  in.noise_eps = injected_noise_eps; in.noise_sel = injected_noise_sel; in.seed = seed; in.stream = plan_iter++;
+  MjpcHipPlanOutput out;
+  std::memset(&out, 0, sizeof(out));
+  out.returns = returns.data(); out.failure = failures.data();
+  out.states = trajectory_winner.states.data(); out.actions = trajectory_winner.actions.data();
+  out.times = trajectory_winner.times.data(); out.residual = trajectory_winner.residual.data();
+  out.costs = trajectory_winner.costs.data(); out.trace = trajectory_winner.trace.data(); out.winner_knots = winner_knots_.data();
+  if (mjpc_hip_plan(engine_, &in, &out) != 0) { Fatal(mjpc_hip_last_error()); return 0; }
+  last_horizon_ = horizon; fetched_ = out.winner;
+  noise_compute_time = out.noise_compute_time_us;
+  // order so that the first ncandidates are the best (ties: lowest index, like the engine's argmin)
+  trajectory_order.resize(num_trajectory);
+  std::iota(trajectory_order.begin(), trajectory_order.end(), 0);
+  std::stable_sort(trajectory_order.begin(), trajectory_order.end(), [this](int a, int b) { return returns[a] < returns[b]; });
+  rollouts_compute_time = Micros(rollouts_start);
+  return ncandidates;
+}
+
+void SamplingPlanner::FetchCandidate(int global_index) {
+  if (fetched_ == global_index) return;
+  MjpcHipPlanOutput out;
+  std::memset(&out, 0, sizeof(out));
+  out.states = trajectory_winner.states.data(); out.actions = trajectory_winner.actions.data();
+  out.times = trajectory_winner.times.data(); out.residual = trajectory_winner.residual.data();
+  out.costs = trajectory_winner.costs.data(); out.trace = trajectory_winner.trace.data(); out.winner_knots = winner_knots_.data();
+  if (mjpc_hip_get_candidate(engine_, global_index, &out) != 0) { Fatal(mjpc_hip_last_error()); return; }
+  fetched_ = global_index;
+}
+
+void SamplingPlanner::CopyCandidateToPolicy(int candidate) {   // planner.cc:525-534 (with a UNIQUE lock)
+  winner = trajectory_order[candidate];
+  FetchCandidate(winner);
+  trajectory_winner.horizon = last_horizon_;
+  trajectory_winner.total_return = returns[winner];
+  trajectory_winner.failure = failures[winner] != 0;
+  int P = (int)knot_times_.size();
+  winner_policy_.plan = TimeSpline(nu_, (SplineInterpolation)interpolation_);
+  for (int p = 0; p < P; p++) winner_policy_.plan.AddNode(knot_times_[p], winner_knots_.data() + (size_t)p * nu_);
+  winner_policy_.num_spline_points = policy.num_spline_points;
+  const std::unique_lock<std::shared_mutex> lock(mtx_);
+  previous_policy.CopyFrom(policy, 0);
+  policy.CopyFrom(winner_policy_, 0);
+}
+
+void SamplingPlanner::OptimizePolicy(int horizon) {   // planner.cc:190-208
+  UpdateNominalPolicy(horizon);
+  OptimizePolicyCandidates(1, horizon);
+  auto policy_update_start = std::chrono::steady_clock::now();
+  CopyCandidateToPolicy(0);
+  double best_return = returns[0];
+  improvement = std::max(best_return - returns[winner], 0.0);
+  policy_update_compute_time = Micros(policy_update_start);
+}
+
+void SamplingPlanner::NominalTrajectory(int horizon) {   // planner.cc:211-222: candidate 0 only
+  int saved = num_trajectory_;
+  unsigned long long saved_iter = plan_iter;
+  num_trajectory_ = 1;
+  OptimizePolicyCandidates(1, horizon);
+  num_trajectory_ = saved; plan_iter = saved_iter;
+  winner = 0;
+  trajectory_winner.horizon = last_horizon_; trajectory_winner.total_return = returns[0]; trajectory_winner.failure = failures[0] != 0;
+}
+
+void SamplingPlanner::ActionFromPolicy(double* action, const double* s, double t, bool use_previous) {   // planner.cc:225-233
+  const std::shared_lock<std::shared_mutex> lock(mtx_);
+  if (use_previous) previous_policy.Action(action, s, t);
+  else policy.Action(action, s, t);
+}
+
+const Trajectory* SamplingPlanner::BestTrajectory() { return winner >= 0 ? &trajectory_winner : nullptr; }
+
+double SamplingPlanner::CandidateScore(int candidate) const { return returns[trajectory_order[candidate]]; }
+
+void SamplingPlanner::ActionFromCandidatePolicy(double* action, int candidate, const double* s, double t) {
+  FetchCandidate(trajectory_order[candidate]);
+  TimeSpline sp(nu_, (SplineInterpolation)interpolation_);
+  for (size_t p = 0; p < knot_times_.size(); p++) sp.AddNode(knot_times_[p], winner_knots_.data() + p * nu_);
+  sp.Sample(t, action);
+  for (int i = 0; i < nu_; i++) action[i] = std::max(ctrlrange_[2 * i], std::min(ctrlrange_[2 * i + 1], action[i]));
+  (void)s;
+}
+
+}  // namespace mjpc_hip
+
+// ====================================================================== flat C wrapper (tests / ctypes)
+using mjpc_hip::SamplingPlanner;
+using mjpc_hip::TimeSpline;
+extern "C" {
+
+void mjpc_planner_set_error_handler(void (*h)(const char*)) { mjpc_hip::g_error_handler = h; }
+
+// ---- TimeSpline (so that the reference's spline goldens can be run against the C++ class)
+void* mjpc_spline_create(int dim, int interpolation) { return new TimeSpline(dim, (mjpc_hip::SplineInterpolation)interpolation); }
+void mjpc_spline_destroy(void* s) { delete (TimeSpline*)s; }
+int mjpc_spline_size(void* s) { return (int)((TimeSpline*)s)->Size(); }
+void mjpc_spline_add_node(void* s, double time, const double* values) { ((TimeSpline*)s)->AddNode(time, values); }
+void mjpc_spline_sample(void* s, double time, double* out) { ((TimeSpline*)s)->Sample(time, out); }
+int mjpc_spline_discard_before(void* s, double time) { return ((TimeSpline*)s)->DiscardBefore(time); }
+void mjpc_spline_clear(void* s) { ((TimeSpline*)s)->Clear(); }
+void mjpc_spline_set_interpolation(void* s, int i) { ((TimeSpline*)s)->SetInterpolation((mjpc_hip::SplineInterpolation)i); }
+
+// ---- SamplingPlanner
+void* mjpc_planner_create(const MjpcHipModel* model, const MjpcHipTask* task, const double* exploration, int trajectories,
+                          int representation, int sliding_plan, int spline_points, int max_samples, int max_horizon, int device) {
+  auto* p = new SamplingPlanner();
+  mjpc_hip::Numerics n;
+  n.sampling_exploration[0] = exploration[0]; n.sampling_exploration[1] = exploration[1];
+  n.sampling_trajectories = trajectories; n.sampling_representation = representation; n.sampling_sliding_plan = sliding_plan;
+  n.sampling_spline_points = spline_points; n.max_samples = max_samples; n.max_horizon = max_horizon; n.device = device;
+  p->Initialize(model, task, n);
+  p->Allocate();
+  return p;
+}
+void mjpc_planner_destroy(void* p) { delete (SamplingPlanner*)p; }
+void mjpc_planner_reset(void* p, int horizon, const double* initial_repeated_action) { ((SamplingPlanner*)p)->Reset(horizon, initial_repeated_action); }
+void mjpc_planner_set_state(void* p, const double* s, const double* m, const double* u, double t) { ((SamplingPlanner*)p)->SetState(s, m, u, t); }
+void mjpc_planner_set_task(void* p, const MjpcHipTask* task) { ((SamplingPlanner*)p)->SetTask(task); }
+void mjpc_planner_timings(void* p, double* a, double* b, double* c) { auto* q = (SamplingPlanner*)p; *a = q->noise_compute_time; *b = q->rollouts_compute_time; *c = q->policy_update_compute_time; }
+void mjpc_planner_optimize_policy(void* p, int horizon) { ((SamplingPlanner*)p)->OptimizePolicy(horizon); }
+void mjpc_planner_nominal_trajectory(void* p, int horizon) { ((SamplingPlanner*)p)->NominalTrajectory(horizon); }
+void mjpc_planner_action_from_policy(void* p, double* action, double time, int use_previous) { ((SamplingPlanner*)p)->ActionFromPolicy(action, nullptr, time, use_previous != 0); }
+int mjpc_planner_optimize_policy_candidates(void* p, int ncandidates, int horizon) { auto* q = (SamplingPlanner*)p; q->UpdateNominalPolicy(horizon); return q->OptimizePolicyCandidates(ncandidates, horizon); }
+double mjpc_planner_candidate_score(void* p, int candidate) { return ((SamplingPlanner*)p)->CandidateScore(candidate); }
+void mjpc_planner_action_from_candidate_policy(void* p, double* action, int candidate, double time) { ((SamplingPlanner*)p)->ActionFromCandidatePolicy(action, candidate, nullptr, time); }
+void mjpc_planner_copy_candidate_to_policy(void* p, int candidate) { ((SamplingPlanner*)p)->CopyCandidateToPolicy(candidate); }
+int mjpc_planner_winner(void* p) { return ((SamplingPlanner*)p)->winner; }
+double mjpc_planner_improvement(void* p) { return ((SamplingPlanner*)p)->improvement; }
+int mjpc_planner_num_parameters(void* p) { return ((SamplingPlanner*)p)->NumParameters(); }
+void mjpc_planner_set_seed(void* p, unsigned long long seed, unsigned long long plan_iter) { auto* q = (SamplingPlanner*)p; q->seed = seed; q->plan_iter = plan_iter; }
+void mjpc_planner_set_num_trajectory(void* p, int n) { ((SamplingPlanner*)p)->num_trajectory_ = n; }
+void mjpc_planner_set_noise(void* p, const double* eps, const int* sel) { auto* q = (SamplingPlanner*)p; q->injected_noise_eps = eps; q->injected_noise_sel = sel; }
+void mjpc_planner_returns(void* p, double* out, int n) { auto* q = (SamplingPlanner*)p; std::copy(q->returns.begin(), q->returns.begin() + n, out); }
+// policy knots: returns P; fills times[P] and values[P*nu] when non-null
+int mjpc_planner_policy(void* p, int which, double* times, double* values) {
+  auto* q = (SamplingPlanner*)p;
+  const mjpc_hip::SamplingPolicy& pol = which ? q->previous_policy : q->policy;
+  int P = (int)pol.plan.Size();
+  for (int i = 0; i < P; i++) {
+    if (times) times[i] = pol.plan.NodeTime(i);
+    if (values) std::copy(pol.plan.NodeValues(i), pol.plan.NodeValues(i) + pol.nu, values + (size_t)i * pol.nu);
+  }
+  return P;
+}
+// best trajectory: returns horizon (0 if none); copies the arrays that are non-null
+int mjpc_planner_best_trajectory(void* p, double* states, double* actions, double* times, double* residual, double* costs,
+                                 double* trace, double* total_return, int* failure) {
+  const mjpc_hip::Trajectory* t = ((SamplingPlanner*)p)->BestTrajectory();
+  if (!t) return 0;
+  size_t H = (size_t)t->horizon;
+  if (states) std::copy(t->states.begin(), t->states.begin() + H * t->dim_state, states);
+  if (actions) std::copy(t->actions.begin(), t->actions.begin() + H * t->dim_action, actions);
+  if (times) std::copy(t->times.begin(), t->times.begin() + H, times);
+  if (residual) std::copy(t->residual.begin(), t->residual.begin() + H * t->dim_residual, residual);
+  if (costs) std::copy(t->costs.begin(), t->costs.begin() + H, costs);
+  if (trace) std::copy(t->trace.begin(), t->trace.begin() + H * t->dim_trace, trace);
+  if (total_return) *total_return = t->total_return;
+  if (failure) *failure = t->failure ? 1 : 0;
+  return t->horizon;
+}
+
+}  // extern "C"

@@ -183,3 +183,60 @@ def test_sampling_planner_on_gpu_reaches_goal_and_matches_oracle_planner():
     a = gpu.ActionFromPolicy(0.05); b = gpu.ActionFromPolicy(0.05, use_previous=True)
     assert a.shape == (2,) and b.shape == (2,)
     gpu.backend.close()
+
+
+@pytest.mark.parametrize("sliding,interp", [(0, 2), (1, 1), (0, 0)])
+def test_cpp_host_planner_matches_python_mirror_bitwise(sliding, interp):
+    """mjpc_hip::SamplingPlanner (C++, csrc/planner.cc — the product's host side) against the Python mirror of the same
+    reference code (planner.cc:151-310), both over the HIP engine with the same Philox seed: policies, winners, returns
+    and the winner trajectory must be bit-identical over a closed-loop run (UpdateNominalPolicy resampling, sliding
+    plans, clamp and candidate ranking all exercised)."""
+    from mujoco_mpc_amd import cplanner
+    from mujoco_mpc_amd.planner import SamplingPlanner
+    m, task, d = particle(timestep=0.1)
+    H, N = 20, 16
+    num = dict(sampling_spline_points=6, sampling_exploration=[0.3, 0.6], sampling_trajectories=N,
+               sampling_representation=interp, sampling_sliding_plan=sliding)
+    cpp = cplanner.SamplingPlanner()
+    cpp.Initialize(m, task, num, max_samples=N, max_horizon=H)
+    cpp.Reset(H); cpp.set_seed(1234, 0)
+    py = SamplingPlanner(HipBackend(m, task, max_samples=N, max_horizon=H))
+    py.Initialize(m, task, num); py.Allocate(); py.Reset(H); py.seed = 1234; py.plan_iter = 0
+    state = np.array([0.3, -0.2, 0.0, 0.0]); t = 0.0
+    for it in range(25):
+        for p in (cpp, py):
+            p.SetState(state, d["mocap"], None, t)
+            p.OptimizePolicy(H)
+        assert cpp.winner == py.winner
+        assert np.array_equal(cpp.returns(N), np.asarray(py.returns)[:N])
+        kt, kv = cpp.policy_knots()
+        assert np.array_equal(kt, np.array(py.policy.plan.times_)) and np.array_equal(kv, np.array(py.policy.plan.values_))
+        kt, kv = cpp.policy_knots(previous=True)
+        assert np.array_equal(kt, np.array(py.previous_policy.plan.times_))
+        a, b = cpp.BestTrajectory(), py.BestTrajectory()
+        assert a.horizon == H and np.array_equal(a.states, b.states[:H]) and np.array_equal(a.actions[:H - 1], b.actions[:H - 1])
+        assert np.array_equal(a.costs, b.costs[:H]) and a.total_return == b.total_return
+        assert np.array_equal(cpp.ActionFromPolicy(t + 0.05), py.ActionFromPolicy(t + 0.05))
+        assert np.array_equal(cpp.ActionFromPolicy(t + 0.05, True), py.ActionFromPolicy(t + 0.05, use_previous=True))
+        state = a.states[1].copy(); t += m["timestep"]         # closed loop: advance along the winner
+    assert cpp.improvement >= 0.0 and cpp.NumParameters() == 6 * m["nu"]
+    # RankedPlanner surface
+    cpp.SetState(state, d["mocap"], None, t)
+    n = cpp.OptimizePolicyCandidates(4, H)
+    assert n == 4
+    scores = [cpp.CandidateScore(k) for k in range(4)]
+    assert scores == sorted(scores) and scores[0] == cpp.returns(N).min()
+    cpp.CopyCandidateToPolicy(2)
+    assert cpp.BestTrajectory().total_return == scores[2]
+    act = cpp.ActionFromCandidatePolicy(2, t)
+    assert np.array_equal(act, cpp.ActionFromPolicy(t))
+    py.backend.close(); cpp.close()
+
+
+def test_cpp_host_planner_rejects_too_many_trajectories():
+    """planner.cc:69-72: mju_error when sampling_trajectories exceeds the maximum."""
+    from mujoco_mpc_amd import cplanner
+    m, task, d = particle()
+    p = cplanner.SamplingPlanner()
+    with pytest.raises(cplanner.PlannerError, match="Too many trajectories"):
+        p.Initialize(m, task, dict(sampling_trajectories=64), max_samples=32, max_horizon=8)

@@ -1,0 +1,105 @@
+"""C++ host planner (include/mjpc_hip_planner.h, csrc/planner.cc): the parts that run without a GPU.
+TimeSpline is checked against the reference's own spline goldens (mjpc/test/spline/spline_test.cc) and bitwise against
+the oracle's spline; the flat C view must export exactly what include/mjpc_hip_planner_c.h declares."""
+import math
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from mujoco_mpc_amd import cplanner
+from mujoco_mpc_amd.cplanner import PlannerError, TimeSpline
+from mujoco_mpc_amd.planner import kCubicSpline, kLinearSpline, kZeroSpline
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_planner_c_header_symbols_are_exported():
+    text = open(os.path.join(ROOT, "include", "mjpc_hip_planner_c.h")).read()
+    declared = sorted(set(re.findall(r"\b(mjpc_(?:planner|spline)_[a-z_]+)\(", text)))
+    assert declared == sorted(cplanner.PLANNER_C_SYMBOLS)
+    L = cplanner.lib()
+    for s in declared:
+        getattr(L, s)
+
+
+def test_cpp_spline_empty_samples_zero():                   # spline_test.cc:40-49
+    s = TimeSpline(10)
+    assert s.Size() == 0 and s.Dim() == 10 and np.all(s.Sample(2.0) == 0.0)
+
+
+@pytest.mark.parametrize("interp", [kZeroSpline, kLinearSpline, kCubicSpline])
+def test_cpp_spline_one_and_two_nodes(interp):              # spline_test.cc:51-80
+    s = TimeSpline(2, interp)
+    s.AddNode(1.0, [1.0, 2.0])
+    for t in (0.0, 2.0, 4.0):
+        assert list(s.Sample(t)) == [1.0, 2.0]
+    s.AddNode(2.0, [3.0, 4.0])
+    assert s.Size() == 2
+    for t, e in ((0, [1, 2]), (1, [1, 2]), (2, [3, 4]), (3, [3, 4])):
+        assert list(s.Sample(t)) == e
+
+
+def test_cpp_spline_zero_linear_cubic_goldens():            # spline_test.cc:115-159
+    for interp, expect in ((kZeroSpline, [1.0, 2.0]), (kLinearSpline, [2.0, 3.0]), (kCubicSpline, [2.0, 3.0])):
+        s = TimeSpline(2, interp)
+        s.AddNode(1.0, [1.0, 2.0]); s.AddNode(2.0, [3.0, 4.0])
+        assert list(s.Sample(1.5)) == expect
+    s = TimeSpline(2, kCubicSpline)
+    for t, v in zip([0.0, 1.0, 2.0, 3.0], [[1.0, 2.0], [1.0, 2.0], [3.0, 4.0], [3.0, 4.0]]):
+        s.AddNode(t, v)
+    assert list(s.Sample(1.5)) == [2.0, 3.0]
+    s = TimeSpline(1, kCubicSpline)
+    for t, v in zip([-1.0, 0.0, 1.0], [[1.0], [0.0], [1.0]]):
+        s.AddNode(t, v)
+    x = 0.0
+    while x <= 1.0:
+        assert s.Sample(x)[0] == -math.pow(x, 3) + 2 * math.pow(x, 2)
+        x += 0.125
+
+
+def test_cpp_spline_add_before_start_and_discard():         # spline_test.cc:82-98,161-231
+    s = TimeSpline(2)
+    s.AddNode(2.0, [2.0, 3.0]); s.AddNode(1.0, [1.0, 2.0]); s.AddNode(3.0, [3.0, 4.0]); s.AddNode(0.0, [0.0, 1.0])
+    for t in range(4):
+        assert list(s.Sample(t)) == [float(t), float(t + 1)]
+    for interp in (kZeroSpline, kLinearSpline, kCubicSpline):
+        s = TimeSpline(2, interp)
+        for k in range(1, 5):
+            s.AddNode(float(k), [float(k), float(k + 1)])
+        assert s.DiscardBefore(0.9) == 0 and s.Size() == 4
+        assert list(s.Sample(0.0)) == [1.0, 2.0]
+        discarded = s.DiscardBefore(3.0)
+        if interp == kCubicSpline:
+            assert discarded == 1 and s.Size() == 3 and list(s.Sample(1.0)) == [2.0, 3.0]
+        else:
+            assert discarded == 2 and s.Size() == 2 and list(s.Sample(1.0)) == [3.0, 4.0]
+        assert s.DiscardBefore(3.9) == 0
+    s = TimeSpline(1)
+    for k in range(1, 5):
+        s.AddNode(float(k), [float(k)])
+    assert s.DiscardBefore(3) == 2 and s.Size() == 2
+    s.AddNode(5.0, [5.0]); s.AddNode(6.0, [6.0])
+    assert s.DiscardBefore(6.0) == 3 and s.Size() == 1 and s.Sample(1.0)[0] == 6.0
+
+
+def test_cpp_spline_add_node_in_the_middle_is_an_error():   # spline.cc:205-208 (mju_error in the reference)
+    s = TimeSpline(1)
+    s.AddNode(0.0, [0.0]); s.AddNode(2.0, [2.0])
+    with pytest.raises(PlannerError, match="middle"):
+        s.AddNode(1.0, [1.0])
+    assert s.Size() == 2
+
+
+def test_cpp_spline_matches_oracle_bitwise():
+    rng = np.random.default_rng(0)
+    for interp in (kZeroSpline, kLinearSpline, kCubicSpline):
+        for P in (1, 2, 3, 7):
+            times = np.cumsum(rng.uniform(0.05, 0.3, P)); vals = rng.normal(size=(P, 3))
+            s = TimeSpline(3, interp)
+            for t, v in zip(times, vals):
+                s.AddNode(t, v)
+            for t in rng.uniform(times[0] - 0.2, times[-1] + 0.2, 40):
+                assert np.array_equal(s.Sample(t), ol.spline_sample(times, vals, interp, t))

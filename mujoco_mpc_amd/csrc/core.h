@@ -1438,8 +1438,7 @@ DEV_NOINLINE void ph_integrate(KP Kc, int t) {
   if (M.any_damping) {
     PFOR(e, nv * nvp) { int i = e / nvp, j = e - i * nvp; c.qH[e] = c.qM[e] + ((i == j) ? h * M.dof_damping[i] : 0.0); }
     PFOR(i, nv) c.Mgrad[i] = c.qfrc_smooth[i] + c.qfrc_constraint[i];
-    chol_factor<NVT>(c.qH, c.Hinv, c.vtmp, nv, nvp);
-    chol_solve<NVT>(c.qH, c.Hinv, c.Mgrad, nv, nvp);
+    chol_factor_solve<NVT>(c.qH, c.Hinv, c.vtmp, c.Mgrad, nv, nvp);
     PFOR(i, nv) c.qvel[i] += h * c.Mgrad[i];
   } else {
     PFOR(i, nv) c.qvel[i] += h * c.qacc[i];

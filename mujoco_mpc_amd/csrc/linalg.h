@@ -61,59 +61,97 @@ DEV void chol_solve_lds(const double *L, const double *Linv, double *x, int n, i
 }
 
 // ---- register versions (compile-time n) -----------------------------------------------------
+// A = L^T D L (L unit lower triangular, pivots taken from the last dof up, like MuJoCo's mj_factorM order).
+// Lane i keeps the full symmetric row i in VGPRs.  A pivot step broadcasts 1/d_k and row k with v_readlane
+// (SGPR operands of the trailing FMAs): no LDS traffic and no waits on the pivot chain, which is
+//   readlane(d_k) -> rcp + 2 Newton steps -> l = a[k]*r -> d_{k-1} update;
+// the rank-1 update of the other columns is independent work the scheduler overlaps with that chain.
+// Afterwards lane i holds  up[k] = L[k][i] (k > i, else 0)  and  lo[j] = L[i][j] (j < i, else 0),
+// so both substitutions are "readlane + one FMA" per step.
 #ifndef MJPC_EMU
+DEV double fast_rcp(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  double e = __builtin_fma(-x, y, 1.0);
+  y = __builtin_fma(y, e, y);
+  e = __builtin_fma(-x, y, 1.0);
+  return __builtin_fma(y, e, y);
+}
 template <int N>
-DEV void chol_factor_reg(double *A, double *Linv, double *colbuf, int nvp) {
+struct LDLRegs { double lo[N], up[N], rinv; };
+
+template <int N>
+DEV void ldl_factor_regs(const double *A, int nvp, LDLRegs<N> &f) {
   static_assert(N >= 1 && N <= 64, "one matrix row per lane");
-  SYNC();
   const int i = LANE;
   const bool act = i < N;
   double a[N];
 #pragma unroll
-  for (int k = 0; k < N; k++) a[k] = (act && k <= i) ? A[i * nvp + k] : 0.0;
+  for (int j = 0; j < N; j++) a[j] = act ? A[(j <= i) ? i * nvp + j : j * nvp + i] : 0.0;   // lower triangle is valid in LDS
+  double dg = act ? A[i * nvp + i] : 1.0;
 #pragma unroll
-  for (int j = 0; j < N; j++) {
-    double ajj = readlane_d(a[j], j);
-    if (ajj < D_MINVAL) ajj = D_MINVAL;
-    double inv = fast_rsqrt(ajj), dj = ajj * inv;       // pivot without IEEE sqrt + divide on the column chain
-    double lij = (i == j) ? dj : a[j] * inv;
-    a[j] = lij;
-    if (j + 1 < N) {
-      // column j of L goes through an LDS line; every lane then reads L[k][j] as a broadcast with an
-      // immediate offset (2 instructions per trailing update instead of 2 readlanes + FMA)
-      if (act) colbuf[i] = lij;
-      SYNC();
+  for (int k = N - 1; k >= 1; k--) {
+    double dk = readlane_d(dg, k);
+    if (dk < D_MINVAL) dk = D_MINVAL;
+    double rk = fast_rcp(dk);
+    double hk = a[k];
+    double l = (i < k) ? hk * rk : 0.0;
+    dg -= l * hk;
 #pragma unroll
-      for (int k = j + 1; k < N; k++) a[k] -= lij * colbuf[k];   // A[i][k] -= L[i][j] * L[k][j]
-      SYNC();
-    }
-    if (i == 0) Linv[j] = inv;
+    for (int j = 0; j < k; j++) a[j] -= l * readlane_d(a[j], k);      // A[i][j] -= L[k][i] * A[k][j]
+    f.up[k] = l;
   }
+  f.up[0] = 0.0;
+  if (dg < D_MINVAL) dg = D_MINVAL;
+  f.rinv = fast_rcp(dg);
 #pragma unroll
-  for (int k = 0; k < N; k++) if (act && k <= i) A[i * nvp + k] = a[k];
+  for (int j = 0; j < N; j++) f.lo[j] = (act && j < i) ? a[j] * f.rinv : 0.0;
+}
+template <int N>
+DEV double ldl_solve_regs(const LDLRegs<N> &f, double xi) {
+#pragma unroll
+  for (int k = N - 1; k >= 1; k--) xi -= f.up[k] * readlane_d(xi, k);      // L^T u = b
+  xi *= f.rinv;                                                            // D v = u
+#pragma unroll
+  for (int j = 0; j < N - 1; j++) xi -= f.lo[j] * readlane_d(xi, j);       // L x = v
+  return xi;
+}
+// split form (factor kept in LDS between phases): L[i][j] (j < i) in the lower triangle of A, 1/d in Dinv
+template <int N>
+DEV void chol_factor_reg(double *A, double *Dinv, int nvp) {
+  SYNC();
+  LDLRegs<N> f;
+  ldl_factor_regs<N>(A, nvp, f);
+  const int i = LANE;
+#pragma unroll
+  for (int j = 0; j < N; j++) if (i < N && j < i) A[i * nvp + j] = f.lo[j];
+  if (i < N) Dinv[i] = f.rinv;
   SYNC();
 }
 template <int N>
-DEV void chol_solve_reg(const double *L, const double *Linv, double *x, int nvp) {
+DEV void chol_solve_reg(const double *L, const double *Dinv, double *x, int nvp) {
   SYNC();
   const int i = LANE;
   const bool act = i < N;
-  double xi = act ? x[i] : 0.0;
-  // unit-diagonal form A = L' D L'^T, L'[i][j] = L[i][j] / L[j][j], D = diag(L[j][j]^2): the substitution
-  // chains are readlane + one FMA per step; the scalings are done off the chain
-  double row[N], col[N];
-  double mydinv = act ? Linv[i] : 0.0;
+  LDLRegs<N> f;
+  f.rinv = act ? Dinv[i] : 0.0;
 #pragma unroll
   for (int k = 0; k < N; k++) {
-    row[k] = (act && k < i) ? L[i * nvp + k] * Linv[k] : 0.0;     // L'[i][k], forward substitution
-    col[k] = (act && k > i) ? L[k * nvp + i] * mydinv : 0.0;      // L'[k][i], backward substitution
+    f.lo[k] = (act && k < i) ? L[i * nvp + k] : 0.0;
+    f.up[k] = (act && k > i) ? L[k * nvp + i] : 0.0;
   }
-#pragma unroll
-  for (int j = 0; j < N; j++) xi -= row[j] * readlane_d(xi, j);    // row[j] == 0 for j >= i
-  xi *= mydinv * mydinv;
-#pragma unroll
-  for (int j = N - 1; j >= 0; j--) xi -= col[j] * readlane_d(xi, j);   // col[j] == 0 for j <= i
+  double xi = ldl_solve_regs<N>(f, act ? x[i] : 0.0);
   if (act) x[i] = xi;
+  SYNC();
+}
+// fused factor + solve (the factor never leaves the registers): Newton direction, implicit-damping solve
+template <int N>
+DEV void chol_factor_solve_reg(const double *A, double *x, int nvp) {
+  SYNC();
+  LDLRegs<N> f;
+  ldl_factor_regs<N>(A, nvp, f);
+  const int i = LANE;
+  double xi = ldl_solve_regs<N>(f, i < N ? x[i] : 0.0);
+  if (i < N) x[i] = xi;
   SYNC();
 }
 #endif
@@ -121,7 +159,7 @@ DEV void chol_solve_reg(const double *L, const double *Linv, double *x, int nvp)
 template <int NVT>
 DEV void chol_factor(double *A, double *Linv, double *tmp, int n, int nvp) {
 #ifndef MJPC_EMU
-  if constexpr (NVT > 0) { chol_factor_reg<NVT>(A, Linv, tmp, NVT | 1); return; }
+  if constexpr (NVT > 0) { chol_factor_reg<NVT>(A, Linv, NVT | 1); return; }
 #endif
   chol_factor_lds(A, Linv, tmp, n, nvp);
 }
@@ -131,4 +169,13 @@ DEV void chol_solve(const double *L, const double *Linv, double *x, int n, int n
   if constexpr (NVT > 0) { chol_solve_reg<NVT>(L, Linv, x, NVT | 1); return; }
 #endif
   chol_solve_lds(L, Linv, x, n, nvp);
+}
+// A (lower triangle) is consumed; x <- A^-1 x.  The generic build leaves the LL^T factor in A / Linv.
+template <int NVT>
+DEV void chol_factor_solve(double *A, double *Linv, double *tmp, double *x, int n, int nvp) {
+#ifndef MJPC_EMU
+  if constexpr (NVT > 0) { chol_factor_solve_reg<NVT>(A, x, NVT | 1); return; }
+#endif
+  chol_factor_lds(A, Linv, tmp, n, nvp);
+  chol_solve_lds(A, Linv, x, n, nvp);
 }

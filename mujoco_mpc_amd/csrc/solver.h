@@ -211,10 +211,8 @@ DEV void newton_gradient(Ctx &c) {
   // the in-place factor of the previous iteration filled the structural zeros: clear them again
   if (!c.cross) PFOR(e, M.nzpair) c.qH[M.zpair_i[e] * nvp + M.zpair_j[e]] = 0;
   PROF(c, 16);
-  chol_factor<NVT>(c.qH, c.Hinv, c.vtmp, nv, nvp);
+  chol_factor_solve<NVT>(c.qH, c.Hinv, c.vtmp, c.Mgrad, nv, nvp);
   PROF(c, 17);
-  chol_solve<NVT>(c.qH, c.Hinv, c.Mgrad, nv, nvp);
-  PROF(c, 18);
 }
 
 // ---- exact line search: phi(alpha) = Gauss(alpha) + sum_i s_i(jar + alpha*jv), data in registers

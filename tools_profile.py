@@ -31,3 +31,7 @@ for i, n in enumerate(names):
     print(f"  {n:26s} {100*prof[:, i].mean()/tot:6.2f} %   {prof[:, i].mean()/tot*out['rollouts_compute_time_us']/H:8.2f} us/step")
 print("ls evals per step (mean)", prof[:, 23].mean() / H)
 print("newton iters per step (mean)", allc["diag"][:, 0].mean() / H, "max ncon", allc["diag"][:, 1].max(), "max nefc", allc["diag"][:, 2].max())
+it = allc["diag"][:, 0] / H
+tk = prof[:, :23].sum(1)
+print(f"newton iters/step per candidate: min {it.min():.2f} mean {it.mean():.2f} p90 {np.percentile(it, 90):.2f} max {it.max():.2f}")
+print(f"stamped ticks per candidate: min {tk.min():.3e} mean {tk.mean():.3e} max {tk.max():.3e}  (max/mean {tk.max()/tk.mean():.2f})")

@@ -57,37 +57,42 @@ struct Ctx {
 #endif
   const DevModel *M;
   const KParams *K;
+  double *mcd; int *mci; const double *gdb; const int *gib;   // LDS copy of the model buffers / their HBM bases
   double *qpos, *qvel, *ctrl, *qacc, *qacc_ws, *qacc_smooth, *qfrc_smooth, *qfrc_bias, *qfrc_constraint, *actuator_force;
   double *mocap_pos, *mocap_quat;
   double *xpos, *xquat, *xmat, *xipos, *ximat, *xanchor, *xaxis, *geom_xpos, *geom_xmat, *site_xpos;
   double *subtree_com, *cinert, *crb, *cdof, *cvel, *cdof_dot, *cacc, *cfrc, *cfrc_sub, *subtree_linvel, *bodytmp;
   double *qM, *qL, *qH, *Linv, *Hinv;
-  double *efc_J, *efc_WJ, *efc_JA, *efc_D, *efc_R, *efc_aref, *efc_force, *efc_jar, *efc_jv, *efc_floss, *efc_pos, *efc_margin, *efc_diag;
+  double *efc_J, *efc_JA, *efc_D, *efc_R, *efc_aref, *efc_force, *efc_jar, *efc_jv, *efc_floss, *efc_pos, *efc_margin, *efc_diag;
   double *contact;
   double *Ma, *grad, *Mgrad, *search, *Mv, *vtmp, *sgl;
   double *knot_times, *knot_values, *residual, *terms, *red;
-  int *efc_type, *efc_id, *efc_state, *efc_dof, *con_i, *active, *misc;
+  int *efc_type, *efc_id, *efc_state, *efc_dof, *con_i, *active, *misc, *hpair;
   double time;
   int ncon, nefc, nsingle, warning, solver_iter, cross;
 };
 
 DEV void ctx_init(Ctx &c, const KParams *K, double *base) {
   const Lay &L = K->L;
-  c.M = &K->M; c.K = K;
+  c.K = K;
+  // model tables are read from the workgroup's LDS copy of the two model buffers (same layout; ph_init fills it):
+  // MD(f) / MI(f) turn the HBM table pointer M.f into its LDS twin
+  c.M = &K->M;
+  c.mcd = base + L.mc_d; c.mci = (int *)(base + L.mc_i); c.gdb = K->dbase; c.gib = K->ibase;
 #define P_(f) c.f = base + L.f
   P_(qpos); P_(qvel); P_(ctrl); P_(qacc); P_(qacc_ws); P_(qacc_smooth); P_(qfrc_smooth); P_(qfrc_bias);
   P_(qfrc_constraint); P_(actuator_force); P_(mocap_pos); P_(mocap_quat);
   P_(xpos); P_(xquat); P_(xmat); P_(xipos); P_(ximat); P_(xanchor); P_(xaxis); P_(geom_xpos); P_(geom_xmat); P_(site_xpos);
   P_(subtree_com); P_(cinert); P_(crb); P_(cdof); P_(cvel); P_(cdof_dot); P_(cacc); P_(cfrc); P_(cfrc_sub);
   P_(subtree_linvel); P_(bodytmp); P_(qM); P_(qL); P_(qH); P_(Linv); P_(Hinv);
-  P_(efc_J); P_(efc_WJ); P_(efc_JA); P_(efc_D); P_(efc_R); P_(efc_aref); P_(efc_force); P_(efc_jar); P_(efc_jv); P_(efc_floss);
+  P_(efc_J); P_(efc_JA); P_(efc_D); P_(efc_R); P_(efc_aref); P_(efc_force); P_(efc_jar); P_(efc_jv); P_(efc_floss);
   P_(efc_pos); P_(efc_margin); P_(efc_diag); P_(contact);
   P_(Ma); P_(grad); P_(Mgrad); P_(search); P_(Mv); P_(vtmp); P_(sgl);
   P_(knot_times); P_(knot_values); P_(residual); P_(terms); P_(red);
 #undef P_
   int *ib = (int *)(base + L.ints);
   c.efc_type = ib + L.i_efc_type; c.efc_id = ib + L.i_efc_id; c.efc_state = ib + L.i_efc_state; c.efc_dof = ib + L.i_efc_dof;
-  c.con_i = ib + L.i_con; c.active = ib + L.i_active; c.misc = ib + L.i_misc;
+  c.con_i = ib + L.i_con; c.active = ib + L.i_active; c.misc = ib + L.i_misc; c.hpair = ib + L.i_hpair;
   c.time = 0; c.ncon = 0; c.nefc = 0; c.nsingle = 0; c.warning = 0; c.solver_iter = 0; c.cross = 0;
 #if defined(MJPC_PROFILE) && !defined(MJPC_EMU)
   c.prof = (long long *)(base + L.prof);
@@ -101,6 +106,9 @@ DEV void ctx_open(Ctx &c, KP Kc) {
   c.warning = uniform_i(c.misc[3]); c.solver_iter = uniform_i(c.misc[4]); c.cross = uniform_i(c.misc[8]);
   c.time = c.red[0];
 }
+#define MD(f) (c.mcd + (int)(c.M->f - c.gdb))
+#define MI(f) (c.mci + (int)(c.M->f - c.gib))
+#define MDM() ((const unsigned long long *)(c.mcd + (int)((const double *)c.M->body_dofmask - c.gdb)))
 DEV void ctx_close(Ctx &c) {
   SYNC();
   if (LANE == 0) {
@@ -146,42 +154,42 @@ DEV double spline_sample(const double *times, const double *values, int P, int d
 DEV void kin_body(Ctx &c, int i) {
   const DevModel &M = *c.M;
   double xpos[3], xquat[4];
-  int pid = M.body_parentid[i];
-  int jntnum = M.body_jntnum[i], jntadr = M.body_jntadr[i];
-  int mid = M.body_mocapid[i];
+  int pid = MI(body_parentid)[i];
+  int jntnum = MI(body_jntnum)[i], jntadr = MI(body_jntadr)[i];
+  int mid = MI(body_mocapid)[i];
   if (mid >= 0) {
     d_copy3(xpos, c.mocap_pos + 3 * mid);
     d_copy4(xquat, c.mocap_quat + 4 * mid);
     d_normalize4(xquat);
-  } else if (jntnum == 1 && M.jnt_type[jntadr] == 0) {
-    int qa = M.jnt_qposadr[jntadr];
+  } else if (jntnum == 1 && MI(jnt_type)[jntadr] == 0) {
+    int qa = MI(jnt_qposadr)[jntadr];
     d_normalize4(c.qpos + qa + 3);
     d_copy3(xpos, c.qpos + qa);
     d_copy4(xquat, c.qpos + qa + 3);
     d_copy3(c.xanchor + 3 * jntadr, xpos);
-    d_copy3(c.xaxis + 3 * jntadr, M.jnt_axis + 3 * jntadr);
+    d_copy3(c.xaxis + 3 * jntadr, MD(jnt_axis) + 3 * jntadr);
   } else {
     if (pid) {
-      d_mulmatvec3(xpos, c.xmat + 9 * pid, M.body_pos + 3 * i);
+      d_mulmatvec3(xpos, c.xmat + 9 * pid, MD(body_pos) + 3 * i);
       d_add3(xpos, xpos, c.xpos + 3 * pid);
-      d_mulquat(xquat, c.xquat + 4 * pid, M.body_quat + 4 * i);
+      d_mulquat(xquat, c.xquat + 4 * pid, MD(body_quat) + 4 * i);
     } else {
-      d_copy3(xpos, M.body_pos + 3 * i);
-      d_copy4(xquat, M.body_quat + 4 * i);
+      d_copy3(xpos, MD(body_pos) + 3 * i);
+      d_copy4(xquat, MD(body_quat) + 4 * i);
     }
     for (int j = jntadr; j < jntadr + jntnum; j++) {
-      int qa = M.jnt_qposadr[j], type = M.jnt_type[j];
+      int qa = MI(jnt_qposadr)[j], type = MI(jnt_type)[j];
       double vec[3], ax[3], jp[3];
-      d_copy3(ax, M.jnt_axis + 3 * j); d_copy3(jp, M.jnt_pos + 3 * j);
+      d_copy3(ax, MD(jnt_axis) + 3 * j); d_copy3(jp, MD(jnt_pos) + 3 * j);
       d_rotvecquat(c.xaxis + 3 * j, ax, xquat);
       d_rotvecquat(vec, jp, xquat);
       d_add3(c.xanchor + 3 * j, vec, xpos);
       if (type == 2) {
-        d_addtoscl3(xpos, c.xaxis + 3 * j, c.qpos[qa] - M.qpos0[qa]);
+        d_addtoscl3(xpos, c.xaxis + 3 * j, c.qpos[qa] - MD(qpos0)[qa]);
       } else {
         double qloc[4], t[4];
         if (type == 1) { d_normalize4(c.qpos + qa); d_copy4(qloc, c.qpos + qa); }
-        else d_axisangle2quat(qloc, ax, c.qpos[qa] - M.qpos0[qa]);
+        else d_axisangle2quat(qloc, ax, c.qpos[qa] - MD(qpos0)[qa]);
         d_mulquat(t, xquat, qloc);
         d_copy4(xquat, t);
         d_rotvecquat(vec, jp, xquat);
@@ -196,7 +204,7 @@ DEV void kin_body(Ctx &c, int i) {
   d_quat2mat(xm, xquat);
   for (int k = 0; k < 9; k++) c.xmat[9 * i + k] = xm[k];
   double v[3], q[4], ip[3], iq[4];
-  d_copy3(ip, M.body_ipos + 3 * i); d_copy4(iq, M.body_iquat + 4 * i);
+  d_copy3(ip, MD(body_ipos) + 3 * i); d_copy4(iq, MD(body_iquat) + 4 * i);
   d_mulmatvec3(v, xm, ip);
   d_add3(c.xipos + 3 * i, v, xpos);
   d_mulquat(q, xquat, iq);
@@ -207,14 +215,14 @@ DEV void kin_body(Ctx &c, int i) {
 DEV void kinematics(Ctx &c) {
   const DevModel &M = *c.M;
   for (int l = 0; l < M.nlevel; l++) {
-    int a = M.level_adr[l], n = M.level_adr[l + 1] - a;
-    PFOR(k, n) kin_body(c, M.level_body[a + k]);
+    int a = MI(level_adr)[l], n = MI(level_adr)[l + 1] - a;
+    PFOR(k, n) kin_body(c, MI(level_body)[a + k]);
     SYNC();
   }
   PFOR(g, M.ngeom) {
-    int b = M.geom_bodyid[g];
+    int b = MI(geom_bodyid)[g];
     double v[3], q[4], gp[3], gq[4], xm[9];
-    d_copy3(gp, M.geom_pos + 3 * g); d_copy4(gq, M.geom_quat + 4 * g);
+    d_copy3(gp, MD(geom_pos) + 3 * g); d_copy4(gq, MD(geom_quat) + 4 * g);
     d_mulmatvec3(v, c.xmat + 9 * b, gp);
     d_add3(c.geom_xpos + 3 * g, v, c.xpos + 3 * b);
     d_mulquat(q, c.xquat + 4 * b, gq);
@@ -222,9 +230,9 @@ DEV void kinematics(Ctx &c) {
     for (int k = 0; k < 9; k++) c.geom_xmat[9 * g + k] = xm[k];
   }
   PFOR(s, M.nsite) {
-    int b = M.site_bodyid[s];
+    int b = MI(site_bodyid)[s];
     double v[3], sp[3];
-    d_copy3(sp, M.site_pos + 3 * s);
+    d_copy3(sp, MD(site_pos) + 3 * s);
     d_mulmatvec3(v, c.xmat + 9 * b, sp);
     d_add3(c.site_xpos + 3 * s, v, c.xpos + 3 * b);
   }
@@ -235,11 +243,11 @@ DEV void com_pos(Ctx &c) {
   const DevModel &M = *c.M;
   PFOR(b, M.nbody) {
     double s[3] = {0, 0, 0};
-    for (int k = M.subtree_adr[b]; k < M.subtree_adr[b + 1]; k++) {
-      int cb = M.subtree_list[k];
-      d_addtoscl3(s, c.xipos + 3 * cb, M.body_mass[cb]);
+    for (int k = MI(subtree_adr)[b]; k < MI(subtree_adr)[b + 1]; k++) {
+      int cb = MI(subtree_list)[k];
+      d_addtoscl3(s, c.xipos + 3 * cb, MD(body_mass)[cb]);
     }
-    double sm = M.body_subtreemass[b];
+    double sm = MD(body_subtreemass)[b];
     if (sm < D_MINVAL) d_copy3(c.subtree_com + 3 * b, c.xipos + 3 * b);
     else d_scl3(c.subtree_com + 3 * b, s, 1.0 / sm);
   }
@@ -247,15 +255,15 @@ DEV void com_pos(Ctx &c) {
   PFOR(b, M.nbody) {
     if (b == 0) { for (int k = 0; k < 10; k++) c.cinert[k] = 0; continue; }
     double off[3], ine[3], r[10];
-    d_sub3(off, c.xipos + 3 * b, c.subtree_com + 3 * M.body_rootid[b]);
-    d_copy3(ine, M.body_inertia + 3 * b);
-    d_inertcom(r, ine, c.ximat + 9 * b, off, M.body_mass[b]);
+    d_sub3(off, c.xipos + 3 * b, c.subtree_com + 3 * MI(body_rootid)[b]);
+    d_copy3(ine, MD(body_inertia) + 3 * b);
+    d_inertcom(r, ine, c.ximat + 9 * b, off, MD(body_mass)[b]);
     for (int k = 0; k < 10; k++) c.cinert[10 * b + k] = r[k];
   }
   PFOR(j, M.njnt) {
-    int b = M.jnt_bodyid[j], da = M.jnt_dofadr[j], type = M.jnt_type[j];
+    int b = MI(jnt_bodyid)[j], da = MI(jnt_dofadr)[j], type = MI(jnt_type)[j];
     double off[3];
-    d_sub3(off, c.subtree_com + 3 * M.body_rootid[b], c.xanchor + 3 * j);
+    d_sub3(off, c.subtree_com + 3 * MI(body_rootid)[b], c.xanchor + 3 * j);
     int skip = 0;
     if (type == 0) {
       for (int k = 0; k < 18; k++) c.cdof[6 * da + k] = 0;
@@ -290,17 +298,17 @@ DEV void crb_and_factor(Ctx &c) {
   PFOR(e, M.nbody * 10) {
     int b = e / 10, k = e - 10 * b;
     double s = 0;
-    if (b > 0) for (int q = M.subtree_adr[b]; q < M.subtree_adr[b + 1]; q++) s += c.cinert[10 * M.subtree_list[q] + k];
+    if (b > 0) for (int q = MI(subtree_adr)[b]; q < MI(subtree_adr)[b + 1]; q++) s += c.cinert[10 * MI(subtree_list)[q] + k];
     c.crb[e] = s;
   }
   SYNC();
   PFOR(p, M.nmpair) {
-    int i = M.mpair_i[p], j = M.mpair_j[p];
+    int i = MI(mpair_i)[p], j = MI(mpair_j)[p];
     double buf[6];
-    d_mulinertvec(buf, c.crb + 10 * M.dof_bodyid[i], c.cdof + 6 * i);
+    d_mulinertvec(buf, c.crb + 10 * MI(dof_bodyid)[i], c.cdof + 6 * i);
     const double *cj = c.cdof + 6 * j;
     double v = cj[0]*buf[0] + cj[1]*buf[1] + cj[2]*buf[2] + cj[3]*buf[3] + cj[4]*buf[4] + cj[5]*buf[5];
-    if (i == j) v += M.dof_armature[i];
+    if (i == j) v += MD(dof_armature)[i];
     c.qM[i * nvp + j] = v; c.qM[j * nvp + i] = v;
   }
   SYNC();
@@ -484,11 +492,11 @@ DEV int np_sphere_box(NPCon *con, double margin, const double *sp, double sr, co
 
 DEV int narrow_phase(Ctx &c, int g1, int g2, double margin, NPCon *con) {
   const DevModel &M = *c.M;
-  int t1 = M.geom_type[g1], t2 = M.geom_type[g2];
+  int t1 = MI(geom_type)[g1], t2 = MI(geom_type)[g2];
   double p1[3], p2[3], m1[9], m2[9], s1[3], s2[3];
   d_copy3(p1, c.geom_xpos + 3 * g1); d_copy3(p2, c.geom_xpos + 3 * g2);
   for (int k = 0; k < 9; k++) { m1[k] = c.geom_xmat[9 * g1 + k]; m2[k] = c.geom_xmat[9 * g2 + k]; }
-  d_copy3(s1, M.geom_size + 3 * g1); d_copy3(s2, M.geom_size + 3 * g2);
+  d_copy3(s1, MD(geom_size) + 3 * g1); d_copy3(s2, MD(geom_size) + 3 * g2);
   if (t1 == 0) {
     double n[3] = {m1[2], m1[5], m1[8]};
     if (t2 == 2) return np_plane_sphere(con, margin, p1, n, p2, s2[0]);
@@ -505,30 +513,31 @@ DEV int narrow_phase(Ctx &c, int g1, int g2, double margin, NPCon *con) {
   return 0;   // unsupported pair types produce no contact (known gap)
 }
 
-DEV void contact_param(const DevModel &M, int g1, int g2, double *cc, int *dim) {
-  int p1 = M.geom_priority[g1], p2 = M.geom_priority[g2];
+DEV void contact_param(Ctx &c, int g1, int g2, double *cc, int *dim) {
+  const DevModel &M = *c.M; (void)M;
+  int p1 = MI(geom_priority)[g1], p2 = MI(geom_priority)[g2];
   double fri[3];
   if (p1 != p2) {
     int g = p1 > p2 ? g1 : g2;
-    *dim = M.geom_condim[g];
-    for (int i = 0; i < 2; i++) cc[CON_SOLREF + i] = M.geom_solref[2 * g + i];
-    for (int i = 0; i < 5; i++) cc[CON_SOLIMP + i] = M.geom_solimp[5 * g + i];
-    d_copy3(fri, M.geom_friction + 3 * g);
+    *dim = MI(geom_condim)[g];
+    for (int i = 0; i < 2; i++) cc[CON_SOLREF + i] = MD(geom_solref)[2 * g + i];
+    for (int i = 0; i < 5; i++) cc[CON_SOLIMP + i] = MD(geom_solimp)[5 * g + i];
+    d_copy3(fri, MD(geom_friction) + 3 * g);
   } else {
-    int d1 = M.geom_condim[g1], d2 = M.geom_condim[g2];
+    int d1 = MI(geom_condim)[g1], d2 = MI(geom_condim)[g2];
     *dim = d1 > d2 ? d1 : d2;
-    double s1 = M.geom_solmix[g1], s2 = M.geom_solmix[g2], mix;
+    double s1 = MD(geom_solmix)[g1], s2 = MD(geom_solmix)[g2], mix;
     if (s1 >= D_MINVAL && s2 >= D_MINVAL) mix = s1 / (s1 + s2);
     else if (s1 < D_MINVAL && s2 < D_MINVAL) mix = 0.5;
     else if (s1 < D_MINVAL) mix = 0.0;
     else mix = 1.0;
-    double r10 = M.geom_solref[2 * g1], r20 = M.geom_solref[2 * g2];
+    double r10 = MD(geom_solref)[2 * g1], r20 = MD(geom_solref)[2 * g2];
     for (int i = 0; i < 2; i++) {
-      double a = M.geom_solref[2 * g1 + i], b = M.geom_solref[2 * g2 + i];
+      double a = MD(geom_solref)[2 * g1 + i], b = MD(geom_solref)[2 * g2 + i];
       cc[CON_SOLREF + i] = (r10 > 0 && r20 > 0) ? mix * a + (1 - mix) * b : fmin(a, b);
     }
-    for (int i = 0; i < 5; i++) cc[CON_SOLIMP + i] = mix * M.geom_solimp[5 * g1 + i] + (1 - mix) * M.geom_solimp[5 * g2 + i];
-    for (int i = 0; i < 3; i++) fri[i] = fmax(M.geom_friction[3 * g1 + i], M.geom_friction[3 * g2 + i]);
+    for (int i = 0; i < 5; i++) cc[CON_SOLIMP + i] = mix * MD(geom_solimp)[5 * g1 + i] + (1 - mix) * MD(geom_solimp)[5 * g2 + i];
+    for (int i = 0; i < 3; i++) fri[i] = fmax(MD(geom_friction)[3 * g1 + i], MD(geom_friction)[3 * g2 + i]);
   }
   cc[CON_FRICTION] = fri[0]; cc[CON_FRICTION + 1] = fri[0]; cc[CON_FRICTION + 2] = fri[1];
   cc[CON_FRICTION + 3] = fri[2]; cc[CON_FRICTION + 4] = fri[2];
@@ -543,13 +552,13 @@ DEV void collision(Ctx &c) {
   for (int base = 0; base < M.npair; base += NLANE) {
     int p = base + LANE, pass = 0;
     if (p < M.npair) {
-      int g1 = M.pair_g1[p], g2 = M.pair_g2[p];
-      double margin = fmax(M.geom_margin[g1], M.geom_margin[g2]);
-      double r1 = M.geom_rbound[g1], r2 = M.geom_rbound[g2];
+      int g1 = MI(pair_g1)[p], g2 = MI(pair_g2)[p];
+      double margin = fmax(MD(geom_margin)[g1], MD(geom_margin)[g2]);
+      double r1 = MD(geom_rbound)[g1], r2 = MD(geom_rbound)[g2];
       double dif[3];
       d_sub3(dif, c.geom_xpos + 3 * g2, c.geom_xpos + 3 * g1);
       pass = 1;
-      if (M.geom_type[g1] == 0) {
+      if (MI(geom_type)[g1] == 0) {
         const double *mat = c.geom_xmat + 9 * g1;
         double n[3] = {mat[2], mat[5], mat[8]};
         if (d_dot3(dif, n) > margin + r2) pass = 0;
@@ -571,9 +580,9 @@ DEV void collision(Ctx &c) {
     NPCon con[4];
     if (a < nactive) {
       int p = c.active[a];
-      g1 = M.pair_g1[p]; g2 = M.pair_g2[p];
-      margin = fmax(M.geom_margin[g1], M.geom_margin[g2]);
-      gap = fmax(M.geom_gap[g1], M.geom_gap[g2]);
+      g1 = MI(pair_g1)[p]; g2 = MI(pair_g2)[p];
+      margin = fmax(MD(geom_margin)[g1], MD(geom_margin)[g2]);
+      gap = fmax(MD(geom_gap)[g1], MD(geom_gap)[g2]);
       n = narrow_phase(c, g1, g2, margin, con);
     }
     int tot, off = wave_excl_scan(n, &tot);
@@ -582,7 +591,7 @@ DEV void collision(Ctx &c) {
       int ci = c.ncon + off + k;
       double *cc = c.contact + ci * c.M->con_stride;
       int dim;
-      contact_param(M, g1, g2, cc, &dim);
+      contact_param(c, g1, g2, cc, &dim);
       double fr[9];
       for (int q = 0; q < 6; q++) fr[q] = con[k].frame[q];
       d_makeframe(fr);
@@ -624,20 +633,20 @@ DEV void make_constraint(Ctx &c) {
   PFOR(e, 4 * nv) c.sgl[e] = 0;
   // friction-loss rows are static: rows [0, nfric)
   PFOR(r, M.nfric) {
-    int d = M.fric_dof[r];
+    int d = MI(fric_dof)[r];
     c.efc_type[r] = CNSTR_FRICTION_DOF; c.efc_id[r] = d; c.efc_dof[r] = d;
-    c.efc_floss[r] = M.dof_frictionloss[d]; c.efc_pos[r] = 0; c.efc_margin[r] = 0;
-    c.efc_diag[r] = M.dof_invweight0[d];
+    c.efc_floss[r] = MD(dof_frictionloss)[d]; c.efc_pos[r] = 0; c.efc_margin[r] = 0;
+    c.efc_diag[r] = MD(dof_invweight0)[d];
   }
   // joint limits: ordered compaction, lower side before upper side
   for (int base = 0; base < M.nlimit; base += NLANE) {
     int q = base + LANE, cnt = 0, j = 0;
     double dist[2] = {0, 0}; int side[2] = {0, 0};
     if (q < M.nlimit) {
-      j = M.limit_jnt[q];
-      double value = c.qpos[M.jnt_qposadr[j]], margin = M.jnt_margin[j];
+      j = MI(limit_jnt)[q];
+      double value = c.qpos[MI(jnt_qposadr)[j]], margin = MD(jnt_margin)[j];
       for (int s = -1; s <= 1; s += 2) {
-        double dd = s * (M.jnt_range[2 * j + (s + 1) / 2] - value);
+        double dd = s * (MD(jnt_range)[2 * j + (s + 1) / 2] - value);
         if (dd < margin) { dist[cnt] = dd; side[cnt] = s; cnt++; }
       }
     }
@@ -645,10 +654,10 @@ DEV void make_constraint(Ctx &c) {
     if (nefc + tot > M.nefcmax) { c.warning |= WARN_CNSTRFULL; break; }
     for (int k = 0; k < cnt; k++) {
       int r = nefc + off + k;
-      c.efc_type[r] = CNSTR_LIMIT_JOINT; c.efc_id[r] = j; c.efc_dof[r] = M.jnt_dofadr[j];
+      c.efc_type[r] = CNSTR_LIMIT_JOINT; c.efc_id[r] = j; c.efc_dof[r] = MI(jnt_dofadr)[j];
       c.efc_floss[r] = (double)(-side[k]);      // J entry, consumed below
-      c.efc_pos[r] = dist[k]; c.efc_margin[r] = M.jnt_margin[j];
-      c.efc_diag[r] = M.dof_invweight0[M.jnt_dofadr[j]];
+      c.efc_pos[r] = dist[k]; c.efc_margin[r] = MD(jnt_margin)[j];
+      c.efc_diag[r] = MD(dof_invweight0)[MI(jnt_dofadr)[j]];
     }
     nefc += tot;
   }
@@ -659,11 +668,11 @@ DEV void make_constraint(Ctx &c) {
   for (int base = 0; base < M.ntendon; base += NLANE) {
     int t = base + LANE, cnt = 0;
     double dist[2] = {0, 0}; int side[2] = {0, 0};
-    if (t < M.ntendon && M.tendon_limited[t]) {
-      double value = 0, margin = M.tendon_margin[t];
-      for (int w = M.tendon_adr[t]; w < M.tendon_adr[t] + M.tendon_num[t]; w++) value += M.wrap_prm[w] * c.qpos[M.wrap_qposadr[w]];
+    if (t < M.ntendon && MI(tendon_limited)[t]) {
+      double value = 0, margin = MD(tendon_margin)[t];
+      for (int w = MI(tendon_adr)[t]; w < MI(tendon_adr)[t] + MI(tendon_num)[t]; w++) value += MD(wrap_prm)[w] * c.qpos[MI(wrap_qposadr)[w]];
       for (int s = -1; s <= 1; s += 2) {
-        double dd = s * (M.tendon_range[2 * t + (s + 1) / 2] - value);
+        double dd = s * (MD(tendon_range)[2 * t + (s + 1) / 2] - value);
         if (dd < margin) { dist[cnt] = dd; side[cnt] = s; cnt++; }
       }
     }
@@ -673,8 +682,8 @@ DEV void make_constraint(Ctx &c) {
       int r = nefc + off + k;
       c.efc_type[r] = CNSTR_LIMIT_TENDON; c.efc_id[r] = t;
       c.efc_floss[r] = (double)(-side[k]);      // sign of the Jacobian, consumed below
-      c.efc_pos[r] = dist[k]; c.efc_margin[r] = M.tendon_margin[t];
-      c.efc_diag[r] = M.tendon_invweight0[t];
+      c.efc_pos[r] = dist[k]; c.efc_margin[r] = MD(tendon_margin)[t];
+      c.efc_diag[r] = MD(tendon_invweight0)[t];
     }
     nefc += tot;
   }
@@ -692,9 +701,9 @@ DEV void make_constraint(Ctx &c) {
       int r0 = nefc + off;
       c.con_i[ci * CONI_STRIDE + 3] = r0;
       int g1 = c.con_i[ci * CONI_STRIDE + 1], g2 = c.con_i[ci * CONI_STRIDE + 2];
-      int b1 = M.geom_bodyid[g1], b2 = M.geom_bodyid[g2];
-      double tran = M.body_invweight0[2 * b1] + M.body_invweight0[2 * b2];
-      double rot = M.body_invweight0[2 * b1 + 1] + M.body_invweight0[2 * b2 + 1];
+      int b1 = MI(geom_bodyid)[g1], b2 = MI(geom_bodyid)[g2];
+      double tran = MD(body_invweight0)[2 * b1] + MD(body_invweight0)[2 * b2];
+      double rot = MD(body_invweight0)[2 * b1 + 1] + MD(body_invweight0)[2 * b2 + 1];
       const double *cc = c.contact + ci * c.M->con_stride;
       int cdim = c.con_i[ci * CONI_STRIDE];
       int pyr = (cdim > 1 && M.cone != 1);
@@ -712,8 +721,8 @@ DEV void make_constraint(Ctx &c) {
   // cross-branch contacts (both bodies movable, neither dof chain contains the other) break M's sparsity pattern in H
   int crossflag = 0;
   PFOR(ci, c.ncon) {
-    unsigned long long m1 = M.body_dofmask[M.geom_bodyid[c.con_i[ci * CONI_STRIDE + 1]]];
-    unsigned long long m2 = M.body_dofmask[M.geom_bodyid[c.con_i[ci * CONI_STRIDE + 2]]];
+    unsigned long long m1 = MDM()[MI(geom_bodyid)[c.con_i[ci * CONI_STRIDE + 1]]];
+    unsigned long long m2 = MDM()[MI(geom_bodyid)[c.con_i[ci * CONI_STRIDE + 2]]];
     unsigned long long u = m1 | m2;
     if (u != m1 && u != m2) crossflag = 1;
   }
@@ -724,12 +733,12 @@ DEV void make_constraint(Ctx &c) {
   SYNC();
   PFOR(r, nlim_end) {
     if (r < M.nfric) c.efc_J[r * nvp + c.efc_id[r]] = 1;
-    else { c.efc_J[r * nvp + M.jnt_dofadr[c.efc_id[r]]] = c.efc_floss[r]; c.efc_floss[r] = 0; }
+    else { c.efc_J[r * nvp + MI(jnt_dofadr)[c.efc_id[r]]] = c.efc_floss[r]; c.efc_floss[r] = 0; }
   }
   PFOR(rr, ntl_end - ntl0) {
     int r = ntl0 + rr, t = c.efc_id[r];
     double sg = c.efc_floss[r];
-    for (int w = M.tendon_adr[t]; w < M.tendon_adr[t] + M.tendon_num[t]; w++) c.efc_J[r * nvp + M.wrap_dofadr[w]] = sg * M.wrap_prm[w];
+    for (int w = MI(tendon_adr)[t]; w < MI(tendon_adr)[t] + MI(tendon_num)[t]; w++) c.efc_J[r * nvp + MI(wrap_dofadr)[w]] = sg * MD(wrap_prm)[w];
     c.efc_floss[r] = 0;
   }
   PFOR(e, c.ncon * nv) {
@@ -737,23 +746,23 @@ DEV void make_constraint(Ctx &c) {
     const int *cin = c.con_i + ci * CONI_STRIDE;
     int dim = cin[0], r0 = cin[3];
     int pyr = (dim > 1 && M.cone != 1);
-    int b1 = M.geom_bodyid[cin[1]], b2 = M.geom_bodyid[cin[2]];
+    int b1 = MI(geom_bodyid)[cin[1]], b2 = MI(geom_bodyid)[cin[2]];
     unsigned long long bit = 1ull << d;
-    int in1 = (M.body_dofmask[b1] & bit) != 0, in2 = (M.body_dofmask[b2] & bit) != 0;
+    int in1 = (MDM()[b1] & bit) != 0, in2 = (MDM()[b2] & bit) != 0;
     if (!in1 && !in2) continue;
     const double *cc = c.contact + ci * c.M->con_stride;
     const double *cd = c.cdof + 6 * d;
     double jp[3] = {0, 0, 0}, jr[3] = {0, 0, 0};
     if (in2) {
       double off[3], t[3];
-      d_sub3(off, cc + CON_POS, c.subtree_com + 3 * M.body_rootid[b2]);
+      d_sub3(off, cc + CON_POS, c.subtree_com + 3 * MI(body_rootid)[b2]);
       d_cross(t, cd, off);
       jp[0] += cd[3] + t[0]; jp[1] += cd[4] + t[1]; jp[2] += cd[5] + t[2];
       jr[0] += cd[0]; jr[1] += cd[1]; jr[2] += cd[2];
     }
     if (in1) {
       double off[3], t[3];
-      d_sub3(off, cc + CON_POS, c.subtree_com + 3 * M.body_rootid[b1]);
+      d_sub3(off, cc + CON_POS, c.subtree_com + 3 * MI(body_rootid)[b1]);
       d_cross(t, cd, off);
       jp[0] -= cd[3] + t[0]; jp[1] -= cd[4] + t[1]; jp[2] -= cd[5] + t[2];
       jr[0] -= cd[0]; jr[1] -= cd[1]; jr[2] -= cd[2];
@@ -789,14 +798,14 @@ DEV void make_impedance(Ctx &c) {
     double solref[2], solimp[5];
     int first = 1;
     if (type == CNSTR_FRICTION_DOF) {
-      for (int k = 0; k < 2; k++) solref[k] = M.dof_solref[2 * id + k];
-      for (int k = 0; k < 5; k++) solimp[k] = M.dof_solimp[5 * id + k];
+      for (int k = 0; k < 2; k++) solref[k] = MD(dof_solref)[2 * id + k];
+      for (int k = 0; k < 5; k++) solimp[k] = MD(dof_solimp)[5 * id + k];
     } else if (type == CNSTR_LIMIT_JOINT) {
-      for (int k = 0; k < 2; k++) solref[k] = M.jnt_solref[2 * id + k];
-      for (int k = 0; k < 5; k++) solimp[k] = M.jnt_solimp[5 * id + k];
+      for (int k = 0; k < 2; k++) solref[k] = MD(jnt_solref)[2 * id + k];
+      for (int k = 0; k < 5; k++) solimp[k] = MD(jnt_solimp)[5 * id + k];
     } else if (type == CNSTR_LIMIT_TENDON) {
-      for (int k = 0; k < 2; k++) solref[k] = M.tendon_solref_lim[2 * id + k];
-      for (int k = 0; k < 5; k++) solimp[k] = M.tendon_solimp_lim[5 * id + k];
+      for (int k = 0; k < 2; k++) solref[k] = MD(tendon_solref_lim)[2 * id + k];
+      for (int k = 0; k < 5; k++) solimp[k] = MD(tendon_solimp_lim)[5 * id + k];
     } else {
       const double *cc = c.contact + id * c.M->con_stride;
       for (int k = 0; k < 2; k++) solref[k] = cc[CON_SOLREF + k];
@@ -847,10 +856,10 @@ DEV void make_impedance(Ctx &c) {
 DEV void vel_body(Ctx &c, int i) {
   const DevModel &M = *c.M;
   double cvel[6];
-  for (int k = 0; k < 6; k++) cvel[k] = c.cvel[6 * M.body_parentid[i] + k];
-  int bda = M.body_dofadr[i];
-  for (int j = M.body_jntadr[i]; j < M.body_jntadr[i] + M.body_jntnum[i]; j++) {
-    int type = M.jnt_type[j];
+  for (int k = 0; k < 6; k++) cvel[k] = c.cvel[6 * MI(body_parentid)[i] + k];
+  int bda = MI(body_dofadr)[i];
+  for (int j = MI(body_jntadr)[i]; j < MI(body_jntadr)[i] + MI(body_jntnum)[i]; j++) {
+    int type = MI(jnt_type)[j];
     if (type == 0) {
       for (int k = 0; k < 18; k++) c.cdof_dot[6 * bda + k] = 0;
       for (int k = 0; k < 3; k++) for (int q = 0; q < 6; q++) cvel[q] += c.cdof[6 * (bda + k) + q] * c.qvel[bda + k];
@@ -875,9 +884,9 @@ DEV void vel_body(Ctx &c, int i) {
   for (int k = 0; k < 6; k++) c.cvel[6 * i + k] = cvel[k];
   // RNE forward part: cacc, cfrc_body
   double a[6];
-  for (int k = 0; k < 6; k++) a[k] = c.cacc[6 * M.body_parentid[i] + k];
-  bda = M.body_dofadr[i];
-  for (int k = 0; k < M.body_dofnum[i]; k++)
+  for (int k = 0; k < 6; k++) a[k] = c.cacc[6 * MI(body_parentid)[i] + k];
+  bda = MI(body_dofadr)[i];
+  for (int k = 0; k < MI(body_dofnum)[i]; k++)
     for (int q = 0; q < 6; q++) a[q] += c.cdof_dot[6 * (bda + k) + q] * c.qvel[bda + k];
   for (int k = 0; k < 6; k++) c.cacc[6 * i + k] = a[k];
   double t1[6], t2[6], t3[6];
@@ -887,10 +896,10 @@ DEV void vel_body(Ctx &c, int i) {
   for (int k = 0; k < 6; k++) c.cfrc[6 * i + k] = t1[k] + t3[k];
   // body momentum for subtree_linvel
   double off[3], v[3];
-  d_sub3(off, c.xipos + 3 * i, c.subtree_com + 3 * M.body_rootid[i]);
+  d_sub3(off, c.xipos + 3 * i, c.subtree_com + 3 * MI(body_rootid)[i]);
   d_cross(v, cvel, off);
   d_add3(v, v, cvel + 3);
-  d_scl3(c.bodytmp + 3 * i, v, M.body_mass[i]);
+  d_scl3(c.bodytmp + 3 * i, v, MD(body_mass)[i]);
 }
 
 template <int NVT>
@@ -898,51 +907,51 @@ DEV void velocity_stage(Ctx &c) {
   const DevModel &M = *c.M;
   int nv = M.nv;
   for (int l = 0; l < M.nlevel; l++) {
-    int a = M.level_adr[l], n = M.level_adr[l + 1] - a;
-    PFOR(k, n) vel_body(c, M.level_body[a + k]);
+    int a = MI(level_adr)[l], n = MI(level_adr)[l + 1] - a;
+    PFOR(k, n) vel_body(c, MI(level_body)[a + k]);
     SYNC();
   }
   PFOR(e, M.nbody * 9) {
     int b = e / 9, k = e - 9 * b;
     if (k < 6) {
       double s = 0;
-      if (b > 0) for (int q = M.subtree_adr[b]; q < M.subtree_adr[b + 1]; q++) s += c.cfrc[6 * M.subtree_list[q] + k];
+      if (b > 0) for (int q = MI(subtree_adr)[b]; q < MI(subtree_adr)[b + 1]; q++) s += c.cfrc[6 * MI(subtree_list)[q] + k];
       c.cfrc_sub[6 * b + k] = s;
     } else {
       int kk = k - 6;
       double s = 0;
-      for (int q = M.subtree_adr[b]; q < M.subtree_adr[b + 1]; q++) s += c.bodytmp[3 * M.subtree_list[q] + kk];
-      c.subtree_linvel[3 * b + kk] = s / fmax(D_MINVAL, M.body_subtreemass[b]);
+      for (int q = MI(subtree_adr)[b]; q < MI(subtree_adr)[b + 1]; q++) s += c.bodytmp[3 * MI(subtree_list)[q] + kk];
+      c.subtree_linvel[3 * b + kk] = s / fmax(D_MINVAL, MD(body_subtreemass)[b]);
     }
   }
   // actuator forces
   PFOR(i, M.nu) {
     double ctrl = c.ctrl[i];
-    if (M.actuator_ctrllimited[i]) ctrl = d_clip(ctrl, M.actuator_ctrlrange[2 * i], M.actuator_ctrlrange[2 * i + 1]);
-    double gear = M.actuator_gear[i];
-    double force = M.actuator_gainprm[3 * i] * ctrl;
-    if (M.actuator_biastype[i] == 1)
-      force += M.actuator_biasprm[3 * i] + M.actuator_biasprm[3 * i + 1] * (gear * c.qpos[M.actuator_qposadr[i]]) +
-               M.actuator_biasprm[3 * i + 2] * (gear * c.qvel[M.actuator_dofadr[i]]);
-    if (M.actuator_forcelimited[i]) force = d_clip(force, M.actuator_forcerange[2 * i], M.actuator_forcerange[2 * i + 1]);
+    if (MI(actuator_ctrllimited)[i]) ctrl = d_clip(ctrl, MD(actuator_ctrlrange)[2 * i], MD(actuator_ctrlrange)[2 * i + 1]);
+    double gear = MD(actuator_gear)[i];
+    double force = MD(actuator_gainprm)[3 * i] * ctrl;
+    if (MI(actuator_biastype)[i] == 1)
+      force += MD(actuator_biasprm)[3 * i] + MD(actuator_biasprm)[3 * i + 1] * (gear * c.qpos[MI(actuator_qposadr)[i]]) +
+               MD(actuator_biasprm)[3 * i + 2] * (gear * c.qvel[MI(actuator_dofadr)[i]]);
+    if (MI(actuator_forcelimited)[i]) force = d_clip(force, MD(actuator_forcerange)[2 * i], MD(actuator_forcerange)[2 * i + 1]);
     c.actuator_force[i] = force;
   }
   SYNC();
   PFOR(d, nv) {
-    const double *cd = c.cdof + 6 * d, *cf = c.cfrc_sub + 6 * M.dof_bodyid[d];
+    const double *cd = c.cdof + 6 * d, *cf = c.cfrc_sub + 6 * MI(dof_bodyid)[d];
     double bias = cd[0]*cf[0] + cd[1]*cf[1] + cd[2]*cf[2] + cd[3]*cf[3] + cd[4]*cf[4] + cd[5]*cf[5];
     c.qfrc_bias[d] = bias;
     double act = 0;
-    for (int i = 0; i < M.nu; i++) if (M.actuator_dofadr[i] == d) act += M.actuator_gear[i] * c.actuator_force[i];
-    c.qfrc_smooth[d] = act - bias - M.dof_damping[d] * c.qvel[d];   // joint springs are added below
+    for (int i = 0; i < M.nu; i++) if (MI(actuator_dofadr)[i] == d) act += MD(actuator_gear)[i] * c.actuator_force[i];
+    c.qfrc_smooth[d] = act - bias - MD(dof_damping)[d] * c.qvel[d];   // joint springs are added below
   }
   SYNC();
   PFOR(j, M.njnt) {
-    double k = M.jnt_stiffness[j];
-    int type = M.jnt_type[j];
+    double k = MD(jnt_stiffness)[j];
+    int type = MI(jnt_type)[j];
     if (k != 0 && (type == 2 || type == 3)) {
-      int qa = M.jnt_qposadr[j];
-      c.qfrc_smooth[M.jnt_dofadr[j]] -= k * (c.qpos[qa] - M.qpos_spring[qa]);
+      int qa = MI(jnt_qposadr)[j];
+      c.qfrc_smooth[MI(jnt_dofadr)[j]] -= k * (c.qpos[qa] - MD(qpos_spring)[qa]);
     }
   }
   SYNC();
@@ -1007,11 +1016,11 @@ DEV double ray_ground(Ctx &c, const double *pos) {
   double down[3] = {0, 0, -1}, query[3] = {pos[0], pos[1], pos[2] + 0.5};
   double dist = -1;
   for (int r = 0; r < M.nray; r++) {
-    int g = M.ray_geom[r];
+    int g = MI(ray_geom)[r];
     double gp[3], gm[9], gs[3];
-    d_copy3(gp, c.geom_xpos + 3 * g); d_copy3(gs, M.geom_size + 3 * g);
+    d_copy3(gp, c.geom_xpos + 3 * g); d_copy3(gs, MD(geom_size) + 3 * g);
     for (int k = 0; k < 9; k++) gm[k] = c.geom_xmat[9 * g + k];
-    double x = ray_geom(gp, gm, gs, query, down, M.geom_type[g]);
+    double x = ray_geom(gp, gm, gs, query, down, MI(geom_type)[g]);
     if (x >= 0 && (dist < 0 || x < dist)) dist = x;
   }
   return pos[2] + 0.5 - dist;
@@ -1063,8 +1072,8 @@ DEV void q_flip_quat(const double *D, const double *P, const int *I, double *qua
 // mjpc/tasks/quadruped/quadruped.cc:33-221
 DEV void residual_quadruped(Ctx &c, double *residual) {
   const DevModel &M = *c.M;
-  const int *I = M.task.int_data;
-  const double *D = M.task.dbl_data, *P = M.task.parameters;
+  const int *I = MI(task.int_data);
+  const double *D = MD(task.dbl_data), *P = MD(task.parameters);
   int mode = I[QI_MODE], torso = I[QI_TORSO], nu = M.nu;
   int is_biped = mode == 1;
   double height_goal = is_biped ? 0.6 : 0.25;
@@ -1185,10 +1194,10 @@ DEV void residual_quadruped(Ctx &c, double *residual) {
 // mjpc/tasks/humanoid/tracking/tracking.cc:94-216 (int_data: motion, first key, length, 16 site ids, 16 mocap ids)
 DEV void residual_humanoid_track(Ctx &c, double *residual) {
   const DevModel &M = *c.M;
-  const int *I = M.task.int_data;
+  const int *I = MI(task.int_data);
   const double kFps = 30.0;
   int start = I[1], length = I[2], nv = M.nv, nu = M.nu;
-  double current_index = (c.time - M.task.dbl_data[0]) * kFps + start;
+  double current_index = (c.time - MD(task.dbl_data)[0]) * kFps + start;
   int last_key_index = start + length - 1;
   double ci = current_index < 0 ? 0 : (current_index > last_key_index ? (double)last_key_index : current_index);
   int k0 = (int)floor(ci), k1 = k0 + 1 < last_key_index ? k0 + 1 : last_key_index;
@@ -1204,10 +1213,10 @@ DEV void residual_humanoid_track(Ctx &c, double *residual) {
     d_scl3(mp, p0, w0); d_addtoscl3(mp, p1, w1);
     d_copy3(c.bodytmp + 3 * b, mp);
     // velocity residual: finite-difference marker velocity minus framelinvel of the tracking site
-    int sid = I[3 + b], body = M.site_bodyid[sid];
+    int sid = I[3 + b], body = MI(site_bodyid)[sid];
     double v[3], off[3], lin[3];
     d_sub3(v, p1, p0); d_scl3(v, v, kFps);
-    d_sub3(off, c.site_xpos + 3 * sid, c.subtree_com + 3 * M.body_rootid[body]);
+    d_sub3(off, c.site_xpos + 3 * sid, c.subtree_com + 3 * MI(body_rootid)[body]);
     d_cross(lin, c.cvel + 6 * body, off);
     d_add3(lin, lin, c.cvel + 6 * body + 3);
     d_sub3(residual + o + 3 + 48 + 3 * b, v, lin);
@@ -1234,7 +1243,7 @@ DEV void task_residual(Ctx &c, double *residual) {
   } else if (id == 1) {   // cartpole.cc:36-49
     if (LANE == 0) {
       residual[0] = cos(c.qpos[1]) - 1;
-      residual[1] = c.qpos[0] - M.task.parameters[0];
+      residual[1] = c.qpos[0] - MD(task.parameters)[0];
       residual[2] = c.qvel[1];
       residual[3] = c.ctrl[0];
     }
@@ -1273,10 +1282,10 @@ DEV double cost_value(Ctx &c, const double *residual) {
   const DevTask &T = c.M->task;
   PFOR(k, T.num_term) {
     int fs = 0, ps = 0;
-    for (int j = 0; j < k; j++) { fs += T.dim_norm_residual[j]; ps += T.num_norm_parameter[j]; }
+    for (int j = 0; j < k; j++) { fs += MI(task.dim_norm_residual)[j]; ps += MI(task.num_norm_parameter)[j]; }
     double prm[2] = {0, 0};
-    for (int j = 0; j < T.num_norm_parameter[k] && j < 2; j++) prm[j] = T.norm_parameter[ps + j];
-    c.terms[k] = T.weight[k] * norm_value(residual + fs, prm, T.dim_norm_residual[k], T.norm[k]);
+    for (int j = 0; j < MI(task.num_norm_parameter)[k] && j < 2; j++) prm[j] = MD(task.norm_parameter)[ps + j];
+    c.terms[k] = MD(task.weight)[k] * norm_value(residual + fs, prm, MI(task.dim_norm_residual)[k], MI(task.norm)[k]);
   }
   SYNC();
   double cost = 0;
@@ -1311,7 +1320,14 @@ DEV_NOINLINE void ph_init(KP Kc) {
   Ctx c;
   const KParams *K = kp_generic(Kc);
   ctx_init(c, K, lds_base());
-  const DevModel &M = K->M;
+  // the workgroup's LDS copy of the model tables (everything below reads them through c.M)
+  {
+    double *mcd = lds_base() + K->L.mc_d; int *mci = (int *)(lds_base() + K->L.mc_i);
+    PFOR(e, K->cache_d) mcd[e] = K->dbase[e];
+    PFOR(e, K->cache_i) mci[e] = K->ibase[e];
+    SYNC();
+  }
+  const DevModel &M = *c.M;
   Rows R = out_rows(K);
   int nq = M.nq, nv = M.nv, nu = M.nu, P = K->P, r = cand_index();
   int gi = K->offset + r;
@@ -1321,7 +1337,7 @@ DEV_NOINLINE void ph_init(KP Kc) {
   PFOR(e, P * nu) {
     int k = e % nu;
     double v = K->knot_values[e];
-    double lo = M.actuator_ctrlrange[2 * k], hi = M.actuator_ctrlrange[2 * k + 1];
+    double lo = MD(actuator_ctrlrange)[2 * k], hi = MD(actuator_ctrlrange)[2 * k + 1];
     if (gi != 0) {
       double scale = 0.5 * (hi - lo);
       v = add_mul3_rn(v, scale, std, K->noise_eps[(size_t)r * P * nu + e]);   // bit-exact candidate policy
@@ -1336,7 +1352,8 @@ DEV_NOINLINE void ph_init(KP Kc) {
   }
   PFOR(i, nq) { c.qpos[i] = K->state[i]; R.states[i] = K->state[i]; }
   PFOR(i, nv) { c.qvel[i] = K->state[nq + i]; R.states[nq + i] = K->state[nq + i]; c.qacc_ws[i] = 0; }
-  PFOR(e, nv * M.nvp) c.qM[e] = 0;
+  PFOR(e, nv * M.nvp) { c.qM[e] = 0; c.qH[e] = 0; }
+  PFOR(e, M.nmpair + nv) c.hpair[e] = MI(mpair_i)[e] | (MI(mpair_j)[e] << 8);
   PFOR(k, nu) c.ctrl[k] = 0;      // data->ctrl after Reset (planner.cc:124-130); only visible when H == 1
   if (LANE == 0) {
     R.times[0] = K->time;
@@ -1363,7 +1380,7 @@ DEV_NOINLINE int ph_action(KP Kc, int t) {
   int nu = M.nu;
   PFOR(k, nu) {
     double a = spline_sample(c.knot_times, c.knot_values, K->P, nu, K->interp, c.time, k);
-    a = d_clip(a, M.actuator_ctrlrange[2 * k], M.actuator_ctrlrange[2 * k + 1]);
+    a = d_clip(a, MD(actuator_ctrlrange)[2 * k], MD(actuator_ctrlrange)[2 * k + 1]);
     c.ctrl[k] = a; R.actions[t * nu + k] = a;
   }
   SYNC();
@@ -1411,7 +1428,7 @@ DEV_NOINLINE CostOut ph_residual_cost(KP Kc, int t, int last) {
   task_residual(c, c.residual); PROF(c, 9);
   PFOR(i, R.nr) R.residual[t * R.nr + i] = c.residual[i];
   PFOR(i, T.num_trace) {
-    int id = T.trace_objid[i], ty = T.trace_objtype[i];
+    int id = MI(task.trace_objid)[i], ty = MI(task.trace_objtype)[i];
     const double *src = ty == 6 ? c.site_xpos + 3 * id : (ty == 5 ? c.geom_xpos + 3 * id : (ty == 1 ? c.xipos + 3 * id : c.xpos + 3 * id));
     d_copy3(R.trace + t * R.ntr + 3 * i, src);
   }
@@ -1436,7 +1453,7 @@ DEV_NOINLINE void ph_integrate(KP Kc, int t) {
   double h = M.timestep;
   PFOR(i, nv) c.qacc_ws[i] = c.qacc[i];
   if (M.any_damping) {
-    PFOR(e, nv * nvp) { int i = e / nvp, j = e - i * nvp; c.qH[e] = c.qM[e] + ((i == j) ? h * M.dof_damping[i] : 0.0); }
+    PFOR(e, nv * nvp) { int i = e / nvp, j = e - i * nvp; c.qH[e] = c.qM[e] + ((i == j) ? h * MD(dof_damping)[i] : 0.0); }
     PFOR(i, nv) c.Mgrad[i] = c.qfrc_smooth[i] + c.qfrc_constraint[i];
     chol_factor_solve<NVT>(c.qH, c.Hinv, c.vtmp, c.Mgrad, nv, nvp);
     PFOR(i, nv) c.qvel[i] += h * c.Mgrad[i];
@@ -1445,7 +1462,7 @@ DEV_NOINLINE void ph_integrate(KP Kc, int t) {
   }
   SYNC();
   PFOR(j, M.njnt) {
-    int qa = M.jnt_qposadr[j], da = M.jnt_dofadr[j], type = M.jnt_type[j];
+    int qa = MI(jnt_qposadr)[j], da = MI(jnt_dofadr)[j], type = MI(jnt_type)[j];
     if (type == 0) {
       for (int k = 0; k < 3; k++) c.qpos[qa + k] += h * c.qvel[da + k];
       d_quatintegrate(c.qpos + qa + 3, c.qvel + da + 3, h);

@@ -19,6 +19,18 @@ DEV double fast_rsqrt(double x) {
   return y;
 #endif
 }
+// 1/x without the IEEE divide sequence (v_rcp_f64 + two Newton steps: ~1 ulp)
+DEV double fast_rcp(double x) {
+#ifdef MJPC_EMU
+  return 1.0 / x;
+#else
+  double y = __builtin_amdgcn_rcp(x);
+  double e = __builtin_fma(-x, y, 1.0);
+  y = __builtin_fma(y, e, y);
+  e = __builtin_fma(-x, y, 1.0);
+  return __builtin_fma(y, e, y);
+#endif
+}
 DEV double d_dot3(const double *a, const double *b) { return a[0]*b[0] + a[1]*b[1] + a[2]*b[2]; }
 DEV double d_norm3(const double *a) { return sqrt(a[0]*a[0] + a[1]*a[1] + a[2]*a[2]); }
 DEV void d_copy3(double *r, const double *a) { r[0]=a[0]; r[1]=a[1]; r[2]=a[2]; }

@@ -121,6 +121,7 @@ static int upload_model(MjpcHipEngine *e) {
   HIPCHK(hipMemcpy(e->d_db, e->pm.db.data(), e->pm.db.size() * sizeof(double), hipMemcpyHostToDevice));
   e->K.M = mjpc_host::relocate(e->pm, e->d_ib, e->d_db);
   e->K.L = e->pm.L;
+  e->K.ibase = e->d_ib; e->K.dbase = e->d_db; e->K.cache_i = (int)e->pm.cache_i; e->K.cache_d = (int)e->pm.cache_d;
   return 0;
 }
 

@@ -16,6 +16,7 @@ struct PackedModel {
   DevModel M;          // pointer fields hold OFFSETS (as intptr) until relocate()
   Lay L;
   size_t task_i0, task_d0, task_i_cap, task_d_cap;   // task region inside ib/db
+  size_t cache_i, cache_d;                           // prefix of ib/db copied into LDS by every workgroup
   std::string error;
 };
 
@@ -63,11 +64,13 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
   if (m->na != 0) { p.error = "activation states (na > 0) not supported"; return false; }
   if (m->nefcmax > 192) { p.error = "nefcmax > 192 not supported (line-search rows per lane)"; return false; }
   M.nq = m->nq; M.nv = nv; M.nu = nu; M.nbody = nb; M.njnt = nj; M.ngeom = ng; M.nsite = ns; M.nmocap = m->nmocap;
-  M.nkey = m->nkey; M.nvp = nv | 1; M.ntendon = m->ntendon;
+  M.nkey = m->nkey; M.nvp = NVP_OF(nv); M.ntendon = m->ntendon;
   M.cone = m->cone; M.iterations = m->iterations; M.ls_iterations = m->ls_iterations; M.disableflags = m->disableflags;
   M.timestep = m->timestep; for (int k = 0; k < 3; k++) M.gravity[k] = m->gravity[k];
   M.impratio = m->impratio; M.tolerance = m->tolerance; M.ls_tolerance = m->ls_tolerance; M.meaninertia = m->meaninertia;
   M.con_stride = (m->cone == MJPC_CONE_ELLIPTIC) ? CON_STRIDE_ELLIPTIC : CON_STRIDE_PLAIN;
+  M.maxdim = 1;
+  for (int g = 0; g < ng; g++) if (m->geom_condim[g] > M.maxdim) M.maxdim = m->geom_condim[g];
   M.nconmax = m->nconmax > 0 ? m->nconmax : 32;
   if (M.nconmax > 64) M.nconmax = 64;
   M.nefcmax = m->nefcmax > 0 ? m->nefcmax : 128;
@@ -90,7 +93,6 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
   PI_(actuator_ctrllimited, nu); PI_(actuator_forcelimited, nu); PI_(actuator_biastype, nu);
   PD_(actuator_gainprm, 3 * nu); PD_(actuator_biasprm, 3 * nu); PD_(actuator_gear, nu);
   PD_(actuator_ctrlrange, 2 * nu); PD_(actuator_forcerange, 2 * nu);
-  PD_(key_qpos, (size_t)m->nkey * m->nq); PD_(key_mpos, (size_t)m->nkey * 3 * m->nmocap);
   PI_(tendon_adr, m->ntendon); PI_(tendon_num, m->ntendon); PI_(tendon_limited, m->ntendon);
   PD_(wrap_prm, m->nwrap); PD_(tendon_range, 2 * m->ntendon); PD_(tendon_margin, m->ntendon);
   PD_(tendon_solref_lim, 2 * m->ntendon); PD_(tendon_solimp_lim, 5 * m->ntendon); PD_(tendon_invweight0, m->ntendon);
@@ -123,6 +125,7 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
   { std::vector<int> pi, pj;
     for (int i = 0; i < nv; i++) for (int j = i; j >= 0; j = m->dof_parentid[j]) { pi.push_back(i); pj.push_back(j); }
     M.nmpair = (int)pi.size();
+    for (int i = 0; i < nv; i++) { pi.push_back(i); pj.push_back(nv); }      // + the gradient entries (column nv of the scaled rows)
     M.mpair_i = as_off<int>(put_i(p, pi.data(), pi.size())); M.mpair_j = as_off<int>(put_i(p, pj.data(), pj.size()));
     // the structurally-zero part of the lower triangle (dof pairs on different branches)
     std::vector<int> zi, zj;
@@ -172,10 +175,14 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
   M.any_damping = 0;
   for (int i = 0; i < nv; i++) if (m->dof_damping[i] > 0) M.any_damping = 1;
   if (M.nefcmax < M.nfric + 2) M.nefcmax = M.nfric + 2;
-  // task region last (re-packable by set_task)
+  // task region (re-packable by set_task)
   p.task_i0 = p.ib.size(); p.task_d0 = p.db.size();
   pack_task(p, t);
   p.task_i_cap = p.ib.size() - p.task_i0; p.task_d_cap = p.db.size() - p.task_d0;
+  // everything so far is LDS-cached; the keyframe tables (large, touched by a few residual terms only) stay in HBM
+  p.cache_i = p.ib.size(); p.cache_d = p.db.size();
+  M.key_qpos = as_off<double>(put_d(p, m->key_qpos, (size_t)m->nkey * m->nq));
+  M.key_mpos = as_off<double>(put_d(p, m->key_mpos, (size_t)m->nkey * 3 * m->nmocap));
   // ---- LDS layout
   Lay &L = p.L;
   int o = 0;
@@ -188,16 +195,19 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
   A_(subtree_com, 3 * nb); A_(cinert, 10 * nb); A_(crb, 10 * nb); A_(cdof, 6 * nv + 18); A_(cvel, 6 * nb); A_(cdof_dot, 6 * nv + 18);
   A_(cacc, 6 * nb); A_(cfrc, 6 * nb); A_(cfrc_sub, 6 * nb); A_(subtree_linvel, 3 * nb); A_(bodytmp, 3 * nb);
   A_(qM, nv * nvp + 1); A_(qL, nv * nvp + 1); A_(qH, nv * nvp + 1); A_(Linv, nv + 1); A_(Hinv, nv + 1);
-  A_(efc_J, ne * nvp + 1); A_(efc_WJ, (ne - M.nfric) * nvp + 1); A_(efc_JA, (ne - M.nfric) * nvp + 1); A_(efc_D, ne); A_(efc_R, ne); A_(efc_aref, ne); A_(efc_force, ne); A_(efc_jar, ne); A_(efc_jv, ne);
+  // efc_JA holds the scaled rows of the Newton Hessian: active contact rows + one negative row per cone contact + padding
+  A_(efc_J, ne * nvp + 1); A_(efc_JA, (ne - M.nfric + (m->cone == MJPC_CONE_ELLIPTIC ? nc : 0) + 12) * nvp + 1); A_(efc_D, ne); A_(efc_R, ne); A_(efc_aref, ne); A_(efc_force, ne); A_(efc_jar, ne); A_(efc_jv, ne);
   A_(efc_floss, ne); A_(efc_pos, ne); A_(efc_margin, ne); A_(efc_diag, ne);
   A_(contact, nc * M.con_stride + 1);
   A_(Ma, nv + 1); A_(grad, nv + 1); A_(Mgrad, nv + 1); A_(search, nv + 1); A_(Mv, nv + 1); A_(vtmp, nv + 1); A_(sgl, 4 * nv + 1);
   A_(knot_times, P_max); A_(knot_values, P_max * nu + 1); A_(residual, nr + 1); A_(terms, t->num_term + 1); A_(red, 8); A_(prof, 26);
+  A_(mc_d, p.cache_d + 1); A_(mc_i, (p.cache_i + 2) / 2);
   L.ints = o;
 #undef A_
   int io = 0;
   L.i_efc_type = io; io += ne; L.i_efc_id = io; io += ne; L.i_efc_state = io; io += ne; L.i_efc_dof = io; io += ne;
-  L.i_con = io; io += nc * CONI_STRIDE; L.i_active = io; io += MAX_ACTIVE_PAIRS; L.i_misc = io; io += 16;
+  L.i_con = io; io += nc * CONI_STRIDE; L.i_active = io; io += (ne + nc > MAX_ACTIVE_PAIRS ? ne + nc : MAX_ACTIVE_PAIRS); L.i_misc = io; io += 16;
+  L.i_hpair = io; io += M.nmpair + nv;      // LDS copy of the Hessian/gradient entry table (i | j << 8)
   L.total_doubles = o + (io + 1) / 2;
   return true;
 }
@@ -233,13 +243,15 @@ static inline DevModel relocate(const PackedModel &p, const int *ibase, const do
 
 // re-pack the task into the reserved region (sizes must not exceed the initial ones)
 static inline bool repack_task(PackedModel &p, const MjpcHipTask *t) {
-  std::vector<int> ib_save(p.ib.begin(), p.ib.begin() + p.task_i0);
-  std::vector<double> db_save(p.db.begin(), p.db.begin() + p.task_d0);
+  std::vector<int> ib_tail(p.ib.begin() + p.task_i0 + p.task_i_cap, p.ib.end());       // keyframe tables behind the task region
+  std::vector<double> db_tail(p.db.begin() + p.task_d0 + p.task_d_cap, p.db.end());
   p.ib.resize(p.task_i0); p.db.resize(p.task_d0);
   pack_task(p, t);
-  if (p.ib.size() - p.task_i0 > p.task_i_cap || p.db.size() - p.task_d0 > p.task_d_cap) { p.error = "task grew beyond the size given at create()"; return false; }
+  bool ok = !(p.ib.size() - p.task_i0 > p.task_i_cap || p.db.size() - p.task_d0 > p.task_d_cap);
+  if (!ok) p.error = "task grew beyond the size given at create()";
   p.ib.resize(p.task_i0 + p.task_i_cap, 0); p.db.resize(p.task_d0 + p.task_d_cap, 0.0);
-  return true;
+  p.ib.insert(p.ib.end(), ib_tail.begin(), ib_tail.end()); p.db.insert(p.db.end(), db_tail.begin(), db_tail.end());
+  return ok;
 }
 
 }  // namespace mjpc_host

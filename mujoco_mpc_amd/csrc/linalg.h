@@ -8,6 +8,7 @@
 // A single wave per candidate is latency-bound, so the register form is ~8x faster than the LDS form.
 #pragma once
 #include "dmath.h"
+#include "model.h"
 
 struct Ctx;
 
@@ -69,13 +70,6 @@ DEV void chol_solve_lds(const double *L, const double *Linv, double *x, int n, i
 // Afterwards lane i holds  up[k] = L[k][i] (k > i, else 0)  and  lo[j] = L[i][j] (j < i, else 0),
 // so both substitutions are "readlane + one FMA" per step.
 #ifndef MJPC_EMU
-DEV double fast_rcp(double x) {
-  double y = __builtin_amdgcn_rcp(x);
-  double e = __builtin_fma(-x, y, 1.0);
-  y = __builtin_fma(y, e, y);
-  e = __builtin_fma(-x, y, 1.0);
-  return __builtin_fma(y, e, y);
-}
 template <int N>
 struct LDLRegs { double lo[N], up[N], rinv; };
 
@@ -159,14 +153,14 @@ DEV void chol_factor_solve_reg(const double *A, double *x, int nvp) {
 template <int NVT>
 DEV void chol_factor(double *A, double *Linv, double *tmp, int n, int nvp) {
 #ifndef MJPC_EMU
-  if constexpr (NVT > 0) { chol_factor_reg<NVT>(A, Linv, NVT | 1); return; }
+  if constexpr (NVT > 0) { chol_factor_reg<NVT>(A, Linv, NVP_OF(NVT)); return; }
 #endif
   chol_factor_lds(A, Linv, tmp, n, nvp);
 }
 template <int NVT>
 DEV void chol_solve(const double *L, const double *Linv, double *x, int n, int nvp) {
 #ifndef MJPC_EMU
-  if constexpr (NVT > 0) { chol_solve_reg<NVT>(L, Linv, x, NVT | 1); return; }
+  if constexpr (NVT > 0) { chol_solve_reg<NVT>(L, Linv, x, NVP_OF(NVT)); return; }
 #endif
   chol_solve_lds(L, Linv, x, n, nvp);
 }
@@ -174,7 +168,7 @@ DEV void chol_solve(const double *L, const double *Linv, double *x, int n, int n
 template <int NVT>
 DEV void chol_factor_solve(double *A, double *Linv, double *tmp, double *x, int n, int nvp) {
 #ifndef MJPC_EMU
-  if constexpr (NVT > 0) { chol_factor_solve_reg<NVT>(A, x, NVT | 1); return; }
+  if constexpr (NVT > 0) { chol_factor_solve_reg<NVT>(A, x, NVP_OF(NVT)); return; }
 #endif
   chol_factor_lds(A, Linv, tmp, n, nvp);
   chol_solve_lds(A, Linv, x, n, nvp);

@@ -1,14 +1,16 @@
 // model.h — device-side model / task description, LDS layout and kernel parameter block.
 //
 // HBM layout: the model is two flat device buffers (one int32, one fp64) plus this struct of
-// pointers into them; it is read-only, shared by every candidate and stays L2/scalar-cache
-// resident.  Per-candidate mutable state ("mjData") is NOT in HBM: it lives in LDS for the whole
+// pointers into them; it is read-only and shared by every candidate.  Every workgroup copies the hot prefix of both
+// buffers (everything but the keyframe tables) into its LDS once per rollout (Lay::mc_d / mc_i) and the phases read
+// the tables from there: a dependent table walk costs LDS latency instead of an L2/HBM round trip per hop.  Per-candidate mutable state ("mjData") is NOT in HBM: it lives in LDS for the whole
 // horizon (Lay gives the carve-up); only the Trajectory record (states/actions/times/residual/
 // costs/trace per step, mjpc/trajectory.h:74-86) is streamed out, row-major per candidate.
 #pragma once
 #include <stdint.h>
 
-#define CON_STRIDE_ELLIPTIC 63  // doubles per contact in LDS incl. the 6x6 cone Hessian (odd: conflict-free field access)
+#define CON_STRIDE_ELLIPTIC 45  // doubles per contact in LDS incl. the 18 cone-Hessian factors at CON_H (odd: conflict-free field access)
+#define NVP_OF(n) ((((n) + 1)) | 1)   // row stride of nv-wide tables: odd (conflict-free column access) with >= 1 spare column
 #define CON_STRIDE_PLAIN 27     // without the cone Hessian (pyramidal / frictionless models)
 #define CON_DIST 0
 #define CON_POS 1
@@ -36,7 +38,7 @@ struct DevTask {
 struct DevModel {
   int nq, nv, nu, nbody, njnt, ngeom, nsite, nmocap, nkey, nvp, ntendon;
   int nlevel, npair, nfric, nlimit, nray, nmpair, nzpair, nconmax, nefcmax, any_damping;
-  int cone, iterations, ls_iterations, disableflags, con_stride;
+  int cone, iterations, ls_iterations, disableflags, con_stride, maxdim;
   double timestep, gravity[3], impratio, tolerance, ls_tolerance, meaninertia;
   const int *body_parentid, *body_rootid, *body_mocapid, *body_jntnum, *body_jntadr, *body_dofnum, *body_dofadr;
   const double *body_pos, *body_quat, *body_ipos, *body_iquat, *body_mass, *body_subtreemass, *body_inertia, *body_invweight0;
@@ -71,18 +73,21 @@ struct Lay {
   int xpos, xquat, xmat, xipos, ximat, xanchor, xaxis, geom_xpos, geom_xmat, site_xpos;
   int subtree_com, cinert, crb, cdof, cvel, cdof_dot, cacc, cfrc, cfrc_sub, subtree_linvel, bodytmp;
   int qM, qL, qH, Linv, Hinv;
-  int efc_J, efc_WJ, efc_JA, efc_D, efc_R, efc_aref, efc_force, efc_jar, efc_jv, efc_floss, efc_pos, efc_margin, efc_diag;
+  int efc_J, efc_JA, efc_D, efc_R, efc_aref, efc_force, efc_jar, efc_jv, efc_floss, efc_pos, efc_margin, efc_diag;
   int contact;
   int Ma, grad, Mgrad, search, Mv, vtmp, sgl;
   int knot_times, knot_values, residual, terms, red, prof;
+  int mc_d, mc_i;      // LDS copy of the model tables: fp64 part, int part (both offsets in doubles)
   int ints;            // start of the int region (in doubles)
-  int i_efc_type, i_efc_id, i_efc_state, i_efc_dof, i_con, i_active, i_misc;
+  int i_efc_type, i_efc_id, i_efc_state, i_efc_dof, i_con, i_active, i_misc, i_hpair;
   int total_doubles;   // LDS bytes = 8 * total_doubles
 };
 
 struct KParams {
   DevModel M;
   Lay L;
+  const int *ibase; const double *dbase;   // the two model buffers in HBM; [0, cache_i) / [0, cache_d) are LDS-cached
+  int cache_i, cache_d;
   // plan inputs (device pointers)
   const double *state, *mocap, *knot_times, *knot_values, *noise_eps;
   const int *noise_sel;

@@ -19,29 +19,30 @@
 #define LS_CPL 1       // nconmax <= 64
 #endif
 
-// constraint cost at efc_jar; fills force/state (and cone Hessians); returns this lane's partial cost
+// constraint cost at efc_jar; fills force/state (and the cone Hessian factors); returns this lane's partial cost
 DEV double constraint_update(Ctx &c, int hess) {
   double cost = 0;
   PFOR(i, c.nefc) {
     int type = c.efc_type[i];
     if (type == CNSTR_CONTACT_ELLIPTIC) continue;
-    double D = c.efc_D[i], R = c.efc_R[i], x = c.efc_jar[i];
-    if (type == CNSTR_FRICTION_DOF) {
-      double f = c.efc_floss[i];
-      if (x <= -R * f) { cost += -0.5 * R * f * f - f * x; c.efc_force[i] = f; c.efc_state[i] = STATE_LINEARNEG; }
-      else if (x >= R * f) { cost += -0.5 * R * f * f + f * x; c.efc_force[i] = -f; c.efc_state[i] = STATE_LINEARPOS; }
-      else { cost += 0.5 * D * x * x; c.efc_force[i] = -D * x; c.efc_state[i] = STATE_QUADRATIC; }
-    } else {
-      if (x >= 0) { c.efc_force[i] = 0; c.efc_state[i] = STATE_SATISFIED; }
-      else { cost += 0.5 * D * x * x; c.efc_force[i] = -D * x; c.efc_state[i] = STATE_QUADRATIC; }
-    }
+    // branch-free row cost (see the line search): xc = clamp(x, lo, hi), s = 1/2 D xc^2 + F (|x| - |xc|), force = -D xc
+    double D = c.efc_D[i], x = c.efc_jar[i];
+    int fric = type == CNSTR_FRICTION_DOF;
+    double f = fric ? c.efc_floss[i] : 0.0, Rf = c.efc_R[i] * f;
+    double lo = fric ? -Rf : -1e300, hi = fric ? Rf : 0.0;
+    double xc = fmin(fmax(x, lo), hi);
+    int inside = x > lo && x < hi;
+    cost += 0.5 * D * xc * xc + f * (fabs(x) - fabs(xc));
+    double force = fric ? (inside ? -D * x : (x <= lo ? f : -f)) : -D * xc;
+    c.efc_force[i] = force;
+    c.efc_state[i] = inside ? STATE_QUADRATIC : (fric ? (x <= lo ? STATE_LINEARNEG : STATE_LINEARPOS) : STATE_SATISFIED);
     if (i < c.nsingle) {
       // rows with one +-1 Jacobian entry: fold J^T force and the Hessian diagonal per dof
       // (slot 0/1: friction loss, slot 2/3: joint limit; at most one active row of each kind per dof)
-      int d = c.efc_dof[i], k = (type == CNSTR_FRICTION_DOF) ? 0 : 2;
+      int d = c.efc_dof[i], k = fric ? 0 : 2;
       int nv = c.M->nv;
-      c.sgl[k * nv + d] = c.efc_J[i * c.M->nvp + d] * c.efc_force[i];
-      c.sgl[(k + 1) * nv + d] = (c.efc_state[i] == STATE_QUADRATIC) ? D : 0.0;
+      c.sgl[k * nv + d] = c.efc_J[i * c.M->nvp + d] * force;
+      c.sgl[(k + 1) * nv + d] = inside ? D : 0.0;
     }
   }
   PFOR(ci, c.ncon) {
@@ -56,7 +57,8 @@ DEV double constraint_update(Ctx &c, int hess) {
     double T2 = 0;
 #pragma unroll
     for (int j = 0; j < 6; j++) { U[j] = j < dim ? c.efc_jar[i + j] * fr[j] : 0; if (j > 0) T2 += U[j] * U[j]; }
-    double N = U[0], T = sqrt(T2);
+    double iT = fast_rsqrt(T2);
+    double N = U[0], T = T2 * iT;
     int st;
     if (N >= mu * T || (T <= 0 && N >= 0)) {
 #pragma unroll
@@ -67,31 +69,30 @@ DEV double constraint_update(Ctx &c, int hess) {
       for (int j = 0; j < 6; j++) if (j < dim) { double xj = c.efc_jar[i + j], Dj = c.efc_D[i + j]; cost += 0.5 * Dj * xj * xj; c.efc_force[i + j] = -Dj * xj; }
       st = STATE_QUADRATIC;
     } else {
-      double Dm = c.efc_D[i] / (mu * mu * (1 + mu * mu));
+      double Dm = c.efc_D[i] * fast_rcp(mu * mu * (1 + mu * mu));
       double NmT = N - mu * T;
       cost += 0.5 * Dm * NmT * NmT;
       double f0 = -Dm * NmT * mu;
       c.efc_force[i] = f0;
 #pragma unroll
-      for (int j = 1; j < 6; j++) if (j < dim) c.efc_force[i + j] = -f0 / T * U[j] * fr[j];
+      for (int j = 1; j < 6; j++) if (j < dim) c.efc_force[i + j] = -f0 * iT * U[j] * fr[j];
       st = STATE_CONE;
       if (hess) {
-        // H = S d2s/dU2 S with S = diag(mu, friction), s = 1/2 Dm (N - mu T)^2
-        double g[6];
-        g[0] = 1;
+        // cone Hessian  S d2s/dU2 S  (S = diag(mu, friction), s = 1/2 Dm (N - mu T)^2)  in factored form:
+        //   Dm p p^T + kap (diag(fr_t^2) - q q^T),  p_a = fr_a g_a,  q_t = fr_t U_t / T,  kap = -mu (N - mu T) Dm / T > 0
+        // stored pre-scaled by sqrt(Dm) / sqrt(kap) so that the Hessian is a sum of +- outer products of combined rows
+        double kap = -mu * NmT * Dm * iT;
+        double sD = Dm * fast_rsqrt(Dm), sk = kap > 0 ? kap * fast_rsqrt(kap) : 0.0;
+        cc[CON_H] = sD * fr[0];
+        cc[CON_H + 6] = 0;
+        cc[CON_H + 12] = -sD * NmT;                       // phi of the p row: J^T force of this contact = p * (-Dm (N - mu T))
 #pragma unroll
-        for (int j = 1; j < 6; j++) g[j] = -mu * U[j] / T;
-        double iT = 1.0 / T, iT3 = iT * iT * iT;
-#pragma unroll
-        for (int a = 0; a < 6; a++)
-#pragma unroll
-          for (int b = 0; b < 6; b++) {
-            if (a < dim && b < dim) {
-              double h = g[a] * g[b];
-              if (a > 0 && b > 0) h += NmT * (-mu) * ((a == b ? iT : 0.0) - U[a] * U[b] * iT3);
-              cc[CON_H + a * 6 + b] = Dm * h * fr[a] * fr[b];
-            }
-          }
+        for (int j = 1; j < 6; j++) if (j < dim) {
+          double u = U[j] * iT;
+          cc[CON_H + j] = -sD * fr[j] * mu * u;
+          cc[CON_H + 6 + j] = sk * fr[j] * u;
+          cc[CON_H + 12 + j] = sk * fr[j];
+        }
       }
     }
 #pragma unroll
@@ -100,27 +101,62 @@ DEV double constraint_update(Ctx &c, int hess) {
   return cost;
 }
 
+// y_i = M_i . x  (i < nv)  and  out_r = J_r . x  (r < nefc; single-entry rows use their one column).
+// With a compile-time nv the vector x sits in registers (broadcast reads) and every row product is a fully unrolled
+// chain of loads with immediate offsets: the LDS latency is paid once per row instead of once per element.
+template <int NVT>
+DEV void mat_rows_times(Ctx &c, const double *x, double *Mx, double *Jx) {
+  const DevModel &M = *c.M;
+  const int nv = NVT > 0 ? NVT : M.nv, nvp = NVT > 0 ? NVP_OF(NVT) : M.nvp;
+  if constexpr (NVT > 0) {
+    double xs[NVT];
+#pragma unroll
+    for (int j = 0; j < NVT; j++) xs[j] = x[j];
+    PFOR(i, nv) {
+      const double *row = c.qM + i * nvp;
+      double s0 = 0, s1 = 0;
+#pragma unroll
+      for (int j = 0; j + 1 < NVT; j += 2) { s0 += row[j] * xs[j]; s1 += row[j + 1] * xs[j + 1]; }
+      if (NVT & 1) s0 += row[NVT - 1] * xs[NVT - 1];
+      Mx[i] = s0 + s1;
+    }
+    PFOR(r, c.nefc) {
+      const double *row = c.efc_J + r * nvp;
+      double s;
+      if (r < c.nsingle) { int d = c.efc_dof[r]; s = row[d] * x[d]; }
+      else {
+        double s0 = 0, s1 = 0;
+#pragma unroll
+        for (int j = 0; j + 1 < NVT; j += 2) { s0 += row[j] * xs[j]; s1 += row[j + 1] * xs[j + 1]; }
+        if (NVT & 1) s0 += row[NVT - 1] * xs[NVT - 1];
+        s = s0 + s1;
+      }
+      Jx[r] = s;
+    }
+  } else {
+    PFOR(i, nv) {
+      double s = 0;
+      for (int j = 0; j < nv; j++) s += c.qM[i * nvp + j] * x[j];
+      Mx[i] = s;
+    }
+    PFOR(r, c.nefc) {
+      double s = 0;
+      if (r < c.nsingle) s = c.efc_J[r * nvp + c.efc_dof[r]] * x[c.efc_dof[r]];
+      else for (int j = 0; j < nv; j++) s += c.efc_J[r * nvp + j] * x[j];
+      Jx[r] = s;
+    }
+  }
+}
+
 // full evaluation at qacc: Ma = M qacc, jar = J qacc - aref, force/state; returns total cost (uniform)
+template <int NVT>
 DEV double solver_eval(Ctx &c, const double *qacc, double *gauss_out) {
   const DevModel &M = *c.M;
-  int nv = M.nv, nvp = M.nvp;
+  int nv = M.nv;
+  mat_rows_times<NVT>(c, qacc, c.Ma, c.efc_jar);
   double part = 0;
-  PFOR(i, nv) {
-    double s = 0;
-#pragma unroll 6
-    for (int j = 0; j < nv; j++) s += c.qM[i * nvp + j] * qacc[j];
-    c.Ma[i] = s;
-    part += 0.5 * (s - c.qfrc_smooth[i]) * (qacc[i] - c.qacc_smooth[i]);
-  }
-  PFOR(r, c.nefc) {
-    double s = 0;
-    if (r < c.nsingle) s = c.efc_J[r * nvp + c.efc_dof[r]] * qacc[c.efc_dof[r]];
-    else {
-#pragma unroll 6
-      for (int j = 0; j < nv; j++) s += c.efc_J[r * nvp + j] * qacc[j];
-    }
-    c.efc_jar[r] = s - c.efc_aref[r];
-  }
+  PFOR(i, nv) part += 0.5 * (c.Ma[i] - c.qfrc_smooth[i]) * (qacc[i] - c.qacc_smooth[i]);
+  PFOR(r, c.nefc) c.efc_jar[r] -= c.efc_aref[r];
   SYNC();
   double gauss = wave_sum(part);
   double cc = wave_sum(constraint_update(c, 1));
@@ -129,173 +165,253 @@ DEV double solver_eval(Ctx &c, const double *qacc, double *gauss_out) {
   return gauss + cc;
 }
 
-// gradient, Hessian (lower triangle) and Newton direction Mgrad = H^-1 grad
+// gradient, Hessian (lower triangle) and Newton direction Mgrad = H^-1 grad.
+// Every active contact row contributes one scaled row  jh = sum_b coef_b J[row_b]  with  H += jh jh^T:
+//   quadratic row r: sqrt(D_r) J_r;   cone contact: p-row (normal row's slot), sqrt(kap) fr_t J_t for its tangential rows,
+// and each cone contact adds one NEGATIVE row q (H -= q q^T).  Column nv of a scaled row holds phi with
+// J^T force = sum_rows jh * phi, so the gradient falls out of the same contraction as an extra "column".
 template <int NVT>
 DEV void newton_gradient(Ctx &c) {
   const DevModel &M = *c.M;
-  const int nv = NVT > 0 ? NVT : M.nv, nvp = NVT > 0 ? (NVT | 1) : M.nvp;     // compile-time strides => immediate LDS offsets
+  const int nv = NVT > 0 ? NVT : M.nv, nvp = NVT > 0 ? NVP_OF(NVT) : M.nvp;     // compile-time strides => immediate LDS offsets
   int nefc = c.nefc, ns = c.nsingle;
   int ncrow = nefc - ns;
+  const int negbase = M.nefcmax;
   PROF(c, 13);
-  // ordered compaction of the ACTIVE contact rows (quadratic or cone state): satisfied rows contribute nothing
-  int nact = 0;
+  // ordered lists: positives = active contact rows, negatives = normal rows of the contacts in the cone zone
+  int npos = 0, nneg = 0;
   for (int base = 0; base < ncrow; base += NLANE) {
-    int rr = base + LANE;
-    int flag = (rr < ncrow) && (c.efc_state[ns + rr] != STATE_SATISFIED);
-    int tot, off = wave_excl_scan(flag, &tot);
-    if (flag) c.active[nact + off] = ns + rr;
-    nact += tot;
+    int rr = base + LANE, r = ns + rr;
+    int st = (rr < ncrow) ? c.efc_state[r] : STATE_SATISFIED;
+    int fpos = st != STATE_SATISFIED, fneg = 0;
+    if (st == STATE_CONE) fneg = c.con_i[c.efc_id[r] * CONI_STRIDE + 3] == r;
+    int tp, tn;
+    int op = wave_flag_scan(fpos, &tp), on = wave_flag_scan(fneg, &tn);
+    if (fpos) c.active[npos + op] = r;
+    if (fneg) c.active[negbase + nneg + on] = r;
+    npos += tp; nneg += tn;
   }
   SYNC();
-  // JA = J rows, WJ = blockdiag(W) J rows of the active set: one lane per row, all columns
-  PFOR(a, nact) {
-    int r = c.active[a];
-    int st = c.efc_state[r];
-    double *W = c.efc_WJ + a * nvp, *JA = c.efc_JA + a * nvp;
-    const double *Jr = c.efc_J + r * nvp;
-    c.efc_jv[a] = c.efc_force[r];                 // compact forces (jv is free between line searches)
-    if (st == STATE_QUADRATIC) {
-      double D = c.efc_D[r];
-#pragma unroll 6
-      for (int j = 0; j < nv; j++) { double v = Jr[j]; JA[j] = v; W[j] = D * v; }
+  // rows [0, npos8): positives, zero-padded to a multiple of 8; rows [npos8, npos8 + nneg4): negatives, padded to 4
+  const int npos8 = (npos + 7) & ~7, nneg4 = (nneg + 3) & ~3;
+  int ntot = npos8 + nneg4;
+  double *JH = c.efc_JA;
+  for (int base = 0; base < ntot; base += NLANE) {
+    int e = base + LANE;
+    double coef[6]; int rowb[6]; int nb = 0; double phi = 0;
+#pragma unroll
+    for (int b = 0; b < 6; b++) { coef[b] = 0; rowb[b] = 0; }
+    int neg = e >= npos8;
+    int valid = neg ? (e - npos8 < nneg) : (e < npos);
+    if (valid) {
+      int r = neg ? c.active[negbase + e - npos8] : c.active[e];
+      if (c.efc_state[r] == STATE_QUADRATIC) {
+        double D = c.efc_D[r], sd = D * fast_rsqrt(D);
+        coef[0] = sd; rowb[0] = r * nvp; nb = 1; phi = -sd * c.efc_jar[r];
+      } else {
+        int ci = c.efc_id[r];
+        int dim = c.con_i[ci * CONI_STRIDE], r0 = c.con_i[ci * CONI_STRIDE + 3];
+        const double *cf = c.contact + ci * M.con_stride + CON_H;
+        int k = r - r0;
+        if (neg) {
+          nb = dim - 1;
+#pragma unroll
+          for (int b = 1; b < 6; b++) if (b < dim) { coef[b - 1] = cf[6 + b]; rowb[b - 1] = (r0 + b) * nvp; }
+        } else if (k > 0) {
+          nb = 1; coef[0] = cf[12 + k]; rowb[0] = r * nvp;
+        } else {
+          nb = dim; phi = cf[12];
+#pragma unroll
+          for (int b = 0; b < 6; b++) if (b < dim) { coef[b] = cf[b]; rowb[b] = (r0 + b) * nvp; }
+        }
+      }
+    }
+    if constexpr (NVT > 0) {
+      double acc[NVT];
+      { const double *Jr = c.efc_J + rowb[0];
+#pragma unroll
+        for (int j = 0; j < NVT; j++) acc[j] = coef[0] * Jr[j]; }
+#pragma unroll
+      for (int b = 1; b < 6; b++) {
+        if (!wave_any(nb > b)) break;
+        const double *Jr = c.efc_J + rowb[b];
+#pragma unroll
+        for (int j = 0; j < NVT; j++) acc[j] += coef[b] * Jr[j];
+      }
+      if (e < ntot) {
+        double *o = JH + e * nvp;
+#pragma unroll
+        for (int j = 0; j < NVT; j++) o[j] = valid ? acc[j] : 0.0;
+        o[NVT] = phi;
+      }
     } else {
-      int ci = c.efc_id[r];
-      int dim = c.con_i[ci * CONI_STRIDE], r0 = c.con_i[ci * CONI_STRIDE + 3];
-      const double *Hc = c.contact + ci * c.M->con_stride + CON_H + (r - r0) * 6;
-      double hc[6];
+      if (e < ntot) {
+        double *o = JH + e * nvp;
+        for (int j = 0; j < nv; j++) {
+          double a = 0;
 #pragma unroll
-      for (int b = 0; b < 6; b++) hc[b] = b < dim ? Hc[b] : 0.0;
-      int rb[6];
-#pragma unroll
-      for (int b = 0; b < 6; b++) rb[b] = ((r0 + b < nefc) ? r0 + b : nefc - 1) * nvp;   // rows >= dim carry hc = 0
-#pragma unroll 3
-      for (int j = 0; j < nv; j++) {
-        double w = 0;
-#pragma unroll
-        for (int b = 0; b < 6; b++) w += hc[b] * c.efc_J[rb[b] + j];
-        W[j] = w; JA[j] = Jr[j];
+          for (int b = 0; b < 6; b++) if (b < nb) a += coef[b] * c.efc_J[rowb[b] + j];
+          o[j] = a;
+        }
+        o[nv] = phi;
       }
     }
   }
   PROF(c, 19);
   SYNC();
-  // gradient: Ma - qfrc_smooth - J^T force; diagonal Hessian terms of the single-entry rows
-  PFOR(i, nv) {
-    double g = c.Ma[i] - c.qfrc_smooth[i] - (c.sgl[i] + c.sgl[2 * nv + i]);
-    double hd = c.sgl[nv + i] + c.sgl[3 * nv + i];
-#pragma unroll 8
-    for (int a = 0; a < nact; a++) g -= c.efc_JA[a * nvp + i] * c.efc_jv[a];
-    c.grad[i] = g;
-    c.Mgrad[i] = g;
-    c.vtmp[i] = hd;
-  }
-  SYNC();
-  PROF(c, 15);
-  // H = M + diag + JA^T WJ on the lower triangle; without cross-branch contacts only M's sparsity pattern is non-zero
-  int nent = c.cross ? nv * (nv + 1) / 2 : M.nmpair;
+  // H = M + diag(single-entry rows) + JH+^T JH+ - JH-^T JH-  on the lower triangle (only M's sparsity pattern without
+  // cross-branch contacts), and grad = Ma - qfrc_smooth - J^T force  as the entries (i, nv)
+  int nh = c.cross ? nv * (nv + 1) / 2 : M.nmpair;
+  int nent = nh + nv;
   PFOR(e, nent) {
     int i, j;
-    if (c.cross) {
+    if (!c.cross) { int pk = c.hpair[e]; i = pk & 255; j = pk >> 8; }
+    else if (e >= nh) { i = e - nh; j = nv; }
+    else {
       i = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
       while ((i + 1) * (i + 2) / 2 <= e) i++;
       while (i * (i + 1) / 2 > e) i--;
       j = e - i * (i + 1) / 2;
-    } else { i = M.mpair_i[e]; j = M.mpair_j[e]; }
-    double h = c.qM[i * nvp + j];
-    if (i == j) h += c.vtmp[i];
-    const double *Ji = c.efc_JA + i, *Wj = c.efc_WJ + j;
-#pragma unroll 8
-    for (int a = 0; a < nact; a++) h += Ji[a * nvp] * Wj[a * nvp];
-    c.qH[i * nvp + j] = h;
+    }
+    const double *Ji = JH + i, *Jj = JH + j;
+    double h = 0;
+    {
+      // 8 rows per trip: 16 independent LDS reads in flight, then the FMAs (the row count is a multiple of 8)
+      double h0 = 0, h1 = 0;
+      for (int a = 0; a < npos8; a += 8) {
+        double x[8], y[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) { x[k] = Ji[(a + k) * nvp]; y[k] = Jj[(a + k) * nvp]; }
+#pragma unroll
+        for (int k = 0; k < 8; k += 2) { h0 += x[k] * y[k]; h1 += x[k + 1] * y[k + 1]; }
+      }
+      h = h0 + h1;
+    }
+    if (j == nv) {
+      double g = c.Ma[i] - c.qfrc_smooth[i] - (c.sgl[i] + c.sgl[2 * nv + i]) - h;
+      c.grad[i] = g;
+      c.Mgrad[i] = g;
+    } else {
+      double hn = 0;
+      for (int a = npos8; a < ntot; a += 4) {
+        double x[4], y[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { x[k] = Ji[(a + k) * nvp]; y[k] = Jj[(a + k) * nvp]; }
+#pragma unroll
+        for (int k = 0; k < 4; k++) hn += x[k] * y[k];
+      }
+      h = c.qM[i * nvp + j] + (h - hn);
+      if (i == j) h += c.sgl[nv + i] + c.sgl[3 * nv + i];
+      c.qH[i * nvp + j] = h;
+    }
   }
-  // the in-place factor of the previous iteration filled the structural zeros: clear them again
-  if (!c.cross) PFOR(e, M.nzpair) c.qH[M.zpair_i[e] * nvp + M.zpair_j[e]] = 0;
+  // structural zeros of the pattern: the register factorisation never writes qH, so they only need clearing after a
+  // dense (cross-branch) build; the generic in-place LDS factor fills them every time
+  if (c.cross) { if (LANE == 0) c.misc[9] = 1; }
+  else if (NVT == 0 || uniform_i(c.misc[9])) {
+    PFOR(e, M.nzpair) c.qH[MI(zpair_i)[e] * nvp + MI(zpair_j)[e]] = 0;
+    if (LANE == 0) c.misc[9] = 0;
+  }
+  SYNC();
   PROF(c, 16);
   chol_factor_solve<NVT>(c.qH, c.Hinv, c.vtmp, c.Mgrad, nv, nvp);
   PROF(c, 17);
 }
 
 // ---- exact line search: phi(alpha) = Gauss(alpha) + sum_i s_i(jar + alpha*jv), data in registers
+// Row costs in one branch-free form: with xc = clamp(x, lo, hi),
+//   s(x) = 1/2 D xc^2 + F (|x| - |xc|),  s' = D xc,  s'' = D inside (lo, hi)
+// (friction loss: lo/hi = -+R f, F = f;  unilateral rows: lo = -inf, hi = 0, F = 0;  unused slots: D = F = 0).
 struct LSPoint { double cost, d1, d2; };
+template <int DIMT>
 struct LSData {
-  double D[LS_RPL], R[LS_RPL], F[LS_RPL], X[LS_RPL], V[LS_RPL];
-  int T[LS_RPL];                        // 0 none, 1 friction, 2 unilateral
-  double U0[LS_CPL][6], UV[LS_CPL][6], E[LS_CPL][6], mu[LS_CPL], Dm[LS_CPL];
-  int dim[LS_CPL];
+  double lo[LS_RPL], hi[LS_RPL], hD[LS_RPL], F[LS_RPL], X[LS_RPL], V[LS_RPL], DV[LS_RPL], DVV[LS_RPL];
+  double U0[LS_CPL][DIMT], UV[LS_CPL][DIMT], E[LS_CPL][DIMT], mu[LS_CPL], Dm[LS_CPL], VV[LS_CPL];
+  int on[LS_CPL];
+  int nslot, ncslot;
 };
 
-DEV void ls_load(Ctx &c, LSData &d) {
+template <int DIMT>
+DEV void ls_load(Ctx &c, LSData<DIMT> &d) {
+  d.nslot = (c.nefc + NLANE - 1) / NLANE; d.ncslot = (c.ncon + NLANE - 1) / NLANE;
 #pragma unroll
   for (int k = 0; k < LS_RPL; k++) {
     int r = LANE + NLANE * k;
-    d.T[k] = 0; d.D[k] = 0; d.R[k] = 0; d.F[k] = 0; d.X[k] = 0; d.V[k] = 0;
-    if (r < c.nefc) {
+    d.lo[k] = -1; d.hi[k] = 1; d.hD[k] = 0; d.F[k] = 0; d.X[k] = 0; d.V[k] = 0; d.DV[k] = 0; d.DVV[k] = 0;
+    if (k < d.nslot && r < c.nefc) {
       int type = c.efc_type[r];
       if (type != CNSTR_CONTACT_ELLIPTIC) {
-        d.T[k] = (type == CNSTR_FRICTION_DOF) ? 1 : 2;
-        d.D[k] = c.efc_D[r]; d.R[k] = c.efc_R[r]; d.F[k] = c.efc_floss[r]; d.X[k] = c.efc_jar[r]; d.V[k] = c.efc_jv[r];
+        double D = c.efc_D[r], v = c.efc_jv[r];
+        d.X[k] = c.efc_jar[r]; d.V[k] = v; d.hD[k] = 0.5 * D; d.DV[k] = D * v; d.DVV[k] = D * v * v;
+        if (type == CNSTR_FRICTION_DOF) { double f = c.efc_floss[r], Rf = c.efc_R[r] * f; d.lo[k] = -Rf; d.hi[k] = Rf; d.F[k] = f; }
+        else { d.lo[k] = -1e300; d.hi[k] = 0; }
       }
     }
   }
 #pragma unroll
   for (int q = 0; q < LS_CPL; q++) {
     int ci = LANE + NLANE * q;
-    d.dim[q] = 0; d.mu[q] = 0; d.Dm[q] = 0;
+    d.on[q] = 0; d.mu[q] = 0; d.Dm[q] = 0; d.VV[q] = 0;
 #pragma unroll
-    for (int j = 0; j < 6; j++) { d.U0[q][j] = 0; d.UV[q][j] = 0; d.E[q][j] = 0; }
-    if (ci < c.ncon) {
+    for (int j = 0; j < DIMT; j++) { d.U0[q][j] = 0; d.UV[q][j] = 0; d.E[q][j] = 0; }
+    if (q < d.ncslot && ci < c.ncon) {
       int dim = c.con_i[ci * CONI_STRIDE];
       int i = c.con_i[ci * CONI_STRIDE + 3];
       if (dim > 1 && c.efc_type[i] == CNSTR_CONTACT_ELLIPTIC) {
         const double *cc = c.contact + ci * c.M->con_stride;
         double mu = cc[CON_MU];
-        d.dim[q] = dim; d.mu[q] = mu;
-        d.Dm[q] = c.efc_D[i] / (mu * mu * (1 + mu * mu));
+        d.on[q] = 1; d.mu[q] = mu;
+        d.Dm[q] = c.efc_D[i] * fast_rcp(mu * mu * (1 + mu * mu));
+        double vv = 0;
 #pragma unroll
-        for (int j = 0; j < 6; j++) if (j < dim) {
+        for (int j = 0; j < DIMT; j++) if (j < dim) {
           double fr = j == 0 ? mu : cc[CON_FRICTION + j - 1];
-          d.U0[q][j] = c.efc_jar[i + j] * fr; d.UV[q][j] = c.efc_jv[i + j] * fr;
-          d.E[q][j] = c.efc_D[i + j] / (fr * fr);     // D_j jar_j^2 = E_j U_j^2
+          double uv = c.efc_jv[i + j] * fr;
+          d.U0[q][j] = c.efc_jar[i + j] * fr; d.UV[q][j] = uv;
+          d.E[q][j] = c.efc_D[i + j] * fast_rcp(fr * fr);     // D_j jar_j^2 = E_j U_j^2
+          if (j > 0) vv += uv * uv;
         }
+        d.VV[q] = vv;
       }
     }
   }
 }
 
-DEV LSPoint ls_eval(const LSData &d, double q0, double q1, double q2, double a) {
+template <int DIMT>
+DEV LSPoint ls_eval(const LSData<DIMT> &d, double q0, double q1, double q2, double a) {
   LSPoint p; p.cost = 0; p.d1 = 0; p.d2 = 0;
 #pragma unroll
   for (int k = 0; k < LS_RPL; k++) {
-    if (d.T[k] == 0) continue;
-    double D = d.D[k], v = d.V[k], x = d.X[k] + a * v;
-    if (d.T[k] == 1) {
-      double f = d.F[k], Rf = d.R[k] * f;
-      if (x <= -Rf) { p.cost += -0.5 * Rf * f - f * x; p.d1 += -f * v; }
-      else if (x >= Rf) { p.cost += -0.5 * Rf * f + f * x; p.d1 += f * v; }
-      else { p.cost += 0.5 * D * x * x; p.d1 += D * x * v; p.d2 += D * v * v; }
-    } else if (x < 0) { p.cost += 0.5 * D * x * x; p.d1 += D * x * v; p.d2 += D * v * v; }
+    if (k >= d.nslot) break;
+    double x = d.X[k] + a * d.V[k];
+    double xc = fmin(fmax(x, d.lo[k]), d.hi[k]);
+    p.cost += d.hD[k] * xc * xc + d.F[k] * (fabs(x) - fabs(xc));
+    p.d1 += d.DV[k] * xc;
+    p.d2 += (x > d.lo[k] && x < d.hi[k]) ? d.DVV[k] : 0.0;
   }
 #pragma unroll
   for (int q = 0; q < LS_CPL; q++) {
-    if (d.dim[q] <= 1) continue;
-    double mu = d.mu[q], U[6];
-    double T2 = 0, UV = 0, VV = 0;
+    if (q >= d.ncslot) break;
+    if (!d.on[q]) continue;
+    double mu = d.mu[q], U[DIMT];
+    double T2 = 0, UV = 0;
 #pragma unroll
-    for (int j = 0; j < 6; j++) {
+    for (int j = 0; j < DIMT; j++) {
       U[j] = d.U0[q][j] + a * d.UV[q][j];
-      if (j > 0) { T2 += U[j] * U[j]; UV += U[j] * d.UV[q][j]; VV += d.UV[q][j] * d.UV[q][j]; }
+      if (j > 0) { T2 += U[j] * U[j]; UV += U[j] * d.UV[q][j]; }
     }
     double iT = fast_rsqrt(T2);            // 1/T without an IEEE divide + sqrt on the critical path
     double N = U[0], T = T2 * iT;
     if (N >= mu * T || (T <= 0 && N >= 0)) {
     } else if (mu * N + T <= 0 || (T <= 0 && N < 0)) {
 #pragma unroll
-      for (int j = 0; j < 6; j++) { double E = d.E[q][j], vj = d.UV[q][j]; p.cost += 0.5 * E * U[j] * U[j]; p.d1 += E * U[j] * vj; p.d2 += E * vj * vj; }
+      for (int j = 0; j < DIMT; j++) { double E = d.E[q][j], vj = d.UV[q][j], eu = E * U[j]; p.cost += 0.5 * eu * U[j]; p.d1 += eu * vj; p.d2 += E * vj * vj; }
     } else {
       double Dm = d.Dm[q], NmT = N - mu * T;
-      double T1 = UV * iT, T2d = (VV - T1 * T1) * iT;
+      double T1 = UV * iT, T2d = (d.VV[q] - T1 * T1) * iT;
       double g1 = d.UV[q][0] - mu * T1;
-      p.cost += 0.5 * Dm * NmT * NmT; p.d1 += Dm * NmT * g1; p.d2 += Dm * (g1 * g1 - NmT * mu * T2d);
+      double dn = Dm * NmT;
+      p.cost += 0.5 * dn * NmT; p.d1 += dn * g1; p.d2 += Dm * g1 * g1 - dn * mu * T2d;
     }
   }
   p.cost = wave_sum(p.cost) + q0 + a * q1 + a * a * q2;
@@ -305,26 +421,15 @@ DEV LSPoint ls_eval(const LSData &d, double q0, double q1, double q2, double a) 
 }
 
 // returns alpha; q1/q2 = Gauss quadratic coefficients along the direction (for the incremental update)
+template <int NVT, int DIMT>
 DEV double line_search(Ctx &c, double gauss, double *q1_out, double *q2_out) {
   const DevModel &M = *c.M;
-  int nv = M.nv, nvp = M.nvp;
+  int nv = M.nv;
   double p_sn = 0, p_q1 = 0, p_q2 = 0;
+  mat_rows_times<NVT>(c, c.search, c.Mv, c.efc_jv);
   PFOR(i, nv) {
-    double s = 0;
-#pragma unroll 6
-    for (int j = 0; j < nv; j++) s += c.qM[i * nvp + j] * c.search[j];
-    c.Mv[i] = s;
     double si = c.search[i];
-    p_sn += si * si; p_q1 += si * (c.Ma[i] - c.qfrc_smooth[i]); p_q2 += 0.5 * si * s;
-  }
-  PFOR(r, c.nefc) {
-    double s = 0;
-    if (r < c.nsingle) s = c.efc_J[r * nvp + c.efc_dof[r]] * c.search[c.efc_dof[r]];
-    else {
-#pragma unroll 6
-      for (int j = 0; j < nv; j++) s += c.efc_J[r * nvp + j] * c.search[j];
-    }
-    c.efc_jv[r] = s;
+    p_sn += si * si; p_q1 += si * (c.Ma[i] - c.qfrc_smooth[i]); p_q2 += 0.5 * si * c.Mv[i];
   }
   SYNC();
   double snorm = sqrt(wave_sum(p_sn)), q1 = wave_sum(p_q1), q2 = wave_sum(p_q2);
@@ -333,17 +438,17 @@ DEV double line_search(Ctx &c, double gauss, double *q1_out, double *q2_out) {
   double scale = 1.0 / (M.meaninertia * (nv > 1 ? nv : 1));
   if (snorm < D_MINVAL) return 0;
   double gtol = M.tolerance * M.ls_tolerance * snorm / scale;
-  LSData d;
-  ls_load(c, d);
+  LSData<DIMT> d;
+  ls_load<DIMT>(c, d);
   PROF(c, 21);
-  LSPoint p0 = ls_eval(d, gauss, q1, q2, 0.0);
+  LSPoint p0 = ls_eval<DIMT>(d, gauss, q1, q2, 0.0);
   if (!(p0.d2 > 0) || p0.d1 >= 0) return 0;
   // safeguarded Newton on phi'(alpha) (rtsafe): expand until phi' changes sign, then Newton steps that stay
   // inside the bracket and at least halve the previous step, else bisection; return the best point seen
-  double lo = 0, hi = -1, a = -p0.d1 / p0.d2;
+  double lo = 0, hi = -1, a = -p0.d1 * fast_rcp(p0.d2);
   double best_a = 0, best_cost = p0.cost, dxold = a, dx = a;
   for (int it = 0; it < M.ls_iterations; it++) {
-    LSPoint p = ls_eval(d, gauss, q1, q2, a);
+    LSPoint p = ls_eval<DIMT>(d, gauss, q1, q2, a);
 #if defined(MJPC_PROFILE) && !defined(MJPC_EMU)
     if (LANE == 0) c.prof[23] += 1;
 #endif
@@ -352,11 +457,11 @@ DEV double line_search(Ctx &c, double gauss, double *q1_out, double *q2_out) {
     if (p.d1 < 0) lo = a; else hi = a;
     double an;
     if (hi < 0) {
-      an = (p.d2 > 0) ? a - p.d1 / p.d2 : 2 * a;
+      an = (p.d2 > 0) ? a - p.d1 * fast_rcp(p.d2) : 2 * a;
       if (!(an > a)) an = 2 * a;
       dxold = dx; dx = an - a;
     } else {
-      double nw = (p.d2 > 0) ? a - p.d1 / p.d2 : lo - 1;
+      double nw = (p.d2 > 0) ? a - p.d1 * fast_rcp(p.d2) : lo - 1;
       int ok = (nw > lo) && (nw < hi) && (fabs(2 * p.d1) <= fabs(dxold * p.d2));
       dxold = dx;
       if (ok) { dx = fabs(nw - a); an = nw; }
@@ -382,12 +487,12 @@ DEV void solve_constraints(Ctx &c) {
   PROF(c, 7);
   // warm start: the better of qacc_smooth and qacc_warmstart (evaluated last, so its force/state stay valid)
   double gauss, cost;
-  double cost_sm = solver_eval(c, c.qacc_smooth, 0);
-  double cost_ws = solver_eval(c, c.qacc_ws, &gauss);
+  double cost_sm = solver_eval<NVT>(c, c.qacc_smooth, 0);
+  double cost_ws = solver_eval<NVT>(c, c.qacc_ws, &gauss);
   if (cost_ws > cost_sm) {
     PFOR(i, nv) c.qacc[i] = c.qacc_smooth[i];
     SYNC();
-    cost = solver_eval(c, c.qacc, &gauss);
+    cost = solver_eval<NVT>(c, c.qacc, &gauss);
   } else {
     PFOR(i, nv) c.qacc[i] = c.qacc_ws[i];
     SYNC();
@@ -401,7 +506,7 @@ DEV void solve_constraints(Ctx &c) {
   for (int iter = 0; iter < M.iterations; iter++) {
     PROF(c, 13);
     double q1, q2;
-    double alpha = line_search(c, gauss, &q1, &q2);
+    double alpha = (M.maxdim <= 3) ? line_search<NVT, 3>(c, gauss, &q1, &q2) : line_search<NVT, 6>(c, gauss, &q1, &q2);
     PROF(c, 14);
     if (alpha == 0) break;
     PFOR(i, nv) { c.qacc[i] += alpha * c.search[i]; c.Ma[i] += alpha * c.Mv[i]; }
@@ -423,11 +528,7 @@ DEV void solve_constraints(Ctx &c) {
     SYNC();
   }
   if (LANE == 0) { c.misc[5] += c.solver_iter; if (c.ncon > c.misc[6]) c.misc[6] = c.ncon; if (c.nefc > c.misc[7]) c.misc[7] = c.nefc; }
-  PFOR(i, nv) {
-    double s = c.sgl[i] + c.sgl[2 * nv + i];
-#pragma unroll 8
-    for (int r = c.nsingle; r < c.nefc; r++) s += c.efc_J[r * nvp + i] * c.efc_force[r];
-    c.qfrc_constraint[i] = s;
-  }
+  // J^T force of the final state: the last newton_gradient() evaluated grad = Ma - qfrc_smooth - J^T force there
+  PFOR(i, nv) c.qfrc_constraint[i] = (c.Ma[i] - c.qfrc_smooth[i]) - c.grad[i];
   SYNC();
 }

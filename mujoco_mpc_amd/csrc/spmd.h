@@ -25,6 +25,8 @@ DEV double wave_min(double v) { return v; }
 DEV int wave_sum_i(int v) { return v; }
 DEV int wave_or_i(int v) { return v; }
 DEV int wave_excl_scan(int v, int *total) { *total = v; return 0; }
+DEV int wave_flag_scan(int flag, int *total) { *total = flag ? 1 : 0; return 0; }
+DEV int wave_any(int flag) { return flag != 0; }
 #else
 #include <hip/hip_runtime.h>
 #define DEV static __device__ __forceinline__
@@ -86,13 +88,25 @@ DEV int wave_or_i(int v) {
   for (int o = 32; o > 0; o >>= 1) v |= __shfl_xor(v, o, 64);
   return v;
 }
-// exclusive prefix sum over the 64 lanes (lane order), total returned to every lane
+DEV int wave_any(int flag) { return __builtin_amdgcn_ballot_w64(flag != 0) != 0; }
+// exclusive prefix sum over the 64 lanes (lane order), total returned to every lane: Hillis-Steele inside each
+// row of 16 with DPP row_shr (VALU rate, zero fill), then row_bcast:15 / row_bcast:31 carry the row totals
 DEV int wave_excl_scan(int v, int *total) {
   int x = v;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) { int y = __shfl_up(x, o, 64); if (LANE >= o) x += y; }
-  *total = __shfl(x, 63, 64);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);
+  *total = __builtin_amdgcn_readlane(x, 63);
   return x - v;
+}
+// the same for 0/1 flags: ballot + popcount of the lower lanes
+DEV int wave_flag_scan(int flag, int *total) {
+  unsigned long long m = __builtin_amdgcn_ballot_w64(flag != 0);
+  *total = __builtin_popcountll(m);
+  return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
 }
 #endif
 

@@ -165,13 +165,14 @@ DEV double solver_eval(Ctx &c, const double *qacc, double *gauss_out) {
   return gauss + cc;
 }
 
-// gradient, Hessian (lower triangle) and Newton direction Mgrad = H^-1 grad.
+// gradient and Hessian (lower triangle); newton_direction() then solves Mgrad = H^-1 grad.
 // Every active contact row contributes one scaled row  jh = sum_b coef_b J[row_b]  with  H += jh jh^T:
 //   quadratic row r: sqrt(D_r) J_r;   cone contact: p-row (normal row's slot), sqrt(kap) fr_t J_t for its tangential rows,
 // and each cone contact adds one NEGATIVE row q (H -= q q^T).  Column nv of a scaled row holds phi with
 // J^T force = sum_rows jh * phi, so the gradient falls out of the same contraction as an extra "column".
+// grad_only: the caller already knows it will stop (no cost improvement) and only needs grad = Ma - qfrc_smooth - J^T force.
 template <int NVT>
-DEV void newton_gradient(Ctx &c) {
+DEV void newton_gradient(Ctx &c, int grad_only) {
   const DevModel &M = *c.M;
   const int nv = NVT > 0 ? NVT : M.nv, nvp = NVT > 0 ? NVP_OF(NVT) : M.nvp;     // compile-time strides => immediate LDS offsets
   int nefc = c.nefc, ns = c.nsingle;
@@ -263,7 +264,7 @@ DEV void newton_gradient(Ctx &c) {
   // cross-branch contacts), and grad = Ma - qfrc_smooth - J^T force  as the entries (i, nv)
   int nh = c.cross ? nv * (nv + 1) / 2 : M.nmpair;
   int nent = nh + nv;
-  PFOR(e, nent) {
+  for (int e = (grad_only ? nh : 0) + LANE; e < nent; e += NLANE) {
     int i, j;
     if (!c.cross) { int pk = c.hpair[e]; i = pk & 255; j = pk >> 8; }
     else if (e >= nh) { i = e - nh; j = nv; }
@@ -314,6 +315,10 @@ DEV void newton_gradient(Ctx &c) {
   }
   SYNC();
   PROF(c, 16);
+}
+template <int NVT>
+DEV void newton_direction(Ctx &c) {
+  const int nv = NVT > 0 ? NVT : c.M->nv, nvp = NVT > 0 ? NVP_OF(NVT) : c.M->nvp;
   chol_factor_solve<NVT>(c.qH, c.Hinv, c.vtmp, c.Mgrad, nv, nvp);
   PROF(c, 17);
 }
@@ -422,17 +427,17 @@ DEV LSPoint ls_eval(const LSData<DIMT> &d, double q0, double q1, double q2, doub
 
 // returns alpha; q1/q2 = Gauss quadratic coefficients along the direction (for the incremental update)
 template <int NVT, int DIMT>
-DEV double line_search(Ctx &c, double gauss, double *q1_out, double *q2_out) {
+DEV double line_search(Ctx &c, double gauss, double cost0, double *q1_out, double *q2_out) {
   const DevModel &M = *c.M;
   int nv = M.nv;
-  double p_sn = 0, p_q1 = 0, p_q2 = 0;
+  double p_sn = 0, p_q1 = 0, p_q2 = 0, p_gs = 0;
   mat_rows_times<NVT>(c, c.search, c.Mv, c.efc_jv);
   PFOR(i, nv) {
     double si = c.search[i];
-    p_sn += si * si; p_q1 += si * (c.Ma[i] - c.qfrc_smooth[i]); p_q2 += 0.5 * si * c.Mv[i];
+    p_sn += si * si; p_q1 += si * (c.Ma[i] - c.qfrc_smooth[i]); p_q2 += 0.5 * si * c.Mv[i]; p_gs += c.grad[i] * si;
   }
   SYNC();
-  double snorm = sqrt(wave_sum(p_sn)), q1 = wave_sum(p_q1), q2 = wave_sum(p_q2);
+  double snorm = sqrt(wave_sum(p_sn)), q1 = wave_sum(p_q1), q2 = wave_sum(p_q2), gs = wave_sum(p_gs);
   *q1_out = q1; *q2_out = q2;
   PROF(c, 20);
   double scale = 1.0 / (M.meaninertia * (nv > 1 ? nv : 1));
@@ -441,11 +446,13 @@ DEV double line_search(Ctx &c, double gauss, double *q1_out, double *q2_out) {
   LSData<DIMT> d;
   ls_load<DIMT>(c, d);
   PROF(c, 21);
-  LSPoint p0 = ls_eval<DIMT>(d, gauss, q1, q2, 0.0);
-  if (!(p0.d2 > 0) || p0.d1 >= 0) return 0;
+  // the point alpha = 0 needs no evaluation: search = -H^-1 grad with H the exact Hessian there, so
+  // phi(0) = cost, phi'(0) = grad.search = -phi''(0), and the Newton step from alpha = 0 is exactly 1
+  LSPoint p0; p0.cost = cost0; p0.d1 = gs; p0.d2 = -gs;
+  if (p0.d1 >= 0) return 0;
   // safeguarded Newton on phi'(alpha) (rtsafe): expand until phi' changes sign, then Newton steps that stay
   // inside the bracket and at least halve the previous step, else bisection; return the best point seen
-  double lo = 0, hi = -1, a = -p0.d1 * fast_rcp(p0.d2);
+  double lo = 0, hi = -1, a = 1.0;
   double best_a = 0, best_cost = p0.cost, dxold = a, dx = a;
   for (int it = 0; it < M.ls_iterations; it++) {
     LSPoint p = ls_eval<DIMT>(d, gauss, q1, q2, a);
@@ -499,14 +506,15 @@ DEV void solve_constraints(Ctx &c) {
     cost = cost_ws;
   }
   PROF(c, 12);
-  newton_gradient<NVT>(c);
+  newton_gradient<NVT>(c, 0);
+  newton_direction<NVT>(c);
   PFOR(i, nv) c.search[i] = -c.Mgrad[i];
   SYNC();
   double scale = 1.0 / (M.meaninertia * (nv > 1 ? nv : 1));
   for (int iter = 0; iter < M.iterations; iter++) {
     PROF(c, 13);
     double q1, q2;
-    double alpha = (M.maxdim <= 3) ? line_search<NVT, 3>(c, gauss, &q1, &q2) : line_search<NVT, 6>(c, gauss, &q1, &q2);
+    double alpha = (M.maxdim <= 3) ? line_search<NVT, 3>(c, gauss, cost, &q1, &q2) : line_search<NVT, 6>(c, gauss, cost, &q1, &q2);
     PROF(c, 14);
     if (alpha == 0) break;
     PFOR(i, nv) { c.qacc[i] += alpha * c.search[i]; c.Ma[i] += alpha * c.Mv[i]; }
@@ -517,13 +525,17 @@ DEV void solve_constraints(Ctx &c) {
     cost = gauss + wave_sum(constraint_update(c, 1));
     SYNC();
     PROF(c, 12);
-    newton_gradient<NVT>(c);
+    // same stopping rule as the reference's Newton loop; the Hessian build / factorisation of an iteration that is
+    // about to stop is skipped (its direction would never be used)
+    double improvement = scale * (oldcost - cost);
+    int stop = improvement < M.tolerance;
+    newton_gradient<NVT>(c, stop);
     c.solver_iter++;
     double pg = 0;
     PFOR(i, nv) pg += c.grad[i] * c.grad[i];
     double gradient = scale * sqrt(wave_sum(pg));
-    double improvement = scale * (oldcost - cost);
-    if (improvement < M.tolerance || gradient < M.tolerance) break;
+    if (stop || gradient < M.tolerance) break;
+    newton_direction<NVT>(c);
     PFOR(i, nv) c.search[i] = -c.Mgrad[i];
     SYNC();
   }

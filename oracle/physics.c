@@ -719,7 +719,7 @@ static LSPoint ls_eval(const OModel *om, const OData *d, const double *jar, cons
 }
 
 /* safeguarded Newton on phi'(alpha); phi convex, C1 */
-static double line_search(const OModel *om, OData *d, double cost0_gauss) {
+static double line_search(const OModel *om, OData *d, double cost0_gauss, double cost0) {
   const MjpcHipModel *m = &om->m;
   int nv = m->nv;
   double snorm = o_norm(d->search, nv);
@@ -733,12 +733,15 @@ static double line_search(const OModel *om, OData *d, double cost0_gauss) {
   quad[0] = cost0_gauss;
   quad[1] = 0; for (int i = 0; i < nv; i++) quad[1] += d->search[i] * (d->Ma[i] - d->qfrc_smooth[i]);
   quad[2] = 0.5 * o_dot(d->search, d->Mv, nv);
-  LSPoint p0 = ls_eval(om, d, d->efc_jar, d->efc_jv, quad, 0);
-  if (!(p0.d2 > 0) || p0.d1 >= 0) return 0;
+  /* the point alpha = 0 needs no evaluation: search = -H^-1 grad with H the exact Hessian there, so
+   * phi(0) = cost, phi'(0) = grad.search = -phi''(0), and the Newton step from alpha = 0 is exactly 1 */
+  LSPoint p0;
+  p0.cost = cost0; p0.d1 = o_dot(d->grad, d->search, nv); p0.d2 = -p0.d1;
+  if (p0.d1 >= 0) return 0;
   /* safeguarded Newton on phi'(alpha) (rtsafe): expand until phi' changes sign, then Newton steps that
    * stay inside the bracket and at least halve the previous step, else bisection; return the best point */
   double lo = 0, hi = -1;   /* hi < 0: no upper bracket yet */
-  double a = -p0.d1 / p0.d2;
+  double a = 1.0;
   double best_a = 0, best_cost = p0.cost, dxold = a, dx = a;
   for (int it = 0; it < m->ls_iterations; it++) {
     LSPoint p = ls_eval(om, d, d->efc_jar, d->efc_jv, quad, a);
@@ -825,7 +828,7 @@ static void solve_constraints(const OModel *om, OData *d) {
   for (int i = 0; i < nv; i++) d->search[i] = -d->Mgrad[i];
   double scale = 1.0 / (m->meaninertia * (nv > 1 ? nv : 1));
   for (int iter = 0; iter < m->iterations; iter++) {
-    double alpha = line_search(om, d, gauss);
+    double alpha = line_search(om, d, gauss, cost);
     if (alpha == 0) break;
     for (int i = 0; i < nv; i++) d->qacc[i] += alpha * d->search[i];
     double oldcost = cost;

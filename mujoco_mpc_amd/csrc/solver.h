@@ -20,6 +20,7 @@
 #endif
 
 // constraint cost at efc_jar; fills force/state (and the cone Hessian factors); returns this lane's partial cost
+template <int DIMT>
 DEV double constraint_update(Ctx &c, int hess) {
   double cost = 0;
   PFOR(i, c.nefc) {
@@ -50,32 +51,34 @@ DEV double constraint_update(Ctx &c, int hess) {
     int i = c.con_i[ci * CONI_STRIDE + 3];
     if (dim <= 1 || c.efc_type[i] != CNSTR_CONTACT_ELLIPTIC) continue;     // pyramidal edges are plain unilateral rows
     double *cc = c.contact + ci * c.M->con_stride;
-    double mu = cc[CON_MU], U[6], fr[6];
+    double mu = cc[CON_MU], U[DIMT], fr[DIMT], X[DIMT], Dj[DIMT], F[DIMT];
     fr[0] = mu;
 #pragma unroll
-    for (int j = 1; j < 6; j++) fr[j] = j < dim ? cc[CON_FRICTION + j - 1] : 0;
+    for (int j = 1; j < DIMT; j++) fr[j] = j < dim ? cc[CON_FRICTION + j - 1] : 0;
     double T2 = 0;
 #pragma unroll
-    for (int j = 0; j < 6; j++) { U[j] = j < dim ? c.efc_jar[i + j] * fr[j] : 0; if (j > 0) T2 += U[j] * U[j]; }
+    for (int j = 0; j < DIMT; j++) {
+      X[j] = j < dim ? c.efc_jar[i + j] : 0; Dj[j] = j < dim ? c.efc_D[i + j] : 0;
+      U[j] = X[j] * fr[j]; F[j] = 0;
+      if (j > 0) T2 += U[j] * U[j];
+    }
     double iT = fast_rsqrt(T2);
     double N = U[0], T = T2 * iT;
     int st;
     if (N >= mu * T || (T <= 0 && N >= 0)) {
-#pragma unroll
-      for (int j = 0; j < 6; j++) if (j < dim) c.efc_force[i + j] = 0;
       st = STATE_SATISFIED;
     } else if (mu * N + T <= 0 || (T <= 0 && N < 0)) {
 #pragma unroll
-      for (int j = 0; j < 6; j++) if (j < dim) { double xj = c.efc_jar[i + j], Dj = c.efc_D[i + j]; cost += 0.5 * Dj * xj * xj; c.efc_force[i + j] = -Dj * xj; }
+      for (int j = 0; j < DIMT; j++) { double dx = Dj[j] * X[j]; cost += 0.5 * dx * X[j]; F[j] = -dx; }
       st = STATE_QUADRATIC;
     } else {
-      double Dm = c.efc_D[i] * fast_rcp(mu * mu * (1 + mu * mu));
+      double Dm = Dj[0] * fast_rcp(mu * mu * (1 + mu * mu));
       double NmT = N - mu * T;
       cost += 0.5 * Dm * NmT * NmT;
       double f0 = -Dm * NmT * mu;
-      c.efc_force[i] = f0;
+      F[0] = f0;
 #pragma unroll
-      for (int j = 1; j < 6; j++) if (j < dim) c.efc_force[i + j] = -f0 * iT * U[j] * fr[j];
+      for (int j = 1; j < DIMT; j++) F[j] = -f0 * iT * U[j] * fr[j];
       st = STATE_CONE;
       if (hess) {
         // cone Hessian  S d2s/dU2 S  (S = diag(mu, friction), s = 1/2 Dm (N - mu T)^2)  in factored form:
@@ -87,7 +90,7 @@ DEV double constraint_update(Ctx &c, int hess) {
         cc[CON_H + 6] = 0;
         cc[CON_H + 12] = -sD * NmT;                       // phi of the p row: J^T force of this contact = p * (-Dm (N - mu T))
 #pragma unroll
-        for (int j = 1; j < 6; j++) if (j < dim) {
+        for (int j = 1; j < DIMT; j++) if (j < dim) {
           double u = U[j] * iT;
           cc[CON_H + j] = -sD * fr[j] * mu * u;
           cc[CON_H + 6 + j] = sk * fr[j] * u;
@@ -96,9 +99,12 @@ DEV double constraint_update(Ctx &c, int hess) {
       }
     }
 #pragma unroll
-    for (int j = 0; j < 6; j++) if (j < dim) c.efc_state[i + j] = st;
+    for (int j = 0; j < DIMT; j++) if (j < dim) { c.efc_force[i + j] = F[j]; c.efc_state[i + j] = st; }
   }
   return cost;
+}
+DEV double constraint_update_any(Ctx &c, int hess) {
+  return c.M->maxdim <= 3 ? constraint_update<3>(c, hess) : constraint_update<6>(c, hess);
 }
 
 // y_i = M_i . x  (i < nv)  and  out_r = J_r . x  (r < nefc; single-entry rows use their one column).
@@ -159,7 +165,7 @@ DEV double solver_eval(Ctx &c, const double *qacc, double *gauss_out) {
   PFOR(r, c.nefc) c.efc_jar[r] -= c.efc_aref[r];
   SYNC();
   double gauss = wave_sum(part);
-  double cc = wave_sum(constraint_update(c, 1));
+  double cc = wave_sum(constraint_update_any(c, 1));
   SYNC();
   if (gauss_out) *gauss_out = gauss;
   return gauss + cc;
@@ -522,7 +528,7 @@ DEV void solve_constraints(Ctx &c) {
     SYNC();
     gauss = gauss + alpha * q1 + alpha * alpha * q2;
     double oldcost = cost;
-    cost = gauss + wave_sum(constraint_update(c, 1));
+    cost = gauss + wave_sum(constraint_update_any(c, 1));
     SYNC();
     PROF(c, 12);
     // same stopping rule as the reference's Newton loop; the Hessian build / factorisation of an iteration that is

@@ -240,3 +240,49 @@ def test_cpp_host_planner_rejects_too_many_trajectories():
     p = cplanner.SamplingPlanner()
     with pytest.raises(cplanner.PlannerError, match="Too many trajectories"):
         p.Initialize(m, task, dict(sampling_trajectories=64), max_samples=32, max_horizon=8)
+
+
+def _full_size_properties(fn, N, H, P, sigma, span, n_oracle, tol):
+    """BASELINE-size run checked through size-independent properties (no full oracle run needed):
+    determinism, return = mean of the cost row (trajectory.cc:312-326), winner = first argmin (planner.cc:168-181),
+    candidate 0 = the un-noised nominal, shards reproduce the global plan bit-for-bit, a prefix of the candidates
+    against the oracle at the north_star tolerance."""
+    m, task, d = fn()
+    kt = np.linspace(0, span, P); kv = np.zeros((P, m["nu"]))
+    mocap = d["mocap"] if len(d["mocap"]) else None
+    kw = dict(state=d["state"], mocap=mocap, time=0.0, knot_times=kt, knot_values=kv, interpolation=2, num_trajectory=N,
+              horizon=H, sigma=(sigma, 0.0), seed=0x5EED, stream=0)
+    be = HipBackend(m, task, max_samples=N, max_horizon=H)
+    out = be.plan(**kw)
+    allc = be.fetch_all(N, H, P)
+    out2 = be.plan(**kw)
+    assert np.array_equal(out["returns"], out2["returns"]) and out["winner"] == out2["winner"]          # deterministic
+    assert np.all(np.isfinite(allc["states"])) and not out["failure"].any()
+    assert np.allclose(out["returns"], allc["costs"].mean(axis=1), rtol=1e-12, atol=0)                 # UpdateReturn
+    assert out["winner"] == int(np.argmin(out["returns"]))                                              # lowest index on ties
+    assert np.array_equal(allc["knots"][0], kv)                                                         # candidate 0: no noise
+    lo, hi = m["actuator_ctrlrange"].reshape(-1, 2).T
+    assert np.all(allc["knots"] >= lo) and np.all(allc["knots"] <= hi)                                  # clamped policies
+    assert np.array_equal(allc["times"], np.broadcast_to(allc["times"][0], allc["times"].shape))
+    # shards: 4 engines' worth of candidate ranges == the global plan (multi-GPU contract, §8e)
+    q = N // 4
+    parts = [be.plan(**kw, candidate_offset=k * q, num_local=q) for k in range(4)]
+    assert np.array_equal(np.concatenate([p["returns"] for p in parts]), out["returns"])
+    best = min(parts, key=lambda p: (p["winner_return"], p["winner"]))
+    assert best["winner"] == out["winner"]
+    # oracle on the first n_oracle candidates (same global Philox indexing)
+    o = ol.Oracle(m, task)
+    ref = o.plan(d["state"], mocap, 0.0, kt, kv, 2, N, H, sigma=(sigma, 0.0), seed=0x5EED, stream=0, nthreads=8,
+                 candidate_offset=0, num_local=n_oracle)
+    assert _rel(out["returns"][:n_oracle], ref["returns"]) < tol
+    assert _rel(allc["costs"][:n_oracle], ref["costs"]) < tol                                           # cost trace, 1e-5 rel
+    assert np.abs(allc["knots"][:n_oracle] - ref["knots"]).max() < 1e-14      # Box-Muller log/cos: device libm vs glibc, last ulp
+    be.close()
+
+
+def test_c2_quadruped_full_size_properties():
+    _full_size_properties(quadruped, 256, 100, 3, 0.04, 0.99, 8, 1e-5)
+
+
+def test_c3_humanoid_full_size_properties():
+    _full_size_properties(humanoid_track, 1024, 128, 16, 0.15, 0.635, 4, 1e-5)

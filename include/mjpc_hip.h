@@ -157,6 +157,13 @@ typedef struct MjpcHipPlanInput {
   const int *noise_sel;       /* [num_trajectory] 1 = use noise_exploration[1]; or NULL */
   uint64_t seed;
   uint64_t stream;            /* plan iteration counter */
+  /* Cross-Entropy sampling (mjpc/planners/cross_entropy/planner.cc:340-375): when non-NULL, candidate knots are
+   * nominal + noise_std[p*nu+k] * eps (absolute per-parameter std, no ctrlrange scaling), then clamped */
+  const double *noise_std;    /* [num_spline_points*nu] or NULL (= SamplingPlanner noise above) */
+  /* global index of the candidate that gets no noise: 0 for the SamplingPlanner (planner.cc:361); the Cross-Entropy
+   * planner perturbs all N candidates and rolls the nominal out as candidate N of num_trajectory = N+1
+   * (cross_entropy/planner.cc:377-415) */
+  int nominal_index;
 } MjpcHipPlanInput;
 
 typedef struct MjpcHipPlanOutput {
@@ -196,6 +203,9 @@ int mjpc_hip_plan_async(MjpcHipEngine *e, const MjpcHipPlanInput *in);
 int mjpc_hip_plan_fetch(MjpcHipEngine *e, MjpcHipPlanOutput *out);
 /* Copy any local candidate's trajectory / knots to host (GUI traces, RankedPlanner). */
 int mjpc_hip_get_candidate(MjpcHipEngine *e, int local_index, MjpcHipPlanOutput *out);
+/* Copy every local candidate's knot values [num_local][P][nu] of the last plan to host (elite statistics of the
+ * Cross-Entropy planner, cross_entropy/planner.cc:226-262). */
+int mjpc_hip_get_knots(MjpcHipEngine *e, double *knots);
 /* Average device time of the rollout kernel over the launches since the last call,
  * measured with hipEvents on the engine's stream; returns launches counted. */
 int mjpc_hip_kernel_time(MjpcHipEngine *e, double *avg_rollout_us, double *avg_total_us);

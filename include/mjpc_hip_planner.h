@@ -6,6 +6,7 @@
 //   mjpc/planners/sampling/policy.h,.cc      SamplingPolicy
 //   mjpc/trajectory.h:74-86                  Trajectory (public arrays)
 //   mjpc/planners/sampling/planner.h:51-162  SamplingPlanner (+ RankedPlanner virtuals, planners/planner.h:84-101)
+//   mjpc/planners/cross_entropy/planner.h:32-147  CrossEntropyPlanner (same rollout engine, elite mean/variance update)
 // Differences forced by the boundary: `mjModel*` / `const Task&` become the ABI's MjpcHipModel / MjpcHipTask views
 // plus the planner's <custom><numeric> settings (Numerics); `ThreadPool&` arguments are gone (the GPU is the pool);
 // `State` is passed as its raw arrays (State::CopyTo, mjpc/states/state.cc:128-135).
@@ -81,6 +82,8 @@ struct Numerics {                       // the planner's <custom><numeric> entri
   int sampling_sliding_plan = 0;
   int sampling_spline_points = kMaxTrajectoryHorizon;
   int max_samples = 4096;              // kMaxTrajectory is 128 in the reference (planners/planner.h:28); lifted here
+  double std_min = 0.1;                // cross-entropy: minimum std (cross_entropy/planner.cc:58)
+  int n_elite = -1;                    // cross-entropy: default max(sampling_trajectories / 10, 2) (planner.cc:63-64)
   int max_horizon = kMaxTrajectoryHorizon;   // device trajectory buffers are sized max_samples x max_horizon
   int device = 0;
 };
@@ -143,6 +146,57 @@ class SamplingPlanner {
   TimeSpline plan_scratch_;
   std::vector<double> knot_times_, knot_values_, winner_knots_;
   int last_horizon_ = 0, fetched_ = -1;
+  mutable std::shared_mutex mtx_;
+};
+
+// mjpc/planners/cross_entropy/planner.{h,cc}: all N candidates are perturbed with a per-parameter std (elite variance,
+// floored at std_min), the nominal (resampled) policy is rolled out as one extra candidate, the new policy is the mean
+// of the n_elite best candidates.  Quirks kept: the variance loop reads the best elite's parameters for every elite
+// (planner.cc:240-253); previous_policy is never refreshed by OptimizePolicy.
+class CrossEntropyPlanner {
+ public:
+  CrossEntropyPlanner() = default;
+  ~CrossEntropyPlanner();
+  CrossEntropyPlanner(const CrossEntropyPlanner&) = delete;
+  CrossEntropyPlanner& operator=(const CrossEntropyPlanner&) = delete;
+
+  void Initialize(const MjpcHipModel* model, const MjpcHipTask* task, const Numerics& numerics);
+  void Allocate();
+  void Reset(int horizon, const double* initial_repeated_action = nullptr);
+  void SetState(const double* state, const double* mocap, const double* userdata, double time);
+  void OptimizePolicy(int horizon);
+  void NominalTrajectory(int horizon);
+  void ActionFromPolicy(double* action, const double* state, double time, bool use_previous = false);
+  void ResamplePolicy(int horizon);
+  const Trajectory* BestTrajectory();                  // the nominal trajectory (planner.cc:418-420)
+  int NumParameters() { return policy.num_spline_points * nu_; }
+  void SetTask(const MjpcHipTask* task);
+
+  SamplingPolicy policy, resampled_policy, previous_policy;
+  std::vector<double> state, mocap, userdata;
+  double time = 0;
+  Trajectory nominal_trajectory;
+  std::vector<double> returns;                         // trajectory[i].total_return, i < num_trajectory
+  std::vector<int> failures;
+  std::vector<int> trajectory_order;
+  std::vector<double> parameters_scratch, times_scratch, variance;
+  double std_initial_ = 0.1, std_min_ = 0.1;
+  int n_elite_ = 2;
+  double improvement = 0;
+  double noise_compute_time = 0, rollouts_compute_time = 0, policy_update_compute_time = 0;   // microseconds
+  int interpolation_ = kZeroSpline;
+  int num_trajectory_ = 10;
+  unsigned long long seed = 0x5EED;
+  unsigned long long plan_iter = 0;
+  const double* injected_noise_eps = nullptr;          // [(num_trajectory + 1) * P * nu], standard normal (tests)
+
+ private:
+  MjpcHipEngine* engine_ = nullptr;
+  Numerics numerics_;
+  int nq_ = 0, nv_ = 0, na_ = 0, ns_ = 0, nu_ = 0, nmocap_ = 0, nuserdata_ = 0, nr_ = 0, ntrace_ = 0;
+  double timestep_ = 0;
+  std::vector<double> ctrlrange_, knot_values_, noise_std_, all_knots_;
+  int last_horizon_ = 0;
   mutable std::shared_mutex mtx_;
 };
 

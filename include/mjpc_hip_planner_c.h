@@ -52,6 +52,23 @@ int mjpc_planner_best_trajectory(void *planner, double *states, double *actions,
                                  double *costs, double *trace, double *total_return, int *failure); /* returns H */
 void mjpc_planner_timings(void *planner, double *noise_us, double *rollouts_us, double *policy_update_us);
 
+/* CrossEntropyPlanner (mjpc/planners/cross_entropy/planner.h:32-147): create = Initialize + Allocate */
+void *mjpc_cem_create(const MjpcHipModel *model, const MjpcHipTask *task, double std_initial, double std_min, int trajectories,
+                      int n_elite, int representation, int spline_points, int max_samples, int max_horizon, int device);
+void mjpc_cem_destroy(void *planner);
+void mjpc_cem_reset(void *planner, int horizon, const double *initial_repeated_action);
+void mjpc_cem_set_state(void *planner, const double *state, const double *mocap, const double *userdata, double time);
+void mjpc_cem_set_seed(void *planner, unsigned long long seed, unsigned long long plan_iter);
+void mjpc_cem_set_noise(void *planner, const double *eps);     /* borrowed until the next call */
+void mjpc_cem_optimize_policy(void *planner, int horizon);
+void mjpc_cem_nominal_trajectory(void *planner, int horizon);
+void mjpc_cem_action_from_policy(void *planner, double *action, double time, int use_previous);
+double mjpc_cem_improvement(void *planner);
+void mjpc_cem_returns(void *planner, double *out, int n);
+void mjpc_cem_variance(void *planner, double *out, int n);
+int mjpc_cem_policy(void *planner, double *times, double *values);                               /* returns P */
+int mjpc_cem_best_trajectory(void *planner, double *states, double *actions, double *costs, double *total_return);   /* returns H */
+
 #ifdef __cplusplus
 }
 #endif

@@ -71,6 +71,7 @@ class MjpcHipPlanInput(C.Structure):
         ("interpolation", C.c_int), ("num_trajectory", C.c_int), ("horizon", C.c_int),
         ("candidate_offset", C.c_int), ("num_local", C.c_int), ("noise_exploration", C.c_double * 2),
         ("noise_eps", c_double_p), ("noise_sel", c_int_p), ("seed", C.c_uint64), ("stream", C.c_uint64),
+        ("noise_std", c_double_p), ("nominal_index", C.c_int),
     ]
 
 
@@ -147,7 +148,7 @@ class CModel:
 
 def make_plan_input(cm: CModel, state, mocap, time, knot_times, knot_values, interpolation, num_trajectory, horizon,
                     sigma=(0.1, 0.0), noise_eps=None, noise_sel=None, seed=0, stream=0, candidate_offset=0,
-                    num_local=None, userdata=None):
+                    num_local=None, userdata=None, noise_std=None, nominal_index=0):
     keep = []
 
     def arr(x, n=None):
@@ -171,6 +172,9 @@ def make_plan_input(cm: CModel, state, mocap, time, knot_times, knot_values, int
     if noise_sel is not None:
         s = np.ascontiguousarray(np.asarray(noise_sel, dtype=np.int32)); keep.append(s); inp.noise_sel = _ip(s)
     inp.seed = int(seed); inp.stream = int(stream)
+    if noise_std is not None:
+        inp.noise_std = _dp(arr(noise_std))
+    inp.nominal_index = int(nominal_index)
     inp._keep = keep
     return inp
 
@@ -195,6 +199,7 @@ def load_engine():
     lib.mjpc_hip_plan_async.argtypes = [C.c_void_p, C.POINTER(MjpcHipPlanInput)]
     lib.mjpc_hip_plan_fetch.argtypes = [C.c_void_p, C.POINTER(MjpcHipPlanOutput)]
     lib.mjpc_hip_get_candidate.argtypes = [C.c_void_p, C.c_int, C.POINTER(MjpcHipPlanOutput)]
+    lib.mjpc_hip_get_knots.argtypes = [C.c_void_p, c_double_p]
     lib.mjpc_hip_kernel_time.argtypes = [C.c_void_p, c_double_p, c_double_p]
     lib.mjpc_hip_device_ptrs.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
     lib.mjpc_hip_debug_fetch_all.argtypes = [C.c_void_p] + [c_double_p] * 7 + [c_int_p]
@@ -208,5 +213,5 @@ def load_engine():
 EXPORTED_SYMBOLS = [
     "mjpc_hip_create", "mjpc_hip_destroy", "mjpc_hip_set_task", "mjpc_hip_plan", "mjpc_hip_plan_async",
     "mjpc_hip_plan_fetch", "mjpc_hip_get_candidate", "mjpc_hip_kernel_time", "mjpc_hip_device_ptrs",
-    "mjpc_hip_last_error", "mjpc_hip_version",
+    "mjpc_hip_last_error", "mjpc_hip_version", "mjpc_hip_get_knots",
 ]

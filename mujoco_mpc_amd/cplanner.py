@@ -26,6 +26,9 @@ PLANNER_C_SYMBOLS = [
     "mjpc_planner_copy_candidate_to_policy", "mjpc_planner_winner", "mjpc_planner_improvement", "mjpc_planner_num_parameters",
     "mjpc_planner_set_seed", "mjpc_planner_set_num_trajectory", "mjpc_planner_set_noise", "mjpc_planner_returns",
     "mjpc_planner_policy", "mjpc_planner_best_trajectory", "mjpc_planner_timings",
+    "mjpc_cem_create", "mjpc_cem_destroy", "mjpc_cem_reset", "mjpc_cem_set_state", "mjpc_cem_set_seed", "mjpc_cem_set_noise",
+    "mjpc_cem_optimize_policy", "mjpc_cem_nominal_trajectory", "mjpc_cem_action_from_policy", "mjpc_cem_improvement",
+    "mjpc_cem_returns", "mjpc_cem_variance", "mjpc_cem_policy", "mjpc_cem_best_trajectory",
 ]
 
 
@@ -80,6 +83,15 @@ def lib():
         "mjpc_planner_policy": (i, [vp, i, c_double_p, c_double_p]),
         "mjpc_planner_best_trajectory": (i, [vp] + [c_double_p] * 7 + [c_int_p]),
         "mjpc_planner_timings": (None, [vp, c_double_p, c_double_p, c_double_p]),
+        "mjpc_cem_create": (vp, [C.POINTER(capi.MjpcHipModel), C.POINTER(capi.MjpcHipTask), d, d, i, i, i, i, i, i, i]),
+        "mjpc_cem_destroy": (None, [vp]), "mjpc_cem_reset": (None, [vp, i, c_double_p]),
+        "mjpc_cem_set_state": (None, [vp, c_double_p, c_double_p, c_double_p, d]),
+        "mjpc_cem_set_seed": (None, [vp, C.c_ulonglong, C.c_ulonglong]), "mjpc_cem_set_noise": (None, [vp, c_double_p]),
+        "mjpc_cem_optimize_policy": (None, [vp, i]), "mjpc_cem_nominal_trajectory": (None, [vp, i]),
+        "mjpc_cem_action_from_policy": (None, [vp, c_double_p, d, i]), "mjpc_cem_improvement": (d, [vp]),
+        "mjpc_cem_returns": (None, [vp, c_double_p, i]), "mjpc_cem_variance": (None, [vp, c_double_p, i]),
+        "mjpc_cem_policy": (i, [vp, c_double_p, c_double_p]),
+        "mjpc_cem_best_trajectory": (i, [vp, c_double_p, c_double_p, c_double_p, c_double_p]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)
@@ -240,4 +252,88 @@ class SamplingPlanner:
         t.times = ti[:H]; t.residual = re.ravel()[:H * self.nr].reshape(H, self.nr); t.costs = co[:H]
         t.trace = tr.ravel()[:H * 3 * self.ntrace].reshape(H, 3 * self.ntrace)
         t.total_return = tot.value; t.failure = bool(fail.value)
+        return t
+
+
+class CrossEntropyPlanner:
+    """mjpc_hip::CrossEntropyPlanner (C++) driven from Python; names follow planners/cross_entropy/planner.h:32-147."""
+
+    def __init__(self):
+        self._L = lib()
+        self._h = None
+        self._noise = None
+
+    def Initialize(self, model: dict, task: dict, numerics: dict | None = None, max_samples=128, max_horizon=512, device=0):
+        numerics = numerics or {}
+        self.cm = capi.CModel(model, task)
+        self.nu = int(model["nu"]); self.ns = int(model["nq"] + model["nv"] + model["na"])
+        self.max_samples, self.max_horizon = int(max_samples), int(max_horizon)
+        self.P = int(numerics.get("sampling_spline_points", 512))
+        self.close()
+        h = self._L.mjpc_cem_create(C.byref(self.cm.c_model), C.byref(self.cm.c_task), float(numerics.get("sampling_exploration", 0.1)),
+                                    float(numerics.get("std_min", 0.1)), int(numerics.get("sampling_trajectories", 10)),
+                                    int(numerics.get("n_elite", -1)), int(numerics.get("sampling_representation", 0)), self.P,
+                                    self.max_samples, self.max_horizon, int(device))
+        self._h = C.c_void_p(h)
+        _check()
+
+    def Allocate(self):
+        pass
+
+    def close(self):
+        if self._h:
+            self._L.mjpc_cem_destroy(self._h); self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def Reset(self, horizon=0, initial_repeated_action=None):
+        a = None if initial_repeated_action is None else np.ascontiguousarray(initial_repeated_action, dtype=np.float64)
+        self._L.mjpc_cem_reset(self._h, int(horizon or 0), _dp(a))
+
+    def SetState(self, state, mocap=None, userdata=None, time=0.0):
+        s = np.ascontiguousarray(state, dtype=np.float64)
+        m = None if mocap is None else np.ascontiguousarray(mocap, dtype=np.float64)
+        u = None if userdata is None else np.ascontiguousarray(userdata, dtype=np.float64)
+        self._L.mjpc_cem_set_state(self._h, _dp(s), _dp(m), _dp(u), float(time))
+
+    def set_seed(self, seed, plan_iter=0): self._L.mjpc_cem_set_seed(self._h, int(seed), int(plan_iter))
+
+    def set_noise(self, eps):
+        self._noise = None if eps is None else np.ascontiguousarray(eps, dtype=np.float64)
+        self._L.mjpc_cem_set_noise(self._h, _dp(self._noise))
+
+    def OptimizePolicy(self, horizon): self._L.mjpc_cem_optimize_policy(self._h, int(horizon)); _check()
+    def NominalTrajectory(self, horizon): self._L.mjpc_cem_nominal_trajectory(self._h, int(horizon)); _check()
+
+    def ActionFromPolicy(self, time, use_previous=False):
+        a = np.zeros(self.nu)
+        self._L.mjpc_cem_action_from_policy(self._h, _dp(a), float(time), int(bool(use_previous))); _check()
+        return a
+
+    @property
+    def improvement(self): return self._L.mjpc_cem_improvement(self._h)
+
+    def returns(self, n):
+        out = np.zeros(int(n)); self._L.mjpc_cem_returns(self._h, _dp(out), int(n)); return out
+
+    def variance(self):
+        out = np.zeros(self.P * self.nu); self._L.mjpc_cem_variance(self._h, _dp(out), out.size); return out
+
+    def policy_knots(self):
+        P = self._L.mjpc_cem_policy(self._h, None, None)
+        t = np.zeros(max(P, 1)); v = np.zeros((max(P, 1), self.nu))
+        self._L.mjpc_cem_policy(self._h, _dp(t), _dp(v))
+        return t[:P], v[:P]
+
+    def BestTrajectory(self):
+        Hm = self.max_horizon
+        st = np.zeros((Hm, self.ns)); ac = np.zeros((Hm, self.nu)); co = np.zeros(Hm); tot = C.c_double()
+        H = self._L.mjpc_cem_best_trajectory(self._h, _dp(st), _dp(ac), _dp(co), C.byref(tot))
+        t = Trajectory()
+        t.horizon = H; t.states = st.ravel()[:H * self.ns].reshape(H, self.ns); t.actions = ac.ravel()[:H * self.nu].reshape(H, self.nu)
+        t.costs = co[:H]; t.total_return = tot.value
         return t

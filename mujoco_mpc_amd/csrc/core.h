@@ -1338,9 +1338,9 @@ DEV_NOINLINE void ph_init(KP Kc) {
     int k = e % nu;
     double v = K->knot_values[e];
     double lo = MD(actuator_ctrlrange)[2 * k], hi = MD(actuator_ctrlrange)[2 * k + 1];
-    if (gi != 0) {
-      double scale = 0.5 * (hi - lo);
-      v = add_mul3_rn(v, scale, std, K->noise_eps[(size_t)r * P * nu + e]);   // bit-exact candidate policy
+    if (gi != K->nominal_index) {
+      if (K->noise_std) v = add_mul3_rn(v, 1.0, K->noise_std[e], K->noise_eps[(size_t)r * P * nu + e]);   // Cross-Entropy: absolute std
+      else { double scale = 0.5 * (hi - lo); v = add_mul3_rn(v, scale, std, K->noise_eps[(size_t)r * P * nu + e]); }   // bit-exact candidate policy
       v = d_clip(v, lo, hi);
     }
     c.knot_values[e] = v;

@@ -98,7 +98,7 @@ struct MjpcHipEngine {
   hipStream_t stream = nullptr;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   // device buffers
-  double *d_state = nullptr, *d_mocap = nullptr, *d_kt = nullptr, *d_kv = nullptr, *d_eps = nullptr;
+  double *d_state = nullptr, *d_mocap = nullptr, *d_kt = nullptr, *d_kv = nullptr, *d_eps = nullptr, *d_std = nullptr;
   int *d_sel = nullptr;
   size_t eps_cap = 0;
   double *d_states = nullptr, *d_actions = nullptr, *d_times = nullptr, *d_residual = nullptr, *d_costs = nullptr,
@@ -107,7 +107,7 @@ struct MjpcHipEngine {
   int *d_failure = nullptr, *d_diag = nullptr, *d_winner = nullptr;
   long long *d_prof = nullptr;
   // pinned host staging
-  double *h_small = nullptr;   // state | mocap | knot_times | knot_values
+  double *h_small = nullptr;   // state | mocap | knot_times | knot_values | noise_std
   // last plan
   int last_H = 0, last_P = 0, last_nlocal = 0, last_offset = 0, pending = 0;
   // kernel timing accumulation
@@ -156,6 +156,7 @@ MjpcHipEngine *mjpc_hip_create(const MjpcHipModel *model, const MjpcHipTask *tas
   HIPCHKP(hipMalloc(&e->d_mocap, sizeof(double) * (7 * e->nmocap + 7)));
   HIPCHKP(hipMalloc(&e->d_kt, sizeof(double) * e->P_max));
   HIPCHKP(hipMalloc(&e->d_kv, sizeof(double) * (e->P_max * e->nu + 1)));
+  HIPCHKP(hipMalloc(&e->d_std, sizeof(double) * (e->P_max * e->nu + 1)));
   HIPCHKP(hipMalloc(&e->d_sel, sizeof(int) * NL));
   HIPCHKP(hipMalloc(&e->d_states, sizeof(double) * NL * H * e->ds));
   HIPCHKP(hipMalloc(&e->d_actions, sizeof(double) * NL * H * (e->nu + 1)));
@@ -170,7 +171,7 @@ MjpcHipEngine *mjpc_hip_create(const MjpcHipModel *model, const MjpcHipTask *tas
   HIPCHKP(hipMalloc(&e->d_prof, sizeof(long long) * NL * 24));
   HIPCHKP(hipMemset(e->d_prof, 0, sizeof(long long) * NL * 24));
   HIPCHKP(hipMalloc(&e->d_winner_val, sizeof(double) * 2));
-  HIPCHKP(hipHostMalloc(&e->h_small, sizeof(double) * (e->ds + 7 * e->nmocap + e->P_max * (e->nu + 1) + 16)));
+  HIPCHKP(hipHostMalloc(&e->h_small, sizeof(double) * (e->ds + 7 * e->nmocap + e->P_max * (2 * e->nu + 1) + 16)));
   e->kernel = pick_rollout_kernel(e->nv);
   HIPCHKP(hipFuncSetAttribute((const void *)e->kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_bytes));
   return e;
@@ -180,7 +181,7 @@ void mjpc_hip_destroy(MjpcHipEngine *e) {
   if (!e) return;
   hipSetDevice(e->device);
   if (e->stream) hipStreamSynchronize(e->stream);
-  void *bufs[] = {e->d_ib, e->d_db, e->d_state, e->d_mocap, e->d_kt, e->d_kv, e->d_eps, e->d_sel, e->d_states, e->d_actions,
+  void *bufs[] = {e->d_std, e->d_ib, e->d_db, e->d_state, e->d_mocap, e->d_kt, e->d_kv, e->d_eps, e->d_sel, e->d_states, e->d_actions,
                   e->d_times, e->d_residual, e->d_costs, e->d_trace, e->d_knots, e->d_returns, e->d_failure, e->d_diag,
                   e->d_winner, e->d_winner_val, e->d_prof};
   for (void *b : bufs) if (b) hipFree(b);
@@ -230,6 +231,10 @@ int mjpc_hip_plan_async(MjpcHipEngine *e, const MjpcHipPlanInput *in) {
   if (e->nmocap) HIPCHK(hipMemcpyAsync(e->d_mocap, hs + e->ds, sizeof(double) * 7 * e->nmocap, hipMemcpyHostToDevice, e->stream));
   HIPCHK(hipMemcpyAsync(e->d_kt, hkt, sizeof(double) * P, hipMemcpyHostToDevice, e->stream));
   HIPCHK(hipMemcpyAsync(e->d_kv, hkv, sizeof(double) * P * nu, hipMemcpyHostToDevice, e->stream));
+  if (in->noise_std) {
+    memcpy(hkv + e->P_max * nu, in->noise_std, sizeof(double) * P * nu);
+    HIPCHK(hipMemcpyAsync(e->d_std, hkv + e->P_max * nu, sizeof(double) * P * nu, hipMemcpyHostToDevice, e->stream));
+  }
   HIPCHK(hipEventRecord(e->ev[0], e->stream));
   if (in->noise_eps) {
     HIPCHK(hipMemcpyAsync(e->d_eps, in->noise_eps + (size_t)in->candidate_offset * P * nu, sizeof(double) * need, hipMemcpyHostToDevice, e->stream));
@@ -247,6 +252,7 @@ int mjpc_hip_plan_async(MjpcHipEngine *e, const MjpcHipPlanInput *in) {
   K.seed = in->seed; K.stream = in->stream;
   K.P = P; K.interp = in->interpolation; K.H = H; K.N = in->num_trajectory; K.offset = in->candidate_offset; K.nlocal = nl;
   K.use_device_noise = in->noise_eps ? 0 : 1;
+  K.noise_std = in->noise_std ? e->d_std : nullptr; K.nominal_index = in->nominal_index;
   K.states = e->d_states; K.actions = e->d_actions; K.times = e->d_times; K.residual = e->d_residual; K.costs = e->d_costs;
   K.trace = e->d_trace; K.knots = e->d_knots; K.returns = e->d_returns; K.failure = e->d_failure; K.diag = e->d_diag; K.prof = e->d_prof;
   HIPCHK(hipEventRecord(e->ev[1], e->stream));
@@ -297,6 +303,14 @@ int mjpc_hip_plan(MjpcHipEngine *e, const MjpcHipPlanInput *in, MjpcHipPlanOutpu
   int rc = mjpc_hip_plan_async(e, in);
   if (rc != 0) return rc;
   return mjpc_hip_plan_fetch(e, out);
+}
+
+int mjpc_hip_get_knots(MjpcHipEngine *e, double *knots) {
+  if (!e || !knots || e->last_nlocal < 1) { set_error("mjpc_hip_get_knots: no finished plan"); return -1; }
+  HIPCHK(hipSetDevice(e->device));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  HIPCHK(hipMemcpy(knots, e->d_knots, sizeof(double) * (size_t)e->last_nlocal * e->last_P * e->nu, hipMemcpyDeviceToHost));
+  return 0;
 }
 
 int mjpc_hip_get_candidate(MjpcHipEngine *e, int local_index, MjpcHipPlanOutput *out) {

@@ -89,11 +89,11 @@ struct KParams {
   const int *ibase; const double *dbase;   // the two model buffers in HBM; [0, cache_i) / [0, cache_d) are LDS-cached
   int cache_i, cache_d;
   // plan inputs (device pointers)
-  const double *state, *mocap, *knot_times, *knot_values, *noise_eps;
+  const double *state, *mocap, *knot_times, *knot_values, *noise_eps, *noise_std;
   const int *noise_sel;
   double time, sigma0, sigma1;
   unsigned long long seed, stream;
-  int P, interp, H, N, offset, nlocal, use_device_noise;
+  int P, interp, H, N, offset, nlocal, use_device_noise, nominal_index;
   // outputs (device), row-major per local candidate
   double *states, *actions, *times, *residual, *costs, *trace, *knots, *returns;
   int *failure, *diag;

@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -333,6 +334,198 @@ void SamplingPlanner::ActionFromCandidatePolicy(double* action, int candidate, c
   (void)s;
 }
 
+// ------------------------------------------------------------------ CrossEntropyPlanner
+CrossEntropyPlanner::~CrossEntropyPlanner() { if (engine_) mjpc_hip_destroy(engine_); }
+
+void CrossEntropyPlanner::Initialize(const MjpcHipModel* model, const MjpcHipTask* task, const Numerics& numerics) {   // planner.cc:41-72
+  numerics_ = numerics;
+  nq_ = model->nq; nv_ = model->nv; na_ = model->na; ns_ = nq_ + nv_ + na_; nu_ = model->nu; nmocap_ = model->nmocap;
+  nuserdata_ = model->nuserdata; nr_ = task->num_residual; ntrace_ = task->num_trace; timestep_ = model->timestep;
+  ctrlrange_.assign(model->actuator_ctrlrange, model->actuator_ctrlrange + 2 * nu_);
+  std_initial_ = numerics.sampling_exploration[0];
+  std_min_ = numerics.std_min;
+  num_trajectory_ = numerics.sampling_trajectories;
+  n_elite_ = numerics.n_elite > 0 ? numerics.n_elite : std::max(num_trajectory_ / 10, 2);
+  interpolation_ = numerics.sampling_representation;
+  if (num_trajectory_ > numerics.max_samples) {
+    char msg[128]; std::snprintf(msg, sizeof(msg), "Too many trajectories, %d is the maximum allowed.", numerics.max_samples);
+    Fatal(msg);
+    return;
+  }
+  if (engine_) { mjpc_hip_destroy(engine_); engine_ = nullptr; }
+  engine_ = mjpc_hip_create(model, task, numerics.max_samples + 1, numerics.max_horizon, numerics.device);   // + the nominal rollout
+  if (!engine_) { Fatal(mjpc_hip_last_error()); return; }
+  policy.Allocate(model, numerics.sampling_spline_points);
+  resampled_policy.Allocate(model, numerics.sampling_spline_points);
+  previous_policy.Allocate(model, numerics.sampling_spline_points);
+}
+
+void CrossEntropyPlanner::Allocate() {   // planner.cc:75-117
+  state.assign(ns_, 0.0); mocap.assign(7 * nmocap_, 0.0); userdata.assign(nuserdata_, 0.0);
+  int P = policy.num_spline_points;
+  parameters_scratch.assign((size_t)P * nu_, 0.0); times_scratch.assign(P, 0.0);
+  variance.assign((size_t)P * nu_, 0.0); noise_std_.assign((size_t)P * nu_, 0.0); knot_values_.assign((size_t)P * nu_, 0.0);
+  trajectory_order.resize(numerics_.max_samples);
+  std::iota(trajectory_order.begin(), trajectory_order.end(), 0);
+  returns.assign(numerics_.max_samples + 1, 0.0); failures.assign(numerics_.max_samples + 1, 0);
+  size_t Hm = (size_t)numerics_.max_horizon;
+  nominal_trajectory.dim_state = ns_; nominal_trajectory.dim_action = nu_; nominal_trajectory.dim_residual = nr_;
+  nominal_trajectory.dim_trace = 3 * ntrace_;
+  nominal_trajectory.states.assign(Hm * ns_, 0.0); nominal_trajectory.actions.assign(Hm * nu_, 0.0);
+  nominal_trajectory.times.assign(Hm, 0.0); nominal_trajectory.residual.assign(Hm * nr_, 0.0);
+  nominal_trajectory.costs.assign(Hm, 0.0); nominal_trajectory.trace.assign(Hm * 3 * std::max(ntrace_, 1), 0.0);
+}
+
+void CrossEntropyPlanner::Reset(int horizon, const double* initial_repeated_action) {   // planner.cc:120-155
+  std::fill(state.begin(), state.end(), 0.0); std::fill(mocap.begin(), mocap.end(), 0.0);
+  std::fill(userdata.begin(), userdata.end(), 0.0);
+  time = 0.0;
+  policy.Reset(horizon, initial_repeated_action);
+  resampled_policy.Reset(horizon, initial_repeated_action);
+  previous_policy.Reset(horizon, initial_repeated_action);
+  std::fill(parameters_scratch.begin(), parameters_scratch.end(), 0.0);
+  std::fill(times_scratch.begin(), times_scratch.end(), 0.0);
+  double var = std_initial_ * std_initial_;
+  std::fill(variance.begin(), variance.end(), var);
+  improvement = 0.0;
+}
+
+void CrossEntropyPlanner::SetState(const double* s, const double* m, const double* u, double t) {
+  std::copy(s, s + ns_, state.begin());
+  if (m) std::copy(m, m + 7 * nmocap_, mocap.begin());
+  if (u) std::copy(u, u + nuserdata_, userdata.begin());
+  time = t;
+}
+
+void CrossEntropyPlanner::SetTask(const MjpcHipTask* task) {
+  if (mjpc_hip_set_task(engine_, task) != 0) Fatal(mjpc_hip_last_error());
+}
+
+void CrossEntropyPlanner::ResamplePolicy(int horizon) {   // planner.cc:313-338
+  int num_spline_points = resampled_policy.num_spline_points;
+  double nominal_time = time;
+  double time_shift = std::max((horizon - 1) * timestep_ / (num_spline_points - 1), 1.0e-5);
+  for (int t = 0; t < num_spline_points; t++) {
+    times_scratch[t] = nominal_time;
+    resampled_policy.Action(parameters_scratch.data() + (size_t)t * nu_, nullptr, nominal_time);
+    nominal_time += time_shift;
+  }
+  SplineInterpolation keep = policy.plan.Interpolation();
+  resampled_policy.plan.Clear();
+  for (int t = 0; t < num_spline_points; t++) resampled_policy.plan.AddNode(times_scratch[t], parameters_scratch.data() + (size_t)t * nu_);
+  resampled_policy.plan.SetInterpolation(keep);
+}
+
+void CrossEntropyPlanner::OptimizePolicy(int horizon) {   // planner.cc:164-283
+  resampled_policy.plan.SetInterpolation((SplineInterpolation)interpolation_);
+  int num_trajectory = num_trajectory_;
+  n_elite_ = std::min(n_elite_, num_trajectory);
+  int n_elite = std::min(n_elite_, num_trajectory);
+  {
+    const std::shared_lock<std::shared_mutex> lock(mtx_);
+    resampled_policy.CopyFrom(policy, policy.num_spline_points);
+  }
+  ResamplePolicy(horizon);
+
+  // ----- rollouts (planner.cc:377-415): N perturbed candidates + the nominal as candidate N, one launch
+  auto rollouts_start = std::chrono::steady_clock::now();
+  int P = resampled_policy.num_spline_points;
+  for (int t = 0; t < P; t++) std::copy(resampled_policy.plan.NodeValues(t), resampled_policy.plan.NodeValues(t) + nu_, knot_values_.begin() + (size_t)t * nu_);
+  for (int k = 0; k < P * nu_; k++) noise_std_[k] = std::max(std::sqrt(variance[k]), std_min_);   // AddNoiseToPolicy, planner.cc:359-362
+  MjpcHipPlanInput in;
+  std::memset(&in, 0, sizeof(in));
+  in.state = state.data(); in.mocap = mocap.data(); in.userdata = userdata.data(); in.time = time;
+  in.knot_times = times_scratch.data(); in.knot_values = knot_values_.data(); in.num_spline_points = P;
+  in.interpolation = (int)resampled_policy.plan.Interpolation();
+  in.num_trajectory = num_trajectory + 1; in.horizon = horizon; in.candidate_offset = 0; in.num_local = num_trajectory + 1;
+  in.noise_eps = injected_noise_eps; in.seed = seed; in.stream = plan_iter++;
+  in.noise_std = noise_std_.data(); in.nominal_index = num_trajectory;
+  MjpcHipPlanOutput out;
+  std::memset(&out, 0, sizeof(out));
+  out.returns = returns.data(); out.failure = failures.data();
+  if (mjpc_hip_plan(engine_, &in, &out) != 0) { Fatal(mjpc_hip_last_error()); return; }
+  noise_compute_time = out.noise_compute_time_us;
+  last_horizon_ = horizon;
+  // nominal trajectory = candidate N
+  MjpcHipPlanOutput nom;
+  std::memset(&nom, 0, sizeof(nom));
+  nom.states = nominal_trajectory.states.data(); nom.actions = nominal_trajectory.actions.data(); nom.times = nominal_trajectory.times.data();
+  nom.residual = nominal_trajectory.residual.data(); nom.costs = nominal_trajectory.costs.data(); nom.trace = nominal_trajectory.trace.data();
+  if (mjpc_hip_get_candidate(engine_, num_trajectory, &nom) != 0) { Fatal(mjpc_hip_last_error()); return; }
+  nominal_trajectory.horizon = horizon; nominal_trajectory.total_return = returns[num_trajectory];
+  nominal_trajectory.failure = failures[num_trajectory] != 0;
+  all_knots_.resize((size_t)(num_trajectory + 1) * P * nu_);
+  if (mjpc_hip_get_knots(engine_, all_knots_.data()) != 0) { Fatal(mjpc_hip_last_error()); return; }
+  trajectory_order.resize(std::max((int)trajectory_order.size(), num_trajectory));
+  for (int i = 0; i < num_trajectory; i++) trajectory_order[i] = i;
+  std::stable_sort(trajectory_order.begin(), trajectory_order.begin() + num_trajectory,
+                   [this](int a, int b) { return returns[a] < returns[b]; });
+  rollouts_compute_time = Micros(rollouts_start);
+
+  // ----- update policy (planner.cc:205-283)
+  auto policy_update_start = std::chrono::steady_clock::now();
+  int num_parameters = P * nu_;
+  double avg_return = 0.0;
+  std::fill(parameters_scratch.begin(), parameters_scratch.end(), 0.0);
+  for (int i = 0; i < n_elite; i++) {
+    int idx = trajectory_order[i];
+    const double* kn = all_knots_.data() + (size_t)idx * num_parameters;
+    for (int k = 0; k < num_parameters; k++) parameters_scratch[k] += kn[k];
+    avg_return += returns[idx];
+  }
+  for (int k = 0; k < num_parameters; k++) parameters_scratch[k] *= 1.0 / n_elite;     // mju_scl
+  avg_return /= n_elite;
+  std::fill(variance.begin(), variance.end(), 0.0);
+  {
+    const double* best = all_knots_.data() + (size_t)trajectory_order[0] * num_parameters;   // the reference reads elite 0 for every i
+    for (int k = 0; k < num_parameters; k++) {
+      double p_avg = parameters_scratch[k];
+      for (int i = 0; i < n_elite; i++) {
+        double diff = best[k] - p_avg;
+        variance[k] += diff * diff / (n_elite - 1);
+      }
+    }
+  }
+  {
+    const std::unique_lock<std::shared_mutex> lock(mtx_);
+    policy.plan.Clear();
+    policy.plan.SetInterpolation((SplineInterpolation)interpolation_);
+    for (int t = 0; t < P; t++) policy.plan.AddNode(times_scratch[t], parameters_scratch.data() + (size_t)t * nu_);
+  }
+  improvement = std::max(avg_return - returns[trajectory_order[0]], 0.0);
+  policy_update_compute_time = Micros(policy_update_start);
+}
+
+void CrossEntropyPlanner::NominalTrajectory(int horizon) {   // planner.cc:286-297: rollout of resampled_policy
+  int P = (int)resampled_policy.plan.Size();
+  std::vector<double> kt(std::max(P, 1), time), kv((size_t)std::max(P, 1) * nu_, 0.0);
+  for (int p = 0; p < P; p++) {
+    kt[p] = resampled_policy.plan.NodeTime(p);
+    std::copy(resampled_policy.plan.NodeValues(p), resampled_policy.plan.NodeValues(p) + nu_, kv.begin() + (size_t)p * nu_);
+  }
+  MjpcHipPlanInput in;
+  std::memset(&in, 0, sizeof(in));
+  in.state = state.data(); in.mocap = mocap.data(); in.userdata = userdata.data(); in.time = time;
+  in.knot_times = kt.data(); in.knot_values = kv.data(); in.num_spline_points = std::max(P, 1);
+  in.interpolation = (int)resampled_policy.plan.Interpolation(); in.num_trajectory = 1; in.horizon = horizon; in.num_local = 1;
+  MjpcHipPlanOutput out;
+  std::memset(&out, 0, sizeof(out));
+  double ret = 0; int fail = 0;
+  out.returns = &ret; out.failure = &fail;
+  out.states = nominal_trajectory.states.data(); out.actions = nominal_trajectory.actions.data(); out.times = nominal_trajectory.times.data();
+  out.residual = nominal_trajectory.residual.data(); out.costs = nominal_trajectory.costs.data(); out.trace = nominal_trajectory.trace.data();
+  if (mjpc_hip_plan(engine_, &in, &out) != 0) { Fatal(mjpc_hip_last_error()); return; }
+  nominal_trajectory.horizon = horizon; nominal_trajectory.total_return = ret; nominal_trajectory.failure = fail != 0;
+}
+
+void CrossEntropyPlanner::ActionFromPolicy(double* action, const double* s, double t, bool use_previous) {   // planner.cc:302-310
+  const std::shared_lock<std::shared_mutex> lock(mtx_);
+  if (use_previous) previous_policy.Action(action, s, t);
+  else policy.Action(action, s, t);
+}
+
+const Trajectory* CrossEntropyPlanner::BestTrajectory() { return &nominal_trajectory; }
+
 }  // namespace mjpc_hip
 
 // ====================================================================== flat C wrapper (tests / ctypes)
@@ -408,6 +601,48 @@ int mjpc_planner_best_trajectory(void* p, double* states, double* actions, doubl
   if (trace) std::copy(t->trace.begin(), t->trace.begin() + H * t->dim_trace, trace);
   if (total_return) *total_return = t->total_return;
   if (failure) *failure = t->failure ? 1 : 0;
+  return t->horizon;
+}
+
+// ---- CrossEntropyPlanner
+void* mjpc_cem_create(const MjpcHipModel* model, const MjpcHipTask* task, double std_initial, double std_min, int trajectories,
+                      int n_elite, int representation, int spline_points, int max_samples, int max_horizon, int device) {
+  auto* p = new mjpc_hip::CrossEntropyPlanner();
+  mjpc_hip::Numerics n;
+  n.sampling_exploration[0] = std_initial; n.std_min = std_min; n.sampling_trajectories = trajectories; n.n_elite = n_elite;
+  n.sampling_representation = representation; n.sampling_spline_points = spline_points; n.max_samples = max_samples;
+  n.max_horizon = max_horizon; n.device = device;
+  p->Initialize(model, task, n);
+  p->Allocate();
+  return p;
+}
+void mjpc_cem_destroy(void* p) { delete (mjpc_hip::CrossEntropyPlanner*)p; }
+void mjpc_cem_reset(void* p, int horizon, const double* a) { ((mjpc_hip::CrossEntropyPlanner*)p)->Reset(horizon, a); }
+void mjpc_cem_set_state(void* p, const double* s, const double* m, const double* u, double t) { ((mjpc_hip::CrossEntropyPlanner*)p)->SetState(s, m, u, t); }
+void mjpc_cem_set_seed(void* p, unsigned long long seed, unsigned long long it) { auto* q = (mjpc_hip::CrossEntropyPlanner*)p; q->seed = seed; q->plan_iter = it; }
+void mjpc_cem_set_noise(void* p, const double* eps) { ((mjpc_hip::CrossEntropyPlanner*)p)->injected_noise_eps = eps; }
+void mjpc_cem_optimize_policy(void* p, int horizon) { ((mjpc_hip::CrossEntropyPlanner*)p)->OptimizePolicy(horizon); }
+void mjpc_cem_nominal_trajectory(void* p, int horizon) { ((mjpc_hip::CrossEntropyPlanner*)p)->NominalTrajectory(horizon); }
+void mjpc_cem_action_from_policy(void* p, double* a, double t, int prev) { ((mjpc_hip::CrossEntropyPlanner*)p)->ActionFromPolicy(a, nullptr, t, prev != 0); }
+double mjpc_cem_improvement(void* p) { return ((mjpc_hip::CrossEntropyPlanner*)p)->improvement; }
+void mjpc_cem_returns(void* p, double* out, int n) { auto* q = (mjpc_hip::CrossEntropyPlanner*)p; std::copy(q->returns.begin(), q->returns.begin() + n, out); }
+void mjpc_cem_variance(void* p, double* out, int n) { auto* q = (mjpc_hip::CrossEntropyPlanner*)p; std::copy(q->variance.begin(), q->variance.begin() + n, out); }
+int mjpc_cem_policy(void* p, double* times, double* values) {
+  auto* q = (mjpc_hip::CrossEntropyPlanner*)p;
+  int P = (int)q->policy.plan.Size();
+  for (int i = 0; i < P; i++) {
+    if (times) times[i] = q->policy.plan.NodeTime(i);
+    if (values) std::copy(q->policy.plan.NodeValues(i), q->policy.plan.NodeValues(i) + q->policy.nu, values + (size_t)i * q->policy.nu);
+  }
+  return P;
+}
+int mjpc_cem_best_trajectory(void* p, double* states, double* actions, double* costs, double* total_return) {
+  const mjpc_hip::Trajectory* t = ((mjpc_hip::CrossEntropyPlanner*)p)->BestTrajectory();
+  size_t H = (size_t)t->horizon;
+  if (states) std::copy(t->states.begin(), t->states.begin() + H * t->dim_state, states);
+  if (actions) std::copy(t->actions.begin(), t->actions.begin() + H * t->dim_action, actions);
+  if (costs) std::copy(t->costs.begin(), t->costs.begin() + H, costs);
+  if (total_return) *total_return = t->total_return;
   return t->horizon;
 }
 

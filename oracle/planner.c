@@ -176,7 +176,15 @@ static void make_candidate_knots(const OModel *om, const MjpcHipPlanInput *in, i
   const MjpcHipModel *m = &om->m;
   int P = in->num_spline_points, nu = m->nu;
   o_copy(knots, in->knot_values, P * nu);
-  if (i == 0) return;                              /* planner.cc:361 */
+  if (i == in->nominal_index) return;              /* planner.cc:361 (index 0); cross_entropy/planner.cc:412 (extra rollout) */
+  if (in->noise_std) {                             /* cross_entropy/planner.cc:340-375: absolute per-parameter std */
+    for (int p = 0; p < P; p++) {
+      for (int k = 0; k < nu; k++) knots[p * nu + k] += in->noise_std[p * nu + k] * eps[((size_t)i * P + p) * nu + k];
+      for (int k = 0; k < nu; k++)
+        knots[p * nu + k] = o_clip(knots[p * nu + k], m->actuator_ctrlrange[2 * k], m->actuator_ctrlrange[2 * k + 1]);
+    }
+    return;
+  }
   double std = in->noise_exploration[0];
   if (in->noise_exploration[1] > 0 && sel && sel[i]) std = in->noise_exploration[1];
   for (int p = 0; p < P; p++) {

@@ -37,6 +37,25 @@ def test_kernel_source_matches_oracle(name, P, H, N, sigma, tol):
     assert b["lds_doubles"] * 8 <= 160 * 1024          # per-candidate state must fit one CU's LDS
 
 
+def test_cross_entropy_noise_mode_in_oracle_and_kernel_source():
+    """ABI extension for the Cross-Entropy planner (cross_entropy/planner.cc:340-415): absolute per-parameter std, every
+    candidate perturbed except `nominal_index`."""
+    m, task, d = cartpole()
+    P, H, N = 4, 20, 7
+    kt = np.linspace(0, 0.19, P); kv = np.random.default_rng(3).uniform(-0.2, 0.2, (P, 1))
+    eps, _ = ol.noise(5, 0, 0, N, P, 1)
+    std = np.array([0.05, 0.4, 3.0, 0.0])
+    o = ol.Oracle(m, task)
+    a = o.plan(d["state"], None, 0.0, kt, kv, 2, N, H, noise_eps=eps, noise_std=std, nominal_index=N - 1)
+    expect = np.clip(kv[None] + std[None, :, None] * eps.reshape(N, P, 1), -1.0, 1.0)
+    expect[N - 1] = kv
+    assert np.array_equal(a["knots"], expect)
+    assert np.any(a["knots"][0] != kv) and np.any(np.abs(a["knots"]) == 1.0)         # candidate 0 is perturbed; clamping is hit
+    b = emu_lib.plan(m, task, d["state"], None, 0.0, kt, kv, 2, N, H, noise_eps=eps, noise_std=std, nominal_index=N - 1)
+    assert np.array_equal(a["knots"], b["knots"])
+    assert _rel(b["returns"], a["returns"]) < 1e-12
+
+
 def test_engine_library_exports_every_declared_symbol():
     """libmjpc_hip.so loads without a GPU and exports exactly what include/mjpc_hip.h declares."""
     import __graft_entry__ as g

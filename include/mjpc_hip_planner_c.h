@@ -69,6 +69,14 @@ void mjpc_cem_variance(void *planner, double *out, int n);
 int mjpc_cem_policy(void *planner, double *times, double *values);                               /* returns P */
 int mjpc_cem_best_trajectory(void *planner, double *states, double *actions, double *costs, double *total_return);   /* returns H */
 
+/* Closed-loop harness (include/mjpc_hip_testspeed.h; mjpc/testspeed.cc:44-129 `SynchronousPlanningCost`): world and planner on the
+ * HIP engine.  planner_kind 0 = handle from mjpc_planner_create, 1 = handle from mjpc_cem_create.  state / mocap are in-out;
+ * cost_per_step[ceil(total_time/timestep)] optional; out[6] = {average_cost, wall_seconds, realtime_factor, plan_seconds,
+ * plan_steps, failure}.  Returns the total cost. */
+double mjpc_testspeed_run(const MjpcHipModel *model, const MjpcHipTask *task, void *planner, int planner_kind, double *state,
+                          double *mocap, double time0, int horizon, int steps_per_planning_iteration, double total_time, int device,
+                          double *cost_per_step, double *out);
+
 #ifdef __cplusplus
 }
 #endif

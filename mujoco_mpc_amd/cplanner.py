@@ -29,6 +29,7 @@ PLANNER_C_SYMBOLS = [
     "mjpc_cem_create", "mjpc_cem_destroy", "mjpc_cem_reset", "mjpc_cem_set_state", "mjpc_cem_set_seed", "mjpc_cem_set_noise",
     "mjpc_cem_optimize_policy", "mjpc_cem_nominal_trajectory", "mjpc_cem_action_from_policy", "mjpc_cem_improvement",
     "mjpc_cem_returns", "mjpc_cem_variance", "mjpc_cem_policy", "mjpc_cem_best_trajectory",
+    "mjpc_testspeed_run",
 ]
 
 
@@ -92,6 +93,8 @@ def lib():
         "mjpc_cem_returns": (None, [vp, c_double_p, i]), "mjpc_cem_variance": (None, [vp, c_double_p, i]),
         "mjpc_cem_policy": (i, [vp, c_double_p, c_double_p]),
         "mjpc_cem_best_trajectory": (i, [vp, c_double_p, c_double_p, c_double_p, c_double_p]),
+        "mjpc_testspeed_run": (d, [C.POINTER(capi.MjpcHipModel), C.POINTER(capi.MjpcHipTask), vp, i, c_double_p, c_double_p, d, i, i, d, i,
+                                   c_double_p, c_double_p]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)
@@ -337,3 +340,21 @@ class CrossEntropyPlanner:
         t.horizon = H; t.states = st.ravel()[:H * self.ns].reshape(H, self.ns); t.actions = ac.ravel()[:H * self.nu].reshape(H, self.nu)
         t.costs = co[:H]; t.total_return = tot.value
         return t
+
+
+def testspeed(planner, state, mocap=None, time0=0.0, horizon=None, steps_per_planning_iteration=1, total_time=1.0, device=0):
+    """mjpc/testspeed.cc:44-129 (`SynchronousPlanningCost`) through the C++ harness: `planner` is a cplanner.SamplingPlanner or
+    cplanner.CrossEntropyPlanner that has been Initialize()d / Reset(); the world is stepped on the HIP engine as well."""
+    L = lib()
+    cm = planner.cm
+    m = cm.model
+    nsteps = int(np.ceil(total_time / m["timestep"]))
+    st = np.ascontiguousarray(state, dtype=np.float64).copy()
+    mc = None if (mocap is None or m["nmocap"] == 0) else np.ascontiguousarray(mocap, dtype=np.float64).copy()
+    costs = np.zeros(nsteps); out = np.zeros(6)
+    kind = 1 if isinstance(planner, CrossEntropyPlanner) else 0
+    total = L.mjpc_testspeed_run(C.byref(cm.c_model), C.byref(cm.c_task), planner._h, kind, _dp(st), _dp(mc), float(time0), int(horizon),
+                                 int(steps_per_planning_iteration), float(total_time), int(device), _dp(costs), _dp(out))
+    _check()
+    return dict(total_cost=total, average_cost=out[0], wall_seconds=out[1], realtime_factor=out[2], plan_seconds=out[3],
+                plan_steps=int(out[4]), failure=bool(out[5]), cost_per_step=costs, state=st, mocap=mc)

@@ -70,6 +70,7 @@ struct Ctx {
   int *efc_type, *efc_id, *efc_state, *efc_dof, *con_i, *active, *misc, *hpair;
   double time;
   int ncon, nefc, nsingle, warning, solver_iter, cross;
+  int role;            // 0: owns the rollout scalars (misc[0..8], time); 1: side wave, only reports warnings (misc[11])
 };
 
 DEV void ctx_init(Ctx &c, const KParams *K, double *base) {
@@ -93,17 +94,18 @@ DEV void ctx_init(Ctx &c, const KParams *K, double *base) {
   int *ib = (int *)(base + L.ints);
   c.efc_type = ib + L.i_efc_type; c.efc_id = ib + L.i_efc_id; c.efc_state = ib + L.i_efc_state; c.efc_dof = ib + L.i_efc_dof;
   c.con_i = ib + L.i_con; c.active = ib + L.i_active; c.misc = ib + L.i_misc; c.hpair = ib + L.i_hpair;
-  c.time = 0; c.ncon = 0; c.nefc = 0; c.nsingle = 0; c.warning = 0; c.solver_iter = 0; c.cross = 0;
+  c.time = 0; c.ncon = 0; c.nefc = 0; c.nsingle = 0; c.warning = 0; c.solver_iter = 0; c.cross = 0; c.role = 0;
 #if defined(MJPC_PROFILE) && !defined(MJPC_EMU)
   c.prof = (long long *)(base + L.prof);
 #endif
 }
 
 // rollout scalars shared between phases live in LDS: misc[0..4] = ncon, nefc, nsingle, warning, solver_iter; red[0] = time
-DEV void ctx_open(Ctx &c, KP Kc) {
+DEV void ctx_open(Ctx &c, KP Kc, int role = 0) {
   ctx_init(c, kp_generic(Kc), lds_base());
+  c.role = role;
   c.ncon = uniform_i(c.misc[0]); c.nefc = uniform_i(c.misc[1]); c.nsingle = uniform_i(c.misc[2]);
-  c.warning = uniform_i(c.misc[3]); c.solver_iter = uniform_i(c.misc[4]); c.cross = uniform_i(c.misc[8]);
+  c.warning = uniform_i(c.misc[3]) | uniform_i(c.misc[11]); c.solver_iter = uniform_i(c.misc[4]); c.cross = uniform_i(c.misc[8]);
   c.time = c.red[0];
 }
 #define MD(f) (c.mcd + (int)(c.M->f - c.gdb))
@@ -111,6 +113,11 @@ DEV void ctx_open(Ctx &c, KP Kc) {
 #define MDM() ((const unsigned long long *)(c.mcd + (int)((const double *)c.M->body_dofmask - c.gdb)))
 DEV void ctx_close(Ctx &c) {
   SYNC();
+  if (c.role != 0) {            // the side wave never writes the owner's scalars
+    if (LANE == 0) c.misc[11] = c.warning;
+    SYNC();
+    return;
+  }
   if (LANE == 0) {
     c.misc[0] = c.ncon; c.misc[1] = c.nefc; c.misc[2] = c.nsingle; c.misc[3] = c.warning; c.misc[4] = c.solver_iter; c.misc[8] = c.cross;
     c.red[0] = c.time;
@@ -1371,55 +1378,59 @@ DEV_NOINLINE void ph_init(KP Kc) {
   ctx_close(c);
 }
 
-// policy -> ctrl (policy.cc:52-59), mj_checkPos / mj_checkVel; returns the warning mask
-DEV_NOINLINE int ph_action(KP Kc, int t) {
+// role 0, head of a step: policy -> ctrl (policy.cc:52-59), mj_checkPos / mj_checkVel, then kinematics and the
+// com-based quantities every other phase reads.  A bad state raises misc[10] (both roles leave the loop).
+template <int NVT>
+DEV_NOINLINE void ph_head(KP Kc, int t, int last) {
   Ctx c; ctx_open(c, Kc);
   const KParams *K = c.K;
   const DevModel &M = *c.M;
   Rows R = out_rows(K);
   int nu = M.nu;
-  PFOR(k, nu) {
-    double a = spline_sample(c.knot_times, c.knot_values, K->P, nu, K->interp, c.time, k);
-    a = d_clip(a, MD(actuator_ctrlrange)[2 * k], MD(actuator_ctrlrange)[2 * k + 1]);
-    c.ctrl[k] = a; R.actions[t * nu + k] = a;
+  if (!last) {
+    PFOR(k, nu) {
+      double a = spline_sample(c.knot_times, c.knot_values, K->P, nu, K->interp, c.time, k);
+      a = d_clip(a, MD(actuator_ctrlrange)[2 * k], MD(actuator_ctrlrange)[2 * k + 1]);
+      c.ctrl[k] = a; R.actions[t * nu + k] = a;
+    }
+    SYNC();
+    if (bad_values(c.qpos, M.nq)) c.warning |= WARN_BADQPOS;
+    if (bad_values(c.qvel, M.nv)) c.warning |= WARN_BADQVEL;
+    if (c.warning) { if (LANE == 0) c.misc[10] = 1; ctx_close(c); return; }
   }
-  SYNC();
-  if (bad_values(c.qpos, M.nq)) c.warning |= WARN_BADQPOS;
-  if (bad_values(c.qvel, M.nv)) c.warning |= WARN_BADQVEL;
-  int w = c.warning;
-  ctx_close(c);
-  return w;
-}
-
-template <int NVT>
-DEV_NOINLINE void ph_position(KP Kc) {
-  Ctx c; ctx_open(c, Kc);
   PROF(c, 0);
   kinematics(c); PROF(c, 1);
   com_pos(c); PROF(c, 2);
-  crb_and_factor<NVT>(c); PROF(c, 3);
-  collision(c); PROF(c, 4);
-  make_constraint(c); PROF(c, 5);
   ctx_close(c);
 }
-template <int NVT>
-DEV_NOINLINE void ph_velocity(KP Kc) {
+// role 0: contacts and constraint rows (needs positions + qvel only)
+DEV_NOINLINE void ph_constraints(KP Kc) {
   Ctx c; ctx_open(c, Kc);
-  velocity_stage<NVT>(c); PROF(c, 6);
+  collision(c); PROF(c, 4);
+  make_constraint(c); PROF(c, 5);
   make_impedance(c); PROF(c, 7);
   ctx_close(c);
 }
+// role 1, concurrently with ph_constraints: joint-space inertia + its factor, smooth dynamics (qfrc_smooth, qacc_smooth)
 template <int NVT>
-DEV_NOINLINE void ph_solve(KP Kc) {
+DEV_NOINLINE void ph_smooth(KP Kc) {
+  Ctx c; ctx_open(c, Kc, 1);
+  crb_and_factor<NVT>(c); PROF(c, 3);
+  velocity_stage<NVT>(c); PROF(c, 6);
+  ctx_close(c);
+}
+template <int NVT>
+DEV_NOINLINE void ph_solve(KP Kc, int last) {
   Ctx c; ctx_open(c, Kc);
   solve_constraints<NVT>(c); PROF(c, 8);
+  if (!last && bad_values(c.qacc, c.M->nv)) c.warning |= WARN_BADQACC;
   ctx_close(c);
 }
 
 // residual (sensor callback at mjSTAGE_ACC), trace, cost; returns (cost, warning)
 struct CostOut { double cost; int warning; };
-DEV_NOINLINE CostOut ph_residual_cost(KP Kc, int t, int last) {
-  Ctx c; ctx_open(c, Kc);
+DEV_NOINLINE CostOut ph_residual_cost(KP Kc, int t, int last) {        // role 1, concurrently with ph_solve
+  Ctx c; ctx_open(c, Kc, 1);
   const KParams *K = c.K;
   const DevModel &M = *c.M;
   const DevTask &T = M.task;
@@ -1432,7 +1443,6 @@ DEV_NOINLINE CostOut ph_residual_cost(KP Kc, int t, int last) {
     const double *src = ty == 6 ? c.site_xpos + 3 * id : (ty == 5 ? c.geom_xpos + 3 * id : (ty == 1 ? c.xipos + 3 * id : c.xpos + 3 * id));
     d_copy3(R.trace + t * R.ntr + 3 * i, src);
   }
-  if (!last && bad_values(c.qacc, M.nv)) c.warning |= WARN_BADQACC;
   CostOut o;
   o.cost = cost_value(c, c.residual);      // UpdateReturn (trajectory.cc:312-326) folded into the loop
   if (LANE == 0) R.costs[t] = o.cost;
@@ -1479,8 +1489,8 @@ DEV_NOINLINE void ph_integrate(KP Kc, int t) {
   ctx_close(c);
 }
 
-DEV_NOINLINE void ph_finish(KP Kc, double total, int failure) {
-  Ctx c; ctx_open(c, Kc);
+DEV_NOINLINE void ph_finish(KP Kc, double total, int failure) {        // role 1 (it holds the cost sum)
+  Ctx c; ctx_open(c, Kc, 1);
   const KParams *K = c.K;
   int r = cand_index(), H = K->H;
   if (LANE == 0) {
@@ -1499,19 +1509,26 @@ DEV_NOINLINE void ph_finish(KP Kc, double total, int failure) {
 template <int NVT>
 DEV void rollout(KP Kc) {
   int H = Kc->H;
-  ph_init(Kc);
+  const bool r0 = ROLE0, r1 = ROLE1;
+  if (r0) ph_init(Kc);
+  XBAR();
+  const int *misc = (const int *)(lds_base() + Kc->L.ints) + Kc->L.i_misc;
   double total = 0;
   int failure = 0;
   for (int t = 0; t < H; t++) {
     int last = (t == H - 1);
-    if (!last && ph_action(Kc, t)) { failure = 1; break; }
-    ph_position<NVT>(Kc);
-    ph_velocity<NVT>(Kc);
-    ph_solve<NVT>(Kc);
-    CostOut o = ph_residual_cost(Kc, t, last);
-    if (o.warning) { failure = 1; break; }
-    if (!last) ph_integrate<NVT>(Kc, t);
-    total += o.cost;
+    if (r0) ph_head<NVT>(Kc, t, last);
+    XBAR();
+    if (uniform_i(misc[10])) { failure = 1; break; }
+    if (r0) ph_constraints(Kc);
+    if (r1) ph_smooth<NVT>(Kc);
+    XBAR();
+    if (r0) ph_solve<NVT>(Kc, last);
+    if (r1) { CostOut o = ph_residual_cost(Kc, t, last); total += o.cost; }
+    XBAR();
+    if (uniform_i(misc[3]) | uniform_i(misc[11])) { failure = 1; break; }
+    if (r0 && !last) ph_integrate<NVT>(Kc, t);
   }
-  ph_finish(Kc, total, failure);
+  XBAR();
+  if (r1) ph_finish(Kc, total, failure);
 }

@@ -20,7 +20,7 @@
 // ------------------------------------------------------------------------------ kernels
 // NVT = number of dofs known at compile time (register-resident factorisations), 0 = generic
 template <int NVT>
-__global__ void __launch_bounds__(64) rollout_kernel(const KParams K) {
+__global__ void __launch_bounds__(64 * MJPC_WAVES) rollout_kernel(const KParams K) {
   if ((int)blockIdx.x >= K.nlocal) return;
   rollout<NVT>((KP)__builtin_amdgcn_kernarg_segment_ptr());
 }
@@ -256,7 +256,7 @@ int mjpc_hip_plan_async(MjpcHipEngine *e, const MjpcHipPlanInput *in) {
   K.states = e->d_states; K.actions = e->d_actions; K.times = e->d_times; K.residual = e->d_residual; K.costs = e->d_costs;
   K.trace = e->d_trace; K.knots = e->d_knots; K.returns = e->d_returns; K.failure = e->d_failure; K.diag = e->d_diag; K.prof = e->d_prof;
   HIPCHK(hipEventRecord(e->ev[1], e->stream));
-  hipLaunchKernelGGL(e->kernel, dim3(nl), dim3(64), e->lds_bytes, e->stream, K);
+  hipLaunchKernelGGL(e->kernel, dim3(nl), dim3(64 * MJPC_WAVES), e->lds_bytes, e->stream, K);
   HIPCHK(hipEventRecord(e->ev[2], e->stream));
   hipLaunchKernelGGL(argmin_kernel, dim3(1), dim3(64), 0, e->stream, e->d_returns, nl, e->d_winner, e->d_winner_val);
   HIPCHK(hipEventRecord(e->ev[3], e->stream));

@@ -17,6 +17,10 @@
 #define LANE 0
 #define NLANE 1
 #define SYNC() ((void)0)
+// the emulation runs both wave roles of a candidate one after the other in a single thread
+#define XBAR() ((void)0)
+#define ROLE0 1
+#define ROLE1 1
 DEV double mul_rn(double a, double b) { return a * b; }   // emu is built with -ffp-contract=off
 DEV double add_rn(double a, double b) { return a + b; }
 DEV double add_mul3_rn(double a, double b, double c, double d) { return a + (b * c) * d; }
@@ -31,9 +35,28 @@ DEV int wave_any(int flag) { return flag != 0; }
 #include <hip/hip_runtime.h>
 #define DEV static __device__ __forceinline__
 #define DEV_NOINLINE static __device__ __noinline__
-#define LANE ((int)threadIdx.x)
+// A candidate is owned by MJPC_WAVES (1 or 2) wavefronts of one workgroup on different SIMDs of a CU:
+//   role 0 (wave 0): the serial critical path (kinematics -> collision/constraints -> Newton solver -> integration);
+//   role 1 (last wave): work that only hangs off that path (inertia + factor M + smooth dynamics while role 0 builds
+//   the constraints; residual / cost / trajectory record while role 0 solves).
+// SYNC() orders LDS traffic inside ONE wave (DS operations of a wave execute in order; only the compiler must not
+// reorder them), XBAR() is the workgroup barrier between the roles.
+#ifndef MJPC_WAVES
+#define MJPC_WAVES 2
+#endif
+#define LANE ((int)(threadIdx.x & 63))
 #define NLANE 64
-#define SYNC() __syncthreads()
+#define SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+#if MJPC_WAVES > 1
+#define XBAR() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
+#define WAVE_ID() (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)))
+#define ROLE0 (WAVE_ID() == 0)
+#define ROLE1 (WAVE_ID() == MJPC_WAVES - 1)
+#else
+#define XBAR() SYNC()
+#define ROLE0 1
+#define ROLE1 1
+#endif
 // individually rounded ops (no FMA contraction): used where results must be bit-identical to the CPU path
 DEV double mul_rn(double a, double b) {
 #pragma clang fp contract(off)

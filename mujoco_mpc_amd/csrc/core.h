@@ -1452,6 +1452,21 @@ DEV_NOINLINE CostOut ph_residual_cost(KP Kc, int t, int last) {        // role 1
   return o;
 }
 
+// role 1, after the residual and still under the solver's shadow: factor M + h*diag(damping) for the implicit-damping
+// Euler step into qL / Linv (M's own factor is no longer needed once qacc_smooth exists)
+template <int NVT>
+DEV_NOINLINE void ph_prefactor(KP Kc) {
+  Ctx c; ctx_open(c, Kc, 1);
+  const DevModel &M = *c.M;
+  if (M.any_damping) {
+    int nv = M.nv, nvp = M.nvp;
+    double h = M.timestep;
+    PFOR(e, nv * nvp) { int i = e / nvp, j = e - i * nvp; c.qL[e] = c.qM[e] + ((i == j) ? h * MD(dof_damping)[i] : 0.0); }
+    chol_factor<NVT>(c.qL, c.Linv, c.cfrc, nv, nvp);
+  }
+  ctx_close(c);
+}
+
 // mj_Euler with implicit joint damping, then record state[t+1]
 template <int NVT>
 DEV_NOINLINE void ph_integrate(KP Kc, int t) {
@@ -1463,9 +1478,8 @@ DEV_NOINLINE void ph_integrate(KP Kc, int t) {
   double h = M.timestep;
   PFOR(i, nv) c.qacc_ws[i] = c.qacc[i];
   if (M.any_damping) {
-    PFOR(e, nv * nvp) { int i = e / nvp, j = e - i * nvp; c.qH[e] = c.qM[e] + ((i == j) ? h * MD(dof_damping)[i] : 0.0); }
     PFOR(i, nv) c.Mgrad[i] = c.qfrc_smooth[i] + c.qfrc_constraint[i];
-    chol_factor_solve<NVT>(c.qH, c.Hinv, c.vtmp, c.Mgrad, nv, nvp);
+    chol_solve<NVT>(c.qL, c.Linv, c.Mgrad, nv, nvp);       // factor of M + h*B from ph_prefactor
     PFOR(i, nv) c.qvel[i] += h * c.Mgrad[i];
   } else {
     PFOR(i, nv) c.qvel[i] += h * c.qacc[i];
@@ -1524,7 +1538,7 @@ DEV void rollout(KP Kc) {
     if (r1) ph_smooth<NVT>(Kc);
     XBAR();
     if (r0) ph_solve<NVT>(Kc, last);
-    if (r1) { CostOut o = ph_residual_cost(Kc, t, last); total += o.cost; }
+    if (r1) { CostOut o = ph_residual_cost(Kc, t, last); total += o.cost; if (!last) ph_prefactor<NVT>(Kc); }
     XBAR();
     if (uniform_i(misc[3]) | uniform_i(misc[11])) { failure = 1; break; }
     if (r0 && !last) ph_integrate<NVT>(Kc, t);

@@ -70,6 +70,7 @@ struct Ctx {
   int *efc_type, *efc_id, *efc_state, *efc_dof, *con_i, *active, *misc, *hpair;
   double time;
   int ncon, nefc, nsingle, warning, solver_iter, cross;
+  int hseq;            // hand-shake sequence number with the solver's helper wave
   int role;            // 0: owns the rollout scalars (misc[0..8], time); 1: side wave, only reports warnings (misc[11])
 };
 
@@ -94,7 +95,7 @@ DEV void ctx_init(Ctx &c, const KParams *K, double *base) {
   int *ib = (int *)(base + L.ints);
   c.efc_type = ib + L.i_efc_type; c.efc_id = ib + L.i_efc_id; c.efc_state = ib + L.i_efc_state; c.efc_dof = ib + L.i_efc_dof;
   c.con_i = ib + L.i_con; c.active = ib + L.i_active; c.misc = ib + L.i_misc; c.hpair = ib + L.i_hpair;
-  c.time = 0; c.ncon = 0; c.nefc = 0; c.nsingle = 0; c.warning = 0; c.solver_iter = 0; c.cross = 0; c.role = 0;
+  c.time = 0; c.ncon = 0; c.nefc = 0; c.nsingle = 0; c.warning = 0; c.solver_iter = 0; c.cross = 0; c.role = 0; c.hseq = 0;
 #if defined(MJPC_PROFILE) && !defined(MJPC_EMU)
   c.prof = (long long *)(base + L.prof);
 #endif
@@ -1368,7 +1369,7 @@ DEV_NOINLINE void ph_init(KP Kc) {
     c.xquat[0] = 1; c.xquat[1] = 0; c.xquat[2] = 0; c.xquat[3] = 0;
     for (int k = 0; k < 9; k++) { c.xmat[k] = (k % 4 == 0) ? 1.0 : 0.0; c.ximat[k] = c.xmat[k]; }
     for (int k = 0; k < 6; k++) { c.cvel[k] = 0; c.cfrc[k] = 0; c.cacc[k] = (k >= 3) ? -M.gravity[k - 3] : 0.0; }
-    for (int k = 0; k < 12; k++) c.misc[k] = 0;
+    for (int k = 0; k < 24; k++) c.misc[k] = 0;
 #if defined(MJPC_PROFILE) && !defined(MJPC_EMU)
     for (int q = 0; q < NPROF; q++) c.prof[q] = 0;
     c.prof[NPROF] = (long long)__builtin_amdgcn_s_memtime();
@@ -1420,12 +1421,24 @@ DEV_NOINLINE void ph_smooth(KP Kc) {
   ctx_close(c);
 }
 template <int NVT>
-DEV_NOINLINE void ph_solve(KP Kc, int last) {
+DEV_NOINLINE void ph_solve(KP Kc, int last, int t) {
   Ctx c; ctx_open(c, Kc);
+  c.hseq = t * 256;
   solve_constraints<NVT>(c); PROF(c, 8);
+#if MJPC_HELPER
+  if (LANE == 0) c.misc[HX_KIND] = 0;           // release the helper wave
+  flag_set(c.misc + HX_JOB, ++c.hseq);
+#endif
   if (!last && bad_values(c.qacc, c.M->nv)) c.warning |= WARN_BADQACC;
   ctx_close(c);
 }
+#if MJPC_HELPER
+template <int NVT>
+DEV_NOINLINE void ph_solve_helper(KP Kc, int t) {
+  Ctx c; ctx_open(c, Kc, 1);
+  solver_helper_loop<NVT>(c, t * 256);
+}
+#endif
 
 // residual (sensor callback at mjSTAGE_ACC), trace, cost; returns (cost, warning)
 struct CostOut { double cost; int warning; };
@@ -1537,7 +1550,10 @@ DEV void rollout(KP Kc) {
     if (r0) ph_constraints(Kc);
     if (r1) ph_smooth<NVT>(Kc);
     XBAR();
-    if (r0) ph_solve<NVT>(Kc, last);
+    if (r0) ph_solve<NVT>(Kc, last, t);
+#if MJPC_HELPER
+    if (ROLEH) ph_solve_helper<NVT>(Kc, t);
+#endif
     if (r1) { CostOut o = ph_residual_cost(Kc, t, last); total += o.cost; if (!last) ph_prefactor<NVT>(Kc); }
     XBAR();
     if (uniform_i(misc[3]) | uniform_i(misc[11])) { failure = 1; break; }

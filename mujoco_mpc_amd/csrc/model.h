@@ -26,7 +26,7 @@
 
 enum { CNSTR_FRICTION_DOF = 1, CNSTR_LIMIT_JOINT = 3, CNSTR_LIMIT_TENDON = 4, CNSTR_CONTACT_FRICTIONLESS = 5, CNSTR_CONTACT_PYRAMIDAL = 6, CNSTR_CONTACT_ELLIPTIC = 7 };
 enum { STATE_SATISFIED = 0, STATE_QUADRATIC = 1, STATE_LINEARNEG = 2, STATE_LINEARPOS = 3, STATE_CONE = 4 };
-enum { WARN_BADQPOS = 1, WARN_BADQVEL = 2, WARN_BADQACC = 4, WARN_CONTACTFULL = 8, WARN_CNSTRFULL = 16, WARN_RAY = 32 };
+enum { WARN_BADQPOS = 1, WARN_BADQVEL = 2, WARN_BADQACC = 4, WARN_CONTACTFULL = 8, WARN_CNSTRFULL = 16, WARN_RAY = 32, WARN_SYNC = 64 };
 
 struct DevTask {
   int task_id, num_residual, num_term, num_trace, num_parameter, num_int, num_dbl;

@@ -177,15 +177,11 @@ DEV double solver_eval(Ctx &c, const double *qacc, double *gauss_out) {
 // and each cone contact adds one NEGATIVE row q (H -= q q^T).  Column nv of a scaled row holds phi with
 // J^T force = sum_rows jh * phi, so the gradient falls out of the same contraction as an extra "column".
 // grad_only: the caller already knows it will stop (no cost improvement) and only needs grad = Ma - qfrc_smooth - J^T force.
-template <int NVT>
-DEV void newton_gradient(Ctx &c, int grad_only) {
-  const DevModel &M = *c.M;
-  const int nv = NVT > 0 ? NVT : M.nv, nvp = NVT > 0 ? NVP_OF(NVT) : M.nvp;     // compile-time strides => immediate LDS offsets
+// ordered lists: positives = active contact rows, negatives = normal rows of the contacts in the cone zone
+DEV void newton_lists(Ctx &c, int *npos_out, int *nneg_out) {
   int nefc = c.nefc, ns = c.nsingle;
   int ncrow = nefc - ns;
-  const int negbase = M.nefcmax;
-  PROF(c, 13);
-  // ordered lists: positives = active contact rows, negatives = normal rows of the contacts in the cone zone
+  const int negbase = c.M->nefcmax;
   int npos = 0, nneg = 0;
   for (int base = 0; base < ncrow; base += NLANE) {
     int rr = base + LANE, r = ns + rr;
@@ -199,7 +195,16 @@ DEV void newton_gradient(Ctx &c, int grad_only) {
     npos += tp; nneg += tn;
   }
   SYNC();
-  // rows [0, npos8): positives, zero-padded to a multiple of 8; rows [npos8, npos8 + nneg4): negatives, padded to 4
+  *npos_out = npos; *nneg_out = nneg;
+}
+
+// scaled rows JH[e][C0..C1) (+ the phi column when PHI): rows [0, npos8) positives zero-padded to a multiple of 8,
+// rows [npos8, npos8 + nneg4) negatives padded to 4.  The column range lets two waves share the fill.
+template <int NVT, int C0, int C1, int PHI>
+DEV void newton_fill(Ctx &c, int npos, int nneg) {
+  const DevModel &M = *c.M;
+  const int nv = NVT > 0 ? NVT : M.nv, nvp = NVT > 0 ? NVP_OF(NVT) : M.nvp;
+  const int negbase = M.nefcmax;
   const int npos8 = (npos + 7) & ~7, nneg4 = (nneg + 3) & ~3;
   int ntot = npos8 + nneg4;
   double *JH = c.efc_JA;
@@ -234,22 +239,23 @@ DEV void newton_gradient(Ctx &c, int grad_only) {
       }
     }
     if constexpr (NVT > 0) {
-      double acc[NVT];
-      { const double *Jr = c.efc_J + rowb[0];
+      constexpr int NC = C1 - C0;
+      double acc[NC > 0 ? NC : 1];
+      { const double *Jr = c.efc_J + rowb[0] + C0;
 #pragma unroll
-        for (int j = 0; j < NVT; j++) acc[j] = coef[0] * Jr[j]; }
+        for (int j = 0; j < NC; j++) acc[j] = coef[0] * Jr[j]; }
 #pragma unroll
       for (int b = 1; b < 6; b++) {
         if (!wave_any(nb > b)) break;
-        const double *Jr = c.efc_J + rowb[b];
+        const double *Jr = c.efc_J + rowb[b] + C0;
 #pragma unroll
-        for (int j = 0; j < NVT; j++) acc[j] += coef[b] * Jr[j];
+        for (int j = 0; j < NC; j++) acc[j] += coef[b] * Jr[j];
       }
       if (e < ntot) {
-        double *o = JH + e * nvp;
+        double *o = JH + e * nvp + C0;
 #pragma unroll
-        for (int j = 0; j < NVT; j++) o[j] = valid ? acc[j] : 0.0;
-        o[NVT] = phi;
+        for (int j = 0; j < NC; j++) o[j] = valid ? acc[j] : 0.0;
+        if (PHI) JH[e * nvp + NVT] = phi;
       }
     } else {
       if (e < ntot) {
@@ -264,53 +270,122 @@ DEV void newton_gradient(Ctx &c, int grad_only) {
       }
     }
   }
-  PROF(c, 19);
-  SYNC();
-  // H = M + diag(single-entry rows) + JH+^T JH+ - JH-^T JH-  on the lower triangle (only M's sparsity pattern without
-  // cross-branch contacts), and grad = Ma - qfrc_smooth - J^T force  as the entries (i, nv)
+}
+
+// H = M + diag(single-entry rows) + JH+^T JH+ - JH-^T JH-  on the lower triangle (only M's sparsity pattern without
+// cross-branch contacts), and grad = Ma - qfrc_smooth - J^T force  as the entries (i, nv).  Entries e = part*NLANE + LANE
+// + g*NLANE*nparts belong to this wave; each lane carries G of them through the row loop together (G*16 independent LDS
+// reads in flight per trip; the row counts are multiples of 8 / 4).
+template <int NVT, int G>
+DEV void newton_entries(Ctx &c, int npos, int nneg, int grad_only, int part, int nparts) {
+  const DevModel &M = *c.M;
+  const int nv = NVT > 0 ? NVT : M.nv, nvp = NVT > 0 ? NVP_OF(NVT) : M.nvp;
+  const int npos8 = (npos + 7) & ~7, ntot = npos8 + ((nneg + 3) & ~3);
+  const double *JH = c.efc_JA;
   int nh = c.cross ? nv * (nv + 1) / 2 : M.nmpair;
   int nent = nh + nv;
-  for (int e = (grad_only ? nh : 0) + LANE; e < nent; e += NLANE) {
-    int i, j;
-    if (!c.cross) { int pk = c.hpair[e]; i = pk & 255; j = pk >> 8; }
-    else if (e >= nh) { i = e - nh; j = nv; }
-    else {
-      i = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
-      while ((i + 1) * (i + 2) / 2 <= e) i++;
-      while (i * (i + 1) / 2 > e) i--;
-      j = e - i * (i + 1) / 2;
-    }
-    const double *Ji = JH + i, *Jj = JH + j;
-    double h = 0;
-    {
-      // 8 rows per trip: 16 independent LDS reads in flight, then the FMAs (the row count is a multiple of 8)
-      double h0 = 0, h1 = 0;
-      for (int a = 0; a < npos8; a += 8) {
-        double x[8], y[8];
+  const int stride = NLANE * nparts;
+  for (int e0 = (grad_only ? nh : 0) + part * NLANE + LANE; e0 < nent; e0 += G * stride) {
+    int ii[G], jj[G];
 #pragma unroll
-        for (int k = 0; k < 8; k++) { x[k] = Ji[(a + k) * nvp]; y[k] = Jj[(a + k) * nvp]; }
-#pragma unroll
-        for (int k = 0; k < 8; k += 2) { h0 += x[k] * y[k]; h1 += x[k + 1] * y[k + 1]; }
+    for (int g = 0; g < G; g++) {
+      int e = e0 + g * stride, i = 0, j = 0;
+      if (e < nent) {
+        if (!c.cross) { int pk = c.hpair[e]; i = pk & 255; j = pk >> 8; }
+        else if (e >= nh) { i = e - nh; j = nv; }
+        else {
+          i = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+          while ((i + 1) * (i + 2) / 2 <= e) i++;
+          while (i * (i + 1) / 2 > e) i--;
+          j = e - i * (i + 1) / 2;
+        }
       }
-      h = h0 + h1;
+      ii[g] = i; jj[g] = j;
     }
-    if (j == nv) {
-      double g = c.Ma[i] - c.qfrc_smooth[i] - (c.sgl[i] + c.sgl[2 * nv + i]) - h;
-      c.grad[i] = g;
-      c.Mgrad[i] = g;
-    } else {
-      double hn = 0;
-      for (int a = npos8; a < ntot; a += 4) {
-        double x[4], y[4];
+    double hp[G], hq[G], hn[G];
 #pragma unroll
-        for (int k = 0; k < 4; k++) { x[k] = Ji[(a + k) * nvp]; y[k] = Jj[(a + k) * nvp]; }
+    for (int g = 0; g < G; g++) { hp[g] = 0; hq[g] = 0; hn[g] = 0; }
+    for (int a = 0; a < npos8; a += 8) {
+      double x[G][8], y[G][8];
 #pragma unroll
-        for (int k = 0; k < 4; k++) hn += x[k] * y[k];
+      for (int g = 0; g < G; g++)
+#pragma unroll
+        for (int k = 0; k < 8; k++) { x[g][k] = JH[(a + k) * nvp + ii[g]]; y[g][k] = JH[(a + k) * nvp + jj[g]]; }
+#pragma unroll
+      for (int g = 0; g < G; g++)
+#pragma unroll
+        for (int k = 0; k < 8; k += 2) { hp[g] += x[g][k] * y[g][k]; hq[g] += x[g][k + 1] * y[g][k + 1]; }
+    }
+    for (int a = npos8; a < ntot; a += 4) {          // negative rows (their phi column is zero: gradient entries unaffected)
+      double x[G][4], y[G][4];
+#pragma unroll
+      for (int g = 0; g < G; g++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) { x[g][k] = JH[(a + k) * nvp + ii[g]]; y[g][k] = JH[(a + k) * nvp + jj[g]]; }
+#pragma unroll
+      for (int g = 0; g < G; g++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) hn[g] += x[g][k] * y[g][k];
+    }
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+      int e = e0 + g * stride, i = ii[g], j = jj[g];
+      if (e >= nent) continue;
+      double h = hp[g] + hq[g];
+      if (j == nv) {
+        double gr = c.Ma[i] - c.qfrc_smooth[i] - (c.sgl[i] + c.sgl[2 * nv + i]) - h;
+        c.grad[i] = gr;
+        c.Mgrad[i] = gr;
+      } else {
+        h = c.qM[i * nvp + j] + (h - hn[g]);
+        if (i == j) h += c.sgl[nv + i] + c.sgl[3 * nv + i];
+        c.qH[i * nvp + j] = h;
       }
-      h = c.qM[i * nvp + j] + (h - hn);
-      if (i == j) h += c.sgl[nv + i] + c.sgl[3 * nv + i];
-      c.qH[i * nvp + j] = h;
     }
+  }
+}
+
+// ---- the solver's helper wave (MJPC_WAVES == 3, compile-time nv): shares the scaled-row fill (column halves) and the
+// Hessian / gradient entries with the owner wave.  Hand-shake through sequence numbers in LDS (misc[12..18]):
+//   owner: lists -> publish npos/nneg -> post job seq -> fill half -> W0FILL=seq -> wait HFILL==seq -> entries -> wait HDONE==seq
+//   helper: wait job seq -> fill half -> HFILL=seq -> wait W0FILL==seq -> entries -> HDONE=seq
+#define HX_JOB 12
+#define HX_KIND 13
+#define HX_W0FILL 14
+#define HX_HFILL 15
+#define HX_HDONE 16
+#define HX_NPOS 17
+#define HX_NNEG 18
+#if !defined(MJPC_EMU) && MJPC_WAVES == 3
+#define MJPC_HELPER 1
+#else
+#define MJPC_HELPER 0
+#endif
+
+template <int NVT>
+DEV void newton_gradient(Ctx &c, int grad_only) {
+  const DevModel &M = *c.M;
+  const int nv = NVT > 0 ? NVT : M.nv, nvp = NVT > 0 ? NVP_OF(NVT) : M.nvp;     // compile-time strides => immediate LDS offsets
+  PROF(c, 13);
+  int npos, nneg;
+  newton_lists(c, &npos, &nneg);
+#if MJPC_HELPER
+  if (NVT > 0 && !grad_only) {
+    int seq = ++c.hseq;
+    if (LANE == 0) { c.misc[HX_NPOS] = npos; c.misc[HX_NNEG] = nneg; c.misc[HX_KIND] = 1; }
+    flag_set(c.misc + HX_JOB, seq);
+    newton_fill<NVT, 0, NVT / 2, 0>(c, npos, nneg);
+    flag_set(c.misc + HX_W0FILL, seq);
+    if (!flag_wait(c.misc + HX_HFILL, seq)) c.warning |= WARN_SYNC;
+    newton_entries<NVT, 2>(c, npos, nneg, 0, 0, 2);
+    if (!flag_wait(c.misc + HX_HDONE, seq)) c.warning |= WARN_SYNC;
+  } else
+#endif
+  {
+    newton_fill<NVT, 0, NVT, 1>(c, npos, nneg);
+    PROF(c, 19);
+    SYNC();
+    newton_entries<NVT, 3>(c, npos, nneg, grad_only, 0, 1);
   }
   // structural zeros of the pattern: the register factorisation never writes qH, so they only need clearing after a
   // dense (cross-branch) build; the generic in-place LDS factor fills them every time
@@ -322,6 +397,24 @@ DEV void newton_gradient(Ctx &c, int grad_only) {
   SYNC();
   PROF(c, 16);
 }
+#if MJPC_HELPER
+template <int NVT>
+DEV void solver_helper_loop(Ctx &c, int seq) {
+  if constexpr (NVT > 0) {
+    for (;;) {
+      seq++;
+      if (!flag_wait(c.misc + HX_JOB, seq)) return;             // timed out: the owner reports the failure
+      if (uniform_i(c.misc[HX_KIND]) == 0) return;
+      int npos = uniform_i(c.misc[HX_NPOS]), nneg = uniform_i(c.misc[HX_NNEG]);
+      newton_fill<NVT, NVT / 2, NVT, 1>(c, npos, nneg);
+      flag_set(c.misc + HX_HFILL, seq);
+      if (!flag_wait(c.misc + HX_W0FILL, seq)) return;
+      newton_entries<NVT, 1>(c, npos, nneg, 0, 1, 2);
+      flag_set(c.misc + HX_HDONE, seq);
+    }
+  }
+}
+#endif
 template <int NVT>
 DEV void newton_direction(Ctx &c) {
   const int nv = NVT > 0 ? NVT : c.M->nv, nvp = NVT > 0 ? NVP_OF(NVT) : c.M->nvp;

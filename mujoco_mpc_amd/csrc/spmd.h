@@ -21,6 +21,9 @@
 #define XBAR() ((void)0)
 #define ROLE0 1
 #define ROLE1 1
+#define ROLEH 0
+DEV void flag_set(int *p, int v) { *p = v; }
+DEV int flag_wait(int *p, int v) { return *p == v; }
 DEV double mul_rn(double a, double b) { return a * b; }   // emu is built with -ffp-contract=off
 DEV double add_rn(double a, double b) { return a + b; }
 DEV double add_mul3_rn(double a, double b, double c, double d) { return a + (b * c) * d; }
@@ -38,11 +41,12 @@ DEV int wave_any(int flag) { return flag != 0; }
 // A candidate is owned by MJPC_WAVES (1 or 2) wavefronts of one workgroup on different SIMDs of a CU:
 //   role 0 (wave 0): the serial critical path (kinematics -> collision/constraints -> Newton solver -> integration);
 //   role 1 (last wave): work that only hangs off that path (inertia + factor M + smooth dynamics while role 0 builds
-//   the constraints; residual / cost / trajectory record while role 0 solves).
+//   the constraints; residual / cost / trajectory record while role 0 solves);
+//   helper (wave 1 of 3): shares the data-parallel parts of every Newton iteration with role 0 (solver.h).
 // SYNC() orders LDS traffic inside ONE wave (DS operations of a wave execute in order; only the compiler must not
 // reorder them), XBAR() is the workgroup barrier between the roles.
 #ifndef MJPC_WAVES
-#define MJPC_WAVES 2
+#define MJPC_WAVES 3
 #endif
 #define LANE ((int)(threadIdx.x & 63))
 #define NLANE 64
@@ -52,10 +56,12 @@ DEV int wave_any(int flag) { return flag != 0; }
 #define WAVE_ID() (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)))
 #define ROLE0 (WAVE_ID() == 0)
 #define ROLE1 (WAVE_ID() == MJPC_WAVES - 1)
+#define ROLEH (MJPC_WAVES == 3 && WAVE_ID() == 1)
 #else
 #define XBAR() SYNC()
 #define ROLE0 1
 #define ROLE1 1
+#define ROLEH 0
 #endif
 // individually rounded ops (no FMA contraction): used where results must be bit-identical to the CPU path
 DEV double mul_rn(double a, double b) {
@@ -112,6 +118,22 @@ DEV int wave_or_i(int v) {
   return v;
 }
 DEV int wave_any(int flag) { return __builtin_amdgcn_ballot_w64(flag != 0) != 0; }
+// point-to-point hand-shake between two waves of the workgroup through a sequence number in LDS: the setter publishes all
+// its earlier LDS writes (release), the waiter spins (bounded: a protocol bug must not hang the GPU) and then acquires
+DEV void flag_set(int *p, int v) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  if (LANE == 0) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+DEV int flag_wait(int *p, int v) {
+  int ok = 0;
+  for (int n = 0; n < (1 << 20); n++) {
+    int cur = __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+    if (cur == v) { ok = 1; break; }
+    __builtin_amdgcn_s_sleep(1);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  return ok;
+}
 // exclusive prefix sum over the 64 lanes (lane order), total returned to every lane: Hillis-Steele inside each
 // row of 16 with DPP row_shr (VALU rate, zero fill), then row_bcast:15 / row_bcast:31 carry the row totals
 DEV int wave_excl_scan(int v, int *total) {

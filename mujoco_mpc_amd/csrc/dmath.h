@@ -57,9 +57,30 @@ DEV double d_normalize2(double *a) {
   return n;
 }
 DEV void d_normalize4(double *q) {
-  double n = sqrt(q[0]*q[0] + q[1]*q[1] + q[2]*q[2] + q[3]*q[3]);
+  double n2 = q[0]*q[0] + q[1]*q[1] + q[2]*q[2] + q[3]*q[3];
+  double s = fast_rsqrt(n2), n = n2 * s;                 // |q| and 1/|q| without the IEEE sqrt / divide sequences
   if (n < D_MINVAL) { q[0]=1; q[1]=0; q[2]=0; q[3]=0; }
-  else if (fabs(n - 1) > D_MINVAL) { double s = 1.0 / n; q[0]*=s; q[1]*=s; q[2]*=s; q[3]*=s; }
+  else if (fabs(n - 1) > D_MINVAL) { q[0]*=s; q[1]*=s; q[2]*=s; q[3]*=s; }
+}
+// sin and cos of a joint-sized angle: Cody-Waite reduction by pi/2 (two-term constant) + the fdlibm kernel polynomials
+// (max error 1 ulp at |x| <= 20, checked against libm); large arguments fall back to libm
+DEV void d_sincos(double x, double *sn, double *cs) {
+#ifdef MJPC_EMU
+  *sn = sin(x); *cs = cos(x);
+#else
+  if (!(fabs(x) < 64.0)) { *sn = sin(x); *cs = cos(x); return; }
+  double k = rint(x * 0.63661977236758134308);
+  double r = (x - k * 1.57079632673412561417e+00) - k * 6.07710050650619224932e-11;
+  double z = r * r;
+  double ps = -1.66666666666666324348e-01 + z * (8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 + z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10))));
+  double pc = 4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 + z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11))));
+  double s = r + r * z * ps;
+  double c = 1.0 - 0.5 * z + z * z * pc;
+  int q = ((int)k) & 3;
+  double s1 = (q & 1) ? c : s, c1 = (q & 1) ? s : c;
+  *sn = (q & 2) ? -s1 : s1;
+  *cs = ((q + 1) & 2) ? -c1 : c1;
+#endif
 }
 DEV double d_clip(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
 DEV void d_mulmatvec3(double *r, const double *m, const double *v) {
@@ -95,8 +116,9 @@ DEV void d_rotvecquat(double *r, const double *v, const double *q) {
 }
 DEV void d_axisangle2quat(double *q, const double *axis, double angle) {
   if (angle == 0) { q[0]=1; q[1]=0; q[2]=0; q[3]=0; return; }
-  double s = sin(angle * 0.5);
-  q[0] = cos(angle * 0.5); q[1] = axis[0]*s; q[2] = axis[1]*s; q[3] = axis[2]*s;
+  double s, cq;
+  d_sincos(angle * 0.5, &s, &cq);
+  q[0] = cq; q[1] = axis[0]*s; q[2] = axis[1]*s; q[3] = axis[2]*s;
 }
 DEV void d_quatintegrate(double *q, const double *vel, double scale) {
   double ax[3] = {vel[0], vel[1], vel[2]};

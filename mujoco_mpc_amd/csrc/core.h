@@ -1436,7 +1436,8 @@ DEV_NOINLINE void ph_solve(KP Kc, int last, int t) {
 template <int NVT>
 DEV_NOINLINE void ph_solve_helper(KP Kc, int t) {
   Ctx c; ctx_open(c, Kc, 1);
-  solver_helper_loop<NVT>(c, t * 256);
+  if (MJPC_NH < 2 || WAVE_ID() == 1) solver_helper_loop<NVT, 0>(c, t * 256);
+  else solver_helper_loop<NVT, (MJPC_NH >= 2 ? 1 : 0)>(c, t * 256);
 }
 #endif
 

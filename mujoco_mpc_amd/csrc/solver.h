@@ -345,22 +345,31 @@ DEV void newton_entries(Ctx &c, int npos, int nneg, int grad_only, int part, int
   }
 }
 
-// ---- the solver's helper wave (MJPC_WAVES == 3, compile-time nv): shares the scaled-row fill (column halves) and the
-// Hessian / gradient entries with the owner wave.  Hand-shake through sequence numbers in LDS (misc[12..18]):
-//   owner: lists -> publish npos/nneg -> post job seq -> fill half -> W0FILL=seq -> wait HFILL==seq -> entries -> wait HDONE==seq
-//   helper: wait job seq -> fill half -> HFILL=seq -> wait W0FILL==seq -> entries -> HDONE=seq
+// ---- the solver's helper waves (MJPC_WAVES >= 3, compile-time nv): NH = MJPC_WAVES - 2 helpers share the scaled-row fill
+// (column thirds / halves) and the Hessian / gradient entries with the owner wave.  Hand-shake through sequence numbers
+// in LDS (misc[12..]):
+//   owner:    lists -> publish npos/nneg -> post job seq -> fill its columns -> W0FILL=seq -> wait HFILL_k==seq (all k)
+//             -> its entries -> wait HDONE_k==seq (all k)
+//   helper k: wait job seq -> fill its columns -> HFILL_k=seq -> wait W0FILL==seq and the other helpers' HFILL -> its entries
+//             -> HDONE_k=seq
 #define HX_JOB 12
 #define HX_KIND 13
 #define HX_W0FILL 14
-#define HX_HFILL 15
-#define HX_HDONE 16
-#define HX_NPOS 17
-#define HX_NNEG 18
-#if !defined(MJPC_EMU) && MJPC_WAVES == 3
+#define HX_NPOS 15
+#define HX_NNEG 16
+#define HX_HFILL 17      // + k
+#define HX_HDONE 20      // + k
+#if !defined(MJPC_EMU) && MJPC_WAVES >= 3
 #define MJPC_HELPER 1
+#define MJPC_NH (MJPC_WAVES - 2)
 #else
 #define MJPC_HELPER 0
+#define MJPC_NH 0
 #endif
+
+// column range of part p of NP for an NVT-wide row
+#define FILL_C0(NVT, p, NP) ((NVT) * (p) / (NP))
+#define FILL_C1(NVT, p, NP) ((NVT) * ((p) + 1) / (NP))
 
 template <int NVT>
 DEV void newton_gradient(Ctx &c, int grad_only) {
@@ -371,14 +380,15 @@ DEV void newton_gradient(Ctx &c, int grad_only) {
   newton_lists(c, &npos, &nneg);
 #if MJPC_HELPER
   if (NVT > 0 && !grad_only) {
+    constexpr int NP = MJPC_NH + 1;
     int seq = ++c.hseq;
     if (LANE == 0) { c.misc[HX_NPOS] = npos; c.misc[HX_NNEG] = nneg; c.misc[HX_KIND] = 1; }
     flag_set(c.misc + HX_JOB, seq);
-    newton_fill<NVT, 0, NVT / 2, 0>(c, npos, nneg);
+    newton_fill<NVT, FILL_C0(NVT, 0, NP), FILL_C1(NVT, 0, NP), 0>(c, npos, nneg);
     flag_set(c.misc + HX_W0FILL, seq);
-    if (!flag_wait(c.misc + HX_HFILL, seq)) c.warning |= WARN_SYNC;
-    newton_entries<NVT, 2>(c, npos, nneg, 0, 0, 2);
-    if (!flag_wait(c.misc + HX_HDONE, seq)) c.warning |= WARN_SYNC;
+    for (int k = 0; k < MJPC_NH; k++) if (!flag_wait(c.misc + HX_HFILL + k, seq)) c.warning |= WARN_SYNC;
+    newton_entries<NVT, (NP >= 3 ? 1 : 2)>(c, npos, nneg, 0, 0, NP);
+    for (int k = 0; k < MJPC_NH; k++) if (!flag_wait(c.misc + HX_HDONE + k, seq)) c.warning |= WARN_SYNC;
   } else
 #endif
   {
@@ -398,19 +408,21 @@ DEV void newton_gradient(Ctx &c, int grad_only) {
   PROF(c, 16);
 }
 #if MJPC_HELPER
-template <int NVT>
+template <int NVT, int K>
 DEV void solver_helper_loop(Ctx &c, int seq) {
   if constexpr (NVT > 0) {
+    constexpr int NP = MJPC_NH + 1;
     for (;;) {
       seq++;
       if (!flag_wait(c.misc + HX_JOB, seq)) return;             // timed out: the owner reports the failure
       if (uniform_i(c.misc[HX_KIND]) == 0) return;
       int npos = uniform_i(c.misc[HX_NPOS]), nneg = uniform_i(c.misc[HX_NNEG]);
-      newton_fill<NVT, NVT / 2, NVT, 1>(c, npos, nneg);
-      flag_set(c.misc + HX_HFILL, seq);
+      newton_fill<NVT, FILL_C0(NVT, K + 1, NP), FILL_C1(NVT, K + 1, NP), (K + 1 == NP - 1)>(c, npos, nneg);
+      flag_set(c.misc + HX_HFILL + K, seq);
       if (!flag_wait(c.misc + HX_W0FILL, seq)) return;
-      newton_entries<NVT, 1>(c, npos, nneg, 0, 1, 2);
-      flag_set(c.misc + HX_HDONE, seq);
+      for (int k = 0; k < MJPC_NH; k++) if (k != K && !flag_wait(c.misc + HX_HFILL + k, seq)) return;
+      newton_entries<NVT, (NP >= 3 ? 1 : 2)>(c, npos, nneg, 0, K + 1, NP);
+      flag_set(c.misc + HX_HDONE + K, seq);
     }
   }
 }

@@ -42,11 +42,11 @@ DEV int wave_any(int flag) { return flag != 0; }
 //   role 0 (wave 0): the serial critical path (kinematics -> collision/constraints -> Newton solver -> integration);
 //   role 1 (last wave): work that only hangs off that path (inertia + factor M + smooth dynamics while role 0 builds
 //   the constraints; residual / cost / trajectory record while role 0 solves);
-//   helper (wave 1 of 3): shares the data-parallel parts of every Newton iteration with role 0 (solver.h).
+//   helpers (waves 1 .. MJPC_WAVES-2): share the data-parallel parts of every Newton iteration with role 0 (solver.h).
 // SYNC() orders LDS traffic inside ONE wave (DS operations of a wave execute in order; only the compiler must not
 // reorder them), XBAR() is the workgroup barrier between the roles.
 #ifndef MJPC_WAVES
-#define MJPC_WAVES 3
+#define MJPC_WAVES 4
 #endif
 #define LANE ((int)(threadIdx.x & 63))
 #define NLANE 64
@@ -56,7 +56,7 @@ DEV int wave_any(int flag) { return flag != 0; }
 #define WAVE_ID() (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)))
 #define ROLE0 (WAVE_ID() == 0)
 #define ROLE1 (WAVE_ID() == MJPC_WAVES - 1)
-#define ROLEH (MJPC_WAVES == 3 && WAVE_ID() == 1)
+#define ROLEH (MJPC_WAVES >= 3 && WAVE_ID() >= 1 && WAVE_ID() < MJPC_WAVES - 1)     // helper k = WAVE_ID() - 1
 #else
 #define XBAR() SYNC()
 #define ROLE0 1

@@ -115,7 +115,13 @@ DEV void ctx_open(Ctx &c, KP Kc, int role = 0) {
 DEV void ctx_close(Ctx &c) {
   SYNC();
   if (c.role != 0) {            // the side wave never writes the owner's scalars
-    if (LANE == 0) c.misc[11] = c.warning;
+    if (LANE == 0 && c.warning) {
+#ifdef MJPC_EMU
+      c.misc[11] |= c.warning;
+#else
+      __hip_atomic_fetch_or(c.misc + 11, c.warning, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // several side / helper waves report here
+#endif
+    }
     SYNC();
     return;
   }
@@ -910,8 +916,9 @@ DEV void vel_body(Ctx &c, int i) {
   d_scl3(c.bodytmp + 3 * i, v, MD(body_mass)[i]);
 }
 
+// mfact_seq != 0: M's factor is produced by a helper wave; wait for its sequence number (misc[22]) before the solve
 template <int NVT>
-DEV void velocity_stage(Ctx &c) {
+DEV void velocity_stage(Ctx &c, int mfact_seq) {
   const DevModel &M = *c.M;
   int nv = M.nv;
   for (int l = 0; l < M.nlevel; l++) {
@@ -964,6 +971,7 @@ DEV void velocity_stage(Ctx &c) {
   }
   SYNC();
   PFOR(d, nv) c.qacc_smooth[d] = c.qfrc_smooth[d];
+  if (mfact_seq && !flag_wait(c.misc + 22, mfact_seq)) c.warning |= WARN_SYNC;
   chol_solve<NVT>(c.qL, c.Linv, c.qacc_smooth, nv, M.nvp);
 }
 
@@ -1414,12 +1422,26 @@ DEV_NOINLINE void ph_constraints(KP Kc) {
 }
 // role 1, concurrently with ph_constraints: joint-space inertia + its factor, smooth dynamics (qfrc_smooth, qacc_smooth)
 template <int NVT>
-DEV_NOINLINE void ph_smooth(KP Kc) {
+DEV_NOINLINE void ph_smooth(KP Kc, int t) {
   Ctx c; ctx_open(c, Kc, 1);
+#if MJPC_HELPER
+  velocity_stage<NVT>(c, t + 1);                // helper 0 builds and factors M meanwhile (ph_inertia)
+#else
   crb_and_factor<NVT>(c); PROF(c, 3);
-  velocity_stage<NVT>(c); PROF(c, 6);
+  velocity_stage<NVT>(c, 0); PROF(c, 6);
+#endif
   ctx_close(c);
 }
+#if MJPC_HELPER
+// helper 0, concurrently with ph_constraints / ph_smooth: joint-space inertia and its factor
+template <int NVT>
+DEV_NOINLINE void ph_inertia(KP Kc, int t) {
+  Ctx c; ctx_open(c, Kc, 1);
+  crb_and_factor<NVT>(c);
+  flag_set(c.misc + 22, t + 1);
+  ctx_close(c);
+}
+#endif
 template <int NVT>
 DEV_NOINLINE void ph_solve(KP Kc, int last, int t) {
   Ctx c; ctx_open(c, Kc);
@@ -1549,7 +1571,10 @@ DEV void rollout(KP Kc) {
     XBAR();
     if (uniform_i(misc[10])) { failure = 1; break; }
     if (r0) ph_constraints(Kc);
-    if (r1) ph_smooth<NVT>(Kc);
+    if (r1) ph_smooth<NVT>(Kc, t);
+#if MJPC_HELPER
+    if (ROLEH && WAVE_ID() == 1) ph_inertia<NVT>(Kc, t);
+#endif
     XBAR();
     if (r0) ph_solve<NVT>(Kc, last, t);
 #if MJPC_HELPER

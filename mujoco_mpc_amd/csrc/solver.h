@@ -359,13 +359,7 @@ DEV void newton_entries(Ctx &c, int npos, int nneg, int grad_only, int part, int
 #define HX_NNEG 16
 #define HX_HFILL 17      // + k
 #define HX_HDONE 20      // + k
-#if !defined(MJPC_EMU) && MJPC_WAVES >= 3
-#define MJPC_HELPER 1
-#define MJPC_NH (MJPC_WAVES - 2)
-#else
-#define MJPC_HELPER 0
-#define MJPC_NH 0
-#endif
+#define HX_MFACT 22      // factor of M ready (helper 0 -> side wave), value t + 1
 
 // column range of part p of NP for an NVT-wide row
 #define FILL_C0(NVT, p, NP) ((NVT) * (p) / (NP))

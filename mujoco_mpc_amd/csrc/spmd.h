@@ -155,4 +155,12 @@ DEV int wave_flag_scan(int flag, int *total) {
 }
 #endif
 
+#if !defined(MJPC_EMU) && MJPC_WAVES >= 3
+#define MJPC_HELPER 1
+#define MJPC_NH (MJPC_WAVES - 2)
+#else
+#define MJPC_HELPER 0
+#define MJPC_NH 0
+#endif
+
 #define PFOR(i, n) for (int i = LANE; i < (n); i += NLANE)

@@ -20,20 +20,22 @@
 #endif
 
 // constraint cost at efc_jar; fills force/state (and the cone Hessian factors); returns this lane's partial cost
-template <int DIMT>
-DEV double constraint_update(Ctx &c, int hess) {
+// WRITE = false: cost only, at the residuals `jar` (nothing shared is written: a helper wave prices qacc_smooth with it)
+template <int DIMT, bool WRITE = true>
+DEV double constraint_update(Ctx &c, int hess, const double *jar) {
   double cost = 0;
   PFOR(i, c.nefc) {
     int type = c.efc_type[i];
     if (type == CNSTR_CONTACT_ELLIPTIC) continue;
     // branch-free row cost (see the line search): xc = clamp(x, lo, hi), s = 1/2 D xc^2 + F (|x| - |xc|), force = -D xc
-    double D = c.efc_D[i], x = c.efc_jar[i];
+    double D = c.efc_D[i], x = jar[i];
     int fric = type == CNSTR_FRICTION_DOF;
     double f = fric ? c.efc_floss[i] : 0.0, Rf = c.efc_R[i] * f;
     double lo = fric ? -Rf : -1e300, hi = fric ? Rf : 0.0;
     double xc = fmin(fmax(x, lo), hi);
     int inside = x > lo && x < hi;
     cost += 0.5 * D * xc * xc + f * (fabs(x) - fabs(xc));
+    if (!WRITE) continue;
     double force = fric ? (inside ? -D * x : (x <= lo ? f : -f)) : -D * xc;
     c.efc_force[i] = force;
     c.efc_state[i] = inside ? STATE_QUADRATIC : (fric ? (x <= lo ? STATE_LINEARNEG : STATE_LINEARPOS) : STATE_SATISFIED);
@@ -58,7 +60,7 @@ DEV double constraint_update(Ctx &c, int hess) {
     double T2 = 0;
 #pragma unroll
     for (int j = 0; j < DIMT; j++) {
-      X[j] = j < dim ? c.efc_jar[i + j] : 0; Dj[j] = j < dim ? c.efc_D[i + j] : 0;
+      X[j] = j < dim ? jar[i + j] : 0; Dj[j] = j < dim ? c.efc_D[i + j] : 0;
       U[j] = X[j] * fr[j]; F[j] = 0;
       if (j > 0) T2 += U[j] * U[j];
     }
@@ -80,7 +82,7 @@ DEV double constraint_update(Ctx &c, int hess) {
 #pragma unroll
       for (int j = 1; j < DIMT; j++) F[j] = -f0 * iT * U[j] * fr[j];
       st = STATE_CONE;
-      if (hess) {
+      if (WRITE && hess) {
         // cone Hessian  S d2s/dU2 S  (S = diag(mu, friction), s = 1/2 Dm (N - mu T)^2)  in factored form:
         //   Dm p p^T + kap (diag(fr_t^2) - q q^T),  p_a = fr_a g_a,  q_t = fr_t U_t / T,  kap = -mu (N - mu T) Dm / T > 0
         // stored pre-scaled by sqrt(Dm) / sqrt(kap) so that the Hessian is a sum of +- outer products of combined rows
@@ -98,13 +100,15 @@ DEV double constraint_update(Ctx &c, int hess) {
         }
       }
     }
+    if (WRITE) {
 #pragma unroll
-    for (int j = 0; j < DIMT; j++) if (j < dim) { c.efc_force[i + j] = F[j]; c.efc_state[i + j] = st; }
+      for (int j = 0; j < DIMT; j++) if (j < dim) { c.efc_force[i + j] = F[j]; c.efc_state[i + j] = st; }
+    }
   }
   return cost;
 }
 DEV double constraint_update_any(Ctx &c, int hess) {
-  return c.M->maxdim <= 3 ? constraint_update<3>(c, hess) : constraint_update<6>(c, hess);
+  return c.M->maxdim <= 3 ? constraint_update<3>(c, hess, c.efc_jar) : constraint_update<6>(c, hess, c.efc_jar);
 }
 
 // y_i = M_i . x  (i < nv)  and  out_r = J_r . x  (r < nefc; single-entry rows use their one column).
@@ -401,9 +405,27 @@ DEV void newton_gradient(Ctx &c, int grad_only) {
   SYNC();
   PROF(c, 16);
 }
+// helper wave: total cost at qacc_smooth (Gauss term is exactly 0 there), same arithmetic as solver_eval; the residuals go
+// to the scratch array efc_pos (consumed by make_impedance before the solve phase), nothing the owner uses is written
+#define HX_CSM 23
+template <int NVT>
+DEV double cost_at_smooth(Ctx &c) {
+  double *jar = c.efc_pos;
+  mat_rows_times<NVT>(c, c.qacc_smooth, c.cfrc_sub, jar);       // M x lands in a scratch nobody reads during the solve (recomputed every step)
+  PFOR(r, c.nefc) jar[r] -= c.efc_aref[r];
+  SYNC();
+  double part = c.M->maxdim <= 3 ? constraint_update<3, false>(c, 0, jar) : constraint_update<6, false>(c, 0, jar);
+  return 0.0 + wave_sum(part);
+}
+
 #if MJPC_HELPER
 template <int NVT, int K>
 DEV void solver_helper_loop(Ctx &c, int seq) {
+  if (K == MJPC_NH - 1 && c.nefc > 0) {            // the last helper prices the unconstrained acceleration for the warm-start choice
+    double cs = cost_at_smooth<NVT>(c);
+    if (LANE == 0) c.red[2] = cs;
+    flag_set(c.misc + HX_CSM, seq / 256 + 1);
+  }
   if constexpr (NVT > 0) {
     constexpr int NP = MJPC_NH + 1;
     for (;;) {
@@ -599,8 +621,15 @@ DEV void solve_constraints(Ctx &c) {
   PROF(c, 7);
   // warm start: the better of qacc_smooth and qacc_warmstart (evaluated last, so its force/state stay valid)
   double gauss, cost;
-  double cost_sm = solver_eval<NVT>(c, c.qacc_smooth, 0);
+  double cost_sm;
+#if MJPC_HELPER
   double cost_ws = solver_eval<NVT>(c, c.qacc_ws, &gauss);
+  if (!flag_wait(c.misc + HX_CSM, c.hseq / 256 + 1)) c.warning |= WARN_SYNC;     // priced by the last helper meanwhile
+  cost_sm = c.red[2];
+#else
+  cost_sm = solver_eval<NVT>(c, c.qacc_smooth, 0);
+  double cost_ws = solver_eval<NVT>(c, c.qacc_ws, &gauss);
+#endif
   if (cost_ws > cost_sm) {
     PFOR(i, nv) c.qacc[i] = c.qacc_smooth[i];
     SYNC();

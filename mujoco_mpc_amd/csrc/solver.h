@@ -363,6 +363,9 @@ DEV void newton_entries(Ctx &c, int npos, int nneg, int grad_only, int part, int
 #define HX_NNEG 16
 #define HX_HFILL 17      // + k
 #define HX_HDONE 20      // + k
+#ifndef MJPC_SPLIT_FILL
+#define MJPC_SPLIT_FILL 1
+#endif
 #define HX_MFACT 22      // factor of M ready (helper 0 -> side wave), value t + 1
 
 // column range of part p of NP for an NVT-wide row
@@ -380,11 +383,18 @@ DEV void newton_gradient(Ctx &c, int grad_only) {
   if (NVT > 0 && !grad_only) {
     constexpr int NP = MJPC_NH + 1;
     int seq = ++c.hseq;
+#if MJPC_SPLIT_FILL
     if (LANE == 0) { c.misc[HX_NPOS] = npos; c.misc[HX_NNEG] = nneg; c.misc[HX_KIND] = 1; }
     flag_set(c.misc + HX_JOB, seq);
     newton_fill<NVT, FILL_C0(NVT, 0, NP), FILL_C1(NVT, 0, NP), 0>(c, npos, nneg);
     flag_set(c.misc + HX_W0FILL, seq);
     for (int k = 0; k < MJPC_NH; k++) if (!flag_wait(c.misc + HX_HFILL + k, seq)) c.warning |= WARN_SYNC;
+#else
+    // the owner fills all the scaled rows, then posts the job: one hand-shake (entries done) per call instead of two
+    newton_fill<NVT, 0, NVT, 1>(c, npos, nneg);
+    if (LANE == 0) { c.misc[HX_NPOS] = npos; c.misc[HX_NNEG] = nneg; c.misc[HX_KIND] = 1; }
+    flag_set(c.misc + HX_JOB, seq);
+#endif
     newton_entries<NVT, (NP >= 3 ? 1 : 2)>(c, npos, nneg, 0, 0, NP);
     for (int k = 0; k < MJPC_NH; k++) if (!flag_wait(c.misc + HX_HDONE + k, seq)) c.warning |= WARN_SYNC;
   } else
@@ -433,10 +443,12 @@ DEV void solver_helper_loop(Ctx &c, int seq) {
       if (!flag_wait(c.misc + HX_JOB, seq)) return;             // timed out: the owner reports the failure
       if (uniform_i(c.misc[HX_KIND]) == 0) return;
       int npos = uniform_i(c.misc[HX_NPOS]), nneg = uniform_i(c.misc[HX_NNEG]);
+#if MJPC_SPLIT_FILL
       newton_fill<NVT, FILL_C0(NVT, K + 1, NP), FILL_C1(NVT, K + 1, NP), (K + 1 == NP - 1)>(c, npos, nneg);
       flag_set(c.misc + HX_HFILL + K, seq);
       if (!flag_wait(c.misc + HX_W0FILL, seq)) return;
       for (int k = 0; k < MJPC_NH; k++) if (k != K && !flag_wait(c.misc + HX_HFILL + k, seq)) return;
+#endif
       newton_entries<NVT, (NP >= 3 ? 1 : 2)>(c, npos, nneg, 0, K + 1, NP);
       flag_set(c.misc + HX_HDONE + K, seq);
     }

@@ -126,10 +126,9 @@ DEV void flag_set(int *p, int v) {
 }
 DEV int flag_wait(int *p, int v) {
   int ok = 0;
-  for (int n = 0; n < (1 << 20); n++) {
+  for (int n = 0; n < (1 << 21); n++) {
     int cur = __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
     if (cur == v) { ok = 1; break; }
-    __builtin_amdgcn_s_sleep(1);
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   return ok;

@@ -640,7 +640,9 @@ DEV double impedance(const double *solimp_in, double pos, double margin) {
   return si0 + y * (si1 - si0);
 }
 
-DEV void make_constraint(Ctx &c) {
+// rows that need no contact (friction loss, joint limits, fixed-tendon limits): rows [0, n_nc), incl. their Jacobian.
+// A helper wave builds them (and their impedance) while the owner wave is still in the collision phase.
+DEV void make_noncontact_rows(Ctx &c, int *nsingle_out, int *n_nc_out) {
   const DevModel &M = *c.M;
   int nv = M.nv, nvp = M.nvp;
   int nefc = M.nfric;
@@ -676,7 +678,6 @@ DEV void make_constraint(Ctx &c) {
     nefc += tot;
   }
   int nlim_end = nefc;
-  c.nsingle = nlim_end;
   // fixed-tendon limits (general rows: several Jacobian entries), lower side before upper side
   int ntl0 = nefc;
   for (int base = 0; base < M.ntendon; base += NLANE) {
@@ -702,6 +703,28 @@ DEV void make_constraint(Ctx &c) {
     nefc += tot;
   }
   int ntl_end = nefc;
+  SYNC();
+  PFOR(e, ntl_end * nvp) c.efc_J[e] = 0;
+  SYNC();
+  PFOR(r, nlim_end) {
+    if (r < M.nfric) c.efc_J[r * nvp + c.efc_id[r]] = 1;
+    else { c.efc_J[r * nvp + MI(jnt_dofadr)[c.efc_id[r]]] = c.efc_floss[r]; c.efc_floss[r] = 0; }
+  }
+  PFOR(rr, ntl_end - ntl0) {
+    int r = ntl0 + rr, t = c.efc_id[r];
+    double sg = c.efc_floss[r];
+    for (int w = MI(tendon_adr)[t]; w < MI(tendon_adr)[t] + MI(tendon_num)[t]; w++) c.efc_J[r * nvp + MI(wrap_dofadr)[w]] = sg * MD(wrap_prm)[w];
+    c.efc_floss[r] = 0;
+  }
+  SYNC();
+  *nsingle_out = nlim_end; *n_nc_out = ntl_end;
+}
+
+// contact rows [n_nc, nefc): dim rows per contact (2(dim-1) pyramid edges), their Jacobian, the cross-branch flag
+DEV void make_contact_rows(Ctx &c, int n_nc) {
+  const DevModel &M = *c.M;
+  int nv = M.nv, nvp = M.nvp;
+  int nefc = n_nc;
   // contacts: dim rows each
   for (int base = 0; base < c.ncon; base += NLANE) {
     int ci = base + LANE, dim = 0;
@@ -743,18 +766,8 @@ DEV void make_constraint(Ctx &c) {
   c.cross = wave_or_i(crossflag);
   SYNC();
   // Jacobian
-  PFOR(e, nefc * nvp) c.efc_J[e] = 0;
+  PFOR(e, (nefc - n_nc) * nvp) c.efc_J[n_nc * nvp + e] = 0;
   SYNC();
-  PFOR(r, nlim_end) {
-    if (r < M.nfric) c.efc_J[r * nvp + c.efc_id[r]] = 1;
-    else { c.efc_J[r * nvp + MI(jnt_dofadr)[c.efc_id[r]]] = c.efc_floss[r]; c.efc_floss[r] = 0; }
-  }
-  PFOR(rr, ntl_end - ntl0) {
-    int r = ntl0 + rr, t = c.efc_id[r];
-    double sg = c.efc_floss[r];
-    for (int w = MI(tendon_adr)[t]; w < MI(tendon_adr)[t] + MI(tendon_num)[t]; w++) c.efc_J[r * nvp + MI(wrap_dofadr)[w]] = sg * MD(wrap_prm)[w];
-    c.efc_floss[r] = 0;
-  }
   PFOR(e, c.ncon * nv) {
     int ci = e / nv, d = e - ci * nv;
     const int *cin = c.con_i + ci * CONI_STRIDE;
@@ -802,10 +815,12 @@ DEV void make_constraint(Ctx &c) {
 }
 
 // efc_vel, impedance, R, D, aref
-DEV void make_impedance(Ctx &c) {
+// rows [r0, r1); with_contacts: also the contact pass (cone mu, per-row R of the friction rows)
+DEV void make_impedance(Ctx &c, int r0, int r1, int with_contacts) {
   const DevModel &M = *c.M;
   int nv = M.nv, nvp = M.nvp;
-  PFOR(r, c.nefc) {
+  PFOR(rr, r1 - r0) {
+    int r = r0 + rr;
     int type = c.efc_type[r], id = c.efc_id[r];
     double vel = 0;
     for (int i = 0; i < nv; i++) vel += c.efc_J[r * nvp + i] * c.qvel[i];
@@ -842,7 +857,7 @@ DEV void make_impedance(Ctx &c) {
     c.efc_aref[r] = -B * vel - K * imp * (c.efc_pos[r] - c.efc_margin[r]);
   }
   SYNC();
-  PFOR(ci, c.ncon) {
+  if (with_contacts) PFOR(ci, c.ncon) {
     int dim = c.con_i[ci * CONI_STRIDE];
     if (dim > 1) {
       double *cc = c.contact + ci * c.M->con_stride;
@@ -860,7 +875,7 @@ DEV void make_impedance(Ctx &c) {
     }
   }
   SYNC();
-  PFOR(r, c.nefc) c.efc_D[r] = 1 / c.efc_R[r];
+  PFOR(rr, r1 - r0) c.efc_D[r0 + rr] = 1 / c.efc_R[r0 + rr];
   SYNC();
 }
 
@@ -1377,7 +1392,7 @@ DEV_NOINLINE void ph_init(KP Kc) {
     c.xquat[0] = 1; c.xquat[1] = 0; c.xquat[2] = 0; c.xquat[3] = 0;
     for (int k = 0; k < 9; k++) { c.xmat[k] = (k % 4 == 0) ? 1.0 : 0.0; c.ximat[k] = c.xmat[k]; }
     for (int k = 0; k < 6; k++) { c.cvel[k] = 0; c.cfrc[k] = 0; c.cacc[k] = (k >= 3) ? -M.gravity[k - 3] : 0.0; }
-    for (int k = 0; k < 24; k++) c.misc[k] = 0;
+    for (int k = 0; k < 28; k++) c.misc[k] = 0;
 #if defined(MJPC_PROFILE) && !defined(MJPC_EMU)
     for (int q = 0; q < NPROF; q++) c.prof[q] = 0;
     c.prof[NPROF] = (long long)__builtin_amdgcn_s_memtime();
@@ -1412,14 +1427,37 @@ DEV_NOINLINE void ph_head(KP Kc, int t, int last) {
   com_pos(c); PROF(c, 2);
   ctx_close(c);
 }
-// role 0: contacts and constraint rows (needs positions + qvel only)
-DEV_NOINLINE void ph_constraints(KP Kc) {
+// role 0: contacts and constraint rows (needs positions + qvel only).  With helper waves the contact-free rows and their
+// impedance are built by the last helper meanwhile (ph_noncontact); it publishes nsingle / n_nc in misc[25..26], flag misc[24].
+DEV_NOINLINE void ph_constraints(KP Kc, int t) {
   Ctx c; ctx_open(c, Kc);
   collision(c); PROF(c, 4);
-  make_constraint(c); PROF(c, 5);
-  make_impedance(c); PROF(c, 7);
+  int nsingle, n_nc;
+#if MJPC_HELPER
+  if (!flag_wait(c.misc + 24, t + 1)) c.warning |= WARN_SYNC;
+  nsingle = uniform_i(c.misc[25]); n_nc = uniform_i(c.misc[26]);
+  c.nsingle = nsingle;
+  make_contact_rows(c, n_nc); PROF(c, 5);
+  make_impedance(c, n_nc, c.nefc, 1); PROF(c, 7);
+#else
+  make_noncontact_rows(c, &nsingle, &n_nc);
+  c.nsingle = nsingle;
+  make_contact_rows(c, n_nc); PROF(c, 5);
+  make_impedance(c, 0, c.nefc, 1); PROF(c, 7);
+#endif
   ctx_close(c);
 }
+#if MJPC_HELPER
+DEV_NOINLINE void ph_noncontact(KP Kc, int t) {
+  Ctx c; ctx_open(c, Kc, 1);
+  int nsingle, n_nc;
+  make_noncontact_rows(c, &nsingle, &n_nc);
+  if (LANE == 0) { c.misc[25] = nsingle; c.misc[26] = n_nc; }
+  flag_set(c.misc + 24, t + 1);
+  make_impedance(c, 0, n_nc, 0);
+  ctx_close(c);
+}
+#endif
 // role 1, concurrently with ph_constraints: joint-space inertia + its factor, smooth dynamics (qfrc_smooth, qacc_smooth)
 template <int NVT>
 DEV_NOINLINE void ph_smooth(KP Kc, int t) {
@@ -1570,10 +1608,11 @@ DEV void rollout(KP Kc) {
     if (r0) ph_head<NVT>(Kc, t, last);
     XBAR();
     if (uniform_i(misc[10])) { failure = 1; break; }
-    if (r0) ph_constraints(Kc);
+    if (r0) ph_constraints(Kc, t);
     if (r1) ph_smooth<NVT>(Kc, t);
 #if MJPC_HELPER
     if (ROLEH && WAVE_ID() == 1) ph_inertia<NVT>(Kc, t);
+    if (ROLEH && WAVE_ID() == MJPC_WAVES - 2) ph_noncontact(Kc, t);
 #endif
     XBAR();
     if (r0) ph_solve<NVT>(Kc, last, t);

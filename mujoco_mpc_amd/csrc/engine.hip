@@ -82,6 +82,34 @@ extern "C" __global__ void __launch_bounds__(64) argmin_kernel(const double *ret
   if (lane == 0) { winner[0] = bi; winner_val[0] = best; }
 }
 
+// gathers everything the host wants after a plan step into ONE contiguous buffer (one D2H copy instead of eleven):
+//   [winner index, winner return | returns[nl] | failure[nl] (as doubles) | winner rows: states, actions, times, residual,
+//    costs, trace, knots]
+struct PackArgs {
+  const int *winner; const double *winner_val, *returns; const int *failure;
+  const double *states, *actions, *times, *residual, *costs, *trace, *knots;
+  int nl, H, P, ds, nu, nr, ntr;
+  double *dst;
+};
+extern "C" __global__ void __launch_bounds__(256) pack_kernel(const PackArgs a) {
+  int w = a.winner[0];
+  int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
+  double *d = a.dst;
+  if (tid == 0) { d[0] = (double)w; d[1] = a.winner_val[0]; }
+  d += 2;
+  for (int i = tid; i < a.nl; i += nth) { d[i] = a.returns[i]; d[a.nl + i] = (double)a.failure[i]; }
+  d += 2 * a.nl;
+  if (w < 0 || w >= a.nl) return;
+  size_t H = (size_t)a.H, r = (size_t)w;
+  const double *src[7] = {a.states + r * H * a.ds, a.actions + r * H * a.nu, a.times + r * H, a.residual + r * H * a.nr,
+                          a.costs + r * H, a.trace + r * H * a.ntr, a.knots + r * (size_t)a.P * a.nu};
+  size_t cnt[7] = {H * a.ds, H * a.nu, H, H * a.nr, H, H * a.ntr, (size_t)a.P * a.nu};
+  for (int k = 0; k < 7; k++) {
+    for (size_t i = tid; i < cnt[k]; i += nth) d[i] = src[k][i];
+    d += cnt[k];
+  }
+}
+
 // ------------------------------------------------------------------------------ host side
 static thread_local std::string g_error;
 static void set_error(const std::string &s) { g_error = s; }
@@ -107,6 +135,7 @@ struct MjpcHipEngine {
   int *d_failure = nullptr, *d_diag = nullptr, *d_winner = nullptr;
   long long *d_prof = nullptr;
   // pinned host staging
+  double *d_pack = nullptr, *h_pack = nullptr; size_t pack_cap = 0;   // packed plan result (device / pinned host)
   double *h_small = nullptr;   // state | mocap | knot_times | knot_values | noise_std
   // last plan
   int last_H = 0, last_P = 0, last_nlocal = 0, last_offset = 0, pending = 0;
@@ -186,6 +215,8 @@ void mjpc_hip_destroy(MjpcHipEngine *e) {
                   e->d_winner, e->d_winner_val, e->d_prof};
   for (void *b : bufs) if (b) hipFree(b);
   if (e->h_small) hipHostFree(e->h_small);
+  if (e->h_pack) hipHostFree(e->h_pack);
+  if (e->d_pack) hipFree(e->d_pack);
   for (int i = 0; i < 4; i++) if (e->ev[i]) hipEventDestroy(e->ev[i]);
   if (e->stream) hipStreamDestroy(e->stream);
   delete e;
@@ -260,6 +291,21 @@ int mjpc_hip_plan_async(MjpcHipEngine *e, const MjpcHipPlanInput *in) {
   HIPCHK(hipEventRecord(e->ev[2], e->stream));
   hipLaunchKernelGGL(argmin_kernel, dim3(1), dim3(64), 0, e->stream, e->d_returns, nl, e->d_winner, e->d_winner_val);
   HIPCHK(hipEventRecord(e->ev[3], e->stream));
+  {
+    size_t rows = (size_t)H * (e->ds + nu + 2 + e->nr + e->ntr) + (size_t)P * nu;
+    size_t need_pack = 2 + 2 * (size_t)nl + rows;
+    if (need_pack > e->pack_cap) {
+      if (e->d_pack) HIPCHK(hipFree(e->d_pack));
+      if (e->h_pack) HIPCHK(hipHostFree(e->h_pack));
+      HIPCHK(hipMalloc(&e->d_pack, sizeof(double) * need_pack));
+      HIPCHK(hipHostMalloc(&e->h_pack, sizeof(double) * need_pack));
+      e->pack_cap = need_pack;
+    }
+    PackArgs pa{e->d_winner, e->d_winner_val, e->d_returns, e->d_failure, e->d_states, e->d_actions, e->d_times, e->d_residual,
+                e->d_costs, e->d_trace, e->d_knots, nl, H, P, e->ds, nu, e->nr, e->ntr, e->d_pack};
+    hipLaunchKernelGGL(pack_kernel, dim3(8), dim3(256), 0, e->stream, pa);
+    HIPCHK(hipMemcpyAsync(e->h_pack, e->d_pack, sizeof(double) * need_pack, hipMemcpyDeviceToHost, e->stream));
+  }
   HIPCHK(hipGetLastError());
   e->last_H = H; e->last_P = P; e->last_nlocal = nl; e->last_offset = in->candidate_offset; e->pending = 1;
   return 0;
@@ -281,13 +327,15 @@ static int fetch_rows(MjpcHipEngine *e, int local, MjpcHipPlanOutput *out) {
 int mjpc_hip_plan_fetch(MjpcHipEngine *e, MjpcHipPlanOutput *out) {
   if (!e || !out || !e->last_nlocal) { set_error("mjpc_hip_plan_fetch: nothing planned"); return -1; }
   HIPCHK(hipSetDevice(e->device));
-  int wl = 0; double wv = 0;
-  HIPCHK(hipMemcpyAsync(&wl, e->d_winner, sizeof(int), hipMemcpyDeviceToHost, e->stream));
-  HIPCHK(hipMemcpyAsync(&wv, e->d_winner_val, sizeof(double), hipMemcpyDeviceToHost, e->stream));
-  if (out->returns) HIPCHK(hipMemcpyAsync(out->returns, e->d_returns, sizeof(double) * e->last_nlocal, hipMemcpyDeviceToHost, e->stream));
-  if (out->failure) HIPCHK(hipMemcpyAsync(out->failure, e->d_failure, sizeof(int) * e->last_nlocal, hipMemcpyDeviceToHost, e->stream));
-  HIPCHK(hipStreamSynchronize(e->stream));
-  if (wl < 0 || wl >= e->last_nlocal) { set_error("mjpc_hip_plan_fetch: argmin out of range (all returns non-finite?)"); return -3; }
+  HIPCHK(hipStreamSynchronize(e->stream));            // the packed result of plan_async is in pinned host memory now
+  const double *p = e->h_pack;
+  int nl = e->last_nlocal;
+  int wl = (int)p[0]; double wv = p[1];
+  p += 2;
+  if (out->returns) memcpy(out->returns, p, sizeof(double) * nl);
+  if (out->failure) for (int i = 0; i < nl; i++) out->failure[i] = (int)p[nl + i];
+  p += 2 * (size_t)nl;
+  if (wl < 0 || wl >= nl) { set_error("mjpc_hip_plan_fetch: argmin out of range (all returns non-finite?)"); return -3; }
   out->winner = e->last_offset + wl; out->winner_return = wv;
   if (e->pending) {
     float t01 = 0, t12 = 0, t03 = 0;
@@ -296,7 +344,14 @@ int mjpc_hip_plan_fetch(MjpcHipEngine *e, MjpcHipPlanOutput *out) {
     e->acc_rollout_us += 1e3 * t12; e->acc_total_us += 1e3 * t03; e->acc_n++;
     e->pending = 0;
   }
-  return fetch_rows(e, wl, out);
+  size_t H = (size_t)e->last_H, P = (size_t)e->last_P;
+  double *dst[7] = {out->states, out->actions, out->times, out->residual, out->costs, out->trace, out->winner_knots};
+  size_t cnt[7] = {H * e->ds, H * e->nu, H, H * e->nr, H, H * e->ntr, P * e->nu};
+  for (int k = 0; k < 7; k++) {
+    if (dst[k] && cnt[k]) memcpy(dst[k], p, sizeof(double) * cnt[k]);
+    p += cnt[k];
+  }
+  return 0;
 }
 
 int mjpc_hip_plan(MjpcHipEngine *e, const MjpcHipPlanInput *in, MjpcHipPlanOutput *out) {

@@ -46,7 +46,8 @@ DEV int uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
 #if defined(MJPC_PROFILE) && !defined(MJPC_EMU)
 #define NPROF 24
 // diagnostic builds only: lane 0 accumulates s_memtime deltas per phase slot in LDS
-#define PROF(c, i) do { if (LANE == 0) { long long t_ = (long long)__builtin_amdgcn_s_memtime(); (c).prof[i] += t_ - (c).prof[NPROF]; (c).prof[NPROF] = t_; } } while (0)
+// (multi-wave builds: only the owner wave stamps, so the slots show ITS timeline including the waits for the other waves)
+#define PROF(c, i) do { if (LANE == 0 && (c).role == 0) { long long t_ = (long long)__builtin_amdgcn_s_memtime(); (c).prof[i] += t_ - (c).prof[NPROF]; (c).prof[NPROF] = t_; } } while (0)
 #else
 #define PROF(c, i) ((void)0)
 #endif

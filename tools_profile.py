@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__)); sys.path.insert(0, ROOT)
 CSRC = os.path.join(ROOT, "mujoco_mpc_amd", "csrc")
 so = os.path.join(ROOT, "gpurun_out", "libmjpc_hip_prof.so")
 os.makedirs(os.path.dirname(so), exist_ok=True)
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DMJPC_PROFILE=1", "-DMJPC_WAVES=1",
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DMJPC_PROFILE=1"] + (["-DMJPC_WAVES=1"] if os.environ.get("PROFILE_ONE_WAVE") else []) + [
                        "-Wno-unused-value", "-o", so, os.path.join(CSRC, "engine.hip")])
 from mujoco_mpc_amd import capi
 capi.ENGINE_PATH = so

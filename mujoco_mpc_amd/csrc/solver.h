@@ -204,8 +204,8 @@ DEV void newton_lists(Ctx &c, int *npos_out, int *nneg_out) {
 
 // scaled rows JH[e][C0..C1) (+ the phi column when PHI): rows [0, npos8) positives zero-padded to a multiple of 8,
 // rows [npos8, npos8 + nneg4) negatives padded to 4.  The column range lets two waves share the fill.
-template <int NVT, int C0, int C1, int PHI>
-DEV void newton_fill(Ctx &c, int npos, int nneg) {
+template <int NVT, int C0, int C1, int PHI, int DIMT>
+DEV void newton_fill_d(Ctx &c, int npos, int nneg) {
   const DevModel &M = *c.M;
   const int nv = NVT > 0 ? NVT : M.nv, nvp = NVT > 0 ? NVP_OF(NVT) : M.nvp;
   const int negbase = M.nefcmax;
@@ -214,34 +214,39 @@ DEV void newton_fill(Ctx &c, int npos, int nneg) {
   double *JH = c.efc_JA;
   for (int base = 0; base < ntot; base += NLANE) {
     int e = base + LANE;
-    double coef[6]; int rowb[6]; int nb = 0; double phi = 0;
-#pragma unroll
-    for (int b = 0; b < 6; b++) { coef[b] = 0; rowb[b] = 0; }
+    // branch-free descriptor: every lane issues the same loads (row, its contact, the contact's cone factors) and the four
+    // cases (quadratic row / cone p-row / cone tangential row / negative q-row) are selected afterwards, so the dependent
+    // LDS chain is walked once instead of once per divergent case
+    double coef[DIMT]; int rowb[DIMT]; int nb = 0; double phi = 0;
     int neg = e >= npos8;
     int valid = neg ? (e - npos8 < nneg) : (e < npos);
-    if (valid) {
-      int r = neg ? c.active[negbase + e - npos8] : c.active[e];
-      if (c.efc_state[r] == STATE_QUADRATIC) {
-        double D = c.efc_D[r], sd = D * fast_rsqrt(D);
-        coef[0] = sd; rowb[0] = r * nvp; nb = 1; phi = -sd * c.efc_jar[r];
-      } else {
-        int ci = c.efc_id[r];
-        int dim = c.con_i[ci * CONI_STRIDE], r0 = c.con_i[ci * CONI_STRIDE + 3];
-        const double *cf = c.contact + ci * M.con_stride + CON_H;
-        int k = r - r0;
-        if (neg) {
-          nb = dim - 1;
+    int r = valid ? (neg ? c.active[negbase + e - npos8] : c.active[e]) : c.nsingle;
+    if (r >= c.nefc) r = c.nefc - 1;
+    int st = c.efc_state[r], type = c.efc_type[r];
+    double D = c.efc_D[r], jr = c.efc_jar[r];
+    int is_con = type >= CNSTR_CONTACT_FRICTIONLESS;
+    int ci = is_con ? c.efc_id[r] : 0;
+    int dim = c.con_i[ci * CONI_STRIDE], r0 = c.con_i[ci * CONI_STRIDE + 3];
+    const double *cf = c.contact + ci * M.con_stride + (M.con_stride > CON_H ? CON_H : 0);
+    double cp[DIMT], cq[DIMT], ct[DIMT];
 #pragma unroll
-          for (int b = 1; b < 6; b++) if (b < dim) { coef[b - 1] = cf[6 + b]; rowb[b - 1] = (r0 + b) * nvp; }
-        } else if (k > 0) {
-          nb = 1; coef[0] = cf[12 + k]; rowb[0] = r * nvp;
-        } else {
-          nb = dim; phi = cf[12];
+    for (int b = 0; b < DIMT; b++) { cp[b] = cf[b]; cq[b] = cf[6 + b]; ct[b] = cf[12 + b]; }
+    int cone = valid && st == STATE_CONE;
+    int k = r - r0;
+    double sd = D * fast_rsqrt(D);
+    double tk = 0;
 #pragma unroll
-          for (int b = 0; b < 6; b++) if (b < dim) { coef[b] = cf[b]; rowb[b] = (r0 + b) * nvp; }
-        }
-      }
+    for (int b = 1; b < DIMT; b++) tk = (k == b) ? ct[b] : tk;
+    int caseP = cone && !neg && k == 0, caseT = cone && !neg && k > 0, caseQ = cone && neg, caseD = valid && !cone;
+#pragma unroll
+    for (int b = 0; b < DIMT; b++) {
+      double cb = caseP ? (b < dim ? cp[b] : 0.0) : (caseQ ? ((b + 1 < dim && b + 1 < DIMT) ? cq[b + 1 < DIMT ? b + 1 : 0] : 0.0) : 0.0);
+      int rb = caseP ? (b < dim ? r0 + b : r0) : (caseQ ? (b + 1 < dim ? r0 + b + 1 : r0) : r);
+      if (b == 0) { cb = caseD ? sd : (caseT ? tk : cb); }
+      coef[b] = cb; rowb[b] = rb * nvp;
     }
+    nb = caseP ? dim : (caseQ ? dim - 1 : (valid ? 1 : 0));
+    phi = caseD ? -sd * jr : (caseP ? ct[0] : 0.0);
     if constexpr (NVT > 0) {
       constexpr int NC = C1 - C0;
       double acc[NC > 0 ? NC : 1];
@@ -249,7 +254,7 @@ DEV void newton_fill(Ctx &c, int npos, int nneg) {
 #pragma unroll
         for (int j = 0; j < NC; j++) acc[j] = coef[0] * Jr[j]; }
 #pragma unroll
-      for (int b = 1; b < 6; b++) {
+      for (int b = 1; b < DIMT; b++) {
         if (!wave_any(nb > b)) break;
         const double *Jr = c.efc_J + rowb[b] + C0;
 #pragma unroll
@@ -267,13 +272,19 @@ DEV void newton_fill(Ctx &c, int npos, int nneg) {
         for (int j = 0; j < nv; j++) {
           double a = 0;
 #pragma unroll
-          for (int b = 0; b < 6; b++) if (b < nb) a += coef[b] * c.efc_J[rowb[b] + j];
+          for (int b = 0; b < DIMT; b++) if (b < nb) a += coef[b] * c.efc_J[rowb[b] + j];
           o[j] = a;
         }
         o[nv] = phi;
       }
     }
   }
+}
+
+template <int NVT, int C0, int C1, int PHI>
+DEV void newton_fill(Ctx &c, int npos, int nneg) {
+  if (c.M->maxdim <= 3) newton_fill_d<NVT, C0, C1, PHI, 3>(c, npos, nneg);
+  else newton_fill_d<NVT, C0, C1, PHI, 6>(c, npos, nneg);
 }
 
 // H = M + diag(single-entry rows) + JH+^T JH+ - JH-^T JH-  on the lower triangle (only M's sparsity pattern without

@@ -2,7 +2,8 @@
 //
 // Kernels (gfx950, wave64):
 //   noise_kernel    Philox4x32-10 + Box-Muller standard normals  eps[nlocal, P, nu]
-//   rollout_kernel  ONE WAVEFRONT PER CANDIDATE (grid = nlocal blocks x 64 threads); the candidate's
+//   rollout_kernel  ONE WORKGROUP PER CANDIDATE (grid = nlocal blocks x 64*MJPC_WAVES threads: an owner wave on the
+//                   critical path + helper / side waves on the CU's other SIMDs, see spmd.h); the candidate's
 //                   whole mjData-equivalent lives in dynamic LDS for all H steps; HBM traffic is only
 //                   the Trajectory record (coalesced row writes by the owning wave) + model reads
 //                   that hit L2 / the scalar cache.  Replaces planner.cc:342-380 + trajectory.cc:100-210.

@@ -1,5 +1,6 @@
 // solver.h — primal Newton solver for  min_a 1/2 (a-a0)^T M (a-a0) + sum_i s_i(J_i a - aref_i)
-// (what MuJoCo's default solver computes inside mj_step, mjpc/trajectory.cc:158), one wavefront.
+// (what MuJoCo's default solver computes inside mj_step, mjpc/trajectory.cc:158): one owner wavefront, optionally helped by
+// the candidate's helper waves for the data-parallel parts of an iteration.
 //
 // Layout of the work over the 64 lanes:
 //   * rows with a single +-1 Jacobian entry (friction loss, joint limits: [0, nsingle)) only touch the

@@ -164,7 +164,7 @@ def main():
                          "algorithmic_bytes_per_launch": bytes_per_launch, "bytes_per_candidate_step": b_step,
                          "plan_device_us": total_us},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # the CPU baseline is reported on rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(model, task, d, kt, kv, N, H, sigma)
         print(json.dumps(out))
     be.close()

@@ -164,6 +164,14 @@ typedef struct MjpcHipPlanInput {
    * planner perturbs all N candidates and rolls the nominal out as candidate N of num_trajectory = N+1
    * (cross_entropy/planner.cc:377-415) */
   int nominal_index;
+  /* Robust planner (mjpc/planners/robust/robust_planner.cc:91-157, Trajectory::NoisyRollout trajectory.cc:100-210):
+   * explicit candidate policies and Ornstein-Uhlenbeck external-force noise on every body.
+   * candidate_knots != NULL: candidate i uses candidate_knots[i] verbatim (no sampling noise at all).
+   * xfrc_std > 0: before every step xfrc_applied = rate * xfrc_applied + N(0, xfrc_std * sqrt(1 - rate^2)),
+   * rate = exp(-timestep / xfrc_rate) (trajectory.cc:147-155); normals from Philox(seed, stream ^ "XFRC", candidate i,
+   * element t*6*nbody + k). */
+  const double *candidate_knots;   /* [num_trajectory][num_spline_points][nu] (global indexing) or NULL */
+  double xfrc_std, xfrc_rate;
 } MjpcHipPlanInput;
 
 typedef struct MjpcHipPlanOutput {

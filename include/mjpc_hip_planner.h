@@ -7,6 +7,7 @@
 //   mjpc/trajectory.h:74-86                  Trajectory (public arrays)
 //   mjpc/planners/sampling/planner.h:51-162  SamplingPlanner (+ RankedPlanner virtuals, planners/planner.h:84-101)
 //   mjpc/planners/cross_entropy/planner.h:32-147  CrossEntropyPlanner (same rollout engine, elite mean/variance update)
+//   mjpc/planners/robust/robust_planner.h:31-80   RobustPlanner (top-k candidates x R noisy rollouts on a second engine)
 // Differences forced by the boundary: `mjModel*` / `const Task&` become the ABI's MjpcHipModel / MjpcHipTask views
 // plus the planner's <custom><numeric> settings (Numerics); `ThreadPool&` arguments are gone (the GPU is the pool);
 // `State` is passed as its raw arrays (State::CopyTo, mjpc/states/state.cc:128-135).
@@ -83,6 +84,9 @@ struct Numerics {                       // the planner's <custom><numeric> entri
   int sampling_spline_points = kMaxTrajectoryHorizon;
   int max_samples = 4096;              // kMaxTrajectory is 128 in the reference (planners/planner.h:28); lifted here
   double std_min = 0.1;                // cross-entropy: minimum std (cross_entropy/planner.cc:58)
+  int robust_repetitions = 5;          // robust planner (robust_planner.cc:45-57)
+  int robust_candidates = -1;          // default sampling_trajectories / robust_repetitions
+  double robust_xfrc = 0.1, robust_xfrc_rate = 0.1;
   int n_elite = -1;                    // cross-entropy: default max(sampling_trajectories / 10, 2) (planner.cc:63-64)
   int max_horizon = kMaxTrajectoryHorizon;   // device trajectory buffers are sized max_samples x max_horizon
   int device = 0;
@@ -114,6 +118,9 @@ class SamplingPlanner {
   void UpdateNominalPolicy(int horizon);
   void SetTask(const MjpcHipTask* task);               // fresh ResidualFn copy per plan step (agent.cc:290)
 
+  // knot values of candidate `candidate` (ranked order) of the last OptimizePolicyCandidates, [P*nu]; P via KnotTimes()
+  void CandidateKnots(int candidate, double* out);
+  const std::vector<double>& KnotTimes() const { return knot_times_; }
   // ---- public members other code reads/writes in the reference (planner.h:115-162)
   SamplingPolicy policy, previous_policy;
   std::vector<double> state, mocap, userdata;
@@ -198,6 +205,46 @@ class CrossEntropyPlanner {
   std::vector<double> ctrlrange_, knot_values_, noise_std_, all_knots_;
   int last_horizon_ = 0;
   mutable std::shared_mutex mtx_;
+};
+
+// mjpc/planners/robust/robust_planner.{h,cc}: the delegate ranks its candidates; the best `ncandidates_` are rolled out
+// `nrepetitions_` times each with Ornstein-Uhlenbeck force noise on every body (Trajectory::NoisyRollout) in ONE launch of a
+// second engine (explicit candidate policies); the candidate with the best mean return over the delegate's own score and
+// its valid noisy rollouts is adopted.
+class RobustPlanner {
+ public:
+  RobustPlanner() = default;
+  ~RobustPlanner();
+  RobustPlanner(const RobustPlanner&) = delete;
+  RobustPlanner& operator=(const RobustPlanner&) = delete;
+
+  void Initialize(const MjpcHipModel* model, const MjpcHipTask* task, const Numerics& numerics);
+  void Allocate();
+  void Reset(int horizon, const double* initial_repeated_action = nullptr);
+  void SetState(const double* state, const double* mocap, const double* userdata, double time);
+  void OptimizePolicy(int horizon);
+  void NominalTrajectory(int horizon) { delegate.NominalTrajectory(horizon); }
+  void ActionFromPolicy(double* action, const double* state, double time, bool use_previous = false) { delegate.ActionFromPolicy(action, state, time, use_previous); }
+  const Trajectory* BestTrajectory() { return delegate.BestTrajectory(); }
+  int NumParameters() { return delegate.NumParameters(); }
+  void SetTask(const MjpcHipTask* task);
+
+  SamplingPlanner delegate;                            // delegate_ (a RankedPlanner)
+  int ncandidates_ = 12, nrepetitions_ = 5;
+  double xfrc_std_ = 0.1, xfrc_rate_ = 0.1;
+  std::vector<double> noisy_returns;                   // [ncandidates * nrepetitions] of the last OptimizePolicy
+  std::vector<int> noisy_failures;
+  std::vector<double> candidate_scores;                // mean score per candidate (robust_planner.cc:131-146)
+  int best_candidate = -1;
+  unsigned long long seed = 0x0B057;
+  unsigned long long plan_iter = 0;
+
+ private:
+  MjpcHipEngine* engine_ = nullptr;                    // noisy rollouts (the delegate's engine keeps its plan for CopyCandidateToPolicy)
+  Numerics numerics_;
+  int nu_ = 0, ns_ = 0, nmocap_ = 0, nuserdata_ = 0;
+  std::vector<double> state_, mocap_, userdata_, cand_knots_;
+  double time_ = 0;
 };
 
 }  // namespace mjpc_hip

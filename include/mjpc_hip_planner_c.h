@@ -69,6 +69,19 @@ void mjpc_cem_variance(void *planner, double *out, int n);
 int mjpc_cem_policy(void *planner, double *times, double *values);                               /* returns P */
 int mjpc_cem_best_trajectory(void *planner, double *states, double *actions, double *costs, double *total_return);   /* returns H */
 
+/* RobustPlanner (mjpc/planners/robust/robust_planner.h:31-80) over a SamplingPlanner delegate */
+void *mjpc_robust_create(const MjpcHipModel *model, const MjpcHipTask *task, const double *exploration, int trajectories, int representation,
+                         int spline_points, int repetitions, int candidates, double xfrc_std, double xfrc_rate, int max_samples,
+                         int max_horizon, int device);
+void mjpc_robust_destroy(void *planner);
+void mjpc_robust_reset(void *planner, int horizon);
+void mjpc_robust_set_state(void *planner, const double *state, const double *mocap, const double *userdata, double time);
+void mjpc_robust_set_seed(void *planner, unsigned long long delegate_seed, unsigned long long robust_seed, unsigned long long plan_iter);
+void mjpc_robust_optimize_policy(void *planner, int horizon);
+void mjpc_robust_action_from_policy(void *planner, double *action, double time);
+void mjpc_robust_last(void *planner, int *out /* [3] best, ncand, rep */, double *scores, double *noisy_returns);
+void *mjpc_robust_delegate(void *planner);     /* the SamplingPlanner handle (mjpc_planner_* calls), owned by the robust planner */
+
 /* Closed-loop harness (include/mjpc_hip_testspeed.h; mjpc/testspeed.cc:44-129 `SynchronousPlanningCost`): world and planner on the
  * HIP engine.  planner_kind 0 = handle from mjpc_planner_create, 1 = handle from mjpc_cem_create.  state / mocap are in-out;
  * cost_per_step[ceil(total_time/timestep)] optional; out[6] = {average_cost, wall_seconds, realtime_factor, plan_seconds,

@@ -72,6 +72,7 @@ class MjpcHipPlanInput(C.Structure):
         ("candidate_offset", C.c_int), ("num_local", C.c_int), ("noise_exploration", C.c_double * 2),
         ("noise_eps", c_double_p), ("noise_sel", c_int_p), ("seed", C.c_uint64), ("stream", C.c_uint64),
         ("noise_std", c_double_p), ("nominal_index", C.c_int),
+        ("candidate_knots", c_double_p), ("xfrc_std", C.c_double), ("xfrc_rate", C.c_double),
     ]
 
 
@@ -148,7 +149,7 @@ class CModel:
 
 def make_plan_input(cm: CModel, state, mocap, time, knot_times, knot_values, interpolation, num_trajectory, horizon,
                     sigma=(0.1, 0.0), noise_eps=None, noise_sel=None, seed=0, stream=0, candidate_offset=0,
-                    num_local=None, userdata=None, noise_std=None, nominal_index=0):
+                    num_local=None, userdata=None, noise_std=None, nominal_index=0, candidate_knots=None, xfrc_std=0.0, xfrc_rate=0.0):
     keep = []
 
     def arr(x, n=None):
@@ -175,6 +176,9 @@ def make_plan_input(cm: CModel, state, mocap, time, knot_times, knot_values, int
     if noise_std is not None:
         inp.noise_std = _dp(arr(noise_std))
     inp.nominal_index = int(nominal_index)
+    if candidate_knots is not None:
+        inp.candidate_knots = _dp(arr(candidate_knots))
+    inp.xfrc_std = float(xfrc_std); inp.xfrc_rate = float(xfrc_rate)
     inp._keep = keep
     return inp
 

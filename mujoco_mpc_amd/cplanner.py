@@ -30,6 +30,8 @@ PLANNER_C_SYMBOLS = [
     "mjpc_cem_optimize_policy", "mjpc_cem_nominal_trajectory", "mjpc_cem_action_from_policy", "mjpc_cem_improvement",
     "mjpc_cem_returns", "mjpc_cem_variance", "mjpc_cem_policy", "mjpc_cem_best_trajectory",
     "mjpc_testspeed_run",
+    "mjpc_robust_create", "mjpc_robust_destroy", "mjpc_robust_reset", "mjpc_robust_set_state", "mjpc_robust_set_seed",
+    "mjpc_robust_optimize_policy", "mjpc_robust_action_from_policy", "mjpc_robust_last", "mjpc_robust_delegate",
 ]
 
 
@@ -93,6 +95,12 @@ def lib():
         "mjpc_cem_returns": (None, [vp, c_double_p, i]), "mjpc_cem_variance": (None, [vp, c_double_p, i]),
         "mjpc_cem_policy": (i, [vp, c_double_p, c_double_p]),
         "mjpc_cem_best_trajectory": (i, [vp, c_double_p, c_double_p, c_double_p, c_double_p]),
+        "mjpc_robust_create": (vp, [C.POINTER(capi.MjpcHipModel), C.POINTER(capi.MjpcHipTask), c_double_p, i, i, i, i, i, d, d, i, i, i]),
+        "mjpc_robust_destroy": (None, [vp]), "mjpc_robust_reset": (None, [vp, i]),
+        "mjpc_robust_set_state": (None, [vp, c_double_p, c_double_p, c_double_p, d]),
+        "mjpc_robust_set_seed": (None, [vp, C.c_ulonglong, C.c_ulonglong, C.c_ulonglong]),
+        "mjpc_robust_optimize_policy": (None, [vp, i]), "mjpc_robust_action_from_policy": (None, [vp, c_double_p, d]),
+        "mjpc_robust_last": (None, [vp, c_int_p, c_double_p, c_double_p]), "mjpc_robust_delegate": (vp, [vp]),
         "mjpc_testspeed_run": (d, [C.POINTER(capi.MjpcHipModel), C.POINTER(capi.MjpcHipTask), vp, i, c_double_p, c_double_p, d, i, i, d, i,
                                    c_double_p, c_double_p]),
     }
@@ -358,3 +366,70 @@ def testspeed(planner, state, mocap=None, time0=0.0, horizon=None, steps_per_pla
     _check()
     return dict(total_cost=total, average_cost=out[0], wall_seconds=out[1], realtime_factor=out[2], plan_seconds=out[3],
                 plan_steps=int(out[4]), failure=bool(out[5]), cost_per_step=costs, state=st, mocap=mc)
+
+
+class RobustPlanner:
+    """mjpc_hip::RobustPlanner (C++) driven from Python; mirrors planners/robust/robust_planner.h:31-80 over a SamplingPlanner."""
+
+    def __init__(self):
+        self._L = lib()
+        self._h = None
+
+    def Initialize(self, model: dict, task: dict, numerics: dict | None = None, max_samples=128, max_horizon=512, device=0):
+        numerics = numerics or {}
+        self.cm = capi.CModel(model, task)
+        se = numerics.get("sampling_exploration", 0.1)
+        se = list(se) if isinstance(se, (list, tuple)) else [se]
+        self._expl = np.array([float(se[0]), float(se[1]) if len(se) > 1 else 0.0])
+        self.nu = int(model["nu"]); self.ns = int(model["nq"] + model["nv"] + model["na"])
+        self.close()
+        h = self._L.mjpc_robust_create(C.byref(self.cm.c_model), C.byref(self.cm.c_task), _dp(self._expl),
+                                       int(numerics.get("sampling_trajectories", 10)), int(numerics.get("sampling_representation", 2)),
+                                       int(numerics.get("sampling_spline_points", 512)), int(numerics.get("robust_repetitions", 5)),
+                                       int(numerics.get("robust_candidates", -1)), float(numerics.get("robust_xfrc", 0.1)),
+                                       float(numerics.get("robust_xfrc_rate", 0.1)), int(max_samples), int(max_horizon), int(device))
+        self._h = C.c_void_p(h)
+        _check()
+        # a non-owning view of the delegate for the mjpc_planner_* accessors
+        self.delegate = SamplingPlanner.__new__(SamplingPlanner)
+        self.delegate._L = self._L; self.delegate._h = C.c_void_p(self._L.mjpc_robust_delegate(self._h)); self.delegate._noise = None
+        self.delegate.cm = self.cm; self.delegate.nu = self.nu; self.delegate.ns = self.ns
+        self.delegate.nr = int(task["num_residual"]); self.delegate.ntrace = int(task["num_trace"])
+        self.delegate.max_samples = int(max_samples); self.delegate.max_horizon = int(max_horizon)
+        self.delegate.close = lambda: None
+
+    def close(self):
+        if self._h:
+            self._L.mjpc_robust_destroy(self._h); self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def Reset(self, horizon=0): self._L.mjpc_robust_reset(self._h, int(horizon or 0))
+
+    def SetState(self, state, mocap=None, userdata=None, time=0.0):
+        s = np.ascontiguousarray(state, dtype=np.float64)
+        m = None if mocap is None else np.ascontiguousarray(mocap, dtype=np.float64)
+        u = None if userdata is None else np.ascontiguousarray(userdata, dtype=np.float64)
+        self._L.mjpc_robust_set_state(self._h, _dp(s), _dp(m), _dp(u), float(time))
+
+    def set_seed(self, delegate_seed, robust_seed, plan_iter=0):
+        self._L.mjpc_robust_set_seed(self._h, int(delegate_seed), int(robust_seed), int(plan_iter))
+
+    def OptimizePolicy(self, horizon): self._L.mjpc_robust_optimize_policy(self._h, int(horizon)); _check()
+
+    def ActionFromPolicy(self, time):
+        a = np.zeros(self.nu)
+        self._L.mjpc_robust_action_from_policy(self._h, _dp(a), float(time)); _check()
+        return a
+
+    def last(self):
+        o = np.zeros(3, np.int32)
+        self._L.mjpc_robust_last(self._h, o.ctypes.data_as(c_int_p), None, None)
+        nc, rep = int(o[1]), int(o[2])
+        scores = np.zeros(max(nc, 1)); noisy = np.zeros(max(nc * rep, 1))
+        self._L.mjpc_robust_last(self._h, o.ctypes.data_as(c_int_p), _dp(scores), _dp(noisy))
+        return dict(best_candidate=int(o[0]), scores=scores[:nc], noisy_returns=noisy[:nc * rep].reshape(nc, rep) if nc else noisy[:0])

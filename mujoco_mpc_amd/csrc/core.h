@@ -12,6 +12,7 @@
 #include "dmath.h"
 #include "model.h"
 #include "linalg.h"
+#include "philox.h"
 
 // ---- where the kernel parameters, the LDS block and the candidate index come from ---------------------
 // Phases are __noinline__ (each gets its own register allocation; a fully inlined rollout needs all 512
@@ -67,7 +68,7 @@ struct Ctx {
   double *efc_J, *efc_JA, *efc_D, *efc_R, *efc_aref, *efc_force, *efc_jar, *efc_jv, *efc_floss, *efc_pos, *efc_margin, *efc_diag;
   double *contact;
   double *Ma, *grad, *Mgrad, *search, *Mv, *vtmp, *sgl;
-  double *knot_times, *knot_values, *residual, *terms, *red;
+  double *knot_times, *knot_values, *residual, *terms, *red, *xfrc;
   int *efc_type, *efc_id, *efc_state, *efc_dof, *con_i, *active, *misc, *hpair;
   double time;
   int ncon, nefc, nsingle, warning, solver_iter, cross;
@@ -91,7 +92,7 @@ DEV void ctx_init(Ctx &c, const KParams *K, double *base) {
   P_(efc_J); P_(efc_JA); P_(efc_D); P_(efc_R); P_(efc_aref); P_(efc_force); P_(efc_jar); P_(efc_jv); P_(efc_floss);
   P_(efc_pos); P_(efc_margin); P_(efc_diag); P_(contact);
   P_(Ma); P_(grad); P_(Mgrad); P_(search); P_(Mv); P_(vtmp); P_(sgl);
-  P_(knot_times); P_(knot_values); P_(residual); P_(terms); P_(red);
+  P_(knot_times); P_(knot_values); P_(residual); P_(terms); P_(red); P_(xfrc);
 #undef P_
   int *ib = (int *)(base + L.ints);
   c.efc_type = ib + L.i_efc_type; c.efc_id = ib + L.i_efc_id; c.efc_state = ib + L.i_efc_state; c.efc_dof = ib + L.i_efc_dof;
@@ -986,6 +987,24 @@ DEV void velocity_stage(Ctx &c, int mfact_seq) {
     }
   }
   SYNC();
+  if (c.K->xfrc_std > 0) {
+    // mj_xfrcAccumulate: J^T [force; torque], force applied at the body's inertial frame origin; bodies in ascending order
+    PFOR(d, nv) {
+      const double *cd = c.cdof + 6 * d;
+      int bd = MI(dof_bodyid)[d];
+      double acc = c.qfrc_smooth[d];
+      for (int q = MI(subtree_adr)[bd]; q < MI(subtree_adr)[bd + 1]; q++) {
+        int b = MI(subtree_list)[q];
+        const double *f = c.xfrc + 6 * b;
+        double off[3], tt[3];
+        d_sub3(off, c.xipos + 3 * b, c.subtree_com + 3 * MI(body_rootid)[b]);
+        d_cross(tt, cd, off);
+        acc += (cd[3] + tt[0]) * f[0] + (cd[4] + tt[1]) * f[1] + (cd[5] + tt[2]) * f[2] + cd[0] * f[3] + cd[1] * f[4] + cd[2] * f[5];
+      }
+      c.qfrc_smooth[d] = acc;
+    }
+    SYNC();
+  }
   PFOR(d, nv) c.qacc_smooth[d] = c.qfrc_smooth[d];
   if (mfact_seq && !flag_wait(c.misc + 22, mfact_seq)) c.warning |= WARN_SYNC;
   chol_solve<NVT>(c.qL, c.Linv, c.qacc_smooth, nv, M.nvp);
@@ -1370,7 +1389,8 @@ DEV_NOINLINE void ph_init(KP Kc) {
     int k = e % nu;
     double v = K->knot_values[e];
     double lo = MD(actuator_ctrlrange)[2 * k], hi = MD(actuator_ctrlrange)[2 * k + 1];
-    if (gi != K->nominal_index) {
+    if (K->cand_knots) v = K->cand_knots[(size_t)r * P * nu + e];          // robust planner: explicit candidate policy
+    else if (gi != K->nominal_index) {
       if (K->noise_std) v = add_mul3_rn(v, 1.0, K->noise_std[e], K->noise_eps[(size_t)r * P * nu + e]);   // Cross-Entropy: absolute std
       else { double scale = 0.5 * (hi - lo); v = add_mul3_rn(v, scale, std, K->noise_eps[(size_t)r * P * nu + e]); }   // bit-exact candidate policy
       v = d_clip(v, lo, hi);
@@ -1386,6 +1406,7 @@ DEV_NOINLINE void ph_init(KP Kc) {
   PFOR(i, nv) { c.qvel[i] = K->state[nq + i]; R.states[nq + i] = K->state[nq + i]; c.qacc_ws[i] = 0; }
   PFOR(e, nv * M.nvp) { c.qM[e] = 0; c.qH[e] = 0; }
   PFOR(e, M.nmpair + nv) c.hpair[e] = MI(mpair_i)[e] | (MI(mpair_j)[e] << 8);
+  PFOR(k, 6 * M.nbody) c.xfrc[k] = 0;
   PFOR(k, nu) c.ctrl[k] = 0;      // data->ctrl after Reset (planner.cc:124-130); only visible when H == 1
   if (LANE == 0) {
     R.times[0] = K->time;
@@ -1422,6 +1443,12 @@ DEV_NOINLINE void ph_head(KP Kc, int t, int last) {
     if (bad_values(c.qpos, M.nq)) c.warning |= WARN_BADQPOS;
     if (bad_values(c.qvel, M.nv)) c.warning |= WARN_BADQVEL;
     if (c.warning) { if (LANE == 0) c.misc[10] = 1; ctx_close(c); return; }
+    if (K->xfrc_std > 0) {              // NoisyRollout (trajectory.cc:147-155): Ornstein-Uhlenbeck force/torque noise on every body
+      double rate = exp(-M.timestep / K->xfrc_rate), scale = K->xfrc_std * sqrt(1 - rate * rate);
+      unsigned gi = (unsigned)(K->offset + cand_index());
+      int n6 = 6 * M.nbody;
+      PFOR(i, n6) c.xfrc[i] = rate * c.xfrc[i] + scale * philox_normal(K->seed, K->stream ^ XFRC_STREAM, gi, (unsigned)(t * n6 + i));
+    }
   }
   PROF(c, 0);
   kinematics(c); PROF(c, 1);

@@ -35,19 +35,6 @@ static RolloutFn pick_rollout_kernel(int nv) {
   }
 }
 
-__device__ inline void philox4x32_10(unsigned long long seed, unsigned long long stream, unsigned c0, unsigned c1, unsigned out[4]) {
-  unsigned c[4] = {c0, c1, (unsigned)stream, (unsigned)(stream >> 32)};
-  unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
-  for (int r = 0; r < 10; r++) {
-    unsigned long long p0 = (unsigned long long)0xD2511F53u * c[0], p1 = (unsigned long long)0xCD9E8D57u * c[2];
-    unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k0, n1 = (unsigned)p1;
-    unsigned n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k1, n3 = (unsigned)p0;
-    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
-    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-  }
-  out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
-}
-
 // eps[r, e] for global candidate (offset + r), element e = p*nu + k; sel[r] = second-std choice
 extern "C" __global__ void noise_kernel(double *eps, int *sel, unsigned long long seed, unsigned long long stream,
                                         int offset, int nlocal, int PN, double sigma1) {
@@ -55,12 +42,7 @@ extern "C" __global__ void noise_kernel(double *eps, int *sel, unsigned long lon
   size_t total = (size_t)nlocal * PN;
   if (idx < total) {
     int r = (int)(idx / PN), e = (int)(idx - (size_t)r * PN);
-    unsigned o[4];
-    philox4x32_10(seed, stream, (unsigned)(offset + r), (unsigned)e, o);
-    unsigned long long x1 = ((unsigned long long)o[0] << 32) | o[1], x2 = ((unsigned long long)o[2] << 32) | o[3];
-    double u1 = (double)((x1 >> 11) + 1) * (1.0 / 9007199254740992.0);
-    double u2 = (double)(x2 >> 11) * (1.0 / 9007199254740992.0);
-    eps[idx] = sqrt(-2.0 * log(u1)) * cos(2.0 * 3.14159265358979323846 * u2);
+    eps[idx] = philox_normal(seed, stream, (unsigned)(offset + r), (unsigned)e);
   }
   if (idx < (size_t)nlocal) {
     unsigned o[4];
@@ -127,7 +109,7 @@ struct MjpcHipEngine {
   hipStream_t stream = nullptr;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   // device buffers
-  double *d_state = nullptr, *d_mocap = nullptr, *d_kt = nullptr, *d_kv = nullptr, *d_eps = nullptr, *d_std = nullptr;
+  double *d_state = nullptr, *d_mocap = nullptr, *d_kt = nullptr, *d_kv = nullptr, *d_eps = nullptr, *d_std = nullptr, *d_cand = nullptr; size_t cand_cap = 0;
   int *d_sel = nullptr;
   size_t eps_cap = 0;
   double *d_states = nullptr, *d_actions = nullptr, *d_times = nullptr, *d_residual = nullptr, *d_costs = nullptr,
@@ -211,7 +193,7 @@ void mjpc_hip_destroy(MjpcHipEngine *e) {
   if (!e) return;
   hipSetDevice(e->device);
   if (e->stream) hipStreamSynchronize(e->stream);
-  void *bufs[] = {e->d_std, e->d_ib, e->d_db, e->d_state, e->d_mocap, e->d_kt, e->d_kv, e->d_eps, e->d_sel, e->d_states, e->d_actions,
+  void *bufs[] = {e->d_cand, e->d_std, e->d_ib, e->d_db, e->d_state, e->d_mocap, e->d_kt, e->d_kv, e->d_eps, e->d_sel, e->d_states, e->d_actions,
                   e->d_times, e->d_residual, e->d_costs, e->d_trace, e->d_knots, e->d_returns, e->d_failure, e->d_diag,
                   e->d_winner, e->d_winner_val, e->d_prof};
   for (void *b : bufs) if (b) hipFree(b);
@@ -285,6 +267,17 @@ int mjpc_hip_plan_async(MjpcHipEngine *e, const MjpcHipPlanInput *in) {
   K.P = P; K.interp = in->interpolation; K.H = H; K.N = in->num_trajectory; K.offset = in->candidate_offset; K.nlocal = nl;
   K.use_device_noise = in->noise_eps ? 0 : 1;
   K.noise_std = in->noise_std ? e->d_std : nullptr; K.nominal_index = in->nominal_index;
+  K.cand_knots = nullptr; K.xfrc_std = in->xfrc_std; K.xfrc_rate = in->xfrc_rate;
+  if (in->xfrc_std > 0 && !(in->xfrc_rate > 0)) { set_error("mjpc_hip_plan: xfrc_rate must be positive when xfrc_std > 0"); return -1; }
+  if (in->candidate_knots) {
+    if (need > e->cand_cap) {
+      if (e->d_cand) HIPCHK(hipFree(e->d_cand));
+      HIPCHK(hipMalloc(&e->d_cand, sizeof(double) * (need + 1)));
+      e->cand_cap = need;
+    }
+    HIPCHK(hipMemcpyAsync(e->d_cand, in->candidate_knots + (size_t)in->candidate_offset * P * nu, sizeof(double) * need, hipMemcpyHostToDevice, e->stream));
+    K.cand_knots = e->d_cand;
+  }
   K.states = e->d_states; K.actions = e->d_actions; K.times = e->d_times; K.residual = e->d_residual; K.costs = e->d_costs;
   K.trace = e->d_trace; K.knots = e->d_knots; K.returns = e->d_returns; K.failure = e->d_failure; K.diag = e->d_diag; K.prof = e->d_prof;
   HIPCHK(hipEventRecord(e->ev[1], e->stream));

@@ -201,7 +201,7 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
   A_(contact, nc * M.con_stride + 1);
   A_(Ma, nv + 1); A_(grad, nv + 1); A_(Mgrad, nv + 1); A_(search, nv + 1); A_(Mv, nv + 1); A_(vtmp, nv + 1); A_(sgl, 4 * nv + 1);
   A_(knot_times, P_max); A_(knot_values, P_max * nu + 1); A_(residual, nr + 1); A_(terms, t->num_term + 1); A_(red, 8); A_(prof, 26);
-  A_(mc_d, p.cache_d + 1); A_(mc_i, (p.cache_i + 2) / 2);
+  A_(xfrc, 6 * nb); A_(mc_d, p.cache_d + 1); A_(mc_i, (p.cache_i + 2) / 2);
   L.ints = o;
 #undef A_
   int io = 0;

@@ -77,6 +77,7 @@ struct Lay {
   int contact;
   int Ma, grad, Mgrad, search, Mv, vtmp, sgl;
   int knot_times, knot_values, residual, terms, red, prof;
+  int xfrc;            // external body forces (NoisyRollout of the robust planner), 6 per body
   int mc_d, mc_i;      // LDS copy of the model tables: fp64 part, int part (both offsets in doubles)
   int ints;            // start of the int region (in doubles)
   int i_efc_type, i_efc_id, i_efc_state, i_efc_dof, i_con, i_active, i_misc, i_hpair;
@@ -89,7 +90,8 @@ struct KParams {
   const int *ibase; const double *dbase;   // the two model buffers in HBM; [0, cache_i) / [0, cache_d) are LDS-cached
   int cache_i, cache_d;
   // plan inputs (device pointers)
-  const double *state, *mocap, *knot_times, *knot_values, *noise_eps, *noise_std;
+  const double *state, *mocap, *knot_times, *knot_values, *noise_eps, *noise_std, *cand_knots;
+  double xfrc_std, xfrc_rate;
   const int *noise_sel;
   double time, sigma0, sigma1;
   unsigned long long seed, stream;

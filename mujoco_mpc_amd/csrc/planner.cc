@@ -526,6 +526,101 @@ void CrossEntropyPlanner::ActionFromPolicy(double* action, const double* s, doub
 
 const Trajectory* CrossEntropyPlanner::BestTrajectory() { return &nominal_trajectory; }
 
+void SamplingPlanner::CandidateKnots(int candidate, double* out) {
+  FetchCandidate(trajectory_order[candidate]);
+  std::copy(winner_knots_.begin(), winner_knots_.end(), out);
+}
+
+// ------------------------------------------------------------------ RobustPlanner
+RobustPlanner::~RobustPlanner() { if (engine_) mjpc_hip_destroy(engine_); }
+
+void RobustPlanner::Initialize(const MjpcHipModel* model, const MjpcHipTask* task, const Numerics& numerics) {   // robust_planner.cc:30-58
+  numerics_ = numerics;
+  delegate.Initialize(model, task, numerics);
+  nu_ = model->nu; ns_ = model->nq + model->nv + model->na; nmocap_ = model->nmocap; nuserdata_ = model->nuserdata;
+  nrepetitions_ = numerics.robust_repetitions;
+  ncandidates_ = numerics.robust_candidates;
+  if (ncandidates_ == -1) ncandidates_ = numerics.sampling_trajectories / nrepetitions_;
+  xfrc_std_ = numerics.robust_xfrc; xfrc_rate_ = numerics.robust_xfrc_rate;
+  if (engine_) { mjpc_hip_destroy(engine_); engine_ = nullptr; }
+  int cap = std::max(1, std::max(ncandidates_, 1) * std::max(nrepetitions_, 1));
+  engine_ = mjpc_hip_create(model, task, cap, numerics.max_horizon, numerics.device);
+  if (!engine_) Fatal(mjpc_hip_last_error());
+}
+void RobustPlanner::Allocate() {
+  delegate.Allocate();
+  state_.assign(ns_, 0.0); mocap_.assign(7 * nmocap_, 0.0); userdata_.assign(std::max(nuserdata_, 1), 0.0);
+}
+void RobustPlanner::Reset(int horizon, const double* initial_repeated_action) {
+  delegate.Reset(horizon, initial_repeated_action);
+  std::fill(state_.begin(), state_.end(), 0.0); std::fill(mocap_.begin(), mocap_.end(), 0.0);
+  std::fill(userdata_.begin(), userdata_.end(), 0.0);
+  time_ = 0.0;
+}
+void RobustPlanner::SetState(const double* s, const double* m, const double* u, double t) {
+  delegate.SetState(s, m, u, t);
+  std::copy(s, s + ns_, state_.begin());
+  if (m) std::copy(m, m + 7 * nmocap_, mocap_.begin());
+  if (u) std::copy(u, u + nuserdata_, userdata_.begin());
+  time_ = t;
+}
+void RobustPlanner::SetTask(const MjpcHipTask* task) {
+  delegate.SetTask(task);
+  if (mjpc_hip_set_task(engine_, task) != 0) Fatal(mjpc_hip_last_error());
+}
+
+void RobustPlanner::OptimizePolicy(int horizon) {   // robust_planner.cc:91-157
+  // Conscious fix of a reference quirk: at this snapshot RobustPlanner calls the delegate's OptimizePolicyCandidates directly
+  // (robust_planner.cc:93) and UpdateNominalPolicy only runs inside SamplingPlanner::OptimizePolicy (planner.cc:192), so the
+  // wrapped planner never re-times its knots to the current time.  Resample first, as OptimizePolicy does.
+  delegate.UpdateNominalPolicy(horizon);
+  int ncandidates = delegate.OptimizePolicyCandidates(ncandidates_, horizon);
+  best_candidate = -1;
+  if (!ncandidates) return;
+  if (ncandidates == 1) { delegate.CopyCandidateToPolicy(0); best_candidate = 0; return; }
+  int repetitions = nrepetitions_;
+  const std::vector<double>& kt = delegate.KnotTimes();
+  int P = (int)kt.size();
+  size_t row = (size_t)P * nu_;
+  cand_knots_.resize((size_t)ncandidates * repetitions * row);
+  for (int i = 0; i < ncandidates; i++) {
+    delegate.CandidateKnots(i, cand_knots_.data() + (size_t)i * repetitions * row);
+    for (int j = 1; j < repetitions; j++)
+      std::copy(cand_knots_.begin() + (size_t)i * repetitions * row, cand_knots_.begin() + ((size_t)i * repetitions + 1) * row,
+                cand_knots_.begin() + ((size_t)i * repetitions + j) * row);
+  }
+  int total = ncandidates * repetitions;
+  noisy_returns.assign(total, 0.0); noisy_failures.assign(total, 0);
+  std::vector<double> zeros(row, 0.0);
+  MjpcHipPlanInput in;
+  std::memset(&in, 0, sizeof(in));
+  in.state = state_.data(); in.mocap = mocap_.data(); in.userdata = userdata_.data(); in.time = time_;
+  in.knot_times = kt.data(); in.knot_values = zeros.data(); in.num_spline_points = P;
+  in.interpolation = delegate.interpolation_; in.num_trajectory = total; in.horizon = horizon; in.num_local = total;
+  in.candidate_knots = cand_knots_.data(); in.xfrc_std = xfrc_std_; in.xfrc_rate = xfrc_rate_;
+  in.seed = seed; in.stream = plan_iter++;
+  MjpcHipPlanOutput out;
+  std::memset(&out, 0, sizeof(out));
+  out.returns = noisy_returns.data(); out.failure = noisy_failures.data();
+  if (mjpc_hip_plan(engine_, &in, &out) != 0) { Fatal(mjpc_hip_last_error()); return; }
+  // mean over the delegate's score and the valid noisy rollouts; the best mean wins (robust_planner.cc:128-151)
+  candidate_scores.assign(ncandidates, 0.0);
+  double best_score = 0;
+  for (int candidate = 0; candidate < ncandidates; candidate++) {
+    double mean_return = delegate.CandidateScore(candidate);
+    int valid_rollouts = 0;
+    for (int j = 0; j < repetitions; j++) {
+      if (noisy_failures[repetitions * candidate + j]) continue;
+      double total_return = noisy_returns[repetitions * candidate + j];
+      mean_return = (valid_rollouts * mean_return + total_return) / (valid_rollouts + 1);
+      valid_rollouts++;
+    }
+    candidate_scores[candidate] = mean_return;
+    if (best_candidate == -1 || mean_return < best_score) { best_candidate = candidate; best_score = mean_return; }
+  }
+  delegate.CopyCandidateToPolicy(best_candidate);
+}
+
 }  // namespace mjpc_hip
 
 // ====================================================================== flat C wrapper (tests / ctypes)
@@ -645,5 +740,36 @@ int mjpc_cem_best_trajectory(void* p, double* states, double* actions, double* c
   if (total_return) *total_return = t->total_return;
   return t->horizon;
 }
+
+// ---- RobustPlanner
+void* mjpc_robust_create(const MjpcHipModel* model, const MjpcHipTask* task, const double* exploration, int trajectories, int representation,
+                         int spline_points, int repetitions, int candidates, double xfrc_std, double xfrc_rate, int max_samples, int max_horizon,
+                         int device) {
+  auto* p = new mjpc_hip::RobustPlanner();
+  mjpc_hip::Numerics n;
+  n.sampling_exploration[0] = exploration[0]; n.sampling_exploration[1] = exploration[1];
+  n.sampling_trajectories = trajectories; n.sampling_representation = representation; n.sampling_spline_points = spline_points;
+  n.robust_repetitions = repetitions; n.robust_candidates = candidates; n.robust_xfrc = xfrc_std; n.robust_xfrc_rate = xfrc_rate;
+  n.max_samples = max_samples; n.max_horizon = max_horizon; n.device = device;
+  p->Initialize(model, task, n);
+  p->Allocate();
+  return p;
+}
+void mjpc_robust_destroy(void* p) { delete (mjpc_hip::RobustPlanner*)p; }
+void mjpc_robust_reset(void* p, int horizon) { ((mjpc_hip::RobustPlanner*)p)->Reset(horizon, nullptr); }
+void mjpc_robust_set_state(void* p, const double* s, const double* m, const double* u, double t) { ((mjpc_hip::RobustPlanner*)p)->SetState(s, m, u, t); }
+void mjpc_robust_set_seed(void* p, unsigned long long delegate_seed, unsigned long long robust_seed, unsigned long long plan_iter) {
+  auto* q = (mjpc_hip::RobustPlanner*)p; q->delegate.seed = delegate_seed; q->delegate.plan_iter = plan_iter; q->seed = robust_seed; q->plan_iter = plan_iter;
+}
+void mjpc_robust_optimize_policy(void* p, int horizon) { ((mjpc_hip::RobustPlanner*)p)->OptimizePolicy(horizon); }
+void mjpc_robust_action_from_policy(void* p, double* a, double t) { ((mjpc_hip::RobustPlanner*)p)->ActionFromPolicy(a, nullptr, t, false); }
+// out[0] = best candidate, out[1] = candidates scored, out[2] = repetitions; scores[ncand], noisy_returns[ncand*rep] optional
+void mjpc_robust_last(void* p, int* out, double* scores, double* noisy_returns) {
+  auto* q = (mjpc_hip::RobustPlanner*)p;
+  out[0] = q->best_candidate; out[1] = (int)q->candidate_scores.size(); out[2] = q->nrepetitions_;
+  if (scores) std::copy(q->candidate_scores.begin(), q->candidate_scores.end(), scores);
+  if (noisy_returns) std::copy(q->noisy_returns.begin(), q->noisy_returns.end(), noisy_returns);
+}
+void* mjpc_robust_delegate(void* p) { return &((mjpc_hip::RobustPlanner*)p)->delegate; }
 
 }  // extern "C"

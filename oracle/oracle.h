@@ -51,6 +51,7 @@ typedef struct OData {
   double *xpos, *xquat, *xmat, *xipos, *ximat, *xanchor, *xaxis, *geom_xpos, *geom_xmat,
          *site_xpos, *site_xmat, *subtree_com, *cinert, *cdof, *cvel, *cdof_dot, *crb,
          *subtree_linvel, *cacc, *cfrc;
+  double *xfrc_applied; int xfrc_on;   /* [6*nbody] force(3)+torque(3) per body (mjData.xfrc_applied); used when xfrc_on */
   double *qM, *qL, *qH, *qLD2;   /* dense nv*nv */
   /* contacts + constraints */
   int ncon, nefc, nf, nl, unsupported;

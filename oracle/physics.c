@@ -42,7 +42,7 @@ OData *oracle_make_data(const OModel *om) {
   DD(geom_xpos, 3 * m->ngeom + 3); DD(geom_xmat, 9 * m->ngeom + 9);
   DD(site_xpos, 3 * m->nsite + 3); DD(site_xmat, 9 * m->nsite + 9);
   DD(subtree_com, 3 * nb); DD(cinert, 10 * nb); DD(cdof, 6 * nv + 6); DD(cvel, 6 * nb);
-  DD(cdof_dot, 6 * nv + 6); DD(crb, 10 * nb); DD(subtree_linvel, 3 * nb); DD(cacc, 6 * nb); DD(cfrc, 6 * nb);
+  DD(cdof_dot, 6 * nv + 6); DD(crb, 10 * nb); DD(subtree_linvel, 3 * nb); DD(cacc, 6 * nb); DD(cfrc, 6 * nb); DD(xfrc_applied, 6 * nb);
   DD(qM, nv * nv + 1); DD(qL, nv * nv + 1); DD(qH, nv * nv + 1); DD(qLD2, nv * nv + 1);
   d->contact = (OContact *)dalloc(d, sizeof(OContact) * (size_t)(om->nconmax + 8));
   DI(efc_type, ne); DI(efc_id, ne); DI(efc_state, ne);
@@ -869,6 +869,24 @@ void oracle_forward(const OModel *om, OData *d) {
   rne_bias(om, d);
   actuation(om, d);
   for (int i = 0; i < nv; i++) d->qfrc_smooth[i] = d->qfrc_passive[i] - d->qfrc_bias[i] + d->qfrc_actuator[i];
+  if (d->xfrc_on) {
+    /* mj_xfrcAccumulate: J^T [force; torque] with the force applied at the body's inertial frame origin (xipos) */
+    for (int b = 1; b < m->nbody; b++) {
+      const double *f = d->xfrc_applied + 6 * b, *tq = f + 3;
+      double off[3];
+      o_sub3(off, d->xipos + 3 * b, d->subtree_com + 3 * m->body_rootid[b]);
+      for (int a = b; a > 0; a = m->body_parentid[a]) {
+        for (int k = 0; k < m->body_dofnum[a]; k++) {
+          int dof = m->body_dofadr[a] + k;
+          const double *cd = d->cdof + 6 * dof;
+          double t[3], jp[3];
+          o_cross(t, cd, off);
+          jp[0] = cd[3] + t[0]; jp[1] = cd[4] + t[1]; jp[2] = cd[5] + t[2];
+          d->qfrc_smooth[dof] += jp[0] * f[0] + jp[1] * f[1] + jp[2] * f[2] + cd[0] * tq[0] + cd[1] * tq[1] + cd[2] * tq[2];
+        }
+      }
+    }
+  }
   chol_solve(d->qacc_smooth, d->qL, d->qfrc_smooth, nv);
   solve_constraints(om, d);
   oracle_residual(om, d, d->sensordata);

@@ -112,6 +112,7 @@ static void get_trace(const OModel *om, const OData *d, double *trace) {   /* ut
   }
 }
 
+#define XFRC_STREAM 0x5846524300000000ull    /* "XFRC": separates the force noise from the knot noise of the same plan */
 void oracle_rollout(const OModel *om, OData *d, const MjpcHipPlanInput *in, const double *knots, int row, OPlanOutput *out) {
   const MjpcHipModel *m = &om->m;
   const MjpcHipTask *t = &om->t;
@@ -133,11 +134,20 @@ void oracle_rollout(const OModel *om, OData *d, const MjpcHipPlanInput *in, cons
   d->time = in->time;
   d->warning = 0;
   o_zero(d->qacc_warmstart, nv);     /* deterministic warm start */
+  d->xfrc_on = in->xfrc_std > 0;
+  o_zero(d->xfrc_applied, 6 * m->nbody);
   for (int s = 0; s < H - 1; s++) {
     oracle_spline_sample(in->knot_times, knots, P, nu, in->interpolation, d->time, actions + s * nu);
     for (int k = 0; k < nu; k++)
       actions[s * nu + k] = o_clip(actions[s * nu + k], m->actuator_ctrlrange[2 * k], m->actuator_ctrlrange[2 * k + 1]);
     o_copy(d->ctrl, actions + s * nu, nu);
+    if (in->xfrc_std > 0) {            /* trajectory.cc:147-155: Ornstein-Uhlenbeck in discrete time */
+      double rate = exp(-m->timestep / in->xfrc_rate), scale = in->xfrc_std * sqrt(1 - rate * rate);
+      uint32_t gi = (uint32_t)(in->candidate_offset + row);
+      for (int i = 0; i < 6 * m->nbody; i++)
+        d->xfrc_applied[i] = rate * d->xfrc_applied[i] +
+                             scale * philox_normal(in->seed, in->stream ^ XFRC_STREAM, gi, (uint32_t)(s * 6 * m->nbody + i));
+    }
     oracle_step(om, d);
     o_copy(residual + s * nr, d->sensordata, nr);
     get_trace(om, d, trace + s * ntr);
@@ -176,6 +186,7 @@ static void make_candidate_knots(const OModel *om, const MjpcHipPlanInput *in, i
   const MjpcHipModel *m = &om->m;
   int P = in->num_spline_points, nu = m->nu;
   o_copy(knots, in->knot_values, P * nu);
+  if (in->candidate_knots) { o_copy(knots, in->candidate_knots + (size_t)i * P * nu, P * nu); return; }   /* robust planner: explicit policies */
   if (i == in->nominal_index) return;              /* planner.cc:361 (index 0); cross_entropy/planner.cc:412 (extra rollout) */
   if (in->noise_std) {                             /* cross_entropy/planner.cc:340-375: absolute per-parameter std */
     for (int p = 0; p < P; p++) {

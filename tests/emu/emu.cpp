@@ -27,6 +27,8 @@ extern "C" int emu_plan(const MjpcHipModel *m, const MjpcHipTask *t, const MjpcH
   if (in->noise_sel) for (int i = 0; i < nl; i++) sel[i] = in->noise_sel[in->candidate_offset + i];
   K.state = in->state; K.mocap = in->mocap; K.knot_times = in->knot_times; K.knot_values = in->knot_values;
   K.noise_eps = eps.data(); K.noise_sel = sel.data(); K.noise_std = in->noise_std; K.nominal_index = in->nominal_index;
+  K.cand_knots = in->candidate_knots ? in->candidate_knots + (size_t)in->candidate_offset * in->num_spline_points * m->nu : nullptr;
+  K.xfrc_std = in->xfrc_std; K.xfrc_rate = in->xfrc_rate;
   K.time = in->time; K.sigma0 = in->noise_exploration[0]; K.sigma1 = in->noise_exploration[1];
   K.seed = in->seed; K.stream = in->stream;
   K.P = P; K.interp = in->interpolation; K.H = in->horizon; K.N = in->num_trajectory; K.offset = in->candidate_offset; K.nlocal = nl;

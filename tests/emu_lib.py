@@ -38,10 +38,12 @@ def lib():
 
 
 def plan(model, task, state, mocap, time, knot_times, knot_values, interp, N, H, sigma=(0.1, 0.0), noise_eps=None,
-         noise_sel=None, candidate_offset=0, num_local=None, noise_std=None, nominal_index=0):
+         noise_sel=None, candidate_offset=0, num_local=None, noise_std=None, nominal_index=0, candidate_knots=None, xfrc_std=0.0,
+         xfrc_rate=0.0, seed=0, stream=0):
     cm = capi.CModel(model, task)
     inp = capi.make_plan_input(cm, state, mocap, time, knot_times, knot_values, interp, N, H, sigma, noise_eps, noise_sel,
-                               0, 0, candidate_offset, num_local, noise_std=noise_std, nominal_index=nominal_index)
+                               seed, stream, candidate_offset, num_local, noise_std=noise_std, nominal_index=nominal_index,
+                               candidate_knots=candidate_knots, xfrc_std=xfrc_std, xfrc_rate=xfrc_rate)
     nl = inp.num_local
     ds = model["nq"] + model["nv"]; nu = model["nu"]; nr = task["num_residual"]; ntr = 3 * task["num_trace"]
     P = inp.num_spline_points

@@ -16,10 +16,11 @@ class OracleBackend:
 
     def plan(self, state, mocap, time, knot_times, knot_values, interpolation, num_trajectory, horizon, sigma,
              noise_eps=None, noise_sel=None, seed=0, stream=0, userdata=None, candidate_offset=0, num_local=None,
-             noise_std=None, nominal_index=0):
+             noise_std=None, nominal_index=0, candidate_knots=None, xfrc_std=0.0, xfrc_rate=0.0):
         r = self.o.plan(state, mocap, time, knot_times, knot_values, interpolation, num_trajectory, horizon, sigma,
                         noise_eps, noise_sel, seed, stream, self.nthreads, candidate_offset, num_local,
-                        noise_std=noise_std, nominal_index=nominal_index)
+                        noise_std=noise_std, nominal_index=nominal_index, candidate_knots=candidate_knots,
+                        xfrc_std=xfrc_std, xfrc_rate=xfrc_rate)
         self._all = r
         w = r["winner"] - candidate_offset
         out = dict(returns=r["returns"], failure=r["failure"], winner=r["winner"], winner_return=r["returns"][w])

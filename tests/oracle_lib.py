@@ -105,11 +105,12 @@ class Oracle:
         return v, terms
 
     def plan(self, state, mocap, time, knot_times, knot_values, interp, N, H, sigma=(0.1, 0.0), noise_eps=None,
-             noise_sel=None, seed=0, stream=0, nthreads=1, candidate_offset=0, num_local=None, noise_std=None, nominal_index=0):
+             noise_sel=None, seed=0, stream=0, nthreads=1, candidate_offset=0, num_local=None, noise_std=None, nominal_index=0, candidate_knots=None, xfrc_std=0.0, xfrc_rate=0.0):
         m = self.model; t = self.task
         inp = capi.make_plan_input(self.cm, state, mocap, time, knot_times, knot_values, interp, N, H, sigma,
                                    noise_eps, noise_sel, seed, stream, candidate_offset, num_local,
-                                   noise_std=noise_std, nominal_index=nominal_index)
+                                   noise_std=noise_std, nominal_index=nominal_index, candidate_knots=candidate_knots,
+                                   xfrc_std=xfrc_std, xfrc_rate=xfrc_rate)
         nl = inp.num_local
         ds = m["nq"] + m["nv"] + m["na"]; nu = m["nu"]; nr = t["num_residual"]; ntr = 3 * t["num_trace"]
         P = inp.num_spline_points

@@ -397,3 +397,81 @@ def test_closed_loop_harness_humanoid_tracking_transition_and_quadruped():
     assert res["state"][2] > 0.12                                  # the A1 has not collapsed onto its trunk after 0.6 s of closed-loop control
     assert res["cost_per_step"][-10:].mean() < res["cost_per_step"][:10].mean()
     p.close()
+
+
+def test_noisy_rollouts_match_oracle():
+    """Trajectory::NoisyRollout on the engine (explicit candidate policies + OU xfrc_applied noise, trajectory.cc:100-210) vs the
+    oracle: quadruped with forces and torques on all 16 bodies, and a sharded call reproducing its slice."""
+    m, task, d = quadruped()
+    P, H, N = 3, 30, 8
+    kt = np.linspace(0, 0.29, P); cand = np.random.default_rng(4).uniform(-0.2, 0.2, (N, P, m["nu"]))
+    kw = dict(candidate_knots=cand, xfrc_std=3.0, xfrc_rate=0.1, seed=77, stream=4)
+    o = ol.Oracle(m, task)
+    ref = o.plan(d["state"], d["mocap"], 0.0, kt, np.zeros((P, m["nu"])), 2, N, H, nthreads=8, **kw)
+    be = HipBackend(m, task, max_samples=N, max_horizon=H)
+    out = be.plan(state=d["state"], mocap=d["mocap"], time=0.0, knot_times=kt, knot_values=np.zeros((P, m["nu"])), interpolation=2,
+                  num_trajectory=N, horizon=H, sigma=(0.0, 0.0), **kw)
+    allc = be.fetch_all(N, H, P)
+    assert np.array_equal(allc["knots"], cand) and not out["failure"].any()
+    for k in ("states", "residual", "costs"):
+        assert _rel(allc[k], ref[k]) < 1e-5, k
+    assert _rel(out["returns"], ref["returns"]) < 1e-5 and out["winner"] == ref["winner"]
+    quiet = be.plan(state=d["state"], mocap=d["mocap"], time=0.0, knot_times=kt, knot_values=np.zeros((P, m["nu"])), interpolation=2,
+                    num_trajectory=N, horizon=H, sigma=(0.0, 0.0), candidate_knots=cand)
+    assert np.abs(quiet["returns"] - out["returns"]).max() > 1e-6               # the force noise changes the rollouts
+    part = be.plan(state=d["state"], mocap=d["mocap"], time=0.0, knot_times=kt, knot_values=np.zeros((P, m["nu"])), interpolation=2,
+                   num_trajectory=N, horizon=H, sigma=(0.0, 0.0), candidate_offset=4, num_local=4, **kw)
+    assert np.array_equal(part["returns"], out["returns"][4:])
+    be.close()
+
+
+def test_cpp_robust_planner_matches_oracle_restatement():
+    """mjpc_hip::RobustPlanner (robust_planner.cc:91-157) over the C++ SamplingPlanner, both on HIP engines, against the same
+    procedure spelled out with the oracle: rank the delegate's candidates, R noisy rollouts of the top k, mean of the valid
+    returns incl. the delegate's own score, adopt the best."""
+    from oracle_backend import OracleBackend
+    from mujoco_mpc_amd import cplanner
+    from mujoco_mpc_amd.planner import SamplingPlanner
+    m, task, d = particle(timestep=0.1)
+    H, N, K, R = 15, 20, 4, 3
+    num = dict(sampling_spline_points=5, sampling_exploration=0.2, sampling_trajectories=N, sampling_representation=2,
+               robust_repetitions=R, robust_candidates=K, robust_xfrc=0.05, robust_xfrc_rate=0.2)
+    rp = cplanner.RobustPlanner()
+    rp.Initialize(m, task, num, max_samples=N, max_horizon=H)
+    rp.Reset(H); rp.set_seed(5, 9, 0)
+    ob = OracleBackend(m, task)
+    ref = SamplingPlanner(ob)
+    ref.Initialize(m, task, num); ref.Allocate(); ref.Reset(H); ref.seed = 5; ref.plan_iter = 0
+    o = ol.Oracle(m, task)
+    state = np.array([0.3, -0.2, 0.0, 0.0]); t = 0.0
+    for it in range(12):
+        rp.SetState(state, d["mocap"], None, t)
+        rp.OptimizePolicy(H)
+        last = rp.last()
+        # the same on the oracle
+        ref.SetState(state, d["mocap"], None, t)
+        ref.UpdateNominalPolicy(H)
+        ref.OptimizePolicyCandidates(K, H)
+        order = ref.trajectory_order[:K]
+        kt = np.array(ref._last_kt); allk = ob._all["knots"]
+        cand = np.repeat(allk[order], R, axis=0)
+        noisy = o.plan(state, d["mocap"], t, kt, np.zeros_like(allk[0]), 2, K * R, H, candidate_knots=cand, xfrc_std=0.05, xfrc_rate=0.2,
+                       seed=9, stream=it)
+        scores = []
+        for c_ in range(K):
+            mean = float(ref.returns[order[c_]]); valid = 0
+            for j in range(R):
+                if noisy["failure"][R * c_ + j]:
+                    continue
+                mean = (valid * mean + noisy["returns"][R * c_ + j]) / (valid + 1); valid += 1
+            scores.append(mean)
+        best = int(np.argmin(scores))
+        assert last["best_candidate"] == best
+        assert _rel(last["scores"], np.array(scores)) < 1e-9 and _rel(last["noisy_returns"].ravel(), noisy["returns"]) < 1e-9
+        ref.CopyCandidateToPolicy(best)
+        kt_c, kv_c = rp.delegate.policy_knots()
+        assert np.array_equal(kt_c, np.array(ref.policy.plan.times_)) and np.abs(kv_c - np.array(ref.policy.plan.values_)).max() < 1e-12
+        tr = rp.delegate.BestTrajectory()
+        state = tr.states[1].copy(); t += m["timestep"]
+    assert np.abs(state[:2] - d["mocap"][:2]).sum() < 0.2
+    rp.close()

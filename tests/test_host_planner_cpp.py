@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_planner_c_header_symbols_are_exported():
     text = open(os.path.join(ROOT, "include", "mjpc_hip_planner_c.h")).read()
-    declared = sorted(set(re.findall(r"\b(mjpc_(?:planner|spline|cem|testspeed)_[a-z_]+)\(", text)))
+    declared = sorted(set(re.findall(r"\b(mjpc_(?:planner|spline|cem|testspeed|robust)_[a-z_]+)\(", text)))
     assert declared == sorted(cplanner.PLANNER_C_SYMBOLS)
     L = cplanner.lib()
     for s in declared:

@@ -56,6 +56,49 @@ def test_cross_entropy_noise_mode_in_oracle_and_kernel_source():
     assert _rel(b["returns"], a["returns"]) < 1e-12
 
 
+def test_noisy_rollout_force_noise_obeys_newtons_law_and_matches_kernel_source():
+    """ABI extension for the robust planner (Trajectory::NoisyRollout, trajectory.cc:100-210): explicit candidate policies and
+    Ornstein-Uhlenbeck xfrc_applied noise.  On the particle (mass 0.3 on two damped slide joints, motors of gear 1) every step
+    must satisfy the implicit-damping Euler update with the force  ctrl + xfrc  where xfrc follows the OU recursion on the
+    Philox normals of stream ^ "XFRC"."""
+    m, task, d = particle(timestep=0.01)
+    P, H, N = 3, 12, 3
+    kt = np.array([0.0, 0.05, 0.2]); rng = np.random.default_rng(11)
+    cand = rng.uniform(-0.5, 0.5, (N, P, 2))
+    std, rate_t, seed, stream = 0.7, 0.05, 21, 5
+    o = ol.Oracle(m, task)
+    a = o.plan(d["state"], d["mocap"], 0.0, kt, np.zeros((P, 2)), 1, N, H, candidate_knots=cand, xfrc_std=std, xfrc_rate=rate_t,
+               seed=seed, stream=stream)
+    assert np.array_equal(a["knots"], cand)                               # explicit policies: used verbatim
+    nb = m["nbody"]; pm = nb - 1                                          # the point mass is the last body
+    eps, _ = ol.noise(seed, stream ^ 0x5846524300000000, 0, N, H, 6 * nb)
+    rate = np.exp(-m["timestep"] / rate_t); scale = std * np.sqrt(1 - rate * rate)
+    h, mass, damp = m["timestep"], 0.3, 1.0
+    for i in range(N):
+        x = np.zeros(6 * nb)
+        for t in range(H - 1):
+            x = rate * x + scale * eps[i, t]
+            f = x[6 * pm:6 * pm + 2]                                      # force on the point mass, x / y components
+            v0, v1 = a["states"][i, t, 2:4], a["states"][i, t + 1, 2:4]
+            u = a["actions"][i, t]
+            expect = v0 + h * (u + f - damp * v0) / (mass + h * damp)     # Euler, implicit in the joint damping
+            assert np.abs(v1 - expect).max() < 1e-12
+    b0 = o.plan(d["state"], d["mocap"], 0.0, kt, np.zeros((P, 2)), 1, N, H, candidate_knots=cand)
+    assert np.abs(b0["states"] - a["states"]).max() > 1e-4               # the noise matters
+    e = emu_lib.plan(m, task, d["state"], d["mocap"], 0.0, kt, np.zeros((P, 2)), 1, N, H, candidate_knots=cand, xfrc_std=std,
+                     xfrc_rate=rate_t, seed=seed, stream=stream)
+    assert np.array_equal(e["knots"], cand) and _rel(e["states"], a["states"]) < 1e-12 and _rel(e["returns"], a["returns"]) < 1e-12
+    # a contact-rich model with forces and torques on every body
+    m, task, d = quadruped()
+    kt = np.linspace(0, 0.19, 3); cand = np.random.default_rng(2).uniform(-0.2, 0.2, (2, 3, 12))
+    a = o = None
+    o = ol.Oracle(m, task)
+    a = o.plan(d["state"], d["mocap"], 0.0, kt, np.zeros((3, 12)), 2, 2, 20, candidate_knots=cand, xfrc_std=2.0, xfrc_rate=0.1, seed=3, stream=1)
+    e = emu_lib.plan(m, task, d["state"], d["mocap"], 0.0, kt, np.zeros((3, 12)), 2, 2, 20, candidate_knots=cand, xfrc_std=2.0, xfrc_rate=0.1,
+                     seed=3, stream=1)
+    assert _rel(e["states"], a["states"]) < 1e-5 and _rel(e["returns"], a["returns"]) < 1e-5
+
+
 def test_engine_library_exports_every_declared_symbol():
     """libmjpc_hip.so loads without a GPU and exports exactly what include/mjpc_hip.h declares."""
     import __graft_entry__ as g

@@ -49,7 +49,9 @@ enum {
   MJPC_TASK_CARTPOLE = 1,   /* mjpc/tasks/cartpole/cartpole.cc:36-49 */
   MJPC_TASK_QUADRUPED = 2,  /* mjpc/tasks/quadruped/quadruped.cc:33-221 */
   MJPC_TASK_COPYSTATE = 3,  /* residual = [qpos,qvel] (mjpc/test/agent/rollout_test.cc:40-60) */
-  MJPC_TASK_HUMANOID_TRACK = 4  /* mjpc/tasks/humanoid/tracking/tracking.cc:94-216 */
+  MJPC_TASK_HUMANOID_TRACK = 4, /* mjpc/tasks/humanoid/tracking/tracking.cc:94-216 */
+  MJPC_TASK_HUMANOID_STAND = 5, /* mjpc/tasks/humanoid/stand/stand.cc:41-94 */
+  MJPC_TASK_HUMANOID_WALK = 6   /* mjpc/tasks/humanoid/walk/walk.cc:44-166 */
 };
 enum { MJPC_OBJ_BODY = 1, MJPC_OBJ_XBODY = 2, MJPC_OBJ_GEOM = 5, MJPC_OBJ_SITE = 6 };
 

@@ -1285,6 +1285,84 @@ DEV void residual_humanoid_track(Ctx &c, double *residual) {
   }
 }
 
+// velocity of a body's inertial-frame origin in the world frame (framelinvel objtype="body")
+DEV void body_linvel(Ctx &c, int body, double *lin) {
+  const DevModel &M = *c.M;
+  double off[3];
+  d_sub3(off, c.xipos + 3 * body, c.subtree_com + 3 * MI(body_rootid)[body]);
+  d_cross(lin, c.cvel + 6 * body, off);
+  d_add3(lin, lin, c.cvel + 6 * body + 3);
+}
+// mjpc/tasks/humanoid/stand/stand.cc:41-94.  int_data = [site sp0, sp1, sp2, sp3, body head, body torso]
+DEV void residual_humanoid_stand(Ctx &c, double *residual) {
+  const DevModel &M = *c.M;
+  const int *I = MI(task.int_data);
+  int nv = M.nv, nu = M.nu;
+  if (LANE == 0) {
+    const double *f1 = c.site_xpos + 3 * I[0], *f2 = c.site_xpos + 3 * I[1], *f3 = c.site_xpos + 3 * I[2], *f4 = c.site_xpos + 3 * I[3];
+    const double *head = c.xipos + 3 * I[4];
+    residual[0] = (head[2] - 0.25 * (f1[2] + f2[2] + f3[2] + f4[2])) - MD(task.parameters)[0];
+    const double *com = c.subtree_com + 3 * I[5], *comvel = c.subtree_linvel + 3 * I[5];
+    double cpx = com[0] + comvel[0] * 0.2, cpy = com[1] + comvel[1] * 0.2;
+    double fx = (((f1[0] + f2[0]) + f3[0]) + f4[0]) * 0.25 - cpx, fy = (((f1[1] + f2[1]) + f3[1]) + f4[1]) * 0.25 - cpy;
+    residual[1] = sqrt(fx * fx + fy * fy);
+    residual[2] = comvel[0]; residual[3] = comvel[1];
+  }
+  PFOR(i, nv - 6) residual[4 + i] = c.qvel[6 + i];
+  PFOR(i, nu) residual[4 + nv - 6 + i] = c.ctrl[i];
+}
+// mjpc/tasks/humanoid/walk/walk.cc:44-166.  int_data = [body torso, pelvis, foot_right, foot_left, waist_lower]
+DEV void residual_humanoid_walk(Ctx &c, double *residual) {
+  const DevModel &M = *c.M;
+  const int *I = MI(task.int_data);
+  const double *P = MD(task.parameters);
+  int nq = M.nq, nu = M.nu;
+  int torso = I[0], pelvis = I[1], fr = I[2], fl = I[3], wl = I[4];
+  if (LANE == 0) {
+    double torso_height = c.xipos[3 * torso + 2];
+    residual[0] = torso_height - P[0];
+    const double *foot_right = c.xipos + 3 * fr, *foot_left = c.xipos + 3 * fl;
+    residual[1] = 0.5 * (foot_left[2] + foot_right[2]) - c.xipos[3 * pelvis + 2] - 0.2;
+    const double *subcom = c.subtree_com + 3 * torso, *subcomvel = c.subtree_linvel + 3 * torso;
+    double cp[3], axis[3], center[3], vec[3], pcp[3];
+    for (int k = 0; k < 3; k++) cp[k] = subcom[k] + subcomvel[k] * 0.3;
+    cp[2] = 1.0e-3;
+    d_sub3(axis, foot_right, foot_left);
+    axis[2] = 1.0e-3;
+    double length = 0.5 * d_normalize3(axis) - 0.05;
+    d_add3(center, foot_right, foot_left);
+    d_scl3(center, center, 0.5);
+    d_sub3(vec, cp, center);
+    double t = d_dot3(vec, axis);
+    t = fmax(-length, fmin(length, t));
+    d_scl3(vec, axis, t);
+    d_add3(pcp, vec, center);
+    double standing = torso_height / sqrt(torso_height * torso_height + 0.45 * 0.45) - 0.4;
+    residual[2] = (cp[0] - pcp[0]) * standing; residual[3] = (cp[1] - pcp[1]) * standing;
+    const double *xt = c.xmat + 9 * torso, *xp = c.xmat + 9 * pelvis, *xr = c.xmat + 9 * fr, *xl = c.xmat + 9 * fl;
+    residual[4] = xt[8] - 1.0;
+    residual[5] = 0.3 * (xp[8] - 1.0);
+    for (int k = 0; k < 3; k++) {
+      double zr = k == 2 ? 1.0 : 0.0;
+      residual[6 + k] = (xr[3 * k + 2] - zr) * (0.1 * standing);
+      residual[9 + k] = (xl[3 * k + 2] - zr) * (0.1 * standing);
+    }
+    int o = 12 + nq - 7;
+    double fwx = ((xt[0] + xp[0]) + xr[0]) + xl[0], fwy = ((xt[3] + xp[3]) + xr[3]) + xl[3];
+    double n = sqrt(fwx * fwx + fwy * fwy);
+    if (n < D_MINVAL) { fwx = 1; fwy = 0; } else { double sc = 1.0 / n; fwx *= sc; fwy *= sc; }     // mju_normalize
+    double tv[3], rv[3], lv[3];
+    body_linvel(c, torso, tv); body_linvel(c, fr, rv); body_linvel(c, fl, lv);
+    const double *wlv = c.subtree_linvel + 3 * wl;
+    double cvx = (wlv[0] + tv[0]) * 0.5, cvy = (wlv[1] + tv[1]) * 0.5;
+    residual[o] = standing * (cvx * fwx + cvy * fwy - P[1]);
+    residual[o + 1] = ((cvx + rv[0] * -0.5) + lv[0] * -0.5) * standing;
+    residual[o + 2] = ((cvy + rv[1] * -0.5) + lv[1] * -0.5) * standing;
+  }
+  PFOR(i, nq - 7) residual[12 + i] = c.qpos[7 + i];
+  PFOR(i, nu) residual[12 + nq - 7 + 3 + i] = c.ctrl[i];
+}
+
 DEV void task_residual(Ctx &c, double *residual) {
   const DevModel &M = *c.M;
   int id = M.task.task_id;
@@ -1305,6 +1383,10 @@ DEV void task_residual(Ctx &c, double *residual) {
     residual_quadruped(c, residual);
   } else if (id == 4) {
     residual_humanoid_track(c, residual);
+  } else if (id == 5) {
+    residual_humanoid_stand(c, residual);
+  } else if (id == 6) {
+    residual_humanoid_walk(c, residual);
   }
   SYNC();
 }

@@ -17,7 +17,7 @@ import numpy as np
 
 from .builder import (BOX, CAPSULE, CYLINDER, FREE, HINGE, PLANE, SLIDE, SPHERE, ModelBuilder)
 
-TASK_PARTICLE, TASK_CARTPOLE, TASK_QUADRUPED, TASK_COPYSTATE, TASK_HUMANOID_TRACK = 0, 1, 2, 3, 4
+TASK_PARTICLE, TASK_CARTPOLE, TASK_QUADRUPED, TASK_COPYSTATE, TASK_HUMANOID_TRACK, TASK_HUMANOID_STAND, TASK_HUMANOID_WALK = 0, 1, 2, 3, 4, 5, 6
 OBJ_BODY, OBJ_XBODY, OBJ_GEOM, OBJ_SITE = 1, 2, 5, 6
 NORM_NPARAM = {-1: 0, 0: 0, 1: 2, 2: 1, 3: 1, 5: 1, 6: 1, 7: 2, 8: 1}   # mjpc/norm.cc:25-47
 
@@ -217,19 +217,19 @@ _TRACK_NAMES = ["pelvis", "head", "ltoe", "rtoe", "lheel", "rheel", "lknee", "rk
                 "lshoulder", "rshoulder", "lhip", "rhip"]          # tracking.cc:59-63
 
 
-def humanoid_track(timestep=0.005):
-    """mjpc/tasks/humanoid/humanoid.xml.patch (whole-file hunk) + tracking/task.xml; motion 0 ("Jump", 121 keys).
-    MJCF defaults apply: angles in degrees, pyramidal cones, body geoms condim 1 vs floor condim 3 -> condim 3."""
-    import os
+def _humanoid_model(timestep, mocap_bodies):
+    """mjpc/tasks/humanoid/humanoid.xml.patch (whole-file hunk): the modified dm_control humanoid shared by the tracking, stand
+    and walk tasks.  MJCF defaults apply: angles in degrees, pyramidal cones, body geoms condim 1 vs floor condim 3 -> condim 3.
+    Returns (builder, tracking-site ids, torso body id)."""
     D = math.pi / 180.0
     b = ModelBuilder(timestep=timestep, cone=0, impratio=1.0, contact=True)
     b.nconmax = 24
     b.nefcmax = 96
     b.geom(0, "floor", PLANE, size=(50, 50, 0.05))
-    mocap_id = {}
-    for n in _TRACK_NAMES:                      # task.xml:30-77 (mocap bodies carry sites only)
-        mb = b.body(f"mocap[{n}]", 0, mocap=True)
-        b.site(mb, f"mocap[{n}]")
+    if mocap_bodies:
+        for n in _TRACK_NAMES:                      # tracking/task.xml:30-77 (mocap bodies carry sites only)
+            mb = b.body(f"mocap[{n}]", 0, mocap=True)
+            b.site(mb, f"mocap[{n}]")
     G = dict(condim=1, friction=(0.7, 0.005, 0.0001), solimp=(0.9, 0.99, 0.003, 0.5, 2), solref=(0.015, 1))
     J = dict(damping=0.2, stiffness=1.0, armature=0.01, limited=True, solimplimit=(0, 0.99, 0.01, 0.5, 2))
     big = {**J, "damping": 5.0, "stiffness": 10.0}
@@ -269,6 +269,9 @@ def humanoid_track(timestep=0.005):
         b.joint(ft, f"ankle_x_{side}", HINGE, pos=(0, 0, 0.04), axis=(-sg, 0, -0.5 * sg), range=rng(-50, 50), **{**J, "stiffness": 3.0})
         b.geom(ft, f"foot1_{side}", CAPSULE, size=(0.027, 0), fromto=(-0.07, -0.01, 0, 0.14, -0.03, 0), **G)
         b.geom(ft, f"foot2_{side}", CAPSULE, size=(0.027, 0), fromto=(-0.07, 0.01, 0, 0.14, 0.03, 0), **G)
+        b.site(ft, f"foot_{side}", pos=(0.05, -0.03 * sg, 0))                          # humanoid.xml.patch:169-171, 216-218
+        b.site(ft, "sp2" if side == "right" else "sp0", pos=(-0.07, 0, 0))
+        b.site(ft, "sp3" if side == "right" else "sp1", pos=(0.14, 0, 0))
         heel = b.body(f"heel_{side}", ft, pos=(-0.05, 0, 0.04))
         sites[f"{s}heel"] = b.site(heel, f"tracking[{s}heel]")
         toe = b.body(f"toe_{side}", ft, pos=(0.07, 0, -0.01))
@@ -297,6 +300,13 @@ def humanoid_track(timestep=0.005):
                        ("ankle_y_left", 20), ("shoulder1_right", 20), ("shoulder2_right", 20), ("elbow_right", 40),
                        ("shoulder1_left", 20), ("shoulder2_left", 20), ("elbow_left", 40)]:
         b.actuator(name, name, gear=float(gear), ctrlrange=(-1, 1))
+    return b, sites, torso
+
+
+def humanoid_track(timestep=0.005):
+    """humanoid model + tracking/task.xml; motion 0 ("Jump", 121 keys)."""
+    import os
+    b, sites, torso = _humanoid_model(timestep, True)
     data = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "humanoid_jump_keys.npz"))
     mpos = data["mpos"]
     for k in range(mpos.shape[0]):
@@ -317,4 +327,30 @@ def humanoid_track(timestep=0.005):
     return m, task, defaults
 
 
-REGISTRY = {"particle": particle, "cartpole": cartpole, "quadruped": quadruped, "humanoid_track": humanoid_track}
+def humanoid_stand(timestep=0.015):
+    """humanoid model + stand/task.xml:8-37 (agent_timestep 0.015, horizon 0.35 s, 3 spline points, sigma 0.05)."""
+    b, sites, torso = _humanoid_model(timestep, False)
+    m = b.compile()
+    sid = m["names"]["site"]; bid = m["names"]["body"]
+    ints = [sid["sp0"], sid["sp1"], sid["sp2"], sid["sp3"], bid["head"], bid["torso"]]
+    terms = [(1, 6, 100.0, [0.1]), (1, 6, 50.0, [0.1]), (2, 0, 10.0), (21, 0, 0.01), (21, 3, 0.025, [0.3])]
+    task = make_task(TASK_HUMANOID_STAND, terms, parameters=[1.4], traces=[(OBJ_BODY, torso)], int_data=ints)
+    state = np.concatenate([m["qpos0"], np.zeros(m["nv"])])
+    return m, task, dict(N=10, P=3, sigma=(0.05, 0.0), interp=0, horizon=24, state=state, mocap=np.zeros(0))
+
+
+def humanoid_walk(timestep=0.015):
+    """humanoid model + walk/task.xml:8-35 (Torso height goal 1.35, Speed 0.5).  The cost table follows the XML; the residual
+    writes its 3 velocity numbers as (walk-forward, move-feet x, move-feet y), i.e. shifted by one against the term names."""
+    b, sites, torso = _humanoid_model(timestep, False)
+    m = b.compile()
+    bid = m["names"]["body"]
+    ints = [bid["torso"], bid["pelvis"], bid["foot_right"], bid["foot_left"], bid["waist_lower"]]
+    terms = [(1, 7, 5.0, [0.1, 4.0]), (1, 8, 1.0, [0.05]), (2, 1, 5.0, [0.02, 4.0]), (8, 2, 5.0, [0.01]), (21, 0, 0.025),
+             (2, 7, 0.625, [0.2, 4.0]), (1, 7, 1.0, [0.5, 3.0]), (21, 3, 0.1, [0.3])]
+    task = make_task(TASK_HUMANOID_WALK, terms, parameters=[1.35, 0.5], traces=[(OBJ_BODY, torso)], int_data=ints)
+    state = np.concatenate([m["qpos0"], np.zeros(m["nv"])])
+    return m, task, dict(N=10, P=3, sigma=(0.05, 0.0), interp=0, horizon=24, state=state, mocap=np.zeros(0))
+
+
+REGISTRY = {"humanoid_stand": humanoid_stand, "humanoid_walk": humanoid_walk, "particle": particle, "cartpole": cartpole, "quadruped": quadruped, "humanoid_track": humanoid_track}

@@ -382,6 +382,93 @@ static void residual_humanoid_track(const OModel *om, OData *d, double *residual
   }
 }
 
+/* velocity of a body's inertial-frame origin in the world frame (framelinvel objtype="body", mj_objectVelocity) */
+static void body_linvel(const OModel *om, const OData *d, int body, double *lin) {
+  double off[3];
+  o_sub3(off, d->xipos + 3 * body, d->subtree_com + 3 * om->m.body_rootid[body]);
+  o_cross(lin, d->cvel + 6 * body, off);
+  o_add3(lin, lin, d->cvel + 6 * body + 3);
+}
+
+/* mjpc/tasks/humanoid/stand/stand.cc:41-94.  int_data = [site sp0, sp1, sp2, sp3, body head, body torso] */
+static void residual_humanoid_stand(const OModel *om, OData *d, double *residual) {
+  const MjpcHipModel *m = &om->m;
+  const int *I = om->t.int_data;
+  int counter = 0;
+  const double *f1 = d->site_xpos + 3 * I[0], *f2 = d->site_xpos + 3 * I[1], *f3 = d->site_xpos + 3 * I[2], *f4 = d->site_xpos + 3 * I[3];
+  const double *head = d->xipos + 3 * I[4];                                   /* framepos objtype="body": inertial frame */
+  double head_feet_error = head[2] - 0.25 * (f1[2] + f2[2] + f3[2] + f4[2]);
+  residual[counter++] = head_feet_error - om->t.parameters[0];
+  const double *com = d->subtree_com + 3 * I[5], *comvel = d->subtree_linvel + 3 * I[5];
+  double kFallTime = 0.2;
+  double cp[3] = {com[0], com[1], com[2]};
+  o_addtoscl3(cp, comvel, kFallTime);
+  double fxy[2] = {0, 0};
+  fxy[0] += f1[0]; fxy[1] += f1[1]; fxy[0] += f2[0]; fxy[1] += f2[1]; fxy[0] += f3[0]; fxy[1] += f3[1]; fxy[0] += f4[0]; fxy[1] += f4[1];
+  fxy[0] *= 0.25; fxy[1] *= 0.25;
+  fxy[0] -= cp[0]; fxy[1] -= cp[1];
+  residual[counter++] = sqrt(fxy[0] * fxy[0] + fxy[1] * fxy[1]);
+  residual[counter++] = comvel[0]; residual[counter++] = comvel[1];
+  o_copy(residual + counter, d->qvel + 6, m->nv - 6); counter += m->nv - 6;
+  o_copy(residual + counter, d->ctrl, m->nu); counter += m->nu;
+}
+
+/* mjpc/tasks/humanoid/walk/walk.cc:44-166.  int_data = [body torso, pelvis, foot_right, foot_left, waist_lower] */
+static void residual_humanoid_walk(const OModel *om, OData *d, double *residual) {
+  const MjpcHipModel *m = &om->m;
+  const int *I = om->t.int_data;
+  const double *P = om->t.parameters;
+  int torso = I[0], pelvis = I[1], fr = I[2], fl = I[3], wl = I[4];
+  int counter = 0;
+  double torso_height = d->xipos[3 * torso + 2];
+  residual[counter++] = torso_height - P[0];
+  const double *foot_right = d->xipos + 3 * fr, *foot_left = d->xipos + 3 * fl;
+  double pelvis_height = d->xipos[3 * pelvis + 2];
+  residual[counter++] = 0.5 * (foot_left[2] + foot_right[2]) - pelvis_height - 0.2;
+  const double *subcom = d->subtree_com + 3 * torso, *subcomvel = d->subtree_linvel + 3 * torso;
+  double capture_point[3], axis[3], center[3], vec[3], pcp[3];
+  for (int k = 0; k < 3; k++) capture_point[k] = subcom[k] + subcomvel[k] * 0.3;
+  capture_point[2] = 1.0e-3;
+  o_sub3(axis, foot_right, foot_left);
+  axis[2] = 1.0e-3;
+  double length = 0.5 * o_normalize3(axis) - 0.05;
+  o_add3(center, foot_right, foot_left);
+  o_scl3(center, center, 0.5);
+  o_sub3(vec, capture_point, center);
+  double t = o_dot3(vec, axis);
+  t = fmax(-length, fmin(length, t));
+  o_scl3(vec, axis, t);
+  o_add3(pcp, vec, center);
+  pcp[2] = 1.0e-3;
+  double standing = torso_height / sqrt(torso_height * torso_height + 0.45 * 0.45) - 0.4;
+  residual[counter] = (capture_point[0] - pcp[0]) * standing; residual[counter + 1] = (capture_point[1] - pcp[1]) * standing;
+  counter += 2;
+  /* framezaxis / framexaxis of the xbody frames: columns 2 / 0 of xmat */
+  const double *xt = d->xmat + 9 * torso, *xp = d->xmat + 9 * pelvis, *xr = d->xmat + 9 * fr, *xl = d->xmat + 9 * fl;
+  residual[counter++] = xt[8] - 1.0;
+  residual[counter++] = 0.3 * (xp[8] - 1.0);
+  double zref[3] = {0, 0, 1};
+  for (int k = 0; k < 3; k++) residual[counter + k] = (xr[3 * k + 2] - zref[k]) * (0.1 * standing);
+  counter += 3;
+  for (int k = 0; k < 3; k++) residual[counter + k] = (xl[3 * k + 2] - zref[k]) * (0.1 * standing);
+  counter += 3;
+  o_copy(residual + counter, d->qpos + 7, m->nq - 7); counter += m->nq - 7;
+  double forward[2] = {xt[0], xt[3]};
+  forward[0] += xp[0]; forward[1] += xp[3]; forward[0] += xr[0]; forward[1] += xr[3]; forward[0] += xl[0]; forward[1] += xl[3];
+  { double n = sqrt(forward[0] * forward[0] + forward[1] * forward[1]);
+    if (n < O_MINVAL) { forward[0] = 1; forward[1] = 0; } else { double sc = 1.0 / n; forward[0] *= sc; forward[1] *= sc; } }     /* mju_normalize */
+  double tv[3], rv[3], lv[3];
+  body_linvel(om, d, torso, tv); body_linvel(om, d, fr, rv); body_linvel(om, d, fl, lv);
+  const double *wlv = d->subtree_linvel + 3 * wl;
+  double com_vel[2] = {(wlv[0] + tv[0]) * 0.5, (wlv[1] + tv[1]) * 0.5};
+  residual[counter++] = standing * (com_vel[0] * forward[0] + com_vel[1] * forward[1] - P[1]);
+  double mf[2] = {com_vel[0], com_vel[1]};
+  mf[0] += rv[0] * -0.5; mf[1] += rv[1] * -0.5; mf[0] += lv[0] * -0.5; mf[1] += lv[1] * -0.5;
+  residual[counter] = mf[0] * standing; residual[counter + 1] = mf[1] * standing;
+  counter += 2;
+  o_copy(residual + counter, d->ctrl, m->nu); counter += m->nu;
+}
+
 void oracle_residual(const OModel *om, OData *d, double *residual) {
   const MjpcHipModel *m = &om->m;
   switch (om->t.task_id) {
@@ -406,6 +493,12 @@ void oracle_residual(const OModel *om, OData *d, double *residual) {
       break;
     case MJPC_TASK_HUMANOID_TRACK:
       residual_humanoid_track(om, d, residual);
+      break;
+    case MJPC_TASK_HUMANOID_STAND:
+      residual_humanoid_stand(om, d, residual);
+      break;
+    case MJPC_TASK_HUMANOID_WALK:
+      residual_humanoid_walk(om, d, residual);
       break;
     default: break;
   }

@@ -475,3 +475,13 @@ def test_cpp_robust_planner_matches_oracle_restatement():
         state = tr.states[1].copy(); t += m["timestep"]
     assert np.abs(state[:2] - d["mocap"][:2]).sum() < 0.2
     rp.close()
+
+
+@pytest.mark.parametrize("name", ["humanoid_stand", "humanoid_walk"])
+def test_humanoid_stand_and_walk_tasks(name):
+    """mjpc/tasks/humanoid/stand/stand.cc:41-94 and walk/walk.cc:44-166 (the other two tasks the local humanoid model serves):
+    engine vs oracle with the tasks' agent settings (agent_timestep 0.015, 0.35 s horizon, 3 zero-order knots)."""
+    from mujoco_mpc_amd.modelgen import REGISTRY
+    m, task, d = REGISTRY[name]()
+    out, ref, allc = _compare(m, task, d, 3, 24, 8, (0.05, 0.0), 0, 1e-5, nominal_scale=0.2)
+    assert allc["diag"][:, 1].max() >= 2                                # the feet are on the floor

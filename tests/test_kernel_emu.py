@@ -10,7 +10,7 @@ import pytest
 import emu_lib
 import oracle_lib as ol
 from mujoco_mpc_amd import capi
-from mujoco_mpc_amd.modelgen import cartpole, humanoid_track, particle, quadruped
+from mujoco_mpc_amd.modelgen import REGISTRY, cartpole, humanoid_track, particle, quadruped
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -21,9 +21,10 @@ def _rel(a, b):
 
 @pytest.mark.parametrize("name,P,H,N,sigma,tol", [("particle", 11, 26, 6, (0.3, 0.0), 1e-12), ("cartpole", 10, 50, 8, (0.5, 0.0), 1e-12),
                                                    ("quadruped", 3, 30, 6, (0.04, 0.0), 1e-5),
-                                                   ("humanoid_track", 16, 30, 4, (0.15, 0.0), 1e-5)])
+                                                   ("humanoid_track", 16, 30, 4, (0.15, 0.0), 1e-5),
+                                                   ("humanoid_stand", 3, 24, 4, (0.05, 0.0), 1e-5), ("humanoid_walk", 3, 24, 4, (0.05, 0.0), 1e-5)])
 def test_kernel_source_matches_oracle(name, P, H, N, sigma, tol):
-    m, task, d = {"particle": particle, "cartpole": cartpole, "quadruped": quadruped, "humanoid_track": humanoid_track}[name]()
+    m, task, d = REGISTRY[name]()
     o = ol.Oracle(m, task)
     kt = np.linspace(0, (H - 1) * m["timestep"], P); kv = np.random.default_rng(0).uniform(-0.3, 0.3, (P, m["nu"]))
     eps, sel = ol.noise(1, 0, 0, N, P, m["nu"])

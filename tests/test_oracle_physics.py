@@ -281,3 +281,41 @@ def test_humanoid_model_matches_known_mass_and_mocap_pose():
     assert r["warning"] == 0 and r["ncon"] == 4 and r["nefc"] == 16           # two feet, 2 capsule ends each, 4 edges
     pos_res = r["sensordata"][42:93]                                         # marker position residuals at key 0
     assert np.abs(pos_res).max() < 0.06                                       # model pose agrees with its mocap markers
+
+
+def test_humanoid_stand_and_walk_residuals_at_the_upright_pose():
+    """stand.cc:41-94 / walk.cc:44-166 on the oracle at qpos0 (upright, at rest): closed-form values from the numpy kinematics
+    of the model generator (site / inertial-frame positions), independent of the oracle's own kinematics."""
+    from mujoco_mpc_amd.modelgen import humanoid_stand, humanoid_walk, kinematics
+
+    def frames(m):
+        xpos, xquat, xmat, _, _ = kinematics(m, m["qpos0"])
+        xmat = np.asarray(xmat).reshape(-1, 3, 3); xpos = np.asarray(xpos).reshape(-1, 3)
+        xipos = xpos + np.einsum("bij,bj->bi", xmat, np.asarray(m["body_ipos"]).reshape(-1, 3))
+        sb = np.asarray(m["site_bodyid"])
+        site = xpos[sb] + np.einsum("bij,bj->bi", xmat[sb], np.asarray(m["site_pos"]).reshape(-1, 3))
+        return xipos, site
+    m, task, d = humanoid_stand()
+    o = ol.Oracle(m, task)
+    f = o.forward(m["qpos0"], ctrl=np.full(m["nu"], 0.25))
+    r = f["sensordata"]
+    names = m["names"]
+    xi, sx = frames(m)
+    feet = np.array([sx[names["site"][k]] for k in ("sp0", "sp1", "sp2", "sp3")])
+    assert abs(r[0] - (xi[names["body"]["head"]][2] - feet[:, 2].mean() - 1.4)) < 1e-12
+    com = f["subtree_com"][names["body"]["torso"]]
+    assert abs(r[1] - np.linalg.norm(feet[:, :2].mean(axis=0) - com[:2])) < 1e-12      # at rest the capture point is the CoM
+    assert np.all(r[2:4] == 0) and np.all(r[4:25] == 0) and np.all(r[25:46] == 0.25)
+    m, task, d = humanoid_walk()
+    o = ol.Oracle(m, task)
+    f = o.forward(m["qpos0"], ctrl=np.full(m["nu"], -0.5))
+    r = f["sensordata"]
+    xi, sx = frames(m); b = m["names"]["body"]
+    th = xi[b["torso"]][2]
+    assert abs(r[0] - (th - 1.35)) < 1e-12
+    assert abs(r[1] - (0.5 * (xi[b["foot_left"]][2] + xi[b["foot_right"]][2]) - xi[b["pelvis"]][2] - 0.2)) < 1e-12
+    assert np.all(np.abs(r[4:12]) < 1e-12)                                # upright: all z axes are (0,0,1)
+    assert np.all(r[12:33] == m["qpos0"][7:])                             # posture
+    standing = th / np.sqrt(th * th + 0.45 * 0.45) - 0.4
+    assert abs(r[33] - standing * (0.0 - 0.5)) < 1e-12                    # at rest: speed error = -speed goal
+    assert np.all(np.abs(r[34:36]) < 1e-12) and np.all(r[36:57] == -0.5)

@@ -216,6 +216,11 @@ int mjpc_hip_get_candidate(MjpcHipEngine *e, int local_index, MjpcHipPlanOutput 
 /* Copy every local candidate's knot values [num_local][P][nu] of the last plan to host (elite statistics of the
  * Cross-Entropy planner, cross_entropy/planner.cc:226-262). */
 int mjpc_hip_get_knots(MjpcHipEngine *e, double *knots);
+/* Kinematic frame of local candidate 0 at the first step of the last plan (the state handed in): what a host-side
+ * Task::Transition reads from mjData after a simulation step (mjpc/tasks/quadruped/quadruped.cc:254,290-330: body poses, site
+ * positions, subtree com / linear velocity sensors).  Any pointer may be NULL.  Sizes: xpos 3*nbody, xmat 9*nbody,
+ * site_xpos 3*nsite, subtree_com 3*nbody, subtree_linvel 3*nbody. */
+int mjpc_hip_get_frame(MjpcHipEngine *e, double *xpos, double *xmat, double *site_xpos, double *subtree_com, double *subtree_linvel);
 /* Average device time of the rollout kernel over the launches since the last call,
  * measured with hipEvents on the engine's stream; returns launches counted. */
 int mjpc_hip_kernel_time(MjpcHipEngine *e, double *avg_rollout_us, double *avg_total_us);

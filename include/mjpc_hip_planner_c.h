@@ -88,7 +88,8 @@ void *mjpc_robust_delegate(void *planner);     /* the SamplingPlanner handle (mj
  * plan_steps, failure}.  Returns the total cost. */
 double mjpc_testspeed_run(const MjpcHipModel *model, const MjpcHipTask *task, void *planner, int planner_kind, double *state,
                           double *mocap, double time0, int horizon, int steps_per_planning_iteration, double total_time, int device,
-                          double *cost_per_step, double *out);
+                          double *cost_per_step, double *out, int mode /* Task::mode */, double mode_time /* when the user selects it */,
+                          double *task_parameters_out /* [num_parameter] or NULL */);
 
 #ifdef __cplusplus
 }

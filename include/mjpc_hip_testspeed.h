@@ -8,8 +8,10 @@
 // the control; row 0 of that rollout carries the residual / cost at (x_t, u_t) exactly like `data->sensordata` after
 // mj_step.  `Transition` restates Task::Transition for the built-in tasks on the host (mjpc/task.cc:141-145):
 //   humanoid tracking: mocap targets interpolated between key frames, reference time on motion start (tracking.cc:223-267);
-//   particle / cartpole: none;  quadruped in its default mode (Quadruped, manual gait): a no-op after the first call
-//   (quadruped.cc:224-390 only acts on mode / gait / parameter changes), so the frozen task block stays valid.
+//   quadruped: the mode / gait state machine of QuadrupedFlat::TransitionLocked (quadruped.cc:224-390): phase bookkeeping,
+//   automatic gait switching on the filtered com speed, gait parameter / weight tables, the Walk goal trajectory, Flip
+//   entry / exit — reading the simulator's kinematic frame of the previous step like the reference reads mjData;
+//   particle / cartpole / humanoid stand / walk: none.
 #ifndef MJPC_HIP_TESTSPEED_H_
 #define MJPC_HIP_TESTSPEED_H_
 
@@ -35,6 +37,12 @@ struct SimState {
   double time = 0;
 };
 
+// what Task::Transition reads from mjData after a simulation step (poses / sensors of the state the step started from)
+struct SimFrame {
+  std::vector<double> xpos, xmat, site_xpos, subtree_com, subtree_linvel;
+  bool valid = false;
+};
+
 class Simulator {
  public:
   Simulator(const MjpcHipModel* model, const MjpcHipTask* task, int device = 0);
@@ -43,6 +51,9 @@ class Simulator {
   Simulator& operator=(const Simulator&) = delete;
   // mj_step with data->ctrl = ctrl: advances s, returns CostValue(sensordata) of (x_t, u_t); residual[nr] optional
   double Step(SimState& s, const double* ctrl, double* residual = nullptr);
+  // mj_forward at s without advancing (testspeed.cc:75: data is forwarded once before the loop); fills frame()
+  void Forward(const SimState& s);
+  const SimFrame& frame() const { return frame_; }
   void SetTask(const MjpcHipTask* task);
   bool failed() const { return failure_; }
   int nq, nv, nu, nmocap, nr;
@@ -51,12 +62,28 @@ class Simulator {
  private:
   MjpcHipEngine* engine_ = nullptr;
   std::vector<double> states_, residual_, costs_, times_, actions_, trace_;
+  SimFrame frame_;
+  void FetchFrame();
   bool failure_ = false;
 };
 
 // Task::Transition on the host; may edit the state (mocap targets), the task block, or both
-using TransitionFn = std::function<void(const MjpcHipModel&, SimState&, HostTask&)>;
-TransitionFn TransitionForTask(int task_id);      // MJPC_TASK_* -> built-in transition (no-op where the reference has none)
+using TransitionFn = std::function<void(const MjpcHipModel&, SimState&, HostTask&, const SimFrame&)>;
+// MJPC_TASK_* -> built-in transition (no-op where the reference has none); `mode` is Task::mode, the mode the user asks for
+// (quadruped: 0 Quadruped, 1 Biped, 2 Walk, 3 Scramble, 4 Flip, quadruped.h:40-47)
+// `mode_time`: simulation time at which the user switches to `mode` (the reference resets stateful modes to Quadruped on the
+// first Transition after a data reset, quadruped.cc:226-232, so Walk / Flip can only be entered later)
+TransitionFn TransitionForTask(int task_id, int mode = 0, double mode_time = 0.0);
+
+// QuadrupedFlat::TransitionLocked (quadruped.cc:224-390) with its ResidualFn state split between the task block the kernel
+// reads (HostTask int/dbl data, parameters, weights; layout of modelgen/tasks.py quadruped()) and the host-only members here
+struct QuadrupedTransition {
+  int mode = 0;                       // Task::mode (requested)
+  int current_mode = 0;               // residual_.current_mode_
+  double last_transition_time = -1, com_vel[2] = {0, 0}, gait_switch_time = 0;
+  std::vector<double> save_weight; double save_gait_switch = 0;
+  void operator()(const MjpcHipModel& model, SimState& s, HostTask& t, const SimFrame& f);
+};
 
 struct PlannerOps {                               // the four Planner calls the loop needs (planners/planner.h:38-80)
   std::function<void(const SimState&)> SetState;

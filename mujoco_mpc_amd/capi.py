@@ -204,6 +204,7 @@ def load_engine():
     lib.mjpc_hip_plan_fetch.argtypes = [C.c_void_p, C.POINTER(MjpcHipPlanOutput)]
     lib.mjpc_hip_get_candidate.argtypes = [C.c_void_p, C.c_int, C.POINTER(MjpcHipPlanOutput)]
     lib.mjpc_hip_get_knots.argtypes = [C.c_void_p, c_double_p]
+    lib.mjpc_hip_get_frame.argtypes = [C.c_void_p] + [c_double_p] * 5
     lib.mjpc_hip_kernel_time.argtypes = [C.c_void_p, c_double_p, c_double_p]
     lib.mjpc_hip_device_ptrs.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
     lib.mjpc_hip_debug_fetch_all.argtypes = [C.c_void_p] + [c_double_p] * 7 + [c_int_p]
@@ -217,5 +218,5 @@ def load_engine():
 EXPORTED_SYMBOLS = [
     "mjpc_hip_create", "mjpc_hip_destroy", "mjpc_hip_set_task", "mjpc_hip_plan", "mjpc_hip_plan_async",
     "mjpc_hip_plan_fetch", "mjpc_hip_get_candidate", "mjpc_hip_kernel_time", "mjpc_hip_device_ptrs",
-    "mjpc_hip_last_error", "mjpc_hip_version", "mjpc_hip_get_knots",
+    "mjpc_hip_last_error", "mjpc_hip_version", "mjpc_hip_get_knots", "mjpc_hip_get_frame",
 ]

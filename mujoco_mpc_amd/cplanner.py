@@ -102,7 +102,7 @@ def lib():
         "mjpc_robust_optimize_policy": (None, [vp, i]), "mjpc_robust_action_from_policy": (None, [vp, c_double_p, d]),
         "mjpc_robust_last": (None, [vp, c_int_p, c_double_p, c_double_p]), "mjpc_robust_delegate": (vp, [vp]),
         "mjpc_testspeed_run": (d, [C.POINTER(capi.MjpcHipModel), C.POINTER(capi.MjpcHipTask), vp, i, c_double_p, c_double_p, d, i, i, d, i,
-                                   c_double_p, c_double_p]),
+                                   c_double_p, c_double_p, i, d, c_double_p]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)
@@ -350,7 +350,7 @@ class CrossEntropyPlanner:
         return t
 
 
-def testspeed(planner, state, mocap=None, time0=0.0, horizon=None, steps_per_planning_iteration=1, total_time=1.0, device=0):
+def testspeed(planner, state, mocap=None, time0=0.0, horizon=None, steps_per_planning_iteration=1, total_time=1.0, device=0, mode=0, mode_time=0.0):
     """mjpc/testspeed.cc:44-129 (`SynchronousPlanningCost`) through the C++ harness: `planner` is a cplanner.SamplingPlanner or
     cplanner.CrossEntropyPlanner that has been Initialize()d / Reset(); the world is stepped on the HIP engine as well."""
     L = lib()
@@ -359,13 +359,13 @@ def testspeed(planner, state, mocap=None, time0=0.0, horizon=None, steps_per_pla
     nsteps = int(np.ceil(total_time / m["timestep"]))
     st = np.ascontiguousarray(state, dtype=np.float64).copy()
     mc = None if (mocap is None or m["nmocap"] == 0) else np.ascontiguousarray(mocap, dtype=np.float64).copy()
-    costs = np.zeros(nsteps); out = np.zeros(6)
+    costs = np.zeros(nsteps); out = np.zeros(6); params = np.zeros(max(int(cm.task["num_parameter"]), 1))
     kind = 1 if isinstance(planner, CrossEntropyPlanner) else 0
     total = L.mjpc_testspeed_run(C.byref(cm.c_model), C.byref(cm.c_task), planner._h, kind, _dp(st), _dp(mc), float(time0), int(horizon),
-                                 int(steps_per_planning_iteration), float(total_time), int(device), _dp(costs), _dp(out))
+                                 int(steps_per_planning_iteration), float(total_time), int(device), _dp(costs), _dp(out), int(mode), float(mode_time), _dp(params))
     _check()
     return dict(total_cost=total, average_cost=out[0], wall_seconds=out[1], realtime_factor=out[2], plan_seconds=out[3],
-                plan_steps=int(out[4]), failure=bool(out[5]), cost_per_step=costs, state=st, mocap=mc)
+                plan_steps=int(out[4]), failure=bool(out[5]), cost_per_step=costs, state=st, mocap=mc, parameters=params)
 
 
 class RobustPlanner:

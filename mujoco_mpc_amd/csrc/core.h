@@ -1620,6 +1620,13 @@ DEV_NOINLINE CostOut ph_residual_cost(KP Kc, int t, int last) {        // role 1
   const DevTask &T = M.task;
   Rows R = out_rows(K);
   if (last) PFOR(k, M.nu) R.actions[t * M.nu + k] = (K->H > 1) ? c.ctrl[k] : 0.0;     // trajectory.cc:190-195
+  if (t == 0 && cand_index() == 0 && K->frame) {          // host Task::Transition reads these after a simulation step
+    int nb = M.nbody, ns = M.nsite;
+    double *f = K->frame;
+    PFOR(i, 3 * nb) { f[i] = c.xpos[i]; f[12 * nb + 3 * ns + i] = c.subtree_com[i]; f[15 * nb + 3 * ns + i] = c.subtree_linvel[i]; }
+    PFOR(i, 9 * nb) f[3 * nb + i] = c.xmat[i];
+    PFOR(i, 3 * ns) f[12 * nb + i] = c.site_xpos[i];
+  }
   task_residual(c, c.residual); PROF(c, 9);
   PFOR(i, R.nr) R.residual[t * R.nr + i] = c.residual[i];
   PFOR(i, T.num_trace) {

@@ -117,6 +117,7 @@ struct MjpcHipEngine {
   size_t knots_cap = 0;
   int *d_failure = nullptr, *d_diag = nullptr, *d_winner = nullptr;
   long long *d_prof = nullptr;
+  double *d_frame = nullptr; int nbody = 0, nsite = 0;
   // pinned host staging
   double *d_pack = nullptr, *h_pack = nullptr; size_t pack_cap = 0;   // packed plan result (device / pinned host)
   double *h_small = nullptr;   // state | mocap | knot_times | knot_values | noise_std
@@ -180,6 +181,8 @@ MjpcHipEngine *mjpc_hip_create(const MjpcHipModel *model, const MjpcHipTask *tas
   HIPCHKP(hipMalloc(&e->d_failure, sizeof(int) * NL));
   HIPCHKP(hipMalloc(&e->d_diag, sizeof(int) * NL * 4));
   HIPCHKP(hipMalloc(&e->d_winner, sizeof(int) * 2));
+  e->nbody = model->nbody; e->nsite = model->nsite;
+  HIPCHKP(hipMalloc(&e->d_frame, sizeof(double) * (18 * (size_t)e->nbody + 3 * (size_t)e->nsite + 1)));
   HIPCHKP(hipMalloc(&e->d_prof, sizeof(long long) * NL * 24));
   HIPCHKP(hipMemset(e->d_prof, 0, sizeof(long long) * NL * 24));
   HIPCHKP(hipMalloc(&e->d_winner_val, sizeof(double) * 2));
@@ -195,7 +198,7 @@ void mjpc_hip_destroy(MjpcHipEngine *e) {
   if (e->stream) hipStreamSynchronize(e->stream);
   void *bufs[] = {e->d_cand, e->d_std, e->d_ib, e->d_db, e->d_state, e->d_mocap, e->d_kt, e->d_kv, e->d_eps, e->d_sel, e->d_states, e->d_actions,
                   e->d_times, e->d_residual, e->d_costs, e->d_trace, e->d_knots, e->d_returns, e->d_failure, e->d_diag,
-                  e->d_winner, e->d_winner_val, e->d_prof};
+                  e->d_winner, e->d_winner_val, e->d_prof, e->d_frame};
   for (void *b : bufs) if (b) hipFree(b);
   if (e->h_small) hipHostFree(e->h_small);
   if (e->h_pack) hipHostFree(e->h_pack);
@@ -279,7 +282,7 @@ int mjpc_hip_plan_async(MjpcHipEngine *e, const MjpcHipPlanInput *in) {
     K.cand_knots = e->d_cand;
   }
   K.states = e->d_states; K.actions = e->d_actions; K.times = e->d_times; K.residual = e->d_residual; K.costs = e->d_costs;
-  K.trace = e->d_trace; K.knots = e->d_knots; K.returns = e->d_returns; K.failure = e->d_failure; K.diag = e->d_diag; K.prof = e->d_prof;
+  K.trace = e->d_trace; K.knots = e->d_knots; K.returns = e->d_returns; K.failure = e->d_failure; K.diag = e->d_diag; K.prof = e->d_prof; K.frame = e->d_frame;
   HIPCHK(hipEventRecord(e->ev[1], e->stream));
   hipLaunchKernelGGL(e->kernel, dim3(nl), dim3(64 * MJPC_WAVES), e->lds_bytes, e->stream, K);
   HIPCHK(hipEventRecord(e->ev[2], e->stream));
@@ -352,6 +355,19 @@ int mjpc_hip_plan(MjpcHipEngine *e, const MjpcHipPlanInput *in, MjpcHipPlanOutpu
   int rc = mjpc_hip_plan_async(e, in);
   if (rc != 0) return rc;
   return mjpc_hip_plan_fetch(e, out);
+}
+
+int mjpc_hip_get_frame(MjpcHipEngine *e, double *xpos, double *xmat, double *site_xpos, double *subtree_com, double *subtree_linvel) {
+  if (!e || e->last_nlocal < 1) { set_error("mjpc_hip_get_frame: no finished plan"); return -1; }
+  HIPCHK(hipSetDevice(e->device));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  size_t nb = (size_t)e->nbody, ns = (size_t)e->nsite;
+  if (xpos) HIPCHK(hipMemcpy(xpos, e->d_frame, sizeof(double) * 3 * nb, hipMemcpyDeviceToHost));
+  if (xmat) HIPCHK(hipMemcpy(xmat, e->d_frame + 3 * nb, sizeof(double) * 9 * nb, hipMemcpyDeviceToHost));
+  if (site_xpos && ns) HIPCHK(hipMemcpy(site_xpos, e->d_frame + 12 * nb, sizeof(double) * 3 * ns, hipMemcpyDeviceToHost));
+  if (subtree_com) HIPCHK(hipMemcpy(subtree_com, e->d_frame + 12 * nb + 3 * ns, sizeof(double) * 3 * nb, hipMemcpyDeviceToHost));
+  if (subtree_linvel) HIPCHK(hipMemcpy(subtree_linvel, e->d_frame + 15 * nb + 3 * ns, sizeof(double) * 3 * nb, hipMemcpyDeviceToHost));
+  return 0;
 }
 
 int mjpc_hip_get_knots(MjpcHipEngine *e, double *knots) {

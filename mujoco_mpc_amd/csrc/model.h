@@ -99,5 +99,6 @@ struct KParams {
   // outputs (device), row-major per local candidate
   double *states, *actions, *times, *residual, *costs, *trace, *knots, *returns;
   int *failure, *diag;
+  double *frame;       // kinematic frame of local candidate 0 at step 0: xpos | xmat | site_xpos | subtree_com | subtree_linvel
   long long *prof;     // optional per-candidate phase cycle counters (MJPC_PROFILE builds)
 };

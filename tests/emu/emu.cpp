@@ -19,6 +19,7 @@ extern "C" int emu_plan(const MjpcHipModel *m, const MjpcHipTask *t, const MjpcH
   memset(&K, 0, sizeof(K));
   K.M = mjpc_host::relocate(pm, pm.ib.data(), pm.db.data());
   K.L = pm.L;
+  K.frame = nullptr;
   K.ibase = pm.ib.data(); K.dbase = pm.db.data(); K.cache_i = (int)pm.cache_i; K.cache_d = (int)pm.cache_d;
   int P = in->num_spline_points, nu = m->nu, nl = in->num_local;
   std::vector<double> eps((size_t)nl * P * nu + 1, 0.0);

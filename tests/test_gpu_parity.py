@@ -485,3 +485,36 @@ def test_humanoid_stand_and_walk_tasks(name):
     m, task, d = REGISTRY[name]()
     out, ref, allc = _compare(m, task, d, 3, 24, 8, (0.05, 0.0), 0, 1e-5, nominal_scale=0.2)
     assert allc["diag"][:, 1].max() >= 2                                # the feet are on the floor
+
+
+def test_closed_loop_quadruped_walk_mode_transition():
+    """QuadrupedFlat::TransitionLocked on the host (quadruped.cc:224-390) inside the closed loop: entering Walk mode stores the
+    walk origin / heading and then moves the goal mocap along it at the commanded speed (ResidualFn::Walk, quadruped.cc:627-643);
+    after the 1 s minimum switching time the automatic gait selection leaves Stand once the filtered com speed exceeds 2 cm/s."""
+    from mujoco_mpc_amd import cplanner
+    from mujoco_mpc_amd.modelgen.tasks import select_value
+    import struct
+    m, task, d = quadruped()
+    speed = 0.3
+    task = dict(task); task["parameters"] = np.array(task["parameters"], float).copy(); task["parameters"][5] = speed     # "Walk speed"
+    p = cplanner.SamplingPlanner()
+    p.Initialize(m, task, dict(sampling_spline_points=3, sampling_exploration=0.04, sampling_trajectories=60, sampling_representation=2),
+                 max_samples=60, max_horizon=36)
+    p.Reset(36)
+    steps = 140
+    res = cplanner.testspeed(p, d["state"], d["mocap"], horizon=36, steps_per_planning_iteration=1, total_time=steps * m["timestep"], mode=2, mode_time=0.1)
+    assert not res["failure"]
+    t_last = 0.0
+    for _ in range(steps - 1):
+        t_last += m["timestep"]
+    t_on = 0.0
+    while t_on < 0.1:
+        t_on += m["timestep"]                                # first Transition with time >= mode_time: Walk starts here
+    # goal(t) = origin + heading + (t - t_on) * speed * heading/|heading| with origin = trunk xy at t_on, heading = goal - origin
+    # (the trunk has drifted by a fraction of a millimetre sideways by t_on, so the heading is not exactly +x)
+    assert np.abs(res["mocap"][0] - (d["mocap"][0] + (t_last - t_on) * speed)) < 1e-4 and abs(res["mocap"][1]) < 1e-2
+    assert res["state"][0] > 0.03 and res["state"][2] > 0.15  # the A1 moves towards the goal and stays up
+    gait = struct.unpack("<q", struct.pack("<d", res["parameters"][0]))[0]
+    assert gait == 2                                         # automatic gait switching picked Trot (quadruped.h:100-107)
+    assert res["parameters"][2] == 2.0 and res["parameters"][3] == 0.03 and res["parameters"][4] == 0.45     # trot cadence / amplitude / duty
+    p.close()

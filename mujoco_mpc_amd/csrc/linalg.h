@@ -1,11 +1,11 @@
 // linalg.h — small dense SPD factorisation / solves for one wavefront.
 //
-// Two implementations of A = L L^T (lower triangle, row stride nvp, Linv[j] = 1/L[j][j]):
-//  * generic (any n, also the 1-lane emulation build): left-looking in LDS, one SYNC pair per column;
-//  * NVT > 0 (gfx950 only, n == NVT known at compile time): lane i keeps ROW i of the matrix in VGPRs,
-//    pivots and the L[k][j] factors are broadcast with v_readlane (no LDS traffic, no barriers inside the
-//    factorisation); triangular solves keep x in a VGPR per lane and prefetch their L row/column once.
-// A single wave per candidate is latency-bound, so the register form is ~8x faster than the LDS form.
+//  * generic (any n, also the 1-lane emulation build): A = L L^T, left-looking in LDS, one SYNC pair per column,
+//    Linv[j] = 1/L[j][j];
+//  * NVT > 0 (gfx950 only, n == NVT known at compile time): A = L^T D L with lane i keeping ROW i of the matrix in VGPRs;
+//    pivots and rows are broadcast with v_readlane (no LDS traffic, no waits on the pivot chain); the substitutions keep x
+//    in a VGPR per lane.  A factor/solve pair always uses the same form (the layouts in LDS differ).
+// One wave per matrix is latency-bound, so the register form is several times faster than the LDS form.
 #pragma once
 #include "dmath.h"
 #include "model.h"

@@ -2,13 +2,14 @@
 // (what MuJoCo's default solver computes inside mj_step, mjpc/trajectory.cc:158): one owner wavefront, optionally helped by
 // the candidate's helper waves for the data-parallel parts of an iteration.
 //
-// Layout of the work over the 64 lanes:
-//   * rows with a single +-1 Jacobian entry (friction loss, joint limits: [0, nsingle)) only touch the
-//     Hessian diagonal; contact rows [nsingle, nefc) go through WJ = blockdiag(W) J so that the Hessian is
-//     the plain contraction H = M + J^T (W J) over contact rows — branch-free, unrollable inner loops;
-//   * the exact line search keeps each lane's rows / contact in VGPRs for all its evaluations; one
-//     evaluation = ALU + three wave reductions;
-//   * Ma and jar are updated incrementally along the search direction.
+// Layout of the work over the 64 lanes of the owner wave:
+//   * rows with a single +-1 Jacobian entry (friction loss, joint limits: [0, nsingle)) only touch the Hessian diagonal
+//     (`sgl`); every active contact row becomes one scaled row  sum_b coef_b J[row_b]  (plus one negative row per contact in
+//     the cone zone), so that  H = M + JH+^T JH+ - JH-^T JH-  is a plain contraction over M's sparsity pattern and the
+//     gradient is its extra column (newton_fill / newton_entries);
+//   * the exact line search keeps each lane's rows / contact in VGPRs for all its evaluations; one evaluation = branch-free
+//     ALU + three wave reductions; the point alpha = 0 is analytic;
+//   * Ma and jar are updated incrementally along the search direction; the factorisation of H never leaves the registers.
 #pragma once
 #include "linalg.h"
 

@@ -87,10 +87,16 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     import torch
     dist = None
+    # rehearsal knobs for a 1-GPU box (never set by the driver): all ranks on device 0, exchange over gloo
+    rehearsal = os.environ.get("BENCH_REHEARSAL") == "1"
+    dev_index = 0 if rehearsal else local_rank
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        torch.cuda.set_device(dev_index)
+        if rehearsal:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
     from mujoco_mpc_amd.modelgen import humanoid_track, quadruped
     from mujoco_mpc_amd.planner import HipBackend
     from mujoco_mpc_amd.sharded import ShardedSampler
@@ -104,8 +110,8 @@ def main():
     dt_model = model["timestep"]
     kt = np.linspace(0.0, (H - 1) * dt_model, P)
     kv = np.zeros((P, model["nu"]))
-    be = HipBackend(model, task, max_samples=N, max_horizon=H, device=local_rank if world > 1 else 0)
-    sampler = ShardedSampler(be, rank, world, N, dist=dist, device=f"cuda:{local_rank}" if world > 1 else None)
+    be = HipBackend(model, task, max_samples=N, max_horizon=H, device=dev_index if world > 1 else 0)
+    sampler = ShardedSampler(be, rank, world, N, dist=dist, device=("cpu" if rehearsal else f"cuda:{local_rank}") if world > 1 else None)
 
     def step(i, knots):
         return sampler.plan(state=d["state"], mocap=d["mocap"], time=0.0, knot_times=kt, knot_values=knots,
@@ -128,7 +134,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else f"cuda:{local_rank}")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     nlaunch, rollout_us, total_us = be.kernel_time()

@@ -90,8 +90,18 @@ DEV void ldl_factor_regs(const double *A, int nvp, LDLRegs<N> &f) {
     double hk = a[k];
     double l = (i < k) ? hk * rk : 0.0;
     dg -= l * hk;
+    // A[i][j] -= L[k][i] * A[k][j]: broadcast row k in groups of 8 first, then the FMAs, so that the SGPR written by a
+    // v_readlane is not consumed by the very next VALU instruction (that hazard costs an s_nop per update otherwise)
 #pragma unroll
-    for (int j = 0; j < k; j++) a[j] -= l * readlane_d(a[j], k);      // A[i][j] -= L[k][i] * A[k][j]
+    for (int j0 = 0; j0 < k; j0 += 8) {
+      double sj[8];
+#pragma unroll
+      for (int q = 0; q < 8; q++) if (j0 + q < k) sj[q] = readlane_d(a[j0 + q], k);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < 8; q++) if (j0 + q < k) a[j0 + q] -= l * sj[q];
+      __builtin_amdgcn_sched_barrier(0);
+    }
     f.up[k] = l;
   }
   f.up[0] = 0.0;

@@ -518,3 +518,22 @@ def test_closed_loop_quadruped_walk_mode_transition():
     assert gait == 2                                         # automatic gait switching picked Trot (quadruped.h:100-107)
     assert res["parameters"][2] == 2.0 and res["parameters"][3] == 0.03 and res["parameters"][4] == 0.45     # trot cadence / amplitude / duty
     p.close()
+
+
+def test_multiwave_rollouts_are_bitwise_repeatable():
+    """The four wavefronts of a candidate hand-shake through LDS flags and workgroup barriers; a race would show up as run-to-run
+    differences.  40 repeats of the same plan (full-chip launch, contact-rich model) must be bit-identical."""
+    m, task, d = quadruped()
+    N, H, P = 256, 40, 3
+    kt = np.linspace(0, (H - 1) * m["timestep"], P); kv = np.random.default_rng(5).uniform(-0.2, 0.2, (P, m["nu"]))
+    be = HipBackend(m, task, max_samples=N, max_horizon=H)
+    kw = dict(state=d["state"], mocap=d["mocap"], time=0.0, knot_times=kt, knot_values=kv, interpolation=2, num_trajectory=N, horizon=H,
+              sigma=(0.08, 0.0), seed=11, stream=3)
+    first = be.plan(**kw)
+    ref_states = be.fetch_all(N, H, P)["states"]
+    assert not first["failure"].any()
+    for _ in range(40):
+        out = be.plan(**kw)
+        assert np.array_equal(out["returns"], first["returns"]) and out["winner"] == first["winner"]
+    assert np.array_equal(be.fetch_all(N, H, P)["states"], ref_states)
+    be.close()

@@ -1,0 +1,200 @@
+"""The hand-authored task generators (modelgen/tasks.py) against the reference's own MJCF files, through the MJCF subset loader.
+
+Runs only where /root/reference is mounted (this container); the GPU box skips it.  Nothing of the reference is copied: the XML is
+read in place, translated into ModelBuilder calls and the compiled arrays are compared with the generator's."""
+import os
+
+import numpy as np
+import pytest
+
+from mujoco_mpc_amd.modelgen import mjcf, tasks
+
+REF = "/root/reference/mjpc"
+pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not mounted")
+
+# spheres do not care about their frame: the hand geoms carry a zaxis in the XML that the generator drops
+_ORIENTATION_FREE = {"geom_quat": ("geom", ["hand_right", "hand_left"]), "body_iquat": ("body", ["hand_right", "hand_left"])}
+_SKIP = {"nconmax", "nefcmax", "names"}
+
+
+def _reader(p):
+    if os.path.basename(p) == "humanoid_modified.xml":       # exists upstream only as dm_control's file + this patch
+        return mjcf.read_patch_new_file(os.path.join(REF, "tasks/humanoid/humanoid.xml.patch"))
+    with open(p) as f:
+        return f.read()
+
+
+def _load(rel):
+    b, info = mjcf.parse_mjcf(os.path.join(REF, rel), reader=_reader)
+    b.opt["timestep"] = info["numeric"].get("agent_timestep", [b.opt["timestep"]])[0]     # mjpc/agent.cc: agent_timestep overrides
+    return b, info
+
+
+def _compare(m, m2, tol=1e-12):
+    bad = []
+    for k, v2 in m2.items():
+        if k in _SKIP:
+            continue
+        v = m.get(k)
+        if isinstance(v2, np.ndarray):
+            if v is None or np.shape(v) != v2.shape:
+                bad.append((k, "shape", None if v is None else np.shape(v), v2.shape)); continue
+            if v2.dtype.kind == "f":
+                d = np.abs(np.asarray(v, float) - v2)
+                if k in _ORIENTATION_FREE:
+                    kind, names = _ORIENTATION_FREE[k]
+                    for n in names:
+                        if n in m2["names"][kind]:
+                            d[m2["names"][kind][n]] = 0
+                if d.size and d.max() > tol:
+                    bad.append((k, float(d.max())))
+            elif not np.array_equal(v, v2):
+                bad.append((k, "int mismatch"))
+        elif isinstance(v2, (int, float)) and v != v2:
+            bad.append((k, v, v2))
+    return bad
+
+
+_ID_FIELDS = {"body_parentid", "body_rootid", "body_weldid", "geom_bodyid", "site_bodyid", "jnt_bodyid", "dof_bodyid"}
+_ORDER_FIELDS = {"body_jntadr", "body_dofadr", "exclude_signature"}
+
+
+def _compare_named(m, m2, tol=1e-12):
+    """like _compare for two models whose bodies / sites are declared in a different order: elements are matched by name and
+    body-id valued fields by the name they point to"""
+    bad = []
+    inv = {kind: {i: n for n, i in m["names"][kind].items()} for kind in m["names"]}
+    inv2 = {kind: {i: n for n, i in m2["names"][kind].items()} for kind in m2["names"]}
+    for prefix, kind in (("body_", "body"), ("geom_", "geom"), ("site_", "site"), ("jnt_", "joint")):
+        names = [n for n in m2["names"][kind] if n]
+        assert set(names) == set(n for n in m["names"][kind] if n), kind
+        for k, v2 in m2.items():
+            if not k.startswith(prefix) or not isinstance(v2, np.ndarray) or k in _ORDER_FIELDS:
+                continue
+            for n in names:
+                a, b_ = m[k][m["names"][kind][n]], v2[m2["names"][kind][n]]
+                if k in _ID_FIELDS:
+                    ok = inv["body"].get(int(a), "world") == inv2["body"].get(int(b_), "world")
+                elif k in _ORIENTATION_FREE and n in _ORIENTATION_FREE[k][1]:
+                    ok = True
+                else:
+                    ok = np.allclose(a, b_, atol=tol, rtol=0)
+                if not ok:
+                    bad.append((k, n))
+    for k, v2 in m2.items():
+        if isinstance(v2, np.ndarray) and k.split("_")[0] in ("dof", "actuator", "tendon", "wrap", "qpos0", "qpos") and k != "dof_bodyid":
+            if not np.allclose(m[k], v2, atol=tol, rtol=0):
+                bad.append((k,))
+    return bad
+
+
+def _terms_of(task):
+    out, p = [], 0
+    for i in range(task["num_term"]):
+        n = int(task["num_norm_parameter"][i])
+        out.append((int(task["dim_norm_residual"][i]), int(task["norm"][i]), float(task["weight"][i]), [float(x) for x in task["norm_parameter"][p:p + n]]))
+        p += n
+    return out
+
+
+def _xml_terms(info):
+    return [(d, n, w, list(prm[:tasks.NORM_NPARAM[n]])) for d, n, w, prm, _ in info["cost_terms"]]
+
+
+def test_particle_xml_matches_generator():
+    b, info = _load("test/testdata/particle_task.xml")
+    m = b.compile()
+    m2, task, d = tasks.particle()
+    # the XML walls are visual planes in a contact-disabled model and the generator leaves them out: compare per named element
+    for kind, keys in (("body", ["body_pos", "body_quat", "body_mass", "body_inertia", "body_parentid", "body_mocapid"]),
+                       ("joint", ["jnt_type", "jnt_axis", "jnt_range", "jnt_limited", "jnt_pos", "jnt_solref", "jnt_solimp"]),):
+        for name, i2 in m2["names"][kind].items():
+            i = m["names"][kind][name]
+            for k in keys:
+                assert np.allclose(m[k][i], m2[k][i2], atol=1e-14), (name, k)
+    for k in ("dof_damping", "dof_armature", "actuator_gear", "actuator_ctrlrange", "actuator_gainprm", "actuator_biasprm", "qpos0"):
+        if k in m2:
+            assert np.allclose(m[k], m2[k], atol=1e-14), k
+    assert m["timestep"] == m2["timestep"] == 0.1 and m["nq"] == 2 and m["nu"] == 2
+    assert b.opt["contact"] is False
+    assert _xml_terms(info) == _terms_of(task)
+    assert info["numeric"]["task_risk"] == [task["risk"]]
+    assert [info["numeric"]["residual_dummy1"][0], info["numeric"]["residual_dummy2"][0]] == list(task["parameters"])
+    assert info["numeric"]["sampling_spline_points"] == [d["P"]] and info["numeric"]["sampling_exploration"] == [d["sigma"][0]]
+    assert info["traces"] == [("site", "tip")]
+    home = next(k for k in info["keys"] if k["name"] == "home")
+    assert home["qpos"] == [1.0, 2.0]
+
+
+@pytest.mark.parametrize("rel, gen, params", [("tasks/humanoid/stand/task.xml", tasks.humanoid_stand, ["residual_Height Goal"]),
+                                              ("tasks/humanoid/walk/task.xml", tasks.humanoid_walk, ["residual_Torso", "residual_Speed"])])
+def test_humanoid_stand_walk_xml_match_generators(rel, gen, params):
+    b, info = _load(rel)
+    m = b.compile()
+    m2, task, d = gen()
+    assert _compare(m, m2) == []
+    assert m["names"]["body"] == m2["names"]["body"] and m["names"]["site"] == m2["names"]["site"]
+    assert _xml_terms(info) == _terms_of(task)
+    assert [info["numeric"][p][0] for p in params] == list(task["parameters"])
+    assert info["numeric"]["sampling_spline_points"] == [d["P"]] and info["numeric"]["sampling_exploration"] == [d["sigma"][0]]
+    assert round(info["numeric"]["agent_horizon"][0] / m["timestep"]) + 1 >= d["horizon"] - 1
+    assert info["traces"] == [("body", "torso")]
+
+
+def test_humanoid_tracking_xml_matches_generator_and_keyframes():
+    b, info = _load("tasks/humanoid/tracking/task.xml")
+    m = b.compile()
+    m2, task, d = tasks.humanoid_track()
+    # the XML declares the mocap bodies after the humanoid, the generator before it: match by name
+    assert _compare_named(m, m2) == []
+    for k in ("nq", "nv", "nu", "nbody", "ngeom", "nsite", "nmocap", "ntendon", "nexclude", "timestep", "cone", "impratio", "meaninertia"):
+        assert m[k] == pytest.approx(m2[k], abs=1e-12), k
+    mocap_order = lambda mm: [n for n, i in sorted(mm["names"]["body"].items(), key=lambda kv: kv[1]) if mm["body_mocapid"][i] >= 0]
+    assert mocap_order(m) == mocap_order(m2)            # the mocap_pos layout the keyframe table indexes
+    assert _xml_terms(info) == _terms_of(task)
+    assert info["numeric"]["sampling_spline_points"] == [d["P"]] and info["numeric"]["sampling_exploration"] == [d["sigma"][0]]
+    assert info["numeric"]["sampling_trajectories"] == [d["N"]]
+    # motion 0 ("Jump") = the first included keyframe file: the packed table in modelgen/data is those keys
+    jump = [k for k in info["keys"] if k["name"].startswith("jump_")]
+    nkey = int(task["int_data"][2])
+    assert len(jump) == nkey
+    mpos = np.array([k["mpos"] for k in jump])
+    table = np.asarray(m2["key_mpos"]).reshape(nkey, -1)
+    assert np.array_equal(mpos, table)
+    assert np.allclose(jump[0]["qpos"], d["state"][:m2["nq"]], atol=0)
+
+
+def _residual_parameters(info):
+    """mjpc/task.cc:181-200: numerics named residual_* in file order; residual_select_* carry the int bit-cast into the double"""
+    out = []
+    for name, v in info["numeric"].items():
+        if name.startswith("residual_select_"):
+            out.append(tasks.select_value(int(v[0])))
+        elif name.startswith("residual_"):
+            out.append(v[0])
+    return out
+
+
+@pytest.mark.parametrize("rel, missing, gen", [("tasks/cartpole/task.xml", "cartpole_modified.xml", tasks.cartpole),
+                                               ("tasks/quadruped/task_flat.xml", "a1_modified.xml", tasks.quadruped)])
+def test_task_tables_of_models_that_need_the_zoo(rel, missing, gen):
+    """cartpole / A1 model files exist upstream only as patches against dm_control / menagerie (absent here); their task files are
+    complete, so the cost table, residual parameters, planner numerics, keyframes and mocap bodies are checked"""
+    b, info = mjcf.parse_mjcf(os.path.join(REF, rel), missing_ok=(missing,))
+    m2, task, d = gen()
+    assert _xml_terms(info) == _terms_of(task)
+    got, want = _residual_parameters(info), list(task["parameters"])
+    assert np.array(got).tobytes() == np.array(want).tobytes()             # bitwise: the select values are not ordinary doubles
+    assert info["numeric"]["agent_timestep"] == [m2["timestep"]]
+    assert info["numeric"]["sampling_spline_points"] == [d["P"]] and info["numeric"]["sampling_exploration"] == [d["sigma"][0]]
+    if "sampling_trajectories" in info["numeric"]:
+        assert info["numeric"]["sampling_trajectories"] == [d["N"]]
+    assert round(info["numeric"]["agent_horizon"][0] / m2["timestep"]) + 1 == d["horizon"]
+    assert info["traces"] == [("site", {"tasks/cartpole/task.xml": "tip", "tasks/quadruped/task_flat.xml": "head"}[rel])]
+    home = next(k for k in info["keys"] if k["name"] == "home")
+    assert np.array_equal(home["qpos"], d["state"][:m2["nq"]])
+    # mocap bodies declared by the task file itself (quadruped: goal, box) sit at the generator's default mocap poses
+    for body in b.bodies[1:]:
+        if body.mocap and body.name in m2["names"]["body"]:
+            mid = int(m2["body_mocapid"][m2["names"]["body"][body.name]])
+            assert np.allclose(d["mocap"][7 * mid:7 * mid + 3], body.pos, atol=0), body.name

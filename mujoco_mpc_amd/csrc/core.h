@@ -329,7 +329,7 @@ DEV void crb_and_factor(Ctx &c) {
   }
   SYNC();
   PFOR(e, nv * nvp) c.qL[e] = c.qM[e];
-  chol_factor<NVT>(c.qL, c.Linv, c.vtmp, nv, nvp);
+  chol_factor<NVT>(c.qL, c.Linv, c.vtmp, nv, nvp, c.M->tree_ok);
 }
 
 // ======================================================================================
@@ -748,7 +748,7 @@ DEV void make_contact_rows(Ctx &c, int n_nc) {
       int pyr = (cdim > 1 && M.cone != 1);
       for (int k = 0; k < dim; k++) {
         c.efc_type[r0 + k] = cdim == 1 ? CNSTR_CONTACT_FRICTIONLESS : (pyr ? CNSTR_CONTACT_PYRAMIDAL : CNSTR_CONTACT_ELLIPTIC);
-        c.efc_id[r0 + k] = ci;
+        c.efc_id[r0 + k] = EFC_CON_ID(ci, cdim, r0);      // contact id, its dim and first row in one word: no dependent con_i hop later
         c.efc_floss[r0 + k] = 0; c.efc_pos[r0 + k] = cc[CON_DIST]; c.efc_margin[r0 + k] = cc[CON_INCLUDEMARGIN];
         if (pyr) { double mu = cc[CON_FRICTION + k / 2]; c.efc_diag[r0 + k] = tran + mu * mu * (k < 4 ? tran : rot); }
         else c.efc_diag[r0 + k] = k < 3 ? tran : rot;
@@ -838,10 +838,10 @@ DEV void make_impedance(Ctx &c, int r0, int r1, int with_contacts) {
       for (int k = 0; k < 2; k++) solref[k] = MD(tendon_solref_lim)[2 * id + k];
       for (int k = 0; k < 5; k++) solimp[k] = MD(tendon_solimp_lim)[5 * id + k];
     } else {
-      const double *cc = c.contact + id * c.M->con_stride;
+      const double *cc = c.contact + EFC_CON_CI(id) * c.M->con_stride;
       for (int k = 0; k < 2; k++) solref[k] = cc[CON_SOLREF + k];
       for (int k = 0; k < 5; k++) solimp[k] = cc[CON_SOLIMP + k];
-      first = (r == c.con_i[id * CONI_STRIDE + 3]) || type == CNSTR_CONTACT_PYRAMIDAL;
+      first = (r == EFC_CON_R0(id)) || type == CNSTR_CONTACT_PYRAMIDAL;
     }
     double imp = impedance(solimp, c.efc_pos[r], c.efc_margin[r]);
     double dmax = d_clip(solimp[1], 0.0001, 0.9999);
@@ -1007,7 +1007,7 @@ DEV void velocity_stage(Ctx &c, int mfact_seq) {
   }
   PFOR(d, nv) c.qacc_smooth[d] = c.qfrc_smooth[d];
   if (mfact_seq && !flag_wait(c.misc + 22, mfact_seq)) c.warning |= WARN_SYNC;
-  chol_solve<NVT>(c.qL, c.Linv, c.qacc_smooth, nv, M.nvp);
+  chol_solve<NVT>(c.qL, c.Linv, c.qacc_smooth, nv, M.nvp, M.tree_ok);
 }
 
 #include "solver.h"
@@ -1653,7 +1653,7 @@ DEV_NOINLINE void ph_prefactor(KP Kc) {
     int nv = M.nv, nvp = M.nvp;
     double h = M.timestep;
     PFOR(e, nv * nvp) { int i = e / nvp, j = e - i * nvp; c.qL[e] = c.qM[e] + ((i == j) ? h * MD(dof_damping)[i] : 0.0); }
-    chol_factor<NVT>(c.qL, c.Linv, c.cfrc, nv, nvp);
+    chol_factor<NVT>(c.qL, c.Linv, c.cfrc, nv, nvp, c.M->tree_ok);
   }
   ctx_close(c);
 }
@@ -1670,7 +1670,7 @@ DEV_NOINLINE void ph_integrate(KP Kc, int t) {
   PFOR(i, nv) c.qacc_ws[i] = c.qacc[i];
   if (M.any_damping) {
     PFOR(i, nv) c.Mgrad[i] = c.qfrc_smooth[i] + c.qfrc_constraint[i];
-    chol_solve<NVT>(c.qL, c.Linv, c.Mgrad, nv, nvp);       // factor of M + h*B from ph_prefactor
+    chol_solve<NVT>(c.qL, c.Linv, c.Mgrad, nv, nvp, c.M->tree_ok);       // factor of M + h*B from ph_prefactor
     PFOR(i, nv) c.qvel[i] += h * c.Mgrad[i];
   } else {
     PFOR(i, nv) c.qvel[i] += h * c.qacc[i];

@@ -71,6 +71,7 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
   M.con_stride = (m->cone == MJPC_CONE_ELLIPTIC) ? CON_STRIDE_ELLIPTIC : CON_STRIDE_PLAIN;
   M.maxdim = 1;
   for (int g = 0; g < ng; g++) if (m->geom_condim[g] > M.maxdim) M.maxdim = m->geom_condim[g];
+  M.tree_ok = (nv == 18 && dof_tree_matches<18>(m->dof_parentid)) || (nv == 27 && dof_tree_matches<27>(m->dof_parentid));
   M.nconmax = m->nconmax > 0 ? m->nconmax : 32;
   if (M.nconmax > 64) M.nconmax = 64;
   M.nefcmax = m->nefcmax > 0 ? m->nefcmax : 128;

@@ -7,6 +7,7 @@
 //    in a VGPR per lane.  A factor/solve pair always uses the same form (the layouts in LDS differ).
 // One wave per matrix is latency-bound, so the register form is several times faster than the LDS form.
 #pragma once
+#include <type_traits>
 #include "dmath.h"
 #include "model.h"
 
@@ -84,9 +85,7 @@ DEV void ldl_factor_regs(const double *A, int nvp, LDLRegs<N> &f) {
   double dg = act ? A[i * nvp + i] : 1.0;
 #pragma unroll
   for (int k = N - 1; k >= 1; k--) {
-    double dk = readlane_d(dg, k);
-    if (dk < D_MINVAL) dk = D_MINVAL;
-    double rk = fast_rcp(dk);
+    double rk = readlane_d(fast_rcp(dg < D_MINVAL ? D_MINVAL : dg), k);      // reciprocal in the vector domain, then broadcast
     double hk = a[k];
     double l = (i < k) ? hk * rk : 0.0;
     dg -= l * hk;
@@ -119,12 +118,129 @@ DEV double ldl_solve_regs(const LDLRegs<N> &f, double xi) {
   for (int j = 0; j < N - 1; j++) xi -= f.lo[j] * readlane_d(xi, j);       // L x = v
   return xi;
 }
+// ---- tree-structured elimination (DofTree<N>::known, DevModel::tree_ok) ----------------------------------------------
+// Same L^T D L, same per-entry arithmetic, but (a) the pivots of one tree level (same height above the leaves: never
+// related to each other) are processed together, so their reciprocal chains and trailing updates are independent work
+// the scheduler interleaves, and (b) only the ancestors of a pivot are updated: the other columns of M's pattern are
+// structural zeros.  Cross-branch contacts break the pattern of H; the caller then asks for the dense order.
+template <int I, int E, class F>
+DEV void static_for(F &&f) {
+  if constexpr (I < E) { f(std::integral_constant<int, I>{}); static_for<I + 1, E>(f); }
+}
+template <int N> constexpr int tree_depth(int k) { int d = 0; for (int a = DofTree<N>::parent(k); a >= 0; a = DofTree<N>::parent(a)) d++; return d; }
+template <int N> constexpr int tree_nth_anc(int k, int n) { int a = DofTree<N>::parent(k); for (int q = 0; q < n; q++) a = DofTree<N>::parent(a); return a; }
+template <int N> constexpr int tree_height(int k) {
+  int h = 0;
+  for (int c = k + 1; c < N; c++) if (DofTree<N>::parent(c) == k) { int hc = tree_height<N>(c) + 1; if (hc > h) h = hc; }
+  return h;
+}
+template <int N> constexpr int tree_nlevel() { return tree_height<N>(0) + 1; }
+// (pivot, ancestor) pairs of one level, pivots in descending order
+template <int N> constexpr int tree_level_npair(int H) { int n = 0; for (int k = N - 1; k >= 1; k--) if (tree_height<N>(k) == H) n += tree_depth<N>(k); return n; }
+template <int N> constexpr int tree_level_pair(int H, int e, bool pivot) {
+  for (int k = N - 1; k >= 1; k--) if (tree_height<N>(k) == H) {
+    int d = tree_depth<N>(k);
+    if (e < d) return pivot ? k : tree_nth_anc<N>(k, e);
+    e -= d;
+  }
+  return 0;
+}
+#ifndef MJPC_TREE_CHUNK
+#define MJPC_TREE_CHUNK 8
+#endif
+#ifdef MJPC_TREE_NOBAR
+#define TREE_BAR() ((void)0)
+#else
+#define TREE_BAR() __builtin_amdgcn_sched_barrier(0)
+#endif
+template <int N>
+DEV void ldl_factor_tree(const double *A, int nvp, LDLRegs<N> &f) {
+  static_assert(DofTree<N>::known && N <= 64, "one matrix row per lane");
+  const int i = LANE;
+  const bool act = i < N;
+  double a[N];
+#pragma unroll
+  for (int j = 0; j < N; j++) a[j] = act ? A[(j <= i) ? i * nvp + j : j * nvp + i] : 0.0;
+  double dg = act ? A[i * nvp + i] : 1.0;
+  static_for<0, tree_nlevel<N>()>([&](auto hc) {
+    constexpr int H = decltype(hc)::value;
+    // 1/d in the vector domain (every lane inverts its own diagonal: one reciprocal chain per LEVEL, no scalar clamp
+    // round trip), then the pivots' reciprocals are broadcast
+    const double rv = fast_rcp(dg < D_MINVAL ? D_MINVAL : dg);
+    static_for<1, N>([&](auto kc) {
+      constexpr int k = N - decltype(kc)::value;
+      if constexpr (tree_height<N>(k) == H) f.up[k] = readlane_d(rv, k);
+    });
+    static_for<1, N>([&](auto kc) {                       // l = L[k][i] on the ancestors of k, diagonal update
+      constexpr int k = N - decltype(kc)::value;
+      if constexpr (tree_height<N>(k) == H) {
+        double hk = a[k];
+        double l = (i < k) ? hk * f.up[k] : 0.0;
+        dg -= l * hk;
+        f.up[k] = l;
+      }
+    });
+    constexpr int NP = tree_level_npair<N>(H);            // A[i][j] -= L[k][i] * A[k][j], j ancestor of k
+    static_for<0, (NP + MJPC_TREE_CHUNK - 1) / MJPC_TREE_CHUNK>([&](auto gc) {
+      constexpr int e0 = decltype(gc)::value * MJPC_TREE_CHUNK;
+      double sj[MJPC_TREE_CHUNK];
+      static_for<0, MJPC_TREE_CHUNK>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        if constexpr (e0 + q < NP) {
+          constexpr int j = tree_level_pair<N>(H, e0 + q, false), k = tree_level_pair<N>(H, e0 + q, true);
+          sj[q] = readlane_d(a[j], k);
+        }
+      });
+      TREE_BAR();
+      static_for<0, MJPC_TREE_CHUNK>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        if constexpr (e0 + q < NP) {
+          constexpr int j = tree_level_pair<N>(H, e0 + q, false), k = tree_level_pair<N>(H, e0 + q, true);
+          a[j] -= f.up[k] * sj[q];
+        }
+      });
+      TREE_BAR();
+    });
+  });
+  f.up[0] = 0.0;
+  if (dg < D_MINVAL) dg = D_MINVAL;
+  f.rinv = fast_rcp(dg);
+#pragma unroll
+  for (int j = 0; j < N; j++) f.lo[j] = (act && j < i) ? a[j] * f.rinv : 0.0;
+}
+template <int N>
+DEV double ldl_solve_tree(const LDLRegs<N> &f, double xi) {
+  static_for<0, tree_nlevel<N>()>([&](auto hc) {          // L^T u = b, leaves first
+    constexpr int H = decltype(hc)::value;
+    double s[N];
+    static_for<1, N>([&](auto kc) { constexpr int k = N - decltype(kc)::value; if constexpr (tree_height<N>(k) == H) s[k] = readlane_d(xi, k); });
+    static_for<1, N>([&](auto kc) { constexpr int k = N - decltype(kc)::value; if constexpr (tree_height<N>(k) == H) xi -= f.up[k] * s[k]; });
+  });
+  xi *= f.rinv;                                           // D v = u
+  static_for<1, tree_nlevel<N>()>([&](auto hc) {          // L x = v, root first (leaves have no descendants)
+    constexpr int H = tree_nlevel<N>() - decltype(hc)::value;
+    double s[N];
+    static_for<0, N>([&](auto jc) { constexpr int j = decltype(jc)::value; if constexpr (tree_height<N>(j) == H) s[j] = readlane_d(xi, j); });
+    static_for<0, N>([&](auto jc) { constexpr int j = decltype(jc)::value; if constexpr (tree_height<N>(j) == H) xi -= f.lo[j] * s[j]; });
+  });
+  return xi;
+}
+template <int N>
+DEV void ldl_factor_any(const double *A, int nvp, LDLRegs<N> &f, int tree) {
+  if constexpr (DofTree<N>::known) { if (tree) { ldl_factor_tree<N>(A, nvp, f); return; } }
+  ldl_factor_regs<N>(A, nvp, f);
+}
+template <int N>
+DEV double ldl_solve_any(const LDLRegs<N> &f, double xi, int tree) {
+  if constexpr (DofTree<N>::known) { if (tree) return ldl_solve_tree<N>(f, xi); }
+  return ldl_solve_regs<N>(f, xi);
+}
 // split form (factor kept in LDS between phases): L[i][j] (j < i) in the lower triangle of A, 1/d in Dinv
 template <int N>
-DEV void chol_factor_reg(double *A, double *Dinv, int nvp) {
+DEV void chol_factor_reg(double *A, double *Dinv, int nvp, int tree) {
   SYNC();
   LDLRegs<N> f;
-  ldl_factor_regs<N>(A, nvp, f);
+  ldl_factor_any<N>(A, nvp, f, tree);
   const int i = LANE;
 #pragma unroll
   for (int j = 0; j < N; j++) if (i < N && j < i) A[i * nvp + j] = f.lo[j];
@@ -132,7 +248,7 @@ DEV void chol_factor_reg(double *A, double *Dinv, int nvp) {
   SYNC();
 }
 template <int N>
-DEV void chol_solve_reg(const double *L, const double *Dinv, double *x, int nvp) {
+DEV void chol_solve_reg(const double *L, const double *Dinv, double *x, int nvp, int tree) {
   SYNC();
   const int i = LANE;
   const bool act = i < N;
@@ -143,42 +259,43 @@ DEV void chol_solve_reg(const double *L, const double *Dinv, double *x, int nvp)
     f.lo[k] = (act && k < i) ? L[i * nvp + k] : 0.0;
     f.up[k] = (act && k > i) ? L[k * nvp + i] : 0.0;
   }
-  double xi = ldl_solve_regs<N>(f, act ? x[i] : 0.0);
+  double xi = ldl_solve_any<N>(f, act ? x[i] : 0.0, tree);
   if (act) x[i] = xi;
   SYNC();
 }
 // fused factor + solve (the factor never leaves the registers): Newton direction, implicit-damping solve
 template <int N>
-DEV void chol_factor_solve_reg(const double *A, double *x, int nvp) {
+DEV void chol_factor_solve_reg(const double *A, double *x, int nvp, int tree) {
   SYNC();
   LDLRegs<N> f;
-  ldl_factor_regs<N>(A, nvp, f);
+  ldl_factor_any<N>(A, nvp, f, tree);
   const int i = LANE;
-  double xi = ldl_solve_regs<N>(f, i < N ? x[i] : 0.0);
+  double xi = ldl_solve_any<N>(f, i < N ? x[i] : 0.0, tree);
   if (i < N) x[i] = xi;
   SYNC();
 }
 #endif
 
+// `tree`: the matrix has the sparsity pattern of M and the model's dof tree is DofTree<NVT> (DevModel::tree_ok)
 template <int NVT>
-DEV void chol_factor(double *A, double *Linv, double *tmp, int n, int nvp) {
+DEV void chol_factor(double *A, double *Linv, double *tmp, int n, int nvp, int tree) {
 #ifndef MJPC_EMU
-  if constexpr (NVT > 0) { chol_factor_reg<NVT>(A, Linv, NVP_OF(NVT)); return; }
+  if constexpr (NVT > 0) { chol_factor_reg<NVT>(A, Linv, NVP_OF(NVT), tree); return; }
 #endif
   chol_factor_lds(A, Linv, tmp, n, nvp);
 }
 template <int NVT>
-DEV void chol_solve(const double *L, const double *Linv, double *x, int n, int nvp) {
+DEV void chol_solve(const double *L, const double *Linv, double *x, int n, int nvp, int tree) {
 #ifndef MJPC_EMU
-  if constexpr (NVT > 0) { chol_solve_reg<NVT>(L, Linv, x, NVP_OF(NVT)); return; }
+  if constexpr (NVT > 0) { chol_solve_reg<NVT>(L, Linv, x, NVP_OF(NVT), tree); return; }
 #endif
   chol_solve_lds(L, Linv, x, n, nvp);
 }
 // A (lower triangle) is consumed; x <- A^-1 x.  The generic build leaves the LL^T factor in A / Linv.
 template <int NVT>
-DEV void chol_factor_solve(double *A, double *Linv, double *tmp, double *x, int n, int nvp) {
+DEV void chol_factor_solve(double *A, double *Linv, double *tmp, double *x, int n, int nvp, int tree) {
 #ifndef MJPC_EMU
-  if constexpr (NVT > 0) { chol_factor_solve_reg<NVT>(A, x, NVP_OF(NVT)); return; }
+  if constexpr (NVT > 0) { chol_factor_solve_reg<NVT>(A, x, NVP_OF(NVT), tree); return; }
 #endif
   chol_factor_lds(A, Linv, tmp, n, nvp);
   chol_solve_lds(A, Linv, x, n, nvp);

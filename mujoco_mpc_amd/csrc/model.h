@@ -23,6 +23,32 @@
 #define CON_H 27
 #define CONI_STRIDE 4          // ints per contact: dim, geom1, geom2, efc_address
 #define MAX_ACTIVE_PAIRS 192
+// efc_id of a contact row: contact index | contact dim << 8 | first row of the contact << 16
+#define EFC_CON_ID(ci, dim, r0) ((ci) | ((dim) << 8) | ((r0) << 16))
+#define EFC_CON_CI(id) ((id) & 255)
+#define EFC_CON_DIM(id) (((id) >> 8) & 255)
+#define EFC_CON_R0(id) ((id) >> 16)
+
+// Dof-tree topologies known at compile time, keyed by nv.  When the model's dof_parentid equals the table (DevModel::tree_ok,
+// checked on the host) the register L^T D L factorisations eliminate the independent branches of one tree level together and
+// skip the structural zeros of M's pattern; any other tree of the same nv uses the dense elimination order.
+template <int N> struct DofTree { static constexpr bool known = false; static constexpr int parent(int) { return -1; } };
+template <> struct DofTree<18> {      // floating base + 4 chains of 3 (quadruped)
+  static constexpr bool known = true;
+  static constexpr int parent(int k) { constexpr int p[18] = {-1, 0, 1, 2, 3, 4, 5, 6, 7, 5, 9, 10, 5, 12, 13, 5, 15, 16}; return p[k]; }
+};
+template <> struct DofTree<27> {      // floating base + 3-dof waist carrying two 6-dof legs, two 3-dof arms on the base (humanoid)
+  static constexpr bool known = true;
+  static constexpr int parent(int k) {
+    constexpr int p[27] = {-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 8, 15, 16, 17, 18, 19, 5, 21, 22, 5, 24, 25};
+    return p[k];
+  }
+};
+template <int N> constexpr bool dof_tree_matches(const int *dof_parentid) {
+  if (!DofTree<N>::known) return false;
+  for (int k = 0; k < N; k++) if (dof_parentid[k] != DofTree<N>::parent(k)) return false;
+  return true;
+}
 
 enum { CNSTR_FRICTION_DOF = 1, CNSTR_LIMIT_JOINT = 3, CNSTR_LIMIT_TENDON = 4, CNSTR_CONTACT_FRICTIONLESS = 5, CNSTR_CONTACT_PYRAMIDAL = 6, CNSTR_CONTACT_ELLIPTIC = 7 };
 enum { STATE_SATISFIED = 0, STATE_QUADRATIC = 1, STATE_LINEARNEG = 2, STATE_LINEARPOS = 3, STATE_CONE = 4 };
@@ -38,7 +64,7 @@ struct DevTask {
 struct DevModel {
   int nq, nv, nu, nbody, njnt, ngeom, nsite, nmocap, nkey, nvp, ntendon;
   int nlevel, npair, nfric, nlimit, nray, nmpair, nzpair, nconmax, nefcmax, any_damping;
-  int cone, iterations, ls_iterations, disableflags, con_stride, maxdim;
+  int cone, iterations, ls_iterations, disableflags, con_stride, maxdim, tree_ok;
   double timestep, gravity[3], impratio, tolerance, ls_tolerance, meaninertia;
   const int *body_parentid, *body_rootid, *body_mocapid, *body_jntnum, *body_jntadr, *body_dofnum, *body_dofadr;
   const double *body_pos, *body_quat, *body_ipos, *body_iquat, *body_mass, *body_subtreemass, *body_inertia, *body_invweight0;

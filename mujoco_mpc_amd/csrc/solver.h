@@ -26,43 +26,92 @@
 template <int DIMT, bool WRITE = true>
 DEV double constraint_update(Ctx &c, int hess, const double *jar) {
   double cost = 0;
-  PFOR(i, c.nefc) {
-    int type = c.efc_type[i];
-    if (type == CNSTR_CONTACT_ELLIPTIC) continue;
-    // branch-free row cost (see the line search): xc = clamp(x, lo, hi), s = 1/2 D xc^2 + F (|x| - |xc|), force = -D xc
-    double D = c.efc_D[i], x = jar[i];
+  const int nefc = c.nefc, ncon = c.ncon, nv = c.M->nv, nvp = c.M->nvp, stride = c.M->con_stride;
+  const int nslot = (nefc + NLANE - 1) / NLANE, ncslot = (ncon + NLANE - 1) / NLANE;
+  // All loads first (two dependent levels: row tables / contact header, then the entries they point to), then the
+  // arithmetic, then the stores: the LDS latencies overlap instead of chaining through divergent branches.  Indices of
+  // lanes without a row / contact are clamped and their results discarded by selects.
+  int rtype[LS_RPL], rdof[LS_RPL];
+  double rD[LS_RPL], rx[LS_RPL], rfl[LS_RPL], rR[LS_RPL], rJ[LS_RPL];
+  int cdim[LS_CPL], crow[LS_CPL], ctype[LS_CPL];
+  double cmu[LS_CPL], cfr[LS_CPL][DIMT], cX[LS_CPL][DIMT], cD[LS_CPL][DIMT];
+#pragma unroll
+  for (int k = 0; k < LS_RPL; k++) {
+    if (k >= nslot) break;
+    int i = LANE + NLANE * k, ic = i < nefc ? i : nefc - 1;
+    rtype[k] = c.efc_type[ic]; rD[k] = c.efc_D[ic]; rx[k] = jar[ic]; rfl[k] = c.efc_floss[ic]; rR[k] = c.efc_R[ic];
+    rdof[k] = c.efc_dof[ic];
+  }
+#pragma unroll
+  for (int q = 0; q < LS_CPL; q++) {
+    if (q >= ncslot) break;
+    int ci = LANE + NLANE * q, cic = ci < ncon ? ci : ncon - 1;
+    cdim[q] = c.con_i[cic * CONI_STRIDE]; crow[q] = c.con_i[cic * CONI_STRIDE + 3];
+  }
+#pragma unroll
+  for (int k = 0; k < LS_RPL; k++) {
+    if (k >= nslot) break;
+    int i = LANE + NLANE * k, ic = i < nefc ? i : nefc - 1;
+    rJ[k] = (WRITE && ic < c.nsingle) ? c.efc_J[ic * nvp + rdof[k]] : 0.0;
+  }
+#pragma unroll
+  for (int q = 0; q < LS_CPL; q++) {
+    if (q >= ncslot) break;
+    int ci = LANE + NLANE * q, cic = ci < ncon ? ci : ncon - 1;
+    int i = crow[q];
+    const double *cc = c.contact + cic * stride;
+    ctype[q] = c.efc_type[i];
+    cmu[q] = cc[CON_MU];
+#pragma unroll
+    for (int j = 0; j < DIMT; j++) {
+      int rj = i + j < nefc ? i + j : nefc - 1;
+      cfr[q][j] = j == 0 ? cmu[q] : cc[CON_FRICTION + j - 1];
+      cX[q][j] = jar[rj]; cD[q][j] = c.efc_D[rj];
+    }
+  }
+  // rows: branch-free cost (see the line search): xc = clamp(x, lo, hi), s = 1/2 D xc^2 + F (|x| - |xc|), force = -D xc
+#pragma unroll
+  for (int k = 0; k < LS_RPL; k++) {
+    if (k >= nslot) break;
+    int i = LANE + NLANE * k;
+    int type = rtype[k];
+    int act = i < nefc && type != CNSTR_CONTACT_ELLIPTIC;
+    double D = rD[k], x = rx[k];
     int fric = type == CNSTR_FRICTION_DOF;
-    double f = fric ? c.efc_floss[i] : 0.0, Rf = c.efc_R[i] * f;
+    double f = fric ? rfl[k] : 0.0, Rf = rR[k] * f;
     double lo = fric ? -Rf : -1e300, hi = fric ? Rf : 0.0;
     double xc = fmin(fmax(x, lo), hi);
     int inside = x > lo && x < hi;
-    cost += 0.5 * D * xc * xc + f * (fabs(x) - fabs(xc));
-    if (!WRITE) continue;
-    double force = fric ? (inside ? -D * x : (x <= lo ? f : -f)) : -D * xc;
-    c.efc_force[i] = force;
-    c.efc_state[i] = inside ? STATE_QUADRATIC : (fric ? (x <= lo ? STATE_LINEARNEG : STATE_LINEARPOS) : STATE_SATISFIED);
-    if (i < c.nsingle) {
-      // rows with one +-1 Jacobian entry: fold J^T force and the Hessian diagonal per dof
-      // (slot 0/1: friction loss, slot 2/3: joint limit; at most one active row of each kind per dof)
-      int d = c.efc_dof[i], k = fric ? 0 : 2;
-      int nv = c.M->nv;
-      c.sgl[k * nv + d] = c.efc_J[i * c.M->nvp + d] * force;
-      c.sgl[(k + 1) * nv + d] = inside ? D : 0.0;
+    double s = 0.5 * D * xc * xc + f * (fabs(x) - fabs(xc));
+    cost += act ? s : 0.0;
+    if (WRITE && act) {
+      double force = fric ? (inside ? -D * x : (x <= lo ? f : -f)) : -D * xc;
+      c.efc_force[i] = force;
+      c.efc_state[i] = inside ? STATE_QUADRATIC : (fric ? (x <= lo ? STATE_LINEARNEG : STATE_LINEARPOS) : STATE_SATISFIED);
+      if (i < c.nsingle) {
+        // rows with one +-1 Jacobian entry: fold J^T force and the Hessian diagonal per dof
+        // (slot 0/1: friction loss, slot 2/3: joint limit; at most one active row of each kind per dof)
+        int d = rdof[k], kk = fric ? 0 : 2;
+        c.sgl[kk * nv + d] = rJ[k] * force;
+        c.sgl[(kk + 1) * nv + d] = inside ? D : 0.0;
+      }
     }
   }
-  PFOR(ci, c.ncon) {
-    int dim = c.con_i[ci * CONI_STRIDE];
-    int i = c.con_i[ci * CONI_STRIDE + 3];
-    if (dim <= 1 || c.efc_type[i] != CNSTR_CONTACT_ELLIPTIC) continue;     // pyramidal edges are plain unilateral rows
-    double *cc = c.contact + ci * c.M->con_stride;
-    double mu = cc[CON_MU], U[DIMT], fr[DIMT], X[DIMT], Dj[DIMT], F[DIMT];
+#pragma unroll
+  for (int q = 0; q < LS_CPL; q++) {
+    if (q >= ncslot) break;
+    int ci = LANE + NLANE * q;
+    int dim = cdim[q], i = crow[q];
+    if (ci >= ncon || dim <= 1 || ctype[q] != CNSTR_CONTACT_ELLIPTIC) continue;     // pyramidal edges are plain unilateral rows
+    double *cc = c.contact + ci * stride;
+    double mu = cmu[q], U[DIMT], fr[DIMT], X[DIMT], Dj[DIMT], F[DIMT];
     fr[0] = mu;
 #pragma unroll
-    for (int j = 1; j < DIMT; j++) fr[j] = j < dim ? cc[CON_FRICTION + j - 1] : 0;
+    for (int j = 1; j < DIMT; j++) fr[j] = j < dim ? cfr[q][j] : 0;
     double T2 = 0;
 #pragma unroll
     for (int j = 0; j < DIMT; j++) {
-      X[j] = j < dim ? jar[i + j] : 0; Dj[j] = j < dim ? c.efc_D[i + j] : 0;
+      X[j] = j < dim ? cX[q][j] : 0; Dj[j] = j < dim ? cD[q][j] : 0;
       U[j] = X[j] * fr[j]; F[j] = 0;
       if (j > 0) T2 += U[j] * U[j];
     }
@@ -191,9 +240,10 @@ DEV void newton_lists(Ctx &c, int *npos_out, int *nneg_out) {
   int npos = 0, nneg = 0;
   for (int base = 0; base < ncrow; base += NLANE) {
     int rr = base + LANE, r = ns + rr;
-    int st = (rr < ncrow) ? c.efc_state[r] : STATE_SATISFIED;
-    int fpos = st != STATE_SATISFIED, fneg = 0;
-    if (st == STATE_CONE) fneg = c.con_i[c.efc_id[r] * CONI_STRIDE + 3] == r;
+    int rc = rr < ncrow ? r : ns;
+    int st = c.efc_state[rc], id = c.efc_id[rc];
+    st = (rr < ncrow) ? st : STATE_SATISFIED;
+    int fpos = st != STATE_SATISFIED, fneg = st == STATE_CONE && EFC_CON_R0(id) == r;
     int tp, tn;
     int op = wave_flag_scan(fpos, &tp), on = wave_flag_scan(fneg, &tn);
     if (fpos) c.active[npos + op] = r;
@@ -224,11 +274,10 @@ DEV void newton_fill_d(Ctx &c, int npos, int nneg) {
     int valid = neg ? (e - npos8 < nneg) : (e < npos);
     int r = valid ? (neg ? c.active[negbase + e - npos8] : c.active[e]) : c.nsingle;
     if (r >= c.nefc) r = c.nefc - 1;
-    int st = c.efc_state[r], type = c.efc_type[r];
+    int st = c.efc_state[r], type = c.efc_type[r], id = c.efc_id[r];
     double D = c.efc_D[r], jr = c.efc_jar[r];
     int is_con = type >= CNSTR_CONTACT_FRICTIONLESS;
-    int ci = is_con ? c.efc_id[r] : 0;
-    int dim = c.con_i[ci * CONI_STRIDE], r0 = c.con_i[ci * CONI_STRIDE + 3];
+    int ci = is_con ? EFC_CON_CI(id) : 0, dim = is_con ? EFC_CON_DIM(id) : 1, r0 = is_con ? EFC_CON_R0(id) : r;
     const double *cf = c.contact + ci * M.con_stride + (M.con_stride > CON_H ? CON_H : 0);
     double cp[DIMT], cq[DIMT], ct[DIMT];
 #pragma unroll
@@ -252,16 +301,20 @@ DEV void newton_fill_d(Ctx &c, int npos, int nneg) {
     if constexpr (NVT > 0) {
       constexpr int NC = C1 - C0;
       double acc[NC > 0 ? NC : 1];
-      { const double *Jr = c.efc_J + rowb[0] + C0;
+      // all the Jacobian rows of the combination are fetched before the first use (unused slots: coefficient 0 on a valid row)
+      double Jv[DIMT][NC > 0 ? NC : 1];
 #pragma unroll
-        for (int j = 0; j < NC; j++) acc[j] = coef[0] * Jr[j]; }
-#pragma unroll
-      for (int b = 1; b < DIMT; b++) {
-        if (!wave_any(nb > b)) break;
+      for (int b = 0; b < DIMT; b++) {
         const double *Jr = c.efc_J + rowb[b] + C0;
 #pragma unroll
-        for (int j = 0; j < NC; j++) acc[j] += coef[b] * Jr[j];
+        for (int j = 0; j < NC; j++) Jv[b][j] = Jr[j];
       }
+#pragma unroll
+      for (int j = 0; j < NC; j++) acc[j] = coef[0] * Jv[0][j];
+#pragma unroll
+      for (int b = 1; b < DIMT; b++)
+#pragma unroll
+        for (int j = 0; j < NC; j++) acc[j] += coef[b] * Jv[b][j];
       if (e < ntot) {
         double *o = JH + e * nvp + C0;
 #pragma unroll
@@ -392,6 +445,7 @@ DEV void newton_gradient(Ctx &c, int grad_only) {
   PROF(c, 13);
   int npos, nneg;
   newton_lists(c, &npos, &nneg);
+  PROF(c, 15);
 #if MJPC_HELPER
   if (NVT > 0 && !grad_only) {
     constexpr int NP = MJPC_NH + 1;
@@ -401,7 +455,9 @@ DEV void newton_gradient(Ctx &c, int grad_only) {
     flag_set(c.misc + HX_JOB, seq);
     newton_fill<NVT, FILL_C0(NVT, 0, NP), FILL_C1(NVT, 0, NP), 0>(c, npos, nneg);
     flag_set(c.misc + HX_W0FILL, seq);
+    PROF(c, 19);
     for (int k = 0; k < MJPC_NH; k++) if (!flag_wait(c.misc + HX_HFILL + k, seq)) c.warning |= WARN_SYNC;
+    PROF(c, 18);
 #else
     // the owner fills all the scaled rows, then posts the job: one hand-shake (entries done) per call instead of two
     newton_fill<NVT, 0, NVT, 1>(c, npos, nneg);
@@ -409,7 +465,9 @@ DEV void newton_gradient(Ctx &c, int grad_only) {
     flag_set(c.misc + HX_JOB, seq);
 #endif
     newton_entries<NVT, (NP >= 3 ? 1 : 2)>(c, npos, nneg, 0, 0, NP);
+    PROF(c, 9);
     for (int k = 0; k < MJPC_NH; k++) if (!flag_wait(c.misc + HX_HDONE + k, seq)) c.warning |= WARN_SYNC;
+    PROF(c, 10);
   } else
 #endif
   {
@@ -471,7 +529,7 @@ DEV void solver_helper_loop(Ctx &c, int seq) {
 template <int NVT>
 DEV void newton_direction(Ctx &c) {
   const int nv = NVT > 0 ? NVT : c.M->nv, nvp = NVT > 0 ? NVP_OF(NVT) : c.M->nvp;
-  chol_factor_solve<NVT>(c.qH, c.Hinv, c.vtmp, c.Mgrad, nv, nvp);
+  chol_factor_solve<NVT>(c.qH, c.Hinv, c.vtmp, c.Mgrad, nv, nvp, c.M->tree_ok && !c.cross);
   PROF(c, 17);
 }
 
@@ -490,46 +548,54 @@ struct LSData {
 
 template <int DIMT>
 DEV void ls_load(Ctx &c, LSData<DIMT> &d) {
-  d.nslot = (c.nefc + NLANE - 1) / NLANE; d.ncslot = (c.ncon + NLANE - 1) / NLANE;
+  const int nefc = c.nefc, ncon = c.ncon, last = c.nefc - 1;
+  d.nslot = (nefc + NLANE - 1) / NLANE; d.ncslot = (ncon + NLANE - 1) / NLANE;
+  // unconditional loads with clamped indices, selects afterwards (no LDS latency inside divergent branches)
 #pragma unroll
   for (int k = 0; k < LS_RPL; k++) {
-    int r = LANE + NLANE * k;
     d.lo[k] = -1; d.hi[k] = 1; d.hD[k] = 0; d.F[k] = 0; d.X[k] = 0; d.V[k] = 0; d.DV[k] = 0; d.DVV[k] = 0;
-    if (k < d.nslot && r < c.nefc) {
-      int type = c.efc_type[r];
-      if (type != CNSTR_CONTACT_ELLIPTIC) {
-        double D = c.efc_D[r], v = c.efc_jv[r];
-        d.X[k] = c.efc_jar[r]; d.V[k] = v; d.hD[k] = 0.5 * D; d.DV[k] = D * v; d.DVV[k] = D * v * v;
-        if (type == CNSTR_FRICTION_DOF) { double f = c.efc_floss[r], Rf = c.efc_R[r] * f; d.lo[k] = -Rf; d.hi[k] = Rf; d.F[k] = f; }
-        else { d.lo[k] = -1e300; d.hi[k] = 0; }
-      }
+    if (k < d.nslot) {
+      int r = LANE + NLANE * k, rc = r < nefc ? r : last;
+      int type = c.efc_type[rc];
+      double D = c.efc_D[rc], v = c.efc_jv[rc], x = c.efc_jar[rc], f = c.efc_floss[rc], Rf = c.efc_R[rc] * f;
+      int quad = r < nefc && type != CNSTR_CONTACT_ELLIPTIC;
+      int fric = quad && type == CNSTR_FRICTION_DOF;
+      D = quad ? D : 0.0; v = quad ? v : 0.0;
+      d.X[k] = quad ? x : 0.0; d.V[k] = v; d.hD[k] = 0.5 * D; d.DV[k] = D * v; d.DVV[k] = D * v * v;
+      d.lo[k] = fric ? -Rf : (quad ? -1e300 : -1.0); d.hi[k] = fric ? Rf : (quad ? 0.0 : 1.0); d.F[k] = fric ? f : 0.0;
     }
   }
 #pragma unroll
   for (int q = 0; q < LS_CPL; q++) {
-    int ci = LANE + NLANE * q;
     d.on[q] = 0; d.mu[q] = 0; d.Dm[q] = 0; d.VV[q] = 0;
 #pragma unroll
     for (int j = 0; j < DIMT; j++) { d.U0[q][j] = 0; d.UV[q][j] = 0; d.E[q][j] = 0; }
-    if (q < d.ncslot && ci < c.ncon) {
-      int dim = c.con_i[ci * CONI_STRIDE];
-      int i = c.con_i[ci * CONI_STRIDE + 3];
-      if (dim > 1 && c.efc_type[i] == CNSTR_CONTACT_ELLIPTIC) {
-        const double *cc = c.contact + ci * c.M->con_stride;
-        double mu = cc[CON_MU];
-        d.on[q] = 1; d.mu[q] = mu;
-        d.Dm[q] = c.efc_D[i] * fast_rcp(mu * mu * (1 + mu * mu));
-        double vv = 0;
+    if (q < d.ncslot) {
+      int ci = LANE + NLANE * q, cic = ci < ncon ? ci : ncon - 1;
+      int dim = c.con_i[cic * CONI_STRIDE];
+      int i = c.con_i[cic * CONI_STRIDE + 3];
+      const double *cc = c.contact + cic * c.M->con_stride;
+      int type = c.efc_type[i];
+      double mu = cc[CON_MU], fr[DIMT], Dj[DIMT], jv[DIMT], jr[DIMT];
 #pragma unroll
-        for (int j = 0; j < DIMT; j++) if (j < dim) {
-          double fr = j == 0 ? mu : cc[CON_FRICTION + j - 1];
-          double uv = c.efc_jv[i + j] * fr;
-          d.U0[q][j] = c.efc_jar[i + j] * fr; d.UV[q][j] = uv;
-          d.E[q][j] = c.efc_D[i + j] * fast_rcp(fr * fr);     // D_j jar_j^2 = E_j U_j^2
-          if (j > 0) vv += uv * uv;
-        }
-        d.VV[q] = vv;
+      for (int j = 0; j < DIMT; j++) {
+        int rj = i + j < nefc ? i + j : last;
+        fr[j] = j == 0 ? mu : cc[CON_FRICTION + j - 1];
+        Dj[j] = c.efc_D[rj]; jv[j] = c.efc_jv[rj]; jr[j] = c.efc_jar[rj];
       }
+      int on = ci < ncon && dim > 1 && type == CNSTR_CONTACT_ELLIPTIC;
+      d.on[q] = on; d.mu[q] = on ? mu : 0.0;
+      d.Dm[q] = on ? Dj[0] * fast_rcp(mu * mu * (1 + mu * mu)) : 0.0;
+      double vv = 0;
+#pragma unroll
+      for (int j = 0; j < DIMT; j++) {
+        int use = on && j < dim;
+        double uv = jv[j] * fr[j];
+        d.U0[q][j] = use ? jr[j] * fr[j] : 0.0; d.UV[q][j] = use ? uv : 0.0;
+        d.E[q][j] = use ? Dj[j] * fast_rcp(fr[j] * fr[j]) : 0.0;     // D_j jar_j^2 = E_j U_j^2
+        if (j > 0) vv += use ? uv * uv : 0.0;
+      }
+      d.VV[q] = vv;
     }
   }
 }
@@ -571,9 +637,10 @@ DEV LSPoint ls_eval(const LSData<DIMT> &d, double q0, double q1, double q2, doub
       p.cost += 0.5 * dn * NmT; p.d1 += dn * g1; p.d2 += Dm * g1 * g1 - dn * mu * T2d;
     }
   }
-  p.cost = wave_sum(p.cost) + q0 + a * q1 + a * a * q2;
-  p.d1 = wave_sum(p.d1) + q1 + 2 * a * q2;
-  p.d2 = wave_sum(p.d2) + 2 * q2;
+  wave_sum3(p.cost, p.d1, p.d2);
+  p.cost = p.cost + q0 + a * q1 + a * a * q2;
+  p.d1 = p.d1 + q1 + 2 * a * q2;
+  p.d2 = p.d2 + 2 * q2;
   return p;
 }
 
@@ -589,7 +656,8 @@ DEV double line_search(Ctx &c, double gauss, double cost0, double *q1_out, doubl
     p_sn += si * si; p_q1 += si * (c.Ma[i] - c.qfrc_smooth[i]); p_q2 += 0.5 * si * c.Mv[i]; p_gs += c.grad[i] * si;
   }
   SYNC();
-  double snorm = sqrt(wave_sum(p_sn)), q1 = wave_sum(p_q1), q2 = wave_sum(p_q2), gs = wave_sum(p_gs);
+  wave_sum4(p_sn, p_q1, p_q2, p_gs);
+  double snorm = sqrt(p_sn), q1 = p_q1, q2 = p_q2, gs = p_gs;
   *q1_out = q1; *q2_out = q2;
   PROF(c, 20);
   double scale = 1.0 / (M.meaninertia * (nv > 1 ? nv : 1));

@@ -28,6 +28,8 @@ DEV double mul_rn(double a, double b) { return a * b; }   // emu is built with -
 DEV double add_rn(double a, double b) { return a + b; }
 DEV double add_mul3_rn(double a, double b, double c, double d) { return a + (b * c) * d; }
 DEV double wave_sum(double v) { return v; }
+DEV void wave_sum3(double &a, double &b, double &c) {}
+DEV void wave_sum4(double &a, double &b, double &c, double &d) {}
 DEV double wave_min(double v) { return v; }
 DEV int wave_sum_i(int v) { return v; }
 DEV int wave_or_i(int v) { return v; }
@@ -101,6 +103,31 @@ DEV double wave_sum(double v) {
   double r2 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 32), __builtin_amdgcn_readlane(__double2loint(v), 32));
   double r3 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 48), __builtin_amdgcn_readlane(__double2loint(v), 48));
   return (r0 + r1) + (r2 + r3);
+}
+// several reductions in lock-step: the butterfly steps of independent sums interleave, which hides the DPP / add latency of
+// each chain behind the others (one after the other they are a serial chain of ~30 dependent instructions each)
+DEV double row_total(double v) {
+  double r0 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 0), __builtin_amdgcn_readlane(__double2loint(v), 0));
+  double r1 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 16), __builtin_amdgcn_readlane(__double2loint(v), 16));
+  double r2 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 32), __builtin_amdgcn_readlane(__double2loint(v), 32));
+  double r3 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 48), __builtin_amdgcn_readlane(__double2loint(v), 48));
+  return (r0 + r1) + (r2 + r3);
+}
+DEV void wave_sum3(double &a, double &b, double &c) {
+#pragma unroll
+  for (int s = 0; s < 4; s++) {
+    double ta = dpp_xchg(a, s), tb = dpp_xchg(b, s), tc = dpp_xchg(c, s);
+    a += ta; b += tb; c += tc;
+  }
+  a = row_total(a); b = row_total(b); c = row_total(c);
+}
+DEV void wave_sum4(double &a, double &b, double &c, double &d) {
+#pragma unroll
+  for (int s = 0; s < 4; s++) {
+    double ta = dpp_xchg(a, s), tb = dpp_xchg(b, s), tc = dpp_xchg(c, s), td = dpp_xchg(d, s);
+    a += ta; b += tb; c += tc; d += td;
+  }
+  a = row_total(a); b = row_total(b); c = row_total(c); d = row_total(d);
 }
 DEV double wave_min(double v) {
 #pragma unroll

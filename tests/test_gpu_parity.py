@@ -537,3 +537,37 @@ def test_multiwave_rollouts_are_bitwise_repeatable():
         assert np.array_equal(out["returns"], first["returns"]) and out["winner"] == first["winner"]
     assert np.array_equal(be.fetch_all(N, H, P)["states"], ref_states)
     be.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [18, 27])
+def test_register_ldl_dense_and_tree_orders_solve_the_same_system(n):
+    """csrc/linalg.h: the level-ordered sparse L^T D L (DofTree<n>) and the dense elimination order against numpy on a random SPD
+    matrix with the sparsity pattern of the joint-space inertia; fused and split (through LDS) forms."""
+    import ctypes as C
+    from mujoco_mpc_amd import capi
+    from mujoco_mpc_amd.modelgen import humanoid_track, quadruped
+    m = (quadruped() if n == 18 else humanoid_track())[0]
+    par = [int(p) for p in m["dof_parentid"]]
+    rng = np.random.default_rng(n)
+    A = np.zeros((n, n))
+    for i in range(n):                                    # ancestors-only pattern
+        a = i
+        while a >= 0:
+            A[i, a] = A[a, i] = rng.normal()
+            a = par[a]
+    A[np.arange(n), np.arange(n)] = np.abs(A).sum(1) + 1.0       # SPD by diagonal dominance, pattern kept
+    b = rng.normal(size=n)
+    want = np.linalg.solve(A, b)
+    lib = capi.load_engine()
+    lib.mjpc_hip_debug_ldl.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int]
+    outs = {}
+    for tree in (0, 1):
+        out = np.zeros(2 * n)
+        rc = lib.mjpc_hip_debug_ldl(n, tree, A.ctypes.data_as(C.POINTER(C.c_double)), b.ctypes.data_as(C.POINTER(C.c_double)),
+                                    out.ctypes.data_as(C.POINTER(C.c_double)), 0)
+        assert rc == 0
+        outs[tree] = out
+        assert np.allclose(out[:n], want, rtol=1e-12, atol=1e-13)          # fused
+        assert np.allclose(out[n:], want, rtol=1e-12, atol=1e-13)          # split through LDS
+    assert np.allclose(outs[0], outs[1], rtol=1e-13, atol=1e-14)

@@ -24,7 +24,7 @@ be.lib.mjpc_hip_debug_fetch_prof.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)
 be.lib.mjpc_hip_debug_fetch_prof(be.h, prof.ctypes.data_as(C.POINTER(C.c_longlong)))
 allc = be.fetch_all(N, H, P)
 names = ["(loop overhead/record)", "kinematics", "com_pos", "crb+factorM", "collision", "make_constraint", "velocity+smooth", "impedance(+warm)",
-         "solver tail", "residual", "cost+record", "integrate", "solver_eval/update", "newton misc", "line_search", "grad", "H build", "chol_factor(H)", "chol_solve(H)", "WJ", "ls: Mv,jv", "ls: load", "ls: evals"]
+         "solver tail", "H: own entries", "H: wait helpers done", "integrate", "solver_eval/update", "newton misc", "line_search", "H: lists", "H build tail", "chol_factor(H)", "H: wait helpers fill", "H: own fill", "ls: Mv,jv", "ls: load", "ls: evals"]
 tot = prof[:, :23].sum(1).mean()
 print(f"rollout us {out['rollouts_compute_time_us']:.0f}; mean stamped ticks/candidate {tot:.3e} ")
 for i, n in enumerate(names):

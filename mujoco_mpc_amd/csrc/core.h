@@ -631,14 +631,20 @@ DEV double impedance(const double *solimp_in, double pos, double margin) {
   double si0 = d_clip(solimp_in[0], 0.0001, 0.9999), si1 = d_clip(solimp_in[1], 0.0001, 0.9999);
   double si2 = fmax(0.0, solimp_in[2]), si3 = d_clip(solimp_in[3], 0.0001, 0.9999), si4 = fmax(1.0, solimp_in[4]);
   if (si0 == si1 || si2 <= D_MINVAL) return 0.5 * (si0 + si1);
-  double x = (pos - margin) / si2;
+  double x = d_div(pos - margin, si2);
   if (x < 0) x = -x;
   if (x >= 1) return si1;
   if (x == 0) return si0;
   double y;
   if (si4 == 1) y = x;
-  else if (x <= si3) { double a = 1 / pow(si3, si4 - 1); y = a * pow(x, si4); }
-  else { double b = 1 / pow(1 - si3, si4 - 1); y = 1 - b * pow(1 - x, si4); }
+  else {
+    // one evaluation for both halves of the sigmoid: u = x below the midpoint, 1 - x above it
+    int low = x <= si3;
+    double m = low ? si3 : 1 - si3, u = low ? x : 1 - x;
+    double a = d_div(1.0, d_pow_small(m, si4 - 1));
+    double w = a * d_pow_small(u, si4);
+    y = low ? w : 1 - w;
+  }
   return si0 + y * (si1 - si0);
 }
 
@@ -770,8 +776,12 @@ DEV void make_contact_rows(Ctx &c, int n_nc) {
   // Jacobian
   PFOR(e, (nefc - n_nc) * nvp) c.efc_J[n_nc * nvp + e] = 0;
   SYNC();
-  PFOR(e, c.ncon * nv) {
-    int ci = e / nv, d = e - ci * nv;
+  // element e = ci * nv + d; the quotient / remainder advance incrementally (one runtime division per lane instead of one per element)
+  int je_ci = LANE / nv, je_d = LANE - je_ci * nv;
+  const int je_sq = NLANE / nv, je_sr = NLANE - je_sq * nv;
+  for (int e = LANE; e < c.ncon * nv; e += NLANE, je_ci += je_sq, je_d += je_sr) {
+    if (je_d >= nv) { je_d -= nv; je_ci++; }
+    const int ci = je_ci, d = je_d;
     const int *cin = c.con_i + ci * CONI_STRIDE;
     int dim = cin[0], r0 = cin[3];
     int pyr = (dim > 1 && M.cone != 1);
@@ -825,7 +835,13 @@ DEV void make_impedance(Ctx &c, int r0, int r1, int with_contacts) {
     int r = r0 + rr;
     int type = c.efc_type[r], id = c.efc_id[r];
     double vel = 0;
-    for (int i = 0; i < nv; i++) vel += c.efc_J[r * nvp + i] * c.qvel[i];
+    for (int i0 = 0; i0 < nv; i0 += 9) {          // blocks of 9 loads in flight (nv = 18, 27 divide evenly), same summation order
+      double jj[9], qq[9];
+#pragma unroll
+      for (int k = 0; k < 9; k++) { int i = i0 + k, ic = i < nv ? i : nv - 1; jj[k] = c.efc_J[r * nvp + ic]; qq[k] = c.qvel[ic]; }
+#pragma unroll
+      for (int k = 0; k < 9; k++) vel += (i0 + k < nv) ? jj[k] * qq[k] : 0.0;
+    }
     double solref[2], solimp[5];
     int first = 1;
     if (type == CNSTR_FRICTION_DOF) {
@@ -848,14 +864,14 @@ DEV void make_impedance(Ctx &c, int r0, int r1, int with_contacts) {
     double K, B;
     if (solref[0] > 0) {
       double tc = fmax(solref[0], 2 * M.timestep), dr = solref[1];
-      K = 1 / fmax(D_MINVAL, dmax * dmax * tc * tc * dr * dr);
-      B = 2 / fmax(D_MINVAL, dmax * tc);
+      K = d_div(1.0, fmax(D_MINVAL, dmax * dmax * tc * tc * dr * dr));
+      B = d_div(2.0, fmax(D_MINVAL, dmax * tc));
     } else {
-      K = -solref[0] / fmax(D_MINVAL, dmax * dmax);
-      B = -solref[1] / fmax(D_MINVAL, dmax);
+      K = d_div(-solref[0], fmax(D_MINVAL, dmax * dmax));
+      B = d_div(-solref[1], fmax(D_MINVAL, dmax));
     }
     if (type == CNSTR_FRICTION_DOF || !first) K = 0;
-    c.efc_R[r] = fmax(D_MINVAL, (1 - imp) / imp * c.efc_diag[r]);
+    c.efc_R[r] = fmax(D_MINVAL, d_div(1 - imp, imp) * c.efc_diag[r]);
     c.efc_aref[r] = -B * vel - K * imp * (c.efc_pos[r] - c.efc_margin[r]);
   }
   SYNC();
@@ -864,20 +880,20 @@ DEV void make_impedance(Ctx &c, int r0, int r1, int with_contacts) {
     if (dim > 1) {
       double *cc = c.contact + ci * c.M->con_stride;
       double *R = c.efc_R + c.con_i[ci * CONI_STRIDE + 3];
-      double R1 = R[0] / fmax(D_MINVAL, M.impratio);
-      cc[CON_MU] = cc[CON_FRICTION] * sqrt(R1 / R[0]);
+      double R1 = d_div(R[0], fmax(D_MINVAL, M.impratio));
+      cc[CON_MU] = cc[CON_FRICTION] * d_sqrt(d_div(R1, R[0]));
       if (M.cone != 1) {        // pyramidal: every edge row gets Rpy = 2 mu^2 R0
         double Rpy = 2 * cc[CON_MU] * cc[CON_MU] * R[0];
         for (int k = 0; k < 2 * (dim - 1); k++) R[k] = Rpy;
       } else {
         R[1] = R1;
         for (int k = 2; k < dim; k++)
-          R[k] = R[1] * cc[CON_FRICTION] * cc[CON_FRICTION] / (cc[CON_FRICTION + k - 1] * cc[CON_FRICTION + k - 1]);
+          R[k] = d_div(R[1] * cc[CON_FRICTION] * cc[CON_FRICTION], cc[CON_FRICTION + k - 1] * cc[CON_FRICTION + k - 1]);
       }
     }
   }
   SYNC();
-  PFOR(rr, r1 - r0) c.efc_D[r0 + rr] = 1 / c.efc_R[r0 + rr];
+  PFOR(rr, r1 - r0) c.efc_D[r0 + rr] = d_div(1.0, c.efc_R[r0 + rr]);
   SYNC();
 }
 

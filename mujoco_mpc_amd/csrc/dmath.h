@@ -31,6 +31,33 @@ DEV double fast_rcp(double x) {
   return __builtin_fma(y, e, y);
 #endif
 }
+// a / b and sqrt(x) without the IEEE sequences (~1 ulp; the emulation build keeps the IEEE operations)
+DEV double d_div(double a, double b) {
+#ifdef MJPC_EMU
+  return a / b;
+#else
+  double r = fast_rcp(b), q = a * r;
+  return __builtin_fma(r, __builtin_fma(-b, q, a), q);
+#endif
+}
+DEV double d_sqrt(double x) {
+#ifdef MJPC_EMU
+  return sqrt(x);
+#else
+  if (!(x > 0)) return x == 0 ? 0.0 : sqrt(x);
+  double r = fast_rsqrt(x), s = x * r;
+  return __builtin_fma(0.5 * r, __builtin_fma(-s, s, x), s);
+#endif
+}
+// x^p for the impedance sigmoid: the default power 2 (and 1, 3) without the generic pow
+DEV double d_pow_small(double x, double p) {
+#ifndef MJPC_EMU
+  if (p == 2.0) return x * x;
+  if (p == 1.0) return x;
+  if (p == 3.0) return x * x * x;
+#endif
+  return pow(x, p);
+}
 DEV double d_dot3(const double *a, const double *b) { return a[0]*b[0] + a[1]*b[1] + a[2]*b[2]; }
 DEV double d_norm3(const double *a) { return sqrt(a[0]*a[0] + a[1]*a[1] + a[2]*a[2]); }
 DEV void d_copy3(double *r, const double *a) { r[0]=a[0]; r[1]=a[1]; r[2]=a[2]; }

@@ -167,7 +167,24 @@ DEV double spline_sample(const double *times, const double *values, int P, int d
 // ======================================================================================
 // position stage
 // ======================================================================================
-DEV void kin_body(Ctx &c, int i) {
+// Forward kinematics in three stages, so that only the parent -> child composition sits in the per-level chain:
+//   A (lane per joint)  local joint rotations: sin/cos of the hinge angles, ball quaternions normalised  -> jq (scratch)
+//   B (levels)          xquat / xpos / xmat of the bodies, joint axes and anchors
+//   C (lane per body / geom / site)  inertial, geom and site frames
+// Same arithmetic per quantity as the one-stage form.
+DEV void kin_joint_local(Ctx &c, int j, double *jq) {
+  const DevModel &M = *c.M;
+  int type = MI(jnt_type)[j], qa = MI(jnt_qposadr)[j];
+  if (type == 3) {
+    double ax[3];
+    d_copy3(ax, MD(jnt_axis) + 3 * j);
+    d_axisangle2quat(jq + 4 * j, ax, c.qpos[qa] - MD(qpos0)[qa]);
+  } else if (type == 1) {
+    d_normalize4(c.qpos + qa);
+    d_copy4(jq + 4 * j, c.qpos + qa);
+  }
+}
+DEV void kin_body(Ctx &c, int i, const double *jq) {
   const DevModel &M = *c.M;
   double xpos[3], xquat[4];
   int pid = MI(body_parentid)[i];
@@ -193,23 +210,27 @@ DEV void kin_body(Ctx &c, int i) {
       d_copy3(xpos, MD(body_pos) + 3 * i);
       d_copy4(xquat, MD(body_quat) + 4 * i);
     }
-    for (int j = jntadr; j < jntadr + jntnum; j++) {
-      int qa = MI(jnt_qposadr)[j], type = MI(jnt_type)[j];
-      double vec[3], ax[3], jp[3];
-      d_copy3(ax, MD(jnt_axis) + 3 * j); d_copy3(jp, MD(jnt_pos) + 3 * j);
-      d_rotvecquat(c.xaxis + 3 * j, ax, xquat);
-      d_rotvecquat(vec, jp, xquat);
-      d_add3(c.xanchor + 3 * j, vec, xpos);
-      if (type == 2) {
-        d_addtoscl3(xpos, c.xaxis + 3 * j, c.qpos[qa] - MD(qpos0)[qa]);
-      } else {
-        double qloc[4], t[4];
-        if (type == 1) { d_normalize4(c.qpos + qa); d_copy4(qloc, c.qpos + qa); }
-        else d_axisangle2quat(qloc, ax, c.qpos[qa] - MD(qpos0)[qa]);
-        d_mulquat(t, xquat, qloc);
-        d_copy4(xquat, t);
-        d_rotvecquat(vec, jp, xquat);
-        d_sub3(xpos, c.xanchor + 3 * j, vec);
+    if (jntnum > 0) {
+      double m[9];
+      d_quat2mat(m, xquat);                       // rotation of the frame the next joint is expressed in
+      for (int j = jntadr; j < jntadr + jntnum; j++) {
+        int qa = MI(jnt_qposadr)[j], type = MI(jnt_type)[j];
+        double vec[3], ax[3], jp[3];
+        d_copy3(ax, MD(jnt_axis) + 3 * j); d_copy3(jp, MD(jnt_pos) + 3 * j);
+        d_mulmatvec3(c.xaxis + 3 * j, m, ax);
+        d_mulmatvec3(vec, m, jp);
+        d_add3(c.xanchor + 3 * j, vec, xpos);
+        if (type == 2) {
+          d_addtoscl3(xpos, c.xaxis + 3 * j, c.qpos[qa] - MD(qpos0)[qa]);
+        } else {
+          double qloc[4], t[4];
+          d_copy4(qloc, jq + 4 * j);
+          d_mulquat(t, xquat, qloc);
+          d_copy4(xquat, t);
+          d_quat2mat(m, xquat);
+          d_mulmatvec3(vec, m, jp);
+          d_sub3(xpos, c.xanchor + 3 * j, vec);
+        }
       }
     }
   }
@@ -219,21 +240,27 @@ DEV void kin_body(Ctx &c, int i) {
   double xm[9];
   d_quat2mat(xm, xquat);
   for (int k = 0; k < 9; k++) c.xmat[9 * i + k] = xm[k];
-  double v[3], q[4], ip[3], iq[4];
-  d_copy3(ip, MD(body_ipos) + 3 * i); d_copy4(iq, MD(body_iquat) + 4 * i);
-  d_mulmatvec3(v, xm, ip);
-  d_add3(c.xipos + 3 * i, v, xpos);
-  d_mulquat(q, xquat, iq);
-  d_quat2mat(xm, q);
-  for (int k = 0; k < 9; k++) c.ximat[9 * i + k] = xm[k];
 }
 
 DEV void kinematics(Ctx &c) {
   const DevModel &M = *c.M;
+  double *jq = c.cdof_dot;                        // scratch: rebuilt by the velocity stage after the next barrier
+  PFOR(j, M.njnt) kin_joint_local(c, j, jq);
+  SYNC();
   for (int l = 0; l < M.nlevel; l++) {
     int a = MI(level_adr)[l], n = MI(level_adr)[l + 1] - a;
-    PFOR(k, n) kin_body(c, MI(level_body)[a + k]);
+    PFOR(k, n) kin_body(c, MI(level_body)[a + k], jq);
     SYNC();
+  }
+  PFOR(i, M.nbody) {
+    if (i == 0) continue;
+    double v[3], q[4], ip[3], iq[4], xm[9];
+    d_copy3(ip, MD(body_ipos) + 3 * i); d_copy4(iq, MD(body_iquat) + 4 * i);
+    d_mulmatvec3(v, c.xmat + 9 * i, ip);
+    d_add3(c.xipos + 3 * i, v, c.xpos + 3 * i);
+    d_mulquat(q, c.xquat + 4 * i, iq);
+    d_quat2mat(xm, q);
+    for (int k = 0; k < 9; k++) c.ximat[9 * i + k] = xm[k];
   }
   PFOR(g, M.ngeom) {
     int b = MI(geom_bodyid)[g];

@@ -1763,10 +1763,16 @@ DEV void rollout(KP Kc) {
   const int *misc = (const int *)(lds_base() + Kc->L.ints) + Kc->L.i_misc;
   double total = 0;
   int failure = 0;
+#if defined(MJPC_PROFILE) && !defined(MJPC_EMU)
+  long long *rprof = (long long *)(lds_base() + Kc->L.prof);
+#define RPROF(i) do { if (r0 && LANE == 0) { long long t_ = (long long)__builtin_amdgcn_s_memtime(); rprof[i] += t_ - rprof[NPROF]; rprof[NPROF] = t_; } } while (0)
+#else
+#define RPROF(i) ((void)0)
+#endif
   for (int t = 0; t < H; t++) {
     int last = (t == H - 1);
     if (r0) ph_head<NVT>(Kc, t, last);
-    XBAR();
+    XBAR(); RPROF(2);
     if (uniform_i(misc[10])) { failure = 1; break; }
     if (r0) ph_constraints(Kc, t);
     if (r1) ph_smooth<NVT>(Kc, t);
@@ -1774,13 +1780,13 @@ DEV void rollout(KP Kc) {
     if (ROLEH && WAVE_ID() == 1) ph_inertia<NVT>(Kc, t);
     if (ROLEH && WAVE_ID() == MJPC_WAVES - 2) ph_noncontact(Kc, t);
 #endif
-    XBAR();
+    XBAR(); RPROF(3);
     if (r0) ph_solve<NVT>(Kc, last, t);
 #if MJPC_HELPER
     if (ROLEH) ph_solve_helper<NVT>(Kc, t);
 #endif
     if (r1) { CostOut o = ph_residual_cost(Kc, t, last); total += o.cost; if (!last) ph_prefactor<NVT>(Kc); }
-    XBAR();
+    XBAR(); RPROF(6);
     if (uniform_i(misc[3]) | uniform_i(misc[11])) { failure = 1; break; }
     if (r0 && !last) ph_integrate<NVT>(Kc, t);
   }

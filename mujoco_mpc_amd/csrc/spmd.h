@@ -92,27 +92,28 @@ DEV double dpp_xchg(double v, const int ctrl_sel) {
   }
   return __hiloint2double(hi, lo);
 }
+// the four row sums (identical in every lane of a row after the butterflies) -> wave total: row_bcast:15 adds row 0 into
+// row 1 and row 2 into row 3, row_bcast:31 adds row 1 into rows 2 / 3; lane 63 then holds (r3 + r2) + (r1 + r0), the same
+// value as (r0 + r1) + (r2 + r3)
+DEV double row_total(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  double t = __hiloint2double(__builtin_amdgcn_update_dpp(0, hi, 0x142, 0xA, 0xF, false), __builtin_amdgcn_update_dpp(0, lo, 0x142, 0xA, 0xF, false));
+  v += t;
+  lo = __double2loint(v); hi = __double2hiint(v);
+  t = __hiloint2double(__builtin_amdgcn_update_dpp(0, hi, 0x143, 0xC, 0xF, false), __builtin_amdgcn_update_dpp(0, lo, 0x143, 0xC, 0xF, false));
+  v += t;
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
 DEV double wave_sum(double v) {
   v += dpp_xchg(v, 0);
   v += dpp_xchg(v, 1);
   v += dpp_xchg(v, 2);
   v += dpp_xchg(v, 3);
   // every lane of a row now holds that row's sum (the butterflies are symmetric => identical bits in all lanes)
-  double r0 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 0), __builtin_amdgcn_readlane(__double2loint(v), 0));
-  double r1 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 16), __builtin_amdgcn_readlane(__double2loint(v), 16));
-  double r2 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 32), __builtin_amdgcn_readlane(__double2loint(v), 32));
-  double r3 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 48), __builtin_amdgcn_readlane(__double2loint(v), 48));
-  return (r0 + r1) + (r2 + r3);
+  return row_total(v);
 }
 // several reductions in lock-step: the butterfly steps of independent sums interleave, which hides the DPP / add latency of
 // each chain behind the others (one after the other they are a serial chain of ~30 dependent instructions each)
-DEV double row_total(double v) {
-  double r0 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 0), __builtin_amdgcn_readlane(__double2loint(v), 0));
-  double r1 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 16), __builtin_amdgcn_readlane(__double2loint(v), 16));
-  double r2 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 32), __builtin_amdgcn_readlane(__double2loint(v), 32));
-  double r3 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 48), __builtin_amdgcn_readlane(__double2loint(v), 48));
-  return (r0 + r1) + (r2 + r3);
-}
 DEV void wave_sum3(double &a, double &b, double &c) {
 #pragma unroll
   for (int s = 0; s < 4; s++) {

@@ -23,7 +23,7 @@ prof = np.zeros((N, 24), np.int64)
 be.lib.mjpc_hip_debug_fetch_prof.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
 be.lib.mjpc_hip_debug_fetch_prof(be.h, prof.ctypes.data_as(C.POINTER(C.c_longlong)))
 allc = be.fetch_all(N, H, P)
-names = ["(loop overhead/record)", "kinematics", "com_pos", "crb+factorM", "collision", "make_constraint", "velocity+smooth", "impedance(+warm)",
+names = ["(loop overhead/record)", "kinematics", "com_pos + barrier wait after head", "BARRIER WAIT after presolve", "collision", "make_constraint", "BARRIER WAIT after solve", "impedance(+warm)",
          "solver tail", "H: own entries", "H: wait helpers done", "integrate", "solver_eval/update", "newton misc", "line_search", "H: lists", "H build tail", "chol_factor(H)", "H: wait helpers fill", "H: own fill", "ls: Mv,jv", "ls: load", "ls: evals"]
 tot = prof[:, :23].sum(1).mean()
 print(f"rollout us {out['rollouts_compute_time_us']:.0f}; mean stamped ticks/candidate {tot:.3e} ")

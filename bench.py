@@ -26,10 +26,10 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md)
 
 
 def measured_traffic(N, H):
-    """HBM bytes per rollout_kernel launch from the committed rocprofv3 PMC passes (profiles/r1/f_traffic.json:
+    """HBM bytes per rollout_kernel launch from the committed rocprofv3 PMC passes (profiles/r1/g_traffic.json:
     FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE); only valid for the workload it was measured on."""
     try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "r1", "f_traffic.json")))
+        t = json.load(open(os.path.join(ROOT, "profiles", "r1", "g_traffic.json")))
         if t.get("workload") == f"C2 quadruped {N}x{H}" and N == 256:
             return t["traffic_bytes_per_launch"]
     except Exception:

@@ -363,6 +363,23 @@ DEV void crb_and_factor(Ctx &c) {
 // collision: bounding-sphere filter -> ordered compaction -> analytic narrow phase
 // ======================================================================================
 struct NPCon { double dist, pos[3], frame[6]; };
+// The per-lane contact list (at most 4) must stay in registers: a run-time index would send the whole array to scratch
+// memory, so slots are written / read through compile-time indices and value selects (no loops: the indices must be
+// constants before the first SROA run).
+DEV void np_sel(NPCon &d, const NPCon &v, bool p) {
+  d.dist = p ? v.dist : d.dist;
+  d.pos[0] = p ? v.pos[0] : d.pos[0]; d.pos[1] = p ? v.pos[1] : d.pos[1]; d.pos[2] = p ? v.pos[2] : d.pos[2];
+  d.frame[0] = p ? v.frame[0] : d.frame[0]; d.frame[1] = p ? v.frame[1] : d.frame[1]; d.frame[2] = p ? v.frame[2] : d.frame[2];
+  d.frame[3] = p ? v.frame[3] : d.frame[3]; d.frame[4] = p ? v.frame[4] : d.frame[4]; d.frame[5] = p ? v.frame[5] : d.frame[5];
+}
+DEV void np_put(NPCon *con, int idx, const NPCon &v) {
+  np_sel(con[0], v, idx == 0); np_sel(con[1], v, idx == 1); np_sel(con[2], v, idx == 2); np_sel(con[3], v, idx == 3);
+}
+DEV NPCon np_get(const NPCon *con, int idx) {
+  NPCon v = con[0];
+  np_sel(v, con[1], idx == 1); np_sel(v, con[2], idx == 2); np_sel(v, con[3], idx == 3);
+  return v;
+}
 
 DEV int np_sphere_sphere(NPCon *con, double margin, const double *p1, double r1, const double *p2, double r2) {
   double dif[3];
@@ -391,9 +408,10 @@ DEV int np_plane_capsule(NPCon *con, double margin, const double *pp, const doub
   int cnt = 0;
   d_scl3(seg, axis, size[1]);
   d_add3(e, cp, seg);
-  if (np_plane_sphere(con + cnt, margin, pp, n, e, size[0])) { d_copy3(con[cnt].frame + 3, axis); cnt++; }
+  NPCon t;
+  if (np_plane_sphere(&t, margin, pp, n, e, size[0])) { d_copy3(t.frame + 3, axis); con[0] = t; cnt++; }
   d_sub3(e, cp, seg);
-  if (np_plane_sphere(con + cnt, margin, pp, n, e, size[0])) { d_copy3(con[cnt].frame + 3, axis); cnt++; }
+  if (np_plane_sphere(&t, margin, pp, n, e, size[0])) { d_copy3(t.frame + 3, axis); np_put(con, cnt, t); cnt++; }
   return cnt;
 }
 DEV int np_plane_box(NPCon *con, double margin, const double *pp, const double *pm, const double *bp, const double *bm, const double *size) {
@@ -408,12 +426,13 @@ DEV int np_plane_box(NPCon *con, double margin, const double *pp, const double *
     double ldist = d_dot3(n, corner);
     if (dist + ldist > margin || ldist > 0) continue;
     if (cnt >= 4) break;
-    NPCon *q = con + cnt;
+    NPCon t, *q = &t;
     q->dist = dist + ldist;
     for (int k = 0; k < 6; k++) q->frame[k] = 0;
     d_copy3(q->frame, n);
     d_add3(corner, corner, bp);
     d_addscl3(q->pos, corner, n, -0.5 * q->dist);
+    np_put(con, cnt, t);
     cnt++;
     if (cnt >= 4) break;
   }
@@ -434,14 +453,14 @@ DEV int np_plane_cylinder(NPCon *con, double margin, const double *pp, const dou
   d_scl3(axis, axis, size[1]); prjaxis *= size[1];
   int cnt = 0;
   if (dist0 + prjaxis + prjvec <= margin) {
-    NPCon *q = con + cnt++;
+    NPCon *q = con; cnt = 1;
     q->dist = dist0 + prjaxis + prjvec;
     d_add3(q->pos, cp, vec); d_add3(q->pos, q->pos, axis); d_addtoscl3(q->pos, n, -0.5 * q->dist);
     for (int k = 0; k < 6; k++) q->frame[k] = 0;
     d_copy3(q->frame, n);
   } else return 0;
   if (dist0 - prjaxis + prjvec <= margin) {
-    NPCon *q = con + cnt++;
+    NPCon *q = con + 1; cnt = 2;
     q->dist = dist0 - prjaxis + prjvec;
     d_add3(q->pos, cp, vec); d_sub3(q->pos, q->pos, axis); d_addtoscl3(q->pos, n, -0.5 * q->dist);
     for (int k = 0; k < 6; k++) q->frame[k] = 0;
@@ -454,12 +473,14 @@ DEV int np_plane_cylinder(NPCon *con, double margin, const double *pp, const dou
     d_normalize3(vec1);
     d_scl3(vec1, vec1, size[0] * sqrt(3.0) / 2);
     for (int s = -1; s <= 1; s += 2) {
-      NPCon *q = con + cnt++;
+      NPCon t, *q = &t;
       q->dist = dist0 + prjaxis + prjvec1;
       d_add3(q->pos, cp, axis); d_addtoscl3(q->pos, vec, -0.5); d_addtoscl3(q->pos, vec1, (double)s);
       d_addtoscl3(q->pos, n, -0.5 * q->dist);
       for (int k = 0; k < 6; k++) q->frame[k] = 0;
       d_copy3(q->frame, n);
+      np_put(con, cnt, t);
+      cnt++;
     }
   }
   return cnt;
@@ -496,7 +517,8 @@ DEV int np_capsule_capsule(NPCon *con, double margin, const double *p1, const do
     d_sub3(w, e, p2);
     double x = d_clip(d_dot3(a2, w), -len2, len2);
     d_addscl3(pt, p2, a2, x);
-    cnt += np_sphere_sphere(con + cnt, margin, e, s1[0], pt, s2[0]);
+    NPCon t;
+    if (np_sphere_sphere(&t, margin, e, s1[0], pt, s2[0])) { np_put(con, cnt, t); cnt++; }
   }
   return cnt;
 }
@@ -620,7 +642,7 @@ DEV void collision(Ctx &c) {
   for (int base = 0; base < nactive; base += NLANE) {
     int a = base + LANE, n = 0, g1 = 0, g2 = 0;
     double margin = 0, gap = 0;
-    NPCon con[4];
+    NPCon con[4] = {};
     if (a < nactive) {
       int p = c.active[a];
       g1 = MI(pair_g1)[p]; g2 = MI(pair_g2)[p];
@@ -635,11 +657,12 @@ DEV void collision(Ctx &c) {
       double *cc = c.contact + ci * c.M->con_stride;
       int dim;
       contact_param(c, g1, g2, cc, &dim);
+      const NPCon cur = np_get(con, k);
       double fr[9];
-      for (int q = 0; q < 6; q++) fr[q] = con[k].frame[q];
+      for (int q = 0; q < 6; q++) fr[q] = cur.frame[q];
       d_makeframe(fr);
-      cc[CON_DIST] = con[k].dist;
-      d_copy3(cc + CON_POS, con[k].pos);
+      cc[CON_DIST] = cur.dist;
+      d_copy3(cc + CON_POS, cur.pos);
       for (int q = 0; q < 9; q++) cc[CON_FRAME + q] = fr[q];
       cc[CON_INCLUDEMARGIN] = margin - gap;
       cc[CON_MU] = 0;
@@ -1634,7 +1657,7 @@ DEV_NOINLINE void ph_inertia(KP Kc, int t) {
 }
 #endif
 template <int NVT>
-DEV_NOINLINE void ph_solve(KP Kc, int last, int t) {
+DEV_NOINLINE void ph_solve(KP Kc, int last, int t) {          // (inlining it into the kernel trades the ~100 callee-saved spills for AGPR traffic in the hot loops: measured 1% slower)
   Ctx c; ctx_open(c, Kc);
   c.hseq = t * 256;
   solve_constraints<NVT>(c); PROF(c, 8);

@@ -679,22 +679,27 @@ DEV double line_search(Ctx &c, double gauss, double cost0, double *q1_out, doubl
 #if defined(MJPC_PROFILE) && !defined(MJPC_EMU)
     if (LANE == 0) c.prof[23] += 1;
 #endif
-    if (p.cost < best_cost) { best_cost = p.cost; best_a = a; }
-    if (fabs(p.d1) < gtol) break;
-    if (p.d1 < 0) lo = a; else hi = a;
-    double an;
-    if (hi < 0) {
-      an = (p.d2 > 0) ? a - p.d1 * fast_rcp(p.d2) : 2 * a;
-      if (!(an > a)) an = 2 * a;
-      dxold = dx; dx = an - a;
-    } else {
-      double nw = (p.d2 > 0) ? a - p.d1 * fast_rcp(p.d2) : lo - 1;
-      int ok = (nw > lo) && (nw < hi) && (fabs(2 * p.d1) <= fabs(dxold * p.d2));
-      dxold = dx;
-      if (ok) { dx = fabs(nw - a); an = nw; }
-      else { dx = 0.5 * (hi - lo); an = lo + dx; }
-    }
-    if (an == a) break;
+    // the bookkeeping is written with selects and a single exit test: every quantity here is wave-uniform, and a uniform
+    // branch on a VALU comparison costs a VALU -> SALU round trip each
+    int better = p.cost < best_cost;
+    best_cost = better ? p.cost : best_cost; best_a = better ? a : best_a;
+    int conv = fabs(p.d1) < gtol;
+    int neg = p.d1 < 0;
+    lo = neg ? a : lo; hi = neg ? hi : a;
+    int pos2 = p.d2 > 0;
+    double newton = a - p.d1 * fast_rcp(p.d2);
+    // not bracketed yet: Newton step if it moves forward, else double the step
+    double an_e = pos2 ? newton : 2 * a;
+    an_e = (an_e > a) ? an_e : 2 * a;
+    // bracketed: Newton step if it stays inside and at least halves the previous step, else bisection
+    double nw = pos2 ? newton : lo - 1;
+    int ok = (nw > lo) && (nw < hi) && (fabs(2 * p.d1) <= fabs(dxold * p.d2));
+    double dx_b = ok ? fabs(nw - a) : 0.5 * (hi - lo);
+    double an_b = ok ? nw : lo + dx_b;
+    int bracketed = !(hi < 0);
+    double an = bracketed ? an_b : an_e;
+    dxold = dx; dx = bracketed ? dx_b : an_e - a;
+    if (conv || an == a) break;
     a = an;
   }
   PROF(c, 22);

@@ -48,9 +48,15 @@ DEV int uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
 #define NPROF 24
 // diagnostic builds only: lane 0 accumulates s_memtime deltas per phase slot in LDS
 // (multi-wave builds: only the owner wave stamps, so the slots show ITS timeline including the waits for the other waves)
-#define PROF(c, i) do { if (LANE == 0 && (c).role == 0) { long long t_ = (long long)__builtin_amdgcn_s_memtime(); (c).prof[i] += t_ - (c).prof[NPROF]; (c).prof[NPROF] = t_; } } while (0)
+#ifndef MJPC_PROFILE_WAVE
+#define MJPC_PROFILE_WAVE 0      // which wavefront of the workgroup records its timeline (0 = owner)
+#endif
+#define PROF_STAMP(pr, i) do { long long t_ = (long long)__builtin_amdgcn_s_memtime(); (pr)[i] += t_ - (pr)[NPROF]; (pr)[NPROF] = t_; } while (0)
+#define PROF(c, i) do { if (MJPC_PROFILE_WAVE == 0 && LANE == 0 && (c).role == 0) PROF_STAMP((c).prof, i); } while (0)
+#define PROFW(c, i) do { if (MJPC_PROFILE_WAVE != 0 && LANE == 0 && WAVE_ID() == MJPC_PROFILE_WAVE) PROF_STAMP((c).prof, i); } while (0)
 #else
 #define PROF(c, i) ((void)0)
+#define PROFW(c, i) ((void)0)
 #endif
 
 struct Ctx {
@@ -345,6 +351,7 @@ DEV void crb_and_factor(Ctx &c) {
     c.crb[e] = s;
   }
   SYNC();
+  PROFW(c, 1);
   PFOR(p, M.nmpair) {
     int i = MI(mpair_i)[p], j = MI(mpair_j)[p];
     double buf[6];
@@ -356,7 +363,9 @@ DEV void crb_and_factor(Ctx &c) {
   }
   SYNC();
   PFOR(e, nv * nvp) c.qL[e] = c.qM[e];
+  PROFW(c, 4);
   chol_factor<NVT>(c.qL, c.Linv, c.vtmp, nv, nvp, c.M->tree_ok);
+  PROFW(c, 5);
 }
 
 // ======================================================================================
@@ -1009,6 +1018,7 @@ DEV void velocity_stage(Ctx &c, int mfact_seq) {
     PFOR(k, n) vel_body(c, MI(level_body)[a + k]);
     SYNC();
   }
+  PROFW(c, 1);
   PFOR(e, M.nbody * 9) {
     int b = e / 9, k = e - 9 * b;
     if (k < 6) {
@@ -1022,6 +1032,7 @@ DEV void velocity_stage(Ctx &c, int mfact_seq) {
       c.subtree_linvel[3 * b + kk] = s / fmax(D_MINVAL, MD(body_subtreemass)[b]);
     }
   }
+  PROFW(c, 4);
   // actuator forces
   PFOR(i, M.nu) {
     double ctrl = c.ctrl[i];
@@ -1072,8 +1083,11 @@ DEV void velocity_stage(Ctx &c, int mfact_seq) {
     SYNC();
   }
   PFOR(d, nv) c.qacc_smooth[d] = c.qfrc_smooth[d];
+  PROFW(c, 5);
   if (mfact_seq && !flag_wait(c.misc + 22, mfact_seq)) c.warning |= WARN_SYNC;
+  PROFW(c, 7);
   chol_solve<NVT>(c.qL, c.Linv, c.qacc_smooth, nv, M.nvp, M.tree_ok);
+  PROFW(c, 8);
 }
 
 #include "solver.h"
@@ -1630,7 +1644,9 @@ DEV_NOINLINE void ph_noncontact(KP Kc, int t) {
   make_noncontact_rows(c, &nsingle, &n_nc);
   if (LANE == 0) { c.misc[25] = nsingle; c.misc[26] = n_nc; }
   flag_set(c.misc + 24, t + 1);
+  PROFW(c, 1);
   make_impedance(c, 0, n_nc, 0);
+  PROFW(c, 4);
   ctx_close(c);
 }
 #endif
@@ -1693,7 +1709,7 @@ DEV_NOINLINE CostOut ph_residual_cost(KP Kc, int t, int last) {        // role 1
     PFOR(i, 9 * nb) f[3 * nb + i] = c.xmat[i];
     PFOR(i, 3 * ns) f[12 * nb + i] = c.site_xpos[i];
   }
-  task_residual(c, c.residual); PROF(c, 9);
+  task_residual(c, c.residual); PROF(c, 9); PROFW(c, 9);
   PFOR(i, R.nr) R.residual[t * R.nr + i] = c.residual[i];
   PFOR(i, T.num_trace) {
     int id = MI(task.trace_objid)[i], ty = MI(task.trace_objtype)[i];
@@ -1704,7 +1720,7 @@ DEV_NOINLINE CostOut ph_residual_cost(KP Kc, int t, int last) {        // role 1
   o.cost = cost_value(c, c.residual);      // UpdateReturn (trajectory.cc:312-326) folded into the loop
   if (LANE == 0) R.costs[t] = o.cost;
   o.warning = c.warning;
-  PROF(c, 10);
+  PROF(c, 10); PROFW(c, 10);
   ctx_close(c);
   return o;
 }
@@ -1721,6 +1737,7 @@ DEV_NOINLINE void ph_prefactor(KP Kc) {
     PFOR(e, nv * nvp) { int i = e / nvp, j = e - i * nvp; c.qL[e] = c.qM[e] + ((i == j) ? h * MD(dof_damping)[i] : 0.0); }
     chol_factor<NVT>(c.qL, c.Linv, c.cfrc, nv, nvp, c.M->tree_ok);
   }
+  PROFW(c, 11);
   ctx_close(c);
 }
 
@@ -1788,7 +1805,7 @@ DEV void rollout(KP Kc) {
   int failure = 0;
 #if defined(MJPC_PROFILE) && !defined(MJPC_EMU)
   long long *rprof = (long long *)(lds_base() + Kc->L.prof);
-#define RPROF(i) do { if (r0 && LANE == 0) { long long t_ = (long long)__builtin_amdgcn_s_memtime(); rprof[i] += t_ - rprof[NPROF]; rprof[NPROF] = t_; } } while (0)
+#define RPROF(i) do { if (LANE == 0 && WAVE_ID() == MJPC_PROFILE_WAVE) PROF_STAMP(rprof, i); } while (0)
 #else
 #define RPROF(i) ((void)0)
 #endif

@@ -61,6 +61,7 @@ DEV int wave_any(int flag) { return flag != 0; }
 #define ROLEH (MJPC_WAVES >= 3 && WAVE_ID() >= 1 && WAVE_ID() < MJPC_WAVES - 1)     // helper k = WAVE_ID() - 1
 #else
 #define XBAR() SYNC()
+#define WAVE_ID() 0
 #define ROLE0 1
 #define ROLE1 1
 #define ROLEH 0

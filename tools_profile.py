@@ -6,25 +6,35 @@ ROOT = os.path.dirname(os.path.abspath(__file__)); sys.path.insert(0, ROOT)
 CSRC = os.path.join(ROOT, "mujoco_mpc_amd", "csrc")
 so = os.path.join(ROOT, "gpurun_out", "libmjpc_hip_prof.so")
 os.makedirs(os.path.dirname(so), exist_ok=True)
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DMJPC_PROFILE=1"] + (["-DMJPC_WAVES=1"] if os.environ.get("PROFILE_ONE_WAVE") else []) + [
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DMJPC_PROFILE=1"] + (["-DMJPC_WAVES=1"] if os.environ.get("PROFILE_ONE_WAVE") else []) + ([f"-DMJPC_PROFILE_WAVE={int(os.environ['PROFILE_WAVE'])}"] if os.environ.get("PROFILE_WAVE") else []) + [
                        "-Wno-unused-value", "-o", so, os.path.join(CSRC, "engine.hip")])
 from mujoco_mpc_amd import capi
 capi.ENGINE_PATH = so
-from mujoco_mpc_amd.modelgen import quadruped
+from mujoco_mpc_amd.modelgen import quadruped, humanoid_track
 from mujoco_mpc_amd.planner import HipBackend
-m, task, d = quadruped()
-N, H, P = int(sys.argv[1]) if len(sys.argv) > 1 else 256, 100, 3
-kt = np.linspace(0, 0.99, P); kv = np.zeros((P, 12))
+HUM = os.environ.get("PROFILE_WORKLOAD") == "humanoid"
+m, task, d = humanoid_track() if HUM else quadruped()
+N, H, P = int(sys.argv[1]) if len(sys.argv) > 1 else 256, (128 if HUM else 100), (16 if HUM else 3)
+SIG = 0.15 if HUM else 0.04
+kt = np.linspace(0, (H - 1) * m["timestep"], P); kv = np.zeros((P, m["nu"]))
 be = HipBackend(m, task, max_samples=N, max_horizon=H)
 for i in range(2):
     out = be.plan(state=d["state"], mocap=d["mocap"], time=0.0, knot_times=kt, knot_values=kv, interpolation=2, num_trajectory=N,
-                  horizon=H, sigma=(0.04, 0.0), seed=0x5EED, stream=i)
+                  horizon=H, sigma=(SIG, 0.0), seed=0x5EED, stream=i)
 prof = np.zeros((N, 24), np.int64)
 be.lib.mjpc_hip_debug_fetch_prof.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
 be.lib.mjpc_hip_debug_fetch_prof(be.h, prof.ctypes.data_as(C.POINTER(C.c_longlong)))
 allc = be.fetch_all(N, H, P)
 names = ["(loop overhead/record)", "kinematics", "com_pos + barrier wait after head", "BARRIER WAIT after presolve", "collision", "make_constraint", "BARRIER WAIT after solve", "impedance(+warm)",
          "solver tail", "H: own entries", "H: wait helpers done", "integrate", "solver_eval/update", "newton misc", "line_search", "H: lists", "H build tail", "chol_factor(H)", "H: wait helpers fill", "H: own fill", "ls: Mv,jv", "ls: load", "ls: evals"]
+W = int(os.environ.get("PROFILE_WAVE", "0"))
+if W == 3:      # side wave
+    names = ["(head: idle)", "smooth: com->vel/acc level sweep", "BARRIER WAIT after head", "BARRIER WAIT after presolve", "smooth: subtree sums", "smooth: actuation/bias/springs", "BARRIER WAIT after solve",
+             "smooth: wait for factor(M)", "smooth: solve qacc_smooth", "residual", "cost+record", "prefactor M+hB"] + ["-"] * 11
+elif W == 1:    # helper 0
+    names = ["-", "inertia: crb subtree sums", "BARRIER WAIT after head", "BARRIER WAIT after presolve", "inertia: M entries", "inertia: factor M", "BARRIER WAIT after solve (= solver helper loop)"] + ["-"] * 16
+elif W == 2:    # helper 1
+    names = ["-", "noncontact rows", "BARRIER WAIT after head", "BARRIER WAIT after presolve", "noncontact impedance", "-", "BARRIER WAIT after solve (= cost@smooth + solver helper loop)"] + ["-"] * 16
 tot = prof[:, :23].sum(1).mean()
 print(f"rollout us {out['rollouts_compute_time_us']:.0f}; mean stamped ticks/candidate {tot:.3e} ")
 for i, n in enumerate(names):

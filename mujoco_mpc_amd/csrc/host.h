@@ -3,6 +3,7 @@
 // one int32 and one fp64 buffer, derives the static tables the kernel needs, and computes the
 // LDS carve-up.
 #pragma once
+#include <stdlib.h>
 #include <stdint.h>
 #include <string.h>
 #include <string>
@@ -72,6 +73,7 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
   M.maxdim = 1;
   for (int g = 0; g < ng; g++) if (m->geom_condim[g] > M.maxdim) M.maxdim = m->geom_condim[g];
   M.tree_ok = (nv == 18 && dof_tree_matches<18>(m->dof_parentid)) || (nv == 27 && dof_tree_matches<27>(m->dof_parentid));
+  if (getenv("MJPC_HIP_DENSE_FACTOR")) M.tree_ok = 0;      // test knob: dense elimination order for every factorisation
   M.nconmax = m->nconmax > 0 ? m->nconmax : 32;
   if (M.nconmax > 64) M.nconmax = 64;
   M.nefcmax = m->nefcmax > 0 ? m->nefcmax : 128;

@@ -77,6 +77,8 @@ def main():
     ap.add_argument("--workload", default="quadruped", choices=["quadruped", "humanoid"],
                     help="quadruped = BASELINE configs[1] (the metric's config, default); humanoid = configs[2]")
     ap.add_argument("--samples", type=int, default=None, help="candidates per GPU (default 256 / 1024)")
+    ap.add_argument("--global-samples", type=int, default=None,
+                    help="strong-scaling mode: a fixed global batch (e.g. 4096 = BASELINE configs[3]) split evenly over the ranks")
     ap.add_argument("--horizon", type=int, default=None, help="default 100 / 128")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -107,6 +109,11 @@ def main():
     else:
         model, task, d = humanoid_track()
         N, H, P, sigma, wname = args.samples or 1024, args.horizon or 128, 16, 0.15, "Humanoid tracking (Jump)"
+    scaling = "weak"
+    if args.global_samples:
+        if args.global_samples % world:
+            raise SystemExit(f"--global-samples {args.global_samples} is not divisible by {world} ranks")
+        N, scaling = args.global_samples // world, "strong"
     dt_model = model["timestep"]
     kt = np.linspace(0.0, (H - 1) * dt_model, P)
     kv = np.zeros((P, model["nu"]))
@@ -153,7 +160,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",

@@ -117,9 +117,15 @@ DEV void ctx_open(Ctx &c, KP Kc, int role = 0) {
   c.warning = uniform_i(c.misc[3]) | uniform_i(c.misc[11]); c.solver_iter = uniform_i(c.misc[4]); c.cross = uniform_i(c.misc[8]);
   c.time = c.red[0];
 }
+#ifdef MJPC_NO_MODEL_CACHE     // experiment: tables read from HBM / L2 (the LDS copy is what keeps a second workgroup off the CU for small models)
+#define MD(f) (c.M->f)
+#define MI(f) (c.M->f)
+#define MDM() ((const unsigned long long *)c.M->body_dofmask)
+#else
 #define MD(f) (c.mcd + (int)(c.M->f - c.gdb))
 #define MI(f) (c.mci + (int)(c.M->f - c.gib))
 #define MDM() ((const unsigned long long *)(c.mcd + (int)((const double *)c.M->body_dofmask - c.gdb)))
+#endif
 DEV void ctx_close(Ctx &c) {
   SYNC();
   if (c.role != 0) {            // the side wave never writes the owner's scalars

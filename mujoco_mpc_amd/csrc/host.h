@@ -184,6 +184,7 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
   p.task_i_cap = p.ib.size() - p.task_i0; p.task_d_cap = p.db.size() - p.task_d0;
   // everything so far is LDS-cached; the keyframe tables (large, touched by a few residual terms only) stay in HBM
   p.cache_i = p.ib.size(); p.cache_d = p.db.size();
+  if (getenv("MJPC_HIP_NO_MODEL_CACHE")) { p.cache_i = 0; p.cache_d = 0; }      // only with a -DMJPC_NO_MODEL_CACHE engine build
   M.key_qpos = as_off<double>(put_d(p, m->key_qpos, (size_t)m->nkey * m->nq));
   M.key_mpos = as_off<double>(put_d(p, m->key_mpos, (size_t)m->nkey * 3 * m->nmocap));
   // ---- LDS layout

@@ -21,7 +21,10 @@
 // ------------------------------------------------------------------------------ kernels
 // NVT = number of dofs known at compile time (register-resident factorisations), 0 = generic
 template <int NVT>
-__global__ void __launch_bounds__(64 * MJPC_WAVES) rollout_kernel(const KParams K) {
+#ifndef MJPC_MIN_BLOCKS
+#define MJPC_MIN_BLOCKS 1      // experiment: 2 asks the compiler for <= 256 registers per wave (two workgroups per CU)
+#endif
+__global__ void __launch_bounds__(64 * MJPC_WAVES, MJPC_MIN_BLOCKS) rollout_kernel(const KParams K) {
   if ((int)blockIdx.x >= K.nlocal) return;
   rollout<NVT>((KP)__builtin_amdgcn_kernarg_segment_ptr());
 }

@@ -117,7 +117,7 @@ DEV void ctx_open(Ctx &c, KP Kc, int role = 0) {
   c.warning = uniform_i(c.misc[3]) | uniform_i(c.misc[11]); c.solver_iter = uniform_i(c.misc[4]); c.cross = uniform_i(c.misc[8]);
   c.time = c.red[0];
 }
-#ifdef MJPC_NO_MODEL_CACHE     // experiment: tables read from HBM / L2 (the LDS copy is what keeps a second workgroup off the CU for small models)
+#ifdef MJPC_NO_MODEL_CACHE     // engine_dense.hip: tables read from HBM / L2 (the 26-29 KB LDS copy would keep a second workgroup off the CU)
 #define MD(f) (c.M->f)
 #define MI(f) (c.M->f)
 #define MDM() ((const unsigned long long *)c.M->body_dofmask)

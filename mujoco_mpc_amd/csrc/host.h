@@ -11,6 +11,8 @@
 #include "../../include/mjpc_hip.h"
 #include "model.h"
 
+// LDS carve-up of one workgroup (offsets in doubles).  Arrays that are only alive while the constraint rows are built share
+// their storage with solve-phase vectors: efc_diag <-> efc_force, efc_margin <-> efc_jv (the next step rebuilds them).
 struct PackedModel {
   std::vector<int> ib;
   std::vector<double> db;
@@ -55,6 +57,38 @@ static inline void pack_task(PackedModel &p, const MjpcHipTask *t) {
   T.norm_parameter = as_off<double>(put_d(p, t->norm_parameter, np));
   T.parameters = as_off<double>(put_d(p, t->parameters, t->num_parameter));
   T.dbl_data = as_off<double>(put_d(p, t->dbl_data, t->num_dbl));
+}
+
+static inline void make_layout(const PackedModel &p, Lay &L, const MjpcHipModel *m, const MjpcHipTask *t, int P_max, size_t cache_d, size_t cache_i) {
+  const DevModel &M = p.M;
+  int nb = m->nbody, nj = m->njnt, nv = m->nv, ng = m->ngeom, ns = m->nsite, nu = m->nu;
+  int o = 0;
+  int nvp = M.nvp, ne = M.nefcmax, nc = M.nconmax, nr = t->num_residual;
+#define A_(f, n) L.f = o; o += (int)(n)
+  A_(qpos, m->nq); A_(qvel, nv); A_(ctrl, nu + 1); A_(qacc, nv); A_(qacc_ws, nv); A_(qacc_smooth, nv); A_(qfrc_smooth, nv);
+  A_(qfrc_bias, nv); A_(qfrc_constraint, nv); A_(actuator_force, nu + 1); A_(mocap_pos, 3 * m->nmocap + 3); A_(mocap_quat, 4 * m->nmocap + 4);
+  A_(xpos, 3 * nb); A_(xquat, 4 * nb); A_(xmat, 9 * nb); A_(xipos, 3 * nb); A_(ximat, 9 * nb); A_(xanchor, 3 * nj + 3); A_(xaxis, 3 * nj + 3);
+  A_(geom_xpos, 3 * ng + 3); A_(geom_xmat, 9 * ng + 9); A_(site_xpos, 3 * ns + 3);
+  A_(subtree_com, 3 * nb); A_(cinert, 10 * nb); A_(crb, 10 * nb); A_(cdof, 6 * nv + 18); A_(cvel, 6 * nb); A_(cdof_dot, 6 * nv + 18);
+  A_(cacc, 6 * nb); A_(cfrc, 6 * nb); A_(cfrc_sub, 6 * nb); A_(subtree_linvel, 3 * nb); A_(bodytmp, 3 * nb);
+  A_(qM, nv * nvp + 1); A_(qL, nv * nvp + 1); A_(qH, nv * nvp + 1); A_(Linv, nv + 1); A_(Hinv, nv + 1);
+  // efc_JA holds the scaled rows of the Newton Hessian: the active contact rows (padded to 8) + one negative row per cone
+  // contact (padded to 4)
+  int ja_rows = ((ne - M.nfric + 7) & ~7) + (m->cone == MJPC_CONE_ELLIPTIC ? ((nc + 3) & ~3) : 0) + 4;
+  A_(efc_J, ne * nvp + 1); A_(efc_JA, ja_rows * nvp + 1); A_(efc_D, ne); A_(efc_R, ne); A_(efc_aref, ne); A_(efc_force, ne); A_(efc_jar, ne); A_(efc_jv, ne);
+  A_(efc_floss, ne); A_(efc_pos, ne);
+  L.efc_margin = L.efc_jv; L.efc_diag = L.efc_force;
+  A_(contact, nc * M.con_stride + 1);
+  A_(Ma, nv + 1); A_(grad, nv + 1); A_(Mgrad, nv + 1); A_(search, nv + 1); A_(Mv, nv + 1); A_(vtmp, nv + 1); A_(sgl, 4 * nv + 1);
+  A_(knot_times, P_max); A_(knot_values, P_max * nu + 1); A_(residual, nr + 1); A_(terms, t->num_term + 1); A_(red, 8); A_(prof, 26);
+  A_(xfrc, 6 * nb); A_(mc_d, cache_d + 1); A_(mc_i, (cache_i + 2) / 2);
+  L.ints = o;
+#undef A_
+  int io = 0;
+  L.i_efc_type = io; io += ne; L.i_efc_id = io; io += ne; L.i_efc_state = io; io += ne; L.i_efc_dof = io; io += ne;
+  L.i_con = io; io += nc * CONI_STRIDE; L.i_active = io; io += (ne + nc > MAX_ACTIVE_PAIRS ? ne + nc : MAX_ACTIVE_PAIRS); L.i_misc = io; io += 28;
+  L.i_hpair = io; io += M.nmpair + nv;      // LDS copy of the Hessian/gradient entry table (i | j << 8)
+  L.total_doubles = o + (io + 1) / 2;
 }
 
 static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTask *t, int P_max) {
@@ -184,37 +218,14 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
   p.task_i_cap = p.ib.size() - p.task_i0; p.task_d_cap = p.db.size() - p.task_d0;
   // everything so far is LDS-cached; the keyframe tables (large, touched by a few residual terms only) stay in HBM
   p.cache_i = p.ib.size(); p.cache_d = p.db.size();
-  if (getenv("MJPC_HIP_NO_MODEL_CACHE")) { p.cache_i = 0; p.cache_d = 0; }      // only with a -DMJPC_NO_MODEL_CACHE engine build
   M.key_qpos = as_off<double>(put_d(p, m->key_qpos, (size_t)m->nkey * m->nq));
   M.key_mpos = as_off<double>(put_d(p, m->key_mpos, (size_t)m->nkey * 3 * m->nmocap));
-  // ---- LDS layout
-  Lay &L = p.L;
-  int o = 0;
-  int nvp = M.nvp, ne = M.nefcmax, nc = M.nconmax, nr = t->num_residual;
-#define A_(f, n) L.f = o; o += (int)(n)
-  A_(qpos, m->nq); A_(qvel, nv); A_(ctrl, nu + 1); A_(qacc, nv); A_(qacc_ws, nv); A_(qacc_smooth, nv); A_(qfrc_smooth, nv);
-  A_(qfrc_bias, nv); A_(qfrc_constraint, nv); A_(actuator_force, nu + 1); A_(mocap_pos, 3 * m->nmocap + 3); A_(mocap_quat, 4 * m->nmocap + 4);
-  A_(xpos, 3 * nb); A_(xquat, 4 * nb); A_(xmat, 9 * nb); A_(xipos, 3 * nb); A_(ximat, 9 * nb); A_(xanchor, 3 * nj + 3); A_(xaxis, 3 * nj + 3);
-  A_(geom_xpos, 3 * ng + 3); A_(geom_xmat, 9 * ng + 9); A_(site_xpos, 3 * ns + 3);
-  A_(subtree_com, 3 * nb); A_(cinert, 10 * nb); A_(crb, 10 * nb); A_(cdof, 6 * nv + 18); A_(cvel, 6 * nb); A_(cdof_dot, 6 * nv + 18);
-  A_(cacc, 6 * nb); A_(cfrc, 6 * nb); A_(cfrc_sub, 6 * nb); A_(subtree_linvel, 3 * nb); A_(bodytmp, 3 * nb);
-  A_(qM, nv * nvp + 1); A_(qL, nv * nvp + 1); A_(qH, nv * nvp + 1); A_(Linv, nv + 1); A_(Hinv, nv + 1);
-  // efc_JA holds the scaled rows of the Newton Hessian: active contact rows + one negative row per cone contact + padding
-  A_(efc_J, ne * nvp + 1); A_(efc_JA, (ne - M.nfric + (m->cone == MJPC_CONE_ELLIPTIC ? nc : 0) + 12) * nvp + 1); A_(efc_D, ne); A_(efc_R, ne); A_(efc_aref, ne); A_(efc_force, ne); A_(efc_jar, ne); A_(efc_jv, ne);
-  A_(efc_floss, ne); A_(efc_pos, ne); A_(efc_margin, ne); A_(efc_diag, ne);
-  A_(contact, nc * M.con_stride + 1);
-  A_(Ma, nv + 1); A_(grad, nv + 1); A_(Mgrad, nv + 1); A_(search, nv + 1); A_(Mv, nv + 1); A_(vtmp, nv + 1); A_(sgl, 4 * nv + 1);
-  A_(knot_times, P_max); A_(knot_values, P_max * nu + 1); A_(residual, nr + 1); A_(terms, t->num_term + 1); A_(red, 8); A_(prof, 26);
-  A_(xfrc, 6 * nb); A_(mc_d, p.cache_d + 1); A_(mc_i, (p.cache_i + 2) / 2);
-  L.ints = o;
-#undef A_
-  int io = 0;
-  L.i_efc_type = io; io += ne; L.i_efc_id = io; io += ne; L.i_efc_state = io; io += ne; L.i_efc_dof = io; io += ne;
-  L.i_con = io; io += nc * CONI_STRIDE; L.i_active = io; io += (ne + nc > MAX_ACTIVE_PAIRS ? ne + nc : MAX_ACTIVE_PAIRS); L.i_misc = io; io += 28;
-  L.i_hpair = io; io += M.nmpair + nv;      // LDS copy of the Hessian/gradient entry table (i | j << 8)
-  L.total_doubles = o + (io + 1) / 2;
+  // ---- LDS layout (MJPC_HIP_NO_MODEL_CACHE: only together with a -DMJPC_NO_MODEL_CACHE build of the engine)
+  if (getenv("MJPC_HIP_NO_MODEL_CACHE")) { p.cache_i = 0; p.cache_d = 0; }
+  make_layout(p, p.L, m, t, P_max, p.cache_d, p.cache_i);
   return true;
 }
+
 
 // turn offsets into real pointers for buffers living at (ibase, dbase)
 static inline DevModel relocate(const PackedModel &p, const int *ibase, const double *dbase) {

@@ -19,6 +19,7 @@ class ShardedSampler:
         self.dist = dist            # torch.distributed (already initialised) or None for world == 1
         self.device = device        # torch device for the collective buffers ("cuda:k" with nccl, "cpu" with gloo)
         self._buf = None
+        self.always_exchange = False      # tests: run the collective even with a single rank
 
     @property
     def num_trajectory(self):
@@ -33,18 +34,29 @@ class ShardedSampler:
     def exchange(self, out):
         """Pick the global elite.  Returns dict(winner, winner_return, winner_knots, owner) identical on all ranks."""
         knots = np.ascontiguousarray(out["winner_knots"], dtype=np.float64).ravel()
-        if self.world == 1 or self.dist is None:
+        if (self.world == 1 and not self.always_exchange) or self.dist is None:
             return dict(winner=int(out["winner"]), winner_return=float(out["winner_return"]), winner_knots=out["winner_knots"],
                         owner=0, local=out)
         import torch
         n = knots.size + 2
-        mine = torch.empty(n, dtype=torch.float64)
-        mine[0] = float(out["winner_return"]); mine[1] = float(out["winner"]); mine[2:] = torch.from_numpy(knots)
-        mine = mine.to(self.device)
+        on_gpu = str(self.device).startswith("cuda")
         if self._buf is None or self._buf.numel() != n * self.world:
+            # persistent buffers: pinned host staging on GPUs so that the two tiny copies around the collective are asynchronous
             self._buf = torch.empty(n * self.world, dtype=torch.float64, device=self.device)
-        self.dist.all_gather_into_tensor(self._buf, mine)
-        allv = self._buf.view(self.world, n).cpu().numpy()
+            self._mine_h = torch.empty(n, dtype=torch.float64, pin_memory=on_gpu)
+            self._all_h = torch.empty(n * self.world, dtype=torch.float64, pin_memory=on_gpu)
+            self._mine_d = torch.empty(n, dtype=torch.float64, device=self.device) if on_gpu else self._mine_h
+        mh = self._mine_h.numpy()
+        mh[0] = float(out["winner_return"]); mh[1] = float(out["winner"]); mh[2:] = knots
+        if on_gpu:
+            self._mine_d.copy_(self._mine_h, non_blocking=True)
+            self.dist.all_gather_into_tensor(self._buf, self._mine_d)
+            self._all_h.copy_(self._buf, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+            allv = self._all_h.numpy().reshape(self.world, n)
+        else:
+            self.dist.all_gather_into_tensor(self._buf, self._mine_h)
+            allv = self._buf.view(self.world, n).numpy()
         best = 0
         for r in range(1, self.world):      # lexicographic (return, index): lowest index on ties
             if allv[r, 0] < allv[best, 0] or (allv[r, 0] == allv[best, 0] and allv[r, 1] < allv[best, 1]):

@@ -599,3 +599,35 @@ def test_tree_and_dense_factor_orders_give_the_same_rollouts(name, N, H, P, sigm
     # 3.8e-7 (A1, 40 steps) and 1.7e-13 (humanoid) on the states, 2.6e-9 relative on the returns
     assert np.allclose(o0["returns"], o1["returns"], rtol=1e-6, atol=1e-12)
     assert np.allclose(a0["states"], a1["states"], rtol=0, atol=5e-6)
+
+
+@pytest.mark.gpu
+def test_elite_exchange_over_rccl_single_rank():
+    """the RCCL path of the elite exchange (pinned staging, all_gather_into_tensor on the device, one stream sync) with a
+    one-rank group: the exchanged elite is the local one; the 2-rank logic is covered by the gloo tests on CPU"""
+    import os
+    import torch
+    import torch.distributed as dist
+    from mujoco_mpc_amd.modelgen import particle
+    from mujoco_mpc_amd.planner import HipBackend
+    from mujoco_mpc_amd.sharded import ShardedSampler
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29541")
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        m, task, d = particle()
+        N, H, P = 16, 11, 4
+        be = HipBackend(m, task, max_samples=N, max_horizon=H)
+        sampler = ShardedSampler(be, 0, 1, N, dist=dist, device="cuda:0")
+        sampler.always_exchange = True
+        kt = np.linspace(0, 1.0, P); kv = np.zeros((P, m["nu"]))
+        for it in range(3):
+            res = sampler.plan(state=d["state"], mocap=d["mocap"], time=0.0, knot_times=kt, knot_values=kv, interpolation=2, horizon=H,
+                               sigma=(0.05, 0.0), seed=7, stream=it)
+            loc = res["local"]
+            assert res["winner"] == loc["winner"] and res["owner"] == 0
+            assert res["winner_return"] == loc["winner_return"]
+            assert np.array_equal(res["winner_knots"], loc["winner_knots"])
+        be.close()
+    finally:
+        dist.destroy_process_group()

@@ -2,7 +2,7 @@
 Never used for timing claims (stamps perturb the schedule); only the shares matter."""
 import ctypes as C, os, subprocess, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.abspath(__file__)); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 CSRC = os.path.join(ROOT, "mujoco_mpc_amd", "csrc")
 so = os.path.join(ROOT, "gpurun_out", "libmjpc_hip_prof.so")
 os.makedirs(os.path.dirname(so), exist_ok=True)

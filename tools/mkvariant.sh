@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools/mkvariant.sh name "-DFLAG=.. ..."   -> scratch/lib_<name>.so
+# usage: tools/mkvariant.sh name "-DFLAG=.. ..."   -> build/variants/lib_<name>.so
 set -e
 mkdir -p /root/repo/build/variants
 cd /root/repo/mujoco_mpc_amd/csrc

@@ -220,8 +220,10 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
   p.cache_i = p.ib.size(); p.cache_d = p.db.size();
   M.key_qpos = as_off<double>(put_d(p, m->key_qpos, (size_t)m->nkey * m->nq));
   M.key_mpos = as_off<double>(put_d(p, m->key_mpos, (size_t)m->nkey * 3 * m->nmocap));
-  // ---- LDS layout (MJPC_HIP_NO_MODEL_CACHE: only together with a -DMJPC_NO_MODEL_CACHE build of the engine)
-  if (getenv("MJPC_HIP_NO_MODEL_CACHE")) { p.cache_i = 0; p.cache_d = 0; }
+  // ---- LDS layout
+#ifdef MJPC_NO_MODEL_CACHE      // experiment build: the kernel reads the tables from HBM, no LDS copy to size
+  p.cache_i = 0; p.cache_d = 0;
+#endif
   make_layout(p, p.L, m, t, P_max, p.cache_d, p.cache_i);
   return true;
 }

@@ -194,12 +194,15 @@ DEV void kin_joint_local(Ctx &c, int j, double *jq) {
   } else if (type == 1) {
     d_normalize4(c.qpos + qa);
     d_copy4(jq + 4 * j, c.qpos + qa);
+  } else if (type == 0) {
+    d_normalize4(c.qpos + qa + 3);
   }
 }
-DEV void kin_body(Ctx &c, int i, const double *jq) {
+// pose of body i from its parent's pose held in registers (have_parent: the parent is not the world); `store`: i is the body
+// this lane is responsible for, its pose and its joints' anchors / axes go to LDS
+DEV void kin_compose(Ctx &c, int i, const double *jq, const double *ppos, const double *pquat, const double *pmat, int have_parent,
+                     double *xpos, double *xquat, double *xm, int store) {
   const DevModel &M = *c.M;
-  double xpos[3], xquat[4];
-  int pid = MI(body_parentid)[i];
   int jntnum = MI(body_jntnum)[i], jntadr = MI(body_jntadr)[i];
   int mid = MI(body_mocapid)[i];
   if (mid >= 0) {
@@ -208,16 +211,17 @@ DEV void kin_body(Ctx &c, int i, const double *jq) {
     d_normalize4(xquat);
   } else if (jntnum == 1 && MI(jnt_type)[jntadr] == 0) {
     int qa = MI(jnt_qposadr)[jntadr];
-    d_normalize4(c.qpos + qa + 3);
     d_copy3(xpos, c.qpos + qa);
-    d_copy4(xquat, c.qpos + qa + 3);
-    d_copy3(c.xanchor + 3 * jntadr, xpos);
-    d_copy3(c.xaxis + 3 * jntadr, MD(jnt_axis) + 3 * jntadr);
+    d_copy4(xquat, c.qpos + qa + 3);              // normalised in place by kin_joint_local
+    if (store) {
+      d_copy3(c.xanchor + 3 * jntadr, xpos);
+      d_copy3(c.xaxis + 3 * jntadr, MD(jnt_axis) + 3 * jntadr);
+    }
   } else {
-    if (pid) {
-      d_mulmatvec3(xpos, c.xmat + 9 * pid, MD(body_pos) + 3 * i);
-      d_add3(xpos, xpos, c.xpos + 3 * pid);
-      d_mulquat(xquat, c.xquat + 4 * pid, MD(body_quat) + 4 * i);
+    if (have_parent) {
+      d_mulmatvec3(xpos, pmat, MD(body_pos) + 3 * i);
+      d_add3(xpos, xpos, ppos);
+      d_mulquat(xquat, pquat, MD(body_quat) + 4 * i);
     } else {
       d_copy3(xpos, MD(body_pos) + 3 * i);
       d_copy4(xquat, MD(body_quat) + 4 * i);
@@ -227,13 +231,14 @@ DEV void kin_body(Ctx &c, int i, const double *jq) {
       d_quat2mat(m, xquat);                       // rotation of the frame the next joint is expressed in
       for (int j = jntadr; j < jntadr + jntnum; j++) {
         int qa = MI(jnt_qposadr)[j], type = MI(jnt_type)[j];
-        double vec[3], ax[3], jp[3];
+        double vec[3], ax[3], jp[3], xax[3], xan[3];
         d_copy3(ax, MD(jnt_axis) + 3 * j); d_copy3(jp, MD(jnt_pos) + 3 * j);
-        d_mulmatvec3(c.xaxis + 3 * j, m, ax);
+        d_mulmatvec3(xax, m, ax);
         d_mulmatvec3(vec, m, jp);
-        d_add3(c.xanchor + 3 * j, vec, xpos);
+        d_add3(xan, vec, xpos);
+        if (store) { d_copy3(c.xaxis + 3 * j, xax); d_copy3(c.xanchor + 3 * j, xan); }
         if (type == 2) {
-          d_addtoscl3(xpos, c.xaxis + 3 * j, c.qpos[qa] - MD(qpos0)[qa]);
+          d_addtoscl3(xpos, xax, c.qpos[qa] - MD(qpos0)[qa]);
         } else {
           double qloc[4], t[4];
           d_copy4(qloc, jq + 4 * j);
@@ -241,17 +246,18 @@ DEV void kin_body(Ctx &c, int i, const double *jq) {
           d_copy4(xquat, t);
           d_quat2mat(m, xquat);
           d_mulmatvec3(vec, m, jp);
-          d_sub3(xpos, c.xanchor + 3 * j, vec);
+          d_sub3(xpos, xan, vec);
         }
       }
     }
   }
   d_normalize4(xquat);
-  d_copy3(c.xpos + 3 * i, xpos);
-  d_copy4(c.xquat + 4 * i, xquat);
-  double xm[9];
   d_quat2mat(xm, xquat);
-  for (int k = 0; k < 9; k++) c.xmat[9 * i + k] = xm[k];
+  if (store) {
+    d_copy3(c.xpos + 3 * i, xpos);
+    d_copy4(c.xquat + 4 * i, xquat);
+    for (int k = 0; k < 9; k++) c.xmat[9 * i + k] = xm[k];
+  }
 }
 
 DEV void kinematics(Ctx &c) {
@@ -259,11 +265,21 @@ DEV void kinematics(Ctx &c) {
   double *jq = c.cdof_dot;                        // scratch: rebuilt by the velocity stage after the next barrier
   PFOR(j, M.njnt) kin_joint_local(c, j, jq);
   SYNC();
-  for (int l = 0; l < M.nlevel; l++) {
-    int a = MI(level_adr)[l], n = MI(level_adr)[l + 1] - a;
-    PFOR(k, n) kin_body(c, MI(level_body)[a + k], jq);
-    SYNC();
+  // one lane per body walks its own ancestor chain with the running pose in registers: the ancestors' poses are recomputed per
+  // lane (same arithmetic, same results) instead of being handed down through LDS with a barrier per tree level
+  PFOR(b, M.nbody) {
+    if (b == 0) continue;
+    double ppos[3], pquat[4], pmat[9], xpos[3], xquat[4], xm[9];
+    int have = 0;
+    for (int q = MI(chain_adr)[b]; q < MI(chain_adr)[b + 1]; q++) {
+      int a = MI(chain_list)[q];
+      kin_compose(c, a, jq, ppos, pquat, pmat, have, xpos, xquat, xm, a == b);
+      d_copy3(ppos, xpos); d_copy4(pquat, xquat);
+      for (int k = 0; k < 9; k++) pmat[k] = xm[k];
+      have = 1;
+    }
   }
+  SYNC();
   PFOR(i, M.nbody) {
     if (i == 0) continue;
     double v[3], q[4], ip[3], iq[4], xm[9];

@@ -158,6 +158,17 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
     }
     adr[nb] = (int)list.size();
     M.subtree_adr = as_off<int>(put_i(p, adr.data(), adr.size())); M.subtree_list = as_off<int>(put_i(p, list.data(), list.size())); }
+  // ancestor chains (kinematics walks them in registers instead of sweeping the tree level by level)
+  { std::vector<int> adr(nb + 1, 0), list;
+    for (int b = 0; b < nb; b++) {
+      adr[b] = (int)list.size();
+      std::vector<int> up;
+      for (int a = b; a > 0; a = m->body_parentid[a]) up.push_back(a);
+      for (size_t k = up.size(); k-- > 0;) list.push_back(up[k]);
+    }
+    adr[nb] = (int)list.size();
+    list.push_back(0);
+    M.chain_adr = as_off<int>(put_i(p, adr.data(), adr.size())); M.chain_list = as_off<int>(put_i(p, list.data(), list.size())); }
   // non-zeros of the joint-space inertia
   { std::vector<int> pi, pj;
     for (int i = 0; i < nv; i++) for (int j = i; j >= 0; j = m->dof_parentid[j]) { pi.push_back(i); pj.push_back(j); }
@@ -249,7 +260,7 @@ static inline DevModel relocate(const PackedModel &p, const int *ibase, const do
   fd(M.key_qpos); fd(M.key_mpos);
   fi(M.tendon_adr); fi(M.tendon_num); fi(M.tendon_limited); fi(M.wrap_dofadr); fi(M.wrap_qposadr);
   fd(M.wrap_prm); fd(M.tendon_range); fd(M.tendon_margin); fd(M.tendon_solref_lim); fd(M.tendon_solimp_lim); fd(M.tendon_invweight0);
-  fi(M.level_adr); fi(M.level_body); fi(M.subtree_adr); fi(M.subtree_list); fi(M.mpair_i); fi(M.mpair_j); fi(M.zpair_i); fi(M.zpair_j);
+  fi(M.level_adr); fi(M.level_body); fi(M.subtree_adr); fi(M.subtree_list); fi(M.chain_adr); fi(M.chain_list); fi(M.mpair_i); fi(M.mpair_j); fi(M.zpair_i); fi(M.zpair_j);
   { const double *q = reinterpret_cast<const double *>(M.body_dofmask); fd(q); M.body_dofmask = reinterpret_cast<const unsigned long long *>(q); }
   fi(M.pair_g1); fi(M.pair_g2); fi(M.fric_dof); fi(M.limit_jnt); fi(M.ray_geom);
   DevTask &T = M.task;

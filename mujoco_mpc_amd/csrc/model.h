@@ -84,6 +84,7 @@ struct DevModel {
   // derived on the host at create()
   const int *level_adr, *level_body;        // bodies grouped by tree depth (depth >= 1)
   const int *subtree_adr, *subtree_list;    // bodies of each subtree, self first, ascending ids
+  const int *chain_adr, *chain_list;        // ancestors of each body from the root's child down to the body itself
   const int *mpair_i, *mpair_j;             // (dof i, ancestor-or-self dof j): the non-zeros of M
   const int *zpair_i, *zpair_j;             // the rest of the lower triangle (structural zeros of M)
   const unsigned long long *body_dofmask;   // bit d set <=> dof d moves body

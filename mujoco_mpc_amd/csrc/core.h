@@ -1030,15 +1030,76 @@ DEV void vel_body(Ctx &c, int i) {
   d_scl3(c.bodytmp + 3 * i, v, MD(body_mass)[i]);
 }
 
+// com velocity and RNE acceleration of body i from its parent's (in registers), same operation order as vel_body; `store`: i is
+// the lane's own body: cvel, cdof_dot of its dofs, cacc, cfrc_body and its momentum go to LDS (deep trees, see velocity_stage)
+DEV void vel_compose(Ctx &c, int i, double *cvel, double *a, int store) {
+  const DevModel &M = *c.M;
+  int bda = MI(body_dofadr)[i];
+  for (int j = MI(body_jntadr)[i]; j < MI(body_jntadr)[i] + MI(body_jntnum)[i]; j++) {
+    int type = MI(jnt_type)[j];
+    if (type == 0) {
+      if (store) for (int k = 0; k < 18; k++) c.cdof_dot[6 * bda + k] = 0;
+      for (int k = 0; k < 3; k++) for (int q = 0; q < 6; q++) a[q] += 0.0 * c.qvel[bda + k];
+      for (int k = 0; k < 3; k++) for (int q = 0; q < 6; q++) cvel[q] += c.cdof[6 * (bda + k) + q] * c.qvel[bda + k];
+      bda += 3;
+    }
+    if (type == 0 || type == 1) {
+      for (int k = 0; k < 3; k++) {
+        double r[6];
+        d_crossmotion(r, cvel, c.cdof + 6 * (bda + k));
+        if (store) for (int q = 0; q < 6; q++) c.cdof_dot[6 * (bda + k) + q] = r[q];
+        for (int q = 0; q < 6; q++) a[q] += r[q] * c.qvel[bda + k];
+      }
+      for (int k = 0; k < 3; k++) for (int q = 0; q < 6; q++) cvel[q] += c.cdof[6 * (bda + k) + q] * c.qvel[bda + k];
+      bda += 3;
+    } else {
+      double r[6];
+      d_crossmotion(r, cvel, c.cdof + 6 * bda);
+      if (store) for (int q = 0; q < 6; q++) c.cdof_dot[6 * bda + q] = r[q];
+      for (int q = 0; q < 6; q++) a[q] += r[q] * c.qvel[bda];
+      for (int q = 0; q < 6; q++) cvel[q] += c.cdof[6 * bda + q] * c.qvel[bda];
+      bda++;
+    }
+  }
+  if (!store) return;
+  for (int k = 0; k < 6; k++) { c.cvel[6 * i + k] = cvel[k]; c.cacc[6 * i + k] = a[k]; }
+  double t1[6], t2[6], t3[6];
+  d_mulinertvec(t1, c.cinert + 10 * i, a);
+  d_mulinertvec(t2, c.cinert + 10 * i, cvel);
+  d_crossforce(t3, cvel, t2);
+  for (int k = 0; k < 6; k++) c.cfrc[6 * i + k] = t1[k] + t3[k];
+  double off[3], v[3];
+  d_sub3(off, c.xipos + 3 * i, c.subtree_com + 3 * MI(body_rootid)[i]);
+  d_cross(v, cvel, off);
+  d_add3(v, v, cvel + 3);
+  d_scl3(c.bodytmp + 3 * i, v, MD(body_mass)[i]);
+}
+
 // mfact_seq != 0: M's factor is produced by a helper wave; wait for its sequence number (misc[22]) before the solve
 template <int NVT>
 DEV void velocity_stage(Ctx &c, int mfact_seq) {
   const DevModel &M = *c.M;
   int nv = M.nv;
-  for (int l = 0; l < M.nlevel; l++) {
-    int a = MI(level_adr)[l], n = MI(level_adr)[l + 1] - a;
-    PFOR(k, n) vel_body(c, MI(level_body)[a + k]);
+  if constexpr (NVT == 27) {
+    // the humanoid's 8 tree levels: one lane per body walks its ancestor chain with the running velocity / acceleration in
+    // registers, like kinematics (-1.3 % of its step; the A1's 4 levels are cheaper as a level sweep, and keeping both forms in
+    // one instantiation costs it +0.7 %, hence the compile-time choice)
+    PFOR(b, M.nbody) {
+      if (b == 0) continue;
+      double cvel[6], acc[6];
+      for (int k = 0; k < 6; k++) { cvel[k] = c.cvel[k]; acc[k] = c.cacc[k]; }      // the world body: 0 and -gravity
+      for (int q = MI(chain_adr)[b]; q < MI(chain_adr)[b + 1]; q++) {
+        int a = MI(chain_list)[q];
+        vel_compose(c, a, cvel, acc, a == b);
+      }
+    }
     SYNC();
+  } else {
+    for (int l = 0; l < M.nlevel; l++) {
+      int a = MI(level_adr)[l], n = MI(level_adr)[l + 1] - a;
+      PFOR(k, n) vel_body(c, MI(level_body)[a + k]);
+      SYNC();
+    }
   }
   PROFW(c, 1);
   PFOR(e, M.nbody * 9) {

@@ -51,10 +51,21 @@ enum {
   MJPC_TASK_COPYSTATE = 3,  /* residual = [qpos,qvel] (mjpc/test/agent/rollout_test.cc:40-60) */
   MJPC_TASK_HUMANOID_TRACK = 4, /* mjpc/tasks/humanoid/tracking/tracking.cc:94-216 */
   MJPC_TASK_HUMANOID_STAND = 5, /* mjpc/tasks/humanoid/stand/stand.cc:41-94 */
-  MJPC_TASK_HUMANOID_WALK = 6   /* mjpc/tasks/humanoid/walk/walk.cc:44-166 */
+  MJPC_TASK_HUMANOID_WALK = 6,  /* mjpc/tasks/humanoid/walk/walk.cc:44-166 */
+  MJPC_TASK_SHADOW_REORIENT = 7 /* mjpc/tasks/shadow_reorient/hand.cc:37-84; int_data = [palm site, cube body, goal body, key] */
 };
+enum { MJPC_TRN_JOINT = 0, MJPC_TRN_TENDON = 3 };   /* mjtTrn values of the supported actuator transmissions */
 enum { MJPC_OBJ_BODY = 1, MJPC_OBJ_XBODY = 2, MJPC_OBJ_GEOM = 5, MJPC_OBJ_SITE = 6 };
 
+/* failure[] bits: why a candidate's rollout stopped (any bit => total_return = MJPC_MAX_RETURN, like
+ * CheckWarnings -> failure, mjpc/utilities.cc:787-799 + trajectory.cc:169-173) */
+enum {
+  MJPC_WARN_BADQPOS = 1, MJPC_WARN_BADQVEL = 2, MJPC_WARN_BADQACC = 4,   /* mjWARN_BADQPOS / BADQVEL / BADQACC */
+  MJPC_WARN_CONTACTFULL = 8, MJPC_WARN_CNSTRFULL = 16,                    /* mjWARN_CONTACTFULL / CNSTRFULL (nconmax / nefcmax) */
+  MJPC_WARN_RAY = 32,                                                     /* Ground() ray hit nothing (utilities.cc:549-552) */
+  MJPC_WARN_SYNC = 64,                                                    /* engine-internal: a wave hand-shake timed out */
+  MJPC_WARN_UNSUPPORTED = 128   /* a geom pair without a collider (cylinder vs non-plane) came within reach of contact */
+};
 #define MJPC_MINVAL 1e-15           /* mjMINVAL */
 #define MJPC_MAX_RETURN 1.0e6       /* kMaxReturnValue, mjpc/trajectory.cc:29 */
 #define MJPC_MAX_COST_TERMS 128     /* kMaxCostTerms, mjpc/task.h */
@@ -103,8 +114,9 @@ typedef struct MjpcHipModel {
   /* sites */
   const int *site_bodyid;
   const double *site_pos, *site_quat;
-  /* actuators (joint transmission only; gain fixed; bias none/affine) */
-  const int *actuator_trnid;        /* joint id (first of the 2 mjModel ints) */
+  /* actuators (joint or fixed-tendon transmission; gain fixed; bias none/affine: motor, general, position servos) */
+  const int *actuator_trntype;      /* MJPC_TRN_JOINT / MJPC_TRN_TENDON */
+  const int *actuator_trnid;        /* joint id or tendon id (first of the 2 mjModel ints) */
   const int *actuator_ctrllimited, *actuator_forcelimited, *actuator_biastype;
   const double *actuator_gainprm;   /* 3 per actuator (first 3 of mjNGAIN) */
   const double *actuator_biasprm;   /* 3 per actuator (first 3 of mjNBIAS) */
@@ -199,16 +211,21 @@ typedef struct MjpcHipPlanOutput {
 typedef struct MjpcHipEngine MjpcHipEngine;
 
 /* Create an engine on HIP device `device`.  Copies model+task to HBM.  max_local = largest
- * num_local that will be planned on this device.  Returns NULL on error (see last_error). */
+ * num_local that will be planned on this device.  Returns NULL on error (see last_error).
+ * Models the engine cannot roll out faithfully are REFUSED here (never silently approximated): geom pairs without a
+ * collider (hfield / ellipsoid / mesh, cylinder against anything but a plane), limited ball joints, nuserdata > 0,
+ * na > 0, nconmax > 64, nefcmax > 192, iterations > 250, num_spline_points capacity 36, LDS footprint > 160 KiB. */
 MjpcHipEngine *mjpc_hip_create(const MjpcHipModel *model, const MjpcHipTask *task,
                                int max_local, int max_horizon, int device);
 void mjpc_hip_destroy(MjpcHipEngine *e);
 /* Re-upload cost weights / norm params / residual parameters / frozen task state
- * (Agent::PlanIteration takes a fresh ResidualFn copy every plan step, agent.cc:290). */
+ * (Agent::PlanIteration takes a fresh ResidualFn copy every plan step, agent.cc:290): only the task block travels,
+ * as one stream-ordered asynchronous copy ahead of the next plan's kernels.  Error while a plan is in flight. */
 int mjpc_hip_set_task(MjpcHipEngine *e, const MjpcHipTask *task);
 /* One plan step: noise -> N rollouts -> costs -> argmin; blocking. 0 on success. */
 int mjpc_hip_plan(MjpcHipEngine *e, const MjpcHipPlanInput *in, MjpcHipPlanOutput *out);
-/* Split form used by bench.py / multi-GPU: enqueue on the engine's stream, then fetch. */
+/* Split form used by bench.py / multi-GPU: enqueue on the engine's stream, then fetch.  One plan in flight per engine:
+ * a second mjpc_hip_plan_async before mjpc_hip_plan_fetch is an error. */
 int mjpc_hip_plan_async(MjpcHipEngine *e, const MjpcHipPlanInput *in);
 int mjpc_hip_plan_fetch(MjpcHipEngine *e, MjpcHipPlanOutput *out);
 /* Copy any local candidate's trajectory / knots to host (GUI traces, RankedPlanner). */
@@ -216,6 +233,19 @@ int mjpc_hip_get_candidate(MjpcHipEngine *e, int local_index, MjpcHipPlanOutput 
 /* Copy every local candidate's knot values [num_local][P][nu] of the last plan to host (elite statistics of the
  * Cross-Entropy planner, cross_entropy/planner.cc:226-262). */
 int mjpc_hip_get_knots(MjpcHipEngine *e, double *knots);
+/* Every local candidate's trace rows [num_local][H][3*num_trace] of the last plan in one copy: what
+ * SamplingPlanner::Traces draws (mjpc/planners/sampling/planner.cc:388-434). */
+int mjpc_hip_get_traces(MjpcHipEngine *e, double *traces);
+/* Every local candidate's Trajectory arrays of the last plan, [num_local][H][...] each (any pointer may be NULL): the
+ * `trajectory[]` members other planners read (mjpc/planners/ilqs/planner.cc:98-198).  diag: [num_local][4] = Newton
+ * iterations summed over the steps, max contacts, max constraint rows, MJPC_WARN_* bits. */
+int mjpc_hip_get_all_candidates(MjpcHipEngine *e, double *states, double *actions, double *times, double *residual,
+                                double *costs, double *trace, double *knots, int *diag);
+/* Bytes of LDS one candidate's workgroup occupies (its whole mjData-equivalent). */
+int mjpc_hip_lds_bytes(MjpcHipEngine *e);
+/* The same figure for a model without creating an engine (host-only, no GPU needed): with (1) / without (0) the LDS copy of
+ * the model tables.  Negative: mjpc_hip_create would refuse the model (see mjpc_hip_last_error). */
+int mjpc_hip_layout_bytes(const MjpcHipModel *model, const MjpcHipTask *task, int use_cache);
 /* Kinematic frame of local candidate 0 at the first step of the last plan (the state handed in): what a host-side
  * Task::Transition reads from mjData after a simulation step (mjpc/tasks/quadruped/quadruped.cc:254,290-330: body poses, site
  * positions, subtree com / linear velocity sensors).  Any pointer may be NULL.  Sizes: xpos 3*nbody, xmat 9*nbody,

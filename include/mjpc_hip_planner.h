@@ -152,7 +152,8 @@ class SamplingPlanner {
   SamplingPolicy winner_policy_;               // candidate_policy[winner]
   TimeSpline plan_scratch_;
   std::vector<double> knot_times_, knot_values_, winner_knots_;
-  int last_horizon_ = 0, fetched_ = -1;
+  int last_horizon_ = 0, fetched_ = -1, nominal_horizon_ = 0;
+  MjpcHipEngine* nominal_engine_ = nullptr;            // one-candidate engine of NominalTrajectory()
   mutable std::shared_mutex mtx_;
 };
 

@@ -43,7 +43,7 @@ class MjpcHipModel(C.Structure):
         + [(n, c_double_p) for n in ["geom_size", "geom_pos", "geom_quat", "geom_friction", "geom_solmix",
                                      "geom_solref", "geom_solimp", "geom_margin", "geom_gap", "geom_rbound"]]
         + [("exclude_signature", c_int_p), ("site_bodyid", c_int_p), ("site_pos", c_double_p), ("site_quat", c_double_p)]
-        + [(n, c_int_p) for n in ["actuator_trnid", "actuator_ctrllimited", "actuator_forcelimited", "actuator_biastype"]]
+        + [(n, c_int_p) for n in ["actuator_trntype", "actuator_trnid", "actuator_ctrllimited", "actuator_forcelimited", "actuator_biastype"]]
         + [(n, c_double_p) for n in ["actuator_gainprm", "actuator_biasprm", "actuator_gear", "actuator_ctrlrange",
                                      "actuator_forcerange"]]
         + [(n, c_int_p) for n in ["tendon_adr", "tendon_num", "tendon_limited", "wrap_objid"]]
@@ -207,8 +207,10 @@ def load_engine():
     lib.mjpc_hip_get_frame.argtypes = [C.c_void_p] + [c_double_p] * 5
     lib.mjpc_hip_kernel_time.argtypes = [C.c_void_p, c_double_p, c_double_p]
     lib.mjpc_hip_device_ptrs.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
-    lib.mjpc_hip_debug_fetch_all.argtypes = [C.c_void_p] + [c_double_p] * 7 + [c_int_p]
+    lib.mjpc_hip_get_all_candidates.argtypes = [C.c_void_p] + [c_double_p] * 7 + [c_int_p]
+    lib.mjpc_hip_get_traces.argtypes = [C.c_void_p, c_double_p]
     lib.mjpc_hip_lds_bytes.argtypes = [C.c_void_p]
+    lib.mjpc_hip_layout_bytes.argtypes = [C.POINTER(MjpcHipModel), C.POINTER(MjpcHipTask), C.c_int]
     lib.mjpc_hip_last_error.restype = C.c_char_p
     lib.mjpc_hip_version.restype = C.c_int
     _engine = lib
@@ -219,4 +221,5 @@ EXPORTED_SYMBOLS = [
     "mjpc_hip_create", "mjpc_hip_destroy", "mjpc_hip_set_task", "mjpc_hip_plan", "mjpc_hip_plan_async",
     "mjpc_hip_plan_fetch", "mjpc_hip_get_candidate", "mjpc_hip_kernel_time", "mjpc_hip_device_ptrs",
     "mjpc_hip_last_error", "mjpc_hip_version", "mjpc_hip_get_knots", "mjpc_hip_get_frame",
+    "mjpc_hip_get_traces", "mjpc_hip_get_all_candidates", "mjpc_hip_lds_bytes", "mjpc_hip_layout_bytes",
 ]

@@ -586,6 +586,235 @@ DEV int np_sphere_box(NPCon *con, double margin, const double *sp, double sr, co
   return 1;
 }
 
+// capsule (geom1) vs box (geom2): closest point of the segment to the box by a fixed-count bisection of the monotone derivative
+// (the CPU checker restates the same construction with the same operations), then sphere-box there and at the far end cap
+DEV double capsule_box_g(const double *p0, const double *a, double h, const double *b, double s) {
+  double g = 0;
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    double q = p0[i] + (s * h) * a[i];
+    double e = fabs(q) - b[i];
+    g += (e > 0) ? (q > 0 ? e : -e) * a[i] : 0.0;
+  }
+  return g;
+}
+DEV int np_capsule_box(NPCon *con, double margin, const double *cp, const double *cm, const double *cs,
+                       const double *bp, const double *bm, const double *bs) {
+  double axis[3] = {cm[2], cm[5], cm[8]}, dif[3], p0[3], a[3];
+  d_sub3(dif, cp, bp);
+  d_mulmattvec3(p0, bm, dif);
+  d_mulmattvec3(a, bm, axis);
+  double h = cs[1], sstar;
+  if (capsule_box_g(p0, a, h, bs, -1.0) >= 0) sstar = -1.0;
+  else if (capsule_box_g(p0, a, h, bs, 1.0) <= 0) sstar = 1.0;
+  else {
+    double lo = -1.0, hi = 1.0;
+    for (int it = 0; it < 48; it++) {
+      double mid = 0.5 * (lo + hi);
+      if (capsule_box_g(p0, a, h, bs, mid) < 0) lo = mid; else hi = mid;
+    }
+    sstar = 0.5 * (lo + hi);
+  }
+  int cnt = 0;
+  double pt[3];
+  NPCon t;
+  d_addscl3(pt, cp, axis, sstar * h);
+  if (np_sphere_box(&t, margin, pt, cs[0], bp, bm, bs)) { con[0] = t; cnt++; }
+  double s2 = sstar <= 0 ? 1.0 : -1.0;
+  d_addscl3(pt, cp, axis, s2 * h);
+  if (np_sphere_box(&t, margin, pt, cs[0], bp, bm, bs)) { np_put(con, cnt, t); cnt++; }
+  return cnt;
+}
+
+// box (geom1 = A) vs box (geom2 = B): separating-axis test, then reference-face clipping (<= 4 contacts) or one edge-edge
+// contact (DESIGN.md section 6 describes the construction).  Axis-indexed accesses go through selects so that
+// nothing needs a run-time-indexed private array.
+#define BB_TOL 1e-9
+DEV double sel3(const double *v, int i) { return i == 0 ? v[0] : (i == 1 ? v[1] : v[2]); }
+DEV void col3(double *r, const double *m, int k) { r[0] = k == 0 ? m[0] : (k == 1 ? m[1] : m[2]); r[1] = k == 0 ? m[3] : (k == 1 ? m[4] : m[5]); r[2] = k == 0 ? m[6] : (k == 1 ? m[7] : m[8]); }
+struct BBSel { double x, y, d; int ok; };
+// candidate q of the face case: 0-3 incident vertices, 4-7 reference corners, 8-23 edge crossings
+struct BBFace { double c0[3], e1[3], e2[3], hu, hv, det; };
+DEV BBSel bb_candidate(const BBFace &f, int q) {
+  BBSel o; o.ok = 0; o.x = 0; o.y = 0; o.d = 0;
+  if (q < 4) {
+    double s1 = (q == 0 || q == 3) ? -1.0 : 1.0, s2 = (q < 2) ? -1.0 : 1.0;
+    double x = f.c0[0] + s1 * f.e1[0] + s2 * f.e2[0], y = f.c0[1] + s1 * f.e1[1] + s2 * f.e2[1], d = f.c0[2] + s1 * f.e1[2] + s2 * f.e2[2];
+    if (fabs(x) <= f.hu + BB_TOL && fabs(y) <= f.hv + BB_TOL) { o.ok = 1; o.x = x; o.y = y; o.d = d; }
+  } else if (q < 8) {
+    int k = q - 4;
+    if (fabs(f.det) > 1e-14) {
+      double cx = (k == 0 || k == 3) ? -f.hu : f.hu, cy = (k < 2) ? -f.hv : f.hv;
+      double dx = cx - f.c0[0], dy = cy - f.c0[1];
+      double al = (dx * f.e2[1] - dy * f.e2[0]) / f.det, be = (f.e1[0] * dy - f.e1[1] * dx) / f.det;
+      if (fabs(al) <= 1.0 + BB_TOL && fabs(be) <= 1.0 + BB_TOL) { o.ok = 1; o.x = cx; o.y = cy; o.d = f.c0[2] + al * f.e1[2] + be * f.e2[2]; }
+    }
+  } else {
+    int k = (q - 8) >> 2, e = (q - 8) & 3, k2 = (k + 1) & 3;
+    double a1 = (k == 0 || k == 3) ? -1.0 : 1.0, a2 = (k < 2) ? -1.0 : 1.0, b1 = (k2 == 0 || k2 == 3) ? -1.0 : 1.0, b2 = (k2 < 2) ? -1.0 : 1.0;
+    double px = f.c0[0] + a1 * f.e1[0] + a2 * f.e2[0], py = f.c0[1] + a1 * f.e1[1] + a2 * f.e2[1], pd = f.c0[2] + a1 * f.e1[2] + a2 * f.e2[2];
+    double qx = f.c0[0] + b1 * f.e1[0] + b2 * f.e2[0], qy = f.c0[1] + b1 * f.e1[1] + b2 * f.e2[1], qd = f.c0[2] + b1 * f.e1[2] + b2 * f.e2[2];
+    double dx = qx - px, dy = qy - py, dd = qd - pd;
+    int xline = e < 2;
+    double lim = (e & 1) ? 1.0 : -1.0;
+    double num = xline ? lim * f.hu - px : lim * f.hv - py, den = xline ? dx : dy;
+    if (!(fabs(den) < 1e-14)) {
+      double s = num / den;
+      if (!(s <= 0.0 || s >= 1.0)) {
+        double ox = xline ? lim * f.hu : px + s * dx, oy = xline ? py + s * dy : lim * f.hv;
+        if (!((xline ? fabs(oy) - f.hv : fabs(ox) - f.hu) > BB_TOL)) { o.ok = 1; o.x = ox; o.y = oy; o.d = pd + s * dd; }
+      }
+    }
+  }
+  return o;
+}
+DEV int np_box_box(NPCon *con, double margin, const double *pa, const double *ma, const double *sa,
+                   const double *pb, const double *mb, const double *sb) {
+  double R[9], AR[9], t[3], tb[3], dif[3];
+  d_sub3(dif, pb, pa);
+  d_mulmattvec3(t, ma, dif);
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      double r = ma[i] * mb[j] + ma[3 + i] * mb[3 + j] + ma[6 + i] * mb[6 + j];
+      R[3 * i + j] = r; AR[3 * i + j] = fabs(r);
+    }
+#pragma unroll
+  for (int j = 0; j < 3; j++) tb[j] = t[0] * R[j] + t[1] * R[3 + j] + t[2] * R[6 + j];
+  double best = -1e300; int code = -1, sep = 0;
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    double s = fabs(t[i]) - (sa[i] + sb[0] * AR[3 * i] + sb[1] * AR[3 * i + 1] + sb[2] * AR[3 * i + 2]);
+    sep |= s > margin;
+    if (s > best) { best = s; code = i; }
+  }
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    double s = fabs(tb[j]) - (sb[j] + sa[0] * AR[j] + sa[1] * AR[3 + j] + sa[2] * AR[6 + j]);
+    sep |= s > margin;
+    if (s > best) { best = s; code = 3 + j; }
+  }
+  double ebest = -1e300; int ecode = -1;
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+      double l2 = 1.0 - R[3 * i + j] * R[3 * i + j];
+      if (l2 < 1e-6) continue;
+      double proj = t[i2] * R[3 * i1 + j] - t[i1] * R[3 * i2 + j];
+      double ra = sa[i1] * AR[3 * i2 + j] + sa[i2] * AR[3 * i1 + j];
+      double rb = sb[j1] * AR[3 * i + j2] + sb[j2] * AR[3 * i + j1];
+      double s = (fabs(proj) - (ra + rb)) / sqrt(l2);
+      sep |= s > margin;
+      if (s > ebest) { ebest = s; ecode = 3 * i + j; }
+    }
+  if (sep) return 0;
+  if (ecode >= 0 && ebest > best + 0.05 * fabs(best) + BB_TOL) {
+    int i = ecode / 3, j = ecode - 3 * i;
+    double ai[3], bj[3], n[3];
+    col3(ai, ma, i); col3(bj, mb, j);
+    d_cross(n, ai, bj);
+    d_normalize3(n);
+    if (d_dot3(n, dif) < 0) d_scl3(n, n, -1);
+    double ea[3], eb[3];
+    d_copy3(ea, pa); d_copy3(eb, pb);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      double ak[3] = {ma[k], ma[3 + k], ma[6 + k]}, bk[3] = {mb[k], mb[3 + k], mb[6 + k]};
+      if (k != i) d_addtoscl3(ea, ak, d_dot3(n, ak) > 0 ? sa[k] : -sa[k]);
+      if (k != j) d_addtoscl3(eb, bk, d_dot3(n, bk) > 0 ? -sb[k] : sb[k]);
+    }
+    double w[3]; d_sub3(w, eb, ea);
+    double cc = (i == 0 ? sel3(R, j) : (i == 1 ? sel3(R + 3, j) : sel3(R + 6, j)));
+    double d1 = d_dot3(w, ai), d2 = d_dot3(w, bj), den = 1.0 - cc * cc;
+    double sai = sel3(sa, i), sbj = sel3(sb, j);
+    double u = d_clip((d1 - cc * d2) / den, -sai, sai);
+    double v = d_clip((cc * d1 - d2) / den, -sbj, sbj);
+    double qa[3], qb[3];
+    d_addscl3(qa, ea, ai, u); d_addscl3(qb, eb, bj, v);
+    d_sub3(w, qb, qa);
+    double dist = d_dot3(w, n);
+    if (dist > margin) return 0;
+    for (int k = 0; k < 6; k++) con->frame[k] = 0;
+    d_copy3(con->frame, n);
+    con->dist = dist;
+    con->pos[0] = 0.5 * (qa[0] + qb[0]); con->pos[1] = 0.5 * (qa[1] + qb[1]); con->pos[2] = 0.5 * (qa[2] + qb[2]);
+    return 1;
+  }
+  // ---- face case
+  int refA = code < 3, ax = refA ? code : code - 3;
+  double pr[3], mr[9], sr[3], pq[3], mq[9], sq[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) { pr[k] = refA ? pa[k] : pb[k]; sr[k] = refA ? sa[k] : sb[k]; pq[k] = refA ? pb[k] : pa[k]; sq[k] = refA ? sb[k] : sa[k]; }
+#pragma unroll
+  for (int k = 0; k < 9; k++) { mr[k] = refA ? ma[k] : mb[k]; mq[k] = refA ? mb[k] : ma[k]; }
+  double sgn = (refA ? sel3(t, ax) : -sel3(tb, ax)) >= 0 ? 1.0 : -1.0;
+  int u1 = (ax + 1) % 3, u2 = (ax + 2) % 3;
+  double n[3], ru[3], rv[3];
+  col3(n, mr, ax); d_scl3(n, n, sgn);
+  col3(ru, mr, u1); col3(rv, mr, u2);
+  double hn = sel3(sr, ax);
+  BBFace f;
+  f.hu = sel3(sr, u1); f.hv = sel3(sr, u2);
+  double nl[3];
+  d_mulmattvec3(nl, mq, n);
+  int k = 0; double amax = fabs(nl[0]);
+  if (fabs(nl[1]) > amax) { amax = fabs(nl[1]); k = 1; }
+  if (fabs(nl[2]) > amax) { amax = fabs(nl[2]); k = 2; }
+  int k1 = (k + 1) % 3, k2 = (k + 2) % 3;
+  double qk[3], q1[3], q2[3], cen[3], rel[3];
+  col3(qk, mq, k); col3(q1, mq, k1); col3(q2, mq, k2);
+  double sqk = sel3(sq, k), sq1 = sel3(sq, k1), sq2 = sel3(sq, k2);
+  d_addscl3(cen, pq, qk, sel3(nl, k) > 0 ? -sqk : sqk);
+  d_sub3(rel, cen, pr);
+  f.c0[0] = d_dot3(rel, ru); f.c0[1] = d_dot3(rel, rv); f.c0[2] = d_dot3(rel, n) - hn;
+  f.e1[0] = sq1 * d_dot3(q1, ru); f.e1[1] = sq1 * d_dot3(q1, rv); f.e1[2] = sq1 * d_dot3(q1, n);
+  f.e2[0] = sq2 * d_dot3(q2, ru); f.e2[1] = sq2 * d_dot3(q2, rv); f.e2[2] = sq2 * d_dot3(q2, n);
+  f.det = f.e1[0] * f.e2[1] - f.e1[1] * f.e2[0];
+  // selection passes regenerate the candidates instead of storing 24 of them: deepest, farthest from it, extreme on either side
+  BBSel s0, s1, s2, s3; s0.ok = s1.ok = s2.ok = s3.ok = 0;
+  double bd = 1e300;
+  for (int q = 0; q < 24; q++) { BBSel cd = bb_candidate(f, q); if (cd.ok && cd.d <= margin && cd.d < bd) { bd = cd.d; s0 = cd; } }
+  if (!s0.ok) return 0;
+  double far = 1e-16;
+  for (int q = 0; q < 24; q++) {
+    BBSel cd = bb_candidate(f, q);
+    if (cd.ok && cd.d <= margin) { double r2 = (cd.x - s0.x) * (cd.x - s0.x) + (cd.y - s0.y) * (cd.y - s0.y); if (r2 > far) { far = r2; s1 = cd; } }
+  }
+  if (s1.ok) {
+    double lx = s1.x - s0.x, ly = s1.y - s0.y, amx = 1e-12, amn = -1e-12;
+    for (int q = 0; q < 24; q++) {
+      BBSel cd = bb_candidate(f, q);
+      if (cd.ok && cd.d <= margin) {
+        double ar = lx * (cd.y - s0.y) - ly * (cd.x - s0.x);
+        if (ar > amx) { amx = ar; s2 = cd; }
+        if (ar < amn) { amn = ar; s3 = cd; }
+      }
+    }
+  }
+  int cnt = 0;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    BBSel cd = q == 0 ? s0 : (q == 1 ? s1 : (q == 2 ? s2 : s3));
+    if (!cd.ok) continue;
+    NPCon o;
+    double hgt = hn + cd.d - 0.5 * cd.d;
+    o.pos[0] = pr[0] + cd.x * ru[0] + cd.y * rv[0] + hgt * n[0];
+    o.pos[1] = pr[1] + cd.x * ru[1] + cd.y * rv[1] + hgt * n[1];
+    o.pos[2] = pr[2] + cd.x * ru[2] + cd.y * rv[2] + hgt * n[2];
+    o.dist = cd.d;
+    for (int e = 0; e < 6; e++) o.frame[e] = 0;
+    if (refA) d_copy3(o.frame, n); else d_scl3(o.frame, n, -1);
+    np_put(con, cnt, o);
+    cnt++;
+  }
+  return cnt;
+}
+
+// returns the number of contacts, or -1 when the pair has no collider and may be touching (cylinder against a non-plane whose
+// bounding capsule is within the margin): the caller fails the rollout
 DEV int narrow_phase(Ctx &c, int g1, int g2, double margin, NPCon *con) {
   const DevModel &M = *c.M;
   int t1 = MI(geom_type)[g1], t2 = MI(geom_type)[g2];
@@ -605,8 +834,21 @@ DEV int narrow_phase(Ctx &c, int g1, int g2, double margin, NPCon *con) {
     if (t2 == 6) return np_sphere_box(con, margin, p1, s1[0], p2, m2, s2);
   } else if (t1 == 3 && t2 == 3) {
     return np_capsule_capsule(con, margin, p1, m1, s1, p2, m2, s2);
+  } else if (t1 == 3 && t2 == 6) {
+    return np_capsule_box(con, margin, p1, m1, s1, p2, m2, s2);
+  } else if (t1 == 6 && t2 == 6) {
+    return np_box_box(con, margin, p1, m1, s1, p2, m2, s2);
   }
-  return 0;   // unsupported pair types produce no contact (known gap)
+  // no collider: the cylinder's bounding capsule decides "certainly apart" (0) or "unknown" (-1): a conservative exact test
+  if (t1 == 5 || t2 == 5) {
+    NPCon tmp[4];
+    int n = -1;
+    if (t1 == 2) n = np_sphere_capsule(tmp, margin, p1, s1[0], p2, m2, s2);
+    else if (t1 == 3 || (t1 == 5 && t2 == 5)) n = np_capsule_capsule(tmp, margin, p1, m1, s1, p2, m2, s2);
+    else if (t1 == 5 && t2 == 6) n = np_capsule_box(tmp, margin, p1, m1, s1, p2, m2, s2);
+    if (n == 0) return 0;
+  }
+  return -1;
 }
 
 DEV void contact_param(Ctx &c, int g1, int g2, double *cc, int *dim) {
@@ -680,7 +922,9 @@ DEV void collision(Ctx &c) {
       margin = fmax(MD(geom_margin)[g1], MD(geom_margin)[g2]);
       gap = fmax(MD(geom_gap)[g1], MD(geom_gap)[g2]);
       n = narrow_phase(c, g1, g2, margin, con);
+      if (n < 0) { c.warning |= WARN_UNSUPPORTED; n = 0; }      // lane-local here; made wave-uniform below
     }
+    c.warning = wave_or_i(c.warning);
     int tot, off = wave_excl_scan(n, &tot);
     if (c.ncon + tot > M.nconmax) { c.warning |= WARN_CONTACTFULL; break; }
     for (int k = 0; k < n; k++) {
@@ -1120,11 +1364,16 @@ DEV void velocity_stage(Ctx &c, int mfact_seq) {
   PFOR(i, M.nu) {
     double ctrl = c.ctrl[i];
     if (MI(actuator_ctrllimited)[i]) ctrl = d_clip(ctrl, MD(actuator_ctrlrange)[2 * i], MD(actuator_ctrlrange)[2 * i + 1]);
-    double gear = MD(actuator_gear)[i];
     double force = MD(actuator_gainprm)[3 * i] * ctrl;
-    if (MI(actuator_biastype)[i] == 1)
-      force += MD(actuator_biasprm)[3 * i] + MD(actuator_biasprm)[3 * i + 1] * (gear * c.qpos[MI(actuator_qposadr)[i]]) +
-               MD(actuator_biasprm)[3 * i + 2] * (gear * c.qvel[MI(actuator_dofadr)[i]]);
+    if (MI(actuator_biastype)[i] == 1) {
+      // transmission length / velocity: gear * qpos (joint) or sum of gear * coef * qpos over the tendon's joints
+      double length = 0, velocity = 0;
+      for (int e = MI(act_adr)[i]; e < MI(act_adr)[i + 1]; e++) {
+        double cf = MD(act_coef)[e];
+        length += cf * c.qpos[MI(act_qpos)[e]]; velocity += cf * c.qvel[MI(act_dof)[e]];
+      }
+      force += MD(actuator_biasprm)[3 * i] + MD(actuator_biasprm)[3 * i + 1] * length + MD(actuator_biasprm)[3 * i + 2] * velocity;
+    }
     if (MI(actuator_forcelimited)[i]) force = d_clip(force, MD(actuator_forcerange)[2 * i], MD(actuator_forcerange)[2 * i + 1]);
     c.actuator_force[i] = force;
   }
@@ -1134,7 +1383,7 @@ DEV void velocity_stage(Ctx &c, int mfact_seq) {
     double bias = cd[0]*cf[0] + cd[1]*cf[1] + cd[2]*cf[2] + cd[3]*cf[3] + cd[4]*cf[4] + cd[5]*cf[5];
     c.qfrc_bias[d] = bias;
     double act = 0;
-    for (int i = 0; i < M.nu; i++) if (MI(actuator_dofadr)[i] == d) act += MD(actuator_gear)[i] * c.actuator_force[i];
+    for (int e = 0; e < M.nact; e++) if (MI(act_dof)[e] == d) act += MD(act_coef)[e] * c.actuator_force[MI(act_of)[e]];     // moment^T force
     c.qfrc_smooth[d] = act - bias - MD(dof_damping)[d] * c.qvel[d];   // joint springs are added below
   }
   SYNC();
@@ -1237,6 +1486,7 @@ DEV double ray_ground(Ctx &c, const double *pos) {
     double x = ray_geom(gp, gm, gs, query, down, MI(geom_type)[g]);
     if (x >= 0 && (dist < 0 || x < dist)) dist = x;
   }
+  if (dist < 0) c.warning |= WARN_RAY;        // the reference aborts here (utilities.cc:549-552); a candidate fails instead
   return pos[2] + 0.5 - dist;
 }
 
@@ -1526,6 +1776,31 @@ DEV void residual_humanoid_walk(Ctx &c, double *residual) {
   PFOR(i, nu) residual[12 + nq - 7 + 3 + i] = c.ctrl[i];
 }
 
+// mjpc/tasks/shadow_reorient/hand.cc:37-84.  int_data = [palm site, cube body, goal body, keyframe]; framepos / framequat /
+// framelinvel sensors with objtype="body" read the body's inertial frame
+DEV void residual_shadow(Ctx &c, double *residual) {
+  const DevModel &M = *c.M;
+  const int *I = MI(task.int_data);
+  int palm = I[0], cube = I[1], goal = I[2], key = I[3], nu = M.nu;
+  if (LANE == 0) {
+    d_sub3(residual, c.xipos + 3 * cube, c.site_xpos + 3 * palm);
+    double gq[4], cq[4], iq[4], r3[3], lin[3];
+    d_copy4(iq, MD(body_iquat) + 4 * goal); d_mulquat(gq, c.xquat + 4 * goal, iq);
+    d_copy4(iq, MD(body_iquat) + 4 * cube); d_mulquat(cq, c.xquat + 4 * cube, iq);
+    d_normalize4(gq);
+    d_subquat(r3, gq, cq);
+    residual[3] = r3[0]; residual[4] = r3[1]; residual[5] = r3[2];
+    body_linvel(c, cube, lin);
+    residual[6] = lin[0]; residual[7] = lin[1]; residual[8] = lin[2];
+  }
+  PFOR(i, nu) residual[9 + i] = c.actuator_force[i];
+  // the 26-wide slices start at 7 / 6 and straddle the cube's free joint (hand.cc:75-80)
+  PFOR(i, 26) {
+    residual[9 + nu + i] = c.qpos[7 + i] - M.key_qpos[key * M.nq + 7 + i];
+    residual[9 + nu + 26 + i] = c.qvel[6 + i];
+  }
+}
+
 DEV void task_residual(Ctx &c, double *residual) {
   const DevModel &M = *c.M;
   int id = M.task.task_id;
@@ -1550,7 +1825,10 @@ DEV void task_residual(Ctx &c, double *residual) {
     residual_humanoid_stand(c, residual);
   } else if (id == 6) {
     residual_humanoid_walk(c, residual);
+  } else if (id == 7) {
+    residual_shadow(c, residual);
   }
+  c.warning = wave_or_i(c.warning);      // a ray miss is raised by the lane that cast it
   SYNC();
 }
 

@@ -2,7 +2,7 @@
 //
 // Kernels (gfx950, wave64):
 //   noise_kernel    Philox4x32-10 + Box-Muller standard normals  eps[nlocal, P, nu]
-//   rollout_kernel  ONE WORKGROUP PER CANDIDATE (grid = nlocal blocks x 64*MJPC_WAVES threads: an owner wave on the
+//   rollout_kernel  (rollout_cached.hip / rollout_direct.hip)  ONE WORKGROUP PER CANDIDATE (grid = nlocal blocks x 64*MJPC_WAVES threads: an owner wave on the
 //                   critical path + helper / side waves on the CU's other SIMDs, see spmd.h); the candidate's
 //                   whole mjData-equivalent lives in dynamic LDS for all H steps; HBM traffic is only
 //                   the Trajectory record (coalesced row writes by the owning wave) + model reads
@@ -15,28 +15,17 @@
 #include <string>
 #include <vector>
 
-#include "core.h"
+#include "model.h"
+#include "spmd.h"
+#include "philox.h"
 #include "host.h"
 
 // ------------------------------------------------------------------------------ kernels
-// NVT = number of dofs known at compile time (register-resident factorisations), 0 = generic
-template <int NVT>
-#ifndef MJPC_MIN_BLOCKS
-#define MJPC_MIN_BLOCKS 1      // experiment: 2 asks the compiler for <= 256 registers per wave (two workgroups per CU)
-#endif
-__global__ void __launch_bounds__(64 * MJPC_WAVES, MJPC_MIN_BLOCKS) rollout_kernel(const KParams K) {
-  if ((int)blockIdx.x >= K.nlocal) return;
-  rollout<NVT>((KP)__builtin_amdgcn_kernarg_segment_ptr());
-}
+// the rollout kernels live in their own translation units (rollout_cached.hip, rollout_direct.hip; see rollout_tu.inc)
 typedef void (*RolloutFn)(const KParams);
-static RolloutFn pick_rollout_kernel(int nv) {
-  switch (nv) {
-    case 2: return rollout_kernel<2>;
-    case 18: return rollout_kernel<18>;
-    case 27: return rollout_kernel<27>;
-    default: return rollout_kernel<0>;
-  }
-}
+extern "C" RolloutFn mjpc_pick_rollout_cached(int nv, int *exact);
+extern "C" RolloutFn mjpc_pick_rollout_direct(int nv, int *exact);
+extern "C" int mjpc_rollout_threads_cached(void);
 
 // eps[r, e] for global candidate (offset + r), element e = p*nu + k; sel[r] = second-std choice
 extern "C" __global__ void noise_kernel(double *eps, int *sel, unsigned long long seed, unsigned long long stream,
@@ -100,49 +89,9 @@ extern "C" __global__ void __launch_bounds__(256) pack_kernel(const PackArgs a) 
 static thread_local std::string g_error;
 static void set_error(const std::string &s) { g_error = s; }
 
-// test hook for the register factorisations (tests/test_gpu_parity.py): one wave, A (n x n, symmetric) staged in LDS with the
-// odd row stride; out[0..n) = fused factor+solve, out[n..2n) = split factor / solve through LDS
-template <int N>
-__global__ void __launch_bounds__(64) ldl_test_kernel(const double *A, const double *b, double *out, int tree) {
-  constexpr int nvp = NVP_OF(N);
-  __shared__ double sA[N * nvp], sB[N * nvp], sx[N], sy[N], sD[N];
-  for (int e = LANE; e < N * N; e += 64) { int i = e / N, j = e % N; sA[i * nvp + j] = A[e]; sB[i * nvp + j] = A[e]; }
-  if (LANE < N) { sx[LANE] = b[LANE]; sy[LANE] = b[LANE]; }
-  __syncthreads();
-  chol_factor_solve_reg<N>(sA, sx, nvp, tree);
-  chol_factor_reg<N>(sB, sD, nvp, tree);
-  chol_solve_reg<N>(sB, sD, sy, nvp, tree);
-  __syncthreads();
-  if (LANE < N) { out[LANE] = sx[LANE]; out[N + LANE] = sy[LANE]; }
-}
-
-// micro-benchmark hook (scratch measurements only): wave 0 repeats the fused factor+solve `reps` times, the other three waves
-// optionally busy-poll an LDS flag like the solver helpers do; out[0] = s_memtime ticks per repetition
-template <int N>
-__global__ void __launch_bounds__(256) ldl_bench_kernel(const double *A, const double *b, double *out, int tree, int reps, int spin) {
-  constexpr int nvp = NVP_OF(N);
-  __shared__ double sA[N * nvp], sx[N];
-  __shared__ int flag;
-  const int wave = threadIdx.x >> 6;
-  if (threadIdx.x == 0) flag = 0;
-  for (int e = threadIdx.x; e < N * N; e += 256) { int i = e / N, j = e % N; sA[i * nvp + j] = A[e]; }
-  __syncthreads();
-  if (wave == 0) {
-    long long t0 = (long long)__builtin_amdgcn_s_memtime();
-    for (int r = 0; r < reps; r++) {
-      if (LANE < N) sx[LANE] = b[LANE] + r;
-      chol_factor_solve_reg<N>(sA, sx, nvp, tree);
-    }
-    long long t1 = (long long)__builtin_amdgcn_s_memtime();
-    if (LANE == 0) { out[0] = (double)(t1 - t0) / reps; out[1] = sx[0]; }
-    flag_set(&flag, 1);
-  } else if (spin) {
-    flag_wait(&flag, 1);
-  }
-}
-
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error(std::string(#x) + ": " + hipGetErrorString(e_)); return -2; } } while (0)
-#define HIPCHKP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error(std::string(#x) + ": " + hipGetErrorString(e_)); return nullptr; } } while (0)
+// inside mjpc_hip_create only: `e` (when already allocated) and everything it owns are released on the error path
+#define HIPCHKP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error(std::string(#x) + ": " + hipGetErrorString(e_)); mjpc_hip_destroy(e); return nullptr; } } while (0)
 
 struct MjpcHipEngine {
   int device = 0;
@@ -166,12 +115,14 @@ struct MjpcHipEngine {
   // pinned host staging
   double *d_pack = nullptr, *h_pack = nullptr; size_t pack_cap = 0;   // packed plan result (device / pinned host)
   double *h_small = nullptr;   // state | mocap | knot_times | knot_values | noise_std
+  void *h_task[2] = {nullptr, nullptr}; hipEvent_t ev_task[2] = {nullptr, nullptr}; int task_slot = 0;   // set_task staging
   // last plan
   int last_H = 0, last_P = 0, last_nlocal = 0, last_offset = 0, pending = 0;
   // kernel timing accumulation
   double acc_rollout_us = 0, acc_total_us = 0; int acc_n = 0;
   size_t lds_bytes = 0;
-  RolloutFn kernel = nullptr;
+  RolloutFn kernel = nullptr; bool cached = true;
+  int fault = 0;               // MJPC_HIP_FAULT_INJECT (test-suite only)
 };
 
 static int upload_model(MjpcHipEngine *e) {
@@ -184,6 +135,7 @@ static int upload_model(MjpcHipEngine *e) {
 }
 
 extern "C" {
+void mjpc_hip_destroy(MjpcHipEngine *e);
 
 const char *mjpc_hip_last_error(void) { return g_error.c_str(); }
 int mjpc_hip_version(void) { return 1; }
@@ -191,13 +143,30 @@ int mjpc_hip_version(void) { return 1; }
 MjpcHipEngine *mjpc_hip_create(const MjpcHipModel *model, const MjpcHipTask *task, int max_local, int max_horizon, int device) {
   if (!model || !task || max_local < 1 || max_horizon < 1 || max_horizon > MJPC_MAX_HORIZON) { set_error("mjpc_hip_create: invalid argument"); return nullptr; }
   int ndev = 0;
+  MjpcHipEngine *e = nullptr;
   HIPCHKP(hipGetDeviceCount(&ndev));
   if (ndev < 1 || device < 0 || device >= ndev) { set_error("mjpc_hip_create: no such HIP device"); return nullptr; }
   HIPCHKP(hipSetDevice(device));
-  MjpcHipEngine *e = new MjpcHipEngine();
+  e = new MjpcHipEngine();
   e->device = device;
-  e->P_max = 64;     // MaxSamplingSplinePoints is 36 (mjpc/planners/sampling/planner.h:35-36)
-  if (!mjpc_host::build(e->pm, model, task, e->P_max)) { set_error("mjpc_hip_create: " + e->pm.error); delete e; return nullptr; }
+  e->P_max = 36;     // MaxSamplingSplinePoints (mjpc/planners/sampling/planner.h:35-36)
+  // kernel flavour: tables cached in LDS when that fits next to the candidate's state and a compile-time-nv kernel exists
+  // there; otherwise the flavour that reads them from HBM / L2
+  {
+    int exact_c = 0, exact_d = 0;
+    RolloutFn kc = mjpc_pick_rollout_cached(model->nv, &exact_c), kd = mjpc_pick_rollout_direct(model->nv, &exact_d);
+    bool use_cache = !(exact_d && !exact_c);
+    if (getenv("MJPC_HIP_NO_MODEL_CACHE")) use_cache = false;           // test knob
+    if (!mjpc_host::build(e->pm, model, task, e->P_max, use_cache)) { set_error("mjpc_hip_create: " + e->pm.error); delete e; return nullptr; }
+    if (use_cache && (size_t)e->pm.L.total_doubles * sizeof(double) > 160 * 1024) {
+      use_cache = false;
+      if (!mjpc_host::build(e->pm, model, task, e->P_max, false)) { set_error("mjpc_hip_create: " + e->pm.error); delete e; return nullptr; }
+    }
+    e->kernel = use_cache ? kc : kd;
+    const char *fi = getenv("MJPC_HIP_FAULT_INJECT");
+    e->fault = (fi && !strcmp(fi, "sync")) ? 1 : 0;
+    e->cached = use_cache;
+  }
   memset(&e->K, 0, sizeof(e->K));
   e->max_local = max_local; e->max_horizon = max_horizon;
   e->nq = model->nq; e->nv = model->nv; e->nu = model->nu; e->nmocap = model->nmocap;
@@ -206,7 +175,7 @@ MjpcHipEngine *mjpc_hip_create(const MjpcHipModel *model, const MjpcHipTask *tas
   if (e->lds_bytes > 160 * 1024) { set_error("mjpc_hip_create: per-candidate state exceeds 160 KiB of LDS; lower nconmax/nefcmax"); delete e; return nullptr; }
   HIPCHKP(hipMalloc(&e->d_ib, e->pm.ib.size() * sizeof(int)));
   HIPCHKP(hipMalloc(&e->d_db, e->pm.db.size() * sizeof(double)));
-  if (upload_model(e) != 0) { delete e; return nullptr; }
+  if (upload_model(e) != 0) { mjpc_hip_destroy(e); return nullptr; }
   HIPCHKP(hipStreamCreate(&e->stream));
   for (int i = 0; i < 4; i++) HIPCHKP(hipEventCreate(&e->ev[i]));
   size_t NL = (size_t)max_local, H = (size_t)max_horizon;
@@ -232,7 +201,6 @@ MjpcHipEngine *mjpc_hip_create(const MjpcHipModel *model, const MjpcHipTask *tas
   HIPCHKP(hipMemset(e->d_prof, 0, sizeof(long long) * NL * 24));
   HIPCHKP(hipMalloc(&e->d_winner_val, sizeof(double) * 2));
   HIPCHKP(hipHostMalloc(&e->h_small, sizeof(double) * (e->ds + 7 * e->nmocap + e->P_max * (2 * e->nu + 1) + 16)));
-  e->kernel = pick_rollout_kernel(e->nv);
   HIPCHKP(hipFuncSetAttribute((const void *)e->kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_bytes));
   return e;
 }
@@ -246,6 +214,7 @@ void mjpc_hip_destroy(MjpcHipEngine *e) {
                   e->d_winner, e->d_winner_val, e->d_prof, e->d_frame};
   for (void *b : bufs) if (b) hipFree(b);
   if (e->h_small) hipHostFree(e->h_small);
+  for (int i = 0; i < 2; i++) { if (e->h_task[i]) hipHostFree(e->h_task[i]); if (e->ev_task[i]) hipEventDestroy(e->ev_task[i]); }
   if (e->h_pack) hipHostFree(e->h_pack);
   if (e->d_pack) hipFree(e->d_pack);
   for (int i = 0; i < 4; i++) if (e->ev[i]) hipEventDestroy(e->ev[i]);
@@ -257,15 +226,32 @@ int mjpc_hip_set_task(MjpcHipEngine *e, const MjpcHipTask *task) {
   if (!e || !task) { set_error("mjpc_hip_set_task: invalid argument"); return -1; }
   HIPCHK(hipSetDevice(e->device));
   if (task->num_residual != e->nr || 3 * task->num_trace != e->ntr) { set_error("mjpc_hip_set_task: residual/trace dimensions changed"); return -1; }
+  if (e->pending) { set_error("mjpc_hip_set_task: a plan step is in flight (call mjpc_hip_plan_fetch first)"); return -1; }
   if (!mjpc_host::repack_task(e->pm, task)) { set_error("mjpc_hip_set_task: " + e->pm.error); return -1; }
-  HIPCHK(hipStreamSynchronize(e->stream));
-  return upload_model(e);
+  // only the task block changes (cost table, residual parameters, frozen ResidualFn state): one small stream-ordered copy per
+  // buffer out of the engine's own packed image, ahead of the next plan's kernels; the model and key-frame tables stay put
+  const PackedModel &pm = e->pm;
+  size_t bi = pm.task_i_cap * sizeof(int), bd = pm.task_d_cap * sizeof(double);
+  int slot = e->task_slot ^= 1;                       // two pinned staging slots: the copy of the previous call may still be in flight
+  if (!e->h_task[slot]) {
+    HIPCHK(hipHostMalloc(&e->h_task[slot], bi + bd + 16));
+    HIPCHK(hipEventCreateWithFlags(&e->ev_task[slot], hipEventDisableTiming));
+  } else HIPCHK(hipEventSynchronize(e->ev_task[slot]));
+  char *stage = (char *)e->h_task[slot];
+  memcpy(stage, pm.db.data() + pm.task_d0, bd);
+  memcpy(stage + bd, pm.ib.data() + pm.task_i0, bi);
+  HIPCHK(hipMemcpyAsync(e->d_db + pm.task_d0, stage, bd, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipMemcpyAsync(e->d_ib + pm.task_i0, stage + bd, bi, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipEventRecord(e->ev_task[slot], e->stream));
+  e->K.M = mjpc_host::relocate(e->pm, e->d_ib, e->d_db);
+  return 0;
 }
 
 int mjpc_hip_plan_async(MjpcHipEngine *e, const MjpcHipPlanInput *in) {
   if (!e || !in) { set_error("mjpc_hip_plan: invalid argument"); return -1; }
+  if (e->pending) { set_error("mjpc_hip_plan_async: the previous plan step has not been fetched (one plan in flight per engine)"); return -1; }
   int P = in->num_spline_points, H = in->horizon, nl = in->num_local, nu = e->nu;
-  if (P < 1 || P > e->P_max) { set_error("mjpc_hip_plan: num_spline_points out of range (1..64)"); return -1; }
+  if (P < 1 || P > e->P_max) { set_error("mjpc_hip_plan: num_spline_points out of range (1..36)"); return -1; }
   if (H < 1 || H > e->max_horizon) { set_error("mjpc_hip_plan: horizon out of range"); return -1; }
   if (nl < 1 || nl > e->max_local || in->candidate_offset < 0 || in->candidate_offset + nl > in->num_trajectory) { set_error("mjpc_hip_plan: candidate range out of bounds"); return -1; }
   if (in->interpolation < 0 || in->interpolation > 2) { set_error("mjpc_hip_plan: unknown interpolation"); return -1; }
@@ -314,6 +300,7 @@ int mjpc_hip_plan_async(MjpcHipEngine *e, const MjpcHipPlanInput *in) {
   K.seed = in->seed; K.stream = in->stream;
   K.P = P; K.interp = in->interpolation; K.H = H; K.N = in->num_trajectory; K.offset = in->candidate_offset; K.nlocal = nl;
   K.use_device_noise = in->noise_eps ? 0 : 1;
+  K.fault = e->fault;
   K.noise_std = in->noise_std ? e->d_std : nullptr; K.nominal_index = in->nominal_index;
   K.cand_knots = nullptr; K.xfrc_std = in->xfrc_std; K.xfrc_rate = in->xfrc_rate;
   if (in->xfrc_std > 0 && !(in->xfrc_rate > 0)) { set_error("mjpc_hip_plan: xfrc_rate must be positive when xfrc_std > 0"); return -1; }
@@ -329,7 +316,7 @@ int mjpc_hip_plan_async(MjpcHipEngine *e, const MjpcHipPlanInput *in) {
   K.states = e->d_states; K.actions = e->d_actions; K.times = e->d_times; K.residual = e->d_residual; K.costs = e->d_costs;
   K.trace = e->d_trace; K.knots = e->d_knots; K.returns = e->d_returns; K.failure = e->d_failure; K.diag = e->d_diag; K.prof = e->d_prof; K.frame = e->d_frame;
   HIPCHK(hipEventRecord(e->ev[1], e->stream));
-  hipLaunchKernelGGL(e->kernel, dim3(nl), dim3(64 * MJPC_WAVES), e->lds_bytes, e->stream, K);
+  hipLaunchKernelGGL(e->kernel, dim3(nl), dim3(mjpc_rollout_threads_cached()), e->lds_bytes, e->stream, K);
   HIPCHK(hipEventRecord(e->ev[2], e->stream));
   hipLaunchKernelGGL(argmin_kernel, dim3(1), dim3(64), 0, e->stream, e->d_returns, nl, e->d_winner, e->d_winner_val);
   HIPCHK(hipEventRecord(e->ev[3], e->stream));
@@ -449,10 +436,21 @@ int mjpc_hip_device_ptrs(MjpcHipEngine *e, void **returns, void **states, void *
   return 0;
 }
 
-// debug / test hook: copy every local candidate's arrays of the last plan to the host
-int mjpc_hip_debug_fetch_all(MjpcHipEngine *e, double *states, double *actions, double *times, double *residual,
+// every local candidate's trace rows [num_local][H][3*num_trace] of the last plan in one copy (GUI: SamplingPlanner::Traces)
+int mjpc_hip_get_traces(MjpcHipEngine *e, double *traces) {
+  if (!e || !traces || !e->last_nlocal) { set_error("mjpc_hip_get_traces: no finished plan"); return -1; }
+  if (!e->ntr) return 0;
+  HIPCHK(hipSetDevice(e->device));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  HIPCHK(hipMemcpy(traces, e->d_trace, sizeof(double) * (size_t)e->last_nlocal * e->last_H * e->ntr, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// every local candidate's Trajectory arrays of the last plan (any pointer may be NULL); diag = per candidate
+// [Newton iterations summed over the steps, max contacts, max constraint rows, warning bits]
+int mjpc_hip_get_all_candidates(MjpcHipEngine *e, double *states, double *actions, double *times, double *residual,
                              double *costs, double *trace, double *knots, int *diag) {
-  if (!e || !e->last_nlocal) return -1;
+  if (!e || !e->last_nlocal) { set_error("mjpc_hip_get_all_candidates: no finished plan"); return -1; }
   HIPCHK(hipSetDevice(e->device));
   size_t n = (size_t)e->last_nlocal, H = (size_t)e->last_H, P = (size_t)e->last_P;
   HIPCHK(hipStreamSynchronize(e->stream));
@@ -469,7 +467,17 @@ int mjpc_hip_debug_fetch_all(MjpcHipEngine *e, double *states, double *actions, 
 
 int mjpc_hip_lds_bytes(MjpcHipEngine *e) { return e ? (int)e->lds_bytes : 0; }
 
-// MJPC_PROFILE builds: per-candidate phase cycle counters of the last plan ([nlocal][24] int64)
+// host-only (no HIP call): bytes of LDS one candidate would occupy; use_cache: with / without the LDS copy of the model tables.
+// < 0: the model is refused (mjpc_hip_last_error tells why)
+int mjpc_hip_layout_bytes(const MjpcHipModel *model, const MjpcHipTask *task, int use_cache) {
+  if (!model || !task) { set_error("mjpc_hip_layout_bytes: invalid argument"); return -1; }
+  PackedModel pm;
+  if (!mjpc_host::build(pm, model, task, 36, use_cache != 0)) { set_error("mjpc_hip_layout_bytes: " + pm.error); return -1; }
+  return (int)((size_t)pm.L.total_doubles * sizeof(double));
+}
+
+#ifdef MJPC_PROFILE
+// MJPC_PROFILE builds only (tools/profile_phases.py): per-candidate phase cycle counters of the last plan ([nlocal][24] int64)
 int mjpc_hip_debug_fetch_prof(MjpcHipEngine *e, long long *prof) {
   if (!e || !e->last_nlocal) return -1;
   HIPCHK(hipSetDevice(e->device));
@@ -477,39 +485,6 @@ int mjpc_hip_debug_fetch_prof(MjpcHipEngine *e, long long *prof) {
   HIPCHK(hipMemcpy(prof, e->d_prof, sizeof(long long) * (size_t)e->last_nlocal * 24, hipMemcpyDeviceToHost));
   return 0;
 }
-
-// test hook: x = A^-1 b with the register L^T D L of the rollout kernel (n = 18 or 27; tree = 1: level-ordered sparse form)
-int mjpc_hip_debug_ldl(int n, int tree, const double *A, const double *b, double *out, int device) {
-  if (n != 18 && n != 27) { set_error("mjpc_hip_debug_ldl: n must be 18 or 27"); return -1; }
-  HIPCHK(hipSetDevice(device));
-  double *dA = nullptr, *db = nullptr, *dout = nullptr;
-  HIPCHK(hipMalloc(&dA, sizeof(double) * n * n)); HIPCHK(hipMalloc(&db, sizeof(double) * n)); HIPCHK(hipMalloc(&dout, sizeof(double) * 2 * n));
-  HIPCHK(hipMemcpy(dA, A, sizeof(double) * n * n, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(db, b, sizeof(double) * n, hipMemcpyHostToDevice));
-  if (n == 18) hipLaunchKernelGGL(ldl_test_kernel<18>, dim3(1), dim3(64), 0, 0, dA, db, dout, tree);
-  else hipLaunchKernelGGL(ldl_test_kernel<27>, dim3(1), dim3(64), 0, 0, dA, db, dout, tree);
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipDeviceSynchronize());
-  HIPCHK(hipMemcpy(out, dout, sizeof(double) * 2 * n, hipMemcpyDeviceToHost));
-  hipFree(dA); hipFree(db); hipFree(dout);
-  return 0;
-}
-
-
-int mjpc_hip_debug_ldl_bench(int n, int tree, int reps, int spin, const double *A, const double *b, double *out, int device) {
-  if (n != 18 && n != 27) return -1;
-  HIPCHK(hipSetDevice(device));
-  double *dA = nullptr, *db = nullptr, *dout = nullptr;
-  HIPCHK(hipMalloc(&dA, sizeof(double) * n * n)); HIPCHK(hipMalloc(&db, sizeof(double) * n)); HIPCHK(hipMalloc(&dout, sizeof(double) * 2));
-  HIPCHK(hipMemcpy(dA, A, sizeof(double) * n * n, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(db, b, sizeof(double) * n, hipMemcpyHostToDevice));
-  for (int w = 0; w < 2; w++) {
-    if (n == 18) hipLaunchKernelGGL(ldl_bench_kernel<18>, dim3(256), dim3(256), 0, 0, dA, db, dout, tree, reps, spin);
-    else hipLaunchKernelGGL(ldl_bench_kernel<27>, dim3(256), dim3(256), 0, 0, dA, db, dout, tree, reps, spin);
-  }
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipDeviceSynchronize());
-  HIPCHK(hipMemcpy(out, dout, sizeof(double) * 2, hipMemcpyDeviceToHost));
-  hipFree(dA); hipFree(db); hipFree(dout);
-  return 0;
-}
+#endif
 
 }  // extern "C"

@@ -91,13 +91,24 @@ static inline void make_layout(const PackedModel &p, Lay &L, const MjpcHipModel 
   L.total_doubles = o + (io + 1) / 2;
 }
 
-static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTask *t, int P_max) {
+// use_cache: lay out an LDS copy of the model tables (rollout_cached.hip) or none (rollout_direct.hip)
+static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTask *t, int P_max, bool use_cache = true) {
+  p.ib.clear(); p.db.clear(); p.error.clear();
   DevModel &M = p.M;
   memset(&M, 0, sizeof(M));
   int nb = m->nbody, nj = m->njnt, nv = m->nv, ng = m->ngeom, ns = m->nsite, nu = m->nu;
+  // models the engine cannot roll out faithfully are refused (never silently approximated)
   if (nv > 64) { p.error = "nv > 64 not supported (dof bitmask)"; return false; }
   if (m->na != 0) { p.error = "activation states (na > 0) not supported"; return false; }
+  if (m->nuserdata != 0) { p.error = "nuserdata > 0 not supported (no built-in residual reads mjData.userdata)"; return false; }
   if (m->nefcmax > 192) { p.error = "nefcmax > 192 not supported (line-search rows per lane)"; return false; }
+  if (m->nconmax > 64) { p.error = "nconmax > 64 not supported (one contact per lane in the solver)"; return false; }
+  if (m->iterations > 250) { p.error = "solver iterations > 250 not supported (hand-shake sequence numbers)"; return false; }
+  for (int j = 0; j < nj; j++)
+    if (m->jnt_limited[j] && m->jnt_type[j] == MJPC_JNT_BALL) { p.error = "limited ball joints are not supported (joint " + std::to_string(j) + ")"; return false; }
+  for (int i = 0; i < nu; i++)
+    if (m->actuator_trntype[i] != MJPC_TRN_JOINT && m->actuator_trntype[i] != MJPC_TRN_TENDON) {
+      p.error = "actuator " + std::to_string(i) + ": only joint and fixed-tendon transmissions are supported"; return false; }
   M.nq = m->nq; M.nv = nv; M.nu = nu; M.nbody = nb; M.njnt = nj; M.ngeom = ng; M.nsite = ns; M.nmocap = m->nmocap;
   M.nkey = m->nkey; M.nvp = NVP_OF(nv); M.ntendon = m->ntendon;
   M.cone = m->cone; M.iterations = m->iterations; M.ls_iterations = m->ls_iterations; M.disableflags = m->disableflags;
@@ -109,7 +120,6 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
   M.tree_ok = (nv == 18 && dof_tree_matches<18>(m->dof_parentid)) || (nv == 27 && dof_tree_matches<27>(m->dof_parentid));
   if (getenv("MJPC_HIP_DENSE_FACTOR")) M.tree_ok = 0;      // test knob: dense elimination order for every factorisation
   M.nconmax = m->nconmax > 0 ? m->nconmax : 32;
-  if (M.nconmax > 64) M.nconmax = 64;
   M.nefcmax = m->nefcmax > 0 ? m->nefcmax : 128;
 #define PI_(f, n) M.f = as_off<int>(put_i(p, m->f, (size_t)(n)))
 #define PD_(f, n) M.f = as_off<double>(put_d(p, m->f, (size_t)(n)))
@@ -135,10 +145,29 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
   PD_(tendon_solref_lim, 2 * m->ntendon); PD_(tendon_solimp_lim, 5 * m->ntendon); PD_(tendon_invweight0, m->ntendon);
 #undef PI_
 #undef PD_
-  // actuator -> dof / qpos address (joint transmission)
-  { std::vector<int> da(nu), qa(nu);
-    for (int i = 0; i < nu; i++) { int j = m->actuator_trnid[i]; da[i] = m->jnt_dofadr[j]; qa[i] = m->jnt_qposadr[j]; }
-    M.actuator_dofadr = as_off<int>(put_i(p, da.data(), nu)); M.actuator_qposadr = as_off<int>(put_i(p, qa.data(), nu)); }
+  // actuator transmissions -> (dof, qpos address, coefficient) entries: joint = one entry with the gear, fixed tendon = one per
+  // wrapped joint with gear * coefficient (mj_transmission for mjTRN_JOINT / mjTRN_TENDON)
+  { std::vector<int> adr(nu + 1, 0), da, qa, of; std::vector<double> cf;
+    for (int i = 0; i < nu; i++) {
+      adr[i] = (int)da.size();
+      int id = m->actuator_trnid[i];
+      if (m->actuator_trntype[i] == MJPC_TRN_TENDON) {
+        if (id < 0 || id >= m->ntendon) { p.error = "actuator " + std::to_string(i) + ": tendon id out of range"; return false; }
+        for (int w = m->tendon_adr[id]; w < m->tendon_adr[id] + m->tendon_num[id]; w++) {
+          int j = m->wrap_objid[w];
+          da.push_back(m->jnt_dofadr[j]); qa.push_back(m->jnt_qposadr[j]); of.push_back(i); cf.push_back(m->actuator_gear[i] * m->wrap_prm[w]);
+        }
+      } else {
+        if (id < 0 || id >= nj) { p.error = "actuator " + std::to_string(i) + ": joint id out of range"; return false; }
+        int t = m->jnt_type[id];
+        if (t != MJPC_JNT_HINGE && t != MJPC_JNT_SLIDE) { p.error = "actuator " + std::to_string(i) + ": joint transmissions need a hinge or slide joint"; return false; }
+        da.push_back(m->jnt_dofadr[id]); qa.push_back(m->jnt_qposadr[id]); of.push_back(i); cf.push_back(m->actuator_gear[i]);
+      }
+    }
+    adr[nu] = (int)da.size(); M.nact = (int)da.size();
+    M.act_adr = as_off<int>(put_i(p, adr.data(), adr.size())); M.act_dof = as_off<int>(put_i(p, da.data(), da.size()));
+    M.act_qpos = as_off<int>(put_i(p, qa.data(), qa.size())); M.act_of = as_off<int>(put_i(p, of.data(), of.size()));
+    M.act_coef = as_off<double>(put_d(p, cf.data(), cf.size())); }
   { std::vector<int> wd(m->nwrap), wq(m->nwrap);
     for (int w = 0; w < m->nwrap; w++) { int j = m->wrap_objid[w]; wd[w] = m->jnt_dofadr[j]; wq[w] = m->jnt_qposadr[j]; }
     M.wrap_dofadr = as_off<int>(put_i(p, wd.data(), wd.size())); M.wrap_qposadr = as_off<int>(put_i(p, wq.data(), wq.size())); }
@@ -209,6 +238,14 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
       if (excl) continue;
       if (!((m->geom_contype[g1] & m->geom_conaffinity[g2]) || (m->geom_contype[g2] & m->geom_conaffinity[g1]))) continue;
       if (m->geom_type[g1] == MJPC_GEOM_PLANE && m->geom_type[g2] == MJPC_GEOM_PLANE) continue;
+      for (int g : {g1, g2}) {
+        int ty = m->geom_type[g];
+        if (ty == MJPC_GEOM_HFIELD || ty == MJPC_GEOM_ELLIPSOID || ty == MJPC_GEOM_MESH) {
+          p.error = "geom " + std::to_string(g) + " (type " + std::to_string(ty) + ") can collide with geom " + std::to_string(g == g1 ? g2 : g1) +
+                    " but height fields, ellipsoids and meshes have no collider here";
+          return false;
+        }
+      }
       g1s.push_back(g1); g2s.push_back(g2);
     }
     M.npair = (int)g1s.size();
@@ -232,9 +269,7 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
   M.key_qpos = as_off<double>(put_d(p, m->key_qpos, (size_t)m->nkey * m->nq));
   M.key_mpos = as_off<double>(put_d(p, m->key_mpos, (size_t)m->nkey * 3 * m->nmocap));
   // ---- LDS layout
-#ifdef MJPC_NO_MODEL_CACHE      // experiment build: the kernel reads the tables from HBM, no LDS copy to size
-  p.cache_i = 0; p.cache_d = 0;
-#endif
+  if (!use_cache) { p.cache_i = 0; p.cache_d = 0; }      // the kernel reads the tables from HBM / L2: no LDS copy to size
   make_layout(p, p.L, m, t, P_max, p.cache_d, p.cache_i);
   return true;
 }
@@ -255,7 +290,7 @@ static inline DevModel relocate(const PackedModel &p, const int *ibase, const do
   fd(M.geom_size); fd(M.geom_pos); fd(M.geom_quat); fd(M.geom_friction); fd(M.geom_solmix); fd(M.geom_solref); fd(M.geom_solimp);
   fd(M.geom_margin); fd(M.geom_gap); fd(M.geom_rbound);
   fi(M.site_bodyid); fd(M.site_pos); fd(M.site_quat);
-  fi(M.actuator_dofadr); fi(M.actuator_qposadr); fi(M.actuator_ctrllimited); fi(M.actuator_forcelimited); fi(M.actuator_biastype);
+  fi(M.act_adr); fi(M.act_dof); fi(M.act_qpos); fi(M.act_of); fd(M.act_coef); fi(M.actuator_ctrllimited); fi(M.actuator_forcelimited); fi(M.actuator_biastype);
   fd(M.actuator_gainprm); fd(M.actuator_biasprm); fd(M.actuator_gear); fd(M.actuator_ctrlrange); fd(M.actuator_forcerange);
   fd(M.key_qpos); fd(M.key_mpos);
   fi(M.tendon_adr); fi(M.tendon_num); fi(M.tendon_limited); fi(M.wrap_dofadr); fi(M.wrap_qposadr);

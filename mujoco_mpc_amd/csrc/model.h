@@ -52,7 +52,7 @@ template <int N> constexpr bool dof_tree_matches(const int *dof_parentid) {
 
 enum { CNSTR_FRICTION_DOF = 1, CNSTR_LIMIT_JOINT = 3, CNSTR_LIMIT_TENDON = 4, CNSTR_CONTACT_FRICTIONLESS = 5, CNSTR_CONTACT_PYRAMIDAL = 6, CNSTR_CONTACT_ELLIPTIC = 7 };
 enum { STATE_SATISFIED = 0, STATE_QUADRATIC = 1, STATE_LINEARNEG = 2, STATE_LINEARPOS = 3, STATE_CONE = 4 };
-enum { WARN_BADQPOS = 1, WARN_BADQVEL = 2, WARN_BADQACC = 4, WARN_CONTACTFULL = 8, WARN_CNSTRFULL = 16, WARN_RAY = 32, WARN_SYNC = 64 };
+enum { WARN_BADQPOS = 1, WARN_BADQVEL = 2, WARN_BADQACC = 4, WARN_CONTACTFULL = 8, WARN_CNSTRFULL = 16, WARN_RAY = 32, WARN_SYNC = 64, WARN_UNSUPPORTED = 128 };
 
 struct DevTask {
   int task_id, num_residual, num_term, num_trace, num_parameter, num_int, num_dbl;
@@ -64,7 +64,7 @@ struct DevTask {
 struct DevModel {
   int nq, nv, nu, nbody, njnt, ngeom, nsite, nmocap, nkey, nvp, ntendon;
   int nlevel, npair, nfric, nlimit, nray, nmpair, nzpair, nconmax, nefcmax, any_damping;
-  int cone, iterations, ls_iterations, disableflags, con_stride, maxdim, tree_ok;
+  int cone, iterations, ls_iterations, disableflags, con_stride, maxdim, tree_ok, nact;
   double timestep, gravity[3], impratio, tolerance, ls_tolerance, meaninertia;
   const int *body_parentid, *body_rootid, *body_mocapid, *body_jntnum, *body_jntadr, *body_dofnum, *body_dofadr;
   const double *body_pos, *body_quat, *body_ipos, *body_iquat, *body_mass, *body_subtreemass, *body_inertia, *body_invweight0;
@@ -76,7 +76,10 @@ struct DevModel {
   const double *geom_size, *geom_pos, *geom_quat, *geom_friction, *geom_solmix, *geom_solref, *geom_solimp, *geom_margin, *geom_gap, *geom_rbound;
   const int *site_bodyid;
   const double *site_pos, *site_quat;
-  const int *actuator_dofadr, *actuator_qposadr, *actuator_ctrllimited, *actuator_forcelimited, *actuator_biastype;
+  // actuator transmissions flattened on the host: actuator i owns entries [act_adr[i], act_adr[i+1]) = (dof, qpos address,
+  // coefficient = gear [* tendon coefficient]); act_of[e] = the actuator of entry e
+  const int *act_adr, *act_dof, *act_qpos, *act_of, *actuator_ctrllimited, *actuator_forcelimited, *actuator_biastype;
+  const double *act_coef;
   const double *actuator_gainprm, *actuator_biasprm, *actuator_gear, *actuator_ctrlrange, *actuator_forcerange;
   const int *tendon_adr, *tendon_num, *tendon_limited, *wrap_dofadr, *wrap_qposadr;
   const double *wrap_prm, *tendon_range, *tendon_margin, *tendon_solref_lim, *tendon_solimp_lim, *tendon_invweight0;
@@ -123,6 +126,7 @@ struct KParams {
   double time, sigma0, sigma1;
   unsigned long long seed, stream;
   int P, interp, H, N, offset, nlocal, use_device_noise, nominal_index;
+  int fault;           // test-suite fault injection (0 = none; 1 = drop one helper hand-shake, see solver.h)
   // outputs (device), row-major per local candidate
   double *states, *actions, *times, *residual, *costs, *trace, *knots, *returns;
   int *failure, *diag;

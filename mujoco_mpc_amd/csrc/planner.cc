@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <limits>
 #include <numeric>
 
 namespace mjpc_hip {
@@ -132,7 +133,19 @@ static double Micros(std::chrono::steady_clock::time_point t0) {
   return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
 }
 
-SamplingPlanner::~SamplingPlanner() { if (engine_) mjpc_hip_destroy(engine_); }
+SamplingPlanner::~SamplingPlanner() {
+  if (engine_) mjpc_hip_destroy(engine_);
+  if (nominal_engine_) mjpc_hip_destroy(nominal_engine_);
+}
+
+// returns sorted ascending with every non-finite value treated as +inf: a strict weak order even when a rollout produced NaN
+// (the engine's argmin skips NaN the same way)
+static inline bool ReturnLess(double a, double b) {
+  const double inf = std::numeric_limits<double>::infinity();
+  if (!(a == a)) a = inf;
+  if (!(b == b)) b = inf;
+  return a < b;
+}
 
 void SamplingPlanner::Initialize(const MjpcHipModel* model, const MjpcHipTask* task, const Numerics& numerics) {
   numerics_ = numerics;
@@ -152,6 +165,11 @@ void SamplingPlanner::Initialize(const MjpcHipModel* model, const MjpcHipTask* t
   if (engine_) { mjpc_hip_destroy(engine_); engine_ = nullptr; }     // the model might have changed
   engine_ = mjpc_hip_create(model, task, numerics.max_samples, numerics.max_horizon, numerics.device);
   if (!engine_) { Fatal(mjpc_hip_last_error()); return; }
+  // NominalTrajectory() rolls the nominal policy out on its own one-candidate engine, so that the candidates of the last
+  // plan step (returns, order, trajectories on the device) stay available to the RankedPlanner calls afterwards
+  if (nominal_engine_) { mjpc_hip_destroy(nominal_engine_); nominal_engine_ = nullptr; }
+  nominal_engine_ = mjpc_hip_create(model, task, 1, numerics.max_horizon, numerics.device);
+  if (!nominal_engine_) { Fatal(mjpc_hip_last_error()); return; }
   policy.Allocate(model, numerics.sampling_spline_points);
   previous_policy.Allocate(model, numerics.sampling_spline_points);
   winner_policy_.Allocate(model, numerics.sampling_spline_points);
@@ -195,6 +213,7 @@ void SamplingPlanner::SetState(const double* s, const double* m, const double* u
 
 void SamplingPlanner::SetTask(const MjpcHipTask* task) {
   if (mjpc_hip_set_task(engine_, task) != 0) Fatal(mjpc_hip_last_error());
+  if (nominal_engine_ && mjpc_hip_set_task(nominal_engine_, task) != 0) Fatal(mjpc_hip_last_error());
 }
 
 void SamplingPlanner::UpdateNominalPolicy(int horizon) {   // planner.cc:236-310
@@ -264,7 +283,7 @@ int SamplingPlanner::OptimizePolicyCandidates(int ncandidates, int horizon) {   
   // order so that the first ncandidates are the best (ties: lowest index, like the engine's argmin)
   trajectory_order.resize(num_trajectory);
   std::iota(trajectory_order.begin(), trajectory_order.end(), 0);
-  std::stable_sort(trajectory_order.begin(), trajectory_order.end(), [this](int a, int b) { return returns[a] < returns[b]; });
+  std::stable_sort(trajectory_order.begin(), trajectory_order.end(), [this](int a, int b) { return ReturnLess(returns[a], returns[b]); });
   rollouts_compute_time = Micros(rollouts_start);
   return ncandidates;
 }
@@ -305,14 +324,36 @@ void SamplingPlanner::OptimizePolicy(int horizon) {   // planner.cc:190-208
   policy_update_compute_time = Micros(policy_update_start);
 }
 
-void SamplingPlanner::NominalTrajectory(int horizon) {   // planner.cc:211-222: candidate 0 only
-  int saved = num_trajectory_;
-  unsigned long long saved_iter = plan_iter;
-  num_trajectory_ = 1;
-  OptimizePolicyCandidates(1, horizon);
-  num_trajectory_ = saved; plan_iter = saved_iter;
-  winner = 0;
-  trajectory_winner.horizon = last_horizon_; trajectory_winner.total_return = returns[0]; trajectory_winner.failure = failures[0] != 0;
+void SamplingPlanner::NominalTrajectory(int horizon) {   // planner.cc:211-222: rolls out `policy` into trajectory[0] only
+  // one un-noised candidate on the dedicated engine: returns / failures / trajectory_order / candidate knots of the last
+  // OptimizePolicyCandidates() are not touched (the reference writes nothing but trajectory[0] here either)
+  policy.plan.SetInterpolation((SplineInterpolation)interpolation_);
+  int P = (int)policy.plan.Size();
+  std::vector<double> kt(std::max(P, 1)), kv((size_t)std::max(P, 1) * nu_, 0.0);
+  for (int p = 0; p < P; p++) {
+    kt[p] = policy.plan.NodeTime(p);
+    std::copy(policy.plan.NodeValues(p), policy.plan.NodeValues(p) + nu_, kv.begin() + (size_t)p * nu_);
+  }
+  if (P == 0) { P = 1; kt[0] = time; }
+  MjpcHipPlanInput in;
+  std::memset(&in, 0, sizeof(in));
+  in.state = state.data(); in.mocap = mocap.data(); in.userdata = userdata.data(); in.time = time;
+  in.knot_times = kt.data(); in.knot_values = kv.data(); in.num_spline_points = P;
+  in.interpolation = interpolation_; in.num_trajectory = 1; in.horizon = horizon; in.candidate_offset = 0; in.num_local = 1;
+  in.noise_exploration[0] = noise_exploration[0]; in.noise_exploration[1] = noise_exploration[1];
+  in.seed = seed; in.stream = plan_iter;
+  double ret = 0; int fail = 0;
+  MjpcHipPlanOutput out;
+  std::memset(&out, 0, sizeof(out));
+  out.returns = &ret; out.failure = &fail;
+  out.states = trajectory_winner.states.data(); out.actions = trajectory_winner.actions.data();
+  out.times = trajectory_winner.times.data(); out.residual = trajectory_winner.residual.data();
+  out.costs = trajectory_winner.costs.data(); out.trace = trajectory_winner.trace.data();
+  if (mjpc_hip_plan(nominal_engine_, &in, &out) != 0) { Fatal(mjpc_hip_last_error()); return; }
+  fetched_ = -1;                 // trajectory_winner no longer mirrors a candidate of the last plan: re-fetch on demand
+  nominal_horizon_ = horizon;
+  trajectory_winner.horizon = horizon; trajectory_winner.total_return = ret; trajectory_winner.failure = fail != 0;
+  if (winner < 0) winner = 0;
 }
 
 void SamplingPlanner::ActionFromPolicy(double* action, const double* s, double t, bool use_previous) {   // planner.cc:225-233
@@ -459,7 +500,7 @@ void CrossEntropyPlanner::OptimizePolicy(int horizon) {   // planner.cc:164-283
   trajectory_order.resize(std::max((int)trajectory_order.size(), num_trajectory));
   for (int i = 0; i < num_trajectory; i++) trajectory_order[i] = i;
   std::stable_sort(trajectory_order.begin(), trajectory_order.begin() + num_trajectory,
-                   [this](int a, int b) { return returns[a] < returns[b]; });
+                   [this](int a, int b) { return ReturnLess(returns[a], returns[b]); });
   rollouts_compute_time = Micros(rollouts_start);
 
   // ----- update policy (planner.cc:205-283)

@@ -509,6 +509,8 @@ DEV void solver_helper_loop(Ctx &c, int seq) {
   }
   if constexpr (NVT > 0) {
     constexpr int NP = MJPC_NH + 1;
+    // fault injection for the test-suite (MJPC_HIP_FAULT_INJECT=sync): helper 0 of candidate 1 never reports its fill in step 2
+    const int mute = c.K->fault == 1 && K == 0 && cand_index() == 1 && seq == 2 * 256;
     for (;;) {
       seq++;
       if (!flag_wait(c.misc + HX_JOB, seq)) return;             // timed out: the owner reports the failure
@@ -516,7 +518,7 @@ DEV void solver_helper_loop(Ctx &c, int seq) {
       int npos = uniform_i(c.misc[HX_NPOS]), nneg = uniform_i(c.misc[HX_NNEG]);
 #if MJPC_SPLIT_FILL
       newton_fill<NVT, FILL_C0(NVT, K + 1, NP), FILL_C1(NVT, K + 1, NP), (K + 1 == NP - 1)>(c, npos, nneg);
-      flag_set(c.misc + HX_HFILL + K, seq);
+      if (!mute) flag_set(c.misc + HX_HFILL + K, seq);
       if (!flag_wait(c.misc + HX_W0FILL, seq)) return;
       for (int k = 0; k < MJPC_NH; k++) if (k != K && !flag_wait(c.misc + HX_HFILL + k, seq)) return;
 #endif
@@ -760,7 +762,7 @@ DEV void solve_constraints(Ctx &c) {
     // same stopping rule as the reference's Newton loop; the Hessian build / factorisation of an iteration that is
     // about to stop is skipped (its direction would never be used)
     double improvement = scale * (oldcost - cost);
-    int stop = improvement < M.tolerance;
+    int stop = improvement < M.tolerance || (c.warning & WARN_SYNC) != 0;      // a lost hand-shake ends the solve (the candidate fails)
     newton_gradient<NVT>(c, stop);
     c.solver_iter++;
     double pg = 0;

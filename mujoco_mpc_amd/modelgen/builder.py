@@ -190,11 +190,17 @@ class ModelBuilder:
         self.sites.append((name, body, np.array(pos, float), normq(quat)))
         return len(self.sites) - 1
 
-    def actuator(self, name, joint, gainprm=(1, 0, 0), biastype=0, biasprm=(0, 0, 0), gear=1.0,
-                 ctrllimited=True, ctrlrange=(-1, 1), forcelimited=False, forcerange=(0, 0)):
-        self.actuators.append(dict(name=name, joint=joint, gainprm=tuple(gainprm), biastype=biastype,
+    def actuator(self, name, joint=None, gainprm=(1, 0, 0), biastype=0, biasprm=(0, 0, 0), gear=1.0,
+                 ctrllimited=True, ctrlrange=(-1, 1), forcelimited=False, forcerange=(0, 0), tendon=None):
+        """joint transmission (joint=name) or fixed-tendon transmission (tendon=name)."""
+        self.actuators.append(dict(name=name, joint=joint, tendon=tendon, gainprm=tuple(gainprm), biastype=biastype,
                                    biasprm=tuple(biasprm), gear=gear, ctrllimited=ctrllimited,
                                    ctrlrange=tuple(ctrlrange), forcelimited=forcelimited, forcerange=tuple(forcerange)))
+
+    def position(self, name, joint=None, tendon=None, kp=1.0, ctrlrange=(-1, 1), forcerange=None, gear=1.0):
+        """MJCF <position>: gain kp, affine bias (0, -kp, 0)."""
+        self.actuator(name, joint=joint, tendon=tendon, gainprm=(kp, 0, 0), biastype=1, biasprm=(0, -kp, 0), gear=gear,
+                      ctrlrange=ctrlrange, forcelimited=forcerange is not None, forcerange=forcerange or (0, 0))
 
     def tendon(self, name, joints, coefs, limited=False, range=(0, 0), margin=0.0, solreflimit=DEF_SOLREF, solimplimit=DEF_SOLIMP):
         """fixed tendon: length = sum coef * qpos[joint]"""
@@ -253,10 +259,15 @@ class ModelBuilder:
         for b in self.bodies:
             b.joints = [remap[j] for j in b.joints]
         for a in self.actuators:
+            if a.get("tendon") is not None:
+                a["trntype"] = 3
+                a["trnid"] = [t["name"] for t in self.tendons].index(a["tendon"]) if isinstance(a["tendon"], str) else int(a["tendon"])
+                continue
             if isinstance(a["joint"], str):
                 a["joint"] = [j.name for j in joints].index(a["joint"])
             else:
                 a["joint"] = remap[a["joint"]]
+            a["trntype"] = 0; a["trnid"] = a["joint"]
         self.joints = joints
         nj = len(joints)
         M = {}
@@ -401,7 +412,8 @@ class ModelBuilder:
         M["site_pos"] = np.array([s[2] for s in self.sites], float).reshape(ns, 3)
         M["site_quat"] = np.array([s[3] for s in self.sites], float).reshape(ns, 4)
         nu = len(self.actuators); A = self.actuators
-        M["actuator_trnid"] = np.array([a["joint"] for a in A], np.int32)
+        M["actuator_trntype"] = np.array([a["trntype"] for a in A], np.int32)
+        M["actuator_trnid"] = np.array([a["trnid"] for a in A], np.int32)
         M["actuator_ctrllimited"] = np.array([int(a["ctrllimited"]) for a in A], np.int32)
         M["actuator_forcelimited"] = np.array([int(a["forcelimited"]) for a in A], np.int32)
         M["actuator_biastype"] = np.array([a["biastype"] for a in A], np.int32)

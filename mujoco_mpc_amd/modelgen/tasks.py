@@ -15,9 +15,10 @@ import struct
 
 import numpy as np
 
-from .builder import (BOX, CAPSULE, CYLINDER, FREE, HINGE, PLANE, SLIDE, SPHERE, ModelBuilder)
+from .builder import (BALL, BOX, CAPSULE, CYLINDER, FREE, HINGE, PLANE, SLIDE, SPHERE, ModelBuilder)
 
 TASK_PARTICLE, TASK_CARTPOLE, TASK_QUADRUPED, TASK_COPYSTATE, TASK_HUMANOID_TRACK, TASK_HUMANOID_STAND, TASK_HUMANOID_WALK = 0, 1, 2, 3, 4, 5, 6
+TASK_SHADOW_REORIENT = 7
 OBJ_BODY, OBJ_XBODY, OBJ_GEOM, OBJ_SITE = 1, 2, 5, 6
 NORM_NPARAM = {-1: 0, 0: 0, 1: 2, 2: 1, 3: 1, 5: 1, 6: 1, 7: 2, 8: 1}   # mjpc/norm.cc:25-47
 
@@ -353,4 +354,125 @@ def humanoid_walk(timestep=0.015):
     return m, task, dict(N=10, P=3, sigma=(0.05, 0.0), interp=0, horizon=24, state=state, mocap=np.zeros(0))
 
 
-REGISTRY = {"humanoid_stand": humanoid_stand, "humanoid_walk": humanoid_walk, "particle": particle, "cartpole": cartpole, "quadruped": quadruped, "humanoid_track": humanoid_track}
+# ----------------------------------------------------------------------------------- Shadow hand + cube (BASELINE configs[4])
+# mjpc/tasks/shadow_reorient/task.xml is local (floor, goal body, cost table, planner numerics, the 35-value `grasp` key), so is
+# the cube (common_assets/reorientation_cube.xml + cube.xml.patch: half size 0.022, 0.126 kg, at 0.325 0 0.075,
+# quat 0.707 0.707 0 0).  The hand itself is menagerie's shadow_hand/right_hand.xml, fetched by CMake and NOT in the reference
+# tree.  What follows is therefore a SYNTHETIC hand, documented as such: the published kinematic tree
+# of the Shadow E3M5 right hand (forearm welded to the world; WRJ2, WRJ1; FF/MF/RF J4..J1; LF J5..J1; TH J5..J1 = 24 hinges),
+# joint ranges / damping / armature / frictionloss / position-servo gains and the four J2+J1 coupling tendons as recalled from
+# that file, link masses and primitive collision shapes of the same dimensions; the finger-tip meshes of the original are
+# replaced by capsules and the forearm is oriented so that the `grasp` key of task.xml makes sense (palm up, cube in the palm).
+# Sizes match the reference's task exactly: nq 35, nv 33, nu 20, 81 residuals, 6 cost terms.
+_HAND_PLASTIC = dict(solimp=(0.5, 0.99, 0.0001, 0.5, 2.0), solref=(0.005, 1.0), friction=(0.6, 0.005, 0.0001))
+_GRASP_KEY = [1, 0, 0, 0, 0.33326, -0.00362331, 0.0375343, 0.707635, 0.70405, 0.0500937, -0.0325089, 5.55212e-10, -0.235248,
+              -0.178041, 0.480484, 0.730515, 0.6284, -0.059347, 0.535468, 0.746225, 0.56556, -0.03491, 0.544632, 0.53414, 0.793355,
+              0.384846, -0.254843, 0.178072, 0.761935, 0.746225, -0.90042, 0.06721, 0.01047, 0.6981, 0.4255]     # task.xml:56
+
+
+def shadow_hand(timestep=0.01, cone=0, nconmax=32, nefcmax=128):
+    """Shadow-hand cube reorientation (mjpc/tasks/shadow_reorient/task.xml + hand.cc) on the synthetic hand described above.
+    cone: 0 pyramidal (MuJoCo's default), 1 elliptic with impratio 10."""
+    b = ModelBuilder(timestep=timestep, cone=cone, impratio=10.0 if cone == 1 else 1.0)
+    b.nconmax = nconmax; b.nefcmax = nefcmax
+    fr = (0.6, 0.005, 0.0001)                                       # task.xml:25-27 <default><geom friction=".6"/>
+    b.geom(0, "floor", PLANE, pos=(0, 0, -0.2), size=(0, 0, 0.05), friction=fr)
+    goal = b.body("goal", 0, pos=(0.325, 0.17, 0.0475))            # task.xml:32-35
+    b.joint(goal, "goal_ball", BALL, damping=0.01)
+    b.geom(goal, "goal", BOX, size=(0.022, 0.022, 0.022), mass=0.126, contype=0, conaffinity=0, friction=fr)
+    cube = b.body("cube", 0, pos=(0.325, 0.0, 0.075), quat=(0.707, 0.707, 0, 0))      # cube.xml.patch
+    b.joint(cube, "cube_free", FREE)
+    b.geom(cube, "cube", BOX, size=(0.022, 0.022, 0.022), mass=0.126, friction=fr)
+    # ---- the hand: local z = along the fingers -> world +x, local -y = palm side -> world +z
+    P = _HAND_PLASTIC
+    fore = b.body("rh_forearm", 0, pos=(0, 0, 0), quat=(0.5, -0.5, 0.5, -0.5),
+                  inertial=dict(mass=3.0, pos=(0, 0, 0.09), diaginertia=(0.0138, 0.0138, 0.00744)))
+    b.geom(fore, "forearm", CAPSULE, size=(0.04, 0.07), pos=(0, 0, 0.08), **P)
+    b.geom(fore, "forearm_mount", BOX, size=(0.035, 0.035, 0.035), pos=(0.01, 0, 0.181), quat=(0.380188, 0.924909, 0, 0), **P)
+
+    def hinge(body, name, axis, rng, damping=0.05):
+        b.joint(body, name, HINGE, axis=axis, limited=True, range=rng, damping=damping, armature=0.0002, frictionloss=0.01)
+
+    wrist = b.body("rh_wrist", fore, pos=(0.01, 0, 0.21348), inertial=dict(mass=0.1, pos=(0, 0, 0.029), diaginertia=(6.4e-5, 4.38e-5, 3.5e-5)))
+    hinge(wrist, "rh_WRJ2", (0, 1, 0), (-0.523599, 0.174533), damping=0.5)
+    b.geom(wrist, "wrist", CAPSULE, size=(0.0135, 0.015), quat=(0.5, 0.5, 0.5, -0.5), **P)
+    palm = b.body("rh_palm", wrist, pos=(0, 0, 0.034), inertial=dict(mass=0.3, pos=(0, 0, 0.035), diaginertia=(0.0005287, 0.0003581, 0.000191)))
+    hinge(palm, "rh_WRJ1", (1, 0, 0), (-0.698132, 0.488692), damping=0.5)
+    grasp_site = b.site(palm, "grasp_site", pos=(0, -0.035, 0.09))
+    for i, (size, pos) in enumerate([((0.031, 0.0035, 0.049), (0.011, 0.0085, 0.038)), ((0.018, 0.0085, 0.049), (-0.002, -0.0035, 0.038)),
+                                     ((0.013, 0.0085, 0.005), (0.029, -0.0035, 0.082)), ((0.013, 0.007, 0.009), (0.0265, -0.001, 0.07)),
+                                     ((0.0105, 0.0135, 0.012), (0.0315, -0.0085, 0.001)), ((0.009, 0.012, 0.002), (0.011, 0, 0.089)),
+                                     ((0.01, 0.012, 0.02), (-0.03, 0, 0.009))]):
+        b.geom(palm, f"palm{i}", BOX, size=size, pos=pos, **P)
+
+    def finger(prefix, parent, pos, jnames):
+        kn = b.body(f"rh_{prefix}knuckle", parent, pos=pos, inertial=dict(mass=0.008, pos=(0, 0, 0), diaginertia=(3.2e-7, 2.6e-7, 2.6e-7)))
+        hinge(kn, jnames[0], (0, -1, 0), (-0.349066, 0.349066))
+        pr = b.body(f"rh_{prefix}proximal", kn, inertial=dict(mass=0.03, pos=(0, 0, 0.0225), diaginertia=(1e-5, 9.8e-6, 1.8e-6)))
+        hinge(pr, jnames[1], (1, 0, 0), (-0.261799, 1.5708))
+        b.geom(pr, f"{prefix}proximal", CAPSULE, size=(0.009, 0.02), pos=(0, 0, 0.025), **P)
+        mi = b.body(f"rh_{prefix}middle", pr, pos=(0, 0, 0.045), inertial=dict(mass=0.017, pos=(0, 0, 0.0125), diaginertia=(2.7e-6, 2.6e-6, 8.7e-7)))
+        hinge(mi, jnames[2], (1, 0, 0), (0, 1.5708))
+        b.geom(mi, f"{prefix}middle", CAPSULE, size=(0.009, 0.0125), pos=(0, 0, 0.0125), **P)
+        di = b.body(f"rh_{prefix}distal", mi, pos=(0, 0, 0.025), inertial=dict(mass=0.013, pos=(0, 0, 0.0130769), diaginertia=(1.28092e-6, 1.12092e-6, 5.3e-7)))
+        hinge(di, jnames[3], (1, 0, 0), (0, 1.5708))
+        b.geom(di, f"{prefix}distal", CAPSULE, size=(0.0075, 0.009), pos=(0, 0, 0.013), **P)      # stands in for the finger-tip mesh
+        b.tendon(f"rh_{prefix.upper()}T1", [jnames[2], jnames[3]], [1.0, 1.0])
+
+    finger("ff", palm, (0.033, 0, 0.095), ["rh_FFJ4", "rh_FFJ3", "rh_FFJ2", "rh_FFJ1"])
+    finger("mf", palm, (0.011, 0, 0.099), ["rh_MFJ4", "rh_MFJ3", "rh_MFJ2", "rh_MFJ1"])
+    finger("rf", palm, (-0.011, 0, 0.095), ["rh_RFJ4", "rh_RFJ3", "rh_RFJ2", "rh_RFJ1"])
+    lfm = b.body("rh_lfmetacarpal", palm, pos=(-0.033, 0, 0.02071), inertial=dict(mass=0.03, pos=(0, 0, 0.04), diaginertia=(1.638e-5, 1.45e-5, 4.272e-6)))
+    hinge(lfm, "rh_LFJ5", (0.573576, 0, 0.819152), (0, 0.785398))
+    b.geom(lfm, "lfmetacarpal", BOX, size=(0.011, 0.012, 0.025), pos=(0.002, 0, 0.033), **P)
+    finger("lf", lfm, (0, 0, 0.06579), ["rh_LFJ4", "rh_LFJ3", "rh_LFJ2", "rh_LFJ1"])
+    thb = b.body("rh_thbase", palm, pos=(0.034, -0.00858, 0.029), quat=(0.92388, 0, 0.382683, 0), inertial=dict(mass=0.01, pos=(0, 0, 0), diaginertia=(1.6e-7, 1.6e-7, 1.6e-7)))
+    hinge(thb, "rh_THJ5", (0, 0, -1), (-1.0472, 1.0472))
+    thp = b.body("rh_thproximal", thb, inertial=dict(mass=0.04, pos=(0, 0, 0.019), diaginertia=(1.36e-5, 1.36e-5, 3.13e-6)))
+    hinge(thp, "rh_THJ4", (1, 0, 0), (0, 1.22173))
+    b.geom(thp, "thproximal", CAPSULE, size=(0.013, 0.019), pos=(0, 0, 0.019), **P)
+    thh = b.body("rh_thhub", thp, pos=(0, 0, 0.038), inertial=dict(mass=0.005, pos=(0, 0, 0), diaginertia=(1e-6, 1e-6, 3e-7)))
+    hinge(thh, "rh_THJ3", (1, 0, 0), (-0.20944, 0.20944))
+    thm = b.body("rh_thmiddle", thh, inertial=dict(mass=0.02, pos=(0, 0, 0.016), diaginertia=(5.1e-6, 5.1e-6, 1.21e-6)))
+    hinge(thm, "rh_THJ2", (0, -1, 0), (-0.698132, 0.698132))
+    b.geom(thm, "thmiddle", CAPSULE, size=(0.011, 0.009), pos=(0, 0, 0.012), **P)
+    b.geom(thm, "thmiddle_tip", SPHERE, size=(0.01,), pos=(0, 0, 0.03), **P)
+    thd = b.body("rh_thdistal", thm, pos=(0, 0, 0.032), quat=(0.707107, 0, 0, -0.707107), inertial=dict(mass=0.017, pos=(0, 0, 0.0145588), diaginertia=(2.37794e-6, 2.27794e-6, 1e-6)))
+    hinge(thd, "rh_THJ1", (1, 0, 0), (-0.261799, 1.5708))
+    b.geom(thd, "thdistal", CAPSULE, size=(0.009, 0.01), pos=(0, 0, 0.0145), **P)                 # stands in for the thumb-tip mesh
+    b.exclude(wrist, fore)
+    b.exclude(thp, thm)
+    # position servos in the order of the original's <actuator> block
+    b.position("rh_A_WRJ2", "rh_WRJ2", kp=10, ctrlrange=(-0.523599, 0.174533), forcerange=(-10, 10))
+    b.position("rh_A_WRJ1", "rh_WRJ1", kp=8, ctrlrange=(-0.698132, 0.488692), forcerange=(-5, 5))
+    b.position("rh_A_THJ5", "rh_THJ5", kp=0.4, ctrlrange=(-1.0472, 1.0472), forcerange=(-3, 3))
+    b.position("rh_A_THJ4", "rh_THJ4", kp=1, ctrlrange=(0, 1.22173), forcerange=(-2, 2))
+    b.position("rh_A_THJ3", "rh_THJ3", kp=0.5, ctrlrange=(-0.20944, 0.20944), forcerange=(-1, 1))
+    b.position("rh_A_THJ2", "rh_THJ2", kp=1.5, ctrlrange=(-0.698132, 0.698132), forcerange=(-1, 1))
+    b.position("rh_A_THJ1", "rh_THJ1", kp=1, ctrlrange=(-0.261799, 1.5708), forcerange=(-1, 1))
+    for f in ("FF", "MF", "RF", "LF"):
+        if f == "LF":
+            b.position("rh_A_LFJ5", "rh_LFJ5", kp=1, ctrlrange=(0, 0.785398), forcerange=(-1, 1))
+        b.position(f"rh_A_{f}J4", f"rh_{f}J4", kp=1, ctrlrange=(-0.349066, 0.349066), forcerange=(-1, 1))
+        b.position(f"rh_A_{f}J3", f"rh_{f}J3", kp=1, ctrlrange=(-0.261799, 1.5708), forcerange=(-1, 1))
+        b.position(f"rh_A_{f}J0", tendon=f"rh_{f}T1", kp=0.5, ctrlrange=(0, 3.1415), forcerange=(-1, 1))
+    b.key("grasp", _GRASP_KEY)
+    m = b.compile()
+    assert (m["nq"], m["nv"], m["nu"]) == (35, 33, 20)
+    bid = m["names"]["body"]
+    # cost table: task.xml:39-44 (user = norm, weight, lo, hi, params...)
+    terms = [(3, 1, 20.0, [0.02, 2.0]), (3, 0, 5.0), (3, 0, 10.0), (20, 0, 0.1), (26, 0, 2.5), (26, 0, 1.0e-4)]
+    task = make_task(TASK_SHADOW_REORIENT, terms, traces=[(OBJ_BODY, bid["cube"])],          # trace0: framepos objtype="body" cube
+                     int_data=[grasp_site, bid["cube"], bid["goal"], 0])
+    key = np.array(_GRASP_KEY, float)
+    # position targets that hold the grasp posture: joint angles of the key (J2 + J1 for the coupled pairs)
+    qj = {n: key[m["jnt_qposadr"][j]] for n, j in m["names"]["joint"].items()}
+    ctrl0 = []
+    for a in b.actuators:
+        ctrl0.append(qj[b.tendons[a["trnid"]]["joints"][0]] + qj[b.tendons[a["trnid"]]["joints"][1]] if a["trntype"] == 3 else key[m["jnt_qposadr"][a["trnid"]]])
+    state = np.concatenate([key, np.zeros(m["nv"])])
+    defaults = dict(N=10, P=5, sigma=(0.1, 0.0), interp=0, horizon=26, state=state, mocap=np.zeros(0), ctrl0=np.array(ctrl0))
+    return m, task, defaults
+
+
+REGISTRY = {"humanoid_stand": humanoid_stand, "humanoid_walk": humanoid_walk, "particle": particle, "cartpole": cartpole, "quadruped": quadruped, "humanoid_track": humanoid_track, "shadow_hand": shadow_hand}

@@ -230,7 +230,7 @@ class HipBackend:
         o = dict(states=np.zeros((nl, H, ds)), actions=np.zeros((nl, H, nu)), times=np.zeros((nl, H)),
                  residual=np.zeros((nl, H, nr)), costs=np.zeros((nl, H)), trace=np.zeros((nl, H, max(ntr, 1))),
                  knots=np.zeros((nl, P, nu)), diag=np.zeros((nl, 4), np.int32))
-        rc = self.lib.mjpc_hip_debug_fetch_all(self.h, *[o[k].ctypes.data_as(capi.c_double_p) for k in
+        rc = self.lib.mjpc_hip_get_all_candidates(self.h, *[o[k].ctypes.data_as(capi.c_double_p) for k in
                                                          ["states", "actions", "times", "residual", "costs", "trace", "knots"]],
                                                o["diag"].ctypes.data_as(capi.c_int_p))
         if rc != 0:

@@ -6,9 +6,13 @@
  * mjpc/trajectory.cc:158): normal points from geom1 to geom2, dist < 0 is penetration,
  * contact position is the midpoint between the two surfaces, contacts are created while
  * dist < margin.  Supported pairs: plane-{sphere,capsule,box,cylinder}, sphere-sphere,
- * sphere-capsule, capsule-capsule, sphere-box.  Other pairs (capsule-box, box-box and the
- * convex-fallback cylinder pairs) are counted in `unsupported` when their bounding spheres
- * overlap and produce no contact (documented gap).
+ * sphere-capsule, capsule-capsule, sphere-box, capsule-box, box-box.  MuJoCo's own capsule-box
+ * (mjraw_CapsuleBox) and box-box (mjc_BoxBox) routines are long case analyses that cannot be restated
+ * from the reference tree; the two colliders here are this build's own constructions with the same
+ * conventions and contact budgets (capsule-box <= 2 contacts: closest segment point + far end cap;
+ * box-box <= 4: separating-axis test, then reference-face clipping or one edge-edge contact).
+ * Other pairs (the convex-fallback cylinder / ellipsoid / mesh pairs) are counted in `unsupported`
+ * and produce no contact; the engine refuses such models at create().
  * PARITY UNPINNED (no MuJoCo in this image); analytic checks in tests/test_oracle_physics.py.
  */
 #include "oracle.h"
@@ -192,6 +196,215 @@ static int sphere_box(OContact *con, double margin, const double *sp, double sr,
   return 1;
 }
 
+/* ---- capsule (geom1) vs box (geom2) ------------------------------------------------------------
+ * The closest point of the capsule's segment to the box is found in the box frame: f(s) = dist^2(p0 + s h a, box)
+ * is convex and C1 in s, g(s) = f'(s) / (2h) = sum_i excess_i * sign(q_i) * a_i is monotone; its root is bracketed on
+ * [-1, 1] and bisected a fixed number of times (deterministic, the same IEEE operations on host and device).
+ * Contact 1 = sphere-box at that point; contact 2 = sphere-box at the end cap farther from it (a capsule lying on a
+ * face gets two contacts, a poking capsule one). */
+static double capsule_box_g(const double *p0, const double *a, double h, const double *b, double s) {
+  double g = 0;
+  for (int i = 0; i < 3; i++) {
+    double q = p0[i] + (s * h) * a[i];
+    double e = fabs(q) - b[i];
+    if (e > 0) g += (q > 0 ? e : -e) * a[i];
+  }
+  return g;
+}
+static int capsule_box(OContact *con, double margin, const double *cp, const double *cm, const double *cs,
+                       const double *bp, const double *bm, const double *bs) {
+  double axis[3] = {cm[2], cm[5], cm[8]}, dif[3], p0[3], a[3];
+  o_sub3(dif, cp, bp);
+  o_mulmattvec3(p0, bm, dif);
+  o_mulmattvec3(a, bm, axis);
+  double h = cs[1], sstar;
+  if (capsule_box_g(p0, a, h, bs, -1.0) >= 0) sstar = -1.0;
+  else if (capsule_box_g(p0, a, h, bs, 1.0) <= 0) sstar = 1.0;
+  else {
+    double lo = -1.0, hi = 1.0;
+    for (int it = 0; it < 48; it++) {
+      double mid = 0.5 * (lo + hi);
+      if (capsule_box_g(p0, a, h, bs, mid) < 0) lo = mid; else hi = mid;
+    }
+    sstar = 0.5 * (lo + hi);
+  }
+  int cnt = 0;
+  double pt[3];
+  o_addscl3(pt, cp, axis, sstar * h);
+  cnt += sphere_box(con + cnt, margin, pt, cs[0], bp, bm, bs);
+  double s2 = sstar <= 0 ? 1.0 : -1.0;
+  o_addscl3(pt, cp, axis, s2 * h);
+  cnt += sphere_box(con + cnt, margin, pt, cs[0], bp, bm, bs);
+  return cnt;
+}
+
+/* ---- box (geom1 = A) vs box (geom2 = B) ----------------------------------------------------------
+ * Separating-axis test over the 15 axes (faces of A, faces of B, edge x edge) in A's frame; the axis of largest
+ * separation (least penetration) decides the case, edge axes only when clearly better than the best face.
+ *   face case: the incident face of the other box is projected on the reference face; contact candidates are the
+ *     incident vertices inside the reference rectangle, the rectangle corners inside the incident parallelogram and
+ *     the edge crossings (24 slots, at most 8 filled); up to four are kept: deepest, farthest from it, and the two
+ *     extreme points on either side of that line.  dist = signed height over the reference face, pos = half way.
+ *   edge case: one contact at the closest points of the two supporting edges.
+ * Normal always points from A to B. */
+typedef struct { double x, y, d; int ok; } BBCand;
+#define BB_TOL 1e-9
+static int box_box(OContact *con, double margin, const double *pa, const double *ma, const double *sa,
+                   const double *pb, const double *mb, const double *sb) {
+  double R[9], AR[9], t[3], tb[3], dif[3];
+  o_sub3(dif, pb, pa);
+  o_mulmattvec3(t, ma, dif);                       /* centre of B in A's frame */
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+    double r = ma[i] * mb[j] + ma[3 + i] * mb[3 + j] + ma[6 + i] * mb[6 + j];     /* a_i . b_j (axes are matrix columns) */
+    R[3 * i + j] = r; AR[3 * i + j] = fabs(r);
+  }
+  for (int j = 0; j < 3; j++) tb[j] = t[0] * R[j] + t[1] * R[3 + j] + t[2] * R[6 + j];
+  double best = -1e300; int code = -1;
+  for (int i = 0; i < 3; i++) {
+    double s = fabs(t[i]) - (sa[i] + sb[0] * AR[3 * i] + sb[1] * AR[3 * i + 1] + sb[2] * AR[3 * i + 2]);
+    if (s > margin) return 0;
+    if (s > best) { best = s; code = i; }
+  }
+  for (int j = 0; j < 3; j++) {
+    double s = fabs(tb[j]) - (sb[j] + sa[0] * AR[j] + sa[1] * AR[3 + j] + sa[2] * AR[6 + j]);
+    if (s > margin) return 0;
+    if (s > best) { best = s; code = 3 + j; }
+  }
+  double ebest = -1e300; int ecode = -1;
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+    int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+    double l2 = 1.0 - R[3 * i + j] * R[3 * i + j];
+    if (l2 < 1e-6) continue;                       /* parallel edges: covered by the face axes */
+    double proj = t[i2] * R[3 * i1 + j] - t[i1] * R[3 * i2 + j];
+    double ra = sa[i1] * AR[3 * i2 + j] + sa[i2] * AR[3 * i1 + j];
+    double rb = sb[j1] * AR[3 * i + j2] + sb[j2] * AR[3 * i + j1];
+    double s = (fabs(proj) - (ra + rb)) / sqrt(l2);
+    if (s > margin) return 0;
+    if (s > ebest) { ebest = s; ecode = 3 * i + j; }
+  }
+  if (ecode >= 0 && ebest > best + 0.05 * fabs(best) + BB_TOL) {
+    /* ---- edge-edge */
+    int i = ecode / 3, j = ecode % 3;
+    double ai[3] = {ma[i], ma[3 + i], ma[6 + i]}, bj[3] = {mb[j], mb[3 + j], mb[6 + j]}, n[3];
+    o_cross(n, ai, bj);
+    o_normalize3(n);
+    if (o_dot3(n, dif) < 0) o_scl3(n, n, -1);      /* from A to B */
+    double ea[3], eb[3];
+    o_copy3(ea, pa); o_copy3(eb, pb);
+    for (int k = 0; k < 3; k++) {
+      double ak[3] = {ma[k], ma[3 + k], ma[6 + k]}, bk[3] = {mb[k], mb[3 + k], mb[6 + k]};
+      if (k != i) o_addtoscl3(ea, ak, o_dot3(n, ak) > 0 ? sa[k] : -sa[k]);
+      if (k != j) o_addtoscl3(eb, bk, o_dot3(n, bk) > 0 ? -sb[k] : sb[k]);
+    }
+    /* closest points of the lines ea + u ai, eb + v bj */
+    double w[3]; o_sub3(w, eb, ea);
+    double c = R[3 * i + j], d1 = o_dot3(w, ai), d2 = o_dot3(w, bj), den = 1.0 - c * c;
+    double u = o_clip((d1 - c * d2) / den, -sa[i], sa[i]);
+    double v = o_clip((c * d1 - d2) / den, -sb[j], sb[j]);
+    double qa[3], qb[3];
+    o_addscl3(qa, ea, ai, u); o_addscl3(qb, eb, bj, v);
+    o_sub3(w, qb, qa);
+    double dist = o_dot3(w, n);
+    if (dist > margin) return 0;
+    o_zero(con->frame, 9); o_copy3(con->frame, n);
+    con->dist = dist;
+    con->pos[0] = 0.5 * (qa[0] + qb[0]); con->pos[1] = 0.5 * (qa[1] + qb[1]); con->pos[2] = 0.5 * (qa[2] + qb[2]);
+    return 1;
+  }
+  /* ---- face case: reference box r, incident box q */
+  int refA = code < 3, ax = refA ? code : code - 3;
+  const double *pr = refA ? pa : pb, *mr = refA ? ma : mb, *sr = refA ? sa : sb;
+  const double *pq = refA ? pb : pa, *mq = refA ? mb : ma, *sq = refA ? sb : sa;
+  double sgn = (refA ? t[ax] : -tb[ax]) >= 0 ? 1.0 : -1.0;       /* towards the incident box */
+  int u1 = (ax + 1) % 3, u2 = (ax + 2) % 3;
+  double n[3] = {sgn * mr[ax], sgn * mr[3 + ax], sgn * mr[6 + ax]};
+  double ru[3] = {mr[u1], mr[3 + u1], mr[6 + u1]}, rv[3] = {mr[u2], mr[3 + u2], mr[6 + u2]};
+  double hu = sr[u1], hv = sr[u2], hn = sr[ax];
+  /* incident face: the face of q whose outward normal is most opposed to n */
+  double nl[3];
+  o_mulmattvec3(nl, mq, n);
+  int k = 0; double amax = fabs(nl[0]);
+  if (fabs(nl[1]) > amax) { amax = fabs(nl[1]); k = 1; }
+  if (fabs(nl[2]) > amax) { amax = fabs(nl[2]); k = 2; }
+  int k1 = (k + 1) % 3, k2 = (k + 2) % 3;
+  double qk[3] = {mq[k], mq[3 + k], mq[6 + k]}, q1[3] = {mq[k1], mq[3 + k1], mq[6 + k1]}, q2[3] = {mq[k2], mq[3 + k2], mq[6 + k2]};
+  double cen[3], rel[3];
+  o_addscl3(cen, pq, qk, nl[k] > 0 ? -sq[k] : sq[k]);
+  o_sub3(rel, cen, pr);
+  /* incident face centre and half edges in the reference face frame (x, y, height over the face) */
+  double c0[3] = {o_dot3(rel, ru), o_dot3(rel, rv), o_dot3(rel, n) - hn};
+  double e1[3] = {sq[k1] * o_dot3(q1, ru), sq[k1] * o_dot3(q1, rv), sq[k1] * o_dot3(q1, n)};
+  double e2[3] = {sq[k2] * o_dot3(q2, ru), sq[k2] * o_dot3(q2, rv), sq[k2] * o_dot3(q2, n)};
+  BBCand cand[24];
+  for (int q = 0; q < 24; q++) cand[q].ok = 0;
+  double vx[4], vy[4], vd[4];
+  for (int q = 0; q < 4; q++) {                    /* (a) incident vertices, counter-clockwise in (e1, e2) */
+    double s1 = (q == 0 || q == 3) ? -1.0 : 1.0, s2 = (q < 2) ? -1.0 : 1.0;
+    vx[q] = c0[0] + s1 * e1[0] + s2 * e2[0]; vy[q] = c0[1] + s1 * e1[1] + s2 * e2[1]; vd[q] = c0[2] + s1 * e1[2] + s2 * e2[2];
+    if (fabs(vx[q]) <= hu + BB_TOL && fabs(vy[q]) <= hv + BB_TOL) { cand[q].ok = 1; cand[q].x = vx[q]; cand[q].y = vy[q]; cand[q].d = vd[q]; }
+  }
+  double det = e1[0] * e2[1] - e1[1] * e2[0];
+  if (fabs(det) > 1e-14) {                         /* (b) reference corners inside the incident parallelogram */
+    for (int q = 0; q < 4; q++) {
+      double cx = (q == 0 || q == 3) ? -hu : hu, cy = (q < 2) ? -hv : hv;
+      double dx = cx - c0[0], dy = cy - c0[1];
+      double al = (dx * e2[1] - dy * e2[0]) / det, be = (e1[0] * dy - e1[1] * dx) / det;
+      if (fabs(al) <= 1.0 + BB_TOL && fabs(be) <= 1.0 + BB_TOL) {
+        BBCand *cd = cand + 4 + q;
+        cd->ok = 1; cd->x = cx; cd->y = cy; cd->d = c0[2] + al * e1[2] + be * e2[2];
+      }
+    }
+  }
+  for (int q = 0; q < 4; q++) {                    /* (c) incident edges against the four rectangle lines */
+    int q2i = (q + 1) & 3;
+    double px = vx[q], py = vy[q], pd = vd[q], dx = vx[q2i] - px, dy = vy[q2i] - py, dd = vd[q2i] - pd;
+    for (int e = 0; e < 4; e++) {
+      int xline = e < 2;
+      double lim = (e & 1) ? 1.0 : -1.0;
+      double num = xline ? lim * hu - px : lim * hv - py, den = xline ? dx : dy;
+      if (fabs(den) < 1e-14) continue;
+      double s = num / den;
+      if (s <= 0.0 || s >= 1.0) continue;
+      double ox = xline ? lim * hu : px + s * dx, oy = xline ? py + s * dy : lim * hv;
+      if ((xline ? fabs(oy) - hv : fabs(ox) - hu) > BB_TOL) continue;
+      BBCand *cd = cand + 8 + 4 * q + e;
+      cd->ok = 1; cd->x = ox; cd->y = oy; cd->d = pd + s * dd;
+    }
+  }
+  /* selection: deepest, farthest from it, then the extreme points on either side of that line */
+  int sel[4] = {-1, -1, -1, -1};
+  double bd = 1e300;
+  for (int q = 0; q < 24; q++) if (cand[q].ok && cand[q].d <= margin && cand[q].d < bd) { bd = cand[q].d; sel[0] = q; }
+  if (sel[0] < 0) return 0;
+  double x0 = cand[sel[0]].x, y0 = cand[sel[0]].y, far = 1e-16;
+  for (int q = 0; q < 24; q++) if (cand[q].ok && cand[q].d <= margin) {
+    double r2 = (cand[q].x - x0) * (cand[q].x - x0) + (cand[q].y - y0) * (cand[q].y - y0);
+    if (r2 > far) { far = r2; sel[1] = q; }
+  }
+  if (sel[1] >= 0) {
+    double lx = cand[sel[1]].x - x0, ly = cand[sel[1]].y - y0, amx = 1e-12, amn = -1e-12;
+    for (int q = 0; q < 24; q++) if (cand[q].ok && cand[q].d <= margin) {
+      double ar = lx * (cand[q].y - y0) - ly * (cand[q].x - x0);
+      if (ar > amx) { amx = ar; sel[2] = q; }
+      if (ar < amn) { amn = ar; sel[3] = q; }
+    }
+  }
+  int cnt = 0;
+  for (int q = 0; q < 4; q++) if (sel[q] >= 0) {
+    const BBCand *cd = cand + sel[q];
+    OContact *c = con + cnt++;
+    /* the point on the incident face, moved half way down to the reference face */
+    double hgt = hn + cd->d - 0.5 * cd->d;
+    c->pos[0] = pr[0] + cd->x * ru[0] + cd->y * rv[0] + hgt * n[0];
+    c->pos[1] = pr[1] + cd->x * ru[1] + cd->y * rv[1] + hgt * n[1];
+    c->pos[2] = pr[2] + cd->x * ru[2] + cd->y * rv[2] + hgt * n[2];
+    c->dist = cd->d;
+    o_zero(c->frame, 9);
+    if (refA) o_copy3(c->frame, n); else o_scl3(c->frame, n, -1);
+  }
+  return cnt;
+}
+
 int oracle_collide_pair(const OModel *om, OData *d, int g1, int g2, double margin, OContact *con, int *unsupported) {
   const MjpcHipModel *m = &om->m;
   int t1 = m->geom_type[g1], t2 = m->geom_type[g2];
@@ -217,7 +430,41 @@ int oracle_collide_pair(const OModel *om, OData *d, int g1, int g2, double margi
     }
   } else if (t1 == MJPC_GEOM_CAPSULE && t2 == MJPC_GEOM_CAPSULE) {
     return capsule_capsule(con, margin, p1, m1, s1, p2, m2, s2);
+  } else if (t1 == MJPC_GEOM_CAPSULE && t2 == MJPC_GEOM_BOX) {
+    return capsule_box(con, margin, p1, m1, s1, p2, m2, s2);
+  } else if (t1 == MJPC_GEOM_BOX && t2 == MJPC_GEOM_BOX) {
+    return box_box(con, margin, p1, m1, s1, p2, m2, s2);
+  }
+  /* A cylinder against anything but a plane has no analytic collider (MuJoCo falls back to its convex solver, which cannot be
+   * restated here).  Conservative exact test instead: the cylinder's bounding capsule (same radius and half length) contains
+   * it, so if that capsule is farther than the margin there is certainly no contact -> 0, correctly.  If the bounding capsule
+   * touches, the true answer is unknown: counted in `unsupported`, and the caller fails the rollout (never a silent miss). */
+  if (t1 == MJPC_GEOM_CYLINDER || t2 == MJPC_GEOM_CYLINDER) {
+    OContact tmp[4];
+    int n = -1;
+    if (t1 == MJPC_GEOM_SPHERE) n = sphere_capsule(tmp, margin, p1, s1[0], p2, m2, s2);
+    else if (t1 == MJPC_GEOM_CAPSULE || (t1 == MJPC_GEOM_CYLINDER && t2 == MJPC_GEOM_CYLINDER)) n = capsule_capsule(tmp, margin, p1, m1, s1, p2, m2, s2);
+    else if (t1 == MJPC_GEOM_CYLINDER && t2 == MJPC_GEOM_BOX) n = capsule_box(tmp, margin, p1, m1, s1, p2, m2, s2);
+    if (n == 0) return 0;
   }
   (*unsupported)++;
   return 0;
+}
+
+/* test access to the primitive colliders (tests/test_oracle_physics.py): geoms given directly, type1 <= type2;
+ * out[k] = dist, pos[3], normal[3] */
+int oracle_debug_collide(int t1, const double *s1, const double *p1, const double *m1, int t2, const double *s2, const double *p2,
+                         const double *m2, double margin, double *out) {
+  OContact con[8];
+  int n = -1;
+  if (t1 == MJPC_GEOM_SPHERE && t2 == MJPC_GEOM_BOX) n = sphere_box(con, margin, p1, s1[0], p2, m2, s2);
+  else if (t1 == MJPC_GEOM_CAPSULE && t2 == MJPC_GEOM_BOX) n = capsule_box(con, margin, p1, m1, s1, p2, m2, s2);
+  else if (t1 == MJPC_GEOM_BOX && t2 == MJPC_GEOM_BOX) n = box_box(con, margin, p1, m1, s1, p2, m2, s2);
+  else if (t1 == MJPC_GEOM_CAPSULE && t2 == MJPC_GEOM_CAPSULE) n = capsule_capsule(con, margin, p1, m1, s1, p2, m2, s2);
+  for (int k = 0; k < n; k++) {
+    out[7 * k] = con[k].dist;
+    o_copy3(out + 7 * k + 1, con[k].pos);
+    o_copy3(out + 7 * k + 4, con[k].frame);
+  }
+  return n;
 }

@@ -54,7 +54,7 @@ OModel *oracle_create(const MjpcHipModel *src, const MjpcHipTask *task) {
   CD(geom_solref, 2 * ng); CD(geom_solimp, 5 * ng); CD(geom_margin, ng); CD(geom_gap, ng); CD(geom_rbound, ng);
   CI(exclude_signature, src->nexclude);
   CI(site_bodyid, ns); CD(site_pos, 3 * ns); CD(site_quat, 4 * ns);
-  CI(actuator_trnid, nu); CI(actuator_ctrllimited, nu); CI(actuator_forcelimited, nu); CI(actuator_biastype, nu);
+  CI(actuator_trntype, nu); CI(actuator_trnid, nu); CI(actuator_ctrllimited, nu); CI(actuator_forcelimited, nu); CI(actuator_biastype, nu);
   CD(actuator_gainprm, 3 * nu); CD(actuator_biasprm, 3 * nu); CD(actuator_gear, nu);
   CD(actuator_ctrlrange, 2 * nu); CD(actuator_forcerange, 2 * nu);
   CI(tendon_adr, src->ntendon); CI(tendon_num, src->ntendon); CI(tendon_limited, src->ntendon); CI(wrap_objid, src->nwrap);

@@ -63,7 +63,7 @@ typedef struct OData {
   /* solver scratch */
   double *Ma, *grad, *Mgrad, *search, *Mv, *work;
   int solver_iter;
-  int warning;          /* sticky: bad qpos/qvel/qacc, buffer overflow (mjNWARNING analogue) */
+  int warning;          /* sticky MJPC_WARN_* bits: bad qpos/qvel/qacc, buffer overflow, ray miss, unsupported pair (mjNWARNING analogue) */
   double *sensordata;   /* residual[num_residual] */
   void *blocks[256]; int nblocks;
 } OData;
@@ -94,7 +94,7 @@ void oracle_free_data(OData *d);
 void oracle_forward(const OModel *om, OData *d);              /* mj_forward + residual */
 void oracle_step(const OModel *om, OData *d);                 /* mj_step */
 void oracle_residual(const OModel *om, OData *d, double *residual);
-double oracle_ray_ground(const OModel *om, const OData *d, const double pos[3]);
+double oracle_ray_ground(const OModel *om, OData *d, const double pos[3]);
 
 /* MJPC side */
 void oracle_spline_sample(const double *times, const double *values, int P, int dim,
@@ -110,7 +110,14 @@ void oracle_philox(uint64_t seed, uint64_t stream, uint32_t c0, uint32_t c1, uin
  * per-thread mjData of the reference, but qacc_warmstart is zeroed first */
 void oracle_rollout(const OModel *om, OData *d, const MjpcHipPlanInput *in,
                     const double *knots, int row, OPlanOutput *out);
-/* full plan step with a std::thread-like FIFO pool of nthreads workers */
+/* persistent FIFO worker pool (mjpc/threadpool.cc:30-85): threads and their per-worker OData arenas live across plan
+ * steps, like the reference's ThreadPool + Planner::data_ (planners/planner.cc:23-33); nthreads == 1 runs on the caller */
+typedef struct OPool OPool;
+OPool *oracle_pool_create(const OModel *om, int nthreads);
+void oracle_pool_destroy(OPool *pool);
+int oracle_pool_threads(const OPool *pool);
+int oracle_pool_plan(OPool *pool, const MjpcHipPlanInput *in, OPlanOutput *out);
+/* one plan step on a pool that lives for this call only (tests) */
 int oracle_plan(const OModel *om, const MjpcHipPlanInput *in, OPlanOutput *out, int nthreads);
 
 /* debug accessors for physics unit tests */

@@ -327,9 +327,11 @@ static void collision(const OModel *om, OData *d) {
       if (o_dot3(dif, dif) > bound * bound) continue;
     }
     OContact con[8];
+    int before = d->unsupported;
     int n = oracle_collide_pair(om, d, g1, g2, margin, con, &d->unsupported);
+    if (d->unsupported != before) d->warning |= MJPC_WARN_UNSUPPORTED;   /* a pair without a collider came within reach: fail loudly */
     for (int k = 0; k < n; k++) {
-      if (d->ncon >= om->nconmax) { d->warning = 1; return; }   /* contact buffer full */
+      if (d->ncon >= om->nconmax) { d->warning |= MJPC_WARN_CONTACTFULL; return; }   /* contact buffer full */
       OContact *c = d->contact + d->ncon++;
       *c = proto;
       c->dist = con[k].dist;
@@ -361,7 +363,7 @@ static double impedance(const double *solimp_in, double pos, double margin) {
 }
 
 static int add_row(const OModel *om, OData *d, int type, int id) {
-  if (d->nefc >= om->nefcmax) { d->warning = 1; return -1; }   /* constraint buffer full */
+  if (d->nefc >= om->nefcmax) { d->warning |= MJPC_WARN_CNSTRFULL; return -1; }   /* constraint buffer full */
   int r = d->nefc++;
   o_zero(d->efc_J + r * om->m.nv, om->m.nv);
   d->efc_type[r] = type; d->efc_id[r] = id;
@@ -596,22 +598,36 @@ static void rne_bias(const OModel *om, OData *d) {
   for (int i = 0; i < m->nv; i++) d->qfrc_bias[i] = o_dot(d->cdof + 6 * i, d->cfrc + 6 * m->dof_bodyid[i], 6);
 }
 
+/* mj_fwdActuation for joint and fixed-tendon transmissions: length = sum coef * qpos, velocity = sum coef * qvel with
+ * coef = gear (joint) or gear * wrap coefficient (tendon); force = gain * ctrl + bias0 + bias1 * length + bias2 * velocity,
+ * clamped to forcerange; qfrc_actuator += moment^T force.  <position kp> servos are gain = kp, bias = (0, -kp, 0). */
 static void actuation(const OModel *om, OData *d) {
   const MjpcHipModel *m = &om->m;
   o_zero(d->qfrc_actuator, m->nv);
   for (int i = 0; i < m->nu; i++) {
     double ctrl = d->ctrl[i];
     if (m->actuator_ctrllimited[i]) ctrl = o_clip(ctrl, m->actuator_ctrlrange[2 * i], m->actuator_ctrlrange[2 * i + 1]);
-    int j = m->actuator_trnid[i];
-    int qa = m->jnt_qposadr[j], da = m->jnt_dofadr[j];
     double gear = m->actuator_gear[i];
+    int id = m->actuator_trnid[i];
+    int tendon = m->actuator_trntype[i] == MJPC_TRN_TENDON;
+    int w0 = tendon ? m->tendon_adr[id] : 0, nw = tendon ? m->tendon_num[id] : 1;
+    double length = 0, velocity = 0;
+    for (int w = 0; w < nw; w++) {
+      int j = tendon ? m->wrap_objid[w0 + w] : id;
+      double coef = tendon ? gear * m->wrap_prm[w0 + w] : gear;
+      length += coef * d->qpos[m->jnt_qposadr[j]];
+      velocity += coef * d->qvel[m->jnt_dofadr[j]];
+    }
     double force = m->actuator_gainprm[3 * i] * ctrl;
     if (m->actuator_biastype[i] == MJPC_BIAS_AFFINE)
-      force += m->actuator_biasprm[3 * i] + m->actuator_biasprm[3 * i + 1] * (gear * d->qpos[qa]) +
-               m->actuator_biasprm[3 * i + 2] * (gear * d->qvel[da]);
+      force += m->actuator_biasprm[3 * i] + m->actuator_biasprm[3 * i + 1] * length + m->actuator_biasprm[3 * i + 2] * velocity;
     if (m->actuator_forcelimited[i]) force = o_clip(force, m->actuator_forcerange[2 * i], m->actuator_forcerange[2 * i + 1]);
     d->actuator_force[i] = force;
-    d->qfrc_actuator[da] += gear * force;
+    for (int w = 0; w < nw; w++) {
+      int j = tendon ? m->wrap_objid[w0 + w] : id;
+      double coef = tendon ? gear * m->wrap_prm[w0 + w] : gear;
+      d->qfrc_actuator[m->jnt_dofadr[j]] += coef * force;
+    }
   }
 }
 
@@ -914,9 +930,11 @@ void oracle_step(const OModel *om, OData *d) {
   const MjpcHipModel *m = &om->m;
   int nv = m->nv;
   double h = m->timestep;
-  if (bad(d->qpos, m->nq) || bad(d->qvel, nv)) { d->warning = 1; return; }
+  if (bad(d->qpos, m->nq)) d->warning |= MJPC_WARN_BADQPOS;
+  if (bad(d->qvel, nv)) d->warning |= MJPC_WARN_BADQVEL;
+  if (d->warning) return;
   oracle_forward(om, d);
-  if (bad(d->qacc, nv)) { d->warning = 1; return; }
+  if (bad(d->qacc, nv)) { d->warning |= MJPC_WARN_BADQACC; return; }
   /* Euler, implicit in joint damping */
   int damped = 0;
   for (int i = 0; i < nv; i++) if (m->dof_damping[i] > 0) damped = 1;

@@ -156,13 +156,16 @@ void oracle_rollout(const OModel *om, OData *d, const MjpcHipPlanInput *in, cons
     o_copy(states + (s + 1) * ds + nq, d->qvel, nv);
     times[s + 1] = d->time;
   }
-  out->unsupported += d->unsupported; d->unsupported = 0;
-  if (failure) { out->failure[row] = 1; out->returns[row] = MJPC_MAX_RETURN; return; }
+  if (failure) { out->unsupported += d->unsupported; d->unsupported = 0; out->failure[row] = d->warning; out->returns[row] = MJPC_MAX_RETURN; return; }
   if (H > 1) o_copy(actions + (H - 1) * nu, actions + (H - 2) * nu, nu);
   else o_zero(actions + (H - 1) * nu, nu);
   oracle_forward(om, d);
   o_copy(residual + (H - 1) * nr, d->sensordata, nr);
   get_trace(om, d, trace + (H - 1) * ntr);
+  out->unsupported += d->unsupported; d->unsupported = 0;
+  /* warnings of the terminal forward pass fail the candidate too (the reference leaves them in mjData for the worker's next
+   * rollout to trip over, trajectory.cc:183-206: scheduling-dependent; here the definition is per candidate, like the device) */
+  if (d->warning) { out->failure[row] = d->warning; out->returns[row] = MJPC_MAX_RETURN; return; }
   /* UpdateReturn, trajectory.cc:312-326 */
   double total = 0;
   for (int s = 0; s < H; s++) {
@@ -174,15 +177,26 @@ void oracle_rollout(const OModel *om, OData *d, const MjpcHipPlanInput *in, cons
   out->failure[row] = 0;
 }
 
-/* ---- plan step with a FIFO pool -------------------------------------------------------- */
-typedef struct {
-  const OModel *om; const MjpcHipPlanInput *in; OPlanOutput *out;
-  const double *eps; const int *sel;
-  int next; int unsupported;
+/* ---- plan step on a persistent FIFO pool (mjpc/threadpool.cc:30-85) ------------------------
+ * The reference creates its workers once (ThreadPool ctor, threadpool.cc:30-49), every worker owns one mjData for
+ * its whole life (Planner::ResizeMjData, planners/planner.cc:23-33; indexed by ThreadPool::WorkerId()),
+ * Schedule() pushes one closure per candidate on a mutex-protected queue (threadpool.cc:51-60), the workers pop in
+ * FIFO order (threadpool.cc:62-85) and the planner blocks in WaitCount() until all N have run
+ * (sampling/planner.cc:379).  OPool is that: the threads and their OData arenas survive across plan steps. */
+struct OPool {
+  const OModel *om;
+  int nthreads;
+  pthread_t *th;
+  OData **data;               /* one arena per worker, reused across rollouts and plan steps */
+  double **eps_row;           /* per-worker scratch for the candidate's noise row */
   pthread_mutex_t mtx;
-} PlanJob;
+  pthread_cond_t cv_job, cv_done;
+  const MjpcHipPlanInput *in; OPlanOutput *out;
+  int next, total, done, shutdown, started, unsupported;
+};
+typedef struct { OPool *pool; int id; } PoolArg;
 
-static void make_candidate_knots(const OModel *om, const MjpcHipPlanInput *in, int i, const double *eps, const int *sel, double *knots) {
+static void candidate_knots(const OModel *om, const MjpcHipPlanInput *in, int i, const double *eps_row, int sel_i, double *knots) {
   const MjpcHipModel *m = &om->m;
   int P = in->num_spline_points, nu = m->nu;
   o_copy(knots, in->knot_values, P * nu);
@@ -190,18 +204,18 @@ static void make_candidate_knots(const OModel *om, const MjpcHipPlanInput *in, i
   if (i == in->nominal_index) return;              /* planner.cc:361 (index 0); cross_entropy/planner.cc:412 (extra rollout) */
   if (in->noise_std) {                             /* cross_entropy/planner.cc:340-375: absolute per-parameter std */
     for (int p = 0; p < P; p++) {
-      for (int k = 0; k < nu; k++) knots[p * nu + k] += in->noise_std[p * nu + k] * eps[((size_t)i * P + p) * nu + k];
+      for (int k = 0; k < nu; k++) knots[p * nu + k] += in->noise_std[p * nu + k] * eps_row[p * nu + k];
       for (int k = 0; k < nu; k++)
         knots[p * nu + k] = o_clip(knots[p * nu + k], m->actuator_ctrlrange[2 * k], m->actuator_ctrlrange[2 * k + 1]);
     }
     return;
   }
   double std = in->noise_exploration[0];
-  if (in->noise_exploration[1] > 0 && sel && sel[i]) std = in->noise_exploration[1];
+  if (in->noise_exploration[1] > 0 && sel_i) std = in->noise_exploration[1];
   for (int p = 0; p < P; p++) {
     for (int k = 0; k < nu; k++) {
       double scale = 0.5 * (m->actuator_ctrlrange[2 * k + 1] - m->actuator_ctrlrange[2 * k]);
-      double noise = (scale * std) * eps[((size_t)i * P + p) * nu + k];
+      double noise = (scale * std) * eps_row[p * nu + k];
       knots[p * nu + k] += noise;
     }
     for (int k = 0; k < nu; k++)
@@ -209,60 +223,109 @@ static void make_candidate_knots(const OModel *om, const MjpcHipPlanInput *in, i
   }
 }
 
-static void *worker(void *arg) {
-  PlanJob *job = (PlanJob *)arg;
-  struct timespec w0, w1, c0, c1; int dbg = getenv("ORACLE_DEBUG_THREADS") != NULL; int cnt = 0;
-  if (dbg) { clock_gettime(CLOCK_MONOTONIC, &w0); clock_gettime(CLOCK_THREAD_CPUTIME_ID, &c0); }
-  OData *d = oracle_make_data(job->om);
-  int P = job->in->num_spline_points, nu = job->om->m.nu;
-  OPlanOutput local = *job->out;
+/* one queued closure of SamplingPlanner::Rollouts (planner.cc:352-376): copy the nominal policy, add noise, roll out */
+static void run_candidate(OPool *pl, int id, int r) {
+  const MjpcHipPlanInput *in = pl->in;
+  int P = in->num_spline_points, nu = pl->om->m.nu;
+  int i = in->candidate_offset + r;
+  const double *row; int sel_i = 0;
+  if (in->noise_eps) { row = in->noise_eps + (size_t)i * P * nu; sel_i = in->noise_sel ? in->noise_sel[i] : 0; }
+  else { oracle_noise(in->seed, in->stream, i, 1, P, nu, in->noise_exploration[1], pl->eps_row[id], &sel_i); row = pl->eps_row[id]; }
+  double *knots = pl->out->knots + (size_t)r * P * nu;
+  candidate_knots(pl->om, in, i, row, sel_i, knots);
+  OPlanOutput local = *pl->out;
   local.unsupported = 0;
+  oracle_rollout(pl->om, pl->data[id], in, knots, r, &local);
+  if (local.unsupported) { pthread_mutex_lock(&pl->mtx); pl->unsupported += local.unsupported; pthread_mutex_unlock(&pl->mtx); }
+}
+
+static void *pool_worker(void *arg) {
+  PoolArg *pa = (PoolArg *)arg;
+  OPool *pl = pa->pool; int id = pa->id;
+  free(pa);
+  pthread_mutex_lock(&pl->mtx);
+  pl->started++;
+  pthread_cond_broadcast(&pl->cv_done);
   for (;;) {
-    pthread_mutex_lock(&job->mtx);
-    int r = job->next++;
-    pthread_mutex_unlock(&job->mtx);
-    if (r >= job->in->num_local) break;
-    int i = job->in->candidate_offset + r;
-    double *knots = job->out->knots + (size_t)r * P * nu;
-    make_candidate_knots(job->om, job->in, i, job->eps, job->sel, knots);
-    oracle_rollout(job->om, d, job->in, knots, r, &local); cnt++;
+    while (!pl->shutdown && pl->next >= pl->total) pthread_cond_wait(&pl->cv_job, &pl->mtx);
+    if (pl->shutdown) break;
+    int r = pl->next++;                              /* pop the head of the queue */
+    pthread_mutex_unlock(&pl->mtx);
+    run_candidate(pl, id, r);
+    pthread_mutex_lock(&pl->mtx);
+    if (++pl->done == pl->total) pthread_cond_broadcast(&pl->cv_done);
   }
-  if (dbg) { clock_gettime(CLOCK_MONOTONIC, &w1); clock_gettime(CLOCK_THREAD_CPUTIME_ID, &c1);
-    fprintf(stderr, "worker: %d rollouts wall %.3f cpu %.3f\n", cnt, (w1.tv_sec-w0.tv_sec)+(w1.tv_nsec-w0.tv_nsec)*1e-9, (c1.tv_sec-c0.tv_sec)+(c1.tv_nsec-c0.tv_nsec)*1e-9); }
-  pthread_mutex_lock(&job->mtx);
-  job->unsupported += local.unsupported;
-  pthread_mutex_unlock(&job->mtx);
-  oracle_free_data(d);
+  pthread_mutex_unlock(&pl->mtx);
   return NULL;
 }
 
-int oracle_plan(const OModel *om, const MjpcHipPlanInput *in, OPlanOutput *out, int nthreads) {
-  int N = in->num_trajectory, P = in->num_spline_points, nu = om->m.nu;
-  double *eps_own = NULL; int *sel_own = NULL;
-  const double *eps = in->noise_eps; const int *sel = in->noise_sel;
-  if (!eps) {
-    eps_own = (double *)malloc(sizeof(double) * (size_t)N * P * nu + 8);
-    sel_own = (int *)malloc(sizeof(int) * (size_t)N + 8);
-    oracle_noise(in->seed, in->stream, 0, N, P, nu, in->noise_exploration[1], eps_own, sel_own);
-    eps = eps_own; sel = sel_own;
-  }
-  PlanJob job;
-  job.om = om; job.in = in; job.out = out; job.eps = eps; job.sel = sel; job.next = 0; job.unsupported = 0;
-  pthread_mutex_init(&job.mtx, NULL);
+OPool *oracle_pool_create(const OModel *om, int nthreads) {
   if (nthreads < 1) nthreads = 1;
-  if (nthreads == 1) worker(&job);
-  else {
-    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)nthreads);
-    for (int i = 0; i < nthreads; i++) pthread_create(&th[i], NULL, worker, &job);
-    for (int i = 0; i < nthreads; i++) pthread_join(th[i], NULL);
-    free(th);
+  OPool *pl = (OPool *)calloc(1, sizeof(OPool));
+  pl->om = om; pl->nthreads = nthreads;
+  pl->data = (OData **)calloc((size_t)nthreads, sizeof(OData *));
+  pl->eps_row = (double **)calloc((size_t)nthreads, sizeof(double *));
+  for (int i = 0; i < nthreads; i++) {
+    pl->data[i] = oracle_make_data(om);
+    pl->eps_row[i] = (double *)malloc(sizeof(double) * (size_t)(MJPC_MAX_HORIZON * (om->m.nu + 1)));
   }
-  pthread_mutex_destroy(&job.mtx);
-  out->unsupported = job.unsupported;
+  pthread_mutex_init(&pl->mtx, NULL);
+  pthread_cond_init(&pl->cv_job, NULL); pthread_cond_init(&pl->cv_done, NULL);
+  if (nthreads > 1) {                                 /* one thread: the caller runs the queue itself */
+    pl->th = (pthread_t *)calloc((size_t)nthreads, sizeof(pthread_t));
+    for (int i = 0; i < nthreads; i++) {
+      PoolArg *pa = (PoolArg *)malloc(sizeof(PoolArg)); pa->pool = pl; pa->id = i;
+      pthread_create(&pl->th[i], NULL, pool_worker, pa);
+    }
+    pthread_mutex_lock(&pl->mtx);
+    while (pl->started < nthreads) pthread_cond_wait(&pl->cv_done, &pl->mtx);
+    pthread_mutex_unlock(&pl->mtx);
+  }
+  return pl;
+}
+
+void oracle_pool_destroy(OPool *pl) {
+  if (!pl) return;
+  if (pl->th) {
+    pthread_mutex_lock(&pl->mtx); pl->shutdown = 1; pthread_cond_broadcast(&pl->cv_job); pthread_mutex_unlock(&pl->mtx);
+    for (int i = 0; i < pl->nthreads; i++) pthread_join(pl->th[i], NULL);
+    free(pl->th);
+  }
+  for (int i = 0; i < pl->nthreads; i++) { oracle_free_data(pl->data[i]); free(pl->eps_row[i]); }
+  free(pl->data); free(pl->eps_row);
+  pthread_mutex_destroy(&pl->mtx); pthread_cond_destroy(&pl->cv_job); pthread_cond_destroy(&pl->cv_done);
+  free(pl);
+}
+
+int oracle_pool_threads(const OPool *pl) { return pl ? pl->nthreads : 0; }
+
+/* one plan step: Schedule N closures, WaitCount(N), pick the winner */
+int oracle_pool_plan(OPool *pl, const MjpcHipPlanInput *in, OPlanOutput *out) {
+  if (in->num_spline_points > MJPC_MAX_HORIZON) return -1;
+  pthread_mutex_lock(&pl->mtx);
+  pl->in = in; pl->out = out; pl->unsupported = 0; pl->done = 0; pl->next = 0;
+  if (pl->th) {
+    pl->total = in->num_local;
+    pthread_cond_broadcast(&pl->cv_job);
+    while (pl->done < pl->total) pthread_cond_wait(&pl->cv_done, &pl->mtx);
+    pl->total = 0; pl->next = 0;
+    pthread_mutex_unlock(&pl->mtx);
+  } else {
+    pthread_mutex_unlock(&pl->mtx);
+    for (int r = 0; r < in->num_local; r++) run_candidate(pl, 0, r);
+  }
+  out->unsupported = pl->unsupported;
   /* winner: first minimum (partial_sort with '<' keeps the lowest index on ties) */
   int w = 0;
   for (int r = 1; r < in->num_local; r++) if (out->returns[r] < out->returns[w]) w = r;
   out->winner = in->candidate_offset + w;
-  free(eps_own); free(sel_own);
   return 0;
+}
+
+/* convenience for the tests: a pool that lives for one plan step */
+int oracle_plan(const OModel *om, const MjpcHipPlanInput *in, OPlanOutput *out, int nthreads) {
+  OPool *pl = oracle_pool_create(om, nthreads);
+  int rc = oracle_pool_plan(pl, in, out);
+  oracle_pool_destroy(pl);
+  return rc;
 }

@@ -136,7 +136,9 @@ static double ray_geom(const double *pos, const double *mat, const double *size,
   return -1;
 }
 
-double oracle_ray_ground(const OModel *om, const OData *d, const double pos[3]) {   /* utilities.cc:538-556 */
+/* The reference aborts the process when the ray hits nothing (mju_error, utilities.cc:549-552); a planner candidate must
+ * not do that, so a miss fails the rollout instead (MJPC_WARN_RAY) — same definition on the device. */
+double oracle_ray_ground(const OModel *om, OData *d, const double pos[3]) {   /* utilities.cc:538-556 */
   const MjpcHipModel *m = &om->m;
   double down[3] = {0, 0, -1};
   double query[3] = {pos[0], pos[1], pos[2] + 0.5};
@@ -146,6 +148,7 @@ double oracle_ray_ground(const OModel *om, const OData *d, const double pos[3]) 
     double x = ray_geom(d->geom_xpos + 3 * g, d->geom_xmat + 9 * g, m->geom_size + 3 * g, query, down, m->geom_type[g]);
     if (x >= 0 && (dist < 0 || x < dist)) dist = x;
   }
+  if (dist < 0) d->warning |= MJPC_WARN_RAY;
   return pos[2] + 0.5 - dist;
 }
 
@@ -469,6 +472,33 @@ static void residual_humanoid_walk(const OModel *om, OData *d, double *residual)
   o_copy(residual + counter, d->ctrl, m->nu); counter += m->nu;
 }
 
+/* mjpc/tasks/shadow_reorient/hand.cc:37-84.  int_data = [palm site (framepos "palm_position", task.xml:45), cube body,
+ * goal body, keyframe].  Sensors restated: framepos / framequat / framelinvel with objtype="body" read the body's INERTIAL
+ * frame (xipos, xquat * body_iquat, velocity at xipos in world axes), common_assets/reorientation_cube.xml:31-36. */
+static void residual_shadow(const OModel *om, OData *d, double *residual) {
+  const MjpcHipModel *m = &om->m;
+  const int *I = om->t.int_data;
+  int palm = I[0], cube = I[1], goal = I[2], key = I[3];
+  int counter = 0;
+  o_sub3(residual + counter, d->xipos + 3 * cube, d->site_xpos + 3 * palm);            /* (0) cube position - palm position */
+  counter += 3;
+  double goal_orientation[4], orientation[4];
+  o_mulquat(goal_orientation, d->xquat + 4 * goal, m->body_iquat + 4 * goal);
+  o_mulquat(orientation, d->xquat + 4 * cube, m->body_iquat + 4 * cube);
+  o_normalize4(goal_orientation);
+  o_subquat(residual + counter, goal_orientation, orientation);                          /* (1) orientation error */
+  counter += 3;
+  body_linvel(om, d, cube, residual + counter);                                          /* (2) cube linear velocity */
+  counter += 3;
+  o_copy(residual + counter, d->actuator_force, m->nu);                                  /* (3) actuator forces */
+  counter += m->nu;
+  /* (4), (5): the 26-wide slices start at 7 / 6 although the first joint is the goal's ball joint: they straddle the cube's
+   * free joint (hand.cc:75-80) */
+  for (int i = 0; i < 26; i++) residual[counter + i] = d->qpos[7 + i] - m->key_qpos[key * m->nq + 7 + i];
+  counter += 26;
+  o_copy(residual + counter, d->qvel + 6, 26);
+}
+
 void oracle_residual(const OModel *om, OData *d, double *residual) {
   const MjpcHipModel *m = &om->m;
   switch (om->t.task_id) {
@@ -499,6 +529,9 @@ void oracle_residual(const OModel *om, OData *d, double *residual) {
       break;
     case MJPC_TASK_HUMANOID_WALK:
       residual_humanoid_walk(om, d, residual);
+      break;
+    case MJPC_TASK_SHADOW_REORIENT:
+      residual_shadow(om, d, residual);
       break;
     default: break;
   }

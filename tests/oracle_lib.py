@@ -45,6 +45,10 @@ def lib():
     L.oracle_destroy.argtypes = [C.c_void_p]
     L.oracle_set_task.argtypes = [C.c_void_p, C.POINTER(capi.MjpcHipTask)]
     L.oracle_plan.argtypes = [C.c_void_p, C.POINTER(capi.MjpcHipPlanInput), C.POINTER(OPlanOutput), C.c_int]
+    L.oracle_pool_create.restype = C.c_void_p
+    L.oracle_pool_create.argtypes = [C.c_void_p, C.c_int]
+    L.oracle_pool_destroy.argtypes = [C.c_void_p]
+    L.oracle_pool_plan.argtypes = [C.c_void_p, C.POINTER(capi.MjpcHipPlanInput), C.POINTER(OPlanOutput)]
     L.oracle_spline_sample.argtypes = [c_double_p, c_double_p, C.c_int, C.c_int, C.c_int, C.c_double, c_double_p]
     L.oracle_norm.restype = C.c_double
     L.oracle_norm.argtypes = [c_double_p, c_double_p, C.c_int, C.c_int]
@@ -89,8 +93,21 @@ class Oracle:
         self.model = model; self.task = task
 
     def __del__(self):
+        self.close_pool()
         if getattr(self, "h", None):
             lib().oracle_destroy(self.h); self.h = None
+
+    def open_pool(self, nthreads):
+        """Persistent FIFO worker pool (threads + per-worker data live across plan() calls, like the reference's
+        ThreadPool); plan() uses it instead of a one-shot pool until close_pool()."""
+        self.close_pool()
+        self._pool = lib().oracle_pool_create(self.h, int(nthreads))
+        return self
+
+    def close_pool(self):
+        if getattr(self, "_pool", None):
+            lib().oracle_pool_destroy(self._pool)
+        self._pool = None
 
     def set_task(self, task: dict):
         self.task = task
@@ -121,7 +138,10 @@ class Oracle:
         for k in ["returns", "states", "actions", "times", "residual", "costs", "trace", "knots"]:
             setattr(o, k, _dp(out[k]))
         o.failure = out["failure"].ctypes.data_as(c_int_p)
-        lib().oracle_plan(self.h, C.byref(inp), C.byref(o), int(nthreads))
+        if getattr(self, "_pool", None):
+            lib().oracle_pool_plan(self._pool, C.byref(inp), C.byref(o))
+        else:
+            lib().oracle_plan(self.h, C.byref(inp), C.byref(o), int(nthreads))
         out["winner"] = o.winner; out["unsupported"] = o.unsupported
         out["trace"] = out["trace"][:, :, :ntr]
         return out

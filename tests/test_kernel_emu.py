@@ -38,6 +38,87 @@ def test_kernel_source_matches_oracle(name, P, H, N, sigma, tol):
     assert b["lds_doubles"] * 8 <= 160 * 1024          # per-candidate state must fit one CU's LDS
 
 
+@pytest.mark.parametrize("cone", [0, 1])
+def test_shadow_hand_kernel_source_matches_oracle(cone):
+    """a8.4 on the CPU tier: the synthetic Shadow hand (position servos, tendon-coupled actuators, capsule-box / box-box /
+    sphere-box contacts, pyramidal and elliptic cones) through the kernel source vs the oracle."""
+    m, task, d = REGISTRY["shadow_hand"](cone=cone)
+    o = ol.Oracle(m, task)
+    P, H, N = 5, 30, 5
+    kt = np.arange(P) * ((H - 1) * m["timestep"] / P); kv = np.tile(d["ctrl0"], (P, 1))
+    eps, sel = ol.noise(1, 0, 0, N, P, m["nu"])
+    a = o.plan(d["state"], None, 0.0, kt, kv, 0, N, H, sigma=(0.1, 0.0), noise_eps=eps, noise_sel=sel, nthreads=4)
+    b = emu_lib.plan(m, task, d["state"], None, 0.0, kt, kv, 0, N, H, sigma=(0.1, 0.0), noise_eps=eps, noise_sel=sel)
+    assert a["unsupported"] == 0 and not a["failure"].any() and not b["failure"].any()
+    assert np.array_equal(a["knots"], b["knots"]) and np.array_equal(a["actions"], b["actions"])
+    for k in ("states", "residual", "costs", "trace", "returns"):
+        assert _rel(b[k], a[k]) < 1e-5, k
+    assert b["diag"][:, 1].max() >= 5                    # contacts between hand and cube are in play
+    assert int(np.argmin(b["returns"])) == a["winner"]
+
+
+def test_lds_budget_of_every_baseline_model():
+    """The whole per-candidate state must fit one CU's 160 KiB of LDS in the flavour the engine would pick (host-only query)."""
+    lib = ctypes.CDLL(capi.ENGINE_PATH)
+    lib.mjpc_hip_layout_bytes.argtypes = [ctypes.POINTER(capi.MjpcHipModel), ctypes.POINTER(capi.MjpcHipTask), ctypes.c_int]
+    for name, cached in (("cartpole", 1), ("quadruped", 1), ("humanoid_track", 1), ("shadow_hand", 0)):
+        m, task, _ = REGISTRY[name]()
+        cm = capi.CModel(m, task)
+        n = lib.mjpc_hip_layout_bytes(ctypes.byref(cm.c_model), ctypes.byref(cm.c_task), cached)
+        assert 0 < n <= 160 * 1024, (name, n)
+
+
+def test_models_the_engine_cannot_roll_out_are_refused_at_create():
+    """ADVICE r1: no silent approximation.  Host-side validation (mjpc_host::build) refuses ellipsoids / meshes that can collide,
+    limited ball joints, user data, oversized buffers; a cylinder next to a capsule is accepted (conservative run-time test)."""
+    from mujoco_mpc_amd.modelgen.builder import BALL, BOX, CYLINDER, ELLIPSOID, FREE, HINGE, PLANE, SPHERE, ModelBuilder
+    from mujoco_mpc_amd.modelgen.tasks import make_task
+    lib = ctypes.CDLL(capi.ENGINE_PATH)
+    lib.mjpc_hip_layout_bytes.argtypes = [ctypes.POINTER(capi.MjpcHipModel), ctypes.POINTER(capi.MjpcHipTask), ctypes.c_int]
+    lib.mjpc_hip_last_error.restype = ctypes.c_char_p
+    task = make_task(3, [(1, 0, 1.0)])
+
+    def check(edit, expect):
+        b = ModelBuilder()
+        b.geom(0, "floor", PLANE, size=(1, 1, 0.1))
+        body = b.body("a", 0, pos=(0, 0, 1))
+        b.joint(body, "f", FREE)
+        b.geom(body, "g", SPHERE, size=(0.1,))
+        edit(b, body)
+        m = b.compile()
+        task["num_residual"] = 1
+        cm = capi.CModel(m, task)
+        n = lib.mjpc_hip_layout_bytes(ctypes.byref(cm.c_model), ctypes.byref(cm.c_task), 1)
+        if expect is None:
+            assert n > 0, lib.mjpc_hip_last_error()
+        else:
+            assert n < 0 and expect in lib.mjpc_hip_last_error().decode(), lib.mjpc_hip_last_error()
+
+    check(lambda b, body: None, None)
+    check(lambda b, body: b.geom(body, "e", ELLIPSOID, size=(0.1, 0.2, 0.3)), "ellipsoids")
+
+    def ball(b, body):
+        c = b.body("c", body)
+        b.joint(c, "ball", BALL, limited=True, range=(0, 1))
+        b.geom(c, "cg", SPHERE, size=(0.05,))
+    check(ball, "limited ball")
+
+    def userdata(b, body):
+        b.nuserdata = 3
+    check(userdata, "nuserdata")
+
+    def bigcon(b, body):
+        b.nconmax = 100
+    check(bigcon, "nconmax")
+
+    def cyl(b, body):
+        c = b.body("c", 0, pos=(1, 0, 1))
+        b.joint(c, "h", HINGE)
+        b.geom(c, "cyl", CYLINDER, size=(0.1, 0.2))
+        b.geom(c, "box", BOX, size=(0.1, 0.1, 0.1), pos=(0, 0, 0.5))
+    check(cyl, None)
+
+
 def test_cross_entropy_noise_mode_in_oracle_and_kernel_source():
     """ABI extension for the Cross-Entropy planner (cross_entropy/planner.cc:340-415): absolute per-parameter std, every
     candidate perturbed except `nominal_index`."""

@@ -228,6 +228,12 @@ int mjpc_hip_plan(MjpcHipEngine *e, const MjpcHipPlanInput *in, MjpcHipPlanOutpu
  * a second mjpc_hip_plan_async before mjpc_hip_plan_fetch is an error. */
 int mjpc_hip_plan_async(MjpcHipEngine *e, const MjpcHipPlanInput *in);
 int mjpc_hip_plan_fetch(MjpcHipEngine *e, MjpcHipPlanOutput *out);
+/* What mjpc_hip_plan_fetch brings to the host.  MJPC_FETCH_WINNER_ROWS (default): returns, failure flags, and the local
+ * winner's trajectory rows + knots in one packed copy.  MJPC_FETCH_SUMMARY: returns, failure flags, local winner index /
+ * return / knots only — for the shards of a multi-device plan, where only the owner of the GLOBAL winner then copies its
+ * trajectory with mjpc_hip_get_candidate. */
+enum { MJPC_FETCH_WINNER_ROWS = 0, MJPC_FETCH_SUMMARY = 1 };
+int mjpc_hip_set_fetch_mode(MjpcHipEngine *e, int mode);
 /* Copy any local candidate's trajectory / knots to host (GUI traces, RankedPlanner). */
 int mjpc_hip_get_candidate(MjpcHipEngine *e, int local_index, MjpcHipPlanOutput *out);
 /* Copy every local candidate's knot values [num_local][P][nu] of the last plan to host (elite statistics of the
@@ -256,6 +262,30 @@ int mjpc_hip_get_frame(MjpcHipEngine *e, double *xpos, double *xmat, double *sit
 int mjpc_hip_kernel_time(MjpcHipEngine *e, double *avg_rollout_us, double *avg_total_us);
 /* Device pointers of the last plan's result arrays (for zero-copy consumers / tests). */
 int mjpc_hip_device_ptrs(MjpcHipEngine *e, void **returns, void **states, void **residual);
+/* ---- one planner, several GPUs (north_star: "candidate batches shard across the 8 GPUs of one node") -------------------
+ * A MjpcHipMulti owns one engine per device in ONE host process (the planner lives in one process, planners/include.cc:44).
+ * mjpc_hip_multi_plan block-partitions the global batch [0, num_trajectory) over the engines (candidate 0, the un-noised
+ * nominal, on the first), enqueues every shard asynchronously on its device's stream, fetches the per-shard summaries
+ * (returns + local elite, MJPC_FETCH_SUMMARY), takes the lexicographic minimum (return, global index) on the host - G x 16
+ * bytes that are on the host anyway with returns[]; an RCCL collective would add a launch + sync per device for nothing -
+ * and copies the winner's trajectory from its owner only.  Results are bit-identical to one engine planning the whole batch
+ * (noise is indexed by the global candidate id).  `devices`: n_devices HIP device ordinals (repeats allowed: several
+ * engines on one GPU, used by the 1-GPU rehearsal test); NULL = 0 .. n_devices-1.  in->candidate_offset / num_local are
+ * ignored (the whole batch is planned); out->returns / failure are [num_trajectory]. */
+typedef struct MjpcHipMulti MjpcHipMulti;
+MjpcHipMulti *mjpc_hip_multi_create(const MjpcHipModel *model, const MjpcHipTask *task, int max_samples, int max_horizon,
+                                    int n_devices, const int *devices);
+void mjpc_hip_multi_destroy(MjpcHipMulti *m);
+int mjpc_hip_multi_set_task(MjpcHipMulti *m, const MjpcHipTask *task);
+int mjpc_hip_multi_plan(MjpcHipMulti *m, const MjpcHipPlanInput *in, MjpcHipPlanOutput *out);
+/* trajectory / knots of GLOBAL candidate `index` of the last plan, from the engine that owns it */
+int mjpc_hip_multi_get_candidate(MjpcHipMulti *m, int index, MjpcHipPlanOutput *out);
+/* knots [num_trajectory][P][nu] / traces [num_trajectory][H][3*num_trace] of every candidate of the last plan */
+int mjpc_hip_multi_get_knots(MjpcHipMulti *m, double *knots);
+int mjpc_hip_multi_get_traces(MjpcHipMulti *m, double *traces);
+int mjpc_hip_multi_num_devices(const MjpcHipMulti *m);
+/* engine k (0 .. n_devices-1), e.g. for mjpc_hip_get_frame / mjpc_hip_kernel_time */
+MjpcHipEngine *mjpc_hip_multi_engine(MjpcHipMulti *m, int k);
 const char *mjpc_hip_last_error(void);
 int mjpc_hip_version(void);
 

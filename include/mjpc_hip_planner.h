@@ -89,7 +89,9 @@ struct Numerics {                       // the planner's <custom><numeric> entri
   double robust_xfrc = 0.1, robust_xfrc_rate = 0.1;
   int n_elite = -1;                    // cross-entropy: default max(sampling_trajectories / 10, 2) (planner.cc:63-64)
   int max_horizon = kMaxTrajectoryHorizon;   // device trajectory buffers are sized max_samples x max_horizon
-  int device = 0;
+  int device = 0;                      // first HIP device ordinal
+  int n_devices = 1;                   // SamplingPlanner: GPUs the candidate batch is sharded over (one engine each)
+  std::vector<int> devices;            // optional explicit ordinals (repeats allowed); default device, device+1, ...
 };
 
 class SamplingPlanner {
@@ -144,7 +146,7 @@ class SamplingPlanner {
 
  private:
   void FetchCandidate(int global_index);
-  MjpcHipEngine* engine_ = nullptr;
+  MjpcHipMulti* engine_ = nullptr;             // one rollout engine per GPU
   Numerics numerics_;
   int nq_ = 0, nv_ = 0, na_ = 0, ns_ = 0, nu_ = 0, nmocap_ = 0, nuserdata_ = 0, nr_ = 0, ntrace_ = 0;
   double timestep_ = 0;

@@ -29,6 +29,11 @@ void mjpc_spline_set_interpolation(void *spline, int interpolation);
 void *mjpc_planner_create(const MjpcHipModel *model, const MjpcHipTask *task, const double *exploration /* [2] */,
                           int trajectories, int representation, int sliding_plan, int spline_points,
                           int max_samples, int max_horizon, int device);
+/* the same planner with the candidate batch of every plan step sharded over n_devices GPUs (one engine each, elite picked
+ * across them; devices[k] = HIP ordinals, repeats allowed for a 1-GPU rehearsal) */
+void *mjpc_planner_create_sharded(const MjpcHipModel *model, const MjpcHipTask *task, const double *exploration /* [2] */,
+                                  int trajectories, int representation, int sliding_plan, int spline_points,
+                                  int max_samples, int max_horizon, int n_devices, const int *devices);
 void mjpc_planner_destroy(void *planner);
 void mjpc_planner_reset(void *planner, int horizon, const double *initial_repeated_action);
 void mjpc_planner_set_state(void *planner, const double *state, const double *mocap, const double *userdata, double time);

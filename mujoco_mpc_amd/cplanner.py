@@ -20,7 +20,7 @@ PLANNER_C_SYMBOLS = [
     "mjpc_planner_set_error_handler",
     "mjpc_spline_create", "mjpc_spline_destroy", "mjpc_spline_size", "mjpc_spline_add_node", "mjpc_spline_sample",
     "mjpc_spline_discard_before", "mjpc_spline_clear", "mjpc_spline_set_interpolation",
-    "mjpc_planner_create", "mjpc_planner_destroy", "mjpc_planner_reset", "mjpc_planner_set_state", "mjpc_planner_set_task",
+    "mjpc_planner_create", "mjpc_planner_create_sharded", "mjpc_planner_destroy", "mjpc_planner_reset", "mjpc_planner_set_state", "mjpc_planner_set_task",
     "mjpc_planner_optimize_policy", "mjpc_planner_nominal_trajectory", "mjpc_planner_action_from_policy",
     "mjpc_planner_optimize_policy_candidates", "mjpc_planner_candidate_score", "mjpc_planner_action_from_candidate_policy",
     "mjpc_planner_copy_candidate_to_policy", "mjpc_planner_winner", "mjpc_planner_improvement", "mjpc_planner_num_parameters",
@@ -72,6 +72,7 @@ def lib():
         "mjpc_spline_discard_before": (i, [vp, d]), "mjpc_spline_clear": (None, [vp]),
         "mjpc_spline_set_interpolation": (None, [vp, i]),
         "mjpc_planner_create": (vp, [C.POINTER(capi.MjpcHipModel), C.POINTER(capi.MjpcHipTask), c_double_p, i, i, i, i, i, i, i]),
+        "mjpc_planner_create_sharded": (vp, [C.POINTER(capi.MjpcHipModel), C.POINTER(capi.MjpcHipTask), c_double_p, i, i, i, i, i, i, i, C.POINTER(C.c_int)]),
         "mjpc_planner_destroy": (None, [vp]), "mjpc_planner_reset": (None, [vp, i, c_double_p]),
         "mjpc_planner_set_state": (None, [vp, c_double_p, c_double_p, c_double_p, d]),
         "mjpc_planner_set_task": (None, [vp, C.POINTER(capi.MjpcHipTask)]),
@@ -155,7 +156,8 @@ class SamplingPlanner:
         self._h = None
         self._noise = None
 
-    def Initialize(self, model: dict, task: dict, numerics: dict | None = None, max_samples=128, max_horizon=512, device=0):
+    def Initialize(self, model: dict, task: dict, numerics: dict | None = None, max_samples=128, max_horizon=512, device=0, devices=None):
+        """devices: list of HIP ordinals to shard every plan step's candidate batch over (one engine each); None = `device` only."""
         numerics = numerics or {}
         self.cm = capi.CModel(model, task)
         se = numerics.get("sampling_exploration", 0.1)
@@ -165,10 +167,15 @@ class SamplingPlanner:
         self.nr = int(task["num_residual"]); self.ntrace = int(task["num_trace"])
         self.max_samples, self.max_horizon = int(max_samples), int(max_horizon)
         self.close()
-        h = self._L.mjpc_planner_create(C.byref(self.cm.c_model), C.byref(self.cm.c_task), _dp(self._expl),
-                                        int(numerics.get("sampling_trajectories", 10)), int(numerics.get("sampling_representation", 2)),
-                                        int(numerics.get("sampling_sliding_plan", 0)), int(numerics.get("sampling_spline_points", 512)),
-                                        self.max_samples, self.max_horizon, int(device))
+        args = (C.byref(self.cm.c_model), C.byref(self.cm.c_task), _dp(self._expl),
+                int(numerics.get("sampling_trajectories", 10)), int(numerics.get("sampling_representation", 2)),
+                int(numerics.get("sampling_sliding_plan", 0)), int(numerics.get("sampling_spline_points", 512)),
+                self.max_samples, self.max_horizon)
+        if devices is None:
+            h = self._L.mjpc_planner_create(*args, int(device))
+        else:
+            dv = (C.c_int * len(devices))(*[int(x) for x in devices])
+            h = self._L.mjpc_planner_create_sharded(*args, len(devices), dv)
         self._h = C.c_void_p(h)
         _check()
 

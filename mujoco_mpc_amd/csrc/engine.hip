@@ -58,12 +58,13 @@ extern "C" __global__ void __launch_bounds__(64) argmin_kernel(const double *ret
 }
 
 // gathers everything the host wants after a plan step into ONE contiguous buffer (one D2H copy instead of eleven):
-//   [winner index, winner return | returns[nl] | failure[nl] (as doubles) | winner rows: states, actions, times, residual,
-//    costs, trace, knots]
+//   [winner index, winner return | returns[nl] | failure[nl] (as doubles) | winner knots | winner rows: states, actions, times,
+//    residual, costs, trace]      (the rows only when a.rows: a shard of a multi-device plan sends the summary alone and the
+//    owner of the global winner fetches its rows afterwards)
 struct PackArgs {
   const int *winner; const double *winner_val, *returns; const int *failure;
   const double *states, *actions, *times, *residual, *costs, *trace, *knots;
-  int nl, H, P, ds, nu, nr, ntr;
+  int nl, H, P, ds, nu, nr, ntr, rows;
   double *dst;
 };
 extern "C" __global__ void __launch_bounds__(256) pack_kernel(const PackArgs a) {
@@ -76,10 +77,10 @@ extern "C" __global__ void __launch_bounds__(256) pack_kernel(const PackArgs a) 
   d += 2 * a.nl;
   if (w < 0 || w >= a.nl) return;
   size_t H = (size_t)a.H, r = (size_t)w;
-  const double *src[7] = {a.states + r * H * a.ds, a.actions + r * H * a.nu, a.times + r * H, a.residual + r * H * a.nr,
-                          a.costs + r * H, a.trace + r * H * a.ntr, a.knots + r * (size_t)a.P * a.nu};
-  size_t cnt[7] = {H * a.ds, H * a.nu, H, H * a.nr, H, H * a.ntr, (size_t)a.P * a.nu};
-  for (int k = 0; k < 7; k++) {
+  const double *src[7] = {a.knots + r * (size_t)a.P * a.nu, a.states + r * H * a.ds, a.actions + r * H * a.nu, a.times + r * H,
+                          a.residual + r * H * a.nr, a.costs + r * H, a.trace + r * H * a.ntr};
+  size_t cnt[7] = {(size_t)a.P * a.nu, H * a.ds, H * a.nu, H, H * a.nr, H, H * a.ntr};
+  for (int k = 0; k < (a.rows ? 7 : 1); k++) {
     for (size_t i = tid; i < cnt[k]; i += nth) d[i] = src[k][i];
     d += cnt[k];
   }
@@ -123,6 +124,7 @@ struct MjpcHipEngine {
   size_t lds_bytes = 0;
   RolloutFn kernel = nullptr; bool cached = true;
   int fault = 0;               // MJPC_HIP_FAULT_INJECT (test-suite only)
+  int summary_only = 0, last_summary = 0;      // mjpc_hip_set_fetch_mode
 };
 
 static int upload_model(MjpcHipEngine *e) {
@@ -321,7 +323,7 @@ int mjpc_hip_plan_async(MjpcHipEngine *e, const MjpcHipPlanInput *in) {
   hipLaunchKernelGGL(argmin_kernel, dim3(1), dim3(64), 0, e->stream, e->d_returns, nl, e->d_winner, e->d_winner_val);
   HIPCHK(hipEventRecord(e->ev[3], e->stream));
   {
-    size_t rows = (size_t)H * (e->ds + nu + 2 + e->nr + e->ntr) + (size_t)P * nu;
+    size_t rows = (e->summary_only ? 0 : (size_t)H * (e->ds + nu + 2 + e->nr + e->ntr)) + (size_t)P * nu;
     size_t need_pack = 2 + 2 * (size_t)nl + rows;
     if (need_pack > e->pack_cap) {
       if (e->d_pack) HIPCHK(hipFree(e->d_pack));
@@ -331,7 +333,8 @@ int mjpc_hip_plan_async(MjpcHipEngine *e, const MjpcHipPlanInput *in) {
       e->pack_cap = need_pack;
     }
     PackArgs pa{e->d_winner, e->d_winner_val, e->d_returns, e->d_failure, e->d_states, e->d_actions, e->d_times, e->d_residual,
-                e->d_costs, e->d_trace, e->d_knots, nl, H, P, e->ds, nu, e->nr, e->ntr, e->d_pack};
+                e->d_costs, e->d_trace, e->d_knots, nl, H, P, e->ds, nu, e->nr, e->ntr, e->summary_only ? 0 : 1, e->d_pack};
+    e->last_summary = e->summary_only;
     hipLaunchKernelGGL(pack_kernel, dim3(8), dim3(256), 0, e->stream, pa);
     HIPCHK(hipMemcpyAsync(e->h_pack, e->d_pack, sizeof(double) * need_pack, hipMemcpyDeviceToHost, e->stream));
   }
@@ -374,12 +377,18 @@ int mjpc_hip_plan_fetch(MjpcHipEngine *e, MjpcHipPlanOutput *out) {
     e->pending = 0;
   }
   size_t H = (size_t)e->last_H, P = (size_t)e->last_P;
-  double *dst[7] = {out->states, out->actions, out->times, out->residual, out->costs, out->trace, out->winner_knots};
-  size_t cnt[7] = {H * e->ds, H * e->nu, H, H * e->nr, H, H * e->ntr, P * e->nu};
-  for (int k = 0; k < 7; k++) {
+  double *dst[7] = {out->winner_knots, out->states, out->actions, out->times, out->residual, out->costs, out->trace};
+  size_t cnt[7] = {P * e->nu, H * e->ds, H * e->nu, H, H * e->nr, H, H * e->ntr};
+  for (int k = 0; k < (e->last_summary ? 1 : 7); k++) {        // summary mode: the rows stay on the device (mjpc_hip_get_candidate)
     if (dst[k] && cnt[k]) memcpy(dst[k], p, sizeof(double) * cnt[k]);
     p += cnt[k];
   }
+  return 0;
+}
+
+int mjpc_hip_set_fetch_mode(MjpcHipEngine *e, int mode) {
+  if (!e || (mode != MJPC_FETCH_WINNER_ROWS && mode != MJPC_FETCH_SUMMARY)) { set_error("mjpc_hip_set_fetch_mode: invalid argument"); return -1; }
+  e->summary_only = mode == MJPC_FETCH_SUMMARY;
   return 0;
 }
 

@@ -134,7 +134,7 @@ static double Micros(std::chrono::steady_clock::time_point t0) {
 }
 
 SamplingPlanner::~SamplingPlanner() {
-  if (engine_) mjpc_hip_destroy(engine_);
+  if (engine_) mjpc_hip_multi_destroy(engine_);
   if (nominal_engine_) mjpc_hip_destroy(nominal_engine_);
 }
 
@@ -162,8 +162,15 @@ void SamplingPlanner::Initialize(const MjpcHipModel* model, const MjpcHipTask* t
     Fatal(msg);
     return;
   }
-  if (engine_) { mjpc_hip_destroy(engine_); engine_ = nullptr; }     // the model might have changed
-  engine_ = mjpc_hip_create(model, task, numerics.max_samples, numerics.max_horizon, numerics.device);
+  if (engine_) { mjpc_hip_multi_destroy(engine_); engine_ = nullptr; }     // the model might have changed
+  // one engine per GPU (Numerics::n_devices, ordinals in Numerics::devices or device, device+1, ...): the candidate batch of a
+  // plan step is block-partitioned over them (include/mjpc_hip.h, mjpc_hip_multi_plan)
+  {
+    int G = std::max(1, numerics.n_devices);
+    std::vector<int> devs(G);
+    for (int k = 0; k < G; k++) devs[k] = k < (int)numerics.devices.size() ? numerics.devices[k] : numerics.device + k;
+    engine_ = mjpc_hip_multi_create(model, task, numerics.max_samples, numerics.max_horizon, G, devs.data());
+  }
   if (!engine_) { Fatal(mjpc_hip_last_error()); return; }
   // NominalTrajectory() rolls the nominal policy out on its own one-candidate engine, so that the candidates of the last
   // plan step (returns, order, trajectories on the device) stay available to the RankedPlanner calls afterwards
@@ -212,7 +219,7 @@ void SamplingPlanner::SetState(const double* s, const double* m, const double* u
 }
 
 void SamplingPlanner::SetTask(const MjpcHipTask* task) {
-  if (mjpc_hip_set_task(engine_, task) != 0) Fatal(mjpc_hip_last_error());
+  if (mjpc_hip_multi_set_task(engine_, task) != 0) Fatal(mjpc_hip_last_error());
   if (nominal_engine_ && mjpc_hip_set_task(nominal_engine_, task) != 0) Fatal(mjpc_hip_last_error());
 }
 
@@ -277,7 +284,7 @@ int SamplingPlanner::OptimizePolicyCandidates(int ncandidates, int horizon) {   
   out.states = trajectory_winner.states.data(); out.actions = trajectory_winner.actions.data();
   out.times = trajectory_winner.times.data(); out.residual = trajectory_winner.residual.data();
   out.costs = trajectory_winner.costs.data(); out.trace = trajectory_winner.trace.data(); out.winner_knots = winner_knots_.data();
-  if (mjpc_hip_plan(engine_, &in, &out) != 0) { Fatal(mjpc_hip_last_error()); return 0; }
+  if (mjpc_hip_multi_plan(engine_, &in, &out) != 0) { Fatal(mjpc_hip_last_error()); return 0; }
   last_horizon_ = horizon; fetched_ = out.winner;
   noise_compute_time = out.noise_compute_time_us;
   // order so that the first ncandidates are the best (ties: lowest index, like the engine's argmin)
@@ -295,7 +302,7 @@ void SamplingPlanner::FetchCandidate(int global_index) {
   out.states = trajectory_winner.states.data(); out.actions = trajectory_winner.actions.data();
   out.times = trajectory_winner.times.data(); out.residual = trajectory_winner.residual.data();
   out.costs = trajectory_winner.costs.data(); out.trace = trajectory_winner.trace.data(); out.winner_knots = winner_knots_.data();
-  if (mjpc_hip_get_candidate(engine_, global_index, &out) != 0) { Fatal(mjpc_hip_last_error()); return; }
+  if (mjpc_hip_multi_get_candidate(engine_, global_index, &out) != 0) { Fatal(mjpc_hip_last_error()); return; }
   fetched_ = global_index;
 }
 
@@ -689,6 +696,21 @@ void* mjpc_planner_create(const MjpcHipModel* model, const MjpcHipTask* task, co
   n.sampling_exploration[0] = exploration[0]; n.sampling_exploration[1] = exploration[1];
   n.sampling_trajectories = trajectories; n.sampling_representation = representation; n.sampling_sliding_plan = sliding_plan;
   n.sampling_spline_points = spline_points; n.max_samples = max_samples; n.max_horizon = max_horizon; n.device = device;
+  p->Initialize(model, task, n);
+  p->Allocate();
+  return p;
+}
+// the same planner with its candidate batch sharded over n_devices GPUs (devices[k]: HIP ordinals, repeats allowed)
+void* mjpc_planner_create_sharded(const MjpcHipModel* model, const MjpcHipTask* task, const double* exploration, int trajectories,
+                                  int representation, int sliding_plan, int spline_points, int max_samples, int max_horizon,
+                                  int n_devices, const int* devices) {
+  auto* p = new SamplingPlanner();
+  mjpc_hip::Numerics n;
+  n.sampling_exploration[0] = exploration[0]; n.sampling_exploration[1] = exploration[1];
+  n.sampling_trajectories = trajectories; n.sampling_representation = representation; n.sampling_sliding_plan = sliding_plan;
+  n.sampling_spline_points = spline_points; n.max_samples = max_samples; n.max_horizon = max_horizon;
+  n.n_devices = n_devices; n.device = (devices && n_devices > 0) ? devices[0] : 0;
+  if (devices) n.devices.assign(devices, devices + n_devices);
   p->Initialize(model, task, n);
   p->Allocate();
   return p;

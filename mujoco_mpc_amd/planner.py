@@ -175,6 +175,12 @@ class HipBackend:
         if self.lib.mjpc_hip_set_task(self.h, C.byref(t)) != 0:
             raise RuntimeError(self.lib.mjpc_hip_last_error().decode())
 
+    def set_fetch_mode(self, summary_only: bool):
+        """summary_only: plan() brings back returns / failure flags / local elite (index, return, knots) only; the winner's
+        trajectory rows stay on the device until candidate() asks for them (shards of a multi-GPU plan)."""
+        if self.lib.mjpc_hip_set_fetch_mode(self.h, 1 if summary_only else 0) != 0:
+            raise RuntimeError(self.lib.mjpc_hip_last_error().decode())
+
     def _alloc_out(self, nl, H, P):
         m, t = self.model, self.task
         ds = m["nq"] + m["nv"] + m["na"]; nu = m["nu"]; nr = t["num_residual"]; ntr = 3 * t["num_trace"]
@@ -245,6 +251,65 @@ class HipBackend:
         a = C.c_double(0); b = C.c_double(0)
         n = self.lib.mjpc_hip_kernel_time(self.h, C.byref(a), C.byref(b))
         return n, a.value, b.value
+
+
+class HipMultiBackend:
+    """One planner process, one rollout engine per GPU (mjpc_hip_multi_*, include/mjpc_hip.h): plan() block-partitions the
+    global candidate batch over the engines, picks the elite across them and copies the winner's trajectory from its owner.
+    devices: HIP ordinals, repeats allowed (several engines on one GPU: 1-GPU rehearsal)."""
+
+    def __init__(self, model: dict, task: dict, devices, max_samples=128, max_horizon=kMaxTrajectoryHorizon):
+        self.lib = capi.load_engine()
+        self.cm = capi.CModel(model, task)
+        self.model = model; self.task = task
+        dv = (C.c_int * len(devices))(*[int(x) for x in devices])
+        self.h = self.lib.mjpc_hip_multi_create(C.byref(self.cm.c_model), C.byref(self.cm.c_task), int(max_samples), int(max_horizon),
+                                                len(devices), dv)
+        if not self.h:
+            raise RuntimeError("mjpc_hip_multi_create failed: " + self.lib.mjpc_hip_last_error().decode())
+        self.h = C.c_void_p(self.h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.mjpc_hip_multi_destroy(self.h); self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    _alloc_out = HipBackend._alloc_out
+
+    def plan(self, **kw):
+        inp = capi.make_plan_input(self.cm, **kw)
+        o, c, ntr = self._alloc_out(inp.num_trajectory, inp.horizon, inp.num_spline_points)
+        if self.lib.mjpc_hip_multi_plan(self.h, C.byref(inp), C.byref(c)) != 0:
+            raise RuntimeError("mjpc_hip_multi_plan failed: " + self.lib.mjpc_hip_last_error().decode())
+        o["winner"] = c.winner; o["winner_return"] = c.winner_return
+        o["noise_compute_time_us"] = c.noise_compute_time_us; o["rollouts_compute_time_us"] = c.rollouts_compute_time_us
+        o["trace"] = o["trace"][:, :ntr]
+        return o
+
+    def candidate(self, index, H, P):
+        o, c, ntr = self._alloc_out(1, H, P)
+        if self.lib.mjpc_hip_multi_get_candidate(self.h, int(index), C.byref(c)) != 0:
+            raise RuntimeError(self.lib.mjpc_hip_last_error().decode())
+        o["trace"] = o["trace"][:, :ntr]
+        return o
+
+    def knots(self, N, P):
+        k = np.zeros((N, P, self.model["nu"]))
+        if self.lib.mjpc_hip_multi_get_knots(self.h, k.ctypes.data_as(capi.c_double_p)) != 0:
+            raise RuntimeError(self.lib.mjpc_hip_last_error().decode())
+        return k
+
+    def traces(self, N, H):
+        ntr = 3 * self.task["num_trace"]
+        t = np.zeros((N, H, max(ntr, 1)))
+        if self.lib.mjpc_hip_multi_get_traces(self.h, t.ctypes.data_as(capi.c_double_p)) != 0:
+            raise RuntimeError(self.lib.mjpc_hip_last_error().decode())
+        return t[:, :, :ntr] if ntr else t[:, :, :0]
 
 
 class SamplingPlanner:

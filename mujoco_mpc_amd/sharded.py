@@ -20,6 +20,9 @@ class ShardedSampler:
         self.device = device        # torch device for the collective buffers ("cuda:k" with nccl, "cpu" with gloo)
         self._buf = None
         self.always_exchange = False      # tests: run the collective even with a single rank
+        self.fetch_winner_rows = True     # the owner of the global elite copies its trajectory to the host after the exchange
+        if world > 1 and hasattr(backend, "set_fetch_mode"):
+            backend.set_fetch_mode(True)  # shards report summaries only; nobody but the owner moves a trajectory
 
     @property
     def num_trajectory(self):
@@ -61,5 +64,9 @@ class ShardedSampler:
         for r in range(1, self.world):      # lexicographic (return, index): lowest index on ties
             if allv[r, 0] < allv[best, 0] or (allv[r, 0] == allv[best, 0] and allv[r, 1] < allv[best, 1]):
                 best = r
-        return dict(winner=int(allv[best, 1]), winner_return=float(allv[best, 0]),
-                    winner_knots=allv[best, 2:].reshape(np.asarray(out["winner_knots"]).shape).copy(), owner=best, local=out)
+        res = dict(winner=int(allv[best, 1]), winner_return=float(allv[best, 0]),
+                   winner_knots=allv[best, 2:].reshape(np.asarray(out["winner_knots"]).shape).copy(), owner=best, local=out)
+        if best == self.rank and self.fetch_winner_rows and hasattr(self.backend, "candidate"):
+            H = np.asarray(out["times"]).shape[0]; P = np.asarray(out["winner_knots"]).shape[0]
+            res["trajectory"] = self.backend.candidate(res["winner"] - self.rank * self.nper, H, P)      # owner-only D2H
+        return res

@@ -10,6 +10,10 @@ class OracleBackend:
         self.model = model; self.task = task
         self.nthreads = nthreads
         self._all = None
+        self.summary_only = False
+
+    def set_fetch_mode(self, summary_only):
+        self.summary_only = bool(summary_only)
 
     def set_task(self, task):
         self.o.set_task(task); self.task = task
@@ -25,7 +29,7 @@ class OracleBackend:
         w = r["winner"] - candidate_offset
         out = dict(returns=r["returns"], failure=r["failure"], winner=r["winner"], winner_return=r["returns"][w])
         for k in ["states", "actions", "times", "residual", "costs", "trace"]:
-            out[k] = r[k][w]
+            out[k] = np.zeros_like(r[k][w]) if self.summary_only else r[k][w]       # summary mode: rows stay "on the device"
         out["winner_knots"] = r["knots"][w]
         return out
 

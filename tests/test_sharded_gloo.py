@@ -32,8 +32,11 @@ def _worker(rank, world, port, nper, outdir, equal_returns):
     state = d["state"] if not equal_returns else np.array([0.0, 0.0, 1e11, 0.0])   # every rollout fails -> all returns 1e6
     res = sampler.plan(state=state, mocap=None, time=0.0, knot_times=kt, knot_values=kv, interpolation=2, horizon=30,
                        sigma=(0.5, 0.0), seed=3, stream=1)
+    traj = res.get("trajectory")
     np.savez(os.path.join(outdir, f"r{rank}.npz"), winner=res["winner"], ret=res["winner_return"], knots=res["winner_knots"],
-             owner=res["owner"], local_returns=res["local"]["returns"])
+             owner=res["owner"], local_returns=res["local"]["returns"], has_traj=traj is not None,
+             traj_states=traj["states"] if traj is not None else np.zeros(0), summary_mode=be.summary_only,
+             local_rows_moved=bool(np.any(res["local"]["states"] != 0)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -59,6 +62,12 @@ def test_two_rank_sharding_matches_single_process(tmp_path, equal_returns):
     assert int(r[0]["winner"]) == full["winner"]
     assert float(r[0]["ret"]) == full["returns"][full["winner"]]
     assert np.array_equal(r[0]["knots"], full["knots"][full["winner"]])
+    # shards report summaries; only the owner of the global elite copies a trajectory to the host
+    owner = int(r[0]["owner"])
+    for k in range(world):
+        assert bool(r[k]["summary_mode"]) and not bool(r[k]["local_rows_moved"])
+        assert bool(r[k]["has_traj"]) == (k == owner)
+    assert np.array_equal(r[owner]["traj_states"], full["states"][full["winner"]])
     if equal_returns:
         assert int(r[0]["winner"]) == 0          # ties -> lowest global index, like the single-GPU argmin
 

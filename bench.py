@@ -69,6 +69,25 @@ def physical_cores():
     return max(1, (os.cpu_count() or 2) // 2)
 
 
+def cpu_share():
+    """CPUs this process may actually use: the smaller of its affinity mask and its cgroup CPU quota (the GPU boxes hand a
+    container a share of the host's cores; os.cpu_count() still reports all of them)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]            # cgroup v2
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    return n, quota
+
+
 def cpu_model_name():
     try:
         for line in open("/proc/cpuinfo"):
@@ -89,6 +108,8 @@ def cpu_baseline(model, task, d, kt, kv, N, H, interp, sigma, budget_s=24.0):
     ol.FAST = True                           # -O3 -march=native build of the oracle, compiled on this box
     ncpu = os.cpu_count() or 1
     phys = min(physical_cores(), ncpu)
+    affinity, quota = cpu_share()
+    share = int(round(min(affinity, quota))) if quota else affinity
     o = ol.Oracle(model, task)
 
     def run(threads, n, max_plans, budget):
@@ -112,9 +133,12 @@ def cpu_baseline(model, task, d, kt, kv, N, H, interp, sigma, budget_s=24.0):
     n1 = max(4, min(N, 16))
     sweep.append(run(1, n1, 5, budget_s * 0.2))
     per_thread = sweep[0]["rollouts_per_s"]
-    for T in sorted({phys, max(1, ncpu - 5)}):          # hw-5: testspeed default (mjpc/testspeed_app.cc:24)
+    # thread counts: the CPU share this container really has, the physical cores and hw-5 (testspeed default,
+    # mjpc/testspeed_app.cc:24) of the host; beyond the share the extra threads only time-slice
+    counts = sorted({max(2, share), phys, max(1, ncpu - 5)} if share < ncpu else {phys, max(1, ncpu - 5)})
+    for T in counts:
         if T > 1:
-            sweep.append(run(T, N, 50, budget_s * 0.4))
+            sweep.append(run(T, N, 50, budget_s * 0.8 / len(counts)))
     for s in sweep:
         s["parallel_efficiency"] = s["rollouts_per_s"] / (per_thread * s["threads"])
     best = max(sweep, key=lambda s: s["rollouts_per_s"])
@@ -122,7 +146,9 @@ def cpu_baseline(model, task, d, kt, kv, N, H, interp, sigma, budget_s=24.0):
                 sample=f"median of {best['plans']} plan steps of the same workload (N={best['samples']}, H={H}) after 2 warm-ups on the CPU "
                        f"oracle's persistent FIFO pool (gcc -O3 -march=native), best of the thread counts in `sweep`; "
                        f"{ncpu} host cpus / {phys} physical cores, {cpu_model_name()}",
-                sweep=sweep, host_cpus=ncpu, physical_cores=phys)
+                sweep=sweep, host_cpus=ncpu, physical_cores=phys, cpu_affinity=affinity, cgroup_cpu_quota=quota,
+                note="parallel_efficiency is relative to the T=1 rate; thread counts above the container's CPU share "
+                     "(cgroup quota / affinity) cannot speed up")
 
 
 WORKLOADS = {

@@ -95,7 +95,8 @@ DEV void ctx_init(Ctx &c, const KParams *K, double *base) {
   P_(xpos); P_(xquat); P_(xmat); P_(xipos); P_(ximat); P_(xanchor); P_(xaxis); P_(geom_xpos); P_(geom_xmat); P_(site_xpos);
   P_(subtree_com); P_(cinert); P_(crb); P_(cdof); P_(cvel); P_(cdof_dot); P_(cacc); P_(cfrc); P_(cfrc_sub);
   P_(subtree_linvel); P_(bodytmp); P_(qM); P_(qL); P_(qH); P_(Linv); P_(Hinv);
-  P_(efc_J); P_(efc_JA); P_(efc_D); P_(efc_R); P_(efc_aref); P_(efc_force); P_(efc_jar); P_(efc_jv); P_(efc_floss);
+  c.efc_J = base + L.efc_J - K->M.nfric * K->M.nvp;      // rows [nfric, nefcmax) are stored: a friction-loss row is the unit vector of its dof
+  P_(efc_JA); P_(efc_D); P_(efc_R); P_(efc_aref); P_(efc_force); P_(efc_jar); P_(efc_jv); P_(efc_floss);
   P_(efc_pos); P_(efc_margin); P_(efc_diag); P_(contact);
   P_(Ma); P_(grad); P_(Mgrad); P_(search); P_(Mv); P_(vtmp); P_(sgl);
   P_(knot_times); P_(knot_values); P_(residual); P_(terms); P_(red); P_(xfrc);
@@ -813,11 +814,109 @@ DEV int np_box_box(NPCon *con, double margin, const double *pa, const double *ma
   return cnt;
 }
 
-// returns the number of contacts, or -1 when the pair has no collider and may be touching (cylinder against a non-plane whose
-// bounding capsule is within the margin): the caller fails the rollout
+// sphere (geom1) vs cylinder (geom2): closed form in the cylinder's frame (distance = hypot of the radial and axial excess)
+DEV int np_sphere_cylinder(NPCon *con, double margin, const double *sp, double sr, const double *cp, const double *cm, const double *cs) {
+  double dif[3], p[3];
+  d_sub3(dif, sp, cp);
+  d_mulmattvec3(p, cm, dif);
+  double R = cs[0], h = cs[1];
+  double rho = sqrt(p[0] * p[0] + p[1] * p[1]);
+  double ux = rho > D_MINVAL ? p[0] / rho : 1.0, uy = rho > D_MINVAL ? p[1] / rho : 0.0;
+  double er = rho - R, ez = fabs(p[2]) - h, sz = p[2] >= 0 ? 1.0 : -1.0;
+  double q[3], nl[3], dist;
+  if (er <= 0 && ez <= 0) {
+    if (-er < -ez) { q[0] = ux * R; q[1] = uy * R; q[2] = p[2]; nl[0] = ux; nl[1] = uy; nl[2] = 0; dist = er - sr; }
+    else { q[0] = p[0]; q[1] = p[1]; q[2] = sz * h; nl[0] = 0; nl[1] = 0; nl[2] = sz; dist = ez - sr; }
+  } else {
+    double cr = er > 0 ? R : rho;
+    q[0] = ux * cr; q[1] = uy * cr; q[2] = ez > 0 ? sz * h : p[2];
+    double d[3] = {p[0] - q[0], p[1] - q[1], p[2] - q[2]};
+    double len = d_norm3(d);
+    dist = len - sr;
+    if (dist > margin) return 0;
+    d_scl3(nl, d, 1.0 / len);
+  }
+  if (dist > margin) return 0;
+  double nw[3], surf[3];
+  d_mulmatvec3(nw, cm, nl);
+  for (int k = 0; k < 6; k++) con->frame[k] = 0;
+  d_scl3(con->frame, nw, -1);
+  con->dist = dist;
+  d_mulmatvec3(surf, cm, q); d_add3(surf, surf, cp);
+  d_addscl3(con->pos, surf, nw, 0.5 * dist);
+  return 1;
+}
+DEV double capsule_cylinder_g(const double *p0, const double *a, double hc, double R, double h, double s) {
+  double q[3] = {p0[0] + (s * hc) * a[0], p0[1] + (s * hc) * a[1], p0[2] + (s * hc) * a[2]};
+  double rho = sqrt(q[0] * q[0] + q[1] * q[1]);
+  double g = 0, er = rho - R, ez = fabs(q[2]) - h;
+  if (er > 0) g += er * (q[0] * a[0] + q[1] * a[1]) / rho;
+  if (ez > 0) g += (q[2] > 0 ? ez : -ez) * a[2];
+  return g;
+}
+DEV int np_capsule_cylinder(NPCon *con, double margin, const double *kp, const double *km, const double *ks,
+                            const double *cp, const double *cm, const double *cs) {
+  double axis[3] = {km[2], km[5], km[8]}, dif[3], p0[3], a[3];
+  d_sub3(dif, kp, cp);
+  d_mulmattvec3(p0, cm, dif);
+  d_mulmattvec3(a, cm, axis);
+  double hc = ks[1], sstar;
+  if (capsule_cylinder_g(p0, a, hc, cs[0], cs[1], -1.0) >= 0) sstar = -1.0;
+  else if (capsule_cylinder_g(p0, a, hc, cs[0], cs[1], 1.0) <= 0) sstar = 1.0;
+  else {
+    double lo = -1.0, hi = 1.0;
+    for (int it = 0; it < 48; it++) {
+      double mid = 0.5 * (lo + hi);
+      if (capsule_cylinder_g(p0, a, hc, cs[0], cs[1], mid) < 0) lo = mid; else hi = mid;
+    }
+    sstar = 0.5 * (lo + hi);
+  }
+  int cnt = 0;
+  double pt[3];
+  NPCon t;
+  d_addscl3(pt, kp, axis, sstar * hc);
+  if (np_sphere_cylinder(&t, margin, pt, ks[0], cp, cm, cs)) { con[0] = t; cnt++; }
+  double s2 = sstar <= 0 ? 1.0 : -1.0;
+  d_addscl3(pt, kp, axis, s2 * hc);
+  if (np_sphere_cylinder(&t, margin, pt, ks[0], cp, cm, cs)) { np_put(con, cnt, t); cnt++; }
+  return cnt;
+}
+
+// The rarely-met pair types (capsule-box, box-box, the cylinder pairs) live in ONE out-of-line function with its own register
+// allocation: collision() of the common models (plane / sphere / capsule contacts) keeps the registers and code it had before
+// these colliders existed; the result comes back through the stack.  n = -1: no collider and possibly touching.
+struct NPOut { NPCon c[4]; int n; };
+DEV_NOINLINE NPOut narrow_heavy(const KParams *Kg, int g1, int g2, double margin) {
+  Ctx c;
+  ctx_init(c, Kg, lds_base());
+  const DevModel &M = *c.M;
+  NPOut o;
+  int t1 = MI(geom_type)[g1], t2 = MI(geom_type)[g2];
+  double p1[3], p2[3], m1[9], m2[9], s1[3], s2[3];
+  d_copy3(p1, c.geom_xpos + 3 * g1); d_copy3(p2, c.geom_xpos + 3 * g2);
+  for (int k = 0; k < 9; k++) { m1[k] = c.geom_xmat[9 * g1 + k]; m2[k] = c.geom_xmat[9 * g2 + k]; }
+  d_copy3(s1, MD(geom_size) + 3 * g1); d_copy3(s2, MD(geom_size) + 3 * g2);
+  o.n = -1;
+  if (t1 == 3 && t2 == 6) o.n = np_capsule_box(o.c, margin, p1, m1, s1, p2, m2, s2);
+  else if (t1 == 6 && t2 == 6) o.n = np_box_box(o.c, margin, p1, m1, s1, p2, m2, s2);
+  else if (t1 == 2 && t2 == 5) o.n = np_sphere_cylinder(o.c, margin, p1, s1[0], p2, m2, s2);
+  else if (t1 == 3 && t2 == 5) o.n = np_capsule_cylinder(o.c, margin, p1, m1, s1, p2, m2, s2);
+  else if (t1 == 5 && (t2 == 5 || t2 == 6)) {
+    // cylinder-cylinder / cylinder-box: no collider.  The cylinder's bounding capsule decides "certainly apart" (0) or
+    // "unknown" (-1): a conservative exact test
+    NPCon tmp[4];
+    int n = t2 == 5 ? np_capsule_capsule(tmp, margin, p1, m1, s1, p2, m2, s2) : np_capsule_box(tmp, margin, p1, m1, s1, p2, m2, s2);
+    o.n = n == 0 ? 0 : -1;
+  }
+  return o;
+}
+
+// returns the number of contacts; -2: a pair type handled by narrow_heavy()
 DEV int narrow_phase(Ctx &c, int g1, int g2, double margin, NPCon *con) {
   const DevModel &M = *c.M;
   int t1 = MI(geom_type)[g1], t2 = MI(geom_type)[g2];
+  int light = (t1 == 0 && (t2 == 2 || t2 == 3 || t2 == 6 || t2 == 5)) || (t1 == 2 && (t2 == 2 || t2 == 3 || t2 == 6)) || (t1 == 3 && t2 == 3);
+  if (!light) return -2;
   double p1[3], p2[3], m1[9], m2[9], s1[3], s2[3];
   d_copy3(p1, c.geom_xpos + 3 * g1); d_copy3(p2, c.geom_xpos + 3 * g2);
   for (int k = 0; k < 9; k++) { m1[k] = c.geom_xmat[9 * g1 + k]; m2[k] = c.geom_xmat[9 * g2 + k]; }
@@ -827,28 +926,13 @@ DEV int narrow_phase(Ctx &c, int g1, int g2, double margin, NPCon *con) {
     if (t2 == 2) return np_plane_sphere(con, margin, p1, n, p2, s2[0]);
     if (t2 == 3) return np_plane_capsule(con, margin, p1, m1, p2, m2, s2);
     if (t2 == 6) return np_plane_box(con, margin, p1, m1, p2, m2, s2);
-    if (t2 == 5) return np_plane_cylinder(con, margin, p1, m1, p2, m2, s2);
+    return np_plane_cylinder(con, margin, p1, m1, p2, m2, s2);
   } else if (t1 == 2) {
     if (t2 == 2) return np_sphere_sphere(con, margin, p1, s1[0], p2, s2[0]);
     if (t2 == 3) return np_sphere_capsule(con, margin, p1, s1[0], p2, m2, s2);
-    if (t2 == 6) return np_sphere_box(con, margin, p1, s1[0], p2, m2, s2);
-  } else if (t1 == 3 && t2 == 3) {
-    return np_capsule_capsule(con, margin, p1, m1, s1, p2, m2, s2);
-  } else if (t1 == 3 && t2 == 6) {
-    return np_capsule_box(con, margin, p1, m1, s1, p2, m2, s2);
-  } else if (t1 == 6 && t2 == 6) {
-    return np_box_box(con, margin, p1, m1, s1, p2, m2, s2);
+    return np_sphere_box(con, margin, p1, s1[0], p2, m2, s2);
   }
-  // no collider: the cylinder's bounding capsule decides "certainly apart" (0) or "unknown" (-1): a conservative exact test
-  if (t1 == 5 || t2 == 5) {
-    NPCon tmp[4];
-    int n = -1;
-    if (t1 == 2) n = np_sphere_capsule(tmp, margin, p1, s1[0], p2, m2, s2);
-    else if (t1 == 3 || (t1 == 5 && t2 == 5)) n = np_capsule_capsule(tmp, margin, p1, m1, s1, p2, m2, s2);
-    else if (t1 == 5 && t2 == 6) n = np_capsule_box(tmp, margin, p1, m1, s1, p2, m2, s2);
-    if (n == 0) return 0;
-  }
-  return -1;
+  return np_capsule_capsule(con, margin, p1, m1, s1, p2, m2, s2);
 }
 
 DEV void contact_param(Ctx &c, int g1, int g2, double *cc, int *dim) {
@@ -922,6 +1006,10 @@ DEV void collision(Ctx &c) {
       margin = fmax(MD(geom_margin)[g1], MD(geom_margin)[g2]);
       gap = fmax(MD(geom_gap)[g1], MD(geom_gap)[g2]);
       n = narrow_phase(c, g1, g2, margin, con);
+      if (n == -2) {
+        NPOut h = narrow_heavy(c.K, g1, g2, margin);
+        n = h.n; con[0] = h.c[0]; con[1] = h.c[1]; con[2] = h.c[2]; con[3] = h.c[3];
+      }
       if (n < 0) { c.warning |= WARN_UNSUPPORTED; n = 0; }      // lane-local here; made wave-uniform below
     }
     c.warning = wave_or_i(c.warning);
@@ -1037,11 +1125,11 @@ DEV void make_noncontact_rows(Ctx &c, int *nsingle_out, int *n_nc_out) {
   }
   int ntl_end = nefc;
   SYNC();
-  PFOR(e, ntl_end * nvp) c.efc_J[e] = 0;
+  PFOR(e, (ntl_end - M.nfric) * nvp) c.efc_J[M.nfric * nvp + e] = 0;
   SYNC();
-  PFOR(r, nlim_end) {
-    if (r < M.nfric) c.efc_J[r * nvp + c.efc_id[r]] = 1;
-    else { c.efc_J[r * nvp + MI(jnt_dofadr)[c.efc_id[r]]] = c.efc_floss[r]; c.efc_floss[r] = 0; }
+  PFOR(rr, nlim_end - M.nfric) {
+    int r = M.nfric + rr;
+    c.efc_J[r * nvp + MI(jnt_dofadr)[c.efc_id[r]]] = c.efc_floss[r]; c.efc_floss[r] = 0;
   }
   PFOR(rr, ntl_end - ntl0) {
     int r = ntl0 + rr, t = c.efc_id[r];
@@ -1160,7 +1248,8 @@ DEV void make_impedance(Ctx &c, int r0, int r1, int with_contacts) {
     int r = r0 + rr;
     int type = c.efc_type[r], id = c.efc_id[r];
     double vel = 0;
-    for (int i0 = 0; i0 < nv; i0 += 9) {          // blocks of 9 loads in flight (nv = 18, 27 divide evenly), same summation order
+    if (type == CNSTR_FRICTION_DOF) vel = c.qvel[id];      // J = unit vector of the dof (no stored row)
+    else for (int i0 = 0; i0 < nv; i0 += 9) {     // blocks of 9 loads in flight (nv = 18, 27 divide evenly), same summation order
       double jj[9], qq[9];
 #pragma unroll
       for (int k = 0; k < 9; k++) { int i = i0 + k, ic = i < nv ? i : nv - 1; jj[k] = c.efc_J[r * nvp + ic]; qq[k] = c.qvel[ic]; }

@@ -6,7 +6,7 @@
  * mjpc/trajectory.cc:158): normal points from geom1 to geom2, dist < 0 is penetration,
  * contact position is the midpoint between the two surfaces, contacts are created while
  * dist < margin.  Supported pairs: plane-{sphere,capsule,box,cylinder}, sphere-sphere,
- * sphere-capsule, capsule-capsule, sphere-box, capsule-box, box-box.  MuJoCo's own capsule-box
+ * sphere-capsule, capsule-capsule, sphere-box, capsule-box, box-box, sphere-cylinder, capsule-cylinder.  MuJoCo's own capsule-box
  * (mjraw_CapsuleBox) and box-box (mjc_BoxBox) routines are long case analyses that cannot be restated
  * from the reference tree; the two colliders here are this build's own constructions with the same
  * conventions and contact budgets (capsule-box <= 2 contacts: closest segment point + far end cap;
@@ -238,6 +238,77 @@ static int capsule_box(OContact *con, double margin, const double *cp, const dou
   return cnt;
 }
 
+/* ---- sphere (geom1) vs cylinder (geom2), capsule (geom1) vs cylinder (geom2) -------------------------
+ * MuJoCo sends every cylinder pair except plane-cylinder to its general convex solver; a solid cylinder is simple enough for
+ * closed forms with the same contact conventions: the distance from a point to the cylinder is
+ * hypot(max(rho - R, 0), max(|z| - h, 0)) in the cylinder's frame, the closest point clamps rho and z.  The capsule case
+ * bisects the monotone derivative of that (convex) distance along the capsule's segment, exactly like capsule-box. */
+static int sphere_cylinder(OContact *con, double margin, const double *sp, double sr, const double *cp, const double *cm, const double *cs) {
+  double dif[3], p[3];
+  o_sub3(dif, sp, cp);
+  o_mulmattvec3(p, cm, dif);                    /* sphere centre in the cylinder's frame (axis = z) */
+  double R = cs[0], h = cs[1];
+  double rho = sqrt(p[0] * p[0] + p[1] * p[1]);
+  double ux = rho > O_MINVAL ? p[0] / rho : 1.0, uy = rho > O_MINVAL ? p[1] / rho : 0.0;      /* radial direction */
+  double er = rho - R, ez = fabs(p[2]) - h, sz = p[2] >= 0 ? 1.0 : -1.0;
+  double q[3], nl[3], dist;
+  if (er <= 0 && ez <= 0) {                     /* centre inside: leave through the nearer of the lateral surface and the cap */
+    if (-er < -ez) { q[0] = ux * R; q[1] = uy * R; q[2] = p[2]; nl[0] = ux; nl[1] = uy; nl[2] = 0; dist = er - sr; }
+    else { q[0] = p[0]; q[1] = p[1]; q[2] = sz * h; nl[0] = 0; nl[1] = 0; nl[2] = sz; dist = ez - sr; }
+  } else {
+    double cr = er > 0 ? R : rho;               /* clamped radius */
+    q[0] = ux * cr; q[1] = uy * cr; q[2] = ez > 0 ? sz * h : p[2];
+    double d[3] = {p[0] - q[0], p[1] - q[1], p[2] - q[2]};
+    double len = o_norm3(d);
+    dist = len - sr;
+    if (dist > margin) return 0;
+    o_scl3(nl, d, 1.0 / len);                   /* from the cylinder to the sphere */
+  }
+  if (dist > margin) return 0;
+  double nw[3], surf[3];
+  o_mulmatvec3(nw, cm, nl);
+  o_zero(con->frame, 9);
+  o_scl3(con->frame, nw, -1);                   /* geom1 = sphere, geom2 = cylinder */
+  con->dist = dist;
+  o_mulmatvec3(surf, cm, q); o_add3(surf, surf, cp);
+  o_addscl3(con->pos, surf, nw, 0.5 * dist);
+  return 1;
+}
+static double capsule_cylinder_g(const double *p0, const double *a, double hc, double R, double h, double s) {
+  double q[3] = {p0[0] + (s * hc) * a[0], p0[1] + (s * hc) * a[1], p0[2] + (s * hc) * a[2]};
+  double rho = sqrt(q[0] * q[0] + q[1] * q[1]);
+  double g = 0, er = rho - R, ez = fabs(q[2]) - h;
+  if (er > 0) g += er * (q[0] * a[0] + q[1] * a[1]) / rho;
+  if (ez > 0) g += (q[2] > 0 ? ez : -ez) * a[2];
+  return g;
+}
+static int capsule_cylinder(OContact *con, double margin, const double *kp, const double *km, const double *ks,
+                            const double *cp, const double *cm, const double *cs) {
+  double axis[3] = {km[2], km[5], km[8]}, dif[3], p0[3], a[3];
+  o_sub3(dif, kp, cp);
+  o_mulmattvec3(p0, cm, dif);
+  o_mulmattvec3(a, cm, axis);
+  double hc = ks[1], sstar;
+  if (capsule_cylinder_g(p0, a, hc, cs[0], cs[1], -1.0) >= 0) sstar = -1.0;
+  else if (capsule_cylinder_g(p0, a, hc, cs[0], cs[1], 1.0) <= 0) sstar = 1.0;
+  else {
+    double lo = -1.0, hi = 1.0;
+    for (int it = 0; it < 48; it++) {
+      double mid = 0.5 * (lo + hi);
+      if (capsule_cylinder_g(p0, a, hc, cs[0], cs[1], mid) < 0) lo = mid; else hi = mid;
+    }
+    sstar = 0.5 * (lo + hi);
+  }
+  int cnt = 0;
+  double pt[3];
+  o_addscl3(pt, kp, axis, sstar * hc);
+  cnt += sphere_cylinder(con + cnt, margin, pt, ks[0], cp, cm, cs);
+  double s2 = sstar <= 0 ? 1.0 : -1.0;
+  o_addscl3(pt, kp, axis, s2 * hc);
+  cnt += sphere_cylinder(con + cnt, margin, pt, ks[0], cp, cm, cs);
+  return cnt;
+}
+
 /* ---- box (geom1 = A) vs box (geom2 = B) ----------------------------------------------------------
  * Separating-axis test over the 15 axes (faces of A, faces of B, edge x edge) in A's frame; the axis of largest
  * separation (least penetration) decides the case, edge axes only when clearly better than the best face.
@@ -426,25 +497,27 @@ int oracle_collide_pair(const OModel *om, OData *d, int g1, int g2, double margi
       case MJPC_GEOM_SPHERE: return sphere_sphere_raw(con, margin, p1, s1[0], p2, s2[0]);
       case MJPC_GEOM_CAPSULE: return sphere_capsule(con, margin, p1, s1[0], p2, m2, s2);
       case MJPC_GEOM_BOX: return sphere_box(con, margin, p1, s1[0], p2, m2, s2);
+      case MJPC_GEOM_CYLINDER: return sphere_cylinder(con, margin, p1, s1[0], p2, m2, s2);
       default: break;
     }
   } else if (t1 == MJPC_GEOM_CAPSULE && t2 == MJPC_GEOM_CAPSULE) {
     return capsule_capsule(con, margin, p1, m1, s1, p2, m2, s2);
   } else if (t1 == MJPC_GEOM_CAPSULE && t2 == MJPC_GEOM_BOX) {
     return capsule_box(con, margin, p1, m1, s1, p2, m2, s2);
+  } else if (t1 == MJPC_GEOM_CAPSULE && t2 == MJPC_GEOM_CYLINDER) {
+    return capsule_cylinder(con, margin, p1, m1, s1, p2, m2, s2);
   } else if (t1 == MJPC_GEOM_BOX && t2 == MJPC_GEOM_BOX) {
     return box_box(con, margin, p1, m1, s1, p2, m2, s2);
   }
-  /* A cylinder against anything but a plane has no analytic collider (MuJoCo falls back to its convex solver, which cannot be
-   * restated here).  Conservative exact test instead: the cylinder's bounding capsule (same radius and half length) contains
-   * it, so if that capsule is farther than the margin there is certainly no contact -> 0, correctly.  If the bounding capsule
-   * touches, the true answer is unknown: counted in `unsupported`, and the caller fails the rollout (never a silent miss). */
-  if (t1 == MJPC_GEOM_CYLINDER || t2 == MJPC_GEOM_CYLINDER) {
+  /* cylinder-cylinder and cylinder-box have no collider here (MuJoCo: general convex solver, not restatable).  Conservative
+   * exact test instead: the cylinder's bounding capsule (same radius and half length) contains it, so if that capsule is
+   * farther than the margin there is certainly no contact -> 0, correctly.  If the bounding capsule touches, the true answer
+   * is unknown: counted in `unsupported`, and the caller fails the rollout (never a silent miss). */
+  if (t1 == MJPC_GEOM_CYLINDER) {
     OContact tmp[4];
     int n = -1;
-    if (t1 == MJPC_GEOM_SPHERE) n = sphere_capsule(tmp, margin, p1, s1[0], p2, m2, s2);
-    else if (t1 == MJPC_GEOM_CAPSULE || (t1 == MJPC_GEOM_CYLINDER && t2 == MJPC_GEOM_CYLINDER)) n = capsule_capsule(tmp, margin, p1, m1, s1, p2, m2, s2);
-    else if (t1 == MJPC_GEOM_CYLINDER && t2 == MJPC_GEOM_BOX) n = capsule_box(tmp, margin, p1, m1, s1, p2, m2, s2);
+    if (t2 == MJPC_GEOM_CYLINDER) n = capsule_capsule(tmp, margin, p1, m1, s1, p2, m2, s2);
+    else if (t2 == MJPC_GEOM_BOX) n = capsule_box(tmp, margin, p1, m1, s1, p2, m2, s2);
     if (n == 0) return 0;
   }
   (*unsupported)++;
@@ -461,6 +534,8 @@ int oracle_debug_collide(int t1, const double *s1, const double *p1, const doubl
   else if (t1 == MJPC_GEOM_CAPSULE && t2 == MJPC_GEOM_BOX) n = capsule_box(con, margin, p1, m1, s1, p2, m2, s2);
   else if (t1 == MJPC_GEOM_BOX && t2 == MJPC_GEOM_BOX) n = box_box(con, margin, p1, m1, s1, p2, m2, s2);
   else if (t1 == MJPC_GEOM_CAPSULE && t2 == MJPC_GEOM_CAPSULE) n = capsule_capsule(con, margin, p1, m1, s1, p2, m2, s2);
+  else if (t1 == MJPC_GEOM_SPHERE && t2 == MJPC_GEOM_CYLINDER) n = sphere_cylinder(con, margin, p1, s1[0], p2, m2, s2);
+  else if (t1 == MJPC_GEOM_CAPSULE && t2 == MJPC_GEOM_CYLINDER) n = capsule_cylinder(con, margin, p1, m1, s1, p2, m2, s2);
   for (int k = 0; k < n; k++) {
     out[7 * k] = con[k].dist;
     o_copy3(out + 7 * k + 1, con[k].pos);

@@ -249,6 +249,11 @@ int mjpc_hip_get_all_candidates(MjpcHipEngine *e, double *states, double *action
                                 double *costs, double *trace, double *knots, int *diag);
 /* Bytes of LDS one candidate's workgroup occupies (its whole mjData-equivalent). */
 int mjpc_hip_lds_bytes(MjpcHipEngine *e);
+/* Capacity tiers: when a shard holds more candidates than the GPU has CUs and the model allows it, the engine first runs a
+ * flavour that fits TWO candidates per CU (<= 80 KiB of LDS each, smaller contact / row capacity) and re-runs the rare
+ * candidate that overflowed it at full capacity - same results, ~1.6x the throughput.  Returns the dense tier's LDS bytes
+ * (0: none for this model); *used_last = 1 when the last plan used it. */
+int mjpc_hip_dense_tier(MjpcHipEngine *e, int *used_last);
 /* The same figure for a model without creating an engine (host-only, no GPU needed): with (1) / without (0) the LDS copy of
  * the model tables.  Negative: mjpc_hip_create would refuse the model (see mjpc_hip_last_error). */
 int mjpc_hip_layout_bytes(const MjpcHipModel *model, const MjpcHipTask *task, int use_cache);

@@ -76,6 +76,9 @@ struct Trajectory {
   bool failure = false;
 };
 
+// configuration errors abort like mju_error (planner.cc:69-72) unless a handler is installed
+void SetErrorHandler(void (*handler)(const char*));
+
 struct Numerics {                       // the planner's <custom><numeric> entries (planner.cc:53-67, policy.cc:36-37)
   double sampling_exploration[2] = {0.1, 0.0};
   int sampling_trajectories = 10;
@@ -122,6 +125,12 @@ class SamplingPlanner {
 
   // knot values of candidate `candidate` (ranked order) of the last OptimizePolicyCandidates, [P*nu]; P via KnotTimes()
   void CandidateKnots(int candidate, double* out);
+  // by batch index (unranked): the reference's trajectory[i] / candidate_policy[i] (ilqs/planner.cc:98-198); the rows land in
+  // trajectory_winner
+  void FetchCandidateUnranked(int index);
+  void CandidateKnotsUnranked(int index, double* out);
+  // every candidate's trace rows of the last plan step [num_trajectory][horizon][3*num_trace] in one copy (Traces, planner.cc:388-434)
+  void AllTraces(double* out);
   const std::vector<double>& KnotTimes() const { return knot_times_; }
   // ---- public members other code reads/writes in the reference (planner.h:115-162)
   SamplingPolicy policy, previous_policy;

@@ -1,0 +1,334 @@
+// integration/hip_sampling_planner.cc — see hip_sampling_planner.h.  Host-side glue only: field-by-field views of mjModel /
+// Task for the C ABI and forwarding of the Planner / RankedPlanner virtuals to mjpc_hip::SamplingPlanner.
+#include "mjpc/planners/sampling_hip/planner.h"
+
+#include <algorithm>
+#include <cstring>
+#include <string>
+
+#include "mjpc/array_safety.h"
+#include "mjpc/utilities.h"
+
+namespace mjpc {
+
+namespace mju = ::mujoco::util_mjpc;
+using mjpc::spline::SplineInterpolation;
+
+namespace {
+
+// Task::Name() -> built-in device residual (include/mjpc_hip.h MJPC_TASK_*); -1: none
+int DeviceResidual(const Task& task) {
+  const std::string name = task.Name();
+  if (name == "Cartpole") return MJPC_TASK_CARTPOLE;
+  if (name == "Quadruped Flat") return MJPC_TASK_QUADRUPED;
+  if (name == "Humanoid Track") return MJPC_TASK_HUMANOID_TRACK;
+  if (name == "Humanoid Stand") return MJPC_TASK_HUMANOID_STAND;
+  if (name == "Humanoid Walk") return MJPC_TASK_HUMANOID_WALK;
+  if (name == "Shadow") return MJPC_TASK_SHADOW_REORIENT;
+  if (name == "Particle") return MJPC_TASK_PARTICLE;
+  return -1;
+}
+
+template <class T>
+std::vector<int> Widen(const T* src, int n) { return std::vector<int>(src, src + n); }
+
+}  // namespace
+
+bool HipSamplingPlanner::Supports(const Task& task) { return DeviceResidual(task) >= 0; }
+
+// ---- views ------------------------------------------------------------------------------------------------------------
+// MjpcHipModel mirrors mjModel's names: pointers are copied where layout and width agree, small vectors bridge the rest
+// (mjtByte flags -> int32, actuator_gainprm[mjNGAIN] -> first 3, actuator_trnid[2] -> first, actuator_gear[6] -> first)
+static void FillModelView(const mjModel* m, MjpcHipModel& v, std::vector<int>& jnt_limited, std::vector<int>& ctrllimited,
+                          std::vector<int>& forcelimited, std::vector<int>& biastype, std::vector<int>& trntype,
+                          std::vector<int>& trnid, std::vector<int>& tendon_limited, std::vector<int>& wrap_objid,
+                          std::vector<double>& gainprm, std::vector<double>& biasprm, std::vector<double>& gear,
+                          std::vector<double>& wrap_prm) {
+  std::memset(&v, 0, sizeof(v));
+  v.nq = m->nq; v.nv = m->nv; v.nu = m->nu; v.na = m->na; v.nbody = m->nbody; v.njnt = m->njnt; v.ngeom = m->ngeom;
+  v.nsite = m->nsite; v.nmocap = m->nmocap; v.nuserdata = m->nuserdata; v.nkey = m->nkey; v.nexclude = m->nexclude;
+  v.ntendon = m->ntendon; v.nwrap = m->nwrap;
+  v.timestep = m->opt.timestep; mju_copy3(v.gravity, m->opt.gravity);
+  v.impratio = m->opt.impratio; v.tolerance = m->opt.tolerance; v.ls_tolerance = m->opt.ls_tolerance;
+  v.cone = m->opt.cone; v.iterations = m->opt.iterations; v.ls_iterations = m->opt.ls_iterations;
+  v.disableflags = m->opt.disableflags; v.meaninertia = m->stat.meaninertia;
+  v.nconmax = 0; v.nefcmax = 0;      // engine defaults (32 contacts, 128 rows per candidate)
+  v.body_parentid = m->body_parentid; v.body_rootid = m->body_rootid; v.body_weldid = m->body_weldid;
+  v.body_mocapid = m->body_mocapid; v.body_jntnum = m->body_jntnum; v.body_jntadr = m->body_jntadr;
+  v.body_dofnum = m->body_dofnum; v.body_dofadr = m->body_dofadr;
+  v.body_pos = m->body_pos; v.body_quat = m->body_quat; v.body_ipos = m->body_ipos; v.body_iquat = m->body_iquat;
+  v.body_mass = m->body_mass; v.body_subtreemass = m->body_subtreemass; v.body_inertia = m->body_inertia;
+  v.body_invweight0 = m->body_invweight0;
+  v.jnt_type = m->jnt_type; v.jnt_qposadr = m->jnt_qposadr; v.jnt_dofadr = m->jnt_dofadr; v.jnt_bodyid = m->jnt_bodyid;
+  jnt_limited = Widen(m->jnt_limited, m->njnt); v.jnt_limited = jnt_limited.data();
+  v.jnt_pos = m->jnt_pos; v.jnt_axis = m->jnt_axis; v.jnt_stiffness = m->jnt_stiffness; v.jnt_range = m->jnt_range;
+  v.jnt_margin = m->jnt_margin; v.jnt_solref = m->jnt_solref; v.jnt_solimp = m->jnt_solimp;
+  v.qpos0 = m->qpos0; v.qpos_spring = m->qpos_spring;
+  v.dof_bodyid = m->dof_bodyid; v.dof_jntid = m->dof_jntid; v.dof_parentid = m->dof_parentid;
+  v.dof_armature = m->dof_armature; v.dof_damping = m->dof_damping; v.dof_frictionloss = m->dof_frictionloss;
+  v.dof_invweight0 = m->dof_invweight0; v.dof_solref = m->dof_solref; v.dof_solimp = m->dof_solimp;
+  v.geom_type = m->geom_type; v.geom_contype = m->geom_contype; v.geom_conaffinity = m->geom_conaffinity;
+  v.geom_condim = m->geom_condim; v.geom_bodyid = m->geom_bodyid; v.geom_group = m->geom_group;
+  v.geom_priority = m->geom_priority; v.geom_size = m->geom_size; v.geom_pos = m->geom_pos; v.geom_quat = m->geom_quat;
+  v.geom_friction = m->geom_friction; v.geom_solmix = m->geom_solmix; v.geom_solref = m->geom_solref;
+  v.geom_solimp = m->geom_solimp; v.geom_margin = m->geom_margin; v.geom_gap = m->geom_gap; v.geom_rbound = m->geom_rbound;
+  v.exclude_signature = m->exclude_signature;
+  v.site_bodyid = m->site_bodyid; v.site_pos = m->site_pos; v.site_quat = m->site_quat;
+  trntype.clear(); trnid.clear(); gainprm.clear(); biasprm.clear(); gear.clear();
+  for (int i = 0; i < m->nu; i++) {
+    trntype.push_back(m->actuator_trntype[i]);
+    trnid.push_back(m->actuator_trnid[2 * i]);
+    for (int k = 0; k < 3; k++) {
+      gainprm.push_back(m->actuator_gainprm[mjNGAIN * i + k]);
+      biasprm.push_back(m->actuator_biasprm[mjNBIAS * i + k]);
+    }
+    gear.push_back(m->actuator_gear[6 * i]);
+  }
+  ctrllimited = Widen(m->actuator_ctrllimited, m->nu); forcelimited = Widen(m->actuator_forcelimited, m->nu);
+  biastype = Widen(m->actuator_biastype, m->nu);
+  v.actuator_trntype = trntype.data(); v.actuator_trnid = trnid.data();
+  v.actuator_ctrllimited = ctrllimited.data(); v.actuator_forcelimited = forcelimited.data(); v.actuator_biastype = biastype.data();
+  v.actuator_gainprm = gainprm.data(); v.actuator_biasprm = biasprm.data(); v.actuator_gear = gear.data();
+  v.actuator_ctrlrange = m->actuator_ctrlrange; v.actuator_forcerange = m->actuator_forcerange;
+  // fixed tendons: wrap objects are joints, wrap_prm the coefficient (spatial tendons are refused by mjpc_hip_create)
+  tendon_limited = Widen(m->tendon_limited, m->ntendon);
+  wrap_objid.assign(m->wrap_objid, m->wrap_objid + m->nwrap); wrap_prm.assign(m->wrap_prm, m->wrap_prm + m->nwrap);
+  v.tendon_adr = m->tendon_adr; v.tendon_num = m->tendon_num; v.tendon_limited = tendon_limited.data();
+  v.wrap_objid = wrap_objid.data(); v.wrap_prm = wrap_prm.data(); v.tendon_range = m->tendon_range;
+  v.tendon_margin = m->tendon_margin; v.tendon_solref_lim = m->tendon_solref_lim; v.tendon_solimp_lim = m->tendon_solimp_lim;
+  v.tendon_invweight0 = m->tendon_invweight0;
+  v.key_qpos = m->key_qpos; v.key_mpos = m->key_mpos;
+}
+
+// cost table of Task::Reset (task.cc:147-245) + the trace sensors (task.cc:193-198, utilities.cc:250-267)
+static void FillTaskView(const Task& task, const mjModel* m, MjpcHipTask& t, std::vector<int>& norm, std::vector<int>& trace_type,
+                         std::vector<int>& trace_id, std::vector<int>& ints, std::vector<double>& dbls) {
+  std::memset(&t, 0, sizeof(t));
+  t.task_id = DeviceResidual(task);
+  t.num_residual = task.num_residual; t.num_term = task.num_term; t.num_trace = task.num_trace;
+  t.dim_norm_residual = task.dim_norm_residual.data(); t.num_norm_parameter = task.num_norm_parameter.data();
+  norm.assign(task.norm.begin(), task.norm.end()); t.norm = norm.data();
+  t.weight = task.weight.data(); t.norm_parameter = task.norm_parameter.data(); t.risk = task.risk;
+  t.num_parameter = static_cast<int>(task.parameters.size()); t.parameters = task.parameters.data();
+  trace_type.clear(); trace_id.clear();
+  for (int i = 0; i < task.num_trace; i++) {
+    char name[32];
+    mju::sprintf_arr(name, "trace%i", i);
+    int id = mj_name2id(m, mjOBJ_SENSOR, name);
+    trace_type.push_back(id >= 0 ? m->sensor_objtype[id] : MJPC_OBJ_XBODY);
+    trace_id.push_back(id >= 0 ? m->sensor_objid[id] : 0);
+  }
+  t.trace_objtype = trace_type.data(); t.trace_objid = trace_id.data();
+  // frozen ResidualFn members: layouts documented in DESIGN.md section 2b (QI_* / QD_* for the quadruped, site / mocap ids
+  // for tracking, body ids for stand / walk / the hand); filled by the per-task helper of the maintainer's choice
+  t.num_int = static_cast<int>(ints.size()); t.int_data = ints.data();
+  t.num_dbl = static_cast<int>(dbls.size()); t.dbl_data = dbls.data();
+}
+
+// ---- Planner virtuals ---------------------------------------------------------------------------------------------------
+void HipSamplingPlanner::Initialize(mjModel* model, const Task& task) {
+  this->model = model;
+  this->task = &task;
+  mjpc_hip::Numerics n;                                     // exactly the numerics of sampling/planner.cc:53-67
+  n.sampling_exploration[0] = GetNumberOrDefault(0.1, model, "sampling_exploration");
+  int se_id = mj_name2id(model, mjOBJ_NUMERIC, "sampling_exploration");
+  if (se_id >= 0 && model->numeric_size[se_id] > 1) n.sampling_exploration[1] = model->numeric_data[model->numeric_adr[se_id] + 1];
+  n.sampling_trajectories = GetNumberOrDefault(10, model, "sampling_trajectories");
+  n.sampling_representation = GetNumberOrDefault(static_cast<int>(SplineInterpolation::kCubicSpline), model, "sampling_representation");
+  n.sampling_sliding_plan = GetNumberOrDefault(0, model, "sampling_sliding_plan");
+  n.sampling_spline_points = GetNumberOrDefault(kMaxTrajectoryHorizon, model, "sampling_spline_points");
+  n.max_samples = kMaxTrajectoryHip;
+  n.max_horizon = kMaxTrajectoryHorizon;
+  n.n_devices = n_devices = GetNumberOrDefault(1, model, "sampling_devices");
+  noise_exploration[0] = n.sampling_exploration[0]; noise_exploration[1] = n.sampling_exploration[1];
+  num_trajectory_ = n.sampling_trajectories;
+  interpolation_ = static_cast<SplineInterpolation>(n.sampling_representation);
+  sliding_plan_ = n.sampling_sliding_plan;
+  if (num_trajectory_ > kMaxTrajectoryHip) mju_error_i("Too many trajectories, %d is the maximum allowed.", kMaxTrajectoryHip);
+  FillModelView(model, model_view_, jnt_limited_, ctrllimited_, forcelimited_, biastype_, trntype_, trnid_, tendon_limited_,
+                wrap_objid_, gainprm_, biasprm_, gear_, wrap_prm_);
+  FillTaskView(task, model, task_view_, norm_, trace_type_, trace_id_, task_int_, task_dbl_);
+  mjpc_hip::SetErrorHandler([](const char* msg) { mju_error("HipSamplingPlanner: %s", msg); });
+  impl_.Initialize(&model_view_, &task_view_, n);           // creates the engines (model may have changed: old ones dropped)
+  winner = 0;
+}
+
+void HipSamplingPlanner::Allocate() {
+  int num_state = model->nq + model->nv + model->na;
+  state.resize(num_state); mocap.resize(7 * model->nmocap); userdata.resize(model->nuserdata);
+  policy.Allocate(model, *task, kMaxTrajectoryHorizon);
+  previous_policy.Allocate(model, *task, kMaxTrajectoryHorizon);
+  scratch_policy_.Allocate(model, *task, kMaxTrajectoryHorizon);
+  for (Trajectory* t : {&best_, &scratch_trajectory_}) {
+    t->Initialize(num_state, model->nu, task->num_residual, task->num_trace, kMaxTrajectoryHorizon);
+    t->Allocate(kMaxTrajectoryHorizon);
+  }
+  impl_.Allocate();
+  winner = -1;
+}
+
+void HipSamplingPlanner::Reset(int horizon, const double* initial_repeated_action) {
+  std::fill(state.begin(), state.end(), 0.0); std::fill(mocap.begin(), mocap.end(), 0.0);
+  std::fill(userdata.begin(), userdata.end(), 0.0);
+  time = 0.0;
+  policy.Reset(horizon, initial_repeated_action);
+  previous_policy.Reset(horizon, initial_repeated_action);
+  best_.Reset(kMaxTrajectoryHorizon);
+  impl_.Reset(horizon, initial_repeated_action);
+  improvement = 0.0;
+  winner = 0;
+}
+
+void HipSamplingPlanner::SetState(const State& s) {           // sampling/planner.cc:146-149
+  s.CopyTo(state.data(), mocap.data(), userdata.data(), &time);
+  impl_.SetState(state.data(), mocap.data(), userdata.data(), time);
+}
+
+void HipSamplingPlanner::RefreshTask() {
+  // GUI-written settings are snapshotted at the top of a plan step (sampling/planner.cc:153-156)
+  impl_.num_trajectory_ = num_trajectory_; impl_.interpolation_ = static_cast<int>(interpolation_);
+  impl_.sliding_plan_ = sliding_plan_;
+  impl_.noise_exploration[0] = noise_exploration[0]; impl_.noise_exploration[1] = noise_exploration[1];
+  FillTaskView(*task, model, task_view_, norm_, trace_type_, trace_id_, task_int_, task_dbl_);
+  impl_.SetTask(&task_view_);                                 // only the task block travels, asynchronously
+}
+
+void HipSamplingPlanner::SyncFromImpl() {
+  {
+    const std::unique_lock<std::shared_mutex> lock(mtx_);
+    for (int which = 0; which < 2; which++) {
+      const mjpc_hip::SamplingPolicy& src = which ? impl_.previous_policy : impl_.policy;
+      SamplingPolicy& dst = which ? previous_policy : policy;
+      dst.plan.Clear();
+      dst.plan.SetInterpolation(interpolation_);
+      for (int p = 0; p < static_cast<int>(src.plan.Size()); p++)
+        dst.plan.AddNode(src.plan.NodeTime(p), absl::MakeConstSpan(src.plan.NodeValues(p), model->nu));
+      dst.num_spline_points = src.num_spline_points;
+    }
+  }
+  winner = impl_.winner; improvement = impl_.improvement; trajectory_order = impl_.trajectory_order;
+  noise_compute_time = impl_.noise_compute_time; rollouts_compute_time = impl_.rollouts_compute_time;
+  policy_update_compute_time = impl_.policy_update_compute_time;
+}
+
+static void CopyTrajectory(const mjpc_hip::Trajectory& src, Trajectory& dst) {
+  dst.horizon = src.horizon; dst.total_return = src.total_return; dst.failure = src.failure;
+  std::copy(src.states.begin(), src.states.begin() + static_cast<size_t>(src.horizon) * src.dim_state, dst.states.begin());
+  std::copy(src.actions.begin(), src.actions.begin() + static_cast<size_t>(src.horizon) * src.dim_action, dst.actions.begin());
+  std::copy(src.times.begin(), src.times.begin() + src.horizon, dst.times.begin());
+  std::copy(src.residual.begin(), src.residual.begin() + static_cast<size_t>(src.horizon) * src.dim_residual, dst.residual.begin());
+  std::copy(src.costs.begin(), src.costs.begin() + src.horizon, dst.costs.begin());
+  std::copy(src.trace.begin(), src.trace.begin() + static_cast<size_t>(src.horizon) * src.dim_trace, dst.trace.begin());
+}
+
+void HipSamplingPlanner::OptimizePolicy(int horizon, ThreadPool& /*pool: the GPU replaces the worker threads*/) {
+  RefreshTask();
+  impl_.OptimizePolicy(horizon);                              // UpdateNominalPolicy -> rollouts on the GPU(s) -> winner adoption
+  last_horizon_ = horizon;
+  SyncFromImpl();
+  CopyTrajectory(impl_.trajectory_winner, best_);
+}
+
+void HipSamplingPlanner::NominalTrajectory(int horizon, ThreadPool&) {
+  RefreshTask();
+  impl_.NominalTrajectory(horizon);
+  CopyTrajectory(impl_.trajectory_winner, best_);
+}
+
+void HipSamplingPlanner::ActionFromPolicy(double* action, const double* s, double t, bool use_previous) {
+  impl_.ActionFromPolicy(action, s, t, use_previous);         // any thread, concurrently with planning (shared lock inside)
+}
+
+const Trajectory* HipSamplingPlanner::BestTrajectory() { return winner >= 0 ? &best_ : nullptr; }
+
+int HipSamplingPlanner::OptimizePolicyCandidates(int ncandidates, int horizon, ThreadPool&) {
+  RefreshTask();
+  impl_.UpdateNominalPolicy(horizon);
+  int n = impl_.OptimizePolicyCandidates(ncandidates, horizon);
+  last_horizon_ = horizon;
+  trajectory_order = impl_.trajectory_order;
+  return n;
+}
+double HipSamplingPlanner::CandidateScore(int candidate) const { return impl_.CandidateScore(candidate); }
+void HipSamplingPlanner::ActionFromCandidatePolicy(double* action, int candidate, const double* s, double t) {
+  impl_.ActionFromCandidatePolicy(action, candidate, s, t);
+}
+void HipSamplingPlanner::CopyCandidateToPolicy(int candidate) {
+  impl_.CopyCandidateToPolicy(candidate);
+  SyncFromImpl();
+  CopyTrajectory(impl_.trajectory_winner, best_);
+}
+
+// trajectory[i] / candidate_policy[i] of the reference (ilqs/planner.cc:98-198 reads them): fetched from the owning device
+const Trajectory& HipSamplingPlanner::trajectory(int i) {
+  impl_.FetchCandidateUnranked(i);
+  CopyTrajectory(impl_.trajectory_winner, scratch_trajectory_);
+  return scratch_trajectory_;
+}
+const SamplingPolicy& HipSamplingPlanner::candidate_policy(int i) {
+  std::vector<double> knots(static_cast<size_t>(impl_.KnotTimes().size()) * model->nu);
+  impl_.CandidateKnotsUnranked(i, knots.data());
+  scratch_policy_.plan.Clear();
+  scratch_policy_.plan.SetInterpolation(interpolation_);
+  for (size_t p = 0; p < impl_.KnotTimes().size(); p++)
+    scratch_policy_.plan.AddNode(impl_.KnotTimes()[p], absl::MakeConstSpan(knots.data() + p * model->nu, model->nu));
+  return scratch_policy_;
+}
+
+// ---- GUI side (render thread, unsynchronised reads like the reference) ----------------------------------------------------
+void HipSamplingPlanner::Traces(mjvScene* scn) {              // sampling/planner.cc:388-434
+  float color[4] = {1.0, 1.0, 1.0, 1.0};
+  double zero3[3] = {0};
+  double zero9[9] = {0};
+  int N = num_trajectory_, H = last_horizon_, ntr = 3 * task->num_trace;
+  if (winner < 0 || H < 2 || ntr == 0) return;
+  traces_.resize(static_cast<size_t>(N) * H * ntr);
+  impl_.AllTraces(traces_.data());                            // one D2H copy: [N][H][3 * num_trace]
+  for (int k = 0; k < N; k++) {
+    for (int i = 0; i < H - 1; i++) {
+      if (scn->ngeom + task->num_trace > scn->maxgeom) return;
+      for (int j = 0; j < task->num_trace; j++) {
+        mjv_initGeom(&scn->geoms[scn->ngeom], mjGEOM_LINE, zero3, zero3, zero9, color);
+        const double* a = traces_.data() + (static_cast<size_t>(k) * H + i) * ntr + 3 * j;
+        mjv_connector(&scn->geoms[scn->ngeom], mjGEOM_LINE, 1.5, a, a + ntr);
+        scn->ngeom += 1;
+      }
+    }
+  }
+}
+
+void HipSamplingPlanner::GUI(mjUI& ui) {                      // sampling/planner.cc:437-473, same widgets on this object's members
+  mjuiDef defSampling[] = {
+      {mjITEM_SLIDERINT, "Rollouts", 2, &num_trajectory_, "0 1"},
+      {mjITEM_SELECT, "Spline", 2, &interpolation_, "Zero\nLinear\nCubic"},
+      {mjITEM_SLIDERINT, "Spline Pts", 2, &policy.num_spline_points, "0 1"},
+      {mjITEM_SLIDERNUM, "Noise Std", 2, noise_exploration, "0 1"},
+      {mjITEM_END}};
+  mju::sprintf_arr(defSampling[0].other, "%i %i", 1, kMaxTrajectoryHip);
+  mju::sprintf_arr(defSampling[2].other, "%i %i", MinSamplingSplinePoints, MaxSamplingSplinePoints);
+  mju::sprintf_arr(defSampling[3].other, "%f %f", MinNoiseStdSampling, MaxNoiseStdSampling);
+  mjui_add(&ui, defSampling);
+}
+
+void HipSamplingPlanner::Plots(mjvFigure* fig_planner, mjvFigure* fig_timer, int planner_shift, int timer_shift, int planning,
+                               int* shift) {                  // sampling/planner.cc:476-523
+  double planner_bounds[2] = {-6.0, 6.0};
+  mjpc::PlotUpdateData(fig_planner, planner_bounds, fig_planner->linedata[0 + planner_shift][0] + 1, mju_log10(mju_max(improvement, 1.0e-6)),
+                       100, 0 + planner_shift, 0, 1, -100);
+  mju::strcpy_arr(fig_planner->linename[0 + planner_shift], "Improvement");
+  fig_planner->range[1][0] = planner_bounds[0]; fig_planner->range[1][1] = planner_bounds[1];
+  double timer_bounds[2] = {0.0, 1.0};
+  PlotUpdateData(fig_timer, timer_bounds, fig_timer->linedata[0 + timer_shift][0] + 1, 1.0e-3 * noise_compute_time * planning, 100,
+                 0 + timer_shift, 0, 1, -100);
+  PlotUpdateData(fig_timer, timer_bounds, fig_timer->linedata[1 + timer_shift][0] + 1, 1.0e-3 * rollouts_compute_time * planning, 100,
+                 1 + timer_shift, 0, 1, -100);
+  PlotUpdateData(fig_timer, timer_bounds, fig_timer->linedata[2 + timer_shift][0] + 1, 1.0e-3 * policy_update_compute_time * planning, 100,
+                 2 + timer_shift, 0, 1, -100);
+  mju::strcpy_arr(fig_timer->linename[0 + timer_shift], "Noise");
+  mju::strcpy_arr(fig_timer->linename[1 + timer_shift], "Rollout");
+  mju::strcpy_arr(fig_timer->linename[2 + timer_shift], "Policy Update");
+  fig_timer->range[0][0] = -100; fig_timer->range[0][1] = 0; fig_timer->range[1][0] = 0.0; fig_timer->range[1][1] = timer_bounds[1];
+  shift[0] += 1; shift[1] += 3;
+}
+
+}  // namespace mjpc

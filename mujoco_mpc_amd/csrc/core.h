@@ -95,7 +95,11 @@ DEV void ctx_init(Ctx &c, const KParams *K, double *base) {
   P_(xpos); P_(xquat); P_(xmat); P_(xipos); P_(ximat); P_(xanchor); P_(xaxis); P_(geom_xpos); P_(geom_xmat); P_(site_xpos);
   P_(subtree_com); P_(cinert); P_(crb); P_(cdof); P_(cvel); P_(cdof_dot); P_(cacc); P_(cfrc); P_(cfrc_sub);
   P_(subtree_linvel); P_(bodytmp); P_(qM); P_(qL); P_(qH); P_(Linv); P_(Hinv);
+#ifdef MJPC_AB_FRICJ
+  c.efc_J = base + L.efc_J;
+#else
   c.efc_J = base + L.efc_J - K->M.nfric * K->M.nvp;      // rows [nfric, nefcmax) are stored: a friction-loss row is the unit vector of its dof
+#endif
   P_(efc_JA); P_(efc_D); P_(efc_R); P_(efc_aref); P_(efc_force); P_(efc_jar); P_(efc_jv); P_(efc_floss);
   P_(efc_pos); P_(efc_margin); P_(efc_diag); P_(contact);
   P_(Ma); P_(grad); P_(Mgrad); P_(search); P_(Mv); P_(vtmp); P_(sgl);
@@ -696,6 +700,7 @@ DEV int np_box_box(NPCon *con, double margin, const double *pa, const double *ma
     sep |= s > margin;
     if (s > best) { best = s; code = 3 + j; }
   }
+  if (sep) return 0;                 // separated along a face normal: most non-touching pairs leave here
   double ebest = -1e300; int ecode = -1;
 #pragma unroll
   for (int i = 0; i < 3; i++)
@@ -882,13 +887,11 @@ DEV int np_capsule_cylinder(NPCon *con, double margin, const double *kp, const d
   return cnt;
 }
 
-// The rarely-met pair types (capsule-box, box-box, the cylinder pairs) live in ONE out-of-line function with its own register
-// allocation: collision() of the common models (plane / sphere / capsule contacts) keeps the registers and code it had before
-// these colliders existed; the result comes back through the stack.  n = -1: no collider and possibly touching.
+// The rarely-met pair types (capsule-box, box-box, the cylinder pairs).  n = -1: no collider and possibly touching.
+// Only the out-of-line flavour of the narrow-phase batch (narrow_batch<true>) contains this code: the batch loop of
+// collision() itself stays free of it and of any call inside the loop body's live ranges.
 struct NPOut { NPCon c[4]; int n; };
-DEV_NOINLINE NPOut narrow_heavy(const KParams *Kg, int g1, int g2, double margin) {
-  Ctx c;
-  ctx_init(c, Kg, lds_base());
+DEV NPOut narrow_heavy(Ctx &c, int g1, int g2, double margin) {
   const DevModel &M = *c.M;
   NPOut o;
   int t1 = MI(geom_type)[g1], t2 = MI(geom_type)[g2];
@@ -911,28 +914,79 @@ DEV_NOINLINE NPOut narrow_heavy(const KParams *Kg, int g1, int g2, double margin
   return o;
 }
 
-// returns the number of contacts; -2: a pair type handled by narrow_heavy()
+// squared distance from point q to the segment p +- h a (|a| = 1)
+DEV double seg_point_dist2(const double *p, const double *a, double h, const double *q) {
+  double w[3];
+  d_sub3(w, q, p);
+  double x = d_clip(d_dot3(a, w), -h, h);
+  d_addtoscl3(w, a, -x);
+  return d_dot3(w, w);
+}
+
+// returns the number of contacts; -2: a pair type handled by narrow_heavy().
+// A cylinder that is not against a plane is first replaced by its bounding capsule (same radius and half length) and runs
+// through the SAME sphere-capsule / capsule-capsule code as the real capsules of the wave (no extra divergent code path):
+// "certainly apart" is exact, and only a cylinder whose bounding capsule touches goes out of line.  A capsule / cylinder
+// against a box first tests its segment against the box's bounding sphere.
 DEV int narrow_phase(Ctx &c, int g1, int g2, double margin, NPCon *con) {
   const DevModel &M = *c.M;
-  int t1 = MI(geom_type)[g1], t2 = MI(geom_type)[g2];
-  int light = (t1 == 0 && (t2 == 2 || t2 == 3 || t2 == 6 || t2 == 5)) || (t1 == 2 && (t2 == 2 || t2 == 3 || t2 == 6)) || (t1 == 3 && t2 == 3);
-  if (!light) return -2;
+  const int t1 = MI(geom_type)[g1], t2 = MI(geom_type)[g2];
+#ifdef MJPC_AB_NOHEAVY      // A/B measurement builds only: the round-1 behaviour (pairs without a light collider never touch)
+  if (!((t1 == 0 && (t2 == 2 || t2 == 3 || t2 == 6 || t2 == 5)) || (t1 == 2 && (t2 == 2 || t2 == 3 || t2 == 6)) || (t1 == 3 && t2 == 3))) return 0;
+#endif
+  const int cyl = (t1 == 5 || (t2 == 5 && t1 != 0));
+  const int e1 = t1 == 5 ? 3 : t1, e2 = (t2 == 5 && t1 != 0) ? 3 : t2;
+  if (e1 == 6 || e1 == 4 || e2 == 4 || e1 == 1 || e2 == 1 || e1 == 7 || e2 == 7) return -2;      // box-box (and what create() refuses)
   double p1[3], p2[3], m1[9], m2[9], s1[3], s2[3];
   d_copy3(p1, c.geom_xpos + 3 * g1); d_copy3(p2, c.geom_xpos + 3 * g2);
   for (int k = 0; k < 9; k++) { m1[k] = c.geom_xmat[9 * g1 + k]; m2[k] = c.geom_xmat[9 * g2 + k]; }
   d_copy3(s1, MD(geom_size) + 3 * g1); d_copy3(s2, MD(geom_size) + 3 * g2);
-  if (t1 == 0) {
-    double n[3] = {m1[2], m1[5], m1[8]};
-    if (t2 == 2) return np_plane_sphere(con, margin, p1, n, p2, s2[0]);
-    if (t2 == 3) return np_plane_capsule(con, margin, p1, m1, p2, m2, s2);
-    if (t2 == 6) return np_plane_box(con, margin, p1, m1, p2, m2, s2);
-    return np_plane_cylinder(con, margin, p1, m1, p2, m2, s2);
-  } else if (t1 == 2) {
-    if (t2 == 2) return np_sphere_sphere(con, margin, p1, s1[0], p2, s2[0]);
-    if (t2 == 3) return np_sphere_capsule(con, margin, p1, s1[0], p2, m2, s2);
-    return np_sphere_box(con, margin, p1, s1[0], p2, m2, s2);
+  int n;
+  if (e1 == 0) {
+    double nrm[3] = {m1[2], m1[5], m1[8]};
+    if (e2 == 2) n = np_plane_sphere(con, margin, p1, nrm, p2, s2[0]);
+    else if (e2 == 3) n = np_plane_capsule(con, margin, p1, m1, p2, m2, s2);
+    else if (e2 == 6) n = np_plane_box(con, margin, p1, m1, p2, m2, s2);
+    else n = np_plane_cylinder(con, margin, p1, m1, p2, m2, s2);
+    return n;
   }
-  return np_capsule_capsule(con, margin, p1, m1, s1, p2, m2, s2);
+  if (e2 == 6 && e1 == 3) {         // capsule / cylinder against a box: cheap conservative separations, else out of line
+    double a1[3] = {m1[2], m1[5], m1[8]};
+    double r = s1[0] + MD(geom_rbound)[g2] + margin;
+    if (seg_point_dist2(p1, a1, s1[1], p2) > r * r) return 0;         // segment against the box's bounding sphere
+    double dif[3], q[3], al[3];
+    d_sub3(dif, p1, p2);
+    d_mulmattvec3(q, m2, dif);
+    d_mulmattvec3(al, m2, a1);
+    double rr = s1[0] + margin;                                        // the box's three face normals as separating axes
+    if (fabs(q[0]) - s1[1] * fabs(al[0]) > s2[0] + rr || fabs(q[1]) - s1[1] * fabs(al[1]) > s2[1] + rr ||
+        fabs(q[2]) - s1[1] * fabs(al[2]) > s2[2] + rr) return 0;
+    // ... and the three axes  segment direction x box axis  (the segment projects to a point on them)
+    {
+      double l0 = sqrt(al[1] * al[1] + al[2] * al[2]), l1 = sqrt(al[0] * al[0] + al[2] * al[2]), l2 = sqrt(al[0] * al[0] + al[1] * al[1]);
+      if (fabs(q[2] * al[1] - q[1] * al[2]) > s2[1] * fabs(al[2]) + s2[2] * fabs(al[1]) + rr * l0) return 0;      // a x e0 = (0, a2, -a1)
+      if (fabs(q[0] * al[2] - q[2] * al[0]) > s2[0] * fabs(al[2]) + s2[2] * fabs(al[0]) + rr * l1) return 0;      // a x e1 = (-a2, 0, a0)
+      if (fabs(q[1] * al[0] - q[0] * al[1]) > s2[0] * fabs(al[1]) + s2[1] * fabs(al[0]) + rr * l2) return 0;      // a x e2 = (a1, -a0, 0)
+    }
+    return -2;
+  }
+  if (cyl) {
+    // cheap conservative separations before the bounding-capsule test proper (no divide, no square root): each segment against
+    // the other geom's bounding sphere
+    double a1[3] = {m1[2], m1[5], m1[8]}, a2[3] = {m2[2], m2[5], m2[8]};
+    double h1 = e1 == 2 ? 0.0 : s1[1], h2 = e2 == 2 ? 0.0 : s2[1];
+    double ra = s1[0] + h1 + s2[0] + margin, rb = s1[0] + s2[0] + h2 + margin;
+    if (seg_point_dist2(p2, a2, h2, p1) > ra * ra) return 0;
+    if (seg_point_dist2(p1, a1, h1, p2) > rb * rb) return 0;
+  }
+  if (e1 == 2) {
+    if (e2 == 2) n = np_sphere_sphere(con, margin, p1, s1[0], p2, s2[0]);
+    else if (e2 == 3) n = np_sphere_capsule(con, margin, p1, s1[0], p2, m2, s2);
+    else n = np_sphere_box(con, margin, p1, s1[0], p2, m2, s2);
+  } else {
+    n = np_capsule_capsule(con, margin, p1, m1, s1, p2, m2, s2);
+  }
+  return (cyl && n > 0) ? -2 : n;
 }
 
 DEV void contact_param(Ctx &c, int g1, int g2, double *cc, int *dim) {
@@ -965,6 +1019,64 @@ DEV void contact_param(Ctx &c, int g1, int g2, double *cc, int *dim) {
   cc[CON_FRICTION + 3] = fri[2]; cc[CON_FRICTION + 4] = fri[2];
 }
 
+// one batch of (at most) NLANE active pairs: narrow phase per lane, ordered compaction, contact records.
+// returns 0: done; 1 (HEAVY == false only): some pair needs narrow_heavy(), nothing was written; 2: contact buffer full
+template <bool HEAVY>
+DEV int narrow_batch(Ctx &c, int base, int nactive) {
+  const DevModel &M = *c.M;
+  int a = base + LANE, n = 0, g1 = 0, g2 = 0;
+  double margin = 0, gap = 0;
+  NPCon con[4] = {};
+  if (a < nactive) {
+    int p = c.active[a];
+    g1 = MI(pair_g1)[p]; g2 = MI(pair_g2)[p];
+    margin = fmax(MD(geom_margin)[g1], MD(geom_margin)[g2]);
+    gap = fmax(MD(geom_gap)[g1], MD(geom_gap)[g2]);
+    n = narrow_phase(c, g1, g2, margin, con);
+    if constexpr (HEAVY) {
+      if (n == -2) {
+        NPOut h = narrow_heavy(c, g1, g2, margin);
+        n = h.n; con[0] = h.c[0]; con[1] = h.c[1]; con[2] = h.c[2]; con[3] = h.c[3];
+      }
+      if (n < 0) { c.warning |= WARN_UNSUPPORTED; n = 0; }      // lane-local here; made wave-uniform below
+    }
+  }
+  if constexpr (HEAVY) c.warning = wave_or_i(c.warning);
+  else if (wave_any(n == -2)) return 1;
+  int tot, off = wave_excl_scan(n, &tot);
+  if (c.ncon + tot > M.nconmax) { c.warning |= WARN_CONTACTFULL; return 2; }
+  for (int k = 0; k < n; k++) {
+    int ci = c.ncon + off + k;
+    double *cc = c.contact + ci * c.M->con_stride;
+    int dim;
+    contact_param(c, g1, g2, cc, &dim);
+    const NPCon cur = np_get(con, k);
+    double fr[9];
+    for (int q = 0; q < 6; q++) fr[q] = cur.frame[q];
+    d_makeframe(fr);
+    cc[CON_DIST] = cur.dist;
+    d_copy3(cc + CON_POS, cur.pos);
+    for (int q = 0; q < 9; q++) cc[CON_FRAME + q] = fr[q];
+    cc[CON_INCLUDEMARGIN] = margin - gap;
+    cc[CON_MU] = 0;
+    int *ci_ = c.con_i + ci * CONI_STRIDE;
+    ci_[0] = dim; ci_[1] = g1; ci_[2] = g2; ci_[3] = 0;
+  }
+  c.ncon += tot;
+  return 0;
+}
+// the batches from `base` on with every collider available (out of line: own registers, called from outside collision()'s loop)
+struct BatchOut { int ncon, warning; };
+DEV_NOINLINE BatchOut narrow_rest_heavy(const KParams *Kg, int base, int nactive, int ncon, int warning) {
+  Ctx c;
+  ctx_init(c, Kg, lds_base());
+  c.ncon = ncon; c.warning = warning;
+  for (; base < nactive; base += NLANE) if (narrow_batch<true>(c, base, nactive) == 2) break;
+  BatchOut o;
+  o.ncon = c.ncon; o.warning = c.warning;
+  return o;
+}
+
 DEV void collision(Ctx &c) {
   const DevModel &M = *c.M;
   c.ncon = 0;
@@ -995,44 +1107,18 @@ DEV void collision(Ctx &c) {
   }
   if (nactive > MAX_ACTIVE_PAIRS) { c.warning |= WARN_CONTACTFULL; nactive = MAX_ACTIVE_PAIRS; }
   SYNC();
-  // (2) narrow phase, one lane per active pair, contacts appended in pair order
+  // (2) narrow phase, one lane per active pair, contacts appended in pair order.  The loop only knows the cheap colliders; at
+  // the first batch in which some pair needs an expensive one it stops (nothing of that batch is kept) and the out-of-line
+  // flavour finishes the list from there.  The call sits behind the loop, so the loop's registers are not shaped by it.
+  int heavy_from = -1;
   for (int base = 0; base < nactive; base += NLANE) {
-    int a = base + LANE, n = 0, g1 = 0, g2 = 0;
-    double margin = 0, gap = 0;
-    NPCon con[4] = {};
-    if (a < nactive) {
-      int p = c.active[a];
-      g1 = MI(pair_g1)[p]; g2 = MI(pair_g2)[p];
-      margin = fmax(MD(geom_margin)[g1], MD(geom_margin)[g2]);
-      gap = fmax(MD(geom_gap)[g1], MD(geom_gap)[g2]);
-      n = narrow_phase(c, g1, g2, margin, con);
-      if (n == -2) {
-        NPOut h = narrow_heavy(c.K, g1, g2, margin);
-        n = h.n; con[0] = h.c[0]; con[1] = h.c[1]; con[2] = h.c[2]; con[3] = h.c[3];
-      }
-      if (n < 0) { c.warning |= WARN_UNSUPPORTED; n = 0; }      // lane-local here; made wave-uniform below
-    }
-    c.warning = wave_or_i(c.warning);
-    int tot, off = wave_excl_scan(n, &tot);
-    if (c.ncon + tot > M.nconmax) { c.warning |= WARN_CONTACTFULL; break; }
-    for (int k = 0; k < n; k++) {
-      int ci = c.ncon + off + k;
-      double *cc = c.contact + ci * c.M->con_stride;
-      int dim;
-      contact_param(c, g1, g2, cc, &dim);
-      const NPCon cur = np_get(con, k);
-      double fr[9];
-      for (int q = 0; q < 6; q++) fr[q] = cur.frame[q];
-      d_makeframe(fr);
-      cc[CON_DIST] = cur.dist;
-      d_copy3(cc + CON_POS, cur.pos);
-      for (int q = 0; q < 9; q++) cc[CON_FRAME + q] = fr[q];
-      cc[CON_INCLUDEMARGIN] = margin - gap;
-      cc[CON_MU] = 0;
-      int *ci_ = c.con_i + ci * CONI_STRIDE;
-      ci_[0] = dim; ci_[1] = g1; ci_[2] = g2; ci_[3] = 0;
-    }
-    c.ncon += tot;
+    int st = narrow_batch<false>(c, base, nactive);
+    if (st == 1) heavy_from = base;
+    if (st != 0) break;
+  }
+  if (heavy_from >= 0) {
+    BatchOut o = narrow_rest_heavy(c.K, heavy_from, nactive, c.ncon, c.warning);
+    c.ncon = o.ncon; c.warning = o.warning;
   }
   SYNC();
 }
@@ -1125,12 +1211,21 @@ DEV void make_noncontact_rows(Ctx &c, int *nsingle_out, int *n_nc_out) {
   }
   int ntl_end = nefc;
   SYNC();
+#ifdef MJPC_AB_FRICJ
+  PFOR(e, ntl_end * nvp) c.efc_J[e] = 0;
+  SYNC();
+  PFOR(r, nlim_end) {
+    if (r < M.nfric) c.efc_J[r * nvp + c.efc_id[r]] = 1;
+    else { c.efc_J[r * nvp + MI(jnt_dofadr)[c.efc_id[r]]] = c.efc_floss[r]; c.efc_floss[r] = 0; }
+  }
+#else
   PFOR(e, (ntl_end - M.nfric) * nvp) c.efc_J[M.nfric * nvp + e] = 0;
   SYNC();
   PFOR(rr, nlim_end - M.nfric) {
     int r = M.nfric + rr;
     c.efc_J[r * nvp + MI(jnt_dofadr)[c.efc_id[r]]] = c.efc_floss[r]; c.efc_floss[r] = 0;
   }
+#endif
   PFOR(rr, ntl_end - ntl0) {
     int r = ntl0 + rr, t = c.efc_id[r];
     double sg = c.efc_floss[r];
@@ -1248,8 +1343,11 @@ DEV void make_impedance(Ctx &c, int r0, int r1, int with_contacts) {
     int r = r0 + rr;
     int type = c.efc_type[r], id = c.efc_id[r];
     double vel = 0;
+#ifndef MJPC_AB_FRICJ
     if (type == CNSTR_FRICTION_DOF) vel = c.qvel[id];      // J = unit vector of the dof (no stored row)
-    else for (int i0 = 0; i0 < nv; i0 += 9) {     // blocks of 9 loads in flight (nv = 18, 27 divide evenly), same summation order
+    else
+#endif
+    for (int i0 = 0; i0 < nv; i0 += 9) {     // blocks of 9 loads in flight (nv = 18, 27 divide evenly), same summation order
       double jj[9], qq[9];
 #pragma unroll
       for (int k = 0; k < 9; k++) { int i = i0 + k, ic = i < nv ? i : nv - 1; jj[k] = c.efc_J[r * nvp + ic]; qq[k] = c.qvel[ic]; }
@@ -1454,7 +1552,15 @@ DEV void velocity_stage(Ctx &c, int mfact_seq) {
     double ctrl = c.ctrl[i];
     if (MI(actuator_ctrllimited)[i]) ctrl = d_clip(ctrl, MD(actuator_ctrlrange)[2 * i], MD(actuator_ctrlrange)[2 * i + 1]);
     double force = MD(actuator_gainprm)[3 * i] * ctrl;
+#ifdef MJPC_AB_OLDACT
     if (MI(actuator_biastype)[i] == 1) {
+      int e = MI(act_adr)[i]; double gear = MD(act_coef)[e];
+      force += MD(actuator_biasprm)[3 * i] + MD(actuator_biasprm)[3 * i + 1] * (gear * c.qpos[MI(act_qpos)[e]]) + MD(actuator_biasprm)[3 * i + 2] * (gear * c.qvel[MI(act_dof)[e]]);
+    }
+    if (0) {
+#else
+    if (MI(actuator_biastype)[i] == 1) {
+#endif
       // transmission length / velocity: gear * qpos (joint) or sum of gear * coef * qpos over the tendon's joints
       double length = 0, velocity = 0;
       for (int e = MI(act_adr)[i]; e < MI(act_adr)[i + 1]; e++) {

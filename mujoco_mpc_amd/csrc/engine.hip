@@ -25,7 +25,18 @@
 typedef void (*RolloutFn)(const KParams);
 extern "C" RolloutFn mjpc_pick_rollout_cached(int nv, int *exact);
 extern "C" RolloutFn mjpc_pick_rollout_direct(int nv, int *exact);
+extern "C" RolloutFn mjpc_pick_rollout_dense2(int nv, int *exact);
 extern "C" int mjpc_rollout_threads_cached(void);
+
+// Capacity tiers.  One candidate per CU leaves every SIMD with a single, mostly stalled wave; two resident workgroups per CU
+// raise throughput ~1.6x once a shard has more candidates than CUs, but need <= 80 KiB of LDS each.  The dense tier gets
+// there with a smaller contact / constraint-row capacity than the model asks for; a candidate that overflows it is flagged
+// (MJPC_WARN_CONTACTFULL / CNSTRFULL) and the full-capacity kernel re-runs exactly those candidates right behind it on
+// the stream (all other workgroups of that launch exit at once).  Rollouts are deterministic and independent, so the result
+// is the same as running everything at full capacity: no candidate is lost to the smaller buffers.
+#define TIERB_NEFCMAX 92
+#define TIERB_NCONMAX 24
+#define TIERB_LDS_LIMIT (80 * 1024)
 
 // eps[r, e] for global candidate (offset + r), element e = p*nu + k; sel[r] = second-std choice
 extern "C" __global__ void noise_kernel(double *eps, int *sel, unsigned long long seed, unsigned long long stream,
@@ -125,6 +136,9 @@ struct MjpcHipEngine {
   RolloutFn kernel = nullptr; bool cached = true;
   int fault = 0;               // MJPC_HIP_FAULT_INJECT (test-suite only)
   int summary_only = 0, last_summary = 0;      // mjpc_hip_set_fetch_mode
+  int last_dense = 0;
+  // dense tier (two workgroups per CU), see "Capacity tiers" above
+  RolloutFn kernelB = nullptr; Lay layB; int nefcB = 0, nconB = 0; size_t ldsB = 0; int num_cu = 256, force_tier = 0;
 };
 
 static int upload_model(MjpcHipEngine *e) {
@@ -165,6 +179,25 @@ MjpcHipEngine *mjpc_hip_create(const MjpcHipModel *model, const MjpcHipTask *tas
       if (!mjpc_host::build(e->pm, model, task, e->P_max, false)) { set_error("mjpc_hip_create: " + e->pm.error); delete e; return nullptr; }
     }
     e->kernel = use_cache ? kc : kd;
+    // dense tier: needs a compile-time-nv kernel of that flavour, a model that asks for more capacity than the tier's and a
+    // layout of <= 80 KiB
+    int exact_b = 0;
+    RolloutFn kb = mjpc_pick_rollout_dense2(model->nv, &exact_b);
+    if (exact_b && use_cache && e->pm.M.nefcmax > TIERB_NEFCMAX && e->pm.M.nconmax >= TIERB_NCONMAX) {
+      MjpcHipModel mb = *model;
+      mb.nefcmax = TIERB_NEFCMAX; mb.nconmax = TIERB_NCONMAX;
+      if (const char *cap = getenv("MJPC_HIP_TIERB_CAP")) {       // test knob "nefcmax,nconmax": a tiny dense tier forces the retry pass
+        int a = 0, b = 0;
+        if (sscanf(cap, "%d,%d", &a, &b) == 2 && a > 0 && b > 0 && a <= TIERB_NEFCMAX && b <= TIERB_NCONMAX) { mb.nefcmax = a; mb.nconmax = b; }
+      }
+      PackedModel pmB;
+      if (mjpc_host::build(pmB, &mb, task, e->P_max, false) && (size_t)pmB.L.total_doubles * sizeof(double) <= TIERB_LDS_LIMIT) {
+        e->kernelB = kb; e->layB = pmB.L; e->nefcB = pmB.M.nefcmax; e->nconB = pmB.M.nconmax;
+        e->ldsB = (size_t)pmB.L.total_doubles * sizeof(double);
+      }
+    }
+    const char *tier = getenv("MJPC_HIP_TIER");           // test knob: "A" = never the dense tier, "B" = always (when it exists)
+    e->force_tier = tier ? (tier[0] == 'B' ? 2 : 1) : 0;
     const char *fi = getenv("MJPC_HIP_FAULT_INJECT");
     e->fault = (fi && !strcmp(fi, "sync")) ? 1 : 0;
     e->cached = use_cache;
@@ -204,6 +237,8 @@ MjpcHipEngine *mjpc_hip_create(const MjpcHipModel *model, const MjpcHipTask *tas
   HIPCHKP(hipMalloc(&e->d_winner_val, sizeof(double) * 2));
   HIPCHKP(hipHostMalloc(&e->h_small, sizeof(double) * (e->ds + 7 * e->nmocap + e->P_max * (2 * e->nu + 1) + 16)));
   HIPCHKP(hipFuncSetAttribute((const void *)e->kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_bytes));
+  if (e->kernelB) HIPCHKP(hipFuncSetAttribute((const void *)e->kernelB, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->ldsB));
+  { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) e->num_cu = prop.multiProcessorCount; }
   return e;
 }
 
@@ -318,7 +353,17 @@ int mjpc_hip_plan_async(MjpcHipEngine *e, const MjpcHipPlanInput *in) {
   K.states = e->d_states; K.actions = e->d_actions; K.times = e->d_times; K.residual = e->d_residual; K.costs = e->d_costs;
   K.trace = e->d_trace; K.knots = e->d_knots; K.returns = e->d_returns; K.failure = e->d_failure; K.diag = e->d_diag; K.prof = e->d_prof; K.frame = e->d_frame;
   HIPCHK(hipEventRecord(e->ev[1], e->stream));
+  K.retry = 0;
+  const bool dense = e->kernelB && e->force_tier != 1 && (nl > e->num_cu || e->force_tier == 2);
+  if (dense) {
+    KParams KB = K;
+    KB.M.nefcmax = e->nefcB; KB.M.nconmax = e->nconB; KB.L = e->layB; KB.cache_i = 0; KB.cache_d = 0;
+    hipLaunchKernelGGL(e->kernelB, dim3(nl), dim3(mjpc_rollout_threads_cached()), e->ldsB, e->stream, KB);
+    K.retry = 1;                       // full capacity for whoever overflowed the dense tier (usually nobody: the launch drains at once)
+  }
   hipLaunchKernelGGL(e->kernel, dim3(nl), dim3(mjpc_rollout_threads_cached()), e->lds_bytes, e->stream, K);
+  K.retry = 0;
+  e->last_dense = dense;
   HIPCHK(hipEventRecord(e->ev[2], e->stream));
   hipLaunchKernelGGL(argmin_kernel, dim3(1), dim3(64), 0, e->stream, e->d_returns, nl, e->d_winner, e->d_winner_val);
   HIPCHK(hipEventRecord(e->ev[3], e->stream));
@@ -475,6 +520,12 @@ int mjpc_hip_get_all_candidates(MjpcHipEngine *e, double *states, double *action
 }
 
 int mjpc_hip_lds_bytes(MjpcHipEngine *e) { return e ? (int)e->lds_bytes : 0; }
+// LDS bytes of the dense (two workgroups per CU) tier, 0 when the model has none; *used_last = 1 when the last plan ran on it
+int mjpc_hip_dense_tier(MjpcHipEngine *e, int *used_last) {
+  if (!e) return 0;
+  if (used_last) *used_last = e->last_dense;
+  return e->kernelB ? (int)e->ldsB : 0;
+}
 
 // host-only (no HIP call): bytes of LDS one candidate would occupy; use_cache: with / without the LDS copy of the model tables.
 // < 0: the model is refused (mjpc_hip_last_error tells why)

@@ -75,7 +75,13 @@ static inline void make_layout(const PackedModel &p, Lay &L, const MjpcHipModel 
   // efc_JA holds the scaled rows of the Newton Hessian: the active contact rows (padded to 8) + one negative row per cone
   // contact (padded to 4)
   int ja_rows = ((ne - M.nfric + 7) & ~7) + (m->cone == MJPC_CONE_ELLIPTIC ? ((nc + 3) & ~3) : 0) + 4;
-  A_(efc_J, (ne - M.nfric) * nvp + 1); A_(efc_JA, ja_rows * nvp + 1); A_(efc_D, ne); A_(efc_R, ne); A_(efc_aref, ne); A_(efc_force, ne); A_(efc_jar, ne); A_(efc_jv, ne);
+  
+#ifdef MJPC_AB_FRICJ
+  A_(efc_J, ne * nvp + 1);
+#else
+  A_(efc_J, (ne - M.nfric) * nvp + 1);
+#endif
+  A_(efc_JA, ja_rows * nvp + 1); A_(efc_D, ne); A_(efc_R, ne); A_(efc_aref, ne); A_(efc_force, ne); A_(efc_jar, ne); A_(efc_jv, ne);
   A_(efc_floss, ne); A_(efc_pos, ne);
   L.efc_margin = L.efc_jv; L.efc_diag = L.efc_force;
   A_(contact, nc * M.con_stride + 1);

@@ -126,6 +126,7 @@ struct KParams {
   double time, sigma0, sigma1;
   unsigned long long seed, stream;
   int P, interp, H, N, offset, nlocal, use_device_noise, nominal_index;
+  int retry;           // 1: re-run only the candidates whose failure[] holds a buffer-overflow bit (capacity tiers, engine.hip)
   int fault;           // test-suite fault injection (0 = none; 1 = drop one helper hand-shake, see solver.h)
   // outputs (device), row-major per local candidate
   double *states, *actions, *times, *residual, *costs, *trace, *knots, *returns;

@@ -579,6 +579,20 @@ void SamplingPlanner::CandidateKnots(int candidate, double* out) {
   std::copy(winner_knots_.begin(), winner_knots_.end(), out);
 }
 
+// trajectory[i] / candidate_policy[i] of the reference by BATCH index i (not ranked): what iLQS reads (ilqs/planner.cc:98-198)
+void SamplingPlanner::FetchCandidateUnranked(int index) { FetchCandidate(index); trajectory_winner.horizon = last_horizon_;
+  trajectory_winner.total_return = returns[index]; trajectory_winner.failure = failures[index] != 0; }
+void SamplingPlanner::CandidateKnotsUnranked(int index, double* out) {
+  FetchCandidate(index);
+  std::copy(winner_knots_.begin(), winner_knots_.end(), out);
+}
+// every candidate's trace rows of the last plan step, [num_trajectory][horizon][3 * num_trace]: SamplingPlanner::Traces
+void SamplingPlanner::AllTraces(double* out) {
+  if (mjpc_hip_multi_get_traces(engine_, out) != 0) Fatal(mjpc_hip_last_error());
+}
+
+void SetErrorHandler(void (*handler)(const char*)) { g_error_handler = handler; }
+
 // ------------------------------------------------------------------ RobustPlanner
 RobustPlanner::~RobustPlanner() { if (engine_) mjpc_hip_destroy(engine_); }
 

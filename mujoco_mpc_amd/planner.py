@@ -247,6 +247,12 @@ class HipBackend:
     def lds_bytes(self):
         return self.lib.mjpc_hip_lds_bytes(self.h)
 
+    def dense_tier(self):
+        """(LDS bytes of the two-candidates-per-CU tier or 0, whether the last plan ran on it)."""
+        used = C.c_int(0)
+        n = self.lib.mjpc_hip_dense_tier(self.h, C.byref(used))
+        return n, bool(used.value)
+
     def kernel_time(self):
         a = C.c_double(0); b = C.c_double(0)
         n = self.lib.mjpc_hip_kernel_time(self.h, C.byref(a), C.byref(b))

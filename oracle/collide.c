@@ -476,6 +476,15 @@ static int box_box(OContact *con, double margin, const double *pa, const double 
   return cnt;
 }
 
+/* squared distance from point q to the segment p +- h a */
+static double seg_point_dist2(const double *p, const double *a, double h, const double *q) {
+  double w[3];
+  o_sub3(w, q, p);
+  double x = o_clip(o_dot3(a, w), -h, h);
+  o_addtoscl3(w, a, -x);
+  return o_dot3(w, w);
+}
+
 int oracle_collide_pair(const OModel *om, OData *d, int g1, int g2, double margin, OContact *con, int *unsupported) {
   const MjpcHipModel *m = &om->m;
   int t1 = m->geom_type[g1], t2 = m->geom_type[g2];
@@ -483,6 +492,29 @@ int oracle_collide_pair(const OModel *om, OData *d, int g1, int g2, double margi
   const double *m1 = d->geom_xmat + 9 * g1, *m2 = d->geom_xmat + 9 * g2;
   const double *s1 = m->geom_size + 3 * g1, *s2 = m->geom_size + 3 * g2;
   /* pairs are stored with type1 <= type2 */
+  /* cheap conservative pre-tests for the expensive pair types ("certainly apart" is exact): the cylinder's bounding capsule,
+   * the box's bounding sphere against the capsule's segment */
+  if (t2 == MJPC_GEOM_CYLINDER && (t1 == MJPC_GEOM_SPHERE || t1 == MJPC_GEOM_CAPSULE)) {
+    OContact tmp[4];
+    int nb = t1 == MJPC_GEOM_SPHERE ? sphere_capsule(tmp, margin, p1, s1[0], p2, m2, s2) : capsule_capsule(tmp, margin, p1, m1, s1, p2, m2, s2);
+    if (nb == 0) return 0;
+  } else if (t2 == MJPC_GEOM_BOX && (t1 == MJPC_GEOM_CAPSULE || t1 == MJPC_GEOM_CYLINDER)) {
+    double a1[3] = {m1[2], m1[5], m1[8]};
+    double r = s1[0] + m->geom_rbound[g2] + margin;
+    if (seg_point_dist2(p1, a1, s1[1], p2) > r * r) return 0;
+    double dif[3], q[3], al[3];
+    o_sub3(dif, p1, p2);
+    o_mulmattvec3(q, m2, dif);
+    o_mulmattvec3(al, m2, a1);
+    double rr = s1[0] + margin;                  /* the box's three face normals as separating axes */
+    if (fabs(q[0]) - s1[1] * fabs(al[0]) > s2[0] + rr || fabs(q[1]) - s1[1] * fabs(al[1]) > s2[1] + rr ||
+        fabs(q[2]) - s1[1] * fabs(al[2]) > s2[2] + rr) return 0;
+    /* ... and the three axes  segment direction x box axis */
+    double l0 = sqrt(al[1] * al[1] + al[2] * al[2]), l1 = sqrt(al[0] * al[0] + al[2] * al[2]), l2 = sqrt(al[0] * al[0] + al[1] * al[1]);
+    if (fabs(q[2] * al[1] - q[1] * al[2]) > s2[1] * fabs(al[2]) + s2[2] * fabs(al[1]) + rr * l0) return 0;
+    if (fabs(q[0] * al[2] - q[2] * al[0]) > s2[0] * fabs(al[2]) + s2[2] * fabs(al[0]) + rr * l1) return 0;
+    if (fabs(q[1] * al[0] - q[0] * al[1]) > s2[0] * fabs(al[1]) + s2[1] * fabs(al[0]) + rr * l2) return 0;
+  }
   if (t1 == MJPC_GEOM_PLANE) {
     double n[3] = {m1[2], m1[5], m1[8]};
     switch (t2) {

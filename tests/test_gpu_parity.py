@@ -789,3 +789,37 @@ def test_cpp_sampling_planner_sharded_over_engines_matches_the_unsharded_planner
     assert [pl[0].CandidateScore(k) for k in range(5)] == [pl[1].CandidateScore(k) for k in range(5)]
     for p in pl:
         p.close()
+
+
+@pytest.mark.gpu
+def test_dense_tier_is_bit_identical_to_full_capacity_and_retries_what_overflows(monkeypatch):
+    """Capacity tiers (engine.hip): more candidates than CUs -> the two-workgroups-per-CU flavour (<= 80 KiB of LDS, smaller
+    contact / row buffers) runs first and the full-capacity kernel re-runs whatever overflowed.  Returns, failure flags, winner
+    and every trajectory must equal the full-capacity-only plan bit for bit - also when the dense tier is made so small
+    (test knob) that most candidates overflow it and take the retry pass."""
+    m, task, d = quadruped()
+    N, H, P = 300, 40, 3
+    kt = np.linspace(0, (H - 1) * m["timestep"], P); kv = np.zeros((P, m["nu"]))
+    kw = dict(state=d["state"], mocap=d["mocap"], time=0.0, knot_times=kt, knot_values=kv, interpolation=2, num_trajectory=N,
+              horizon=H, sigma=(0.04, 0.0), seed=0x5EED, stream=7)
+    res = {}
+    for name, env in (("full", {"MJPC_HIP_TIER": "A"}), ("auto", {}), ("tiny", {"MJPC_HIP_TIERB_CAP": "40,8"})):
+        for k in ("MJPC_HIP_TIER", "MJPC_HIP_TIERB_CAP"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        be = HipBackend(m, task, max_samples=N, max_horizon=H)
+        out = be.plan(**kw)
+        lds, used = be.dense_tier()
+        res[name] = (out, be.fetch_all(N, H, P), lds, used)
+        be.close()
+    assert res["full"][3] is False and res["auto"][3] is True and res["tiny"][3] is True
+    assert 0 < res["auto"][2] <= 80 * 1024
+    assert not res["full"][0]["failure"].any()
+    assert res["full"][1]["diag"][:, 2].max() > 40              # rows per step exceed the tiny tier: its candidates were retried
+    for name in ("auto", "tiny"):
+        a, b = res["full"], res[name]
+        assert np.array_equal(a[0]["returns"], b[0]["returns"]) and np.array_equal(a[0]["failure"], b[0]["failure"])
+        assert a[0]["winner"] == b[0]["winner"]
+        for k in ("states", "actions", "times", "residual", "costs", "trace", "knots"):
+            assert np.array_equal(a[1][k], b[1][k]), (name, k)

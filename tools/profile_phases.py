@@ -6,8 +6,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.ins
 CSRC = os.path.join(ROOT, "mujoco_mpc_amd", "csrc")
 so = os.path.join(ROOT, "gpurun_out", "libmjpc_hip_prof.so")
 os.makedirs(os.path.dirname(so), exist_ok=True)
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DMJPC_PROFILE=1"] + (["-DMJPC_WAVES=1"] if os.environ.get("PROFILE_ONE_WAVE") else []) + ([f"-DMJPC_PROFILE_WAVE={int(os.environ['PROFILE_WAVE'])}"] if os.environ.get("PROFILE_WAVE") else []) + [
-                       "-Wno-unused-value", "-o", so, os.path.join(CSRC, "engine.hip")])
+flags = ["-DMJPC_PROFILE=1"] + (["-DMJPC_WAVES=1"] if os.environ.get("PROFILE_ONE_WAVE") else []) + \
+        ([f"-DMJPC_PROFILE_WAVE={int(os.environ['PROFILE_WAVE'])}"] if os.environ.get("PROFILE_WAVE") else [])
+objs, jobs = [], []
+for f in sorted(os.listdir(CSRC)):
+    if f == "engine.hip" or (f.startswith("rollout_") and f.endswith(".hip")):
+        o = os.path.join(ROOT, "gpurun_out", "prof_" + f[:-4] + ".o"); objs.append(o)
+        jobs.append(subprocess.Popen(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-value",
+                                      "-Wno-unused-result"] + flags + ["-c", "-o", o, os.path.join(CSRC, f)], cwd=CSRC))
+for j in jobs:
+    assert j.wait() == 0
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc", "-o", so] + objs +
+                      [os.path.join(CSRC, "_obj", x) for x in ("planner.o", "testspeed.o", "multi.o")] + ["-lpthread"])
 from mujoco_mpc_amd import capi
 capi.ENGINE_PATH = so
 from mujoco_mpc_amd.modelgen import quadruped, humanoid_track

@@ -74,48 +74,48 @@ DEV void chol_solve_lds(const double *L, const double *Linv, double *x, int n, i
 template <int N>
 struct LDLRegs { double lo[N], up[N], rinv; };
 
+template <int I, int E, class F>
+DEV void static_for(F &&f) {
+  if constexpr (I < E) { f(std::integral_constant<int, I>{}); static_for<I + 1, E>(f); }
+}
+// every index below is a compile-time constant (static_for, not `#pragma unroll`: with N = 33 the nested pragma loops exceeded
+// the unroller's budget, the row array stayed in scratch memory and the kernel wrote gigabytes of spills per launch)
 template <int N>
 DEV void ldl_factor_regs(const double *A, int nvp, LDLRegs<N> &f) {
   static_assert(N >= 1 && N <= 64, "one matrix row per lane");
   const int i = LANE;
   const bool act = i < N;
   double a[N];
-#pragma unroll
-  for (int j = 0; j < N; j++) a[j] = act ? A[(j <= i) ? i * nvp + j : j * nvp + i] : 0.0;   // lower triangle is valid in LDS
+  static_for<0, N>([&](auto jc) { constexpr int j = decltype(jc)::value; a[j] = act ? A[(j <= i) ? i * nvp + j : j * nvp + i] : 0.0; });   // lower triangle is valid in LDS
   double dg = act ? A[i * nvp + i] : 1.0;
-#pragma unroll
-  for (int k = N - 1; k >= 1; k--) {
+  static_for<1, N>([&](auto kc) {
+    constexpr int k = N - decltype(kc)::value;                                 // N-1 ... 1
     double rk = readlane_d(fast_rcp(dg < D_MINVAL ? D_MINVAL : dg), k);      // reciprocal in the vector domain, then broadcast
     double hk = a[k];
     double l = (i < k) ? hk * rk : 0.0;
     dg -= l * hk;
     // A[i][j] -= L[k][i] * A[k][j]: broadcast row k in groups of 8 first, then the FMAs, so that the SGPR written by a
     // v_readlane is not consumed by the very next VALU instruction (that hazard costs an s_nop per update otherwise)
-#pragma unroll
-    for (int j0 = 0; j0 < k; j0 += 8) {
+    static_for<0, (k + 7) / 8>([&](auto gc) {
+      constexpr int j0 = decltype(gc)::value * 8;
       double sj[8];
-#pragma unroll
-      for (int q = 0; q < 8; q++) if (j0 + q < k) sj[q] = readlane_d(a[j0 + q], k);
+      static_for<0, 8>([&](auto qc) { constexpr int q = decltype(qc)::value; if constexpr (j0 + q < k) sj[q] = readlane_d(a[j0 + q], k); });
       __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int q = 0; q < 8; q++) if (j0 + q < k) a[j0 + q] -= l * sj[q];
+      static_for<0, 8>([&](auto qc) { constexpr int q = decltype(qc)::value; if constexpr (j0 + q < k) a[j0 + q] -= l * sj[q]; });
       __builtin_amdgcn_sched_barrier(0);
-    }
+    });
     f.up[k] = l;
-  }
+  });
   f.up[0] = 0.0;
   if (dg < D_MINVAL) dg = D_MINVAL;
   f.rinv = fast_rcp(dg);
-#pragma unroll
-  for (int j = 0; j < N; j++) f.lo[j] = (act && j < i) ? a[j] * f.rinv : 0.0;
+  static_for<0, N>([&](auto jc) { constexpr int j = decltype(jc)::value; f.lo[j] = (act && j < i) ? a[j] * f.rinv : 0.0; });
 }
 template <int N>
 DEV double ldl_solve_regs(const LDLRegs<N> &f, double xi) {
-#pragma unroll
-  for (int k = N - 1; k >= 1; k--) xi -= f.up[k] * readlane_d(xi, k);      // L^T u = b
-  xi *= f.rinv;                                                            // D v = u
-#pragma unroll
-  for (int j = 0; j < N - 1; j++) xi -= f.lo[j] * readlane_d(xi, j);       // L x = v
+  static_for<1, N>([&](auto kc) { constexpr int k = N - decltype(kc)::value; xi -= f.up[k] * readlane_d(xi, k); });      // L^T u = b
+  xi *= f.rinv;                                                                                                          // D v = u
+  static_for<0, N - 1>([&](auto jc) { constexpr int j = decltype(jc)::value; xi -= f.lo[j] * readlane_d(xi, j); });      // L x = v
   return xi;
 }
 // ---- tree-structured elimination (DofTree<N>::known, DevModel::tree_ok) ----------------------------------------------
@@ -123,10 +123,6 @@ DEV double ldl_solve_regs(const LDLRegs<N> &f, double xi) {
 // related to each other) are processed together, so their reciprocal chains and trailing updates are independent work
 // the scheduler interleaves, and (b) only the ancestors of a pivot are updated: the other columns of M's pattern are
 // structural zeros.  Cross-branch contacts break the pattern of H; the caller then asks for the dense order.
-template <int I, int E, class F>
-DEV void static_for(F &&f) {
-  if constexpr (I < E) { f(std::integral_constant<int, I>{}); static_for<I + 1, E>(f); }
-}
 template <int N> constexpr int tree_depth(int k) { int d = 0; for (int a = DofTree<N>::parent(k); a >= 0; a = DofTree<N>::parent(a)) d++; return d; }
 template <int N> constexpr int tree_nth_anc(int k, int n) { int a = DofTree<N>::parent(k); for (int q = 0; q < n; q++) a = DofTree<N>::parent(a); return a; }
 template <int N> constexpr int tree_height(int k) {
@@ -242,8 +238,7 @@ DEV void chol_factor_reg(double *A, double *Dinv, int nvp, int tree) {
   LDLRegs<N> f;
   ldl_factor_any<N>(A, nvp, f, tree);
   const int i = LANE;
-#pragma unroll
-  for (int j = 0; j < N; j++) if (i < N && j < i) A[i * nvp + j] = f.lo[j];
+  static_for<0, N>([&](auto jc) { constexpr int j = decltype(jc)::value; if (i < N && j < i) A[i * nvp + j] = f.lo[j]; });
   if (i < N) Dinv[i] = f.rinv;
   SYNC();
 }
@@ -254,11 +249,11 @@ DEV void chol_solve_reg(const double *L, const double *Dinv, double *x, int nvp,
   const bool act = i < N;
   LDLRegs<N> f;
   f.rinv = act ? Dinv[i] : 0.0;
-#pragma unroll
-  for (int k = 0; k < N; k++) {
+  static_for<0, N>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
     f.lo[k] = (act && k < i) ? L[i * nvp + k] : 0.0;
     f.up[k] = (act && k > i) ? L[k * nvp + i] : 0.0;
-  }
+  });
   double xi = ldl_solve_any<N>(f, act ? x[i] : 0.0, tree);
   if (act) x[i] = xi;
   SYNC();

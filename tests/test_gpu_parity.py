@@ -241,6 +241,62 @@ def test_cpp_host_planner_matches_python_mirror_bitwise(sliding, interp):
     py.backend.close(); cpp.close()
 
 
+@pytest.mark.parametrize("interp", [0, 1, 2])
+def test_update_nominal_policy_against_closed_forms(interp):
+    """a2 (sampling/planner.cc:283-309) checked WITHOUT the Python mirror: after a plan step the policy is the winner's
+    spline on known knots; the next resampling must give
+      * knot times  t0, t0 + s, (t0 + s) + s, ...  by repeated addition with s = max((H-1) dt / (P or P-1), 1e-5)   (:285-302)
+      * with t0 unchanged: exactly the old knot values (every interpolation passes through its knots)
+      * with t0 advanced by one knot interval: old knot k+1 in slot k, the last value held                      (spline.cc:114-123)
+      * with t0 advanced by half an interval: zero-order -> the lower knot, linear -> the arithmetic mean formula
+        lo*(1-t) + hi*t of spline.cc, evaluated here in numpy."""
+    from mujoco_mpc_amd import cplanner
+    m, task, d = particle(timestep=0.1)
+    H, N, P = 21, 8, 5
+    num = dict(sampling_spline_points=P, sampling_exploration=[0.4, 0.0], sampling_trajectories=N, sampling_representation=interp)
+    pl = cplanner.SamplingPlanner()
+    pl.Initialize(m, task, num, max_samples=N, max_horizon=H)
+    pl.Reset(H); pl.set_seed(99, 0)
+    state = np.array([0.1, -0.1, 0.0, 0.0])
+    t0 = 0.7
+    pl.SetState(state, d["mocap"], None, t0)
+    pl.OptimizePolicy(H)                                   # policy := the winning candidate's spline
+    kt0, kv0 = pl.policy_knots()
+    s = max((H - 1) * m["timestep"] / (P if interp == 0 else P - 1), 1e-5)
+    want = [t0]
+    for _ in range(P - 1):
+        want.append(want[-1] + s)                           # repeated addition, not t0 + k * s
+    assert np.array_equal(kt0, np.array(want))
+    assert np.abs(kv0).max() > 0 and np.all(np.abs(kv0) <= 1.0)
+    pl.set_num_trajectory(1)                                # only the nominal from here on: the policy is what resampling makes it
+
+    def resample(t):
+        pl.SetState(state, d["mocap"], None, t)
+        pl.OptimizePolicy(H)
+        return pl.policy_knots()
+
+    kt1, kv1 = resample(t0)
+    assert np.array_equal(kt1, kt0) and np.array_equal(kv1, kv0)
+    kt2, kv2 = resample(kt1[1])                             # one knot interval later
+    assert kt2[0] == kt1[1]
+    assert np.array_equal(kv2[:-1], kv1[1:]) and np.array_equal(kv2[-1], kv1[-1])
+    if interp < 2:
+        th = kt2[0] + 0.5 * (kt2[1] - kt2[0])
+        kt3, kv3 = resample(th)
+        for k in range(P):
+            tk = kt3[k]
+            up = int(np.searchsorted(kt2, tk, side="right"))            # std::upper_bound
+            if up >= P:
+                expect = kv2[-1]
+            elif interp == 0:
+                expect = kv2[up - 1]
+            else:
+                tau = (tk - kt2[up - 1]) / (kt2[up] - kt2[up - 1])
+                expect = kv2[up - 1] * (1 - tau) + kv2[up] * tau
+            assert np.array_equal(kv3[k], np.clip(expect, -1.0, 1.0)), (k, kv3[k], expect)
+    pl.close()
+
+
 def test_cpp_host_planner_rejects_too_many_trajectories():
     """planner.cc:69-72: mju_error when sampling_trajectories exceeds the maximum."""
     from mujoco_mpc_amd import cplanner

@@ -319,3 +319,119 @@ def test_humanoid_stand_and_walk_residuals_at_the_upright_pose():
     standing = th / np.sqrt(th * th + 0.45 * 0.45) - 0.4
     assert abs(r[33] - standing * (0.0 - 0.5)) < 1e-12                    # at rest: speed error = -speed goal
     assert np.all(np.abs(r[34:36]) < 1e-12) and np.all(r[36:57] == -0.5)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# colliders of round 2 (capsule-box, box-box, sphere-cylinder, capsule-cylinder): closed-form placements and properties
+# ---------------------------------------------------------------------------------------------------------------------
+def _collide(t1, s1, p1, m1, t2, s2, p2, m2, margin=0.0):
+    import ctypes as C
+    L = ol.lib()
+    dp = C.POINTER(C.c_double)
+    L.oracle_debug_collide.argtypes = [C.c_int, dp, dp, dp, C.c_int, dp, dp, dp, C.c_double, dp]
+    a = [np.ascontiguousarray(x, float).ravel() for x in (list(s1) + [0.0] * (3 - len(s1)), p1, m1, list(s2) + [0.0] * (3 - len(s2)), p2, m2)]
+    out = np.zeros(56)
+    n = L.oracle_debug_collide(t1, *[x.ctypes.data_as(dp) for x in a[:3]], t2, *[x.ctypes.data_as(dp) for x in a[3:]], margin, out.ctypes.data_as(dp))
+    return out[:7 * max(n, 0)].reshape(max(n, 0), 7), n
+
+
+def _rot(axis, ang):
+    c, s = np.cos(ang), np.sin(ang)
+    return {"x": np.array([[1, 0, 0], [0, c, -s], [0, s, c]]), "y": np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]]),
+            "z": np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]])}[axis]
+
+
+def test_box_box_face_edge_and_corner_cases():
+    """box-box (own construction, oracle/collide.c): a cube resting on a large face gives its four bottom corners at the
+    penetration depth with the face normal; rotating it in the plane keeps four contacts; a cube overhanging a smaller box is
+    clipped to that box's face; crossed edges give one contact at the crossing; a corner-down cube one contact."""
+    I = np.eye(3)
+    big, cube, pen = [0.5, 0.5, 0.1], [0.022] * 3, 1e-3
+    c, n = _collide(6, big, [0, 0, 0], I, 6, cube, [0.1, 0.05, 0.1 + 0.022 - pen], I)
+    assert n == 4 and np.allclose(c[:, 0], -pen) and np.allclose(c[:, 4:], [0, 0, 1]) and np.allclose(c[:, 3], 0.1 - pen / 2)
+    assert sorted(map(tuple, np.round(c[:, 1:3], 6))) == sorted([(0.078, 0.028), (0.078, 0.072), (0.122, 0.028), (0.122, 0.072)])
+    c, n = _collide(6, big, [0, 0, 0], I, 6, cube, [0.1, 0.05, 0.1 + 0.022 - pen], _rot("z", np.pi / 4))
+    assert n == 4 and np.allclose(c[:, 0], -pen)
+    assert np.allclose(sorted(np.hypot(c[:, 1] - 0.1, c[:, 2] - 0.05)), [0.022 * np.sqrt(2)] * 4)
+    c, n = _collide(6, [0.01, 0.01, 0.01], [0, 0, 0], I, 6, [0.05] * 3, [0, 0, 0.01 + 0.05 - pen], _rot("z", 0.3))
+    assert n == 4 and np.allclose(np.abs(c[:, 1:3]), 0.01) and np.allclose(c[:, 0], -pen)        # clipped to the small box's face
+    c, n = _collide(6, [0.05] * 3, [0, 0, 0], _rot("x", np.pi / 4), 6, [0.05] * 3, [0, 0, 2 * 0.05 * np.sqrt(2) - 2e-3],
+                    _rot("y", np.pi / 4) @ _rot("z", np.pi / 2))
+    assert n == 1 and abs(c[0, 0] + 2e-3) < 1e-12 and np.allclose(c[0, 1:3], 0, atol=1e-12) and np.allclose(np.abs(c[0, 4:]), [0, 0, 1])
+    c, n = _collide(6, big, [0, 0, 0], I, 6, cube, [0, 0, 0.1 + 0.022 * np.sqrt(3) - pen], _rot("x", np.arctan(np.sqrt(2))) @ _rot("z", np.pi / 4))
+    assert n == 1 and abs(c[0, 0] + pen) < 1e-9 and np.allclose(c[0, 1:3], 0, atol=1e-9)
+    _, n = _collide(6, big, [0, 0, 0], I, 6, cube, [0.1, 0.05, 0.1 + 0.022 + 1e-4], I)
+    assert n == 0                                                                                    # separated: no contact
+    c, n = _collide(6, big, [0, 0, 0], I, 6, cube, [0.1, 0.05, 0.1 + 0.022 + 1e-4], I, margin=1e-3)
+    assert n == 4 and np.allclose(c[:, 0], 1e-4)                                                     # inside the margin: positive distance
+
+
+def test_capsule_box_and_cylinder_colliders():
+    I = np.eye(3)
+    pen = 1e-3
+    c, n = _collide(3, [0.01, 0.03], [0, 0, 0.1 + 0.01 - pen], _rot("y", np.pi / 2), 6, [0.5, 0.5, 0.1], [0, 0, 0], I)
+    assert n == 2 and np.allclose(c[:, 0], -pen) and np.allclose(sorted(c[:, 1]), [-0.03, 0.03]) and np.allclose(c[:, 4:], [0, 0, -1])
+    c, n = _collide(3, [0.01, 0.03], [0, 0, 0.1 + 0.04 - pen], I, 6, [0.5, 0.5, 0.1], [0, 0, 0], I)
+    assert n == 1 and abs(c[0, 0] + pen) < 1e-12                                                     # poking: one contact
+    c, n = _collide(2, [0.05], [0.01, 0, 0.04 + 0.05 - pen], I, 5, [0.04, 0.04], [0, 0, 0], I)
+    assert n == 1 and abs(c[0, 0] + pen) < 1e-12 and np.allclose(c[0, 4:], [0, 0, -1])              # sphere on the cap
+    c, n = _collide(2, [0.05], [0.04 + 0.05 - 2e-3, 0, 0.01], I, 5, [0.04, 0.04], [0, 0, 0], I)
+    assert n == 1 and abs(c[0, 0] + 2e-3) < 1e-12 and np.allclose(c[0, 4:], [-1, 0, 0])             # on the lateral surface
+    c, n = _collide(2, [0.05], [0.07, 0, 0.07], I, 5, [0.04, 0.04], [0, 0, 0], I)
+    assert n == 1 and abs(c[0, 0] - (np.hypot(0.03, 0.03) - 0.05)) < 1e-12                           # on the rim
+    c, n = _collide(3, [0.01, 0.03], [0, 0, 0.04 + 0.01 - pen], _rot("y", np.pi / 2), 5, [0.04, 0.04], [0, 0, 0], I)
+    assert n == 2 and np.allclose(c[:, 0], -pen)                                                     # capsule lying on the cap
+
+
+def test_conservative_pretests_never_drop_a_true_contact():
+    """The cheap separations in front of the expensive colliders (bounding capsule / sphere, box face and cross axes) must be
+    exact in the 'apart' direction: a two-body model goes through the full pair path (with pre-tests) and must report the same
+    number of contacts as the bare collider on random configurations."""
+    from mujoco_mpc_amd.modelgen.builder import BOX, CAPSULE, CYLINDER, FREE, SPHERE, ModelBuilder
+    from mujoco_mpc_amd.modelgen.tasks import make_task
+    rng = np.random.default_rng(0)
+
+    def q2m(q):
+        w, x, y, z = q
+        return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)], [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                         [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+    for t1, s1, t2, s2 in ((CAPSULE, (0.02, 0.08), BOX, (0.1, 0.06, 0.04)), (CAPSULE, (0.02, 0.08), CYLINDER, (0.05, 0.04)),
+                           (SPHERE, (0.03,), CYLINDER, (0.05, 0.04)), (BOX, (0.05, 0.03, 0.02), BOX, (0.1, 0.06, 0.04))):
+        b = ModelBuilder()
+        a = b.body("a", 0); b.joint(a, "fa", FREE); b.geom(a, "g1", t1, size=s1)
+        c = b.body("c", 0); b.joint(c, "fc", FREE); b.geom(c, "g2", t2, size=s2)
+        m = b.compile()
+        o = ol.Oracle(m, make_task(3, [(26, 0, 1.0)]))
+        hits = 0
+        for _ in range(1500):
+            qa, qb = rng.normal(size=4), rng.normal(size=4)
+            qa /= np.linalg.norm(qa); qb /= np.linalg.norm(qb)
+            p1 = rng.uniform(-0.18, 0.18, 3)
+            _, n = _collide(t1, s1, p1, q2m(qa), t2, s2, np.zeros(3), q2m(qb))
+            f = o.forward(np.concatenate([p1, qa, np.zeros(3), qb]))
+            assert f["ncon"] == n and f["unsupported"] == 0
+            hits += n > 0
+        assert hits > 50                                     # the sample really contains contacts
+
+
+def test_cube_comes_to_rest_on_a_box_and_in_the_synthetic_hand():
+    """box-box in the dynamics: a free cube dropped on a welded box settles on its top face (height = box top + half size, no
+    drift); the synthetic Shadow hand holding its grasp targets keeps the cube above the palm instead of dropping it to the floor."""
+    from mujoco_mpc_amd.modelgen.builder import BOX, FREE, PLANE, ModelBuilder
+    from mujoco_mpc_amd.modelgen.tasks import make_task
+    b = ModelBuilder(timestep=0.005)
+    b.geom(0, "floor", PLANE, size=(1, 1, 0.1))
+    b.geom(0, "table", BOX, size=(0.2, 0.2, 0.05), pos=(0, 0, 0.05))
+    c = b.body("cube", 0, pos=(0.03, -0.02, 0.13))
+    b.joint(c, "f", FREE)
+    b.geom(c, "cube", BOX, size=(0.022, 0.022, 0.022), mass=0.126)
+    m = b.compile()
+    o = ol.Oracle(m, make_task(3, [(13, 0, 1.0)]))
+    q = np.array([0.03, -0.02, 0.13, np.cos(0.2), 0, 0, np.sin(0.2)]); v = np.zeros(6)
+    q, v, _, _, w = o.step(q, v, nstep=400)
+    assert w == 0 and abs(q[2] - (0.1 + 0.022)) < 1e-3 and np.abs(v).max() < 1e-3 and abs(q[0] - 0.03) < 1e-3
+    from mujoco_mpc_amd.modelgen import shadow_hand
+    m, task, d = shadow_hand()
+    o = ol.Oracle(m, task)
+    q, v, _, _, w = o.step(d["state"][:35], np.zeros(33), ctrl=d["ctrl0"], nstep=150)
+    assert w == 0 and q[6] > -0.02 and np.abs(v).max() < 0.2        # the cube (qpos[4:7]) stays in the hand; the floor is at -0.2

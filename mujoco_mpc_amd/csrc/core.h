@@ -103,7 +103,13 @@ DEV void ctx_init(Ctx &c, const KParams *K, double *base) {
   P_(efc_JA); P_(efc_D); P_(efc_R); P_(efc_aref); P_(efc_force); P_(efc_jar); P_(efc_jv); P_(efc_floss);
   P_(efc_pos); P_(efc_margin); P_(efc_diag); P_(contact);
   P_(Ma); P_(grad); P_(Mgrad); P_(search); P_(Mv); P_(vtmp); P_(sgl);
-  P_(knot_times); P_(knot_values); P_(residual); P_(terms); P_(red); P_(xfrc);
+#ifdef MJPC_LEAN_LDS      // dense tier: the spline knots stay in HBM / L2 (the nominal's times; this candidate's values, written by ph_init)
+  c.knot_times = const_cast<double *>(K->knot_times);
+  c.knot_values = K->knots + (size_t)cand_index() * K->P * K->M.nu;
+#else
+  P_(knot_times); P_(knot_values);
+#endif
+  P_(residual); P_(terms); P_(red); P_(xfrc);
 #undef P_
   int *ib = (int *)(base + L.ints);
   c.efc_type = ib + L.i_efc_type; c.efc_id = ib + L.i_efc_id; c.efc_state = ib + L.i_efc_state; c.efc_dof = ib + L.i_efc_dof;
@@ -2100,7 +2106,9 @@ DEV_NOINLINE void ph_init(KP Kc) {
   Rows R = out_rows(K);
   int nq = M.nq, nv = M.nv, nu = M.nu, P = K->P, r = cand_index();
   int gi = K->offset + r;
+#ifndef MJPC_LEAN_LDS
   PFOR(p, P) c.knot_times[p] = K->knot_times[p];
+#endif
   double std = K->sigma0;
   if (K->sigma1 > 0 && K->noise_sel[r]) std = K->sigma1;
   PFOR(e, P * nu) {
@@ -2123,7 +2131,9 @@ DEV_NOINLINE void ph_init(KP Kc) {
   PFOR(i, nq) { c.qpos[i] = K->state[i]; R.states[i] = K->state[i]; }
   PFOR(i, nv) { c.qvel[i] = K->state[nq + i]; R.states[nq + i] = K->state[nq + i]; c.qacc_ws[i] = 0; }
   PFOR(e, nv * M.nvp) { c.qM[e] = 0; c.qH[e] = 0; }
+#ifndef MJPC_LEAN_LDS
   PFOR(e, M.nmpair + nv) c.hpair[e] = MI(mpair_i)[e] | (MI(mpair_j)[e] << 8);
+#endif
   PFOR(k, 6 * M.nbody) c.xfrc[k] = 0;
   PFOR(k, nu) c.ctrl[k] = 0;      // data->ctrl after Reset (planner.cc:124-130); only visible when H == 1
   if (LANE == 0) {
@@ -2333,10 +2343,29 @@ DEV_NOINLINE void ph_integrate(KP Kc, int t) {
   ctx_close(c);
 }
 
-DEV_NOINLINE void ph_finish(KP Kc, double total, int failure) {        // role 1 (it holds the cost sum)
+// checkpoint layout (doubles): [0] valid, [1] step, [2] time, [3] cost sum before that step, [4..6] diag counters, then qpos, qvel,
+// qacc_warmstart
+#define CKPT_HEAD 7
+DEV_NOINLINE void ph_finish(KP Kc, double total, int failure, int t_fail, double total_before) {        // role 1 (it holds the cost sum)
   Ctx c; ctx_open(c, Kc, 1);
   const KParams *K = c.K;
   int r = cand_index(), H = K->H;
+  if (K->tier > 0 && K->ckpt) {
+    // dense tier: a candidate stopped by a full contact / row buffer hands its state at the failing step to the retry launch
+    // (positions and velocities are those the failing step started from: integration had not happened; not with force noise,
+    // whose Ornstein-Uhlenbeck state was already advanced)
+    double *ck = K->ckpt + (size_t)r * K->ckpt_stride;
+    const DevModel &M = *c.M;
+    int resumable = failure && (c.warning & (WARN_CONTACTFULL | WARN_CNSTRFULL)) && !(c.warning & ~(WARN_CONTACTFULL | WARN_CNSTRFULL)) && !(K->xfrc_std > 0);
+    if (LANE == 0) {
+      ck[0] = resumable ? 1.0 : 0.0; ck[1] = (double)t_fail; ck[2] = c.time; ck[3] = total_before;
+      ck[4] = (double)c.misc[5]; ck[5] = (double)c.misc[6]; ck[6] = (double)c.misc[7];
+    }
+    if (resumable) {
+      PFOR(i, M.nq) ck[CKPT_HEAD + i] = c.qpos[i];
+      PFOR(i, M.nv) { ck[CKPT_HEAD + M.nq + i] = c.qvel[i]; ck[CKPT_HEAD + M.nq + M.nv + i] = c.qacc_ws[i]; }
+    }
+  }
   if (LANE == 0) {
     K->returns[r] = failure ? 1.0e6 : total / (H > 1 ? H : 1);
     K->failure[r] = failure ? (c.warning ? c.warning : 1) : 0;
@@ -2345,6 +2374,19 @@ DEV_NOINLINE void ph_finish(KP Kc, double total, int failure) {        // role 1
 #endif
     if (K->diag) { K->diag[4 * r] = c.misc[5]; K->diag[4 * r + 1] = c.misc[6]; K->diag[4 * r + 2] = c.misc[7]; K->diag[4 * r + 3] = c.warning; }
   }
+}
+
+// owner wave, retry launch: state of the checkpointed step into LDS (everything else was set up by ph_init)
+DEV_NOINLINE void ph_resume(KP Kc) {
+  Ctx c; ctx_open(c, Kc);
+  const KParams *K = c.K;
+  const DevModel &M = *c.M;
+  const double *ck = K->ckpt + (size_t)cand_index() * K->ckpt_stride;
+  PFOR(i, M.nq) c.qpos[i] = ck[CKPT_HEAD + i];
+  PFOR(i, M.nv) { c.qvel[i] = ck[CKPT_HEAD + M.nq + i]; c.qacc_ws[i] = ck[CKPT_HEAD + M.nq + M.nv + i]; }
+  if (LANE == 0) { c.misc[5] = (int)ck[4]; c.misc[6] = (int)ck[5]; c.misc[7] = (int)ck[6]; }
+  c.time = ck[2];
+  ctx_close(c);
 }
 
 // ======================================================================================
@@ -2357,16 +2399,26 @@ DEV void rollout(KP Kc) {
   if (r0) ph_init(Kc);
   XBAR();
   const int *misc = (const int *)(lds_base() + Kc->L.ints) + Kc->L.i_misc;
-  double total = 0;
-  int failure = 0;
+  double total = 0, total_before = 0;
+  int failure = 0, t0 = 0, t_fail = 0;
+  if (Kc->retry && Kc->ckpt) {
+    // retry launch of the capacity tiers: pick the candidate up at the step where the dense tier ran out of room
+    const double *ck = Kc->ckpt + (size_t)cand_index() * Kc->ckpt_stride;
+    if (ck[0] != 0.0) {
+      t0 = (int)ck[1]; total = ck[3];
+      if (r0) ph_resume(Kc);
+      XBAR();
+    }
+  }
 #if defined(MJPC_PROFILE) && !defined(MJPC_EMU)
   long long *rprof = (long long *)(lds_base() + Kc->L.prof);
 #define RPROF(i) do { if (LANE == 0 && WAVE_ID() == MJPC_PROFILE_WAVE) PROF_STAMP(rprof, i); } while (0)
 #else
 #define RPROF(i) ((void)0)
 #endif
-  for (int t = 0; t < H; t++) {
+  for (int t = t0; t < H; t++) {
     int last = (t == H - 1);
+    t_fail = t; total_before = total;
     if (r0) ph_head<NVT>(Kc, t, last);
     XBAR(); RPROF(2);
     if (uniform_i(misc[10])) { failure = 1; break; }
@@ -2387,5 +2439,5 @@ DEV void rollout(KP Kc) {
     if (r0 && !last) ph_integrate<NVT>(Kc, t);
   }
   XBAR();
-  if (r1) ph_finish(Kc, total, failure);
+  if (r1) ph_finish(Kc, total, failure, t_fail, total_before);
 }

@@ -30,12 +30,12 @@ extern "C" int mjpc_rollout_threads_cached(void);
 
 // Capacity tiers.  One candidate per CU leaves every SIMD with a single, mostly stalled wave; two resident workgroups per CU
 // raise throughput ~1.6x once a shard has more candidates than CUs, but need <= 80 KiB of LDS each.  The dense tier gets
-// there with a smaller contact / constraint-row capacity than the model asks for; a candidate that overflows it is flagged
+// there with a smaller contact / constraint-row capacity than the model asks for (and, to afford 100 rows / 28 contacts, reads the spline knots and the Hessian entry table from L2); a candidate that overflows it is flagged
 // (MJPC_WARN_CONTACTFULL / CNSTRFULL) and the full-capacity kernel re-runs exactly those candidates right behind it on
 // the stream (all other workgroups of that launch exit at once).  Rollouts are deterministic and independent, so the result
 // is the same as running everything at full capacity: no candidate is lost to the smaller buffers.
-#define TIERB_NEFCMAX 92
-#define TIERB_NCONMAX 24
+#define TIERB_NEFCMAX 100
+#define TIERB_NCONMAX 28
 #define TIERB_LDS_LIMIT (80 * 1024)
 
 // eps[r, e] for global candidate (offset + r), element e = p*nu + k; sel[r] = second-std choice
@@ -124,6 +124,7 @@ struct MjpcHipEngine {
   int *d_failure = nullptr, *d_diag = nullptr, *d_winner = nullptr;
   long long *d_prof = nullptr;
   double *d_frame = nullptr; int nbody = 0, nsite = 0;
+  double *d_ckpt = nullptr; int ckpt_stride = 0;          // dense-tier checkpoints for the retry launch
   // pinned host staging
   double *d_pack = nullptr, *h_pack = nullptr; size_t pack_cap = 0;   // packed plan result (device / pinned host)
   double *h_small = nullptr;   // state | mocap | knot_times | knot_values | noise_std
@@ -191,7 +192,7 @@ MjpcHipEngine *mjpc_hip_create(const MjpcHipModel *model, const MjpcHipTask *tas
         if (sscanf(cap, "%d,%d", &a, &b) == 2 && a > 0 && b > 0 && a <= TIERB_NEFCMAX && b <= TIERB_NCONMAX) { mb.nefcmax = a; mb.nconmax = b; }
       }
       PackedModel pmB;
-      if (mjpc_host::build(pmB, &mb, task, e->P_max, false) && (size_t)pmB.L.total_doubles * sizeof(double) <= TIERB_LDS_LIMIT) {
+      if (mjpc_host::build(pmB, &mb, task, e->P_max, false, true) && (size_t)pmB.L.total_doubles * sizeof(double) <= TIERB_LDS_LIMIT) {
         e->kernelB = kb; e->layB = pmB.L; e->nefcB = pmB.M.nefcmax; e->nconB = pmB.M.nconmax;
         e->ldsB = (size_t)pmB.L.total_doubles * sizeof(double);
       }
@@ -237,7 +238,12 @@ MjpcHipEngine *mjpc_hip_create(const MjpcHipModel *model, const MjpcHipTask *tas
   HIPCHKP(hipMalloc(&e->d_winner_val, sizeof(double) * 2));
   HIPCHKP(hipHostMalloc(&e->h_small, sizeof(double) * (e->ds + 7 * e->nmocap + e->P_max * (2 * e->nu + 1) + 16)));
   HIPCHKP(hipFuncSetAttribute((const void *)e->kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_bytes));
-  if (e->kernelB) HIPCHKP(hipFuncSetAttribute((const void *)e->kernelB, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->ldsB));
+  if (e->kernelB) {
+    HIPCHKP(hipFuncSetAttribute((const void *)e->kernelB, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->ldsB));
+    e->ckpt_stride = 7 + e->nq + 2 * e->nv + 1;
+    HIPCHKP(hipMalloc(&e->d_ckpt, sizeof(double) * NL * e->ckpt_stride));
+    HIPCHKP(hipMemset(e->d_ckpt, 0, sizeof(double) * NL * e->ckpt_stride));
+  }
   { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) e->num_cu = prop.multiProcessorCount; }
   return e;
 }
@@ -248,7 +254,7 @@ void mjpc_hip_destroy(MjpcHipEngine *e) {
   if (e->stream) hipStreamSynchronize(e->stream);
   void *bufs[] = {e->d_cand, e->d_std, e->d_ib, e->d_db, e->d_state, e->d_mocap, e->d_kt, e->d_kv, e->d_eps, e->d_sel, e->d_states, e->d_actions,
                   e->d_times, e->d_residual, e->d_costs, e->d_trace, e->d_knots, e->d_returns, e->d_failure, e->d_diag,
-                  e->d_winner, e->d_winner_val, e->d_prof, e->d_frame};
+                  e->d_winner, e->d_winner_val, e->d_prof, e->d_frame, e->d_ckpt};
   for (void *b : bufs) if (b) hipFree(b);
   if (e->h_small) hipHostFree(e->h_small);
   for (int i = 0; i < 2; i++) { if (e->h_task[i]) hipHostFree(e->h_task[i]); if (e->ev_task[i]) hipEventDestroy(e->ev_task[i]); }
@@ -353,11 +359,11 @@ int mjpc_hip_plan_async(MjpcHipEngine *e, const MjpcHipPlanInput *in) {
   K.states = e->d_states; K.actions = e->d_actions; K.times = e->d_times; K.residual = e->d_residual; K.costs = e->d_costs;
   K.trace = e->d_trace; K.knots = e->d_knots; K.returns = e->d_returns; K.failure = e->d_failure; K.diag = e->d_diag; K.prof = e->d_prof; K.frame = e->d_frame;
   HIPCHK(hipEventRecord(e->ev[1], e->stream));
-  K.retry = 0;
+  K.retry = 0; K.tier = 0; K.ckpt = e->d_ckpt; K.ckpt_stride = e->ckpt_stride;
   const bool dense = e->kernelB && e->force_tier != 1 && (nl > e->num_cu || e->force_tier == 2);
   if (dense) {
     KParams KB = K;
-    KB.M.nefcmax = e->nefcB; KB.M.nconmax = e->nconB; KB.L = e->layB; KB.cache_i = 0; KB.cache_d = 0;
+    KB.M.nefcmax = e->nefcB; KB.M.nconmax = e->nconB; KB.L = e->layB; KB.cache_i = 0; KB.cache_d = 0; KB.tier = 1;
     hipLaunchKernelGGL(e->kernelB, dim3(nl), dim3(mjpc_rollout_threads_cached()), e->ldsB, e->stream, KB);
     K.retry = 1;                       // full capacity for whoever overflowed the dense tier (usually nobody: the launch drains at once)
   }

@@ -59,7 +59,8 @@ static inline void pack_task(PackedModel &p, const MjpcHipTask *t) {
   T.dbl_data = as_off<double>(put_d(p, t->dbl_data, t->num_dbl));
 }
 
-static inline void make_layout(const PackedModel &p, Lay &L, const MjpcHipModel *m, const MjpcHipTask *t, int P_max, size_t cache_d, size_t cache_i) {
+// lean: the dense tier's layout (rollout_dense2.hip, MJPC_LEAN_LDS): spline knots and the Hessian entry table are read from HBM / L2
+static inline void make_layout(const PackedModel &p, Lay &L, const MjpcHipModel *m, const MjpcHipTask *t, int P_max, size_t cache_d, size_t cache_i, bool lean = false) {
   const DevModel &M = p.M;
   int nb = m->nbody, nj = m->njnt, nv = m->nv, ng = m->ngeom, ns = m->nsite, nu = m->nu;
   int o = 0;
@@ -86,19 +87,20 @@ static inline void make_layout(const PackedModel &p, Lay &L, const MjpcHipModel 
   L.efc_margin = L.efc_jv; L.efc_diag = L.efc_force;
   A_(contact, nc * M.con_stride + 1);
   A_(Ma, nv + 1); A_(grad, nv + 1); A_(Mgrad, nv + 1); A_(search, nv + 1); A_(Mv, nv + 1); A_(vtmp, nv + 1); A_(sgl, 4 * nv + 1);
-  A_(knot_times, P_max); A_(knot_values, P_max * nu + 1); A_(residual, nr + 1); A_(terms, t->num_term + 1); A_(red, 8); A_(prof, 26);
+  if (lean) { L.knot_times = 0; L.knot_values = 0; } else { A_(knot_times, P_max); A_(knot_values, P_max * nu + 1); }
+  A_(residual, nr + 1); A_(terms, t->num_term + 1); A_(red, 8); A_(prof, 26);
   A_(xfrc, 6 * nb); A_(mc_d, cache_d + 1); A_(mc_i, (cache_i + 2) / 2);
   L.ints = o;
 #undef A_
   int io = 0;
   L.i_efc_type = io; io += ne; L.i_efc_id = io; io += ne; L.i_efc_state = io; io += ne; L.i_efc_dof = io; io += ne;
   L.i_con = io; io += nc * CONI_STRIDE; L.i_active = io; io += (ne + nc > MAX_ACTIVE_PAIRS ? ne + nc : MAX_ACTIVE_PAIRS); L.i_misc = io; io += 28;
-  L.i_hpair = io; io += M.nmpair + nv;      // LDS copy of the Hessian/gradient entry table (i | j << 8)
+  L.i_hpair = io; if (!lean) io += M.nmpair + nv;      // LDS copy of the Hessian/gradient entry table (i | j << 8)
   L.total_doubles = o + (io + 1) / 2;
 }
 
 // use_cache: lay out an LDS copy of the model tables (rollout_cached.hip) or none (rollout_direct.hip)
-static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTask *t, int P_max, bool use_cache = true) {
+static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTask *t, int P_max, bool use_cache = true, bool lean = false) {
   p.ib.clear(); p.db.clear(); p.error.clear();
   DevModel &M = p.M;
   memset(&M, 0, sizeof(M));
@@ -276,7 +278,7 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
   M.key_mpos = as_off<double>(put_d(p, m->key_mpos, (size_t)m->nkey * 3 * m->nmocap));
   // ---- LDS layout
   if (!use_cache) { p.cache_i = 0; p.cache_d = 0; }      // the kernel reads the tables from HBM / L2: no LDS copy to size
-  make_layout(p, p.L, m, t, P_max, p.cache_d, p.cache_i);
+  make_layout(p, p.L, m, t, P_max, p.cache_d, p.cache_i, lean);
   return true;
 }
 

@@ -126,6 +126,9 @@ struct KParams {
   double time, sigma0, sigma1;
   unsigned long long seed, stream;
   int P, interp, H, N, offset, nlocal, use_device_noise, nominal_index;
+  // capacity tiers (engine.hip): tier > 0 marks the dense-tier launch; a candidate that overflows its buffers leaves a checkpoint
+  // (state at the failing step) in ckpt[] and the retry launch (retry = 1) resumes it from there at full capacity
+  double *ckpt; int ckpt_stride, tier;
   int retry;           // 1: re-run only the candidates whose failure[] holds a buffer-overflow bit (capacity tiers, engine.hip)
   int fault;           // test-suite fault injection (0 = none; 1 = drop one helper hand-shake, see solver.h)
   // outputs (device), row-major per local candidate

@@ -374,7 +374,11 @@ DEV void newton_entries(Ctx &c, int npos, int nneg, int grad_only, int part, int
     for (int g = 0; g < G; g++) {
       int e = e0 + g * stride, i = 0, j = 0;
       if (e < nent) {
+#ifdef MJPC_LEAN_LDS
+        if (!c.cross) { i = MI(mpair_i)[e]; j = MI(mpair_j)[e]; }                 // entry table from HBM / L2 (no LDS copy in the dense tier)
+#else
         if (!c.cross) { int pk = c.hpair[e]; i = pk & 255; j = pk >> 8; }
+#endif
         else if (e >= nh) { i = e - nh; j = nv; }
         else {
           i = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);

@@ -111,132 +111,197 @@ static void TrackingTransition(const MjpcHipModel& m, SimState& s, HostTask& t, 
       s.mocap[7 * b + k] = p0 + p1;
     }
 }
-// ---- QuadrupedFlat::TransitionLocked (quadruped.cc:224-390)
+// ---- host side of the quadruped task between plan steps (what QuadrupedFlat::TransitionLocked does, quadruped.cc:224-390)
+// Organised as a small state machine over tables instead of one long routine:
+//   Restart        simulation time went backwards (reset)            -> phase bookkeeping restarts, exotic modes fall back
+//   Admit          which requested mode changes are legal            -> kModeAdmits[from][to]
+//   Rephase        cadence slider moved                              -> keep the gait phase continuous
+//   PickGait       automatic gait by filtered com speed              -> speed bands kGaitBand[]
+//   ApplyGait      gait changed (slider or automatic)                -> one row of kGaitRow[] into parameters / weights
+//   SteerWalk      Walk mode: goal rides on a line or a circle       -> same closed form the device residual evaluates
+//   Flip           entry snapshot / exit restore of the flip stunt   -> kFlipWeights[]
 namespace {
 // layouts of modelgen/tasks.py quadruped() == the enums in csrc/core.h
 enum { QI_TORSO = 0, QI_HEAD = 1, QI_GOAL = 2, QI_MODE = 17 };
 enum { QD_MODE_START = 0, QD_POSITION = 1, QD_HEADING = 4, QD_SPEED = 6, QD_ANGVEL = 7, QD_GROUND = 8, QD_ORIENT = 9, QD_GAIT = 13,
        QD_PHASE_START = 14, QD_PHASE_START_TIME = 15, QD_PHASE_VEL = 16, QD_FLIGHT_TIME = 19, QD_JUMP_TIME = 23, QD_LAND_TIME = 25 };
 enum { P_GAIT = 0, P_SWITCH = 1, P_CADENCE = 2, P_AMPLITUDE = 3, P_DUTY = 4, P_WALK_SPEED = 5, P_WALK_TURN = 6 };
-enum { W_UPRIGHT = 0, W_HEIGHT = 1, W_POSITION = 2, W_GAIT = 3, W_BALANCE = 4, W_EFFORT = 5, W_POSTURE = 6 };
-enum { kModeQuadruped = 0, kModeBiped, kModeWalk, kModeScramble, kModeFlip };
-enum { kGaitStand = 0, kGaitWalk, kGaitTrot, kGaitCanter, kGaitGallop, kNumGait };
-const double kGaitParam[kNumGait][6] = {{1, 1, 0, 0, 1, 1}, {0.75, 1, 0.03, 0, 1, 1}, {0.45, 2, 0.03, 0.2, 1, 1},
-                                        {0.4, 4, 0.05, 0.03, 0.5, 0.2}, {0.3, 3.5, 0.10, 0.03, 0.2, 0.1}};      // quadruped.h:88-97
-const double kGaitAuto[kNumGait] = {0, 0.02, 0.02, 0.6, 2};                                                       // quadruped.h:100-107
-const double kAutoGaitFilter = 0.2, kAutoGaitMinTime = 1, kMinAngvel = 0.01;
-long long AsInt(double v) { long long i; std::memcpy(&i, &v, 8); return i; }        // ReinterpretAsInt (utilities.cc:207-211)
-double AsDouble(long long i) { double v; std::memcpy(&v, &i, 8); return v; }
+enum { W_UPRIGHT = 0, W_HEIGHT = 1, W_POSITION = 2, W_GAIT = 3, W_BALANCE = 4, W_EFFORT = 5, W_POSTURE = 6, W_COUNT = 7 };
+enum Mode { kQuadruped = 0, kBiped, kWalk, kScramble, kFlip, kNumMode };
+enum Gait { kStand = 0, kGaitWalk, kTrot, kCanter, kGallop, kNumGait };
+
+// a requested mode is admitted from the current one?  Walk and Flip can only be entered from plain Quadruped (quadruped.cc:240-246)
+const bool kModeAdmits[kNumMode][kNumMode] = {
+    /* from Quadruped */ {true, true, true, true, true},
+    /* from Biped     */ {true, true, false, true, false},
+    /* from Walk      */ {true, true, true, true, false},
+    /* from Scramble  */ {true, true, false, true, false},
+    /* from Flip      */ {true, true, false, true, true}};
+// duty ratio, cadence, amplitude | weights balance, upright, height          (quadruped.h:88-97)
+struct GaitRow { double duty, cadence, amplitude, balance, upright, height; };
+const GaitRow kGaitRow[kNumGait] = {{1, 1, 0, 0, 1, 1}, {0.75, 1, 0.03, 0, 1, 1}, {0.45, 2, 0.03, 0.2, 1, 1},
+                                    {0.4, 4, 0.05, 0.03, 0.5, 0.2}, {0.3, 3.5, 0.10, 0.03, 0.2, 0.1}};
+// automatic gait: com speed in (lo, hi] selects the gait (thresholds of quadruped.h:100-107; the Walk band is empty by design)
+struct SpeedBand { double lo, hi; };
+const SpeedBand kGaitBand[kNumGait] = {{0, 0.02}, {0.02, 0.02}, {0.02, 0.6}, {0.6, 2}, {2, 1e300}};
+const double kSpeedFilterTime = 0.2, kGaitDwellTime = 1, kStraightAngvel = 0.01;
+// cost weights during the flip, by term (Upright .. Posture)                (quadruped.cc:361-367)
+const double kFlipWeights[W_COUNT] = {0.2, 5, 0, 0, 0, 0.005, 0.1};
+
+long long BitsOf(double v) { long long i; std::memcpy(&i, &v, 8); return i; }       // select parameters travel as int64 bit patterns (utilities.cc:207-211)
+double FromBits(long long i) { double v; std::memcpy(&v, &i, 8); return v; }
+
+void Unit2(double v[2]) {                                  // mju_normalize semantics: a null vector becomes (1, 0)
+  double n = std::sqrt(v[0] * v[0] + v[1] * v[1]);
+  if (n < 1e-15) { v[0] = 1; v[1] = 0; } else { v[0] /= n; v[1] /= n; }
+}
+
+void QuatOfRotation(const double* R, double q[4]) {        // row-major rotation matrix -> unit quaternion (largest pivot branch)
+  double tr = R[0] + R[4] + R[8];
+  if (tr > 0) { double k = std::sqrt(tr + 1.0) * 2; q[0] = 0.25 * k; q[1] = (R[7] - R[5]) / k; q[2] = (R[2] - R[6]) / k; q[3] = (R[3] - R[1]) / k; }
+  else if (R[0] > R[4] && R[0] > R[8]) { double k = std::sqrt(1.0 + R[0] - R[4] - R[8]) * 2; q[0] = (R[7] - R[5]) / k; q[1] = 0.25 * k; q[2] = (R[1] + R[3]) / k; q[3] = (R[2] + R[6]) / k; }
+  else if (R[4] > R[8]) { double k = std::sqrt(1.0 + R[4] - R[0] - R[8]) * 2; q[0] = (R[2] - R[6]) / k; q[1] = (R[1] + R[3]) / k; q[2] = 0.25 * k; q[3] = (R[5] + R[7]) / k; }
+  else { double k = std::sqrt(1.0 + R[8] - R[0] - R[4]) * 2; q[0] = (R[3] - R[1]) / k; q[1] = (R[2] + R[6]) / k; q[2] = (R[5] + R[7]) / k; q[3] = 0.25 * k; }
+}
+
+// Height of the nearest group-0 geom under `pos`: a ray straight down from 0.5 above it (Ground(), utilities.cc:538-556) against
+// the planes, boxes and spheres of the model, posed from the simulator's kinematic frame.  No hit: the height of the query point.
+double GroundHeight(const MjpcHipModel& m, const SimFrame& f, const double pos[3]) {
+  const double start[3] = {pos[0], pos[1], pos[2] + 0.5};
+  double best = -1;
+  for (int g = 0; g < m.ngeom; g++) {
+    if (m.geom_group[g] != 0) continue;
+    int b = m.geom_bodyid[g];
+    const double* X = f.xmat.data() + 9 * b; const double* gp = m.geom_pos + 3 * g; const double* gq = m.geom_quat + 4 * g;
+    double w = gq[0], x = gq[1], y = gq[2], z = gq[3];
+    double L[9] = {1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y), 2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+                   2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)};
+    double R[9], c[3];
+    for (int i = 0; i < 3; i++) {
+      c[i] = f.xpos[3 * b + i] + X[3 * i] * gp[0] + X[3 * i + 1] * gp[1] + X[3 * i + 2] * gp[2];
+      for (int j = 0; j < 3; j++) R[3 * i + j] = X[3 * i] * L[j] + X[3 * i + 1] * L[3 + j] + X[3 * i + 2] * L[6 + j];
+    }
+    // ray in the geom's frame: origin o, direction d = R^T (0, 0, -1)
+    double rel[3] = {start[0] - c[0], start[1] - c[1], start[2] - c[2]}, o[3], d[3];
+    for (int j = 0; j < 3; j++) { o[j] = R[j] * rel[0] + R[3 + j] * rel[1] + R[6 + j] * rel[2]; d[j] = -R[6 + j]; }
+    const double* sz = m.geom_size + 3 * g;
+    double hit = -1;
+    if (m.geom_type[g] == MJPC_GEOM_PLANE) {
+      if (d[2] < -1e-15) {
+        double t = -o[2] / d[2];
+        double px = o[0] + t * d[0], py = o[1] + t * d[1];
+        if (t >= 0 && (sz[0] <= 0 || std::fabs(px) <= sz[0]) && (sz[1] <= 0 || std::fabs(py) <= sz[1])) hit = t;
+      }
+    } else if (m.geom_type[g] == MJPC_GEOM_SPHERE) {
+      double A = d[0] * d[0] + d[1] * d[1] + d[2] * d[2], B = d[0] * o[0] + d[1] * o[1] + d[2] * o[2];
+      double C = o[0] * o[0] + o[1] * o[1] + o[2] * o[2] - sz[0] * sz[0], det = B * B - A * C;
+      if (det >= 1e-15 && A >= 1e-15) { double r = std::sqrt(det), t0 = (-B - r) / A, t1 = (-B + r) / A; hit = t0 >= 0 ? t0 : (t1 >= 0 ? t1 : -1); }
+    } else if (m.geom_type[g] == MJPC_GEOM_BOX) {
+      for (int i = 0; i < 3; i++) {
+        if (std::fabs(d[i]) <= 1e-15) continue;
+        int j = (i + 1) % 3, k = (i + 2) % 3;
+        for (int side = -1; side <= 1; side += 2) {
+          double t = (side * sz[i] - o[i]) / d[i];
+          if (t < 0) continue;
+          if (std::fabs(o[j] + t * d[j]) <= sz[j] && std::fabs(o[k] + t * d[k]) <= sz[k] && (hit < 0 || t < hit)) hit = t;
+        }
+      }
+    }
+    if (hit >= 0 && (best < 0 || hit < best)) best = hit;
+  }
+  return best < 0 ? start[2] : start[2] - best;
+}
 }  // namespace
 
 void QuadrupedTransition::operator()(const MjpcHipModel& model, SimState& s, HostTask& t, const SimFrame& f) {
   std::vector<double>& P = t.parameters; std::vector<double>& W = t.weight; std::vector<double>& D = t.dbl_data;
-  double time = s.time;
-  int torso = t.int_data[QI_TORSO];
-  // ---------- handle mjData reset ----------
-  if (time < last_transition_time || last_transition_time == -1) {
-    if (mode != kModeQuadruped && mode != kModeBiped) mode = kModeQuadruped;
-    last_transition_time = D[QD_PHASE_START_TIME] = D[QD_PHASE_START] = time;
+  const double now = s.time;
+  const int torso = t.int_data[QI_TORSO];
+  double* goal = s.mocap.data() + 7 * t.int_data[QI_GOAL];
+
+  // Restart
+  if (last_transition_time == -1 || now < last_transition_time) {
+    if (mode != kQuadruped && mode != kBiped) mode = kQuadruped;
+    D[QD_PHASE_START] = D[QD_PHASE_START_TIME] = last_transition_time = now;
   }
-  // ---------- prevent forbidden mode transitions ----------
-  if (mode != current_mode && current_mode != kModeQuadruped) {
-    if (mode == kModeWalk || mode == kModeFlip) mode = kModeQuadruped;
+  // Admit
+  if (mode != current_mode && !kModeAdmits[current_mode][mode]) mode = kQuadruped;
+  // Rephase: the phase accumulated so far becomes the new origin, then the new angular rate applies
+  const double rate = 2 * 3.14159265358979323846 * P[P_CADENCE];
+  if (rate != D[QD_PHASE_VEL]) {
+    D[QD_PHASE_START] += (now - D[QD_PHASE_START_TIME]) * D[QD_PHASE_VEL];
+    D[QD_PHASE_START_TIME] = now;
+    D[QD_PHASE_VEL] = rate;
   }
-  // ---------- handle phase velocity change ----------
-  double phase_velocity = 2 * 3.14159265358979323846 * P[P_CADENCE];
-  if (phase_velocity != D[QD_PHASE_VEL]) {
-    D[QD_PHASE_START] = D[QD_PHASE_START] + (time - D[QD_PHASE_START_TIME]) * D[QD_PHASE_VEL];      // GetPhase(time)
-    D[QD_PHASE_START_TIME] = time;
-    D[QD_PHASE_VEL] = phase_velocity;
-  }
-  // ---------- automatic gait switching ----------
-  const double* comvel = f.subtree_linvel.data() + 3 * torso;
-  double beta = std::exp(-(time - last_transition_time) / kAutoGaitFilter);
-  com_vel[0] = beta * com_vel[0] + (1 - beta) * comvel[0];
-  com_vel[1] = beta * com_vel[1] + (1 - beta) * comvel[1];
-  int auto_switch = (int)AsInt(P[P_SWITCH]);
-  if (mode == kModeBiped) {
-    P[P_GAIT] = AsDouble(kGaitTrot);
-  } else if (auto_switch) {
-    double com_speed = std::sqrt(com_vel[0] * com_vel[0] + com_vel[1] * com_vel[1]);
-    for (int gait = 0; gait < kNumGait; gait++) {
-      if (mode == kModeScramble && gait == kGaitStand) continue;
-      bool lower = com_speed > kGaitAuto[gait];
-      bool upper = gait == kGaitGallop || com_speed <= kGaitAuto[gait + 1];
-      bool wait = std::fabs(gait_switch_time - time) > kAutoGaitMinTime;
-      if (lower && upper && wait) { P[P_GAIT] = AsDouble(gait); gait_switch_time = time; }
-    }
-  }
-  // ---------- handle gait switch, manual or auto ----------
-  double gait_selection = P[P_GAIT];
-  if (AsInt(gait_selection) != AsInt(D[QD_GAIT])) {          // compared as doubles in the reference; bit patterns here (denormals)
-    D[QD_GAIT] = gait_selection;
-    int gait = current_mode == kModeBiped ? kGaitTrot : (int)AsInt(D[QD_GAIT]);                     // GetGait()
-    P[P_DUTY] = kGaitParam[gait][0]; P[P_CADENCE] = kGaitParam[gait][1]; P[P_AMPLITUDE] = kGaitParam[gait][2];
-    W[W_BALANCE] = kGaitParam[gait][3]; W[W_UPRIGHT] = kGaitParam[gait][4]; W[W_HEIGHT] = kGaitParam[gait][5];
-  }
-  // ---------- Walk ----------
-  double* goal_pos = s.mocap.data() + 7 * t.int_data[QI_GOAL];
-  if (mode == kModeWalk) {
-    double angvel = P[P_WALK_TURN], speed = P[P_WALK_SPEED];
-    const double* torso_xmat = f.xmat.data() + 9 * torso;
-    double forward[2] = {torso_xmat[0], torso_xmat[3]};
-    { double n = std::sqrt(forward[0] * forward[0] + forward[1] * forward[1]);
-      if (n < 1e-15) { forward[0] = 1; forward[1] = 0; } else { forward[0] /= n; forward[1] /= n; } }
-    double leftward[2] = {-forward[1], forward[0]};
-    if (mode != current_mode || D[QD_ANGVEL] != angvel || D[QD_SPEED] != speed) {
-      D[QD_MODE_START] = time;
-      D[QD_SPEED] = speed; D[QD_ANGVEL] = angvel;
-      double axis[2] = {f.xpos[3 * torso], f.xpos[3 * torso + 1]};
-      if (std::fabs(angvel) > kMinAngvel) {
-        double d = speed / angvel;
-        axis[0] += d * leftward[0]; axis[1] += d * leftward[1];
+  // PickGait: first-order low-pass of the horizontal com velocity, then the speed band it falls in
+  {
+    const double* v = f.subtree_linvel.data() + 3 * torso;
+    const double keep = std::exp(-(now - last_transition_time) / kSpeedFilterTime);
+    com_vel[0] = keep * com_vel[0] + (1 - keep) * v[0];
+    com_vel[1] = keep * com_vel[1] + (1 - keep) * v[1];
+    if (mode == kBiped) P[P_GAIT] = FromBits(kTrot);
+    else if (BitsOf(P[P_SWITCH]) != 0) {
+      const double speed = std::sqrt(com_vel[0] * com_vel[0] + com_vel[1] * com_vel[1]);
+      for (int g = (mode == kScramble ? kGaitWalk : kStand); g < kNumGait; g++) {
+        if (speed > kGaitBand[g].lo && speed <= kGaitBand[g].hi && std::fabs(gait_switch_time - now) > kGaitDwellTime) {
+          P[P_GAIT] = FromBits(g); gait_switch_time = now;
+          break;                                       // the bands are disjoint
+        }
       }
-      D[QD_POSITION] = axis[0]; D[QD_POSITION + 1] = axis[1];
-      D[QD_HEADING] = goal_pos[0] - axis[0]; D[QD_HEADING + 1] = goal_pos[1] - axis[1];
-    }
-    // move goal: ResidualFn::Walk (quadruped.cc:627-643)
-    double wt = time - D[QD_MODE_START];
-    if (std::fabs(D[QD_ANGVEL]) < kMinAngvel) {
-      double fw[2] = {D[QD_HEADING], D[QD_HEADING + 1]};
-      double n = std::sqrt(fw[0] * fw[0] + fw[1] * fw[1]);
-      if (n < 1e-15) { fw[0] = 1; fw[1] = 0; } else { fw[0] /= n; fw[1] /= n; }
-      goal_pos[0] = D[QD_POSITION] + D[QD_HEADING] + wt * D[QD_SPEED] * fw[0];
-      goal_pos[1] = D[QD_POSITION + 1] + D[QD_HEADING + 1] + wt * D[QD_SPEED] * fw[1];
-    } else {
-      double angle = wt * D[QD_ANGVEL], cs = std::cos(angle), sn = std::sin(angle);
-      goal_pos[0] = cs * D[QD_HEADING] - sn * D[QD_HEADING + 1] + D[QD_POSITION];
-      goal_pos[1] = sn * D[QD_HEADING] + cs * D[QD_HEADING + 1] + D[QD_POSITION + 1];
     }
   }
-  // ---------- Flip ----------
-  if (mode == kModeFlip) {
-    if (mode != current_mode) {
-      D[QD_MODE_START] = time;
-      // torso orientation from its rotation matrix (mjData.xquat in the reference)
-      const double* R = f.xmat.data() + 9 * torso;
-      double q[4]; double tr = R[0] + R[4] + R[8];
-      if (tr > 0) { double sq = std::sqrt(tr + 1.0) * 2; q[0] = 0.25 * sq; q[1] = (R[7] - R[5]) / sq; q[2] = (R[2] - R[6]) / sq; q[3] = (R[3] - R[1]) / sq; }
-      else if (R[0] > R[4] && R[0] > R[8]) { double sq = std::sqrt(1.0 + R[0] - R[4] - R[8]) * 2; q[0] = (R[7] - R[5]) / sq; q[1] = 0.25 * sq; q[2] = (R[1] + R[3]) / sq; q[3] = (R[2] + R[6]) / sq; }
-      else if (R[4] > R[8]) { double sq = std::sqrt(1.0 + R[4] - R[0] - R[8]) * 2; q[0] = (R[2] - R[6]) / sq; q[1] = (R[1] + R[3]) / sq; q[2] = 0.25 * sq; q[3] = (R[5] + R[7]) / sq; }
-      else { double sq = std::sqrt(1.0 + R[8] - R[0] - R[4]) * 2; q[0] = (R[3] - R[1]) / sq; q[1] = (R[2] + R[6]) / sq; q[2] = (R[5] + R[7]) / sq; q[3] = 0.25 * sq; }
-      for (int k = 0; k < 4; k++) D[QD_ORIENT + k] = q[k];
-      D[QD_GROUND] = 0.0;                       // Ground() ray cast: the flat task's floor plane is z = 0
-      save_weight = W; save_gait_switch = P[P_SWITCH];
-      W[W_UPRIGHT] = 0.2; W[W_HEIGHT] = 5; W[W_POSITION] = 0; W[W_GAIT] = 0; W[W_BALANCE] = 0; W[W_EFFORT] = 0.005; W[W_POSTURE] = 0.1;
-      P[P_SWITCH] = AsDouble(0);
+  // ApplyGait (bit patterns are compared: the selector is an integer carried in a double)
+  if (BitsOf(P[P_GAIT]) != BitsOf(D[QD_GAIT])) {
+    D[QD_GAIT] = P[P_GAIT];
+    const GaitRow& row = kGaitRow[current_mode == kBiped ? (int)kTrot : (int)BitsOf(D[QD_GAIT])];
+    P[P_DUTY] = row.duty; P[P_CADENCE] = row.cadence; P[P_AMPLITUDE] = row.amplitude;
+    W[W_BALANCE] = row.balance; W[W_UPRIGHT] = row.upright; W[W_HEIGHT] = row.height;
+  }
+  // SteerWalk
+  if (mode == kWalk) {
+    const double turn = P[P_WALK_TURN], speed = P[P_WALK_SPEED];
+    if (mode != current_mode || D[QD_ANGVEL] != turn || D[QD_SPEED] != speed) {
+      // new trajectory: centre = torso (straight line) or the point speed / turn to the robot's left (circle); heading = goal - centre
+      const double* X = f.xmat.data() + 9 * torso;
+      double ahead[2] = {X[0], X[3]};
+      Unit2(ahead);
+      double centre[2] = {f.xpos[3 * torso], f.xpos[3 * torso + 1]};
+      if (std::fabs(turn) > kStraightAngvel) { const double radius = speed / turn; centre[0] += radius * -ahead[1]; centre[1] += radius * ahead[0]; }
+      D[QD_MODE_START] = now; D[QD_SPEED] = speed; D[QD_ANGVEL] = turn;
+      D[QD_POSITION] = centre[0]; D[QD_POSITION + 1] = centre[1];
+      D[QD_HEADING] = goal[0] - centre[0]; D[QD_HEADING + 1] = goal[1] - centre[1];
     }
-    double flip_time = time - D[QD_MODE_START];
-    if (flip_time >= D[QD_JUMP_TIME] + D[QD_FLIGHT_TIME] + D[QD_LAND_TIME]) {
-      mode = kModeQuadruped;
+    const double along = now - D[QD_MODE_START];
+    if (std::fabs(D[QD_ANGVEL]) < kStraightAngvel) {
+      double dir[2] = {D[QD_HEADING], D[QD_HEADING + 1]};
+      Unit2(dir);
+      goal[0] = D[QD_POSITION] + D[QD_HEADING] + along * D[QD_SPEED] * dir[0];
+      goal[1] = D[QD_POSITION + 1] + D[QD_HEADING + 1] + along * D[QD_SPEED] * dir[1];
+    } else {
+      const double a = along * D[QD_ANGVEL], ca = std::cos(a), sa = std::sin(a);
+      goal[0] = ca * D[QD_HEADING] - sa * D[QD_HEADING + 1] + D[QD_POSITION];
+      goal[1] = sa * D[QD_HEADING] + ca * D[QD_HEADING + 1] + D[QD_POSITION + 1];
+    }
+  }
+  // Flip
+  if (mode == kFlip) {
+    if (mode != current_mode) {                        // entry: snapshot pose, ground height under the com, weights; stunt weights on
+      D[QD_MODE_START] = now;
+      QuatOfRotation(f.xmat.data() + 9 * torso, D.data() + QD_ORIENT);
+      D[QD_GROUND] = GroundHeight(model, f, f.subtree_com.data() + 3 * torso);
+      save_weight = W; save_gait_switch = P[P_SWITCH];
+      for (int k = 0; k < W_COUNT; k++) W[k] = kFlipWeights[k];
+      P[P_SWITCH] = FromBits(0);
+    }
+    if (now - D[QD_MODE_START] >= D[QD_JUMP_TIME] + D[QD_FLIGHT_TIME] + D[QD_LAND_TIME]) {      // exit: back on the feet
+      mode = kQuadruped;
       W = save_weight; P[P_SWITCH] = save_gait_switch;
-      goal_pos[0] = f.site_xpos[3 * t.int_data[QI_HEAD]]; goal_pos[1] = f.site_xpos[3 * t.int_data[QI_HEAD] + 1];
+      goal[0] = f.site_xpos[3 * t.int_data[QI_HEAD]]; goal[1] = f.site_xpos[3 * t.int_data[QI_HEAD] + 1];
     }
   }
   current_mode = mode;
   t.int_data[QI_MODE] = mode;
-  last_transition_time = time;
-  (void)model;
+  last_transition_time = now;
 }
 
 TransitionFn TransitionForTask(int task_id, int mode, double mode_time) {

@@ -260,8 +260,11 @@ def test_update_nominal_policy_against_closed_forms(interp):
     state = np.array([0.1, -0.1, 0.0, 0.0])
     t0 = 0.7
     pl.SetState(state, d["mocap"], None, t0)
-    pl.OptimizePolicy(H)                                   # policy := the winning candidate's spline
-    kt0, kv0 = pl.policy_knots()
+    for _ in range(8):                                     # policy := the winning candidate's spline (until a noisy one has won)
+        pl.OptimizePolicy(H)
+        kt0, kv0 = pl.policy_knots()
+        if np.abs(kv0).max() > 0:
+            break
     s = max((H - 1) * m["timestep"] / (P if interp == 0 else P - 1), 1e-5)
     want = [t0]
     for _ in range(P - 1):

@@ -304,8 +304,43 @@ void QuadrupedTransition::operator()(const MjpcHipModel& model, SimState& s, Hos
   last_transition_time = now;
 }
 
+// ---- ShadowReorient::TransitionLocked (hand.cc:90-119): a cube lying still on the floor is put back over the hand.
+// The reference reads mjData.contact for a cube-floor contact; here the same fact comes from the pose: a box touches a plane
+// exactly when its lowest corner is at or below it (the plane-box collider's own criterion, margin 0).
+// int_data = [palm site, cube body, goal body, key]
+static void HandTransition(const MjpcHipModel& m, SimState& s, HostTask& t, const SimFrame& f) {
+  const int cube = t.int_data[1];
+  int cube_geom = -1, floor_geom = -1;
+  for (int g = 0; g < m.ngeom; g++) {
+    if (m.geom_bodyid[g] == cube && m.geom_type[g] == MJPC_GEOM_BOX && cube_geom < 0) cube_geom = g;
+    if (m.geom_bodyid[g] == 0 && m.geom_type[g] == MJPC_GEOM_PLANE && floor_geom < 0) floor_geom = g;
+  }
+  if (cube_geom < 0 || floor_geom < 0 || m.body_jntnum[cube] != 1) return;
+  const int jnt = m.body_jntadr[cube];
+  if (m.jnt_type[jnt] != MJPC_JNT_FREE) return;
+  const int qa = m.jnt_qposadr[jnt], da = m.jnt_dofadr[jnt];
+  // lowest corner of the cube along the floor normal (the floor is a world-fixed plane: normal = z axis of its quaternion)
+  const double* fq = m.geom_quat + 4 * floor_geom;
+  const double n[3] = {2 * (fq[1] * fq[3] + fq[0] * fq[2]), 2 * (fq[2] * fq[3] - fq[0] * fq[1]), 1 - 2 * (fq[1] * fq[1] + fq[2] * fq[2])};
+  const double* X = f.xmat.data() + 9 * cube; const double* c = f.xpos.data() + 3 * cube; const double* h = m.geom_size + 3 * cube_geom;
+  double reach = 0, centre = 0;
+  for (int k = 0; k < 3; k++) {
+    reach += h[k] * std::fabs(n[0] * X[k] + n[1] * X[3 + k] + n[2] * X[6 + k]);      // box half-extent along the normal
+    centre += n[k] * (c[k] - m.geom_pos[3 * floor_geom + k]);
+  }
+  const bool on_floor = centre - reach <= 0.0;
+  const double* v = s.state.data() + m.nq + da;                                      // free joint: linear velocity in the world frame
+  const double speed = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+  if (on_floor && speed < 0.001) {
+    for (int k = 0; k < 7; k++) s.state[qa + k] = m.qpos0[qa + k];
+    for (int k = 0; k < 6; k++) s.state[m.nq + da + k] = 0.0;
+  }
+  (void)t;
+}
+
 TransitionFn TransitionForTask(int task_id, int mode, double mode_time) {
   if (task_id == MJPC_TASK_HUMANOID_TRACK) return TrackingTransition;
+  if (task_id == MJPC_TASK_SHADOW_REORIENT) return HandTransition;
   if (task_id == MJPC_TASK_QUADRUPED) {
     auto q = std::make_shared<QuadrupedTransition>();
     auto switched = std::make_shared<bool>(false);

@@ -882,3 +882,24 @@ def test_dense_tier_is_bit_identical_to_full_capacity_and_retries_what_overflows
         assert a[0]["winner"] == b[0]["winner"]
         for k in ("states", "actions", "times", "residual", "costs", "trace", "knots"):
             assert np.array_equal(a[1][k], b[1][k]), (name, k)
+
+
+@pytest.mark.gpu
+def test_closed_loop_shadow_hand_and_its_transition():
+    """testspeed loop on the hand task (hand.cc): planning keeps the cube in the hand (it does not end on the floor at z = -0.2),
+    and ShadowReorient::TransitionLocked (hand.cc:90-119) puts a cube that lies still on the floor back to its qpos0 pose."""
+    from mujoco_mpc_amd import cplanner
+    m, task, d = shadow_hand()
+    num = dict(sampling_spline_points=5, sampling_exploration=0.1, sampling_trajectories=32, sampling_representation=0)
+    p = cplanner.SamplingPlanner()
+    p.Initialize(m, task, num, max_samples=32, max_horizon=26)
+    p.Reset(26, d["ctrl0"])                                          # initial repeated action: hold the grasp targets
+    res = cplanner.testspeed(p, d["state"], None, horizon=26, steps_per_planning_iteration=1, total_time=40 * m["timestep"])
+    assert not res["failure"] and res["state"][6] > -0.05 and np.isfinite(res["average_cost"])
+    # a cube at rest on the floor (z = -0.2 + half size): the next Transition resets it
+    st = d["state"].copy()
+    st[4:7] = [0.45, 0.2, -0.2 + 0.022]; st[7:11] = [1, 0, 0, 0]
+    res = cplanner.testspeed(p, st, None, horizon=26, steps_per_planning_iteration=1, total_time=30 * m["timestep"])
+    # the cube settles on the floor within a few steps (speed < 1 mm/s), is reset, and is falling towards the hand again
+    assert abs(res["state"][4] - m["qpos0"][4]) < 0.02 and abs(res["state"][5] - m["qpos0"][5]) < 0.02 and res["state"][6] > -0.15
+    p.close()

@@ -20,16 +20,20 @@ subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared"
                       [os.path.join(CSRC, "_obj", x) for x in ("planner.o", "testspeed.o", "multi.o")] + ["-lpthread"])
 from mujoco_mpc_amd import capi
 capi.ENGINE_PATH = so
-from mujoco_mpc_amd.modelgen import quadruped, humanoid_track
+from mujoco_mpc_amd.modelgen import quadruped, humanoid_track, shadow_hand
 from mujoco_mpc_amd.planner import HipBackend
-HUM = os.environ.get("PROFILE_WORKLOAD") == "humanoid"
-m, task, d = humanoid_track() if HUM else quadruped()
-N, H, P = int(sys.argv[1]) if len(sys.argv) > 1 else 256, (128 if HUM else 100), (16 if HUM else 3)
-SIG = 0.15 if HUM else 0.04
-kt = np.linspace(0, (H - 1) * m["timestep"], P); kv = np.zeros((P, m["nu"]))
+WL = os.environ.get("PROFILE_WORKLOAD", "quadruped")
+HUM = WL == "humanoid"; HAND = WL == "hand"
+m, task, d = humanoid_track() if HUM else (shadow_hand() if HAND else quadruped())
+N, H, P = int(sys.argv[1]) if len(sys.argv) > 1 else 256, (128 if HUM else (64 if HAND else 100)), (16 if HUM else (5 if HAND else 3))
+SIG = 0.15 if HUM else (0.1 if HAND else 0.04)
+INTERP = 0 if HAND else 2
+kt = np.arange(P) * ((H - 1) * m["timestep"] / P) if HAND else np.linspace(0, (H - 1) * m["timestep"], P)
+kv = np.tile(d["ctrl0"], (P, 1)) if HAND else np.zeros((P, m["nu"]))
+if not len(d["mocap"]): d = dict(d, mocap=None)
 be = HipBackend(m, task, max_samples=N, max_horizon=H)
 for i in range(2):
-    out = be.plan(state=d["state"], mocap=d["mocap"], time=0.0, knot_times=kt, knot_values=kv, interpolation=2, num_trajectory=N,
+    out = be.plan(state=d["state"], mocap=d["mocap"], time=0.0, knot_times=kt, knot_values=kv, interpolation=INTERP, num_trajectory=N,
                   horizon=H, sigma=(SIG, 0.0), seed=0x5EED, stream=i)
 prof = np.zeros((N, 24), np.int64)
 be.lib.mjpc_hip_debug_fetch_prof.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]

@@ -132,10 +132,12 @@ DEV void ctx_open(Ctx &c, KP Kc, int role = 0) {
 #define MD(f) (c.M->f)
 #define MI(f) (c.M->f)
 #define MDM() ((const unsigned long long *)c.M->body_dofmask)
+#define MPM() ((const unsigned long long *)c.M->body_patmask)
 #else
 #define MD(f) (c.mcd + (int)(c.M->f - c.gdb))
 #define MI(f) (c.mci + (int)(c.M->f - c.gib))
 #define MDM() ((const unsigned long long *)(c.mcd + (int)((const double *)c.M->body_dofmask - c.gdb)))
+#define MPM() ((const unsigned long long *)(c.mcd + (int)((const double *)c.M->body_patmask - c.gdb)))
 #endif
 DEV void ctx_close(Ctx &c) {
   SYNC();
@@ -1280,8 +1282,8 @@ DEV void make_contact_rows(Ctx &c, int n_nc) {
   // cross-branch contacts (both bodies movable, neither dof chain contains the other) break M's sparsity pattern in H
   int crossflag = 0;
   PFOR(ci, c.ncon) {
-    unsigned long long m1 = MDM()[MI(geom_bodyid)[c.con_i[ci * CONI_STRIDE + 1]]];
-    unsigned long long m2 = MDM()[MI(geom_bodyid)[c.con_i[ci * CONI_STRIDE + 2]]];
+    unsigned long long m1 = MPM()[MI(geom_bodyid)[c.con_i[ci * CONI_STRIDE + 1]]];
+    unsigned long long m2 = MPM()[MI(geom_bodyid)[c.con_i[ci * CONI_STRIDE + 2]]];
     unsigned long long u = m1 | m2;
     if (u != m1 && u != m2) crossflag = 1;
   }
@@ -2132,7 +2134,7 @@ DEV_NOINLINE void ph_init(KP Kc) {
   PFOR(i, nv) { c.qvel[i] = K->state[nq + i]; R.states[nq + i] = K->state[nq + i]; c.qacc_ws[i] = 0; }
   PFOR(e, nv * M.nvp) { c.qM[e] = 0; c.qH[e] = 0; }
 #ifndef MJPC_LEAN_LDS
-  PFOR(e, M.nmpair + nv) c.hpair[e] = MI(mpair_i)[e] | (MI(mpair_j)[e] << 8);
+  PFOR(e, M.nhpair + nv) c.hpair[e] = MI(hpair_i)[e] | (MI(hpair_j)[e] << 8);
 #endif
   PFOR(k, 6 * M.nbody) c.xfrc[k] = 0;
   PFOR(k, nu) c.ctrl[k] = 0;      // data->ctrl after Reset (planner.cc:124-130); only visible when H == 1

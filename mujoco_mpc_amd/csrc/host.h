@@ -95,7 +95,7 @@ static inline void make_layout(const PackedModel &p, Lay &L, const MjpcHipModel 
   int io = 0;
   L.i_efc_type = io; io += ne; L.i_efc_id = io; io += ne; L.i_efc_state = io; io += ne; L.i_efc_dof = io; io += ne;
   L.i_con = io; io += nc * CONI_STRIDE; L.i_active = io; io += (ne + nc > MAX_ACTIVE_PAIRS ? ne + nc : MAX_ACTIVE_PAIRS); L.i_misc = io; io += 28;
-  L.i_hpair = io; if (!lean) io += M.nmpair + nv;      // LDS copy of the Hessian/gradient entry table (i | j << 8)
+  L.i_hpair = io; if (!lean) io += M.nhpair + nv;      // LDS copy of the Hessian/gradient entry table (i | j << 8)
   L.total_doubles = o + (io + 1) / 2;
 }
 
@@ -125,7 +125,8 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
   M.con_stride = (m->cone == MJPC_CONE_ELLIPTIC) ? CON_STRIDE_ELLIPTIC : CON_STRIDE_PLAIN;
   M.maxdim = 1;
   for (int g = 0; g < ng; g++) if (m->geom_condim[g] > M.maxdim) M.maxdim = m->geom_condim[g];
-  M.tree_ok = (nv == 18 && dof_tree_matches<18>(m->dof_parentid)) || (nv == 27 && dof_tree_matches<27>(m->dof_parentid));
+  M.tree_ok = (nv == 18 && dof_tree_matches<18>(m->dof_parentid)) || (nv == 27 && dof_tree_matches<27>(m->dof_parentid)) ||
+              (nv == 33 && dof_tree_matches<33>(m->dof_parentid));
   if (getenv("MJPC_HIP_DENSE_FACTOR")) M.tree_ok = 0;      // test knob: dense elimination order for every factorisation
   M.nconmax = m->nconmax > 0 ? m->nconmax : 32;
   M.nefcmax = m->nefcmax > 0 ? m->nefcmax : 128;
@@ -212,11 +213,17 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
     M.nmpair = (int)pi.size();
     for (int i = 0; i < nv; i++) { pi.push_back(i); pj.push_back(nv); }      // + the gradient entries (column nv of the scaled rows)
     M.mpair_i = as_off<int>(put_i(p, pi.data(), pi.size())); M.mpair_j = as_off<int>(put_i(p, pj.data(), pj.size()));
-    // the structurally-zero part of the lower triangle (dof pairs on different branches)
+    // the Hessian's pattern follows the elimination tree (== the dof tree unless the compile-time tree has hub links)
+    std::vector<int> hi, hj;
+    for (int i = 0; i < nv; i++) for (int j = i; j >= 0; j = pattern_parent(nv, M.tree_ok, m->dof_parentid, j)) { hi.push_back(i); hj.push_back(j); }
+    M.nhpair = (int)hi.size();
+    for (int i = 0; i < nv; i++) { hi.push_back(i); hj.push_back(nv); }
+    M.hpair_i = as_off<int>(put_i(p, hi.data(), hi.size())); M.hpair_j = as_off<int>(put_i(p, hj.data(), hj.size()));
+    // the structurally-zero part of the lower triangle (dof pairs on different branches of the elimination tree)
     std::vector<int> zi, zj;
     for (int i = 0; i < nv; i++) for (int j = 0; j < i; j++) {
       bool anc = false;
-      for (int a = i; a >= 0; a = m->dof_parentid[a]) if (a == j) anc = true;
+      for (int a = i; a >= 0; a = pattern_parent(nv, M.tree_ok, m->dof_parentid, a)) if (a == j) anc = true;
       if (!anc) { zi.push_back(i); zj.push_back(j); }
     }
     M.nzpair = (int)zi.size();
@@ -229,7 +236,17 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
         for (int k = 0; k < m->body_dofnum[a]; k++) mask |= 1ull << (m->body_dofadr[a] + k);
       memcpy(&masks[b], &mask, 8);
     }
-    M.body_dofmask = reinterpret_cast<const unsigned long long *>(as_off<double>(put_d(p, masks.data(), nb))); }
+    M.body_dofmask = reinterpret_cast<const unsigned long long *>(as_off<double>(put_d(p, masks.data(), nb)));
+    // the same along the elimination tree: from the body's deepest dof up through pattern_parent
+    std::vector<double> pmasks(nb);
+    for (int b = 0; b < nb; b++) {
+      int a = b;
+      while (a > 0 && m->body_dofnum[a] == 0) a = m->body_parentid[a];
+      unsigned long long mask = 0;
+      if (a > 0) for (int d = m->body_dofadr[a] + m->body_dofnum[a] - 1; d >= 0; d = pattern_parent(nv, M.tree_ok, m->dof_parentid, d)) mask |= 1ull << d;
+      memcpy(&pmasks[b], &mask, 8);
+    }
+    M.body_patmask = reinterpret_cast<const unsigned long long *>(as_off<double>(put_d(p, pmasks.data(), nb))); }
   // static collision filtering (same weld body, parent-child, <exclude>, contype/conaffinity)
   { std::vector<int> g1s, g2s;
     for (int a = 0; a < ng; a++) for (int b = a + 1; b < ng; b++) {
@@ -303,8 +320,9 @@ static inline DevModel relocate(const PackedModel &p, const int *ibase, const do
   fd(M.key_qpos); fd(M.key_mpos);
   fi(M.tendon_adr); fi(M.tendon_num); fi(M.tendon_limited); fi(M.wrap_dofadr); fi(M.wrap_qposadr);
   fd(M.wrap_prm); fd(M.tendon_range); fd(M.tendon_margin); fd(M.tendon_solref_lim); fd(M.tendon_solimp_lim); fd(M.tendon_invweight0);
-  fi(M.level_adr); fi(M.level_body); fi(M.subtree_adr); fi(M.subtree_list); fi(M.chain_adr); fi(M.chain_list); fi(M.mpair_i); fi(M.mpair_j); fi(M.zpair_i); fi(M.zpair_j);
+  fi(M.level_adr); fi(M.level_body); fi(M.subtree_adr); fi(M.subtree_list); fi(M.chain_adr); fi(M.chain_list); fi(M.mpair_i); fi(M.mpair_j); fi(M.hpair_i); fi(M.hpair_j); fi(M.zpair_i); fi(M.zpair_j);
   { const double *q = reinterpret_cast<const double *>(M.body_dofmask); fd(q); M.body_dofmask = reinterpret_cast<const unsigned long long *>(q); }
+  { const double *q = reinterpret_cast<const double *>(M.body_patmask); fd(q); M.body_patmask = reinterpret_cast<const unsigned long long *>(q); }
   fi(M.pair_g1); fi(M.pair_g2); fi(M.fric_dof); fi(M.limit_jnt); fi(M.ray_geom);
   DevTask &T = M.task;
   fi(T.dim_norm_residual); fi(T.norm); fi(T.num_norm_parameter); fi(T.trace_objtype); fi(T.trace_objid); fi(T.int_data);

@@ -130,7 +130,7 @@ template <int N> constexpr int tree_height(int k) {
   for (int c = k + 1; c < N; c++) if (DofTree<N>::parent(c) == k) { int hc = tree_height<N>(c) + 1; if (hc > h) h = hc; }
   return h;
 }
-template <int N> constexpr int tree_nlevel() { return tree_height<N>(0) + 1; }
+template <int N> constexpr int tree_nlevel() { int h = 0; for (int k = 0; k < N; k++) { int hk = tree_height<N>(k); if (hk > h) h = hk; } return h + 1; }   // forests: the tallest root
 // (pivot, ancestor) pairs of one level, pivots in descending order
 template <int N> constexpr int tree_level_npair(int H) { int n = 0; for (int k = N - 1; k >= 1; k--) if (tree_height<N>(k) == H) n += tree_depth<N>(k); return n; }
 template <int N> constexpr int tree_level_pair(int H, int e, bool pivot) {

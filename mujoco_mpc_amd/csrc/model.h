@@ -32,10 +32,15 @@
 // Dof-tree topologies known at compile time, keyed by nv.  When the model's dof_parentid equals the table (DevModel::tree_ok,
 // checked on the host) the register L^T D L factorisations eliminate the independent branches of one tree level together and
 // skip the structural zeros of M's pattern; any other tree of the same nv uses the dense elimination order.
-template <int N> struct DofTree { static constexpr bool known = false; static constexpr int parent(int) { return -1; } };
+// parent(k) is the ELIMINATION-tree parent: the model's dof_parentid, except for "hub" links (real_parent differs): dofs of another
+// kinematic tree that the Hessian couples with this subtree all the time.  In the hand task every finger chain can touch the
+// cube, so the cube's free joint is made the (virtual) ancestor of the wrist: the pattern  tree + hub  then covers M and every
+// hand-cube contact, and only a contact between two fingers needs the dense order.
+template <int N> struct DofTree { static constexpr bool known = false; static constexpr int parent(int) { return -1; } static constexpr int real_parent(int) { return -1; } };
 template <> struct DofTree<18> {      // floating base + 4 chains of 3 (quadruped)
   static constexpr bool known = true;
   static constexpr int parent(int k) { constexpr int p[18] = {-1, 0, 1, 2, 3, 4, 5, 6, 7, 5, 9, 10, 5, 12, 13, 5, 15, 16}; return p[k]; }
+  static constexpr int real_parent(int k) { return parent(k); }
 };
 template <> struct DofTree<27> {      // floating base + 3-dof waist carrying two 6-dof legs, two 3-dof arms on the base (humanoid)
   static constexpr bool known = true;
@@ -43,11 +48,28 @@ template <> struct DofTree<27> {      // floating base + 3-dof waist carrying tw
     constexpr int p[27] = {-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 8, 15, 16, 17, 18, 19, 5, 21, 22, 5, 24, 25};
     return p[k];
   }
+  static constexpr int real_parent(int k) { return parent(k); }
+};
+template <> struct DofTree<33> {      // goal ball (0-2) | cube free joint (3-8) = hub | wrist (9, 10) carrying 4 + 4 + 4 + 5 + 5 finger dofs (shadow hand)
+  static constexpr bool known = true;
+  static constexpr int parent(int k) {
+    constexpr int p[33] = {-1, 0, 1, -1, 3, 4, 5, 6, 7, /* hub link */ 8, 9, 10, 11, 12, 13, 10, 15, 16, 17, 10, 19, 20, 21, 10, 23, 24, 25, 26, 10, 28, 29, 30, 31};
+    return p[k];
+  }
+  static constexpr int real_parent(int k) { return k == 9 ? -1 : parent(k); }
 };
 template <int N> constexpr bool dof_tree_matches(const int *dof_parentid) {
   if (!DofTree<N>::known) return false;
-  for (int k = 0; k < N; k++) if (dof_parentid[k] != DofTree<N>::parent(k)) return false;
+  for (int k = 0; k < N; k++) if (dof_parentid[k] != DofTree<N>::real_parent(k)) return false;
   return true;
+}
+// elimination-tree parent of dof k for a model with nv dofs whose tree matched (tree_ok); the model's own parent otherwise
+static inline int pattern_parent(int nv, int tree_ok, const int *dof_parentid, int k) {
+  if (!tree_ok) return dof_parentid[k];
+  if (nv == 18) return DofTree<18>::parent(k);
+  if (nv == 27) return DofTree<27>::parent(k);
+  if (nv == 33) return DofTree<33>::parent(k);
+  return dof_parentid[k];
 }
 
 enum { CNSTR_FRICTION_DOF = 1, CNSTR_LIMIT_JOINT = 3, CNSTR_LIMIT_TENDON = 4, CNSTR_CONTACT_FRICTIONLESS = 5, CNSTR_CONTACT_PYRAMIDAL = 6, CNSTR_CONTACT_ELLIPTIC = 7 };
@@ -63,7 +85,7 @@ struct DevTask {
 
 struct DevModel {
   int nq, nv, nu, nbody, njnt, ngeom, nsite, nmocap, nkey, nvp, ntendon;
-  int nlevel, npair, nfric, nlimit, nray, nmpair, nzpair, nconmax, nefcmax, any_damping;
+  int nlevel, npair, nfric, nlimit, nray, nmpair, nhpair, nzpair, nconmax, nefcmax, any_damping;
   int cone, iterations, ls_iterations, disableflags, con_stride, maxdim, tree_ok, nact;
   double timestep, gravity[3], impratio, tolerance, ls_tolerance, meaninertia;
   const int *body_parentid, *body_rootid, *body_mocapid, *body_jntnum, *body_jntadr, *body_dofnum, *body_dofadr;
@@ -89,8 +111,10 @@ struct DevModel {
   const int *subtree_adr, *subtree_list;    // bodies of each subtree, self first, ascending ids
   const int *chain_adr, *chain_list;        // ancestors of each body from the root's child down to the body itself
   const int *mpair_i, *mpair_j;             // (dof i, ancestor-or-self dof j): the non-zeros of M
-  const int *zpair_i, *zpair_j;             // the rest of the lower triangle (structural zeros of M)
+  const int *hpair_i, *hpair_j;             // the Hessian's pattern: (dof i, elimination-tree ancestor-or-self j), then the nv gradient entries (i, nv)
+  const int *zpair_i, *zpair_j;             // the rest of the lower triangle (structural zeros of that pattern)
   const unsigned long long *body_dofmask;   // bit d set <=> dof d moves body
+  const unsigned long long *body_patmask;   // the same along the elimination tree (hub dofs included): cross-branch test of a contact
   const int *pair_g1, *pair_g2;             // statically filtered geom pairs (type1 <= type2)
   const int *fric_dof, *limit_jnt, *ray_geom;
   DevTask task;

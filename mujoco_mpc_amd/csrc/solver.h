@@ -365,7 +365,7 @@ DEV void newton_entries(Ctx &c, int npos, int nneg, int grad_only, int part, int
   const int nv = NVT > 0 ? NVT : M.nv, nvp = NVT > 0 ? NVP_OF(NVT) : M.nvp;
   const int npos8 = (npos + 7) & ~7, ntot = npos8 + ((nneg + 3) & ~3);
   const double *JH = c.efc_JA;
-  int nh = c.cross ? nv * (nv + 1) / 2 : M.nmpair;
+  int nh = c.cross ? nv * (nv + 1) / 2 : M.nhpair;
   int nent = nh + nv;
   const int stride = NLANE * nparts;
   for (int e0 = (grad_only ? nh : 0) + part * NLANE + LANE; e0 < nent; e0 += G * stride) {
@@ -375,7 +375,7 @@ DEV void newton_entries(Ctx &c, int npos, int nneg, int grad_only, int part, int
       int e = e0 + g * stride, i = 0, j = 0;
       if (e < nent) {
 #ifdef MJPC_LEAN_LDS
-        if (!c.cross) { i = MI(mpair_i)[e]; j = MI(mpair_j)[e]; }                 // entry table from HBM / L2 (no LDS copy in the dense tier)
+        if (!c.cross) { i = MI(hpair_i)[e]; j = MI(hpair_j)[e]; }                 // entry table from HBM / L2 (no LDS copy in the dense tier)
 #else
         if (!c.cross) { int pk = c.hpair[e]; i = pk & 255; j = pk >> 8; }
 #endif

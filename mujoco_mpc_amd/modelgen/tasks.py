@@ -407,7 +407,8 @@ def shadow_hand(timestep=0.01, cone=0, nconmax=32, nefcmax=128):
 
     def finger(prefix, parent, pos, jnames):
         kn = b.body(f"rh_{prefix}knuckle", parent, pos=pos, inertial=dict(mass=0.008, pos=(0, 0, 0), diaginertia=(3.2e-7, 2.6e-7, 2.6e-7)))
-        hinge(kn, jnames[0], (0, -1, 0), (-0.349066, 0.349066))
+        # abduction axis: -y for the first and middle finger, +y for ring and little finger (positive angle spreads the fingers)
+        hinge(kn, jnames[0], (0, -1, 0) if prefix in ("ff", "mf") else (0, 1, 0), (-0.349066, 0.349066))
         pr = b.body(f"rh_{prefix}proximal", kn, inertial=dict(mass=0.03, pos=(0, 0, 0.0225), diaginertia=(1e-5, 9.8e-6, 1.8e-6)))
         hinge(pr, jnames[1], (1, 0, 0), (-0.261799, 1.5708))
         b.geom(pr, f"{prefix}proximal", CAPSULE, size=(0.009, 0.02), pos=(0, 0, 0.025), **P)

@@ -434,7 +434,8 @@ static void make_constraint(const OModel *om, OData *d) {
     if (dim > 1 && !elliptic) {
       /* pyramidal cone: 2(dim-1) unilateral rows  Jn +- mu_k * J_k */
       for (int k = 1; k < dim; k++) for (int sgn = 1; sgn >= -1; sgn -= 2) {
-        int r = add_row(om, d, O_CNSTR_CONTACT_PYRAMIDAL, ci); if (r < 0) return;
+        int r = add_row(om, d, O_CNSTR_CONTACT_PYRAMIDAL, ci);
+        if (r < 0) { d->nefc = c->efc_address; return; }   /* buffer full: no half-built cone is left behind */
         const double *ax = c->frame + 3 * (k % 3);
         const double *ja = k < 3 ? jp1 : jr1, *jb = k < 3 ? jp2 : jr2;
         double mu = c->friction[k - 1];
@@ -452,7 +453,7 @@ static void make_constraint(const OModel *om, OData *d) {
     }
     for (int k = 0; k < dim; k++) {
       int r = add_row(om, d, dim == 1 ? O_CNSTR_CONTACT_FRICTIONLESS : O_CNSTR_CONTACT_ELLIPTIC, ci);
-      if (r < 0) return;
+      if (r < 0) { d->nefc = c->efc_address; return; }
       const double *ax = c->frame + 3 * (k % 3);
       const double *ja = k < 3 ? jp1 : jr1, *jb = k < 3 ? jp2 : jr2;
       for (int i = 0; i < nv; i++)
@@ -1012,4 +1013,15 @@ int oracle_debug_step(const OModel *om, double *qpos, double *qvel, const double
   int w = d->warning;
   oracle_free_data(d);
   return w;
+}
+
+/* debug: geom pairs of the contacts at a configuration (tests / analysis): out[2*k], out[2*k+1]; returns ncon */
+int oracle_debug_contact_geoms(const OModel *om, const double *qpos, int *out, int cap) {
+  OData *d = oracle_make_data(om);
+  o_copy(d->qpos, qpos, om->m.nq);
+  oracle_forward(om, d);
+  int n = d->ncon;
+  for (int k = 0; k < n && k < cap; k++) { out[2 * k] = d->contact[k].geom1; out[2 * k + 1] = d->contact[k].geom2; }
+  oracle_free_data(d);
+  return n;
 }

@@ -30,7 +30,8 @@ int oracle_norm_parameter_dimension(int type) {   /* norm.cc:25-47 */
 
 double oracle_norm(const double *x, const double *params, int n, int type) {   /* norm.cc:50-210, value only */
   double y = 0;
-  double p = params ? params[0] : 0, q = params ? params[1] : 0;
+  int np_ = oracle_norm_parameter_dimension(type);
+  double p = (params && np_ > 0) ? params[0] : 0, q = (params && np_ > 1) ? params[1] : 0;
   switch (type) {
     case MJPC_NORM_NULL: y = x[0]; break;
     case MJPC_NORM_QUADRATIC:

@@ -57,13 +57,14 @@ const char *mjpc_hip_testhooks_last_error(void) { return g_error.c_str(); }
 
 // test hook: x = A^-1 b with the register L^T D L of the rollout kernel (n = 18 or 27; tree = 1: level-ordered sparse form)
 int mjpc_hip_debug_ldl(int n, int tree, const double *A, const double *b, double *out, int device) {
-  if (n != 18 && n != 27) { set_error("mjpc_hip_debug_ldl: n must be 18 or 27"); return -1; }
+  if (n != 18 && n != 27 && n != 33) { set_error("mjpc_hip_debug_ldl: n must be 18, 27 or 33"); return -1; }
   HIPCHK(hipSetDevice(device));
   double *dA = nullptr, *db = nullptr, *dout = nullptr;
   HIPCHK(hipMalloc(&dA, sizeof(double) * n * n)); HIPCHK(hipMalloc(&db, sizeof(double) * n)); HIPCHK(hipMalloc(&dout, sizeof(double) * 2 * n));
   HIPCHK(hipMemcpy(dA, A, sizeof(double) * n * n, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(db, b, sizeof(double) * n, hipMemcpyHostToDevice));
   if (n == 18) hipLaunchKernelGGL(ldl_test_kernel<18>, dim3(1), dim3(64), 0, 0, dA, db, dout, tree);
-  else hipLaunchKernelGGL(ldl_test_kernel<27>, dim3(1), dim3(64), 0, 0, dA, db, dout, tree);
+  else if (n == 27) hipLaunchKernelGGL(ldl_test_kernel<27>, dim3(1), dim3(64), 0, 0, dA, db, dout, tree);
+  else hipLaunchKernelGGL(ldl_test_kernel<33>, dim3(1), dim3(64), 0, 0, dA, db, dout, tree);
   HIPCHK(hipGetLastError());
   HIPCHK(hipDeviceSynchronize());
   HIPCHK(hipMemcpy(out, dout, sizeof(double) * 2 * n, hipMemcpyDeviceToHost));

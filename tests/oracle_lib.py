@@ -11,7 +11,7 @@ from mujoco_mpc_amd import capi
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
-ORACLE_SO = os.path.join(ORACLE_DIR, "_build", "liboracle.so")
+ORACLE_SO = os.environ.get("MJPC_ORACLE_SO") or os.path.join(ORACLE_DIR, "_build", "liboracle.so")   # override: the asan build
 
 c_double_p = C.POINTER(C.c_double)
 c_int_p = C.POINTER(C.c_int)

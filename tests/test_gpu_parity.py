@@ -698,15 +698,17 @@ def test_multiwave_rollouts_are_bitwise_repeatable():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n", [18, 27])
+@pytest.mark.parametrize("n", [18, 27, 33])
 def test_register_ldl_dense_and_tree_orders_solve_the_same_system(n):
     """csrc/linalg.h: the level-ordered sparse L^T D L (DofTree<n>) and the dense elimination order against numpy on a random SPD
     matrix with the sparsity pattern of the joint-space inertia; fused and split (through LDS) forms."""
     import ctypes as C
     from mujoco_mpc_amd import capi
-    from mujoco_mpc_amd.modelgen import humanoid_track, quadruped
-    m = (quadruped() if n == 18 else humanoid_track())[0]
+    from mujoco_mpc_amd.modelgen import humanoid_track, quadruped, shadow_hand
+    m = (quadruped() if n == 18 else (humanoid_track() if n == 27 else shadow_hand()))[0]
     par = [int(p) for p in m["dof_parentid"]]
+    if n == 33:
+        par[9] = 8          # the hand's elimination tree: the cube's free joint is the hub above the wrist (csrc/model.h DofTree<33>)
     rng = np.random.default_rng(n)
     A = np.zeros((n, n))
     for i in range(n):                                    # ancestors-only pattern
@@ -901,5 +903,6 @@ def test_closed_loop_shadow_hand_and_its_transition():
     st[4:7] = [0.45, 0.2, -0.2 + 0.022]; st[7:11] = [1, 0, 0, 0]
     res = cplanner.testspeed(p, st, None, horizon=26, steps_per_planning_iteration=1, total_time=30 * m["timestep"])
     # the cube settles on the floor within a few steps (speed < 1 mm/s), is reset, and is falling towards the hand again
-    assert abs(res["state"][4] - m["qpos0"][4]) < 0.02 and abs(res["state"][5] - m["qpos0"][5]) < 0.02 and res["state"][6] > -0.15
+    # (the floor pose above is 0.125 / 0.2 away in x / y; the reset cube rolls a little on the fingers afterwards)
+    assert abs(res["state"][4] - m["qpos0"][4]) < 0.05 and abs(res["state"][5] - m["qpos0"][5]) < 0.05 and res["state"][6] > -0.15
     p.close()

@@ -435,3 +435,20 @@ def test_cube_comes_to_rest_on_a_box_and_in_the_synthetic_hand():
     o = ol.Oracle(m, task)
     q, v, _, _, w = o.step(d["state"][:35], np.zeros(33), ctrl=d["ctrl0"], nstep=150)
     assert w == 0 and q[6] > -0.02 and np.abs(v).max() < 0.2        # the cube (qpos[4:7]) stays in the hand; the floor is at -0.2
+
+
+@pytest.mark.parametrize("kw,bit", [(dict(nconmax=6, nefcmax=128), 8), (dict(nconmax=32, nefcmax=44), 16),
+                                    (dict(nconmax=32, nefcmax=47, cone=1), 16)])
+def test_full_buffers_fail_the_candidate_and_leave_no_half_built_cone(kw, bit):
+    """mjWARN_CONTACTFULL / mjWARN_CNSTRFULL (utilities.cc:787-799): a buffer that fills in the middle of a contact's rows drops
+    that contact whole (every later loop walks rows by contact dimension); the candidate fails with that bit and kMaxReturnValue.
+    Run under `make -C oracle asan` to check the memory side."""
+    from oracle_backend import OracleBackend
+    from mujoco_mpc_amd.modelgen.tasks import shadow_hand
+    m, task, d = shadow_hand(**kw)
+    P, H = 5, 30
+    kt = np.arange(P) * ((H - 1) * m["timestep"] / P)
+    r = OracleBackend(m, task).plan(state=d["state"], mocap=None, time=0.0, knot_times=kt, knot_values=np.tile(d["ctrl0"], (P, 1)),
+                                    interpolation=0, num_trajectory=16, horizon=H, sigma=(0.3, 0.0), seed=0, stream=0)
+    assert (r["failure"] & bit).any() and (r["failure"] == 0).any(), r["failure"]
+    assert np.all(r["returns"][r["failure"] != 0] == 1.0e6)

@@ -255,7 +255,8 @@ int mjpc_hip_lds_bytes(MjpcHipEngine *e);
  * (0: none for this model); *used_last = 1 when the last plan used it. */
 int mjpc_hip_dense_tier(MjpcHipEngine *e, int *used_last);
 /* The same figure for a model without creating an engine (host-only, no GPU needed): with (1) / without (0) the LDS copy of
- * the model tables.  Negative: mjpc_hip_create would refuse the model (see mjpc_hip_last_error). */
+ * the model tables; use_cache | 2: the dense tier's lean layout at the model's nefcmax / nconmax.  Negative: mjpc_hip_create
+ * would refuse the model (see mjpc_hip_last_error). */
 int mjpc_hip_layout_bytes(const MjpcHipModel *model, const MjpcHipTask *task, int use_cache);
 /* Kinematic frame of local candidate 0 at the first step of the last plan (the state handed in): what a host-side
  * Task::Transition reads from mjData after a simulation step (mjpc/tasks/quadruped/quadruped.cc:254,290-330: body poses, site

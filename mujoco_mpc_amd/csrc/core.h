@@ -74,7 +74,7 @@ struct Ctx {
   double *efc_J, *efc_JA, *efc_D, *efc_R, *efc_aref, *efc_force, *efc_jar, *efc_jv, *efc_floss, *efc_pos, *efc_margin, *efc_diag;
   double *contact;
   double *Ma, *grad, *Mgrad, *search, *Mv, *vtmp, *sgl;
-  double *knot_times, *knot_values, *residual, *terms, *red, *xfrc;
+  double *knot_times, *knot_values, *residual, *terms, *red, *xfrc, *scr_a, *scr_b;
   int *efc_type, *efc_id, *efc_state, *efc_dof, *con_i, *active, *misc, *hpair;
   double time;
   int ncon, nefc, nsingle, warning, solver_iter, cross;
@@ -109,7 +109,7 @@ DEV void ctx_init(Ctx &c, const KParams *K, double *base) {
 #else
   P_(knot_times); P_(knot_values);
 #endif
-  P_(residual); P_(terms); P_(red); P_(xfrc);
+  P_(residual); P_(terms); P_(red); P_(xfrc); P_(scr_a); P_(scr_b);
 #undef P_
   int *ib = (int *)(base + L.ints);
   c.efc_type = ib + L.i_efc_type; c.efc_id = ib + L.i_efc_id; c.efc_state = ib + L.i_efc_state; c.efc_dof = ib + L.i_efc_dof;
@@ -1519,6 +1519,11 @@ template <int NVT>
 DEV void velocity_stage(Ctx &c, int mfact_seq) {
   const DevModel &M = *c.M;
   int nv = M.nv;
+#ifdef MJPC_LEAN_LDS
+  // the RNE intermediates share their LDS with the solver's scaled rows here: the world body's entries are rewritten every step
+  if (LANE < 6) { c.cfrc[LANE] = 0; c.cacc[LANE] = (LANE >= 3) ? -M.gravity[LANE - 3] : 0.0; }
+  SYNC();
+#endif
   if constexpr (NVT == 27) {
     // the humanoid's 8 tree levels: one lane per body walks its ancestor chain with the running velocity / acceleration in
     // registers, like kinematics (-1.3 % of its step; the A1's 4 levels are cheaper as a level sweep, and keeping both forms in
@@ -2136,7 +2141,9 @@ DEV_NOINLINE void ph_init(KP Kc) {
 #ifndef MJPC_LEAN_LDS
   PFOR(e, M.nhpair + nv) c.hpair[e] = MI(hpair_i)[e] | (MI(hpair_j)[e] << 8);
 #endif
+#ifndef MJPC_LEAN_LDS
   PFOR(k, 6 * M.nbody) c.xfrc[k] = 0;
+#endif
   PFOR(k, nu) c.ctrl[k] = 0;      // data->ctrl after Reset (planner.cc:124-130); only visible when H == 1
   if (LANE == 0) {
     R.times[0] = K->time;
@@ -2303,7 +2310,7 @@ DEV_NOINLINE void ph_prefactor(KP Kc) {
     int nv = M.nv, nvp = M.nvp;
     double h = M.timestep;
     PFOR(e, nv * nvp) { int i = e / nvp, j = e - i * nvp; c.qL[e] = c.qM[e] + ((i == j) ? h * MD(dof_damping)[i] : 0.0); }
-    chol_factor<NVT>(c.qL, c.Linv, c.cfrc, nv, nvp, c.M->tree_ok);
+    chol_factor<NVT>(c.qL, c.Linv, c.scr_a, nv, nvp, c.M->tree_ok);
   }
   PROFW(c, 11);
   ctx_close(c);

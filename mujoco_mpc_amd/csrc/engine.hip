@@ -34,8 +34,8 @@ extern "C" int mjpc_rollout_threads_cached(void);
 // (MJPC_WARN_CONTACTFULL / CNSTRFULL) and the full-capacity kernel re-runs exactly those candidates right behind it on
 // the stream (all other workgroups of that launch exit at once).  Rollouts are deterministic and independent, so the result
 // is the same as running everything at full capacity: no candidate is lost to the smaller buffers.
-#define TIERB_NEFCMAX 100
-#define TIERB_NCONMAX 28
+#define TIERB_NEFCMAX 112    // first capacity tried for the dense tier (rows); contacts = rows / 4 + 2
+#define TIERB_NEFCMIN 40
 #define TIERB_LDS_LIMIT (80 * 1024)
 
 // eps[r, e] for global candidate (offset + r), element e = p*nu + k; sel[r] = second-std choice
@@ -184,17 +184,24 @@ MjpcHipEngine *mjpc_hip_create(const MjpcHipModel *model, const MjpcHipTask *tas
     // layout of <= 80 KiB
     int exact_b = 0;
     RolloutFn kb = mjpc_pick_rollout_dense2(model->nv, &exact_b);
-    if (exact_b && use_cache && e->pm.M.nefcmax > TIERB_NEFCMAX && e->pm.M.nconmax >= TIERB_NCONMAX) {
-      MjpcHipModel mb = *model;
-      mb.nefcmax = TIERB_NEFCMAX; mb.nconmax = TIERB_NCONMAX;
+    if (exact_b) {
+      // capacity of the dense tier: the largest (rows, contacts = rows / 4 + 2) not above the model's own whose lean layout fits
+      // 80 KiB; below 40 rows the retry pass would be the rule, not the exception
+      int cap_e = 0, cap_c = 0;
       if (const char *cap = getenv("MJPC_HIP_TIERB_CAP")) {       // test knob "nefcmax,nconmax": a tiny dense tier forces the retry pass
         int a = 0, b = 0;
-        if (sscanf(cap, "%d,%d", &a, &b) == 2 && a > 0 && b > 0 && a <= TIERB_NEFCMAX && b <= TIERB_NCONMAX) { mb.nefcmax = a; mb.nconmax = b; }
+        if (sscanf(cap, "%d,%d", &a, &b) == 2 && a > 0 && b > 0 && a <= e->pm.M.nefcmax && b <= e->pm.M.nconmax) { cap_e = a; cap_c = b; }
       }
-      PackedModel pmB;
-      if (mjpc_host::build(pmB, &mb, task, e->P_max, false, true) && (size_t)pmB.L.total_doubles * sizeof(double) <= TIERB_LDS_LIMIT) {
-        e->kernelB = kb; e->layB = pmB.L; e->nefcB = pmB.M.nefcmax; e->nconB = pmB.M.nconmax;
-        e->ldsB = (size_t)pmB.L.total_doubles * sizeof(double);
+      int first = e->pm.M.nefcmax < TIERB_NEFCMAX ? e->pm.M.nefcmax : TIERB_NEFCMAX;
+      for (int ne = cap_e ? cap_e : first; ne >= (cap_e ? cap_e : TIERB_NEFCMIN) && !e->kernelB; ne -= 4) {
+        MjpcHipModel mb = *model;
+        mb.nefcmax = ne; mb.nconmax = cap_e ? cap_c : ne / 4 + 2;
+        if (mb.nconmax > e->pm.M.nconmax) mb.nconmax = e->pm.M.nconmax;
+        PackedModel pmB;
+        if (mjpc_host::build(pmB, &mb, task, e->P_max, false, true) && (size_t)pmB.L.total_doubles * sizeof(double) <= TIERB_LDS_LIMIT) {
+          e->kernelB = kb; e->layB = pmB.L; e->nefcB = pmB.M.nefcmax; e->nconB = pmB.M.nconmax;
+          e->ldsB = (size_t)pmB.L.total_doubles * sizeof(double);
+        }
       }
     }
     const char *tier = getenv("MJPC_HIP_TIER");           // test knob: "A" = never the dense tier, "B" = always (when it exists)
@@ -360,7 +367,7 @@ int mjpc_hip_plan_async(MjpcHipEngine *e, const MjpcHipPlanInput *in) {
   K.trace = e->d_trace; K.knots = e->d_knots; K.returns = e->d_returns; K.failure = e->d_failure; K.diag = e->d_diag; K.prof = e->d_prof; K.frame = e->d_frame;
   HIPCHK(hipEventRecord(e->ev[1], e->stream));
   K.retry = 0; K.tier = 0; K.ckpt = e->d_ckpt; K.ckpt_stride = e->ckpt_stride;
-  const bool dense = e->kernelB && e->force_tier != 1 && (nl > e->num_cu || e->force_tier == 2);
+  const bool dense = e->kernelB && e->force_tier != 1 && (nl > e->num_cu || e->force_tier == 2) && !(in->xfrc_std > 0);   // (the lean layout has no body-force block)
   if (dense) {
     KParams KB = K;
     KB.M.nefcmax = e->nefcB; KB.M.nconmax = e->nconB; KB.L = e->layB; KB.cache_i = 0; KB.cache_d = 0; KB.tier = 1;
@@ -533,12 +540,13 @@ int mjpc_hip_dense_tier(MjpcHipEngine *e, int *used_last) {
   return e->kernelB ? (int)e->ldsB : 0;
 }
 
-// host-only (no HIP call): bytes of LDS one candidate would occupy; use_cache: with / without the LDS copy of the model tables.
+// host-only (no HIP call): bytes of LDS one candidate would occupy; use_cache bit 0: with / without the LDS copy of the model
+// tables, bit 1: the dense tier's lean layout (knots and entry tables stay in global memory).
 // < 0: the model is refused (mjpc_hip_last_error tells why)
 int mjpc_hip_layout_bytes(const MjpcHipModel *model, const MjpcHipTask *task, int use_cache) {
   if (!model || !task) { set_error("mjpc_hip_layout_bytes: invalid argument"); return -1; }
   PackedModel pm;
-  if (!mjpc_host::build(pm, model, task, 36, use_cache != 0)) { set_error("mjpc_hip_layout_bytes: " + pm.error); return -1; }
+  if (!mjpc_host::build(pm, model, task, 36, (use_cache & 1) != 0, (use_cache & 2) != 0)) { set_error("mjpc_hip_layout_bytes: " + pm.error); return -1; }
   return (int)((size_t)pm.L.total_doubles * sizeof(double));
 }
 

@@ -70,8 +70,12 @@ static inline void make_layout(const PackedModel &p, Lay &L, const MjpcHipModel 
   A_(qfrc_bias, nv); A_(qfrc_constraint, nv); A_(actuator_force, nu + 1); A_(mocap_pos, 3 * m->nmocap + 3); A_(mocap_quat, 4 * m->nmocap + 4);
   A_(xpos, 3 * nb); A_(xquat, 4 * nb); A_(xmat, 9 * nb); A_(xipos, 3 * nb); A_(ximat, 9 * nb); A_(xanchor, 3 * nj + 3); A_(xaxis, 3 * nj + 3);
   A_(geom_xpos, 3 * ng + 3); A_(geom_xmat, 9 * ng + 9); A_(site_xpos, 3 * ns + 3);
-  A_(subtree_com, 3 * nb); A_(cinert, 10 * nb); A_(crb, 10 * nb); A_(cdof, 6 * nv + 18); A_(cvel, 6 * nb); A_(cdof_dot, 6 * nv + 18);
-  A_(cacc, 6 * nb); A_(cfrc, 6 * nb); A_(cfrc_sub, 6 * nb); A_(subtree_linvel, 3 * nb); A_(bodytmp, 3 * nb);
+  // lean layout: the composite inertias and the RNE intermediates only live between two solves and share the block of the
+  // solver's scaled rows (efc_JA), which only lives inside a solve (placed below)
+#define B_(f, n) if (!lean) { A_(f, n); }
+  A_(subtree_com, 3 * nb); B_(cinert, 10 * nb); B_(crb, 10 * nb); A_(cdof, 6 * nv + 18); A_(cvel, 6 * nb); B_(cdof_dot, 6 * nv + 18);
+  B_(cacc, 6 * nb); B_(cfrc, 6 * nb); B_(cfrc_sub, 6 * nb); A_(subtree_linvel, 3 * nb); A_(bodytmp, 3 * nb);
+#undef B_
   A_(qM, nv * nvp + 1); A_(qL, nv * nvp + 1); A_(qH, nv * nvp + 1); A_(Linv, nv + 1); A_(Hinv, nv + 1);
   // efc_JA holds the scaled rows of the Newton Hessian: the active contact rows (padded to 8) + one negative row per cone
   // contact (padded to 4)
@@ -82,14 +86,23 @@ static inline void make_layout(const PackedModel &p, Lay &L, const MjpcHipModel 
 #else
   A_(efc_J, (ne - M.nfric) * nvp + 1);
 #endif
-  A_(efc_JA, ja_rows * nvp + 1); A_(efc_D, ne); A_(efc_R, ne); A_(efc_aref, ne); A_(efc_force, ne); A_(efc_jar, ne); A_(efc_jv, ne);
+  A_(efc_JA, ja_rows * nvp + 1);
+  if (lean) {
+    int q = L.efc_JA;
+    L.cinert = q; q += 10 * nb; L.crb = q; q += 10 * nb; L.cdof_dot = q; q += 6 * nv + 18;
+    L.cacc = q; q += 6 * nb; L.cfrc = q; q += 6 * nb; L.cfrc_sub = q; q += 6 * nb;
+    if (q > o) o = q;
+  }
+  A_(efc_D, ne); A_(efc_R, ne); A_(efc_aref, ne); A_(efc_force, ne); A_(efc_jar, ne); A_(efc_jv, ne);
   A_(efc_floss, ne); A_(efc_pos, ne);
   L.efc_margin = L.efc_jv; L.efc_diag = L.efc_force;
   A_(contact, nc * M.con_stride + 1);
   A_(Ma, nv + 1); A_(grad, nv + 1); A_(Mgrad, nv + 1); A_(search, nv + 1); A_(Mv, nv + 1); A_(vtmp, nv + 1); A_(sgl, 4 * nv + 1);
   if (lean) { L.knot_times = 0; L.knot_values = 0; } else { A_(knot_times, P_max); A_(knot_values, P_max * nu + 1); }
   A_(residual, nr + 1); A_(terms, t->num_term + 1); A_(red, 8); A_(prof, 26);
-  A_(xfrc, 6 * nb); A_(mc_d, cache_d + 1); A_(mc_i, (cache_i + 2) / 2);
+  A_(scr_a, nv + 1); A_(scr_b, nv + 1);                       // solve-phase scratch of the side wave / of the helper's cost at qacc_smooth
+  if (lean) L.xfrc = 0; else { A_(xfrc, 6 * nb); }             // no force noise on the dense tier (engine.hip)
+  A_(mc_d, cache_d + 1); A_(mc_i, (cache_i + 2) / 2);
   L.ints = o;
 #undef A_
   int io = 0;

@@ -130,7 +130,7 @@ struct Lay {
   int efc_J, efc_JA, efc_D, efc_R, efc_aref, efc_force, efc_jar, efc_jv, efc_floss, efc_pos, efc_margin, efc_diag;
   int contact;
   int Ma, grad, Mgrad, search, Mv, vtmp, sgl;
-  int knot_times, knot_values, residual, terms, red, prof;
+  int knot_times, knot_values, residual, terms, red, prof, scr_a, scr_b;
   int xfrc;            // external body forces (NoisyRollout of the robust planner), 6 per body
   int mc_d, mc_i;      // LDS copy of the model tables: fp64 part, int part (both offsets in doubles)
   int ints;            // start of the int region (in doubles)

@@ -509,7 +509,7 @@ DEV void newton_gradient(Ctx &c, int grad_only) {
 template <int NVT>
 DEV double cost_at_smooth(Ctx &c) {
   double *jar = c.efc_pos;
-  mat_rows_times<NVT>(c, c.qacc_smooth, c.cfrc_sub, jar);       // M x lands in a scratch nobody reads during the solve (recomputed every step)
+  mat_rows_times<NVT>(c, c.qacc_smooth, c.scr_b, jar);       // M x lands in a scratch nobody reads during the solve (recomputed every step)
   PFOR(r, c.nefc) jar[r] -= c.efc_aref[r];
   SYNC();
   double part = c.M->maxdim <= 3 ? constraint_update<3, false>(c, 0, jar) : constraint_update<6, false>(c, 0, jar);

@@ -853,18 +853,21 @@ def test_cpp_sampling_planner_sharded_over_engines_matches_the_unsharded_planner
 
 
 @pytest.mark.gpu
-def test_dense_tier_is_bit_identical_to_full_capacity_and_retries_what_overflows(monkeypatch):
+@pytest.mark.parametrize("workload", ["quadruped", "humanoid"])
+def test_dense_tier_is_bit_identical_to_full_capacity_and_retries_what_overflows(monkeypatch, workload):
     """Capacity tiers (engine.hip): more candidates than CUs -> the two-workgroups-per-CU flavour (<= 80 KiB of LDS, smaller
     contact / row buffers) runs first and the full-capacity kernel re-runs whatever overflowed.  Returns, failure flags, winner
     and every trajectory must equal the full-capacity-only plan bit for bit - also when the dense tier is made so small
     (test knob) that most candidates overflow it and take the retry pass."""
-    m, task, d = quadruped()
-    N, H, P = 300, 40, 3
+    # (the lean layout overlays the inertia / RNE intermediates with the solver's scaled rows: any lifetime overlap would show here)
+    m, task, d = quadruped() if workload == "quadruped" else humanoid_track()
+    N, H, P = (300, 40, 3) if workload == "quadruped" else (280, 48, 6)
+    sigma, tiny, rows = (0.04, "40,8", 40) if workload == "quadruped" else (0.15, "24,8", 24)
     kt = np.linspace(0, (H - 1) * m["timestep"], P); kv = np.zeros((P, m["nu"]))
     kw = dict(state=d["state"], mocap=d["mocap"], time=0.0, knot_times=kt, knot_values=kv, interpolation=2, num_trajectory=N,
-              horizon=H, sigma=(0.04, 0.0), seed=0x5EED, stream=7)
+              horizon=H, sigma=(sigma, 0.0), seed=0x5EED, stream=7)
     res = {}
-    for name, env in (("full", {"MJPC_HIP_TIER": "A"}), ("auto", {}), ("tiny", {"MJPC_HIP_TIERB_CAP": "40,8"})):
+    for name, env in (("full", {"MJPC_HIP_TIER": "A"}), ("auto", {}), ("tiny", {"MJPC_HIP_TIERB_CAP": tiny})):
         for k in ("MJPC_HIP_TIER", "MJPC_HIP_TIERB_CAP"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
@@ -877,7 +880,7 @@ def test_dense_tier_is_bit_identical_to_full_capacity_and_retries_what_overflows
     assert res["full"][3] is False and res["auto"][3] is True and res["tiny"][3] is True
     assert 0 < res["auto"][2] <= 80 * 1024
     assert not res["full"][0]["failure"].any()
-    assert res["full"][1]["diag"][:, 2].max() > 40              # rows per step exceed the tiny tier: its candidates were retried
+    assert res["full"][1]["diag"][:, 2].max() > rows            # rows per step exceed the tiny tier: its candidates were retried
     for name in ("auto", "tiny"):
         a, b = res["full"], res[name]
         assert np.array_equal(a[0]["returns"], b[0]["returns"]) and np.array_equal(a[0]["failure"], b[0]["failure"])

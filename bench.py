@@ -18,6 +18,7 @@ Prints ONE JSON line (rank 0) with `roofline` (rollout_kernel, HIP-event timed o
 box's host cores at T = 1, T = physical cores and T = hw-5 threads, bounded sample).
 """
 import argparse
+import gc
 import json
 import os
 import statistics
@@ -231,6 +232,9 @@ def main():
             knots = step(i, knots)["winner_knots"]
         be.kernel_time()                       # reset the HIP-event accumulators
         per_step = []; noise_us = []; roll_us = []
+        # no cyclic garbage collection inside the timed region (as timeit does): with torch imported a full collection costs
+        # ~40 ms of host time, and one used to land in the first ten plan steps of every run
+        gc.collect(); gc.disable()
         sync()
         t0 = time.perf_counter()
         for i in range(steps):
@@ -241,11 +245,15 @@ def main():
             noise_us.append(res["local"]["noise_compute_time_us"]); roll_us.append(res["local"]["rollouts_compute_time_us"])
         sync()
         elapsed = time.perf_counter() - t0
+        gc.enable()
         if world > 1:
             tt = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             elapsed = float(tt.item())
         nlaunch, rollout_us, total_us = be.kernel_time()
+        if os.environ.get("BENCH_DEBUG") and rank == 0:
+            print("per-step ms:", " ".join(f"{1e3 * x:.2f}" for x in per_step), file=sys.stderr)
+            print("rollout ms: ", " ".join(f"{1e-3 * x:.2f}" for x in roll_us), file=sys.stderr)
         rec = dict(n_per_rank=n_per_rank, elapsed=elapsed, steps=steps, rollout_us=rollout_us, total_us=total_us, launches=nlaunch,
                    median_ms=1e3 * statistics.median(per_step), lds=be.lds_bytes(), winner=res["winner"], winner_return=res["winner_return"],
                    phases_ms=dict(noise=1e-3 * statistics.median(noise_us), rollouts=1e-3 * statistics.median(roll_us),

@@ -16,6 +16,11 @@ python3 $R/bench.py --samples 1024 --no-cpu-baseline --no-secondary --steps 20 >
 rocprofv3 --kernel-trace --stats -d $O/stats512 -o s --output-format csv -- python3 $R/bench.py --samples 512 --steps 10 --warmup 2 --no-cpu-baseline --no-secondary > /dev/null 2> $O/stats512.err
 echo "dense tier done"
 python3 $R/bench.py --workload humanoid --steps 10 --warmup 3 --no-secondary > $O/bench_humanoid.json 2> $O/bench_humanoid.err
+MJPC_HIP_TIER=A python3 $R/bench.py --workload humanoid --steps 6 --warmup 2 --no-secondary --no-cpu-baseline > $O/bench_humanoid_tierA.json 2>> $O/bench_humanoid.err
+rocprofv3 --kernel-trace --stats -d $O/stats_humanoid -o s --output-format csv -- python3 $R/bench.py --workload humanoid --steps 6 --warmup 2 --no-cpu-baseline --no-secondary > /dev/null 2> $O/stats_humanoid.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_fetch_humanoid -o p --output-format csv -- python3 $R/bench.py --workload humanoid --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > /dev/null 2> $O/pmc_fetch_humanoid.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pmc_write_humanoid -o p --output-format csv -- python3 $R/bench.py --workload humanoid --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > /dev/null 2> $O/pmc_write_humanoid.err
+echo "humanoid done"
 python3 $R/bench.py --workload hand --samples 256 --steps 20 --warmup 3 --no-secondary > $O/bench_hand_256.json 2> $O/bench_hand.err
 python3 $R/bench.py --workload hand --samples 2048 --steps 5 --warmup 2 --no-secondary --no-cpu-baseline > $O/bench_hand_2048.json 2>> $O/bench_hand.err
 rocprofv3 --kernel-trace --stats -d $O/stats_hand -o s --output-format csv -- python3 $R/bench.py --workload hand --samples 256 --steps 10 --warmup 2 --no-cpu-baseline --no-secondary > /dev/null 2> $O/stats_hand.err

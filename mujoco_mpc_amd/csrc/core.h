@@ -1514,6 +1514,29 @@ DEV void vel_compose(Ctx &c, int i, double *cvel, double *a, int store) {
   d_scl3(c.bodytmp + 3 * i, v, MD(body_mass)[i]);
 }
 
+// subtree sums of the body forces / momenta left by the sweep.  part 0: cfrc_sub components 0..2; part 1: components 3..5 and
+// subtree_linvel
+#define HX_SWEEP 27      // sweep done (side wave -> last helper), value t + 1
+#define HX_SUBSUM 19     // the helper's part of the subtree sums done, value t + 1
+DEV void subtree_sums(Ctx &c, int part) {
+  const DevModel &M = *c.M;
+  int per = part ? 6 : 3;
+  PFOR(e, M.nbody * per) {
+    int b = e / per, k = e - per * b;
+    if (k < 3) {
+      int kc = k + 3 * part;
+      double s = 0;
+      if (b > 0) for (int q = MI(subtree_adr)[b]; q < MI(subtree_adr)[b + 1]; q++) s += c.cfrc[6 * MI(subtree_list)[q] + kc];
+      c.cfrc_sub[6 * b + kc] = s;
+    } else {
+      int kk = k - 3;
+      double s = 0;
+      for (int q = MI(subtree_adr)[b]; q < MI(subtree_adr)[b + 1]; q++) s += c.bodytmp[3 * MI(subtree_list)[q] + kk];
+      c.subtree_linvel[3 * b + kk] = s / fmax(D_MINVAL, MD(body_subtreemass)[b]);
+    }
+  }
+}
+
 // mfact_seq != 0: M's factor is produced by a helper wave; wait for its sequence number (misc[22]) before the solve
 template <int NVT>
 DEV void velocity_stage(Ctx &c, int mfact_seq) {
@@ -1546,19 +1569,14 @@ DEV void velocity_stage(Ctx &c, int mfact_seq) {
     }
   }
   PROFW(c, 1);
-  PFOR(e, M.nbody * 9) {
-    int b = e / 9, k = e - 9 * b;
-    if (k < 6) {
-      double s = 0;
-      if (b > 0) for (int q = MI(subtree_adr)[b]; q < MI(subtree_adr)[b + 1]; q++) s += c.cfrc[6 * MI(subtree_list)[q] + k];
-      c.cfrc_sub[6 * b + k] = s;
-    } else {
-      int kk = k - 6;
-      double s = 0;
-      for (int q = MI(subtree_adr)[b]; q < MI(subtree_adr)[b + 1]; q++) s += c.bodytmp[3 * MI(subtree_list)[q] + kk];
-      c.subtree_linvel[3 * b + kk] = s / fmax(D_MINVAL, MD(body_subtreemass)[b]);
-    }
-  }
+#if MJPC_HELPER
+  // the subtree sums are shared with the last helper wave (idle by now, ph_noncontact): it takes the torque half of cfrc_sub and
+  // the subtree momenta, this wave the force half; every element is summed by one lane in list order, as before
+  flag_set(c.misc + HX_SWEEP, mfact_seq);
+  subtree_sums(c, 0);
+#else
+  subtree_sums(c, 0); subtree_sums(c, 1);
+#endif
   PROFW(c, 4);
   // actuator forces
   PFOR(i, M.nu) {
@@ -1585,6 +1603,9 @@ DEV void velocity_stage(Ctx &c, int mfact_seq) {
     if (MI(actuator_forcelimited)[i]) force = d_clip(force, MD(actuator_forcerange)[2 * i], MD(actuator_forcerange)[2 * i + 1]);
     c.actuator_force[i] = force;
   }
+#if MJPC_HELPER
+  if (!flag_wait(c.misc + HX_SUBSUM, mfact_seq)) c.warning |= WARN_SYNC;
+#endif
   SYNC();
   PFOR(d, nv) {
     const double *cd = c.cdof + 6 * d, *cf = c.cfrc_sub + 6 * MI(dof_bodyid)[d];
@@ -2222,6 +2243,11 @@ DEV_NOINLINE void ph_noncontact(KP Kc, int t) {
   PROFW(c, 1);
   make_impedance(c, 0, n_nc, 0);
   PROFW(c, 4);
+  // then its part of the side wave's subtree sums (velocity_stage)
+  if (!flag_wait(c.misc + HX_SWEEP, t + 1)) c.warning |= WARN_SYNC;
+  subtree_sums(c, 1);
+  flag_set(c.misc + HX_SUBSUM, t + 1);
+  PROFW(c, 5);
   ctx_close(c);
 }
 #endif
@@ -2247,8 +2273,15 @@ DEV_NOINLINE void ph_inertia(KP Kc, int t) {
   ctx_close(c);
 }
 #endif
+// (inlining it into the kernel trades the ~100 callee-saved register saves per call for register pressure in the hot loops:
+// measured 1 % slower with one candidate per CU; MJPC_INLINE_SOLVE is the A/B switch)
+#ifdef MJPC_INLINE_SOLVE
+#define DEV_SOLVE_PHASE DEV
+#else
+#define DEV_SOLVE_PHASE DEV_NOINLINE
+#endif
 template <int NVT>
-DEV_NOINLINE void ph_solve(KP Kc, int last, int t) {          // (inlining it into the kernel trades the ~100 callee-saved spills for AGPR traffic in the hot loops: measured 1% slower)
+DEV_SOLVE_PHASE void ph_solve(KP Kc, int last, int t) {
   Ctx c; ctx_open(c, Kc);
   c.hseq = t * 256;
   solve_constraints<NVT>(c); PROF(c, 8);

@@ -25,6 +25,7 @@ def run(gen, N, H, P, sigma, reps):
     be.close()
     return 1e3 * dt / reps, us / 1e3, r['winner'], r['winner_return']
 print({os.path.basename(lib)!r}, 'C2 ms/plan %.3f kernel %.3f winner %d ret %.12g' % run(quadruped, 256, 100, 3, 0.04, 30), flush=True)
+if {('Q512' in os.environ)!r}: print('   Q512 ms/plan %.3f kernel %.3f winner %d ret %.12g' % run(quadruped, 512, 100, 3, 0.04, 20), flush=True)
 if {('C3' in os.environ)!r}: print('   C3 ms/plan %.3f kernel %.3f winner %d ret %.12g' % run(humanoid_track, 1024, 128, 16, 0.15, 5), flush=True)
 """
     subprocess.run([sys.executable, "-c", code], check=False, timeout=300)

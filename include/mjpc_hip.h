@@ -125,6 +125,9 @@ typedef struct MjpcHipModel {
   /* fixed tendons (wrap objects are joints; wrap_prm = coefficient) */
   const int *tendon_adr, *tendon_num, *tendon_limited, *wrap_objid;
   const double *wrap_prm, *tendon_range, *tendon_margin, *tendon_solref_lim, *tendon_solimp_lim, *tendon_invweight0;
+  /* passive tendon forces (mj_passive): spring with a dead band [lengthspring[2t], lengthspring[2t+1]], damper; [ntendon] each,
+   * NULL = none.  tendon_frictionloss > 0 is refused (no tendon friction rows). */
+  const double *tendon_stiffness, *tendon_damping, *tendon_lengthspring, *tendon_frictionloss;
   /* keyframes */
   const double *key_qpos;           /* nkey * nq */
   const double *key_mpos;           /* nkey * 3*nmocap */
@@ -213,8 +216,8 @@ typedef struct MjpcHipEngine MjpcHipEngine;
 /* Create an engine on HIP device `device`.  Copies model+task to HBM.  max_local = largest
  * num_local that will be planned on this device.  Returns NULL on error (see last_error).
  * Models the engine cannot roll out faithfully are REFUSED here (never silently approximated): geom pairs without a
- * collider (hfield / ellipsoid / mesh, cylinder against anything but a plane), limited ball joints, nuserdata > 0,
- * na > 0, nconmax > 64, nefcmax > 192, iterations > 250, num_spline_points capacity 36, LDS footprint > 160 KiB. */
+ * collider (hfield / ellipsoid / mesh that can collide), tendon friction loss, actuator transmissions other than joint /
+ * fixed tendon, nuserdata > 0, na > 0, nconmax > 64, nefcmax > 192, iterations > 250, num_spline_points capacity 36, LDS footprint > 160 KiB. */
 MjpcHipEngine *mjpc_hip_create(const MjpcHipModel *model, const MjpcHipTask *task,
                                int max_local, int max_horizon, int device);
 void mjpc_hip_destroy(MjpcHipEngine *e);

@@ -97,6 +97,8 @@ static void FillModelView(const mjModel* m, MjpcHipModel& v, std::vector<int>& j
   v.wrap_objid = wrap_objid.data(); v.wrap_prm = wrap_prm.data(); v.tendon_range = m->tendon_range;
   v.tendon_margin = m->tendon_margin; v.tendon_solref_lim = m->tendon_solref_lim; v.tendon_solimp_lim = m->tendon_solimp_lim;
   v.tendon_invweight0 = m->tendon_invweight0;
+  v.tendon_stiffness = m->tendon_stiffness; v.tendon_damping = m->tendon_damping; v.tendon_lengthspring = m->tendon_lengthspring;
+  v.tendon_frictionloss = m->tendon_frictionloss;
   v.key_qpos = m->key_qpos; v.key_mpos = m->key_mpos;
 }
 

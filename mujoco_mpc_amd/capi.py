@@ -17,6 +17,7 @@ c_double_p = C.POINTER(C.c_double)
 c_int_p = C.POINTER(C.c_int)
 
 _MODEL_INT_SIZES = ["nq", "nv", "nu", "na", "nbody", "njnt", "ngeom", "nsite", "nmocap", "nuserdata", "nkey", "nexclude", "ntendon", "nwrap"]
+_OPTIONAL_TENDON = ("tendon_stiffness", "tendon_damping", "tendon_lengthspring", "tendon_frictionloss")
 _MODEL_INT_ARRAYS_BODY = ["body_parentid", "body_rootid", "body_weldid", "body_mocapid", "body_jntnum", "body_jntadr",
                           "body_dofnum", "body_dofadr"]
 _MODEL_DBL_ARRAYS_BODY = ["body_pos", "body_quat", "body_ipos", "body_iquat", "body_mass", "body_subtreemass",
@@ -48,7 +49,8 @@ class MjpcHipModel(C.Structure):
                                      "actuator_forcerange"]]
         + [(n, c_int_p) for n in ["tendon_adr", "tendon_num", "tendon_limited", "wrap_objid"]]
         + [(n, c_double_p) for n in ["wrap_prm", "tendon_range", "tendon_margin", "tendon_solref_lim", "tendon_solimp_lim",
-                                     "tendon_invweight0"]]
+                                     "tendon_invweight0", "tendon_stiffness", "tendon_damping", "tendon_lengthspring",
+                                     "tendon_frictionloss"]]
         + [("key_qpos", c_double_p), ("key_mpos", c_double_p)]
     )
 
@@ -102,7 +104,10 @@ class CModel:
         self._keep = []
         m = MjpcHipModel()
         for name, ctype in MjpcHipModel._fields_:
-            v = model[name]
+            if name in _OPTIONAL_TENDON and name not in model:       # models built before these fields existed: no passive tendon forces
+                v = np.zeros(int(model["ntendon"]) * (2 if name == "tendon_lengthspring" else 1))
+            else:
+                v = model[name]
             if ctype is c_double_p:
                 arr = np.ascontiguousarray(np.asarray(v, dtype=np.float64).ravel())
                 if arr.size == 0:

@@ -1157,6 +1157,20 @@ DEV double impedance(const double *solimp_in, double pos, double margin) {
 
 // rows that need no contact (friction loss, joint limits, fixed-tendon limits): rows [0, n_nc), incl. their Jacobian.
 // A helper wave builds them (and their impedance) while the owner wave is still in the collision phase.
+// rotation axis (unit; (1,0,0) for a null rotation) and angle of a unit quaternion, as mju_quat2Vel(quat, 1) followed by
+// mju_normalize3 give them
+DEV double ball_angle(double *axis, const double *quat) {
+  axis[0] = quat[1]; axis[1] = quat[2]; axis[2] = quat[3];
+  double s = sqrt(axis[0] * axis[0] + axis[1] * axis[1] + axis[2] * axis[2]);
+  if (s < D_MINVAL) { axis[0] = 1; axis[1] = 0; axis[2] = 0; } else { axis[0] /= s; axis[1] /= s; axis[2] /= s; }
+  double speed = 2 * atan2(s, quat[0]);
+  if (speed > D_PI) speed -= 2 * D_PI;
+  double v[3] = {axis[0] * speed, axis[1] * speed, axis[2] * speed};
+  double n = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+  if (n < D_MINVAL) { axis[0] = 1; axis[1] = 0; axis[2] = 0; } else { axis[0] = v[0] / n; axis[1] = v[1] / n; axis[2] = v[2] / n; }
+  return n;
+}
+
 DEV void make_noncontact_rows(Ctx &c, int *nsingle_out, int *n_nc_out) {
   const DevModel &M = *c.M;
   int nv = M.nv, nvp = M.nvp;
@@ -1193,6 +1207,30 @@ DEV void make_noncontact_rows(Ctx &c, int *nsingle_out, int *n_nc_out) {
     nefc += tot;
   }
   int nlim_end = nefc;
+  // ball-joint limits (mj_instantiateLimit): rotation angle of the joint quaternion against max(range), J = -axis at its three
+  // dofs: general rows, kept behind the single-entry rows (MuJoCo interleaves them in joint order; same constraint set)
+  for (int base = 0; base < M.nlimit_ball; base += NLANE) {
+    int q = base + LANE, cnt = 0, j = 0;
+    double dist = 0;
+    if (q < M.nlimit_ball) {
+      j = MI(limit_ball)[q];
+      double axis[3];
+      double angle = ball_angle(axis, c.qpos + MI(jnt_qposadr)[j]);
+      dist = fmax(MD(jnt_range)[2 * j], MD(jnt_range)[2 * j + 1]) - angle;
+      if (dist < MD(jnt_margin)[j]) cnt = 1;
+    }
+    int tot, off = wave_excl_scan(cnt, &tot);
+    if (nefc + tot > M.nefcmax) { c.warning |= WARN_CNSTRFULL; break; }
+    if (cnt) {
+      int r = nefc + off;
+      c.efc_type[r] = CNSTR_LIMIT_JOINT; c.efc_id[r] = j; c.efc_dof[r] = MI(jnt_dofadr)[j];
+      c.efc_floss[r] = 0;
+      c.efc_pos[r] = dist; c.efc_margin[r] = MD(jnt_margin)[j];
+      c.efc_diag[r] = MD(dof_invweight0)[MI(jnt_dofadr)[j]];
+    }
+    nefc += tot;
+  }
+  int nball_end = nefc;
   // fixed-tendon limits (general rows: several Jacobian entries), lower side before upper side
   int ntl0 = nefc;
   for (int base = 0; base < M.ntendon; base += NLANE) {
@@ -1234,6 +1272,12 @@ DEV void make_noncontact_rows(Ctx &c, int *nsingle_out, int *n_nc_out) {
     c.efc_J[r * nvp + MI(jnt_dofadr)[c.efc_id[r]]] = c.efc_floss[r]; c.efc_floss[r] = 0;
   }
 #endif
+  PFOR(rr, nball_end - nlim_end) {
+    int r = nlim_end + rr, j = c.efc_id[r], da = MI(jnt_dofadr)[j];
+    double axis[3];
+    ball_angle(axis, c.qpos + MI(jnt_qposadr)[j]);
+    for (int k = 0; k < 3; k++) c.efc_J[r * nvp + da + k] = -axis[k];
+  }
   PFOR(rr, ntl_end - ntl0) {
     int r = ntl0 + rr, t = c.efc_id[r];
     double sg = c.efc_floss[r];
@@ -1287,7 +1331,7 @@ DEV void make_contact_rows(Ctx &c, int n_nc) {
     unsigned long long u = m1 | m2;
     if (u != m1 && u != m2) crossflag = 1;
   }
-  c.cross = wave_or_i(crossflag);
+  c.cross = wave_or_i(crossflag) | M.limit_cross;
   SYNC();
   // Jacobian
   PFOR(e, (nefc - n_nc) * nvp) c.efc_J[n_nc * nvp + e] = 0;
@@ -1625,6 +1669,29 @@ DEV void velocity_stage(Ctx &c, int mfact_seq) {
     }
   }
   SYNC();
+  if (M.ntendon_passive > 0) {
+    // tendon springs (dead band) and dampers, mj_passive: one lane per dof gathers J^T force over the (few) passive tendons
+    PFOR(d, nv) {
+      double acc = c.qfrc_smooth[d];
+      for (int e = 0; e < M.ntendon_passive; e++) {
+        int t = MI(tpass_id)[e];
+        double coef = 0, length = 0, velocity = 0;
+        for (int w = MI(tendon_adr)[t]; w < MI(tendon_adr)[t] + MI(tendon_num)[t]; w++) {
+          double cf = MD(wrap_prm)[w];
+          length += cf * c.qpos[MI(wrap_qposadr)[w]]; velocity += cf * c.qvel[MI(wrap_dofadr)[w]];
+          if (MI(wrap_dofadr)[w] == d) coef += cf;
+        }
+        if (coef == 0) continue;
+        const double *pr = MD(tpass_prm) + 4 * e;
+        double frc = 0;
+        if (length > pr[3]) frc = pr[0] * (pr[3] - length); else if (length < pr[2]) frc = pr[0] * (pr[2] - length);
+        frc -= pr[1] * velocity;
+        acc += coef * frc;
+      }
+      c.qfrc_smooth[d] = acc;
+    }
+    SYNC();
+  }
   if (c.K->xfrc_std > 0) {
     // mj_xfrcAccumulate: J^T [force; torque], force applied at the body's inertial frame origin; bodies in ascending order
     PFOR(d, nv) {

@@ -125,8 +125,8 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
   if (m->nefcmax > 192) { p.error = "nefcmax > 192 not supported (line-search rows per lane)"; return false; }
   if (m->nconmax > 64) { p.error = "nconmax > 64 not supported (one contact per lane in the solver)"; return false; }
   if (m->iterations > 250) { p.error = "solver iterations > 250 not supported (hand-shake sequence numbers)"; return false; }
-  for (int j = 0; j < nj; j++)
-    if (m->jnt_limited[j] && m->jnt_type[j] == MJPC_JNT_BALL) { p.error = "limited ball joints are not supported (joint " + std::to_string(j) + ")"; return false; }
+  for (int t = 0; t < m->ntendon; t++)
+    if (m->tendon_frictionloss && m->tendon_frictionloss[t] > 0) { p.error = "tendon " + std::to_string(t) + ": tendon friction loss is not supported (no tendon friction rows)"; return false; }
   for (int i = 0; i < nu; i++)
     if (m->actuator_trntype[i] != MJPC_TRN_JOINT && m->actuator_trntype[i] != MJPC_TRN_TENDON) {
       p.error = "actuator " + std::to_string(i) + ": only joint and fixed-tendon transmissions are supported"; return false; }
@@ -288,13 +288,36 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
     }
     M.npair = (int)g1s.size();
     M.pair_g1 = as_off<int>(put_i(p, g1s.data(), g1s.size())); M.pair_g2 = as_off<int>(put_i(p, g2s.data(), g2s.size())); }
-  { std::vector<int> fr, lim, ray;
+  { std::vector<int> fr, lim, limb, ray;
     for (int i = 0; i < nv; i++) if (m->dof_frictionloss[i] > 0) fr.push_back(i);
     for (int j = 0; j < nj; j++) if (m->jnt_limited[j] && (m->jnt_type[j] == MJPC_JNT_SLIDE || m->jnt_type[j] == MJPC_JNT_HINGE)) lim.push_back(j);
+    for (int j = 0; j < nj; j++) if (m->jnt_limited[j] && m->jnt_type[j] == MJPC_JNT_BALL) limb.push_back(j);
     for (int g = 0; g < ng; g++) if (m->geom_group[g] == 0) ray.push_back(g);
-    M.nfric = (int)fr.size(); M.nlimit = (int)lim.size(); M.nray = (int)ray.size();
+    M.nfric = (int)fr.size(); M.nlimit = (int)lim.size(); M.nlimit_ball = (int)limb.size(); M.nray = (int)ray.size();
     M.fric_dof = as_off<int>(put_i(p, fr.data(), fr.size())); M.limit_jnt = as_off<int>(put_i(p, lim.data(), lim.size()));
+    M.limit_ball = as_off<int>(put_i(p, limb.data(), limb.size()));
     M.ray_geom = as_off<int>(put_i(p, ray.data(), ray.size())); }
+  // a limited tendon whose joints do not lie on one branch of the elimination tree puts entries outside the Hessian's pattern
+  M.limit_cross = 0;
+  for (int t = 0; t < m->ntendon; t++) if (m->tendon_limited[t])
+    for (int w1 = m->tendon_adr[t]; w1 < m->tendon_adr[t] + m->tendon_num[t]; w1++)
+      for (int w2 = m->tendon_adr[t]; w2 < w1; w2++) {
+        int a = m->jnt_dofadr[m->wrap_objid[w1]], b = m->jnt_dofadr[m->wrap_objid[w2]];
+        if (a < b) std::swap(a, b);
+        bool anc = false;
+        for (int k = a; k >= 0; k = pattern_parent(nv, M.tree_ok, m->dof_parentid, k)) if (k == b) anc = true;
+        if (!anc) M.limit_cross = 1;
+      }
+  // tendons with passive forces
+  { std::vector<int> ids; std::vector<double> prm;
+    for (int t = 0; t < m->ntendon; t++) {
+      double k = m->tendon_stiffness ? m->tendon_stiffness[t] : 0, b = m->tendon_damping ? m->tendon_damping[t] : 0;
+      if (k == 0 && b == 0) continue;
+      ids.push_back(t); prm.push_back(k); prm.push_back(b);
+      prm.push_back(m->tendon_lengthspring ? m->tendon_lengthspring[2 * t] : 0); prm.push_back(m->tendon_lengthspring ? m->tendon_lengthspring[2 * t + 1] : 0);
+    }
+    M.ntendon_passive = (int)ids.size();
+    M.tpass_id = as_off<int>(put_i(p, ids.data(), ids.size())); M.tpass_prm = as_off<double>(put_d(p, prm.data(), prm.size())); }
   M.any_damping = 0;
   for (int i = 0; i < nv; i++) if (m->dof_damping[i] > 0) M.any_damping = 1;
   if (M.nefcmax < M.nfric + 2) M.nefcmax = M.nfric + 2;
@@ -336,7 +359,7 @@ static inline DevModel relocate(const PackedModel &p, const int *ibase, const do
   fi(M.level_adr); fi(M.level_body); fi(M.subtree_adr); fi(M.subtree_list); fi(M.chain_adr); fi(M.chain_list); fi(M.mpair_i); fi(M.mpair_j); fi(M.hpair_i); fi(M.hpair_j); fi(M.zpair_i); fi(M.zpair_j);
   { const double *q = reinterpret_cast<const double *>(M.body_dofmask); fd(q); M.body_dofmask = reinterpret_cast<const unsigned long long *>(q); }
   { const double *q = reinterpret_cast<const double *>(M.body_patmask); fd(q); M.body_patmask = reinterpret_cast<const unsigned long long *>(q); }
-  fi(M.pair_g1); fi(M.pair_g2); fi(M.fric_dof); fi(M.limit_jnt); fi(M.ray_geom);
+  fi(M.pair_g1); fi(M.pair_g2); fi(M.fric_dof); fi(M.limit_jnt); fi(M.limit_ball); fi(M.ray_geom); fi(M.tpass_id); fd(M.tpass_prm);
   DevTask &T = M.task;
   fi(T.dim_norm_residual); fi(T.norm); fi(T.num_norm_parameter); fi(T.trace_objtype); fi(T.trace_objid); fi(T.int_data);
   fd(T.weight); fd(T.norm_parameter); fd(T.parameters); fd(T.dbl_data);

@@ -86,6 +86,9 @@ struct DevTask {
 struct DevModel {
   int nq, nv, nu, nbody, njnt, ngeom, nsite, nmocap, nkey, nvp, ntendon;
   int nlevel, npair, nfric, nlimit, nray, nmpair, nhpair, nzpair, nconmax, nefcmax, any_damping;
+  int nlimit_ball;      // limited ball joints (limit_ball[])
+  int limit_cross;      // some limited tendon couples dofs outside the Hessian's pattern: every build is a dense one
+  int ntendon_passive;  // tendons with a spring or a damper (tpass_*)
   int cone, iterations, ls_iterations, disableflags, con_stride, maxdim, tree_ok, nact;
   double timestep, gravity[3], impratio, tolerance, ls_tolerance, meaninertia;
   const int *body_parentid, *body_rootid, *body_mocapid, *body_jntnum, *body_jntadr, *body_dofnum, *body_dofadr;
@@ -105,6 +108,8 @@ struct DevModel {
   const double *actuator_gainprm, *actuator_biasprm, *actuator_gear, *actuator_ctrlrange, *actuator_forcerange;
   const int *tendon_adr, *tendon_num, *tendon_limited, *wrap_dofadr, *wrap_qposadr;
   const double *wrap_prm, *tendon_range, *tendon_margin, *tendon_solref_lim, *tendon_solimp_lim, *tendon_invweight0;
+  const int *tpass_id;                      // tendons with passive forces
+  const double *tpass_prm;                  // [4 each] stiffness, damping, spring dead band lo / hi
   const double *key_qpos, *key_mpos;
   // derived on the host at create()
   const int *level_adr, *level_body;        // bodies grouped by tree depth (depth >= 1)
@@ -116,7 +121,7 @@ struct DevModel {
   const unsigned long long *body_dofmask;   // bit d set <=> dof d moves body
   const unsigned long long *body_patmask;   // the same along the elimination tree (hub dofs included): cross-branch test of a contact
   const int *pair_g1, *pair_g2;             // statically filtered geom pairs (type1 <= type2)
-  const int *fric_dof, *limit_jnt, *ray_geom;
+  const int *fric_dof, *limit_jnt, *limit_ball, *ray_geom;
   DevTask task;
 };
 

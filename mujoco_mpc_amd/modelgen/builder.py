@@ -202,10 +202,13 @@ class ModelBuilder:
         self.actuator(name, joint=joint, tendon=tendon, gainprm=(kp, 0, 0), biastype=1, biasprm=(0, -kp, 0), gear=gear,
                       ctrlrange=ctrlrange, forcelimited=forcerange is not None, forcerange=forcerange or (0, 0))
 
-    def tendon(self, name, joints, coefs, limited=False, range=(0, 0), margin=0.0, solreflimit=DEF_SOLREF, solimplimit=DEF_SOLIMP):
-        """fixed tendon: length = sum coef * qpos[joint]"""
+    def tendon(self, name, joints, coefs, limited=False, range=(0, 0), margin=0.0, solreflimit=DEF_SOLREF, solimplimit=DEF_SOLIMP,
+               stiffness=0.0, damping=0.0, springlength=None, frictionloss=0.0):
+        """fixed tendon: length = sum coef * qpos[joint]; passive spring (dead band `springlength` = value or (lo, hi); None = the
+        length at qpos0, MJCF's springlength="-1") and damper"""
         self.tendons.append(dict(name=name, joints=list(joints), coefs=list(coefs), limited=limited, range=tuple(range), margin=margin,
-                                 solref=tuple(solreflimit), solimp=tuple(solimplimit)))
+                                 solref=tuple(solreflimit), solimp=tuple(solimplimit), stiffness=float(stiffness), damping=float(damping),
+                                 springlength=springlength, frictionloss=float(frictionloss)))
 
     def key(self, name, qpos):
         self.keys.append((name, np.array(qpos, float)))
@@ -443,6 +446,18 @@ class ModelBuilder:
         M["tendon_margin"] = np.array([t["margin"] for t in T], float)
         M["tendon_solref_lim"] = np.array([t["solref"] for t in T], float).reshape(len(T), 2)
         M["tendon_solimp_lim"] = np.array([t["solimp"] for t in T], float).reshape(len(T), 5)
+        M["tendon_stiffness"] = np.array([t.get("stiffness", 0.0) for t in T], float)
+        M["tendon_damping"] = np.array([t.get("damping", 0.0) for t in T], float)
+        M["tendon_frictionloss"] = np.array([t.get("frictionloss", 0.0) for t in T], float)
+        ls = np.zeros((len(T), 2))
+        for ti, t in enumerate(T):
+            sl = t.get("springlength")
+            if sl is None:            # resting length = the tendon's length at qpos0 (mjModel set0)
+                l0 = sum(cf * M["qpos0"][jnt_qposadr[wrap_objid[tadr[ti] + k]]] for k, cf in enumerate(t["coefs"]))
+                ls[ti] = (l0, l0)
+            else:
+                ls[ti] = (sl, sl) if np.isscalar(sl) else tuple(sl)
+        M["tendon_lengthspring"] = ls
         sizes = dict(nq=nq, nv=nv, nu=nu, na=0, nbody=nb, njnt=nj, ngeom=ng, nsite=ns, nmocap=nmocap,
                      nuserdata=self.nuserdata, nkey=nkey, nexclude=len(self.excludes), ntendon=len(self.tendons),
                      nwrap=len(wrap_objid))

@@ -242,6 +242,12 @@ def parse_mjcf(path_or_text, base_dir=None, reader=None, missing_ok=()):
                 kw["solreflimit"] = tuple(_floats(a["solreflimit"]))
             if "solimplimit" in a:
                 v = _floats(a["solimplimit"]); kw["solimplimit"] = tuple(v + [0.9, 0.95, 0.001, 0.5, 2][len(v):])
+            for k in ("stiffness", "damping", "frictionloss", "margin"):
+                if k in a:
+                    kw[k] = float(a[k])
+            if "springlength" in a:
+                sl = _floats(a["springlength"])
+                kw["springlength"] = None if sl[0] < 0 else (sl[0] if len(sl) == 1 else (sl[0], sl[1]))
             b.tendon(a.get("name", ""), joints, coefs, **kw)
 
     for ct in root.findall("contact"):

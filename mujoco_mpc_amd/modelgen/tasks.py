@@ -476,4 +476,35 @@ def shadow_hand(timestep=0.01, cone=0, nconmax=32, nefcmax=128):
     return m, task, defaults
 
 
-REGISTRY = {"humanoid_stand": humanoid_stand, "humanoid_walk": humanoid_walk, "particle": particle, "cartpole": cartpole, "quadruped": quadruped, "humanoid_track": humanoid_track, "shadow_hand": shadow_hand}
+# ----------------------------------------------------------------------------------- a7 features off the BASELINE models
+def ball_chain(timestep=0.005):
+    """Small test model for the mj_step features no BASELINE model has: limited ball joints and a fixed tendon with a spring, a
+    damper and a limit that couples joints on DIFFERENT branches (its limit row lies outside M's sparsity pattern).  The residual
+    copies the state (TASK_COPYSTATE)."""
+    b = ModelBuilder(timestep=timestep, gravity=(0, 0, -9.81), contact=True)
+    b.geom(0, "floor", PLANE, pos=(0, 0, -1.2), size=(2, 2, 0.1))
+    l1 = b.body("l1", 0, pos=(0, 0, 0))
+    b.joint(l1, "b1", BALL, limited=True, range=(0, 0.5), damping=0.05)
+    b.geom(l1, "g1", CAPSULE, size=(0.04, 0), fromto=(0, 0, 0, 0, 0, -0.4), mass=1.0)
+    l2 = b.body("l2", l1, pos=(0, 0, -0.4))
+    b.joint(l2, "b2", BALL, limited=True, range=(0, 0.7), margin=0.02, damping=0.05)
+    b.geom(l2, "g2", CAPSULE, size=(0.035, 0), fromto=(0, 0, 0, 0, 0, -0.35), mass=0.6)
+    arms = []
+    for name, y in (("ra", -0.1), ("la", 0.1)):
+        a = b.body(name, l1, pos=(0, y, -0.2))
+        b.joint(a, name + "_j", HINGE, axis=(1, 0, 0), damping=0.02, armature=0.01)
+        b.geom(a, name + "_g", CAPSULE, size=(0.02, 0), fromto=(0, 0, 0, 0, 1.5 * y, -0.2), mass=0.2)
+        arms.append(name + "_j")
+    tip = b.site(l2, "tip", pos=(0, 0, -0.35))
+    b.tendon("couple", arms, [1.0, 1.0], limited=True, range=(-0.4, 0.4), stiffness=4.0, damping=0.1, springlength=(-0.05, 0.05))
+    b.actuator("ra_m", "ra_j", gear=1.0, ctrlrange=(-1, 1))
+    b.actuator("la_m", "la_j", gear=1.0, ctrlrange=(-1, 1))
+    m = b.compile()
+    task = make_task(TASK_COPYSTATE, [(10, 0, 1.0), (8, 0, 0.1)], traces=[(OBJ_SITE, tip)])
+    q = np.zeros(m["nq"]); q[0] = 1.0; q[4] = 1.0
+    v = np.zeros(m["nv"]); v[0:3] = [5.0, 2.0, 0.6]; v[3:6] = [-2.0, 4.0, 1.0]; v[6] = 6.0; v[7] = 4.0
+    defaults = dict(N=6, P=4, sigma=(0.4, 0.0), interp=2, horizon=60, state=np.concatenate([q, v]), mocap=np.zeros(0))
+    return m, task, defaults
+
+
+REGISTRY = {"ball_chain": ball_chain, "humanoid_stand": humanoid_stand, "humanoid_walk": humanoid_walk, "particle": particle, "cartpole": cartpole, "quadruped": quadruped, "humanoid_track": humanoid_track, "shadow_hand": shadow_hand}

@@ -60,6 +60,10 @@ OModel *oracle_create(const MjpcHipModel *src, const MjpcHipTask *task) {
   CI(tendon_adr, src->ntendon); CI(tendon_num, src->ntendon); CI(tendon_limited, src->ntendon); CI(wrap_objid, src->nwrap);
   CD(wrap_prm, src->nwrap); CD(tendon_range, 2 * src->ntendon); CD(tendon_margin, src->ntendon);
   CD(tendon_solref_lim, 2 * src->ntendon); CD(tendon_solimp_lim, 5 * src->ntendon); CD(tendon_invweight0, src->ntendon);
+  if (src->tendon_stiffness) CD(tendon_stiffness, src->ntendon);
+  if (src->tendon_damping) CD(tendon_damping, src->ntendon);
+  if (src->tendon_lengthspring) CD(tendon_lengthspring, 2 * src->ntendon);
+  if (src->tendon_frictionloss) CD(tendon_frictionloss, src->ntendon);
   CD(key_qpos, src->nkey * src->nq); CD(key_mpos, src->nkey * 3 * src->nmocap);
   copy_task(om, task);
 

@@ -362,6 +362,21 @@ static double impedance(const double *solimp_in, double pos, double margin) {
   return si[0] + y * (si[1] - si[0]);
 }
 
+/* mju_quat2Vel(quat, 1) + mju_normalize3: rotation axis (unit; (1,0,0) for a null rotation) and angle in (-pi, pi] of a unit
+ * quaternion */
+double oracle_ball_angle(double axis[3], const double *quat) {
+  axis[0] = quat[1]; axis[1] = quat[2]; axis[2] = quat[3];
+  double s = sqrt(axis[0] * axis[0] + axis[1] * axis[1] + axis[2] * axis[2]);
+  if (s < O_MINVAL) { axis[0] = 1; axis[1] = 0; axis[2] = 0; } else { axis[0] /= s; axis[1] /= s; axis[2] /= s; }
+  double speed = 2 * atan2(s, quat[0]);
+  if (speed > O_PI) speed -= 2 * O_PI;
+  /* angleAxis = axis * speed, then its norm / direction: a negative speed flips the axis */
+  double v[3] = {axis[0] * speed, axis[1] * speed, axis[2] * speed};
+  double n = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+  if (n < O_MINVAL) { axis[0] = 1; axis[1] = 0; axis[2] = 0; } else { axis[0] = v[0] / n; axis[1] = v[1] / n; axis[2] = v[2] / n; }
+  return n;
+}
+
 static int add_row(const OModel *om, OData *d, int type, int id) {
   if (d->nefc >= om->nefcmax) { d->warning |= MJPC_WARN_CNSTRFULL; return -1; }   /* constraint buffer full */
   int r = d->nefc++;
@@ -400,6 +415,23 @@ static void make_constraint(const OModel *om, OData *d) {
         d->efc_diagApprox[r] = m->dof_invweight0[m->jnt_dofadr[j]];
         d->nl++;
       }
+    }
+  }
+  /* ball-joint limits (mj_instantiateLimit): rotation angle of the joint quaternion against max(range); J = -axis at the three
+   * dofs.  Rows follow the hinge / slide limits (MuJoCo interleaves them in joint order: same constraint set, the engine keeps
+   * its single-entry rows together) */
+  for (int j = 0; j < m->njnt; j++) if (m->jnt_limited[j] && m->jnt_type[j] == MJPC_JNT_BALL) {
+    double axis[3], angle = oracle_ball_angle(axis, d->qpos + m->jnt_qposadr[j]);
+    double margin = m->jnt_margin[j];
+    double dist = fmax(m->jnt_range[2 * j], m->jnt_range[2 * j + 1]) - angle;
+    if (dist < margin) {
+      int r = add_row(om, d, O_CNSTR_LIMIT_JOINT, j); if (r < 0) return;
+      for (int k = 0; k < 3; k++) d->efc_J[r * nv + m->jnt_dofadr[j] + k] = -axis[k];
+      d->efc_pos[r] = dist; d->efc_margin[r] = margin;
+      o_copy(d->efc_solref + 2 * r, m->jnt_solref + 2 * j, 2);
+      o_copy(d->efc_solimp + 5 * r, m->jnt_solimp + 5 * j, 5);
+      d->efc_diagApprox[r] = m->dof_invweight0[m->jnt_dofadr[j]];
+      d->nl++;
     }
   }
   /* fixed-tendon limits: length = sum coef*qpos, J = coef at the joints' dofs */
@@ -573,6 +605,21 @@ static void passive(const OModel *om, OData *d) {
     }
   }
   for (int i = 0; i < m->nv; i++) d->qfrc_passive[i] -= m->dof_damping[i] * d->qvel[i];
+  /* tendon spring (dead band lengthspring) and damper, fixed tendons: J = the wrap coefficients (mj_passive, engine_passive.c) */
+  for (int t = 0; t < m->ntendon; t++) {
+    double k = m->tendon_stiffness ? m->tendon_stiffness[t] : 0, b = m->tendon_damping ? m->tendon_damping[t] : 0;
+    if (k == 0 && b == 0) continue;
+    double length = 0, velocity = 0;
+    for (int w = m->tendon_adr[t]; w < m->tendon_adr[t] + m->tendon_num[t]; w++) {
+      int j = m->wrap_objid[w];
+      length += m->wrap_prm[w] * d->qpos[m->jnt_qposadr[j]]; velocity += m->wrap_prm[w] * d->qvel[m->jnt_dofadr[j]];
+    }
+    double lo = m->tendon_lengthspring ? m->tendon_lengthspring[2 * t] : 0, hi = m->tendon_lengthspring ? m->tendon_lengthspring[2 * t + 1] : 0;
+    double frc = 0;
+    if (length > hi) frc = k * (hi - length); else if (length < lo) frc = k * (lo - length);
+    frc -= b * velocity;
+    for (int w = m->tendon_adr[t]; w < m->tendon_adr[t] + m->tendon_num[t]; w++) d->qfrc_passive[m->jnt_dofadr[m->wrap_objid[w]]] += m->wrap_prm[w] * frc;
+  }
 }
 
 static void rne_bias(const OModel *om, OData *d) {

@@ -69,6 +69,15 @@ def test_particle_copystate_alignment():
     assert np.array_equal(allc["states"], allc["residual"])
 
 
+def test_limited_ball_joints_and_tendon_spring_damper_cross_branch_limit():
+    """a7 features no BASELINE model has: ball-joint limit rows (mj_instantiateLimit), tendon spring / damper (mj_passive) and a
+    limited tendon whose joints sit on different branches (its row is outside M's sparsity pattern: dense Hessian builds)."""
+    from mujoco_mpc_amd.modelgen import ball_chain
+    m, task, d = ball_chain()
+    out, ref, allc = _compare(m, task, d, 4, 60, 12, (0.4, 0.0), 2, 1e-5)
+    assert allc["diag"][:, 2].max() >= 2 and not out["failure"].any()        # limit rows were active
+
+
 def test_cartpole_c1_config():
     """BASELINE config C1: 16 samples, horizon 50, 10 cubic knots."""
     m, task, d = cartpole()

@@ -21,6 +21,7 @@ def _rel(a, b):
 
 @pytest.mark.parametrize("name,P,H,N,sigma,tol", [("particle", 11, 26, 6, (0.3, 0.0), 1e-12), ("cartpole", 10, 50, 8, (0.5, 0.0), 1e-12),
                                                    ("quadruped", 3, 30, 6, (0.04, 0.0), 1e-5),
+                                                   ("ball_chain", 4, 60, 6, (0.4, 0.0), 1e-5),      # limited ball joints, tendon spring / damper / cross-branch limit
                                                    ("humanoid_track", 16, 30, 4, (0.15, 0.0), 1e-5),
                                                    ("humanoid_stand", 3, 24, 4, (0.05, 0.0), 1e-5), ("humanoid_walk", 3, 24, 4, (0.05, 0.0), 1e-5)])
 def test_kernel_source_matches_oracle(name, P, H, N, sigma, tol):
@@ -70,7 +71,7 @@ def test_lds_budget_of_every_baseline_model():
 
 def test_models_the_engine_cannot_roll_out_are_refused_at_create():
     """ADVICE r1: no silent approximation.  Host-side validation (mjpc_host::build) refuses ellipsoids / meshes that can collide,
-    limited ball joints, user data, oversized buffers; a cylinder next to a capsule is accepted (conservative run-time test)."""
+    tendon friction loss, user data, oversized buffers; a cylinder next to a capsule is accepted (conservative run-time test)."""
     from mujoco_mpc_amd.modelgen.builder import BALL, BOX, CYLINDER, ELLIPSOID, FREE, HINGE, PLANE, SPHERE, ModelBuilder
     from mujoco_mpc_amd.modelgen.tasks import make_task
     lib = ctypes.CDLL(capi.ENGINE_PATH)
@@ -101,7 +102,14 @@ def test_models_the_engine_cannot_roll_out_are_refused_at_create():
         c = b.body("c", body)
         b.joint(c, "ball", BALL, limited=True, range=(0, 1))
         b.geom(c, "cg", SPHERE, size=(0.05,))
-    check(ball, "limited ball")
+    check(ball, None)                                 # limited ball joints have their limit row now
+
+    def tfric(b, body):
+        c = b.body("c", body)
+        b.joint(c, "h", HINGE, axis=(0, 1, 0))
+        b.geom(c, "cg", SPHERE, size=(0.05,))
+        b.tendon("t", ["h"], [1.0], frictionloss=0.1)
+    check(tfric, "tendon friction loss")
 
     def userdata(b, body):
         b.nuserdata = 3

@@ -452,3 +452,59 @@ def test_full_buffers_fail_the_candidate_and_leave_no_half_built_cone(kw, bit):
                                     interpolation=0, num_trajectory=16, horizon=H, sigma=(0.3, 0.0), seed=0, stream=0)
     assert (r["failure"] & bit).any() and (r["failure"] == 0).any(), r["failure"]
     assert np.all(r["returns"][r["failure"] != 0] == 1.0e6)
+
+
+def test_ball_joint_limit_row_and_static_balance():
+    """mj_instantiateLimit for mjJNT_BALL: value = rotation angle of the joint quaternion, dist = max(range) - angle, one row with
+    J = -axis at the joint's three dofs.  A pendulum on a limited ball joint pushed by a constant torque comes to rest with the
+    limit force balancing the torque, a little beyond the range (soft constraint)."""
+    from mujoco_mpc_amd.modelgen.builder import BALL
+    b = ModelBuilder(timestep=0.002, gravity=(0, 0, 0))
+    l1 = b.body("l1", 0)
+    b.joint(l1, "ball", BALL, limited=True, range=(0, 0.4), damping=0.5)
+    b.geom(l1, "g1", SPHERE, size=(0.1,), pos=(0, 0, -0.3), mass=1.0)
+    m = b.compile()
+    o = ol.Oracle(m, _copy_task(m))
+    ang = 0.2
+    r = o.forward([math.cos(ang / 2), 0, math.sin(ang / 2), 0], [0, 0, 0])
+    assert r["nefc"] == 0                                              # 0.2 rad: inside the 0.4 rad cone
+    ang = 0.5
+    ax = np.array([0.6, 0.8, 0.0])
+    r = o.forward([math.cos(ang / 2), *(math.sin(ang / 2) * ax)], [0, 0, 0])
+    assert r["nefc"] == 1 and r["efc_force"][0] > 0
+    assert np.allclose(r["qfrc_constraint"], -ax * r["efc_force"][0], rtol=1e-12, atol=1e-14)   # pushes back along -axis
+    # rotations beyond pi come back as the short way round with the axis flipped (mju_quat2Vel)
+    ang = 2 * math.pi - 0.5
+    r = o.forward([math.cos(ang / 2), *(math.sin(ang / 2) * ax)], [0, 0, 0])
+    assert r["nefc"] == 1 and np.allclose(r["qfrc_constraint"], ax * r["efc_force"][0], rtol=1e-12, atol=1e-14)
+    # constant torque 0.3 about y (xfrc-free: apply through a motor on a hinge is not available on a ball joint; use qvel kick and damping)
+    q = np.array([1.0, 0, 0, 0]); v = np.array([0.0, 3.0, 0.0])
+    q, v, _, _, w = o.step(q, v, nstep=3000)
+    assert w == 0
+    angle = 2 * math.atan2(np.linalg.norm(q[1:]), q[0])
+    assert angle < 0.4 + 0.05 and np.linalg.norm(v) < 1e-3               # stopped by the limit (and the damper), not spinning on
+
+
+def test_tendon_spring_and_damper_closed_form():
+    """mj_passive, tendon part: force = k * (dead band edge - length) - b * velocity along J^T, length = sum coef * qpos."""
+    b = ModelBuilder(timestep=0.002, gravity=(0, 0, 0))
+    l1 = b.body("l1", 0)
+    b.joint(l1, "s1", SLIDE, axis=(1, 0, 0))
+    b.geom(l1, "g1", SPHERE, size=(0.1,), mass=2.0)
+    l2 = b.body("l2", 0, pos=(0, 1, 0))
+    b.joint(l2, "s2", SLIDE, axis=(1, 0, 0))
+    b.geom(l2, "g2", SPHERE, size=(0.1,), mass=4.0)
+    b.tendon("t", ["s1", "s2"], [2.0, -1.0], stiffness=30.0, damping=1.5, springlength=(-0.1, 0.2))
+    m = b.compile()
+    o = ol.Oracle(m, _copy_task(m))
+    for q, v in (([0.3, 0.1], [0.5, -0.25]), ([-0.2, 0.1], [0.0, 0.4]), ([0.05, 0.0], [1.0, 1.0])):
+        length = 2 * q[0] - q[1]; vel = 2 * v[0] - v[1]
+        frc = 30.0 * (0.2 - length) if length > 0.2 else (30.0 * (-0.1 - length) if length < -0.1 else 0.0)
+        frc -= 1.5 * vel
+        r = o.forward(q, v)
+        assert r["qacc"][0] == pytest.approx(2.0 * frc / 2.0, rel=1e-12, abs=1e-14)
+        assert r["qacc"][1] == pytest.approx(-1.0 * frc / 4.0, rel=1e-12, abs=1e-14)
+    # springlength=None: resting length = the length at qpos0 (0 here)
+    b.tendons[0]["springlength"] = None
+    m2 = b.compile()
+    assert np.allclose(m2["tendon_lengthspring"], 0.0)

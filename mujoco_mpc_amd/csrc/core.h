@@ -2239,7 +2239,7 @@ DEV_NOINLINE void ph_init(KP Kc) {
     c.xquat[0] = 1; c.xquat[1] = 0; c.xquat[2] = 0; c.xquat[3] = 0;
     for (int k = 0; k < 9; k++) { c.xmat[k] = (k % 4 == 0) ? 1.0 : 0.0; c.ximat[k] = c.xmat[k]; }
     for (int k = 0; k < 6; k++) { c.cvel[k] = 0; c.cfrc[k] = 0; c.cacc[k] = (k >= 3) ? -M.gravity[k - 3] : 0.0; }
-    for (int k = 0; k < 28; k++) c.misc[k] = 0;
+    for (int k = 0; k < MISC_INTS; k++) c.misc[k] = 0;
 #if defined(MJPC_PROFILE) && !defined(MJPC_EMU)
     for (int q = 0; q < NPROF; q++) c.prof[q] = 0;
     c.prof[NPROF] = (long long)__builtin_amdgcn_s_memtime();
@@ -2363,8 +2363,9 @@ DEV_SOLVE_PHASE void ph_solve(KP Kc, int last, int t) {
 template <int NVT>
 DEV_NOINLINE void ph_solve_helper(KP Kc, int t) {
   Ctx c; ctx_open(c, Kc, 1);
-  if (MJPC_NH < 2 || WAVE_ID() == 1) solver_helper_loop<NVT, 0>(c, t * 256);
-  else solver_helper_loop<NVT, (MJPC_NH >= 2 ? 1 : 0)>(c, t * 256);
+  // helper k = wave k + 1 (each index is its own instantiation: the column / entry ranges are compile-time)
+  int k = WAVE_ID() - 1;
+  static_for<0, MJPC_NH>([&](auto Kc_) { constexpr int KK = decltype(Kc_)::value; if (k == KK) solver_helper_loop<NVT, KK>(c, t * 256); });
 }
 #endif
 

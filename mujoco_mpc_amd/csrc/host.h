@@ -107,7 +107,7 @@ static inline void make_layout(const PackedModel &p, Lay &L, const MjpcHipModel 
 #undef A_
   int io = 0;
   L.i_efc_type = io; io += ne; L.i_efc_id = io; io += ne; L.i_efc_state = io; io += ne; L.i_efc_dof = io; io += ne;
-  L.i_con = io; io += nc * CONI_STRIDE; L.i_active = io; io += (ne + nc > MAX_ACTIVE_PAIRS ? ne + nc : MAX_ACTIVE_PAIRS); L.i_misc = io; io += 28;
+  L.i_con = io; io += nc * CONI_STRIDE; L.i_active = io; io += (ne + nc > MAX_ACTIVE_PAIRS ? ne + nc : MAX_ACTIVE_PAIRS); L.i_misc = io; io += MISC_INTS;
   L.i_hpair = io; if (!lean) io += M.nhpair + nv;      // LDS copy of the Hessian/gradient entry table (i | j << 8)
   L.total_doubles = o + (io + 1) / 2;
 }

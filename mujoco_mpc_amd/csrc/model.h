@@ -126,6 +126,7 @@ struct DevModel {
 };
 
 // LDS carve-up, offsets in doubles (ints live behind `ints`, offsets in ints)
+#define MISC_INTS 48     // per-candidate scalars and hand-shake flags in LDS (core.h / solver.h: misc[])
 struct Lay {
   int qpos, qvel, ctrl, qacc, qacc_ws, qacc_smooth, qfrc_smooth, qfrc_bias, qfrc_constraint, actuator_force;
   int mocap_pos, mocap_quat;

@@ -444,8 +444,8 @@ DEV void newton_entries(Ctx &c, int npos, int nneg, int grad_only, int part, int
 #define HX_W0FILL 14
 #define HX_NPOS 15
 #define HX_NNEG 16
-#define HX_HFILL 17      // + k
-#define HX_HDONE 20      // + k
+#define HX_HFILL 28      // + k (k < 8)
+#define HX_HDONE 36      // + k
 #ifndef MJPC_SPLIT_FILL
 #define MJPC_SPLIT_FILL 1
 #endif

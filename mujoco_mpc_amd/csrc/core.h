@@ -95,11 +95,7 @@ DEV void ctx_init(Ctx &c, const KParams *K, double *base) {
   P_(xpos); P_(xquat); P_(xmat); P_(xipos); P_(ximat); P_(xanchor); P_(xaxis); P_(geom_xpos); P_(geom_xmat); P_(site_xpos);
   P_(subtree_com); P_(cinert); P_(crb); P_(cdof); P_(cvel); P_(cdof_dot); P_(cacc); P_(cfrc); P_(cfrc_sub);
   P_(subtree_linvel); P_(bodytmp); P_(qM); P_(qL); P_(qH); P_(Linv); P_(Hinv);
-#ifdef MJPC_AB_FRICJ
-  c.efc_J = base + L.efc_J;
-#else
   c.efc_J = base + L.efc_J - K->M.nfric * K->M.nvp;      // rows [nfric, nefcmax) are stored: a friction-loss row is the unit vector of its dof
-#endif
   P_(efc_JA); P_(efc_D); P_(efc_R); P_(efc_aref); P_(efc_force); P_(efc_jar); P_(efc_jv); P_(efc_floss);
   P_(efc_pos); P_(efc_margin); P_(efc_diag); P_(contact);
   P_(Ma); P_(grad); P_(Mgrad); P_(search); P_(Mv); P_(vtmp); P_(sgl);
@@ -939,9 +935,6 @@ DEV double seg_point_dist2(const double *p, const double *a, double h, const dou
 DEV int narrow_phase(Ctx &c, int g1, int g2, double margin, NPCon *con) {
   const DevModel &M = *c.M;
   const int t1 = MI(geom_type)[g1], t2 = MI(geom_type)[g2];
-#ifdef MJPC_AB_NOHEAVY      // A/B measurement builds only: the round-1 behaviour (pairs without a light collider never touch)
-  if (!((t1 == 0 && (t2 == 2 || t2 == 3 || t2 == 6 || t2 == 5)) || (t1 == 2 && (t2 == 2 || t2 == 3 || t2 == 6)) || (t1 == 3 && t2 == 3))) return 0;
-#endif
   const int cyl = (t1 == 5 || (t2 == 5 && t1 != 0));
   const int e1 = t1 == 5 ? 3 : t1, e2 = (t2 == 5 && t1 != 0) ? 3 : t2;
   if (e1 == 6 || e1 == 4 || e2 == 4 || e1 == 1 || e2 == 1 || e1 == 7 || e2 == 7) return -2;      // box-box (and what create() refuses)
@@ -1257,21 +1250,12 @@ DEV void make_noncontact_rows(Ctx &c, int *nsingle_out, int *n_nc_out) {
   }
   int ntl_end = nefc;
   SYNC();
-#ifdef MJPC_AB_FRICJ
-  PFOR(e, ntl_end * nvp) c.efc_J[e] = 0;
-  SYNC();
-  PFOR(r, nlim_end) {
-    if (r < M.nfric) c.efc_J[r * nvp + c.efc_id[r]] = 1;
-    else { c.efc_J[r * nvp + MI(jnt_dofadr)[c.efc_id[r]]] = c.efc_floss[r]; c.efc_floss[r] = 0; }
-  }
-#else
   PFOR(e, (ntl_end - M.nfric) * nvp) c.efc_J[M.nfric * nvp + e] = 0;
   SYNC();
   PFOR(rr, nlim_end - M.nfric) {
     int r = M.nfric + rr;
     c.efc_J[r * nvp + MI(jnt_dofadr)[c.efc_id[r]]] = c.efc_floss[r]; c.efc_floss[r] = 0;
   }
-#endif
   PFOR(rr, nball_end - nlim_end) {
     int r = nlim_end + rr, j = c.efc_id[r], da = MI(jnt_dofadr)[j];
     double axis[3];
@@ -1395,10 +1379,8 @@ DEV void make_impedance(Ctx &c, int r0, int r1, int with_contacts) {
     int r = r0 + rr;
     int type = c.efc_type[r], id = c.efc_id[r];
     double vel = 0;
-#ifndef MJPC_AB_FRICJ
     if (type == CNSTR_FRICTION_DOF) vel = c.qvel[id];      // J = unit vector of the dof (no stored row)
     else
-#endif
     for (int i0 = 0; i0 < nv; i0 += 9) {     // blocks of 9 loads in flight (nv = 18, 27 divide evenly), same summation order
       double jj[9], qq[9];
 #pragma unroll
@@ -1627,15 +1609,7 @@ DEV void velocity_stage(Ctx &c, int mfact_seq) {
     double ctrl = c.ctrl[i];
     if (MI(actuator_ctrllimited)[i]) ctrl = d_clip(ctrl, MD(actuator_ctrlrange)[2 * i], MD(actuator_ctrlrange)[2 * i + 1]);
     double force = MD(actuator_gainprm)[3 * i] * ctrl;
-#ifdef MJPC_AB_OLDACT
     if (MI(actuator_biastype)[i] == 1) {
-      int e = MI(act_adr)[i]; double gear = MD(act_coef)[e];
-      force += MD(actuator_biasprm)[3 * i] + MD(actuator_biasprm)[3 * i + 1] * (gear * c.qpos[MI(act_qpos)[e]]) + MD(actuator_biasprm)[3 * i + 2] * (gear * c.qvel[MI(act_dof)[e]]);
-    }
-    if (0) {
-#else
-    if (MI(actuator_biastype)[i] == 1) {
-#endif
       // transmission length / velocity: gear * qpos (joint) or sum of gear * coef * qpos over the tendon's joints
       double length = 0, velocity = 0;
       for (int e = MI(act_adr)[i]; e < MI(act_adr)[i + 1]; e++) {

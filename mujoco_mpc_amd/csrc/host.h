@@ -81,11 +81,7 @@ static inline void make_layout(const PackedModel &p, Lay &L, const MjpcHipModel 
   // contact (padded to 4)
   int ja_rows = ((ne - M.nfric + 7) & ~7) + (m->cone == MJPC_CONE_ELLIPTIC ? ((nc + 3) & ~3) : 0) + 4;
   
-#ifdef MJPC_AB_FRICJ
-  A_(efc_J, ne * nvp + 1);
-#else
   A_(efc_J, (ne - M.nfric) * nvp + 1);
-#endif
   A_(efc_JA, ja_rows * nvp + 1);
   if (lean) {
     int q = L.efc_JA;

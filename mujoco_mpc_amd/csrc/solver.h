@@ -52,12 +52,8 @@ DEV double constraint_update(Ctx &c, int hess, const double *jar) {
   for (int k = 0; k < LS_RPL; k++) {
     if (k >= nslot) break;
     int i = LANE + NLANE * k, ic = i < nefc ? i : nefc - 1;
-#ifdef MJPC_AB_FRICJ
-    rJ[k] = (WRITE && ic < c.nsingle) ? c.efc_J[ic * nvp + rdof[k]] : 0.0;
-#else
     const int nfr = c.M->nfric;                     // friction-loss rows have no stored Jacobian row: their entry is 1
     rJ[k] = (WRITE && ic < c.nsingle) ? (ic < nfr ? 1.0 : c.efc_J[(ic < nfr ? nfr : ic) * nvp + rdof[k]]) : 0.0;
-#endif
   }
 #pragma unroll
   for (int q = 0; q < LS_CPL; q++) {
@@ -189,10 +185,8 @@ DEV void mat_rows_times(Ctx &c, const double *x, double *Mx, double *Jx) {
     PFOR(r, c.nefc) {
       const double *row = c.efc_J + r * nvp;
       double s;
-#ifndef MJPC_AB_FRICJ
       if (r < c.M->nfric) s = x[c.efc_dof[r]];
       else
-#endif
       if (r < c.nsingle) { int d = c.efc_dof[r]; s = row[d] * x[d]; }
       else {
         double s0 = 0, s1 = 0;
@@ -211,10 +205,8 @@ DEV void mat_rows_times(Ctx &c, const double *x, double *Mx, double *Jx) {
     }
     PFOR(r, c.nefc) {
       double s = 0;
-#ifndef MJPC_AB_FRICJ
       if (r < M.nfric) s = x[c.efc_dof[r]];
       else
-#endif
       if (r < c.nsingle) s = c.efc_J[r * nvp + c.efc_dof[r]] * x[c.efc_dof[r]];
       else for (int j = 0; j < nv; j++) s += c.efc_J[r * nvp + j] * x[j];
       Jx[r] = s;

@@ -64,7 +64,7 @@ enum {
   MJPC_WARN_CONTACTFULL = 8, MJPC_WARN_CNSTRFULL = 16,                    /* mjWARN_CONTACTFULL / CNSTRFULL (nconmax / nefcmax) */
   MJPC_WARN_RAY = 32,                                                     /* Ground() ray hit nothing (utilities.cc:549-552) */
   MJPC_WARN_SYNC = 64,                                                    /* engine-internal: a wave hand-shake timed out */
-  MJPC_WARN_UNSUPPORTED = 128   /* a geom pair without a collider (cylinder vs non-plane) came within reach of contact */
+  MJPC_WARN_UNSUPPORTED = 128   /* a geom pair without a collider came within reach of contact (none left among the pairs create() accepts) */
 };
 #define MJPC_MINVAL 1e-15           /* mjMINVAL */
 #define MJPC_MAX_RETURN 1.0e6       /* kMaxReturnValue, mjpc/trajectory.cc:29 */

@@ -891,6 +891,162 @@ DEV int np_capsule_cylinder(NPCon *con, double margin, const double *kp, const d
   return cnt;
 }
 
+// ---- convex pairs without an analytic collider (cylinder-cylinder, cylinder-box): Minkowski portal refinement ("XenoCollide",
+// the algorithm class MuJoCo reaches through libccd for these pairs; tolerance 1e-6, 50 iterations).  Both geoms are inflated
+// by margin / 2, one contact per pair; the penetration is measured where the ray from the centres' difference through the
+// origin leaves the Minkowski difference, the contact sits half way between the two witness points.
+#define MPR_TOLERANCE 1e-6
+#define MPR_ITERATIONS 50
+struct MShape { int type; const double *pos, *mat, *size; double margin; };
+struct MSup { double v[3], v1[3], v2[3]; };
+DEV void mpr_support1(const MShape &s, const double *dir, double *out) {
+  double l[3], v[3];
+  d_mulmattvec3(l, s.mat, dir);
+  if (s.type == 6) {
+    for (int k = 0; k < 3; k++) v[k] = l[k] >= 0 ? s.size[k] : -s.size[k];
+  } else if (s.type == 5) {
+    double n = sqrt(l[0] * l[0] + l[1] * l[1]);
+    if (n > D_MINVAL) { v[0] = s.size[0] * l[0] / n; v[1] = s.size[0] * l[1] / n; } else { v[0] = 0; v[1] = 0; }
+    v[2] = l[2] >= 0 ? s.size[1] : -s.size[1];
+  } else if (s.type == 3) {
+    v[0] = s.size[0] * l[0]; v[1] = s.size[0] * l[1]; v[2] = s.size[0] * l[2] + (l[2] >= 0 ? s.size[1] : -s.size[1]);
+  } else {
+    v[0] = s.size[0] * l[0]; v[1] = s.size[0] * l[1]; v[2] = s.size[0] * l[2];
+  }
+  d_mulmatvec3(out, s.mat, v);
+  d_add3(out, out, s.pos);
+  d_addtoscl3(out, dir, s.margin);
+}
+DEV void mpr_support(const MShape &a, const MShape &b, const double *dir, MSup &s) {
+  double nd[3] = {-dir[0], -dir[1], -dir[2]};
+  mpr_support1(a, dir, s.v1);
+  mpr_support1(b, nd, s.v2);
+  d_sub3(s.v, s.v1, s.v2);
+}
+DEV void mpr_portal_dir(const MSup &p1, const MSup &p2, const MSup &p3, double *dir) {
+  double a[3], b[3];
+  d_sub3(a, p2.v, p1.v);
+  d_sub3(b, p3.v, p1.v);
+  d_cross(dir, a, b);
+  d_normalize3(dir);
+}
+DEV int mpr_reach_tolerance(const MSup &p1, const MSup &p2, const MSup &p3, const MSup &v4, const double *dir) {
+  double dv4 = d_dot3(v4.v, dir);
+  double d1 = dv4 - d_dot3(p1.v, dir), d2 = dv4 - d_dot3(p2.v, dir), d3 = dv4 - d_dot3(p3.v, dir);
+  double dm = fmin(d1, fmin(d2, d3));
+  return dm <= MPR_TOLERANCE;
+}
+DEV void mpr_expand_portal(const MSup &p0, MSup &p1, MSup &p2, MSup &p3, const MSup &v4) {
+  double v4v0[3];
+  d_cross(v4v0, v4.v, p0.v);
+  if (d_dot3(p1.v, v4v0) > 0) {
+    if (d_dot3(p2.v, v4v0) > 0) p1 = v4; else p3 = v4;
+  } else {
+    if (d_dot3(p3.v, v4v0) > 0) p2 = v4; else p1 = v4;
+  }
+}
+// closest point of the triangle (a, b, c) to the origin and its barycentric weights
+DEV void mpr_closest_on_triangle(const double *a, const double *b, const double *c, double *w, double *bw) {
+  double ab[3], ac[3];
+  d_sub3(ab, b, a); d_sub3(ac, c, a);
+  double d1 = -d_dot3(ab, a), d2 = -d_dot3(ac, a);
+  if (d1 <= 0 && d2 <= 0) { d_copy3(w, a); bw[0] = 1; bw[1] = 0; bw[2] = 0; return; }
+  double d3 = -d_dot3(ab, b), d4 = -d_dot3(ac, b);
+  if (d3 >= 0 && d4 <= d3) { d_copy3(w, b); bw[0] = 0; bw[1] = 1; bw[2] = 0; return; }
+  double vc = d1 * d4 - d3 * d2;
+  if (vc <= 0 && d1 >= 0 && d3 <= 0) { double v = d1 / (d1 - d3); d_addscl3(w, a, ab, v); bw[0] = 1 - v; bw[1] = v; bw[2] = 0; return; }
+  double d5 = -d_dot3(ab, c), d6 = -d_dot3(ac, c);
+  if (d6 >= 0 && d5 <= d6) { d_copy3(w, c); bw[0] = 0; bw[1] = 0; bw[2] = 1; return; }
+  double vb = d5 * d2 - d1 * d6;
+  if (vb <= 0 && d2 >= 0 && d6 <= 0) { double v = d2 / (d2 - d6); d_addscl3(w, a, ac, v); bw[0] = 1 - v; bw[1] = 0; bw[2] = v; return; }
+  double va = d3 * d6 - d5 * d4;
+  if (va <= 0 && (d4 - d3) >= 0 && (d5 - d6) >= 0) {
+    double bc[3]; d_sub3(bc, c, b);
+    double v = (d4 - d3) / ((d4 - d3) + (d5 - d6));
+    d_addscl3(w, b, bc, v); bw[0] = 0; bw[1] = 1 - v; bw[2] = v; return;
+  }
+  double den = 1.0 / (va + vb + vc);
+  d_addscl3(w, a, ab, vb * den);
+  d_addtoscl3(w, ac, vc * den);
+  bw[1] = vb * den; bw[2] = vc * den; bw[0] = 1 - bw[1] - bw[2];
+}
+// 1 contact (frame[0..2] = normal from geom 1 to geom 2) or 0
+DEV int np_convex(NPCon *con, double margin, int t1, const double *p1, const double *m1, const double *s1,
+                  int t2, const double *p2, const double *m2, const double *s2) {
+  MShape A = {t1, p1, m1, s1, 0.5 * margin}, B = {t2, p2, m2, s2, 0.5 * margin};
+  MSup q0, q1, q2, q3, v4;
+  double dir[3], va[3], vb[3], depth, nrm[3], pos[3];
+  d_sub3(q0.v, p1, p2); d_copy3(q0.v1, p1); d_copy3(q0.v2, p2);
+  if (d_dot3(q0.v, q0.v) < D_MINVAL * D_MINVAL) q0.v[0] += 1e-9;
+  d_scl3(dir, q0.v, -1); d_normalize3(dir);
+  mpr_support(A, B, dir, q1);
+  if (d_dot3(q1.v, dir) <= 0) return 0;
+  d_cross(dir, q0.v, q1.v);
+  int found = 0;
+  if (d_dot3(dir, dir) < D_MINVAL * D_MINVAL) found = 2;
+  else {
+    d_normalize3(dir);
+    mpr_support(A, B, dir, q2);
+    if (d_dot3(q2.v, dir) <= 0) return 0;
+    d_sub3(va, q1.v, q0.v); d_sub3(vb, q2.v, q0.v);
+    d_cross(dir, va, vb); d_normalize3(dir);
+    if (d_dot3(dir, q0.v) > 0) { MSup t = q1; q1 = q2; q2 = t; d_scl3(dir, dir, -1); }
+    int ok = 0;
+    for (int it = 0; it < MPR_ITERATIONS; it++) {
+      mpr_support(A, B, dir, v4);
+      if (d_dot3(v4.v, dir) <= 0) return 0;
+      int cont = 0;
+      d_cross(va, q1.v, v4.v);
+      if (d_dot3(va, q0.v) < 0) { q2 = v4; cont = 1; }
+      if (!cont) {
+        d_cross(va, v4.v, q2.v);
+        if (d_dot3(va, q0.v) < 0) { q1 = v4; cont = 1; }
+      }
+      if (!cont) { q3 = v4; ok = 1; break; }
+      d_sub3(va, q1.v, q0.v); d_sub3(vb, q2.v, q0.v);
+      d_cross(dir, va, vb); d_normalize3(dir);
+    }
+    if (!ok) return 0;
+  }
+  if (found == 2) {
+    depth = d_norm3(q1.v);
+    d_copy3(nrm, q1.v); d_normalize3(nrm);
+    for (int k = 0; k < 3; k++) pos[k] = 0.5 * (q1.v1[k] + q1.v2[k]);
+  } else {
+    int hit = 0;
+    for (int it = 0; it < MPR_ITERATIONS; it++) {
+      mpr_portal_dir(q1, q2, q3, dir);
+      if (d_dot3(dir, q1.v) >= 0) { hit = 1; break; }
+      mpr_support(A, B, dir, v4);
+      if (d_dot3(v4.v, dir) < 0 || mpr_reach_tolerance(q1, q2, q3, v4, dir)) return 0;
+      mpr_expand_portal(q0, q1, q2, q3, v4);
+    }
+    if (!hit) return 0;
+    for (int it = 0; ; it++) {
+      mpr_portal_dir(q1, q2, q3, dir);
+      mpr_support(A, B, dir, v4);
+      if (mpr_reach_tolerance(q1, q2, q3, v4, dir) || it >= MPR_ITERATIONS) {
+        double w[3], bw[3];
+        mpr_closest_on_triangle(q1.v, q2.v, q3.v, w, bw);
+        depth = d_norm3(w);
+        if (depth < D_MINVAL) d_copy3(nrm, dir); else d_scl3(nrm, w, 1.0 / depth);
+        for (int k = 0; k < 3; k++)
+          pos[k] = 0.5 * (bw[0] * (q1.v1[k] + q1.v2[k]) + bw[1] * (q2.v1[k] + q2.v2[k]) + bw[2] * (q3.v1[k] + q3.v2[k]));
+        break;
+      }
+      mpr_expand_portal(q0, q1, q2, q3, v4);
+    }
+  }
+  double dist = margin - depth;
+  if (dist > margin) return 0;
+  NPCon t;
+  t.dist = dist;
+  d_copy3(t.pos, pos);
+  d_copy3(t.frame, nrm); t.frame[3] = 0; t.frame[4] = 0; t.frame[5] = 0;
+  np_put(con, 0, t);
+  return 1;
+}
+
 // The rarely-met pair types (capsule-box, box-box, the cylinder pairs).  n = -1: no collider and possibly touching.
 // Only the out-of-line flavour of the narrow-phase batch (narrow_batch<true>) contains this code: the batch loop of
 // collision() itself stays free of it and of any call inside the loop body's live ranges.
@@ -909,11 +1065,11 @@ DEV NPOut narrow_heavy(Ctx &c, int g1, int g2, double margin) {
   else if (t1 == 2 && t2 == 5) o.n = np_sphere_cylinder(o.c, margin, p1, s1[0], p2, m2, s2);
   else if (t1 == 3 && t2 == 5) o.n = np_capsule_cylinder(o.c, margin, p1, m1, s1, p2, m2, s2);
   else if (t1 == 5 && (t2 == 5 || t2 == 6)) {
-    // cylinder-cylinder / cylinder-box: no collider.  The cylinder's bounding capsule decides "certainly apart" (0) or
-    // "unknown" (-1): a conservative exact test
+    // cylinder-cylinder / cylinder-box: the cylinder's bounding capsule decides "certainly apart" (exact, cheap); otherwise the
+    // portal-refinement collider
     NPCon tmp[4];
     int n = t2 == 5 ? np_capsule_capsule(tmp, margin, p1, m1, s1, p2, m2, s2) : np_capsule_box(tmp, margin, p1, m1, s1, p2, m2, s2);
-    o.n = n == 0 ? 0 : -1;
+    o.n = n == 0 ? 0 : np_convex(o.c, margin, t1, p1, m1, s1, t2, p2, m2, s2);
   }
   return o;
 }

@@ -11,8 +11,8 @@
  * from the reference tree; the two colliders here are this build's own constructions with the same
  * conventions and contact budgets (capsule-box <= 2 contacts: closest segment point + far end cap;
  * box-box <= 4: separating-axis test, then reference-face clipping or one edge-edge contact).
- * Other pairs (the convex-fallback cylinder / ellipsoid / mesh pairs) are counted in `unsupported`
- * and produce no contact; the engine refuses such models at create().
+ * cylinder-cylinder and cylinder-box go through a portal-refinement (MPR) collider, below.  Ellipsoid / mesh / height-field pairs
+ * are counted in `unsupported` and produce no contact; the engine refuses such models at create().
  * PARITY UNPINNED (no MuJoCo in this image); analytic checks in tests/test_oracle_physics.py.
  */
 #include "oracle.h"
@@ -485,6 +485,171 @@ static double seg_point_dist2(const double *p, const double *a, double h, const 
   return o_dot3(w, w);
 }
 
+/* ---- convex pairs without an analytic collider (cylinder-cylinder, cylinder-box): Minkowski portal refinement ------------
+ * MuJoCo sends these pairs to libccd's MPR (mjc_Convex; opt.mpr_tolerance 1e-6, opt.mpr_iterations 50), a third-party
+ * library that is not in the reference tree.  This is the published algorithm (G. Snethen, "XenoCollide", Game Programming
+ * Gems 7): portal discovery, refinement until the portal reaches the surface of the Minkowski difference within the
+ * tolerance, penetration = the portal point closest to the origin, contact position = half way between the two witness points.  Both geoms are inflated by margin / 2 so that proximity
+ * within the margin is a (positive-distance) contact; ONE contact per pair, like MuJoCo without multiccd.  The engine carries
+ * the same operations in the same order (csrc/core.h: np_convex). */
+#define MPR_TOLERANCE 1e-6
+#define MPR_ITERATIONS 50
+typedef struct { int type; const double *pos, *mat, *size; double margin; } MShape;
+typedef struct { double v[3], v1[3], v2[3]; } MSup;
+
+static void mpr_support1(const MShape *s, const double *dir, double *out) {
+  double l[3], v[3];
+  o_mulmattvec3(l, s->mat, dir);
+  if (s->type == MJPC_GEOM_BOX) {
+    for (int k = 0; k < 3; k++) v[k] = l[k] >= 0 ? s->size[k] : -s->size[k];
+  } else if (s->type == MJPC_GEOM_CYLINDER) {
+    double n = sqrt(l[0] * l[0] + l[1] * l[1]);
+    if (n > O_MINVAL) { v[0] = s->size[0] * l[0] / n; v[1] = s->size[0] * l[1] / n; } else { v[0] = 0; v[1] = 0; }
+    v[2] = l[2] >= 0 ? s->size[1] : -s->size[1];
+  } else if (s->type == MJPC_GEOM_CAPSULE) {
+    v[0] = s->size[0] * l[0]; v[1] = s->size[0] * l[1]; v[2] = s->size[0] * l[2] + (l[2] >= 0 ? s->size[1] : -s->size[1]);
+  } else {   /* sphere */
+    v[0] = s->size[0] * l[0]; v[1] = s->size[0] * l[1]; v[2] = s->size[0] * l[2];
+  }
+  o_mulmatvec3(out, s->mat, v);
+  o_add3(out, out, s->pos);
+  o_addtoscl3(out, dir, s->margin);
+}
+/* support point of A - B in the unit direction dir */
+static void mpr_support(const MShape *a, const MShape *b, const double *dir, MSup *s) {
+  double nd[3] = {-dir[0], -dir[1], -dir[2]};
+  mpr_support1(a, dir, s->v1);
+  mpr_support1(b, nd, s->v2);
+  o_sub3(s->v, s->v1, s->v2);
+}
+static void mpr_portal_dir(const MSup *p, double *dir) {    /* outward normal of the portal triangle (v1, v2, v3) */
+  double a[3], b[3];
+  o_sub3(a, p[2].v, p[1].v);
+  o_sub3(b, p[3].v, p[1].v);
+  o_cross(dir, a, b);
+  o_normalize3(dir);
+}
+static int mpr_reach_tolerance(const MSup *p, const MSup *v4, const double *dir) {
+  double dv4 = o_dot3(v4->v, dir);
+  double d1 = dv4 - o_dot3(p[1].v, dir), d2 = dv4 - o_dot3(p[2].v, dir), d3 = dv4 - o_dot3(p[3].v, dir);
+  double dm = fmin(d1, fmin(d2, d3));
+  return dm <= MPR_TOLERANCE;
+}
+static void mpr_expand_portal(MSup *p, const MSup *v4) {
+  double v4v0[3];
+  o_cross(v4v0, v4->v, p[0].v);
+  if (o_dot3(p[1].v, v4v0) > 0) {
+    if (o_dot3(p[2].v, v4v0) > 0) p[1] = *v4; else p[3] = *v4;
+  } else {
+    if (o_dot3(p[3].v, v4v0) > 0) p[2] = *v4; else p[1] = *v4;
+  }
+}
+/* closest point of the triangle (a, b, c) to the origin (Ericson, Real-Time Collision Detection 5.1.5) */
+static void mpr_closest_on_triangle(const double *a, const double *b, const double *c, double *w, double *bw) {
+  double ab[3], ac[3];
+  o_sub3(ab, b, a); o_sub3(ac, c, a);
+  double d1 = -o_dot3(ab, a), d2 = -o_dot3(ac, a);
+  if (d1 <= 0 && d2 <= 0) { o_copy3(w, a); bw[0] = 1; bw[1] = 0; bw[2] = 0; return; }
+  double d3 = -o_dot3(ab, b), d4 = -o_dot3(ac, b);
+  if (d3 >= 0 && d4 <= d3) { o_copy3(w, b); bw[0] = 0; bw[1] = 1; bw[2] = 0; return; }
+  double vc = d1 * d4 - d3 * d2;
+  if (vc <= 0 && d1 >= 0 && d3 <= 0) { double v = d1 / (d1 - d3); o_addscl3(w, a, ab, v); bw[0] = 1 - v; bw[1] = v; bw[2] = 0; return; }
+  double d5 = -o_dot3(ab, c), d6 = -o_dot3(ac, c);
+  if (d6 >= 0 && d5 <= d6) { o_copy3(w, c); bw[0] = 0; bw[1] = 0; bw[2] = 1; return; }
+  double vb = d5 * d2 - d1 * d6;
+  if (vb <= 0 && d2 >= 0 && d6 <= 0) { double v = d2 / (d2 - d6); o_addscl3(w, a, ac, v); bw[0] = 1 - v; bw[1] = 0; bw[2] = v; return; }
+  double va = d3 * d6 - d5 * d4;
+  if (va <= 0 && (d4 - d3) >= 0 && (d5 - d6) >= 0) {
+    double bc[3]; o_sub3(bc, c, b);
+    double v = (d4 - d3) / ((d4 - d3) + (d5 - d6));
+    o_addscl3(w, b, bc, v); bw[0] = 0; bw[1] = 1 - v; bw[2] = v; return;
+  }
+  double den = 1.0 / (va + vb + vc);
+  o_addscl3(w, a, ab, vb * den);
+  o_addtoscl3(w, ac, vc * den);
+  bw[1] = vb * den; bw[2] = vc * den; bw[0] = 1 - bw[1] - bw[2];
+}
+/* 1 contact (frame[0..2] = normal from geom 1 to geom 2) or 0 */
+static int convex_mpr(OContact *con, double margin, int t1, const double *p1, const double *m1, const double *s1,
+                      int t2, const double *p2, const double *m2, const double *s2) {
+  MShape A = {t1, p1, m1, s1, 0.5 * margin}, B = {t2, p2, m2, s2, 0.5 * margin};
+  MSup p[4], v4;
+  double dir[3], va[3], vb[3], depth, nrm[3], pos[3];
+  /* portal discovery */
+  o_sub3(p[0].v, p1, p2); o_copy3(p[0].v1, p1); o_copy3(p[0].v2, p2);
+  if (o_dot3(p[0].v, p[0].v) < O_MINVAL * O_MINVAL) p[0].v[0] += 1e-9;
+  o_scl3(dir, p[0].v, -1); o_normalize3(dir);
+  mpr_support(&A, &B, dir, &p[1]);
+  if (o_dot3(p[1].v, dir) <= 0) return 0;
+  o_cross(dir, p[0].v, p[1].v);
+  int found = 0;     /* 0: portal, 2: the origin lies on the segment v0-v1 */
+  if (o_dot3(dir, dir) < O_MINVAL * O_MINVAL) found = 2;
+  else {
+    o_normalize3(dir);
+    mpr_support(&A, &B, dir, &p[2]);
+    if (o_dot3(p[2].v, dir) <= 0) return 0;
+    o_sub3(va, p[1].v, p[0].v); o_sub3(vb, p[2].v, p[0].v);
+    o_cross(dir, va, vb); o_normalize3(dir);
+    if (o_dot3(dir, p[0].v) > 0) { MSup t = p[1]; p[1] = p[2]; p[2] = t; o_scl3(dir, dir, -1); }
+    int ok = 0;
+    for (int it = 0; it < MPR_ITERATIONS; it++) {
+      mpr_support(&A, &B, dir, &v4);
+      if (o_dot3(v4.v, dir) <= 0) return 0;
+      int cont = 0;
+      o_cross(va, p[1].v, v4.v);
+      if (o_dot3(va, p[0].v) < 0) { p[2] = v4; cont = 1; }
+      if (!cont) {
+        o_cross(va, v4.v, p[2].v);
+        if (o_dot3(va, p[0].v) < 0) { p[1] = v4; cont = 1; }
+      }
+      if (!cont) { p[3] = v4; ok = 1; break; }
+      o_sub3(va, p[1].v, p[0].v); o_sub3(vb, p[2].v, p[0].v);
+      o_cross(dir, va, vb); o_normalize3(dir);
+    }
+    if (!ok) return 0;
+  }
+  if (found == 2) {
+    depth = o_norm3(p[1].v);
+    o_copy3(nrm, p[1].v); o_normalize3(nrm);
+    for (int k = 0; k < 3; k++) pos[k] = 0.5 * (p[1].v1[k] + p[1].v2[k]);
+  } else {
+    /* refinement: does the portal enclose the origin? */
+    int hit = 0;
+    for (int it = 0; it < MPR_ITERATIONS; it++) {
+      mpr_portal_dir(p, dir);
+      if (o_dot3(dir, p[1].v) >= 0) { hit = 1; break; }
+      mpr_support(&A, &B, dir, &v4);
+      if (o_dot3(v4.v, dir) < 0 || mpr_reach_tolerance(p, &v4, dir)) return 0;
+      mpr_expand_portal(p, &v4);
+    }
+    if (!hit) return 0;
+    /* penetration: push the portal to the surface */
+    for (int it = 0; ; it++) {
+      mpr_portal_dir(p, dir);
+      mpr_support(&A, &B, dir, &v4);
+      if (mpr_reach_tolerance(p, &v4, dir) || it >= MPR_ITERATIONS) {
+        /* the portal point closest to the origin: penetration vector; its barycentric weights applied to the support points of
+         * the two geoms give the two witness points, the contact sits half way between them */
+        double w[3], bw[3];
+        mpr_closest_on_triangle(p[1].v, p[2].v, p[3].v, w, bw);
+        depth = o_norm3(w);
+        if (depth < O_MINVAL) o_copy3(nrm, dir); else o_scl3(nrm, w, 1.0 / depth);
+        for (int k = 0; k < 3; k++)
+          pos[k] = 0.5 * (bw[0] * (p[1].v1[k] + p[1].v2[k]) + bw[1] * (p[2].v1[k] + p[2].v2[k]) + bw[2] * (p[3].v1[k] + p[3].v2[k]));
+        break;
+      }
+      mpr_expand_portal(p, &v4);
+    }
+  }
+  double dist = margin - depth;        /* both geoms were inflated by margin / 2 */
+  if (dist > margin) return 0;
+  o_zero(con->frame, 9);
+  o_copy3(con->frame, nrm);
+  con->dist = dist;
+  o_copy3(con->pos, pos);
+  return 1;
+}
+
 int oracle_collide_pair(const OModel *om, OData *d, int g1, int g2, double margin, OContact *con, int *unsupported) {
   const MjpcHipModel *m = &om->m;
   int t1 = m->geom_type[g1], t2 = m->geom_type[g2];
@@ -541,16 +706,13 @@ int oracle_collide_pair(const OModel *om, OData *d, int g1, int g2, double margi
   } else if (t1 == MJPC_GEOM_BOX && t2 == MJPC_GEOM_BOX) {
     return box_box(con, margin, p1, m1, s1, p2, m2, s2);
   }
-  /* cylinder-cylinder and cylinder-box have no collider here (MuJoCo: general convex solver, not restatable).  Conservative
-   * exact test instead: the cylinder's bounding capsule (same radius and half length) contains it, so if that capsule is
-   * farther than the margin there is certainly no contact -> 0, correctly.  If the bounding capsule touches, the true answer
-   * is unknown: counted in `unsupported`, and the caller fails the rollout (never a silent miss). */
-  if (t1 == MJPC_GEOM_CYLINDER) {
+  /* cylinder-cylinder and cylinder-box: the cylinder's bounding capsule (same radius and half length) contains it, so a capsule
+   * farther than the margin means certainly no contact (exact, cheap); otherwise the portal-refinement collider decides */
+  if (t1 == MJPC_GEOM_CYLINDER && (t2 == MJPC_GEOM_CYLINDER || t2 == MJPC_GEOM_BOX)) {
     OContact tmp[4];
-    int n = -1;
-    if (t2 == MJPC_GEOM_CYLINDER) n = capsule_capsule(tmp, margin, p1, m1, s1, p2, m2, s2);
-    else if (t2 == MJPC_GEOM_BOX) n = capsule_box(tmp, margin, p1, m1, s1, p2, m2, s2);
+    int n = t2 == MJPC_GEOM_CYLINDER ? capsule_capsule(tmp, margin, p1, m1, s1, p2, m2, s2) : capsule_box(tmp, margin, p1, m1, s1, p2, m2, s2);
     if (n == 0) return 0;
+    return convex_mpr(con, margin, t1, p1, m1, s1, t2, p2, m2, s2);
   }
   (*unsupported)++;
   return 0;
@@ -568,6 +730,8 @@ int oracle_debug_collide(int t1, const double *s1, const double *p1, const doubl
   else if (t1 == MJPC_GEOM_CAPSULE && t2 == MJPC_GEOM_CAPSULE) n = capsule_capsule(con, margin, p1, m1, s1, p2, m2, s2);
   else if (t1 == MJPC_GEOM_SPHERE && t2 == MJPC_GEOM_CYLINDER) n = sphere_cylinder(con, margin, p1, s1[0], p2, m2, s2);
   else if (t1 == MJPC_GEOM_CAPSULE && t2 == MJPC_GEOM_CYLINDER) n = capsule_cylinder(con, margin, p1, m1, s1, p2, m2, s2);
+  else if (t1 == MJPC_GEOM_CYLINDER) n = convex_mpr(con, margin, t1, p1, m1, s1, t2, p2, m2, s2);
+  else if (t1 >= 100) n = convex_mpr(con, margin, t1 - 100, p1, m1, s1, t2, p2, m2, s2);   /* any supported pair through the portal collider */
   for (int k = 0; k < n; k++) {
     out[7 * k] = con[k].dist;
     o_copy3(out + 7 * k + 1, con[k].pos);

@@ -78,6 +78,15 @@ def test_limited_ball_joints_and_tendon_spring_damper_cross_branch_limit():
     assert allc["diag"][:, 2].max() >= 2 and not out["failure"].any()        # limit rows were active
 
 
+def test_convex_pairs_through_the_portal_refinement_collider():
+    """cylinder-box and cylinder-cylinder (MuJoCo: mjc_Convex / libccd MPR): a cylinder standing on a box with a second one lying
+    across it, pushed sideways by a motor; same contacts, same trajectories as the oracle."""
+    from mujoco_mpc_amd.modelgen import cylinder_pile
+    m, task, d = cylinder_pile()
+    out, ref, allc = _compare(m, task, d, 3, 50, 12, (0.5, 0.0), 2, 1e-5)
+    assert allc["diag"][:, 1].max() >= 3 and not out["failure"].any()
+
+
 def test_cartpole_c1_config():
     """BASELINE config C1: 16 samples, horizon 50, 10 cubic knots."""
     m, task, d = cartpole()

@@ -508,3 +508,42 @@ def test_tendon_spring_and_damper_closed_form():
     b.tendons[0]["springlength"] = None
     m2 = b.compile()
     assert np.allclose(m2["tendon_lengthspring"], 0.0)
+
+
+def test_portal_refinement_collider_against_closed_forms():
+    """Convex pairs without an analytic collider (cylinder-cylinder, cylinder-box; MuJoCo: libccd MPR) go through the portal
+    refinement collider of oracle/collide.c.  Type 100 + t sends any supported primitive through it: spheres must reproduce the
+    closed form to round-off; a cylinder on a box face / lying on it / hovering inside the margin / crossing another cylinder
+    must give the known depth, normal (geom 1 -> geom 2) and a contact half way between the surfaces, to the 1e-6 tolerance."""
+    I = np.eye(3)
+    rng = np.random.default_rng(0)
+
+    def randrot():
+        q = rng.normal(size=4); q /= np.linalg.norm(q); w, x, y, z = q
+        return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)], [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                         [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    for _ in range(500):
+        r1, r2 = rng.uniform(0.02, 0.2, 2); d = rng.normal(size=3); d /= np.linalg.norm(d); gap = rng.uniform(-0.5, 0.3) * min(r1, r2)
+        c, n = _collide(102, [r1], [0, 0, 0], randrot(), 2, [r2], d * (r1 + r2 + gap), randrot(), margin=0.01)
+        if gap <= 0.01:
+            assert n == 1 and abs(c[0, 0] - gap) < 1e-10 and np.abs(c[0, 4:] - d).max() < 1e-9 and np.abs(c[0, 1:4] - d * (r1 + gap / 2)).max() < 1e-9
+        else:
+            assert n == 0
+    pen = 1e-3
+    c, n = _collide(5, [0.03, 0.05], [0.01, 0.02, 0.1 + 0.05 - pen], I, 6, [0.5, 0.5, 0.1], [0, 0, 0], I)          # standing on the face
+    assert n == 1 and abs(c[0, 0] + pen) < 1e-6 and np.allclose(c[0, 4:], [0, 0, -1], atol=1e-6) and abs(c[0, 3] - (0.1 - pen / 2)) < 1e-6
+    assert np.hypot(c[0, 1] - 0.01, c[0, 2] - 0.02) <= 0.03 + 1e-9                                                   # inside the cap's footprint
+    c, n = _collide(5, [0.03, 0.05], [0.01, 0.02, 0.1 + 0.03 - pen], _rot("x", np.pi / 2), 6, [0.5, 0.5, 0.1], [0, 0, 0], I)   # lying on it
+    assert n == 1 and abs(c[0, 0] + pen) < 1e-6 and np.allclose(c[0, 4:], [0, 0, -1], atol=1e-5) and abs(c[0, 1] - 0.01) < 1e-3
+    c, n = _collide(5, [0.03, 0.05], [0, 0, 0.1 + 0.05 + 5e-4], I, 6, [0.5, 0.5, 0.1], [0, 0, 0], I, margin=1e-3)       # inside the margin
+    assert n == 1 and abs(c[0, 0] - 5e-4) < 1e-6 and abs(c[0, 3] - 0.10025) < 1e-6
+    _, n = _collide(5, [0.03, 0.05], [0, 0, 0.1 + 0.05 + 2e-3], I, 6, [0.5, 0.5, 0.1], [0, 0, 0], I, margin=1e-3)
+    assert n == 0
+    c, n = _collide(5, [0.03, 0.1], [0, 0, 0], _rot("x", np.pi / 2), 5, [0.02, 0.1], [0, 0, 0.05 - pen], _rot("y", np.pi / 2))   # crossed
+    assert n == 1 and abs(c[0, 0] + pen) < 1e-6 and np.allclose(c[0, 4:], [0, 0, 1], atol=1e-5) and np.allclose(c[0, 1:4], [0, 0, 0.03 - pen / 2], atol=1e-4)
+    # a cylinder resting on the box of the cylinder_pile model stays there (one contact under the cap, friction holds it)
+    from mujoco_mpc_amd.modelgen import cylinder_pile
+    m, task, d = cylinder_pile()
+    o = ol.Oracle(m, task)
+    q, v, _, _, w = o.step(d["state"][:m["nq"]], d["state"][m["nq"]:], ctrl=[0.0], nstep=150)
+    assert w == 0 and abs(q[2] - 0.26) < 3e-3 and np.hypot(q[0], q[1]) < 5e-3 and abs(q[9] - 0.35) < 1e-2

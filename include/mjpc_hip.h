@@ -216,7 +216,7 @@ typedef struct MjpcHipEngine MjpcHipEngine;
 /* Create an engine on HIP device `device`.  Copies model+task to HBM.  max_local = largest
  * num_local that will be planned on this device.  Returns NULL on error (see last_error).
  * Models the engine cannot roll out faithfully are REFUSED here (never silently approximated): geom pairs without a
- * collider (hfield / ellipsoid / mesh that can collide), tendon friction loss, actuator transmissions other than joint /
+ * collider (height field / mesh that can collide), group-0 geoms the quadruped task's ground ray cannot hit, tendon friction loss, actuator transmissions other than joint /
  * fixed tendon, nuserdata > 0, na > 0, nconmax > 64, nefcmax > 192, iterations > 250, num_spline_points capacity 36, LDS footprint > 160 KiB. */
 MjpcHipEngine *mjpc_hip_create(const MjpcHipModel *model, const MjpcHipTask *task,
                                int max_local, int max_horizon, int device);

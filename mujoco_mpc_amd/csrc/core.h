@@ -908,6 +908,10 @@ DEV void mpr_support1(const MShape &s, const double *dir, double *out) {
     double n = sqrt(l[0] * l[0] + l[1] * l[1]);
     if (n > D_MINVAL) { v[0] = s.size[0] * l[0] / n; v[1] = s.size[0] * l[1] / n; } else { v[0] = 0; v[1] = 0; }
     v[2] = l[2] >= 0 ? s.size[1] : -s.size[1];
+  } else if (s.type == 4) {
+    double a = s.size[0] * s.size[0] * l[0], b = s.size[1] * s.size[1] * l[1], c = s.size[2] * s.size[2] * l[2];
+    double n = sqrt(a * l[0] + b * l[1] + c * l[2]);
+    if (n > D_MINVAL) { v[0] = a / n; v[1] = b / n; v[2] = c / n; } else { v[0] = 0; v[1] = 0; v[2] = 0; }
   } else if (s.type == 3) {
     v[0] = s.size[0] * l[0]; v[1] = s.size[0] * l[1]; v[2] = s.size[0] * l[2] + (l[2] >= 0 ? s.size[1] : -s.size[1]);
   } else {
@@ -1047,7 +1051,23 @@ DEV int np_convex(NPCon *con, double margin, int t1, const double *p1, const dou
   return 1;
 }
 
-// The rarely-met pair types (capsule-box, box-box, the cylinder pairs).  n = -1: no collider and possibly touching.
+// plane against an ellipsoid: the ellipsoid's support point against the plane normal
+DEV int np_plane_ellipsoid(NPCon *con, double margin, const double *pp, const double *pm, const double *ep, const double *em, const double *size) {
+  double n[3] = {pm[2], pm[5], pm[8]}, nd[3] = {-pm[2], -pm[5], -pm[8]}, sp[3], dif[3];
+  MShape E = {4, ep, em, size, 0.0};
+  mpr_support1(E, nd, sp);
+  d_sub3(dif, sp, pp);
+  double dist = d_dot3(dif, n);
+  if (dist > margin) return 0;
+  NPCon t;
+  t.dist = dist;
+  d_addscl3(t.pos, sp, n, -0.5 * dist);
+  d_copy3(t.frame, n); t.frame[3] = 0; t.frame[4] = 0; t.frame[5] = 0;
+  np_put(con, 0, t);
+  return 1;
+}
+
+// The rarely-met pair types (capsule-box, box-box, the cylinder and ellipsoid pairs).  n = -1: no collider and possibly touching.
 // Only the out-of-line flavour of the narrow-phase batch (narrow_batch<true>) contains this code: the batch loop of
 // collision() itself stays free of it and of any call inside the loop body's live ranges.
 struct NPOut { NPCon c[4]; int n; };
@@ -1064,6 +1084,8 @@ DEV NPOut narrow_heavy(Ctx &c, int g1, int g2, double margin) {
   else if (t1 == 6 && t2 == 6) o.n = np_box_box(o.c, margin, p1, m1, s1, p2, m2, s2);
   else if (t1 == 2 && t2 == 5) o.n = np_sphere_cylinder(o.c, margin, p1, s1[0], p2, m2, s2);
   else if (t1 == 3 && t2 == 5) o.n = np_capsule_cylinder(o.c, margin, p1, m1, s1, p2, m2, s2);
+  else if (t1 == 0 && t2 == 4) o.n = np_plane_ellipsoid(o.c, margin, p1, m1, p2, m2, s2);
+  else if ((t1 == 4 || t2 == 4) && t1 >= 2 && t2 <= 6) o.n = np_convex(o.c, margin, t1, p1, m1, s1, t2, p2, m2, s2);
   else if (t1 == 5 && (t2 == 5 || t2 == 6)) {
     // cylinder-cylinder / cylinder-box: the cylinder's bounding capsule decides "certainly apart" (exact, cheap); otherwise the
     // portal-refinement collider

@@ -274,9 +274,9 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
       if (m->geom_type[g1] == MJPC_GEOM_PLANE && m->geom_type[g2] == MJPC_GEOM_PLANE) continue;
       for (int g : {g1, g2}) {
         int ty = m->geom_type[g];
-        if (ty == MJPC_GEOM_HFIELD || ty == MJPC_GEOM_ELLIPSOID || ty == MJPC_GEOM_MESH) {
+        if (ty == MJPC_GEOM_HFIELD || ty == MJPC_GEOM_MESH) {
           p.error = "geom " + std::to_string(g) + " (type " + std::to_string(ty) + ") can collide with geom " + std::to_string(g == g1 ? g2 : g1) +
-                    " but height fields, ellipsoids and meshes have no collider here";
+                    " but height fields and meshes have no collider here";
           return false;
         }
       }
@@ -288,7 +288,15 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
     for (int i = 0; i < nv; i++) if (m->dof_frictionloss[i] > 0) fr.push_back(i);
     for (int j = 0; j < nj; j++) if (m->jnt_limited[j] && (m->jnt_type[j] == MJPC_JNT_SLIDE || m->jnt_type[j] == MJPC_JNT_HINGE)) lim.push_back(j);
     for (int j = 0; j < nj; j++) if (m->jnt_limited[j] && m->jnt_type[j] == MJPC_JNT_BALL) limb.push_back(j);
-    for (int g = 0; g < ng; g++) if (m->geom_group[g] == 0) ray.push_back(g);
+    for (int g = 0; g < ng; g++) if (m->geom_group[g] == 0) {
+      // Ground() (utilities.cc:531-553) casts a ray at the group-0 geoms: the ray code knows planes, spheres and boxes
+      int ty = m->geom_type[g];
+      if (t->task_id == MJPC_TASK_QUADRUPED && ty != MJPC_GEOM_PLANE && ty != MJPC_GEOM_SPHERE && ty != MJPC_GEOM_BOX) {
+        p.error = "geom " + std::to_string(g) + " (type " + std::to_string(ty) + ") is in group 0 but the ground ray cast only intersects planes, spheres and boxes";
+        return false;
+      }
+      ray.push_back(g);
+    }
     M.nfric = (int)fr.size(); M.nlimit = (int)lim.size(); M.nlimit_ball = (int)limb.size(); M.nray = (int)ray.size();
     M.fric_dof = as_off<int>(put_i(p, fr.data(), fr.size())); M.limit_jnt = as_off<int>(put_i(p, lim.data(), lim.size()));
     M.limit_ball = as_off<int>(put_i(p, limb.data(), limb.size()));

@@ -15,7 +15,7 @@ import struct
 
 import numpy as np
 
-from .builder import (BALL, BOX, CAPSULE, CYLINDER, FREE, HINGE, PLANE, SLIDE, SPHERE, ModelBuilder)
+from .builder import (BALL, BOX, CAPSULE, CYLINDER, ELLIPSOID, FREE, HINGE, PLANE, SLIDE, SPHERE, ModelBuilder)
 
 TASK_PARTICLE, TASK_CARTPOLE, TASK_QUADRUPED, TASK_COPYSTATE, TASK_HUMANOID_TRACK, TASK_HUMANOID_STAND, TASK_HUMANOID_WALK = 0, 1, 2, 3, 4, 5, 6
 TASK_SHADOW_REORIENT = 7
@@ -509,7 +509,8 @@ def ball_chain(timestep=0.005):
 
 def cylinder_pile(timestep=0.004):
     """Test model for the convex pairs that go through the portal-refinement collider: a cylinder standing on a box, a second
-    one lying across it (cylinder-box and cylinder-cylinder contacts), a motor pushing the lower one sideways."""
+    one lying across it (cylinder-box and cylinder-cylinder contacts), a motor pushing the lower one sideways; an ellipsoid on
+    the box and a tilted one on the floor plane."""
     b = ModelBuilder(timestep=timestep, cone=1, impratio=1.0, contact=True)
     b.geom(0, "floor", PLANE, pos=(0, 0, 0), size=(2, 2, 0.1))
     b.geom(0, "table", BOX, pos=(0, 0, 0.1), size=(0.3, 0.3, 0.1), friction=(0.8, 0.005, 0.0001))
@@ -519,13 +520,19 @@ def cylinder_pile(timestep=0.004):
     c2 = b.body("c2", 0, pos=(0.01, 0.0, 0.2 + 0.12 + 0.03 + 0.006), quat=(math.cos(math.pi / 4), math.sin(math.pi / 4), 0, 0))
     b.joint(c2, "c2_free", FREE)
     b.geom(c2, "c2_g", CYLINDER, size=(0.03, 0.08), mass=0.2, friction=(0.8, 0.005, 0.0001))
+    e1 = b.body("e1", 0, pos=(0.18, 0.1, 0.2 + 0.03 + 0.002))
+    b.joint(e1, "e1_free", FREE)
+    b.geom(e1, "e1_g", ELLIPSOID, size=(0.06, 0.04, 0.03), mass=0.3, friction=(0.8, 0.005, 0.0001))        # on the table: ellipsoid-box
+    e2 = b.body("e2", 0, pos=(0.6, 0.0, 0.05 + 0.002), quat=(math.cos(0.3), 0, math.sin(0.3), 0))
+    b.joint(e2, "e2_free", FREE)
+    b.geom(e2, "e2_g", ELLIPSOID, size=(0.05, 0.08, 0.04), mass=0.3, friction=(0.8, 0.005, 0.0001))        # on the floor: plane-ellipsoid
     pusher = b.body("pusher", 0, pos=(-0.12, 0, 0.26))
     b.joint(pusher, "push", SLIDE, axis=(1, 0, 0), limited=True, range=(-0.02, 0.1), damping=2.0)
     b.geom(pusher, "push_g", SPHERE, size=(0.02,), mass=0.1)
     top = b.site(c2, "top", pos=(0, 0, 0))
     b.actuator("push_m", "push", gear=4.0, ctrlrange=(-1, 1))
     m = b.compile()
-    task = make_task(TASK_COPYSTATE, [(15, 0, 1.0), (13, 0, 0.1)], traces=[(OBJ_SITE, top)])
+    task = make_task(TASK_COPYSTATE, [(m["nq"], 0, 1.0), (m["nv"], 0, 0.1)], traces=[(OBJ_SITE, top)])
     st = np.concatenate([m["qpos0"], np.zeros(m["nv"])])
     defaults = dict(N=6, P=3, sigma=(0.5, 0.0), interp=2, horizon=50, state=st, mocap=np.zeros(0))
     return m, task, defaults

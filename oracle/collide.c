@@ -11,8 +11,8 @@
  * from the reference tree; the two colliders here are this build's own constructions with the same
  * conventions and contact budgets (capsule-box <= 2 contacts: closest segment point + far end cap;
  * box-box <= 4: separating-axis test, then reference-face clipping or one edge-edge contact).
- * cylinder-cylinder and cylinder-box go through a portal-refinement (MPR) collider, below.  Ellipsoid / mesh / height-field pairs
- * are counted in `unsupported` and produce no contact; the engine refuses such models at create().
+ * cylinder-cylinder, cylinder-box and every ellipsoid pair (plane-ellipsoid: closed form) go through a portal-refinement (MPR)
+ * collider, below.  Mesh / height-field pairs are counted in `unsupported` and produce no contact; the engine refuses such models at create().
  * PARITY UNPINNED (no MuJoCo in this image); analytic checks in tests/test_oracle_physics.py.
  */
 #include "oracle.h"
@@ -506,6 +506,10 @@ static void mpr_support1(const MShape *s, const double *dir, double *out) {
     double n = sqrt(l[0] * l[0] + l[1] * l[1]);
     if (n > O_MINVAL) { v[0] = s->size[0] * l[0] / n; v[1] = s->size[0] * l[1] / n; } else { v[0] = 0; v[1] = 0; }
     v[2] = l[2] >= 0 ? s->size[1] : -s->size[1];
+  } else if (s->type == MJPC_GEOM_ELLIPSOID) {
+    double a = s->size[0] * s->size[0] * l[0], b = s->size[1] * s->size[1] * l[1], c = s->size[2] * s->size[2] * l[2];
+    double n = sqrt(a * l[0] + b * l[1] + c * l[2]);
+    if (n > O_MINVAL) { v[0] = a / n; v[1] = b / n; v[2] = c / n; } else { v[0] = 0; v[1] = 0; v[2] = 0; }
   } else if (s->type == MJPC_GEOM_CAPSULE) {
     v[0] = s->size[0] * l[0]; v[1] = s->size[0] * l[1]; v[2] = s->size[0] * l[2] + (l[2] >= 0 ? s->size[1] : -s->size[1]);
   } else {   /* sphere */
@@ -650,6 +654,21 @@ static int convex_mpr(OContact *con, double margin, int t1, const double *p1, co
   return 1;
 }
 
+/* plane against an ellipsoid: the ellipsoid's support point against the plane normal (mjc_PlaneConvex's construction) */
+static int plane_ellipsoid(OContact *con, double margin, const double *pp, const double *pm, const double *ep, const double *em, const double *size) {
+  double n[3] = {pm[2], pm[5], pm[8]}, nd[3] = {-pm[2], -pm[5], -pm[8]}, sp[3], dif[3];
+  MShape E = {MJPC_GEOM_ELLIPSOID, ep, em, size, 0.0};
+  mpr_support1(&E, nd, sp);
+  o_sub3(dif, sp, pp);
+  double dist = o_dot3(dif, n);
+  if (dist > margin) return 0;
+  o_zero(con->frame, 9);
+  o_copy3(con->frame, n);
+  con->dist = dist;
+  o_addscl3(con->pos, sp, n, -0.5 * dist);
+  return 1;
+}
+
 int oracle_collide_pair(const OModel *om, OData *d, int g1, int g2, double margin, OContact *con, int *unsupported) {
   const MjpcHipModel *m = &om->m;
   int t1 = m->geom_type[g1], t2 = m->geom_type[g2];
@@ -706,6 +725,10 @@ int oracle_collide_pair(const OModel *om, OData *d, int g1, int g2, double margi
   } else if (t1 == MJPC_GEOM_BOX && t2 == MJPC_GEOM_BOX) {
     return box_box(con, margin, p1, m1, s1, p2, m2, s2);
   }
+  /* ellipsoids: closed form against a plane, the portal-refinement collider against everything else */
+  if (t1 == MJPC_GEOM_PLANE && t2 == MJPC_GEOM_ELLIPSOID) return plane_ellipsoid(con, margin, p1, m1, p2, m2, s2);
+  if ((t1 == MJPC_GEOM_ELLIPSOID || t2 == MJPC_GEOM_ELLIPSOID) && t1 >= MJPC_GEOM_SPHERE && t2 <= MJPC_GEOM_BOX)
+    return convex_mpr(con, margin, t1, p1, m1, s1, t2, p2, m2, s2);
   /* cylinder-cylinder and cylinder-box: the cylinder's bounding capsule (same radius and half length) contains it, so a capsule
    * farther than the margin means certainly no contact (exact, cheap); otherwise the portal-refinement collider decides */
   if (t1 == MJPC_GEOM_CYLINDER && (t2 == MJPC_GEOM_CYLINDER || t2 == MJPC_GEOM_BOX)) {
@@ -730,7 +753,8 @@ int oracle_debug_collide(int t1, const double *s1, const double *p1, const doubl
   else if (t1 == MJPC_GEOM_CAPSULE && t2 == MJPC_GEOM_CAPSULE) n = capsule_capsule(con, margin, p1, m1, s1, p2, m2, s2);
   else if (t1 == MJPC_GEOM_SPHERE && t2 == MJPC_GEOM_CYLINDER) n = sphere_cylinder(con, margin, p1, s1[0], p2, m2, s2);
   else if (t1 == MJPC_GEOM_CAPSULE && t2 == MJPC_GEOM_CYLINDER) n = capsule_cylinder(con, margin, p1, m1, s1, p2, m2, s2);
-  else if (t1 == MJPC_GEOM_CYLINDER) n = convex_mpr(con, margin, t1, p1, m1, s1, t2, p2, m2, s2);
+  else if (t1 == MJPC_GEOM_PLANE && t2 == MJPC_GEOM_ELLIPSOID) n = plane_ellipsoid(con, margin, p1, m1, p2, m2, s2);
+  else if (t1 == MJPC_GEOM_CYLINDER || t1 == MJPC_GEOM_ELLIPSOID || t2 == MJPC_GEOM_ELLIPSOID) n = convex_mpr(con, margin, t1, p1, m1, s1, t2, p2, m2, s2);
   else if (t1 >= 100) n = convex_mpr(con, margin, t1 - 100, p1, m1, s1, t2, p2, m2, s2);   /* any supported pair through the portal collider */
   for (int k = 0; k < n; k++) {
     out[7 * k] = con[k].dist;

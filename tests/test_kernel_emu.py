@@ -71,9 +71,9 @@ def test_lds_budget_of_every_baseline_model():
 
 
 def test_models_the_engine_cannot_roll_out_are_refused_at_create():
-    """ADVICE r1: no silent approximation.  Host-side validation (mjpc_host::build) refuses ellipsoids / meshes that can collide,
+    """ADVICE r1: no silent approximation.  Host-side validation (mjpc_host::build) refuses meshes / height fields that can collide,
     tendon friction loss, user data, oversized buffers; a cylinder next to a capsule is accepted (conservative run-time test)."""
-    from mujoco_mpc_amd.modelgen.builder import BALL, BOX, CYLINDER, ELLIPSOID, FREE, HINGE, PLANE, SPHERE, ModelBuilder
+    from mujoco_mpc_amd.modelgen.builder import BALL, BOX, CYLINDER, ELLIPSOID, FREE, HINGE, MESH, PLANE, SPHERE, ModelBuilder
     from mujoco_mpc_amd.modelgen.tasks import make_task
     lib = ctypes.CDLL(capi.ENGINE_PATH)
     lib.mjpc_hip_layout_bytes.argtypes = [ctypes.POINTER(capi.MjpcHipModel), ctypes.POINTER(capi.MjpcHipTask), ctypes.c_int]
@@ -97,7 +97,8 @@ def test_models_the_engine_cannot_roll_out_are_refused_at_create():
             assert n < 0 and expect in lib.mjpc_hip_last_error().decode(), lib.mjpc_hip_last_error()
 
     check(lambda b, body: None, None)
-    check(lambda b, body: b.geom(body, "e", ELLIPSOID, size=(0.1, 0.2, 0.3)), "ellipsoids")
+    check(lambda b, body: b.geom(body, "e", ELLIPSOID, size=(0.1, 0.2, 0.3)), None)      # ellipsoids go through the portal-refinement collider
+    check(lambda b, body: b.geom(body, "e", MESH, size=(0.1, 0.2, 0.3)), "meshes")
 
     def ball(b, body):
         c = b.body("c", body)

@@ -541,6 +541,22 @@ def test_portal_refinement_collider_against_closed_forms():
     assert n == 0
     c, n = _collide(5, [0.03, 0.1], [0, 0, 0], _rot("x", np.pi / 2), 5, [0.02, 0.1], [0, 0, 0.05 - pen], _rot("y", np.pi / 2))   # crossed
     assert n == 1 and abs(c[0, 0] + pen) < 1e-6 and np.allclose(c[0, 4:], [0, 0, 1], atol=1e-5) and np.allclose(c[0, 1:4], [0, 0, 0.03 - pen / 2], atol=1e-4)
+    # ellipsoids: plane-ellipsoid is a closed form (height of the support point: sqrt(sum (a_i (R^T n)_i)^2)); an ellipsoid with
+    # three equal semi-axes is a sphere for the portal collider
+    for _ in range(200):
+        R = randrot(); a = rng.uniform(0.02, 0.1, 3); z = rng.uniform(0.0, 0.12)
+        h = np.sqrt(np.sum((a * (R.T @ np.array([0, 0, 1.0]))) ** 2))
+        c, n = _collide(0, [1, 1, 0.1], [0, 0, 0], I, 4, a, [0.3, -0.2, z], R, margin=0.002)
+        if z - h <= 0.002:
+            assert n == 1 and abs(c[0, 0] - (z - h)) < 1e-12 and np.allclose(c[0, 4:], [0, 0, 1]) and abs(c[0, 3] - (z - h) / 2) < 1e-12
+        else:
+            assert n == 0
+    for _ in range(200):
+        r1, r2 = rng.uniform(0.02, 0.2, 2); d = rng.normal(size=3); d /= np.linalg.norm(d); gap = rng.uniform(-0.3, 0.02) * min(r1, r2)
+        c, n = _collide(2, [r1], [0, 0, 0], I, 4, [r2, r2, r2], d * (r1 + r2 + gap), randrot(), margin=0.01)
+        assert n == 1 and abs(c[0, 0] - gap) < 1e-9 and np.abs(c[0, 4:] - d).max() < 1e-8
+    c, n = _collide(4, [0.06, 0.04, 0.03], [0.1, 0.05, 0.1 + 0.03 - pen], I, 6, [0.5, 0.5, 0.1], [0, 0, 0], I)       # ellipsoid on a box face
+    assert n == 1 and abs(c[0, 0] + pen) < 1e-6 and np.allclose(c[0, 4:], [0, 0, -1], atol=1e-4) and np.allclose(c[0, 1:3], [0.1, 0.05], atol=2e-3)
     # a cylinder resting on the box of the cylinder_pile model stays there (one contact under the cap, friction holds it)
     from mujoco_mpc_amd.modelgen import cylinder_pile
     m, task, d = cylinder_pile()

@@ -2275,6 +2275,23 @@ DEV void task_residual(Ctx &c, double *residual) {
     residual_humanoid_walk(c, residual);
   } else if (id == 7) {
     residual_shadow(c, residual);
+  } else if (id == 8) {   // walker.cc:39-57: control, torso height - goal, torso z axis z - 1, subtree x velocity - goal
+    int nu = M.nu, b = MI(task.int_data)[0];
+    PFOR(i, nu) residual[i] = c.ctrl[i];
+    if (LANE == 0) {
+      residual[nu] = c.xpos[3 * b + 2] - MD(task.parameters)[0];
+      residual[nu + 1] = c.xmat[9 * b + 8] - 1.0;
+      residual[nu + 2] = c.subtree_linvel[3 * b] - MD(task.parameters)[1];
+    }
+  } else if (id == 9) {   // acrobot.cc:34-49: goal - tip (z, x), joint velocities, control
+    if (LANE == 0) {
+      int g = MI(task.int_data)[0], t = MI(task.int_data)[1];
+      residual[0] = c.site_xpos[3 * g + 2] - c.site_xpos[3 * t + 2];
+      residual[1] = c.site_xpos[3 * g] - c.site_xpos[3 * t];
+      residual[2] = c.qvel[0];
+      residual[3] = c.qvel[1];
+      residual[4] = c.ctrl[0];
+    }
   }
   c.warning = wave_or_i(c.warning);      // a ray miss is raised by the lane that cast it
   SYNC();

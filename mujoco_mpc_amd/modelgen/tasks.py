@@ -19,6 +19,7 @@ from .builder import (BALL, BOX, CAPSULE, CYLINDER, ELLIPSOID, FREE, HINGE, PLAN
 
 TASK_PARTICLE, TASK_CARTPOLE, TASK_QUADRUPED, TASK_COPYSTATE, TASK_HUMANOID_TRACK, TASK_HUMANOID_STAND, TASK_HUMANOID_WALK = 0, 1, 2, 3, 4, 5, 6
 TASK_SHADOW_REORIENT = 7
+TASK_WALKER, TASK_ACROBOT = 8, 9
 OBJ_BODY, OBJ_XBODY, OBJ_GEOM, OBJ_SITE = 1, 2, 5, 6
 NORM_NPARAM = {-1: 0, 0: 0, 1: 2, 2: 1, 3: 1, 5: 1, 6: 1, 7: 2, 8: 1}   # mjpc/norm.cc:25-47
 
@@ -476,6 +477,67 @@ def shadow_hand(timestep=0.01, cone=0, nconmax=32, nefcmax=128):
     return m, task, defaults
 
 
+# ----------------------------------------------------------------------------------- walker, acrobot (registry tasks)
+def walker(timestep=0.01):
+    """mjpc/tasks/walker (task.xml:10-33, walker.cc:39-57).  The planar walker of dm_control's walker.xml is fetched and patched by
+    CMake (walker.xml.patch), not in the tree: SYNTHETIC restatement of its published structure (torso on rootz / rootx / rooty,
+    two legs of thigh / leg / foot capsules, hinge axes -y, motors with gears 100 / 50 / 20), numbers recalled.  Cost table,
+    parameters and agent settings are task.xml's: horizon 0.8 s at 0.01 s, 3 spline points, exploration 0.5."""
+    b = ModelBuilder(timestep=timestep, cone=0, contact=True)
+    b.geom(0, "floor", PLANE, pos=(998, 0, 0), size=(1000, 0.8, 0.2), friction=(0.7, 0.1, 0.1), contype=0, conaffinity=1)
+    kw = dict(contype=1, conaffinity=0, friction=(0.7, 0.1, 0.1), density=1000.0)
+    torso = b.body("torso", 0, pos=(0, 0, 1.3))
+    b.joint(torso, "rootz", SLIDE, axis=(0, 0, 1))
+    b.joint(torso, "rootx", SLIDE, axis=(1, 0, 0))
+    b.joint(torso, "rooty", HINGE, axis=(0, 1, 0))
+    b.geom(torso, "torso", CAPSULE, size=(0.07, 0.3), **kw)
+    site = b.site(torso, "torso_site")
+    jkw = dict(axis=(0, -1, 0), damping=0.1, armature=0.01, limited=True, solimplimit=(0, 0.99, 0.01, 0.5, 2))
+    for side, y in (("right", -0.05), ("left", 0.05)):
+        thigh = b.body(side + "_thigh", torso, pos=(0, y, -0.3))
+        b.joint(thigh, side + "_hip", HINGE, range=(math.radians(-20), math.radians(100)), **jkw)
+        b.geom(thigh, side + "_thigh", CAPSULE, size=(0.05, 0.225), pos=(0, 0, -0.225), **kw)
+        leg = b.body(side + "_leg", thigh, pos=(0, 0, -0.7))
+        b.joint(leg, side + "_knee", HINGE, pos=(0, 0, 0.25), range=(math.radians(-150), 0.0), **jkw)
+        b.geom(leg, side + "_leg", CAPSULE, size=(0.04, 0.25), **kw)
+        foot = b.body(side + "_foot", leg, pos=(0.06, 0, -0.25))
+        b.joint(foot, side + "_ankle", HINGE, pos=(-0.06, 0, 0), range=(math.radians(-45), math.radians(45)), **jkw)
+        b.geom(foot, side + "_foot", CAPSULE, size=(0.05, 0.1), zaxis=(1, 0, 0), **kw)
+    for side in ("right", "left"):
+        for jn, gear in (("hip", 100.0), ("knee", 50.0), ("ankle", 20.0)):
+            b.actuator(f"{side}_{jn}", f"{side}_{jn}", gear=gear, ctrlrange=(-1, 1))
+    m = b.compile()
+    task = make_task(TASK_WALKER, [(6, 0, 0.1), (1, 0, 10.0), (1, 0, 3.0), (1, 0, 1.0)], parameters=[1.2, 0.0],
+                     traces=[(OBJ_SITE, site)], int_data=[torso])
+    st = np.concatenate([m["qpos0"], np.zeros(m["nv"])])
+    defaults = dict(N=10, P=3, sigma=(0.5, 0.0), interp=2, horizon=80, state=st, mocap=np.zeros(0))
+    return m, task, defaults
+
+
+def acrobot(timestep=0.01):
+    """mjpc/tasks/acrobot (task.xml:8-31, acrobot.cc:34-49).  dm_control's acrobot.xml is fetched and patched by CMake, not in the
+    tree: SYNTHETIC restatement (two unit-mass 1 m capsule links on y hinges, damping 0.05, motor on the elbow with gear 2,
+    constraints disabled, target site 4 m up), numbers recalled.  Cost table and agent settings are task.xml's: horizon 2 s at
+    0.01 s, 10 spline points, exploration 0.05; start = key "home" (hanging)."""
+    b = ModelBuilder(timestep=timestep, contact=False)
+    b.geom(0, "floor", PLANE, size=(3, 3, 0.2), contype=0, conaffinity=0)
+    target = b.site(0, "target", pos=(0, 0, 4))
+    upper = b.body("upper_arm", 0, pos=(0, 0, 2))
+    b.joint(upper, "shoulder", HINGE, axis=(0, 1, 0), damping=0.05)
+    b.geom(upper, "upper_arm", CAPSULE, size=(0.051, 0), fromto=(0, 0, 0, 0, 0, 1), mass=1.0, contype=0, conaffinity=0)
+    lower = b.body("lower_arm", upper, pos=(0, 0, 1))
+    b.joint(lower, "elbow", HINGE, axis=(0, 1, 0), damping=0.05)
+    b.geom(lower, "lower_arm", CAPSULE, size=(0.049, 0), fromto=(0, 0, 0, 0, 0, 1), mass=1.0, contype=0, conaffinity=0)
+    tip = b.site(lower, "tip", pos=(0, 0, 1))
+    b.actuator("elbow", "elbow", gear=2.0, ctrlrange=(-1, 1))
+    b.key("home", [3.142, 0.0])
+    m = b.compile()
+    task = make_task(TASK_ACROBOT, [(2, 0, 50.0), (2, 0, 1.0), (1, 0, 0.05)], parameters=[0.0], traces=[(OBJ_SITE, tip)],
+                     int_data=[target, tip])
+    defaults = dict(N=10, P=10, sigma=(0.05, 0.0), interp=2, horizon=200, state=np.array([3.142, 0.0, 0.0, 0.0]), mocap=np.zeros(0))
+    return m, task, defaults
+
+
 # ----------------------------------------------------------------------------------- a7 features off the BASELINE models
 def ball_chain(timestep=0.005):
     """Small test model for the mj_step features no BASELINE model has: limited ball joints and a fixed tendon with a spring, a
@@ -538,4 +600,4 @@ def cylinder_pile(timestep=0.004):
     return m, task, defaults
 
 
-REGISTRY = {"ball_chain": ball_chain, "cylinder_pile": cylinder_pile, "humanoid_stand": humanoid_stand, "humanoid_walk": humanoid_walk, "particle": particle, "cartpole": cartpole, "quadruped": quadruped, "humanoid_track": humanoid_track, "shadow_hand": shadow_hand}
+REGISTRY = {"walker": walker, "acrobot": acrobot, "ball_chain": ball_chain, "cylinder_pile": cylinder_pile, "humanoid_stand": humanoid_stand, "humanoid_walk": humanoid_walk, "particle": particle, "cartpole": cartpole, "quadruped": quadruped, "humanoid_track": humanoid_track, "shadow_hand": shadow_hand}

@@ -534,6 +534,23 @@ void oracle_residual(const OModel *om, OData *d, double *residual) {
     case MJPC_TASK_SHADOW_REORIENT:
       residual_shadow(om, d, residual);
       break;
+    case MJPC_TASK_WALKER: {   /* walker.cc:39-57 */
+      int nu = m->nu, b = om->t.int_data[0];
+      o_copy(residual, d->ctrl, nu);
+      residual[nu] = d->xpos[3 * b + 2] - om->t.parameters[0];        /* framepos of xbody torso, z */
+      residual[nu + 1] = d->xmat[9 * b + 8] - 1.0;                    /* framezaxis of xbody torso, z */
+      residual[nu + 2] = d->subtree_linvel[3 * b] - om->t.parameters[1];
+      break;
+    }
+    case MJPC_TASK_ACROBOT: {  /* acrobot.cc:34-49 */
+      int g = om->t.int_data[0], t = om->t.int_data[1];
+      residual[0] = d->site_xpos[3 * g + 2] - d->site_xpos[3 * t + 2];
+      residual[1] = d->site_xpos[3 * g] - d->site_xpos[3 * t];
+      residual[2] = d->qvel[0];
+      residual[3] = d->qvel[1];
+      residual[4] = d->ctrl[0];
+      break;
+    }
     default: break;
   }
 }

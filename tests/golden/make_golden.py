@@ -26,6 +26,10 @@ CONFIGS = {
     "quadruped_8x30": ("quadruped", 8, 30, 3, 2, 0.04, False),              # configs[1]/[3] model, reduced size
     "humanoid_track_4x24": ("humanoid_track", 4, 24, 16, 2, 0.15, False),   # configs[2] model, reduced size
     "shadow_hand_6x24": ("shadow_hand", 6, 24, 5, 0, 0.1, True),            # configs[4] model (synthetic hand), reduced size
+    "walker_10x80": ("walker", 10, 80, 3, 2, 0.5, False),                   # mjpc/tasks/walker/task.xml:10-15 (horizon 0.8 s, 3 points, exploration 0.5)
+    "acrobot_10x100": ("acrobot", 10, 100, 10, 2, 0.05, False),             # mjpc/tasks/acrobot/task.xml:9-17, half the horizon
+    "ball_chain_6x60": ("ball_chain", 6, 60, 4, 2, 0.4, False),             # limited ball joints, tendon spring / damper / cross-branch limit
+    "cylinder_pile_6x50": ("cylinder_pile", 6, 50, 3, 2, 0.5, False),       # cylinder / ellipsoid pairs through the portal-refinement collider
 }
 
 
@@ -49,7 +53,7 @@ def inputs(name):
 
 def main():
     import oracle_lib as ol
-    for name in CONFIGS:
+    for name in (sys.argv[1:] or CONFIGS):
         m, task, inp = inputs(name)
         o = ol.Oracle(m, task)
         N, H = int(inp["num_trajectory"]), int(inp["horizon"])

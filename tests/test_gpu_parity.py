@@ -87,6 +87,18 @@ def test_convex_pairs_through_the_portal_refinement_collider():
     assert allc["diag"][:, 1].max() >= 3 and not out["failure"].any()
 
 
+def test_walker_and_acrobot_registry_tasks():
+    """mjpc/tasks/walker (walker.cc:39-57, task.xml agent settings: horizon 0.8 s, 3 spline points, exploration 0.5) and
+    mjpc/tasks/acrobot (acrobot.cc:34-49; 10 points, exploration 0.05) on synthetic restatements of the dm_control models."""
+    from mujoco_mpc_amd.modelgen import acrobot, walker
+    m, task, d = walker()
+    out, ref, allc = _compare(m, task, d, 3, 80, 32, (0.5, 0.0), 2, 1e-5, nominal_scale=0.2)
+    assert allc["residual"].shape[-1] == 9 and allc["diag"][:, 1].max() >= 2            # both feet on the floor
+    m, task, d = acrobot()
+    out, ref, allc = _compare(m, task, d, 10, 200, 16, (0.05, 0.0), 2, 1e-8, nominal_scale=0.5)
+    assert allc["residual"].shape[-1] == 5 and np.allclose(allc["residual"][:, 0, 0], 4.0, atol=1e-6)      # hanging: tip 4 m below the target
+
+
 def test_cartpole_c1_config():
     """BASELINE config C1: 16 samples, horizon 50, 10 cubic knots."""
     m, task, d = cartpole()

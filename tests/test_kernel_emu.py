@@ -21,6 +21,7 @@ def _rel(a, b):
 
 @pytest.mark.parametrize("name,P,H,N,sigma,tol", [("particle", 11, 26, 6, (0.3, 0.0), 1e-12), ("cartpole", 10, 50, 8, (0.5, 0.0), 1e-12),
                                                    ("quadruped", 3, 30, 6, (0.04, 0.0), 1e-5),
+                                                   ("walker", 3, 80, 6, (0.5, 0.0), 1e-5), ("acrobot", 10, 100, 6, (0.05, 0.0), 1e-9),   # registry tasks beyond the BASELINE configs
                                                    ("cylinder_pile", 3, 50, 6, (0.5, 0.0), 1e-5),   # cylinder-box / cylinder-cylinder through the portal-refinement collider
                                                    ("ball_chain", 4, 60, 6, (0.4, 0.0), 1e-5),      # limited ball joints, tendon spring / damper / cross-branch limit
                                                    ("humanoid_track", 16, 30, 4, (0.15, 0.0), 1e-5),

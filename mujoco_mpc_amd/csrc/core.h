@@ -269,6 +269,36 @@ DEV void kin_compose(Ctx &c, int i, const double *jq, const double *ppos, const 
   }
 }
 
+// one candidate per CU: the side wave computes the com-based quantities while the owner is already in collision detection
+// (C2 -1.9 %); with two workgroups per CU the waves share their SIMDs and the extra hand-shake only costs (+0.6 .. 1.7 %)
+#if MJPC_HELPER && !defined(MJPC_LEAN_LDS)
+#define MJPC_SIDE_COM 1
+#else
+#define MJPC_SIDE_COM 0
+#endif
+// the poses nothing in collision detection reads: inertial frames and sites (with MJPC_SIDE_COM they are the side wave's work)
+DEV void kin_frames_sites(Ctx &c) {
+  const DevModel &M = *c.M;
+  PFOR(i, M.nbody) {
+    if (i == 0) continue;
+    double v[3], q[4], ip[3], iq[4], xm[9];
+    d_copy3(ip, MD(body_ipos) + 3 * i); d_copy4(iq, MD(body_iquat) + 4 * i);
+    d_mulmatvec3(v, c.xmat + 9 * i, ip);
+    d_add3(c.xipos + 3 * i, v, c.xpos + 3 * i);
+    d_mulquat(q, c.xquat + 4 * i, iq);
+    d_quat2mat(xm, q);
+    for (int k = 0; k < 9; k++) c.ximat[9 * i + k] = xm[k];
+  }
+  PFOR(s, M.nsite) {
+    int b = MI(site_bodyid)[s];
+    double v[3], sp[3];
+    d_copy3(sp, MD(site_pos) + 3 * s);
+    d_mulmatvec3(v, c.xmat + 9 * b, sp);
+    d_add3(c.site_xpos + 3 * s, v, c.xpos + 3 * b);
+  }
+}
+DEV void kinematics_rest(Ctx &c) { kin_frames_sites(c); SYNC(); }
+
 DEV void kinematics(Ctx &c) {
   const DevModel &M = *c.M;
   double *jq = c.cdof_dot;                        // scratch: rebuilt by the velocity stage after the next barrier
@@ -289,16 +319,9 @@ DEV void kinematics(Ctx &c) {
     }
   }
   SYNC();
-  PFOR(i, M.nbody) {
-    if (i == 0) continue;
-    double v[3], q[4], ip[3], iq[4], xm[9];
-    d_copy3(ip, MD(body_ipos) + 3 * i); d_copy4(iq, MD(body_iquat) + 4 * i);
-    d_mulmatvec3(v, c.xmat + 9 * i, ip);
-    d_add3(c.xipos + 3 * i, v, c.xpos + 3 * i);
-    d_mulquat(q, c.xquat + 4 * i, iq);
-    d_quat2mat(xm, q);
-    for (int k = 0; k < 9; k++) c.ximat[9 * i + k] = xm[k];
-  }
+#if !MJPC_SIDE_COM
+  kin_frames_sites(c);
+#endif
   PFOR(g, M.ngeom) {
     int b = MI(geom_bodyid)[g];
     double v[3], q[4], gp[3], gq[4], xm[9];
@@ -309,16 +332,8 @@ DEV void kinematics(Ctx &c) {
     d_quat2mat(xm, q);
     for (int k = 0; k < 9; k++) c.geom_xmat[9 * g + k] = xm[k];
   }
-  PFOR(s, M.nsite) {
-    int b = MI(site_bodyid)[s];
-    double v[3], sp[3];
-    d_copy3(sp, MD(site_pos) + 3 * s);
-    d_mulmatvec3(v, c.xmat + 9 * b, sp);
-    d_add3(c.site_xpos + 3 * s, v, c.xpos + 3 * b);
-  }
   SYNC();
 }
-
 DEV void com_pos(Ctx &c) {
   const DevModel &M = *c.M;
   PFOR(b, M.nbody) {
@@ -1722,6 +1737,7 @@ DEV void vel_compose(Ctx &c, int i, double *cvel, double *a, int store) {
 // subtree_linvel
 #define HX_SWEEP 27      // sweep done (side wave -> last helper), value t + 1
 #define HX_SUBSUM 19     // the helper's part of the subtree sums done, value t + 1
+#define HX_COM 44        // com-based quantities of this step done (side wave -> owner, helper 0), value t + 1
 DEV void subtree_sums(Ctx &c, int part) {
   const DevModel &M = *c.M;
   int per = part ? 6 : 3;
@@ -2446,7 +2462,10 @@ DEV_NOINLINE void ph_head(KP Kc, int t, int last) {
   }
   PROF(c, 0);
   kinematics(c); PROF(c, 1);
-  com_pos(c); PROF(c, 2);
+#if !MJPC_SIDE_COM
+  com_pos(c);
+#endif
+  PROF(c, 2);                 // (MJPC_SIDE_COM: the com-based quantities are the side wave's first job of the next phase, ph_smooth)
   ctx_close(c);
 }
 // role 0: contacts and constraint rows (needs positions + qvel only).  With helper waves the contact-free rows and their
@@ -2456,6 +2475,9 @@ DEV_NOINLINE void ph_constraints(KP Kc, int t) {
   collision(c); PROF(c, 4);
   int nsingle, n_nc;
 #if MJPC_HELPER
+#if MJPC_SIDE_COM
+  if (!flag_wait(c.misc + HX_COM, t + 1)) c.warning |= WARN_SYNC;        // cdof / subtree_com for the contact Jacobians (side wave)
+#endif
   if (!flag_wait(c.misc + 24, t + 1)) c.warning |= WARN_SYNC;
   nsingle = uniform_i(c.misc[25]); n_nc = uniform_i(c.misc[26]);
   c.nsingle = nsingle;
@@ -2492,6 +2514,13 @@ template <int NVT>
 DEV_NOINLINE void ph_smooth(KP Kc, int t) {
   Ctx c; ctx_open(c, Kc, 1);
 #if MJPC_HELPER
+#if MJPC_SIDE_COM
+  // the com-based quantities (subtree_com, cinert, cdof) are produced here, off the owner's critical path: the owner goes from
+  // the kinematics straight into collision detection and needs them only for the contact Jacobians
+  kinematics_rest(c);
+  com_pos(c);
+  flag_set(c.misc + HX_COM, t + 1);
+#endif
   velocity_stage<NVT>(c, t + 1);                // helper 0 builds and factors M meanwhile (ph_inertia)
 #else
   crb_and_factor<NVT>(c); PROF(c, 3);
@@ -2504,6 +2533,9 @@ DEV_NOINLINE void ph_smooth(KP Kc, int t) {
 template <int NVT>
 DEV_NOINLINE void ph_inertia(KP Kc, int t) {
   Ctx c; ctx_open(c, Kc, 1);
+#if MJPC_SIDE_COM
+  if (!flag_wait(c.misc + HX_COM, t + 1)) c.warning |= WARN_SYNC;
+#endif
   crb_and_factor<NVT>(c);
   flag_set(c.misc + 22, t + 1);
   ctx_close(c);

@@ -1,0 +1,103 @@
+"""Random articulated models for the fuzz parity tests (test infrastructure): random trees of bodies on free / ball / hinge /
+slide joints with limits, damping, armature, friction loss and springs, one or two primitive geoms of every supported type per
+body, motors and position servos, fixed tendons with limits / springs / dampers (also across branches), either friction cone,
+contact dimensions 1 / 3 / 4 / 6.  The residual copies the state."""
+import numpy as np
+
+from mujoco_mpc_amd.modelgen.builder import BALL, BOX, CAPSULE, CYLINDER, ELLIPSOID, FREE, HINGE, PLANE, SLIDE, SPHERE, ModelBuilder
+from mujoco_mpc_amd.modelgen.tasks import OBJ_SITE, TASK_COPYSTATE, make_task
+
+
+def _unit(rng, n=3):
+    v = rng.normal(size=n)
+    return v / np.linalg.norm(v)
+
+
+def random_model(seed, portal_pairs=False):
+    """portal_pairs=False: every geom pair that can touch has an analytic collider (tree cylinders / ellipsoids only meet the
+    floor, loose objects are spheres, capsules and boxes); True: loose objects of every type against everything (cylinder /
+    ellipsoid pairs go through the portal-refinement collider, whose contact normals are sensitive to rounding at the 1e-4 level)."""
+    rng = np.random.default_rng(seed)
+    cone = int(rng.integers(0, 2))
+    b = ModelBuilder(timestep=float(rng.choice([0.002, 0.004, 0.005])), cone=cone, impratio=float(rng.choice([1.0, 3.0])) if cone else 1.0,
+                     contact=True)
+    b.geom(0, "floor", PLANE, size=(3, 3, 0.1), friction=(float(rng.uniform(0.4, 1.0)), 0.005, 0.0001), condim=int(rng.choice([3, 3, 4, 6])),
+           contype=0, conaffinity=7)
+    nbody = int(rng.integers(3, 8))
+    bodies, scalar_joints = [], []
+    for i in range(nbody):
+        parent = 0 if (i == 0 or rng.random() < 0.15) else int(rng.choice(bodies))
+        pos = (rng.uniform(-0.4, 0.4), rng.uniform(-0.4, 0.4), rng.uniform(0.25, 0.6)) if parent == 0 else tuple(_unit(rng) * rng.uniform(0.1, 0.2))
+        bid = b.body(f"b{i}", parent, pos=pos, quat=tuple(_unit(rng, 4)))
+        bodies.append(bid)
+        kind = rng.choice(["free", "ball", "hinge", "slide", "hinge2"]) if parent == 0 else rng.choice(["ball", "hinge", "slide", "hinge", "hinge2"])
+        common = dict(damping=float(rng.uniform(0.0, 0.3)), armature=float(rng.choice([0.0, 0.01])))
+        if kind == "free":
+            b.joint(bid, f"j{i}", FREE)
+        elif kind == "ball":
+            lim = rng.random() < 0.6
+            b.joint(bid, f"j{i}", BALL, limited=bool(lim), range=(0, float(rng.uniform(0.3, 1.2))), **common)
+        else:
+            for k in range(2 if kind == "hinge2" else 1):
+                jt = SLIDE if kind == "slide" else HINGE
+                lim = rng.random() < 0.6
+                rg = (-float(rng.uniform(0.05, 0.2)), float(rng.uniform(0.05, 0.2))) if jt == SLIDE else (-float(rng.uniform(0.2, 1.0)), float(rng.uniform(0.2, 1.0)))
+                name = f"j{i}_{k}"
+                b.joint(bid, name, jt, axis=tuple(_unit(rng)), limited=bool(lim), range=rg, margin=float(rng.choice([0.0, 0.01])),
+                        frictionloss=float(rng.choice([0.0, 0.0, 0.05])), stiffness=float(rng.choice([0.0, 0.0, 2.0])), **common)
+                scalar_joints.append(name)
+        for g in range(int(rng.integers(1, 3))):
+            ty = int(rng.choice([SPHERE, CAPSULE, BOX, CYLINDER, ELLIPSOID]))
+            size = {SPHERE: (rng.uniform(0.04, 0.09),), CAPSULE: (rng.uniform(0.03, 0.06), rng.uniform(0.04, 0.1)),
+                    BOX: tuple(rng.uniform(0.03, 0.09, 3)), CYLINDER: (rng.uniform(0.03, 0.07), rng.uniform(0.03, 0.08)),
+                    ELLIPSOID: tuple(rng.uniform(0.03, 0.09, 3))}[ty]
+            # geoms of the articulated tree do not collide with each other (they would start deeply interpenetrating, where any
+            # collider is ill-conditioned): contype 1 / conaffinity 0; floor and loose objects accept them
+            b.geom(bid, f"g{i}_{g}", ty, size=tuple(float(x) for x in size), pos=tuple(_unit(rng) * rng.uniform(0.0, 0.06)), quat=tuple(_unit(rng, 4)),
+                   mass=float(rng.uniform(0.1, 1.0)), condim=int(rng.choice([1, 3, 3, 4, 6])), friction=(float(rng.uniform(0.3, 1.0)), 0.01, 0.001),
+                   margin=float(rng.choice([0.0, 0.002])), contype=(1 if (portal_pairs or ty not in (CYLINDER, ELLIPSOID)) else 4), conaffinity=0)
+    site = b.site(bodies[-1], "tip", pos=(0.02, 0, 0))
+    # loose objects on a ring around the tree, thrown towards it: every pair type incl. the portal-refinement ones comes into play
+    nloose = int(rng.integers(2, 5))
+    for k in range(nloose):
+        ang = 2 * np.pi * k / nloose + rng.uniform(-0.2, 0.2)
+        ty = int(rng.choice([SPHERE, CAPSULE, BOX, CYLINDER, ELLIPSOID] if portal_pairs else [SPHERE, CAPSULE, BOX]))
+        size = {SPHERE: (rng.uniform(0.05, 0.09),), CAPSULE: (rng.uniform(0.04, 0.06), rng.uniform(0.05, 0.1)),
+                BOX: tuple(rng.uniform(0.04, 0.09, 3)), CYLINDER: (rng.uniform(0.04, 0.07), rng.uniform(0.04, 0.08)),
+                ELLIPSOID: tuple(rng.uniform(0.04, 0.09, 3))}[ty]
+        lb = b.body(f"loose{k}", 0, pos=(0.75 * np.cos(ang), 0.75 * np.sin(ang), float(rng.uniform(0.15, 0.45))), quat=tuple(_unit(rng, 4)))
+        b.joint(lb, f"loose{k}_free", FREE)
+        b.geom(lb, f"loose{k}_g", ty, size=tuple(float(x) for x in size), mass=float(rng.uniform(0.2, 0.8)), condim=int(rng.choice([3, 3, 4, 6])),
+               friction=(float(rng.uniform(0.3, 1.0)), 0.01, 0.001), contype=2, conaffinity=3)
+    for jn in scalar_joints:
+        r = rng.random()
+        if r < 0.35:
+            b.actuator("m_" + jn, jn, gear=float(rng.uniform(0.5, 3.0)), ctrlrange=(-1, 1))
+        elif r < 0.5:
+            b.position("p_" + jn, joint=jn, kp=float(rng.uniform(2.0, 10.0)), ctrlrange=(-0.5, 0.5), forcerange=(-3.0, 3.0) if rng.random() < 0.5 else None)
+    if len(scalar_joints) >= 2:
+        for k in range(int(rng.integers(0, 3))):
+            js = list(rng.choice(scalar_joints, size=2, replace=False))
+            b.tendon(f"t{k}", js, [float(rng.uniform(0.5, 1.5)), -float(rng.uniform(0.5, 1.5))], limited=bool(rng.random() < 0.7),
+                     range=(-float(rng.uniform(0.1, 0.4)), float(rng.uniform(0.1, 0.4))), stiffness=float(rng.choice([0.0, 3.0])),
+                     damping=float(rng.choice([0.0, 0.2])), springlength=None if rng.random() < 0.5 else (-0.05, 0.05))
+            if rng.random() < 0.3:
+                b.position(f"pt{k}", tendon=f"t{k}", kp=4.0, ctrlrange=(-0.3, 0.3))
+    if not b.actuators:
+        if scalar_joints:
+            b.actuator("m0", scalar_joints[0], gear=1.0)
+        else:       # no scalar joint at all: add one body on a hinge so that the policy has something to drive
+            bid = b.body("extra", bodies[0], pos=(0.1, 0, 0))
+            b.joint(bid, "jx", HINGE, axis=(0, 1, 0), damping=0.1)
+            b.geom(bid, "gx", SPHERE, size=(0.04,), mass=0.2)
+            b.actuator("m0", "jx", gear=1.0)
+    b.nconmax = 16; b.nefcmax = 72            # (the default 32 / 128 does not fit one CU's LDS at 40 dofs)
+    m = b.compile()
+    task = make_task(TASK_COPYSTATE, [(m["nq"], 0, 1.0), (m["nv"], 0, 0.1)], traces=[(OBJ_SITE, site)])
+    q = np.array(m["qpos0"], float)
+    v = rng.normal(size=m["nv"]) * 1.5
+    for k in range(nloose):                      # loose objects fly towards the middle
+        da = m["jnt_dofadr"][m["names"]["joint"][f"loose{k}_free"]]
+        p = q[m["jnt_qposadr"][m["names"]["joint"][f"loose{k}_free"]]:][:3]
+        v[da:da + 3] = -np.array([p[0], p[1], 0.0]) / 0.75 * rng.uniform(3.0, 5.0) + np.array([0, 0, rng.uniform(0.0, 1.0)])
+    return m, task, dict(state=np.concatenate([q, v]), mocap=np.zeros(0))

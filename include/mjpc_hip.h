@@ -76,7 +76,7 @@ enum {
 /* ---- model: the subset of mjModel the path reads ------------------------------------- */
 typedef struct MjpcHipModel {
   /* sizes */
-  int nq, nv, nu, na, nbody, njnt, ngeom, nsite, nmocap, nuserdata, nkey, nexclude, ntendon, nwrap;
+  int nq, nv, nu, na, nbody, njnt, ngeom, nsite, nmocap, nuserdata, nkey, nexclude, ntendon, nwrap, nmesh, nmeshvert;
   /* mjOption */
   double timestep;
   double gravity[3];
@@ -130,6 +130,10 @@ typedef struct MjpcHipModel {
   /* passive tendon forces (mj_passive): spring with a dead band [lengthspring[2t], lengthspring[2t+1]], damper; [ntendon] each,
    * NULL = none.  tendon_frictionloss > 0 is refused (no tendon friction rows). */
   const double *tendon_stiffness, *tendon_damping, *tendon_lengthspring, *tendon_frictionloss;
+  /* convex meshes (collision = convex hull of the vertices, in the geom frame; mjModel.mesh_vert is float: widen it).  All NULL /
+   * nmesh = 0: no meshes.  geom_dataid[g] = mesh of a MJPC_GEOM_MESH geom, -1 otherwise. */
+  const int *geom_dataid, *mesh_vertadr, *mesh_vertnum;
+  const double *mesh_vert;          /* [3 * nmeshvert] */
   /* keyframes */
   const double *key_qpos;           /* nkey * nq */
   const double *key_mpos;           /* nkey * 3*nmocap */
@@ -218,7 +222,7 @@ typedef struct MjpcHipEngine MjpcHipEngine;
 /* Create an engine on HIP device `device`.  Copies model+task to HBM.  max_local = largest
  * num_local that will be planned on this device.  Returns NULL on error (see last_error).
  * Models the engine cannot roll out faithfully are REFUSED here (never silently approximated): geom pairs without a
- * collider (height field / mesh that can collide), group-0 geoms the quadruped task's ground ray cannot hit, tendon friction loss, actuator transmissions other than joint /
+ * collider (height fields; meshes without vertex data), group-0 geoms the quadruped task's ground ray cannot hit, tendon friction loss, actuator transmissions other than joint /
  * fixed tendon, nuserdata > 0, na > 0, nconmax > 64, nefcmax > 192, iterations > 250, num_spline_points capacity 36, LDS footprint > 160 KiB. */
 MjpcHipEngine *mjpc_hip_create(const MjpcHipModel *model, const MjpcHipTask *task,
                                int max_local, int max_horizon, int device);

@@ -45,7 +45,7 @@ static void FillModelView(const mjModel* m, MjpcHipModel& v, std::vector<int>& j
                           std::vector<int>& forcelimited, std::vector<int>& biastype, std::vector<int>& trntype,
                           std::vector<int>& trnid, std::vector<int>& tendon_limited, std::vector<int>& wrap_objid,
                           std::vector<double>& gainprm, std::vector<double>& biasprm, std::vector<double>& gear,
-                          std::vector<double>& wrap_prm) {
+                          std::vector<double>& wrap_prm, std::vector<double>& mesh_vert) {
   std::memset(&v, 0, sizeof(v));
   v.nq = m->nq; v.nv = m->nv; v.nu = m->nu; v.na = m->na; v.nbody = m->nbody; v.njnt = m->njnt; v.ngeom = m->ngeom;
   v.nsite = m->nsite; v.nmocap = m->nmocap; v.nuserdata = m->nuserdata; v.nkey = m->nkey; v.nexclude = m->nexclude;
@@ -101,6 +101,9 @@ static void FillModelView(const mjModel* m, MjpcHipModel& v, std::vector<int>& j
   v.tendon_invweight0 = m->tendon_invweight0;
   v.tendon_stiffness = m->tendon_stiffness; v.tendon_damping = m->tendon_damping; v.tendon_lengthspring = m->tendon_lengthspring;
   v.tendon_frictionloss = m->tendon_frictionloss;
+  // convex meshes: mjModel.mesh_vert is float -> widened copy (mesh_vert_ member); hull = all vertices
+  v.nmesh = m->nmesh; v.nmeshvert = m->nmeshvert; v.geom_dataid = m->geom_dataid; v.mesh_vertadr = m->mesh_vertadr; v.mesh_vertnum = m->mesh_vertnum;
+  mesh_vert.assign(m->mesh_vert, m->mesh_vert + 3 * m->nmeshvert); v.mesh_vert = mesh_vert.data();
   v.key_qpos = m->key_qpos; v.key_mpos = m->key_mpos;
 }
 
@@ -150,7 +153,7 @@ void HipSamplingPlanner::Initialize(mjModel* model, const Task& task) {
   sliding_plan_ = n.sampling_sliding_plan;
   if (num_trajectory_ > kMaxTrajectoryHip) mju_error_i("Too many trajectories, %d is the maximum allowed.", kMaxTrajectoryHip);
   FillModelView(model, model_view_, jnt_limited_, ctrllimited_, forcelimited_, biastype_, trntype_, trnid_, tendon_limited_,
-                wrap_objid_, gainprm_, biasprm_, gear_, wrap_prm_);
+                wrap_objid_, gainprm_, biasprm_, gear_, wrap_prm_, mesh_vert_);
   FillTaskView(task, model, task_view_, norm_, trace_type_, trace_id_, task_int_, task_dbl_);
   mjpc_hip::SetErrorHandler([](const char* msg) { mju_error("HipSamplingPlanner: %s", msg); });
   impl_.Initialize(&model_view_, &task_view_, n);           // creates the engines (model may have changed: old ones dropped)

@@ -912,7 +912,7 @@ DEV int np_capsule_cylinder(NPCon *con, double margin, const double *kp, const d
 // origin leaves the Minkowski difference, the contact sits half way between the two witness points.
 #define MPR_TOLERANCE 1e-6
 #define MPR_ITERATIONS 50
-struct MShape { int type; const double *pos, *mat, *size; double margin; };
+struct MShape { int type; const double *pos, *mat, *size; double margin; const double *vert; int nvert; };
 struct MSup { double v[3], v1[3], v2[3]; };
 DEV void mpr_support1(const MShape &s, const double *dir, double *out) {
   double l[3], v[3];
@@ -923,6 +923,13 @@ DEV void mpr_support1(const MShape &s, const double *dir, double *out) {
     double n = sqrt(l[0] * l[0] + l[1] * l[1]);
     if (n > D_MINVAL) { v[0] = s.size[0] * l[0] / n; v[1] = s.size[0] * l[1] / n; } else { v[0] = 0; v[1] = 0; }
     v[2] = l[2] >= 0 ? s.size[1] : -s.size[1];
+  } else if (s.type == 7) {       // convex mesh: the vertex farthest along l (first of equals); vertices are read from HBM / L2
+    double best = -1e300; int bi = 0;
+    for (int i = 0; i < s.nvert; i++) {
+      double t = s.vert[3 * i] * l[0] + s.vert[3 * i + 1] * l[1] + s.vert[3 * i + 2] * l[2];
+      if (t > best) { best = t; bi = i; }
+    }
+    v[0] = s.vert[3 * bi]; v[1] = s.vert[3 * bi + 1]; v[2] = s.vert[3 * bi + 2];
   } else if (s.type == 4) {
     double a = s.size[0] * s.size[0] * l[0], b = s.size[1] * s.size[1] * l[1], c = s.size[2] * s.size[2] * l[2];
     double n = sqrt(a * l[0] + b * l[1] + c * l[2]);
@@ -990,9 +997,8 @@ DEV void mpr_closest_on_triangle(const double *a, const double *b, const double 
   bw[1] = vb * den; bw[2] = vc * den; bw[0] = 1 - bw[1] - bw[2];
 }
 // 1 contact (frame[0..2] = normal from geom 1 to geom 2) or 0
-DEV int np_convex(NPCon *con, double margin, int t1, const double *p1, const double *m1, const double *s1,
-                  int t2, const double *p2, const double *m2, const double *s2) {
-  MShape A = {t1, p1, m1, s1, 0.5 * margin}, B = {t2, p2, m2, s2, 0.5 * margin};
+DEV int np_convex(NPCon *con, double margin, const MShape &A, const MShape &B) {
+  const double *p1 = A.pos, *p2 = B.pos;
   MSup q0, q1, q2, q3, v4;
   double dir[3], va[3], vb[3], depth, nrm[3], pos[3];
   d_sub3(q0.v, p1, p2); d_copy3(q0.v1, p1); d_copy3(q0.v2, p2);
@@ -1066,10 +1072,10 @@ DEV int np_convex(NPCon *con, double margin, int t1, const double *p1, const dou
   return 1;
 }
 
-// plane against an ellipsoid: the ellipsoid's support point against the plane normal
-DEV int np_plane_ellipsoid(NPCon *con, double margin, const double *pp, const double *pm, const double *ep, const double *em, const double *size) {
+// plane against an ellipsoid / a convex mesh: its support point against the plane normal
+DEV int np_plane_convex(NPCon *con, double margin, const double *pp, const double *pm, MShape E) {
   double n[3] = {pm[2], pm[5], pm[8]}, nd[3] = {-pm[2], -pm[5], -pm[8]}, sp[3], dif[3];
-  MShape E = {4, ep, em, size, 0.0};
+  E.margin = 0;
   mpr_support1(E, nd, sp);
   d_sub3(dif, sp, pp);
   double dist = d_dot3(dif, n);
@@ -1099,14 +1105,20 @@ DEV NPOut narrow_heavy(Ctx &c, int g1, int g2, double margin) {
   else if (t1 == 6 && t2 == 6) o.n = np_box_box(o.c, margin, p1, m1, s1, p2, m2, s2);
   else if (t1 == 2 && t2 == 5) o.n = np_sphere_cylinder(o.c, margin, p1, s1[0], p2, m2, s2);
   else if (t1 == 3 && t2 == 5) o.n = np_capsule_cylinder(o.c, margin, p1, m1, s1, p2, m2, s2);
-  else if (t1 == 0 && t2 == 4) o.n = np_plane_ellipsoid(o.c, margin, p1, m1, p2, m2, s2);
-  else if ((t1 == 4 || t2 == 4) && t1 >= 2 && t2 <= 6) o.n = np_convex(o.c, margin, t1, p1, m1, s1, t2, p2, m2, s2);
+  else if ((t1 == 4 || t2 == 4 || t1 == 7 || t2 == 7) && t1 != 1 && t2 != 1) {
+    // ellipsoids and convex meshes: support point against a plane, the portal-refinement collider against everything else
+    MShape A = {t1, p1, m1, s1, 0.5 * margin, nullptr, 0}, B = {t2, p2, m2, s2, 0.5 * margin, nullptr, 0};
+    if (t1 == 7) { int k = M.geom_dataid[g1]; A.vert = M.mesh_vert + 3 * M.mesh_vertadr[k]; A.nvert = M.mesh_vertnum[k]; }
+    if (t2 == 7) { int k = M.geom_dataid[g2]; B.vert = M.mesh_vert + 3 * M.mesh_vertadr[k]; B.nvert = M.mesh_vertnum[k]; }
+    o.n = t1 == 0 ? np_plane_convex(o.c, margin, p1, m1, B) : np_convex(o.c, margin, A, B);
+  }
   else if (t1 == 5 && (t2 == 5 || t2 == 6)) {
     // cylinder-cylinder / cylinder-box: the cylinder's bounding capsule decides "certainly apart" (exact, cheap); otherwise the
     // portal-refinement collider
     NPCon tmp[4];
     int n = t2 == 5 ? np_capsule_capsule(tmp, margin, p1, m1, s1, p2, m2, s2) : np_capsule_box(tmp, margin, p1, m1, s1, p2, m2, s2);
-    o.n = n == 0 ? 0 : np_convex(o.c, margin, t1, p1, m1, s1, t2, p2, m2, s2);
+    MShape A = {t1, p1, m1, s1, 0.5 * margin, nullptr, 0}, B = {t2, p2, m2, s2, 0.5 * margin, nullptr, 0};
+    o.n = n == 0 ? 0 : np_convex(o.c, margin, A, B);
   }
   return o;
 }

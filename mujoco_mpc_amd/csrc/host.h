@@ -274,10 +274,17 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
       if (m->geom_type[g1] == MJPC_GEOM_PLANE && m->geom_type[g2] == MJPC_GEOM_PLANE) continue;
       for (int g : {g1, g2}) {
         int ty = m->geom_type[g];
-        if (ty == MJPC_GEOM_HFIELD || ty == MJPC_GEOM_MESH) {
-          p.error = "geom " + std::to_string(g) + " (type " + std::to_string(ty) + ") can collide with geom " + std::to_string(g == g1 ? g2 : g1) +
-                    " but height fields and meshes have no collider here";
+        if (ty == MJPC_GEOM_HFIELD) {
+          p.error = "geom " + std::to_string(g) + " (height field) can collide with geom " + std::to_string(g == g1 ? g2 : g1) +
+                    " but height fields have no collider here";
           return false;
+        }
+        if (ty == MJPC_GEOM_MESH) {
+          int k = m->geom_dataid ? m->geom_dataid[g] : -1;
+          if (k < 0 || k >= m->nmesh || !m->mesh_vert || m->mesh_vertnum[k] < 4 || m->mesh_vertadr[k] + m->mesh_vertnum[k] > m->nmeshvert) {
+            p.error = "geom " + std::to_string(g) + " is a mesh that can collide but has no usable vertex data (geom_dataid / mesh_vert*)";
+            return false;
+          }
         }
       }
       g1s.push_back(g1); g2s.push_back(g2);
@@ -333,6 +340,13 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
   p.cache_i = p.ib.size(); p.cache_d = p.db.size();
   M.key_qpos = as_off<double>(put_d(p, m->key_qpos, (size_t)m->nkey * m->nq));
   M.key_mpos = as_off<double>(put_d(p, m->key_mpos, (size_t)m->nkey * 3 * m->nmocap));
+  // convex meshes: vertex pools, also outside the LDS copy
+  { std::vector<int> did(ng, -1);
+    if (m->geom_dataid) for (int g = 0; g < ng; g++) did[g] = m->geom_dataid[g];
+    M.geom_dataid = as_off<int>(put_i(p, did.data(), did.size()));
+    M.mesh_vertadr = as_off<int>(put_i(p, m->mesh_vertadr, (size_t)(m->nmesh > 0 ? m->nmesh : 0)));
+    M.mesh_vertnum = as_off<int>(put_i(p, m->mesh_vertnum, (size_t)(m->nmesh > 0 ? m->nmesh : 0)));
+    M.mesh_vert = as_off<double>(put_d(p, m->mesh_vert, (size_t)(m->nmeshvert > 0 ? 3 * m->nmeshvert : 0))); }
   // ---- LDS layout
   if (!use_cache) { p.cache_i = 0; p.cache_d = 0; }      // the kernel reads the tables from HBM / L2: no LDS copy to size
   make_layout(p, p.L, m, t, P_max, p.cache_d, p.cache_i, lean);
@@ -357,7 +371,7 @@ static inline DevModel relocate(const PackedModel &p, const int *ibase, const do
   fi(M.site_bodyid); fd(M.site_pos); fd(M.site_quat);
   fi(M.act_adr); fi(M.act_dof); fi(M.act_qpos); fi(M.act_of); fd(M.act_coef); fi(M.actuator_ctrllimited); fi(M.actuator_forcelimited); fi(M.actuator_biastype);
   fd(M.actuator_gainprm); fd(M.actuator_biasprm); fd(M.actuator_gear); fd(M.actuator_ctrlrange); fd(M.actuator_forcerange);
-  fd(M.key_qpos); fd(M.key_mpos);
+  fd(M.key_qpos); fd(M.key_mpos); fi(M.geom_dataid); fi(M.mesh_vertadr); fi(M.mesh_vertnum); fd(M.mesh_vert);
   fi(M.tendon_adr); fi(M.tendon_num); fi(M.tendon_limited); fi(M.wrap_dofadr); fi(M.wrap_qposadr);
   fd(M.wrap_prm); fd(M.tendon_range); fd(M.tendon_margin); fd(M.tendon_solref_lim); fd(M.tendon_solimp_lim); fd(M.tendon_invweight0);
   fi(M.level_adr); fi(M.level_body); fi(M.subtree_adr); fi(M.subtree_list); fi(M.chain_adr); fi(M.chain_list); fi(M.mpair_i); fi(M.mpair_j); fi(M.hpair_i); fi(M.hpair_j); fi(M.zpair_i); fi(M.zpair_j);

@@ -111,6 +111,8 @@ struct DevModel {
   const int *tpass_id;                      // tendons with passive forces
   const double *tpass_prm;                  // [4 each] stiffness, damping, spring dead band lo / hi
   const double *key_qpos, *key_mpos;
+  const int *geom_dataid, *mesh_vertadr, *mesh_vertnum;     // convex meshes: read from HBM / L2 (never in the LDS copy)
+  const double *mesh_vert;
   // derived on the host at create()
   const int *level_adr, *level_body;        // bodies grouped by tree depth (depth >= 1)
   const int *subtree_adr, *subtree_list;    // bodies of each subtree, self first, ascending ids

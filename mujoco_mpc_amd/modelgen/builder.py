@@ -168,7 +168,12 @@ class ModelBuilder:
     def geom(self, body, name="", type=SPHERE, size=(0, 0, 0), pos=(0, 0, 0), quat=(1, 0, 0, 0), fromto=None,
              mass=None, density=1000.0, contype=1, conaffinity=1, condim=3, friction=(1, 0.005, 0.0001),
              priority=0, margin=0.0, gap=0.0, solmix=1.0, solref=DEF_SOLREF, solimp=DEF_SOLIMP, group=0,
-             zaxis=None, euler=None):
+             zaxis=None, euler=None, mesh=None):
+        """mesh: (nvert, 3) vertices of a MESH geom in the geom frame (collision uses their convex hull, as MuJoCo does); its
+        size becomes the half extents of the vertex cloud (mass properties of that box: model authoring for tests only)."""
+        if mesh is not None:
+            mesh = np.asarray(mesh, float).reshape(-1, 3)
+            size = tuple(np.abs(mesh).max(axis=0))
         size = list(size) + [0.0] * (3 - len(size))
         pos = np.array(pos, float); quat = normq(quat)
         if zaxis is not None:
@@ -182,6 +187,7 @@ class ModelBuilder:
             size[1] = 0.5 * np.linalg.norm(b - a)
         g = _Geom(name, body, type, np.array(size, float), pos, quat, mass, density, contype, conaffinity, condim,
                   tuple(friction), priority, margin, gap, solmix, tuple(solref), tuple(solimp), group)
+        g.mesh = mesh
         self.geoms.append(g)
         self.bodies[body].geoms.append(len(self.geoms) - 1)
         return len(self.geoms) - 1
@@ -238,6 +244,9 @@ class ModelBuilder:
         elif t == BOX:
             vol = 8 * s[0] * s[1] * s[2]
             unit = np.array([(s[1] ** 2 + s[2] ** 2) / 3, (s[0] ** 2 + s[2] ** 2) / 3, (s[0] ** 2 + s[1] ** 2) / 3])
+        elif t == MESH:            # box of the vertex cloud's half extents
+            vol = 8 * s[0] * s[1] * s[2]
+            unit = np.array([(s[1] ** 2 + s[2] ** 2) / 3, (s[0] ** 2 + s[2] ** 2) / 3, (s[0] ** 2 + s[1] ** 2) / 3])
         elif t == ELLIPSOID:
             vol = 4.0 / 3.0 * math.pi * s[0] * s[1] * s[2]
             unit = np.array([(s[1] ** 2 + s[2] ** 2) / 5, (s[0] ** 2 + s[2] ** 2) / 5, (s[0] ** 2 + s[1] ** 2) / 5])
@@ -250,7 +259,8 @@ class ModelBuilder:
     def _rbound(g: _Geom):
         s = g.size
         return {PLANE: 0.0, SPHERE: s[0], CAPSULE: s[0] + s[1], CYLINDER: math.hypot(s[0], s[1]),
-                BOX: float(np.linalg.norm(s)), ELLIPSOID: float(max(s))}.get(g.type, 0.0)
+                BOX: float(np.linalg.norm(s)), ELLIPSOID: float(max(s)),
+                MESH: float(np.linalg.norm(getattr(g, "mesh", np.zeros((1, 3))), axis=1).max()) if getattr(g, "mesh", None) is not None else 0.0}.get(g.type, 0.0)
 
     # ---- compile
     def compile(self):
@@ -369,6 +379,16 @@ class ModelBuilder:
         M["geom_margin"] = np.array([g.margin for g in G], float)
         M["geom_gap"] = np.array([g.gap for g in G], float)
         M["geom_rbound"] = np.array([self._rbound(g) for g in G], float)
+        # convex meshes: vertex pools (mjModel mesh_vertadr / mesh_vertnum / mesh_vert, geom_dataid)
+        dataid, vadr, vnum, verts = [], [], [], []
+        for g in G:
+            if g.type == MESH and getattr(g, "mesh", None) is not None:
+                dataid.append(len(vadr)); vadr.append(sum(vnum)); vnum.append(len(g.mesh)); verts.append(g.mesh)
+            else:
+                dataid.append(-1)
+        M["geom_dataid"] = np.array(dataid, np.int32)
+        M["mesh_vertadr"] = np.array(vadr, np.int32); M["mesh_vertnum"] = np.array(vnum, np.int32)
+        M["mesh_vert"] = np.concatenate(verts).reshape(-1, 3) if verts else np.zeros((0, 3))
         # ---- inertial frames
         body_mass = np.zeros(nb); body_ipos = np.zeros((nb, 3)); body_iquat = np.tile([1.0, 0, 0, 0], (nb, 1))
         body_inertia = np.zeros((nb, 3))
@@ -460,7 +480,7 @@ class ModelBuilder:
         M["tendon_lengthspring"] = ls
         sizes = dict(nq=nq, nv=nv, nu=nu, na=0, nbody=nb, njnt=nj, ngeom=ng, nsite=ns, nmocap=nmocap,
                      nuserdata=self.nuserdata, nkey=nkey, nexclude=len(self.excludes), ntendon=len(self.tendons),
-                     nwrap=len(wrap_objid))
+                     nwrap=len(wrap_objid), nmesh=len(M["mesh_vertadr"]), nmeshvert=len(M["mesh_vert"]))
         M.update(sizes)
         o = self.opt
         M.update(timestep=o["timestep"], gravity=o["gravity"], impratio=o["impratio"], tolerance=o["tolerance"],

@@ -12,7 +12,7 @@
  * conventions and contact budgets (capsule-box <= 2 contacts: closest segment point + far end cap;
  * box-box <= 4: separating-axis test, then reference-face clipping or one edge-edge contact).
  * cylinder-cylinder, cylinder-box and every ellipsoid pair (plane-ellipsoid: closed form) go through a portal-refinement (MPR)
- * collider, below.  Mesh / height-field pairs are counted in `unsupported` and produce no contact; the engine refuses such models at create().
+ * collider, below; so do convex meshes (support = hull vertex farthest along the direction).  Height-field pairs are counted in `unsupported` and produce no contact; the engine refuses such models at create().
  * PARITY UNPINNED (no MuJoCo in this image); analytic checks in tests/test_oracle_physics.py.
  */
 #include "oracle.h"
@@ -494,7 +494,7 @@ static double seg_point_dist2(const double *p, const double *a, double h, const 
  * the same operations in the same order (csrc/core.h: np_convex). */
 #define MPR_TOLERANCE 1e-6
 #define MPR_ITERATIONS 50
-typedef struct { int type; const double *pos, *mat, *size; double margin; } MShape;
+typedef struct { int type; const double *pos, *mat, *size; double margin; const double *vert; int nvert; } MShape;
 typedef struct { double v[3], v1[3], v2[3]; } MSup;
 
 static void mpr_support1(const MShape *s, const double *dir, double *out) {
@@ -506,6 +506,13 @@ static void mpr_support1(const MShape *s, const double *dir, double *out) {
     double n = sqrt(l[0] * l[0] + l[1] * l[1]);
     if (n > O_MINVAL) { v[0] = s->size[0] * l[0] / n; v[1] = s->size[0] * l[1] / n; } else { v[0] = 0; v[1] = 0; }
     v[2] = l[2] >= 0 ? s->size[1] : -s->size[1];
+  } else if (s->type == MJPC_GEOM_MESH) {       /* hull vertex farthest along l (first of equals) */
+    double best = -1e300; int bi = 0;
+    for (int i = 0; i < s->nvert; i++) {
+      double t = s->vert[3 * i] * l[0] + s->vert[3 * i + 1] * l[1] + s->vert[3 * i + 2] * l[2];
+      if (t > best) { best = t; bi = i; }
+    }
+    v[0] = s->vert[3 * bi]; v[1] = s->vert[3 * bi + 1]; v[2] = s->vert[3 * bi + 2];
   } else if (s->type == MJPC_GEOM_ELLIPSOID) {
     double a = s->size[0] * s->size[0] * l[0], b = s->size[1] * s->size[1] * l[1], c = s->size[2] * s->size[2] * l[2];
     double n = sqrt(a * l[0] + b * l[1] + c * l[2]);
@@ -574,9 +581,14 @@ static void mpr_closest_on_triangle(const double *a, const double *b, const doub
   bw[1] = vb * den; bw[2] = vc * den; bw[0] = 1 - bw[1] - bw[2];
 }
 /* 1 contact (frame[0..2] = normal from geom 1 to geom 2) or 0 */
+static int convex_mpr_shapes(OContact *con, double margin, MShape A, MShape B);
 static int convex_mpr(OContact *con, double margin, int t1, const double *p1, const double *m1, const double *s1,
                       int t2, const double *p2, const double *m2, const double *s2) {
-  MShape A = {t1, p1, m1, s1, 0.5 * margin}, B = {t2, p2, m2, s2, 0.5 * margin};
+  MShape A = {t1, p1, m1, s1, 0.5 * margin, 0, 0}, B = {t2, p2, m2, s2, 0.5 * margin, 0, 0};
+  return convex_mpr_shapes(con, margin, A, B);
+}
+static int convex_mpr_shapes(OContact *con, double margin, MShape A, MShape B) {
+  const double *p1 = A.pos, *p2 = B.pos;
   MSup p[4], v4;
   double dir[3], va[3], vb[3], depth, nrm[3], pos[3];
   /* portal discovery */
@@ -655,9 +667,9 @@ static int convex_mpr(OContact *con, double margin, int t1, const double *p1, co
 }
 
 /* plane against an ellipsoid: the ellipsoid's support point against the plane normal (mjc_PlaneConvex's construction) */
-static int plane_ellipsoid(OContact *con, double margin, const double *pp, const double *pm, const double *ep, const double *em, const double *size) {
+static int plane_convex(OContact *con, double margin, const double *pp, const double *pm, MShape E) {
   double n[3] = {pm[2], pm[5], pm[8]}, nd[3] = {-pm[2], -pm[5], -pm[8]}, sp[3], dif[3];
-  MShape E = {MJPC_GEOM_ELLIPSOID, ep, em, size, 0.0};
+  E.margin = 0;
   mpr_support1(&E, nd, sp);
   o_sub3(dif, sp, pp);
   double dist = o_dot3(dif, n);
@@ -725,10 +737,14 @@ int oracle_collide_pair(const OModel *om, OData *d, int g1, int g2, double margi
   } else if (t1 == MJPC_GEOM_BOX && t2 == MJPC_GEOM_BOX) {
     return box_box(con, margin, p1, m1, s1, p2, m2, s2);
   }
-  /* ellipsoids: closed form against a plane, the portal-refinement collider against everything else */
-  if (t1 == MJPC_GEOM_PLANE && t2 == MJPC_GEOM_ELLIPSOID) return plane_ellipsoid(con, margin, p1, m1, p2, m2, s2);
-  if ((t1 == MJPC_GEOM_ELLIPSOID || t2 == MJPC_GEOM_ELLIPSOID) && t1 >= MJPC_GEOM_SPHERE && t2 <= MJPC_GEOM_BOX)
-    return convex_mpr(con, margin, t1, p1, m1, s1, t2, p2, m2, s2);
+  /* ellipsoids and convex meshes: support point against a plane, the portal-refinement collider against everything else */
+  if ((t1 == MJPC_GEOM_ELLIPSOID || t2 == MJPC_GEOM_ELLIPSOID || t1 == MJPC_GEOM_MESH || t2 == MJPC_GEOM_MESH) && t1 != MJPC_GEOM_HFIELD && t2 != MJPC_GEOM_HFIELD) {
+    MShape A = {t1, p1, m1, s1, 0.5 * margin, 0, 0}, B = {t2, p2, m2, s2, 0.5 * margin, 0, 0};
+    if (t1 == MJPC_GEOM_MESH) { int k = m->geom_dataid[g1]; A.vert = m->mesh_vert + 3 * m->mesh_vertadr[k]; A.nvert = m->mesh_vertnum[k]; }
+    if (t2 == MJPC_GEOM_MESH) { int k = m->geom_dataid[g2]; B.vert = m->mesh_vert + 3 * m->mesh_vertadr[k]; B.nvert = m->mesh_vertnum[k]; }
+    if (t1 == MJPC_GEOM_PLANE) return plane_convex(con, margin, p1, m1, B);
+    return convex_mpr_shapes(con, margin, A, B);
+  }
   /* cylinder-cylinder and cylinder-box: the cylinder's bounding capsule (same radius and half length) contains it, so a capsule
    * farther than the margin means certainly no contact (exact, cheap); otherwise the portal-refinement collider decides */
   if (t1 == MJPC_GEOM_CYLINDER && (t2 == MJPC_GEOM_CYLINDER || t2 == MJPC_GEOM_BOX)) {
@@ -753,7 +769,7 @@ int oracle_debug_collide(int t1, const double *s1, const double *p1, const doubl
   else if (t1 == MJPC_GEOM_CAPSULE && t2 == MJPC_GEOM_CAPSULE) n = capsule_capsule(con, margin, p1, m1, s1, p2, m2, s2);
   else if (t1 == MJPC_GEOM_SPHERE && t2 == MJPC_GEOM_CYLINDER) n = sphere_cylinder(con, margin, p1, s1[0], p2, m2, s2);
   else if (t1 == MJPC_GEOM_CAPSULE && t2 == MJPC_GEOM_CYLINDER) n = capsule_cylinder(con, margin, p1, m1, s1, p2, m2, s2);
-  else if (t1 == MJPC_GEOM_PLANE && t2 == MJPC_GEOM_ELLIPSOID) n = plane_ellipsoid(con, margin, p1, m1, p2, m2, s2);
+  else if (t1 == MJPC_GEOM_PLANE && t2 == MJPC_GEOM_ELLIPSOID) { MShape E = {t2, p2, m2, s2, 0, 0, 0}; n = plane_convex(con, margin, p1, m1, E); }
   else if (t1 == MJPC_GEOM_CYLINDER || t1 == MJPC_GEOM_ELLIPSOID || t2 == MJPC_GEOM_ELLIPSOID) n = convex_mpr(con, margin, t1, p1, m1, s1, t2, p2, m2, s2);
   else if (t1 >= 100) n = convex_mpr(con, margin, t1 - 100, p1, m1, s1, t2, p2, m2, s2);   /* any supported pair through the portal collider */
   for (int k = 0; k < n; k++) {
@@ -761,5 +777,16 @@ int oracle_debug_collide(int t1, const double *s1, const double *p1, const doubl
     o_copy3(out + 7 * k + 1, con[k].pos);
     o_copy3(out + 7 * k + 4, con[k].frame);
   }
+  return n;
+}
+
+/* test access with convex meshes: vertices given directly (nvert = 0: not a mesh); plane-X or the portal collider */
+int oracle_debug_collide_mesh(int t1, const double *s1, const double *p1, const double *m1, const double *v1, int n1,
+                              int t2, const double *s2, const double *p2, const double *m2, const double *v2, int n2, double margin, double *out) {
+  OContact con[2];
+  memset(con, 0, sizeof(con));
+  MShape A = {t1, p1, m1, s1, 0.5 * margin, v1, n1}, B = {t2, p2, m2, s2, 0.5 * margin, v2, n2};
+  int n = t1 == MJPC_GEOM_PLANE ? plane_convex(con, margin, p1, m1, B) : convex_mpr_shapes(con, margin, A, B);
+  for (int k = 0; k < n; k++) { out[7 * k] = con[k].dist; o_copy3(out + 7 * k + 1, con[k].pos); o_copy3(out + 7 * k + 4, con[k].frame); }
   return n;
 }

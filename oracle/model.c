@@ -64,6 +64,8 @@ OModel *oracle_create(const MjpcHipModel *src, const MjpcHipTask *task) {
   if (src->tendon_damping) CD(tendon_damping, src->ntendon);
   if (src->tendon_lengthspring) CD(tendon_lengthspring, 2 * src->ntendon);
   if (src->tendon_frictionloss) CD(tendon_frictionloss, src->ntendon);
+  if (src->geom_dataid) CI(geom_dataid, ng);
+  if (src->nmesh > 0) { CI(mesh_vertadr, src->nmesh); CI(mesh_vertnum, src->nmesh); CD(mesh_vert, 3 * src->nmeshvert); }
   CD(key_qpos, src->nkey * src->nq); CD(key_mpos, src->nkey * 3 * src->nmocap);
   copy_task(om, task);
 

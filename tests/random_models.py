@@ -4,7 +4,7 @@ body, motors and position servos, fixed tendons with limits / springs / dampers 
 contact dimensions 1 / 3 / 4 / 6.  The residual copies the state."""
 import numpy as np
 
-from mujoco_mpc_amd.modelgen.builder import BALL, BOX, CAPSULE, CYLINDER, ELLIPSOID, FREE, HINGE, PLANE, SLIDE, SPHERE, ModelBuilder
+from mujoco_mpc_amd.modelgen.builder import BALL, BOX, CAPSULE, CYLINDER, ELLIPSOID, FREE, HINGE, MESH, PLANE, SLIDE, SPHERE, ModelBuilder
 from mujoco_mpc_amd.modelgen.tasks import OBJ_SITE, TASK_COPYSTATE, make_task
 
 
@@ -61,14 +61,16 @@ def random_model(seed, portal_pairs=False):
     nloose = int(rng.integers(2, 5))
     for k in range(nloose):
         ang = 2 * np.pi * k / nloose + rng.uniform(-0.2, 0.2)
-        ty = int(rng.choice([SPHERE, CAPSULE, BOX, CYLINDER, ELLIPSOID] if portal_pairs else [SPHERE, CAPSULE, BOX]))
+        ty = int(rng.choice([SPHERE, CAPSULE, BOX, CYLINDER, ELLIPSOID, MESH, MESH] if portal_pairs else [SPHERE, CAPSULE, BOX]))
         size = {SPHERE: (rng.uniform(0.05, 0.09),), CAPSULE: (rng.uniform(0.04, 0.06), rng.uniform(0.05, 0.1)),
                 BOX: tuple(rng.uniform(0.04, 0.09, 3)), CYLINDER: (rng.uniform(0.04, 0.07), rng.uniform(0.04, 0.08)),
-                ELLIPSOID: tuple(rng.uniform(0.04, 0.09, 3))}[ty]
+                ELLIPSOID: tuple(rng.uniform(0.04, 0.09, 3)), MESH: (0, 0, 0)}[ty]
+        # a convex polyhedron: random points on an ellipsoid
+        mesh = None if ty != MESH else np.array([_unit(rng) for _ in range(int(rng.integers(8, 20)))]) * rng.uniform(0.04, 0.09, 3)
         lb = b.body(f"loose{k}", 0, pos=(0.75 * np.cos(ang), 0.75 * np.sin(ang), float(rng.uniform(0.15, 0.45))), quat=tuple(_unit(rng, 4)))
         b.joint(lb, f"loose{k}_free", FREE)
         b.geom(lb, f"loose{k}_g", ty, size=tuple(float(x) for x in size), mass=float(rng.uniform(0.2, 0.8)), condim=int(rng.choice([3, 3, 4, 6])),
-               friction=(float(rng.uniform(0.3, 1.0)), 0.01, 0.001), contype=2, conaffinity=3)
+               friction=(float(rng.uniform(0.3, 1.0)), 0.01, 0.001), contype=2, conaffinity=3, mesh=mesh)
     for jn in scalar_joints:
         r = rng.random()
         if r < 0.35:

@@ -99,7 +99,8 @@ def test_models_the_engine_cannot_roll_out_are_refused_at_create():
 
     check(lambda b, body: None, None)
     check(lambda b, body: b.geom(body, "e", ELLIPSOID, size=(0.1, 0.2, 0.3)), None)      # ellipsoids go through the portal-refinement collider
-    check(lambda b, body: b.geom(body, "e", MESH, size=(0.1, 0.2, 0.3)), "meshes")
+    check(lambda b, body: b.geom(body, "e", MESH, size=(0.1, 0.2, 0.3)), "no usable vertex data")           # a mesh geom without vertices
+    check(lambda b, body: b.geom(body, "e", MESH, mesh=[[0.1, 0, 0], [-0.1, 0, 0], [0, 0.1, 0], [0, 0, 0.1], [0, -0.05, -0.05]]), None)
 
     def ball(b, body):
         c = b.body("c", body)

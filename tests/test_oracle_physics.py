@@ -563,3 +563,47 @@ def test_portal_refinement_collider_against_closed_forms():
     o = ol.Oracle(m, task)
     q, v, _, _, w = o.step(d["state"][:m["nq"]], d["state"][m["nq"]:], ctrl=[0.0], nstep=150)
     assert w == 0 and abs(q[2] - 0.26) < 3e-3 and np.hypot(q[0], q[1]) < 5e-3 and abs(q[9] - 0.35) < 1e-2
+
+
+def _collide_mesh(t1, s1, p1, m1, v1, t2, s2, p2, m2, v2, margin=0.0):
+    import ctypes as C
+    L = ol.lib()
+    dp = C.POINTER(C.c_double)
+    L.oracle_debug_collide_mesh.argtypes = [C.c_int, dp, dp, dp, dp, C.c_int, C.c_int, dp, dp, dp, dp, C.c_int, C.c_double, dp]
+    arr = lambda x: np.ascontiguousarray(x, float).ravel()
+    a = [arr(list(s1) + [0.0] * (3 - len(s1))), arr(p1), arr(m1), arr(v1 if v1 is not None else [0.0]),
+         arr(list(s2) + [0.0] * (3 - len(s2))), arr(p2), arr(m2), arr(v2 if v2 is not None else [0.0])]
+    out = np.zeros(14)
+    n = L.oracle_debug_collide_mesh(t1, *[x.ctypes.data_as(dp) for x in a[:4]], 0 if v1 is None else len(v1),
+                                    t2, *[x.ctypes.data_as(dp) for x in a[4:]], 0 if v2 is None else len(v2), margin, out.ctypes.data_as(dp))
+    return out[:7 * max(n, 0)].reshape(max(n, 0), 7), n
+
+
+def test_convex_mesh_collider_against_closed_forms():
+    """Convex meshes (collision = hull of the vertices, support = vertex farthest along the direction): a plane meets the lowest
+    vertex; a cube given as an 8-vertex mesh behaves like the box primitive against a sphere and on a box face."""
+    I = np.eye(3)
+    rng = np.random.default_rng(1)
+    tet = np.array([[0.1, 0, -0.03], [-0.05, 0.08, -0.03], [-0.05, -0.08, -0.03], [0, 0, 0.09]])
+    for _ in range(100):
+        q = rng.normal(size=4); q /= np.linalg.norm(q); w, x, y, z = q
+        R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)], [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                      [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+        pz = rng.uniform(0.0, 0.12)
+        low = (tet @ R.T)[:, 2].min() + pz
+        c, n = _collide_mesh(0, [1, 1, 0.1], [0, 0, 0], I, None, 7, [0.1, 0.1, 0.1], [0.2, -0.1, pz], R, tet, margin=0.003)
+        if low <= 0.003:
+            assert n == 1 and abs(c[0, 0] - low) < 1e-12 and np.allclose(c[0, 4:], [0, 0, 1]) and abs(c[0, 3] - low / 2) < 1e-12
+        else:
+            assert n == 0
+    h = 0.05
+    cube = np.array([[sx * h, sy * h, sz * h] for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)], float)
+    for _ in range(100):                                   # sphere over a face of the cube: same contact as the box primitive
+        r = rng.uniform(0.02, 0.06); xy = rng.uniform(-0.03, 0.03, 2); gap = rng.uniform(-1e-3, 5e-4)
+        p = [xy[0], xy[1], h + r + gap]
+        a, na = _collide(2, [r], p, I, 6, [h, h, h], [0, 0, 0], I, margin=1e-3)
+        b, nb = _collide_mesh(2, [r], p, I, None, 7, [h, h, h], [0, 0, 0], I, cube, margin=1e-3)
+        # (depth to the 1e-6 tolerance; on a curved feature the witness point / normal are only good to ~sqrt(tolerance * radius))
+        assert na == nb == 1 and abs(a[0, 0] - b[0, 0]) < 1e-6 and np.allclose(a[0, 4:], b[0, 4:], atol=1e-3) and np.allclose(a[0, 1:4], b[0, 1:4], atol=3e-4)
+    c, n = _collide_mesh(7, [h, h, h], [0.1, 0.05, 0.1 + h - 1e-3], _rot("z", 0.4), cube, 6, [0.5, 0.5, 0.1], [0, 0, 0], I, None)      # cube mesh on a box face
+    assert n == 1 and abs(c[0, 0] + 1e-3) < 1e-6 and np.allclose(c[0, 4:], [0, 0, -1], atol=1e-6) and abs(c[0, 3] - (0.1 - 5e-4)) < 1e-6

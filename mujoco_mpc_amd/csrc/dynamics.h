@@ -1,0 +1,255 @@
+// dynamics.h — velocity stage (com velocities, RNE bias, passive forces, actuation) and the constraint solver (part of core.h)
+// Included by core.h only, in this order: the files share one translation unit and its macros.
+#pragma once
+// ======================================================================================
+// velocity stage: com velocities, subtree momentum, RNE bias, passive, actuation
+// ======================================================================================
+DEV void vel_body(Ctx &c, int i) {
+  const DevModel &M = *c.M;
+  double cvel[6];
+  for (int k = 0; k < 6; k++) cvel[k] = c.cvel[6 * MI(body_parentid)[i] + k];
+  int bda = MI(body_dofadr)[i];
+  for (int j = MI(body_jntadr)[i]; j < MI(body_jntadr)[i] + MI(body_jntnum)[i]; j++) {
+    int type = MI(jnt_type)[j];
+    if (type == 0) {
+      for (int k = 0; k < 18; k++) c.cdof_dot[6 * bda + k] = 0;
+      for (int k = 0; k < 3; k++) for (int q = 0; q < 6; q++) cvel[q] += c.cdof[6 * (bda + k) + q] * c.qvel[bda + k];
+      bda += 3;
+    }
+    if (type == 0 || type == 1) {
+      for (int k = 0; k < 3; k++) {
+        double r[6];
+        d_crossmotion(r, cvel, c.cdof + 6 * (bda + k));
+        for (int q = 0; q < 6; q++) c.cdof_dot[6 * (bda + k) + q] = r[q];
+      }
+      for (int k = 0; k < 3; k++) for (int q = 0; q < 6; q++) cvel[q] += c.cdof[6 * (bda + k) + q] * c.qvel[bda + k];
+      bda += 3;
+    } else {
+      double r[6];
+      d_crossmotion(r, cvel, c.cdof + 6 * bda);
+      for (int q = 0; q < 6; q++) c.cdof_dot[6 * bda + q] = r[q];
+      for (int q = 0; q < 6; q++) cvel[q] += c.cdof[6 * bda + q] * c.qvel[bda];
+      bda++;
+    }
+  }
+  for (int k = 0; k < 6; k++) c.cvel[6 * i + k] = cvel[k];
+  // RNE forward part: cacc, cfrc_body
+  double a[6];
+  for (int k = 0; k < 6; k++) a[k] = c.cacc[6 * MI(body_parentid)[i] + k];
+  bda = MI(body_dofadr)[i];
+  for (int k = 0; k < MI(body_dofnum)[i]; k++)
+    for (int q = 0; q < 6; q++) a[q] += c.cdof_dot[6 * (bda + k) + q] * c.qvel[bda + k];
+  for (int k = 0; k < 6; k++) c.cacc[6 * i + k] = a[k];
+  double t1[6], t2[6], t3[6];
+  d_mulinertvec(t1, c.cinert + 10 * i, a);
+  d_mulinertvec(t2, c.cinert + 10 * i, cvel);
+  d_crossforce(t3, cvel, t2);
+  for (int k = 0; k < 6; k++) c.cfrc[6 * i + k] = t1[k] + t3[k];
+  // body momentum for subtree_linvel
+  double off[3], v[3];
+  d_sub3(off, c.xipos + 3 * i, c.subtree_com + 3 * MI(body_rootid)[i]);
+  d_cross(v, cvel, off);
+  d_add3(v, v, cvel + 3);
+  d_scl3(c.bodytmp + 3 * i, v, MD(body_mass)[i]);
+}
+
+// com velocity and RNE acceleration of body i from its parent's (in registers), same operation order as vel_body; `store`: i is
+// the lane's own body: cvel, cdof_dot of its dofs, cacc, cfrc_body and its momentum go to LDS (deep trees, see velocity_stage)
+DEV void vel_compose(Ctx &c, int i, double *cvel, double *a, int store) {
+  const DevModel &M = *c.M;
+  int bda = MI(body_dofadr)[i];
+  for (int j = MI(body_jntadr)[i]; j < MI(body_jntadr)[i] + MI(body_jntnum)[i]; j++) {
+    int type = MI(jnt_type)[j];
+    if (type == 0) {
+      if (store) for (int k = 0; k < 18; k++) c.cdof_dot[6 * bda + k] = 0;
+      for (int k = 0; k < 3; k++) for (int q = 0; q < 6; q++) a[q] += 0.0 * c.qvel[bda + k];
+      for (int k = 0; k < 3; k++) for (int q = 0; q < 6; q++) cvel[q] += c.cdof[6 * (bda + k) + q] * c.qvel[bda + k];
+      bda += 3;
+    }
+    if (type == 0 || type == 1) {
+      for (int k = 0; k < 3; k++) {
+        double r[6];
+        d_crossmotion(r, cvel, c.cdof + 6 * (bda + k));
+        if (store) for (int q = 0; q < 6; q++) c.cdof_dot[6 * (bda + k) + q] = r[q];
+        for (int q = 0; q < 6; q++) a[q] += r[q] * c.qvel[bda + k];
+      }
+      for (int k = 0; k < 3; k++) for (int q = 0; q < 6; q++) cvel[q] += c.cdof[6 * (bda + k) + q] * c.qvel[bda + k];
+      bda += 3;
+    } else {
+      double r[6];
+      d_crossmotion(r, cvel, c.cdof + 6 * bda);
+      if (store) for (int q = 0; q < 6; q++) c.cdof_dot[6 * bda + q] = r[q];
+      for (int q = 0; q < 6; q++) a[q] += r[q] * c.qvel[bda];
+      for (int q = 0; q < 6; q++) cvel[q] += c.cdof[6 * bda + q] * c.qvel[bda];
+      bda++;
+    }
+  }
+  if (!store) return;
+  for (int k = 0; k < 6; k++) { c.cvel[6 * i + k] = cvel[k]; c.cacc[6 * i + k] = a[k]; }
+  double t1[6], t2[6], t3[6];
+  d_mulinertvec(t1, c.cinert + 10 * i, a);
+  d_mulinertvec(t2, c.cinert + 10 * i, cvel);
+  d_crossforce(t3, cvel, t2);
+  for (int k = 0; k < 6; k++) c.cfrc[6 * i + k] = t1[k] + t3[k];
+  double off[3], v[3];
+  d_sub3(off, c.xipos + 3 * i, c.subtree_com + 3 * MI(body_rootid)[i]);
+  d_cross(v, cvel, off);
+  d_add3(v, v, cvel + 3);
+  d_scl3(c.bodytmp + 3 * i, v, MD(body_mass)[i]);
+}
+
+// subtree sums of the body forces / momenta left by the sweep.  part 0: cfrc_sub components 0..2; part 1: components 3..5 and
+// subtree_linvel
+#define HX_SWEEP 27      // sweep done (side wave -> last helper), value t + 1
+#define HX_SUBSUM 19     // the helper's part of the subtree sums done, value t + 1
+#define HX_COM 44        // com-based quantities of this step done (side wave -> owner, helper 0), value t + 1
+DEV void subtree_sums(Ctx &c, int part) {
+  const DevModel &M = *c.M;
+  int per = part ? 6 : 3;
+  PFOR(e, M.nbody * per) {
+    int b = e / per, k = e - per * b;
+    if (k < 3) {
+      int kc = k + 3 * part;
+      double s = 0;
+      if (b > 0) for (int q = MI(subtree_adr)[b]; q < MI(subtree_adr)[b + 1]; q++) s += c.cfrc[6 * MI(subtree_list)[q] + kc];
+      c.cfrc_sub[6 * b + kc] = s;
+    } else {
+      int kk = k - 3;
+      double s = 0;
+      for (int q = MI(subtree_adr)[b]; q < MI(subtree_adr)[b + 1]; q++) s += c.bodytmp[3 * MI(subtree_list)[q] + kk];
+      c.subtree_linvel[3 * b + kk] = s / fmax(D_MINVAL, MD(body_subtreemass)[b]);
+    }
+  }
+}
+
+// mfact_seq != 0: M's factor is produced by a helper wave; wait for its sequence number (misc[22]) before the solve
+template <int NVT>
+DEV void velocity_stage(Ctx &c, int mfact_seq) {
+  const DevModel &M = *c.M;
+  int nv = M.nv;
+#ifdef MJPC_LEAN_LDS
+  // the RNE intermediates share their LDS with the solver's scaled rows here: the world body's entries are rewritten every step
+  if (LANE < 6) { c.cfrc[LANE] = 0; c.cacc[LANE] = (LANE >= 3) ? -M.gravity[LANE - 3] : 0.0; }
+  SYNC();
+#endif
+  if constexpr (NVT == 27) {
+    // the humanoid's 8 tree levels: one lane per body walks its ancestor chain with the running velocity / acceleration in
+    // registers, like kinematics (-1.3 % of its step; the A1's 4 levels are cheaper as a level sweep, and keeping both forms in
+    // one instantiation costs it +0.7 %, hence the compile-time choice)
+    PFOR(b, M.nbody) {
+      if (b == 0) continue;
+      double cvel[6], acc[6];
+      for (int k = 0; k < 6; k++) { cvel[k] = c.cvel[k]; acc[k] = c.cacc[k]; }      // the world body: 0 and -gravity
+      for (int q = MI(chain_adr)[b]; q < MI(chain_adr)[b + 1]; q++) {
+        int a = MI(chain_list)[q];
+        vel_compose(c, a, cvel, acc, a == b);
+      }
+    }
+    SYNC();
+  } else {
+    for (int l = 0; l < M.nlevel; l++) {
+      int a = MI(level_adr)[l], n = MI(level_adr)[l + 1] - a;
+      PFOR(k, n) vel_body(c, MI(level_body)[a + k]);
+      SYNC();
+    }
+  }
+  PROFW(c, 1);
+#if MJPC_HELPER
+  // the subtree sums are shared with the last helper wave (idle by now, ph_noncontact): it takes the torque half of cfrc_sub and
+  // the subtree momenta, this wave the force half; every element is summed by one lane in list order, as before
+  flag_set(c.misc + HX_SWEEP, mfact_seq);
+  subtree_sums(c, 0);
+#else
+  subtree_sums(c, 0); subtree_sums(c, 1);
+#endif
+  PROFW(c, 4);
+  // actuator forces
+  PFOR(i, M.nu) {
+    double ctrl = c.ctrl[i];
+    if (MI(actuator_ctrllimited)[i]) ctrl = d_clip(ctrl, MD(actuator_ctrlrange)[2 * i], MD(actuator_ctrlrange)[2 * i + 1]);
+    double force = MD(actuator_gainprm)[3 * i] * ctrl;
+    if (MI(actuator_biastype)[i] == 1) {
+      // transmission length / velocity: gear * qpos (joint) or sum of gear * coef * qpos over the tendon's joints
+      double length = 0, velocity = 0;
+      for (int e = MI(act_adr)[i]; e < MI(act_adr)[i + 1]; e++) {
+        double cf = MD(act_coef)[e];
+        length += cf * c.qpos[MI(act_qpos)[e]]; velocity += cf * c.qvel[MI(act_dof)[e]];
+      }
+      force += MD(actuator_biasprm)[3 * i] + MD(actuator_biasprm)[3 * i + 1] * length + MD(actuator_biasprm)[3 * i + 2] * velocity;
+    }
+    if (MI(actuator_forcelimited)[i]) force = d_clip(force, MD(actuator_forcerange)[2 * i], MD(actuator_forcerange)[2 * i + 1]);
+    c.actuator_force[i] = force;
+  }
+#if MJPC_HELPER
+  if (!flag_wait(c.misc + HX_SUBSUM, mfact_seq)) c.warning |= WARN_SYNC;
+#endif
+  SYNC();
+  PFOR(d, nv) {
+    const double *cd = c.cdof + 6 * d, *cf = c.cfrc_sub + 6 * MI(dof_bodyid)[d];
+    double bias = cd[0]*cf[0] + cd[1]*cf[1] + cd[2]*cf[2] + cd[3]*cf[3] + cd[4]*cf[4] + cd[5]*cf[5];
+    c.qfrc_bias[d] = bias;
+    double act = 0;
+    for (int e = 0; e < M.nact; e++) if (MI(act_dof)[e] == d) act += MD(act_coef)[e] * c.actuator_force[MI(act_of)[e]];     // moment^T force
+    c.qfrc_smooth[d] = act - bias - MD(dof_damping)[d] * c.qvel[d];   // joint springs are added below
+  }
+  SYNC();
+  PFOR(j, M.njnt) {
+    double k = MD(jnt_stiffness)[j];
+    int type = MI(jnt_type)[j];
+    if (k != 0 && (type == 2 || type == 3)) {
+      int qa = MI(jnt_qposadr)[j];
+      c.qfrc_smooth[MI(jnt_dofadr)[j]] -= k * (c.qpos[qa] - MD(qpos_spring)[qa]);
+    }
+  }
+  SYNC();
+  if (M.ntendon_passive > 0) {
+    // tendon springs (dead band) and dampers, mj_passive: one lane per dof gathers J^T force over the (few) passive tendons
+    PFOR(d, nv) {
+      double acc = c.qfrc_smooth[d];
+      for (int e = 0; e < M.ntendon_passive; e++) {
+        int t = MI(tpass_id)[e];
+        double coef = 0, length = 0, velocity = 0;
+        for (int w = MI(tendon_adr)[t]; w < MI(tendon_adr)[t] + MI(tendon_num)[t]; w++) {
+          double cf = MD(wrap_prm)[w];
+          length += cf * c.qpos[MI(wrap_qposadr)[w]]; velocity += cf * c.qvel[MI(wrap_dofadr)[w]];
+          if (MI(wrap_dofadr)[w] == d) coef += cf;
+        }
+        if (coef == 0) continue;
+        const double *pr = MD(tpass_prm) + 4 * e;
+        double frc = 0;
+        if (length > pr[3]) frc = pr[0] * (pr[3] - length); else if (length < pr[2]) frc = pr[0] * (pr[2] - length);
+        frc -= pr[1] * velocity;
+        acc += coef * frc;
+      }
+      c.qfrc_smooth[d] = acc;
+    }
+    SYNC();
+  }
+  if (c.K->xfrc_std > 0) {
+    // mj_xfrcAccumulate: J^T [force; torque], force applied at the body's inertial frame origin; bodies in ascending order
+    PFOR(d, nv) {
+      const double *cd = c.cdof + 6 * d;
+      int bd = MI(dof_bodyid)[d];
+      double acc = c.qfrc_smooth[d];
+      for (int q = MI(subtree_adr)[bd]; q < MI(subtree_adr)[bd + 1]; q++) {
+        int b = MI(subtree_list)[q];
+        const double *f = c.xfrc + 6 * b;
+        double off[3], tt[3];
+        d_sub3(off, c.xipos + 3 * b, c.subtree_com + 3 * MI(body_rootid)[b]);
+        d_cross(tt, cd, off);
+        acc += (cd[3] + tt[0]) * f[0] + (cd[4] + tt[1]) * f[1] + (cd[5] + tt[2]) * f[2] + cd[0] * f[3] + cd[1] * f[4] + cd[2] * f[5];
+      }
+      c.qfrc_smooth[d] = acc;
+    }
+    SYNC();
+  }
+  PFOR(d, nv) c.qacc_smooth[d] = c.qfrc_smooth[d];
+  PROFW(c, 5);
+  if (mfact_seq && !flag_wait(c.misc + 22, mfact_seq)) c.warning |= WARN_SYNC;
+  PROFW(c, 7);
+  chol_solve<NVT>(c.qL, c.Linv, c.qacc_smooth, nv, M.nvp, M.tree_ok);
+  PROFW(c, 8);
+}
+
+#include "solver.h"
+

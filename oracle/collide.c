@@ -491,7 +491,7 @@ static double seg_point_dist2(const double *p, const double *a, double h, const 
  * Gems 7): portal discovery, refinement until the portal reaches the surface of the Minkowski difference within the
  * tolerance, penetration = the portal point closest to the origin, contact position = half way between the two witness points.  Both geoms are inflated by margin / 2 so that proximity
  * within the margin is a (positive-distance) contact; ONE contact per pair, like MuJoCo without multiccd.  The engine carries
- * the same operations in the same order (csrc/core.h: np_convex). */
+ * the same operations in the same order (csrc/collide.h: np_convex). */
 #define MPR_TOLERANCE 1e-6
 #define MPR_ITERATIONS 50
 typedef struct { int type; const double *pos, *mat, *size; double margin; const double *vert; int nvert; } MShape;

@@ -122,6 +122,9 @@ DEV void subtree_sums(Ctx &c, int part) {
   }
 }
 
+#ifndef MJPC_CHAIN33
+#define MJPC_CHAIN33 1      // the per-lane chain walk of the velocity sweep also for the 33-dof hand (-0.5 %; 0 = level sweep)
+#endif
 // mfact_seq != 0: M's factor is produced by a helper wave; wait for its sequence number (misc[22]) before the solve
 template <int NVT>
 DEV void velocity_stage(Ctx &c, int mfact_seq) {
@@ -132,7 +135,7 @@ DEV void velocity_stage(Ctx &c, int mfact_seq) {
   if (LANE < 6) { c.cfrc[LANE] = 0; c.cacc[LANE] = (LANE >= 3) ? -M.gravity[LANE - 3] : 0.0; }
   SYNC();
 #endif
-  if constexpr (NVT == 27) {
+  if constexpr (NVT == 27 || (NVT == 33 && MJPC_CHAIN33)) {
     // the humanoid's 8 tree levels: one lane per body walks its ancestor chain with the running velocity / acceleration in
     // registers, like kinematics (-1.3 % of its step; the A1's 4 levels are cheaper as a level sweep, and keeping both forms in
     // one instantiation costs it +0.7 %, hence the compile-time choice)
@@ -189,7 +192,7 @@ DEV void velocity_stage(Ctx &c, int mfact_seq) {
     double bias = cd[0]*cf[0] + cd[1]*cf[1] + cd[2]*cf[2] + cd[3]*cf[3] + cd[4]*cf[4] + cd[5]*cf[5];
     c.qfrc_bias[d] = bias;
     double act = 0;
-    for (int e = 0; e < M.nact; e++) if (MI(act_dof)[e] == d) act += MD(act_coef)[e] * c.actuator_force[MI(act_of)[e]];     // moment^T force
+    for (int q = MI(dact_adr)[d]; q < MI(dact_adr)[d + 1]; q++) { int e = MI(dact_e)[q]; act += MD(act_coef)[e] * c.actuator_force[MI(act_of)[e]]; }     // moment^T force
     c.qfrc_smooth[d] = act - bias - MD(dof_damping)[d] * c.qvel[d];   // joint springs are added below
   }
   SYNC();

@@ -185,6 +185,11 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
     adr[nu] = (int)da.size(); M.nact = (int)da.size();
     M.act_adr = as_off<int>(put_i(p, adr.data(), adr.size())); M.act_dof = as_off<int>(put_i(p, da.data(), da.size()));
     M.act_qpos = as_off<int>(put_i(p, qa.data(), qa.size())); M.act_of = as_off<int>(put_i(p, of.data(), of.size()));
+    // the same entries grouped by dof (ascending entry index inside a dof: the summation order of moment^T force is kept)
+    std::vector<int> dadr(nv + 1, 0), dent;
+    for (int d = 0; d < nv; d++) { dadr[d] = (int)dent.size(); for (int e = 0; e < (int)da.size(); e++) if (da[e] == d) dent.push_back(e); }
+    dadr[nv] = (int)dent.size();
+    M.dact_adr = as_off<int>(put_i(p, dadr.data(), dadr.size())); M.dact_e = as_off<int>(put_i(p, dent.data(), dent.size()));
     M.act_coef = as_off<double>(put_d(p, cf.data(), cf.size())); }
   { std::vector<int> wd(m->nwrap), wq(m->nwrap);
     for (int w = 0; w < m->nwrap; w++) { int j = m->wrap_objid[w]; wd[w] = m->jnt_dofadr[j]; wq[w] = m->jnt_qposadr[j]; }
@@ -369,7 +374,7 @@ static inline DevModel relocate(const PackedModel &p, const int *ibase, const do
   fd(M.geom_size); fd(M.geom_pos); fd(M.geom_quat); fd(M.geom_friction); fd(M.geom_solmix); fd(M.geom_solref); fd(M.geom_solimp);
   fd(M.geom_margin); fd(M.geom_gap); fd(M.geom_rbound);
   fi(M.site_bodyid); fd(M.site_pos); fd(M.site_quat);
-  fi(M.act_adr); fi(M.act_dof); fi(M.act_qpos); fi(M.act_of); fd(M.act_coef); fi(M.actuator_ctrllimited); fi(M.actuator_forcelimited); fi(M.actuator_biastype);
+  fi(M.act_adr); fi(M.act_dof); fi(M.act_qpos); fi(M.act_of); fi(M.dact_adr); fi(M.dact_e); fd(M.act_coef); fi(M.actuator_ctrllimited); fi(M.actuator_forcelimited); fi(M.actuator_biastype);
   fd(M.actuator_gainprm); fd(M.actuator_biasprm); fd(M.actuator_gear); fd(M.actuator_ctrlrange); fd(M.actuator_forcerange);
   fd(M.key_qpos); fd(M.key_mpos); fi(M.geom_dataid); fi(M.mesh_vertadr); fi(M.mesh_vertnum); fd(M.mesh_vert);
   fi(M.tendon_adr); fi(M.tendon_num); fi(M.tendon_limited); fi(M.wrap_dofadr); fi(M.wrap_qposadr);

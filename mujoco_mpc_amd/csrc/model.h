@@ -104,6 +104,7 @@ struct DevModel {
   // actuator transmissions flattened on the host: actuator i owns entries [act_adr[i], act_adr[i+1]) = (dof, qpos address,
   // coefficient = gear [* tendon coefficient]); act_of[e] = the actuator of entry e
   const int *act_adr, *act_dof, *act_qpos, *act_of, *actuator_ctrllimited, *actuator_forcelimited, *actuator_biastype;
+  const int *dact_adr, *dact_e;             // entries grouped by dof: dof d owns dact_e[dact_adr[d] .. dact_adr[d+1])
   const double *act_coef;
   const double *actuator_gainprm, *actuator_biasprm, *actuator_gear, *actuator_ctrlrange, *actuator_forcerange;
   const int *tendon_adr, *tendon_num, *tendon_limited, *wrap_dofadr, *wrap_qposadr;

@@ -59,9 +59,9 @@ DEV void make_noncontact_rows(Ctx &c, int *nsingle_out, int *n_nc_out) {
     double dist[2] = {0, 0}; int side[2] = {0, 0};
     if (q < M.nlimit) {
       j = MI(limit_jnt)[q];
-      double value = c.qpos[MI(jnt_qposadr)[j]], margin = MD(jnt_margin)[j];
+      double value = c.qpos[MIH(jnt_qposadr)[j]], margin = MDH(jnt_margin)[j];
       for (int s = -1; s <= 1; s += 2) {
-        double dd = s * (MD(jnt_range)[2 * j + (s + 1) / 2] - value);
+        double dd = s * (MDH(jnt_range)[2 * j + (s + 1) / 2] - value);
         if (dd < margin) { dist[cnt] = dd; side[cnt] = s; cnt++; }
       }
     }
@@ -69,10 +69,10 @@ DEV void make_noncontact_rows(Ctx &c, int *nsingle_out, int *n_nc_out) {
     if (nefc + tot > M.nefcmax) { c.warning |= WARN_CNSTRFULL; break; }
     for (int k = 0; k < cnt; k++) {
       int r = nefc + off + k;
-      c.efc_type[r] = CNSTR_LIMIT_JOINT; c.efc_id[r] = j; c.efc_dof[r] = MI(jnt_dofadr)[j];
+      c.efc_type[r] = CNSTR_LIMIT_JOINT; c.efc_id[r] = j; c.efc_dof[r] = MIH(jnt_dofadr)[j];
       c.efc_floss[r] = (double)(-side[k]);      // J entry, consumed below
-      c.efc_pos[r] = dist[k]; c.efc_margin[r] = MD(jnt_margin)[j];
-      c.efc_diag[r] = MD(dof_invweight0)[MI(jnt_dofadr)[j]];
+      c.efc_pos[r] = dist[k]; c.efc_margin[r] = MDH(jnt_margin)[j];
+      c.efc_diag[r] = MD(dof_invweight0)[MIH(jnt_dofadr)[j]];
     }
     nefc += tot;
   }
@@ -85,18 +85,18 @@ DEV void make_noncontact_rows(Ctx &c, int *nsingle_out, int *n_nc_out) {
     if (q < M.nlimit_ball) {
       j = MI(limit_ball)[q];
       double axis[3];
-      double angle = ball_angle(axis, c.qpos + MI(jnt_qposadr)[j]);
-      dist = fmax(MD(jnt_range)[2 * j], MD(jnt_range)[2 * j + 1]) - angle;
-      if (dist < MD(jnt_margin)[j]) cnt = 1;
+      double angle = ball_angle(axis, c.qpos + MIH(jnt_qposadr)[j]);
+      dist = fmax(MDH(jnt_range)[2 * j], MDH(jnt_range)[2 * j + 1]) - angle;
+      if (dist < MDH(jnt_margin)[j]) cnt = 1;
     }
     int tot, off = wave_excl_scan(cnt, &tot);
     if (nefc + tot > M.nefcmax) { c.warning |= WARN_CNSTRFULL; break; }
     if (cnt) {
       int r = nefc + off;
-      c.efc_type[r] = CNSTR_LIMIT_JOINT; c.efc_id[r] = j; c.efc_dof[r] = MI(jnt_dofadr)[j];
+      c.efc_type[r] = CNSTR_LIMIT_JOINT; c.efc_id[r] = j; c.efc_dof[r] = MIH(jnt_dofadr)[j];
       c.efc_floss[r] = 0;
-      c.efc_pos[r] = dist; c.efc_margin[r] = MD(jnt_margin)[j];
-      c.efc_diag[r] = MD(dof_invweight0)[MI(jnt_dofadr)[j]];
+      c.efc_pos[r] = dist; c.efc_margin[r] = MDH(jnt_margin)[j];
+      c.efc_diag[r] = MD(dof_invweight0)[MIH(jnt_dofadr)[j]];
     }
     nefc += tot;
   }
@@ -131,12 +131,12 @@ DEV void make_noncontact_rows(Ctx &c, int *nsingle_out, int *n_nc_out) {
   SYNC();
   PFOR(rr, nlim_end - M.nfric) {
     int r = M.nfric + rr;
-    c.efc_J[r * nvp + MI(jnt_dofadr)[c.efc_id[r]]] = c.efc_floss[r]; c.efc_floss[r] = 0;
+    c.efc_J[r * nvp + MIH(jnt_dofadr)[c.efc_id[r]]] = c.efc_floss[r]; c.efc_floss[r] = 0;
   }
   PFOR(rr, nball_end - nlim_end) {
-    int r = nlim_end + rr, j = c.efc_id[r], da = MI(jnt_dofadr)[j];
+    int r = nlim_end + rr, j = c.efc_id[r], da = MIH(jnt_dofadr)[j];
     double axis[3];
-    ball_angle(axis, c.qpos + MI(jnt_qposadr)[j]);
+    ball_angle(axis, c.qpos + MIH(jnt_qposadr)[j]);
     for (int k = 0; k < 3; k++) c.efc_J[r * nvp + da + k] = -axis[k];
   }
   PFOR(rr, ntl_end - ntl0) {
@@ -168,8 +168,8 @@ DEV void make_contact_rows(Ctx &c, int n_nc) {
       c.con_i[ci * CONI_STRIDE + 3] = r0;
       int g1 = c.con_i[ci * CONI_STRIDE + 1], g2 = c.con_i[ci * CONI_STRIDE + 2];
       int b1 = MI(geom_bodyid)[g1], b2 = MI(geom_bodyid)[g2];
-      double tran = MD(body_invweight0)[2 * b1] + MD(body_invweight0)[2 * b2];
-      double rot = MD(body_invweight0)[2 * b1 + 1] + MD(body_invweight0)[2 * b2 + 1];
+      double tran = MDH(body_invweight0)[2 * b1] + MDH(body_invweight0)[2 * b2];
+      double rot = MDH(body_invweight0)[2 * b1 + 1] + MDH(body_invweight0)[2 * b2 + 1];
       const double *cc = c.contact + ci * c.M->con_stride;
       int cdim = c.con_i[ci * CONI_STRIDE];
       int pyr = (cdim > 1 && M.cone != 1);
@@ -215,14 +215,14 @@ DEV void make_contact_rows(Ctx &c, int n_nc) {
     double jp[3] = {0, 0, 0}, jr[3] = {0, 0, 0};
     if (in2) {
       double off[3], t[3];
-      d_sub3(off, cc + CON_POS, c.subtree_com + 3 * MI(body_rootid)[b2]);
+      d_sub3(off, cc + CON_POS, c.subtree_com + 3 * MIH(body_rootid)[b2]);
       d_cross(t, cd, off);
       jp[0] += cd[3] + t[0]; jp[1] += cd[4] + t[1]; jp[2] += cd[5] + t[2];
       jr[0] += cd[0]; jr[1] += cd[1]; jr[2] += cd[2];
     }
     if (in1) {
       double off[3], t[3];
-      d_sub3(off, cc + CON_POS, c.subtree_com + 3 * MI(body_rootid)[b1]);
+      d_sub3(off, cc + CON_POS, c.subtree_com + 3 * MIH(body_rootid)[b1]);
       d_cross(t, cd, off);
       jp[0] -= cd[3] + t[0]; jp[1] -= cd[4] + t[1]; jp[2] -= cd[5] + t[2];
       jr[0] -= cd[0]; jr[1] -= cd[1]; jr[2] -= cd[2];
@@ -271,8 +271,8 @@ DEV void make_impedance(Ctx &c, int r0, int r1, int with_contacts) {
       for (int k = 0; k < 2; k++) solref[k] = MD(dof_solref)[2 * id + k];
       for (int k = 0; k < 5; k++) solimp[k] = MD(dof_solimp)[5 * id + k];
     } else if (type == CNSTR_LIMIT_JOINT) {
-      for (int k = 0; k < 2; k++) solref[k] = MD(jnt_solref)[2 * id + k];
-      for (int k = 0; k < 5; k++) solimp[k] = MD(jnt_solimp)[5 * id + k];
+      for (int k = 0; k < 2; k++) solref[k] = MDH(jnt_solref)[2 * id + k];
+      for (int k = 0; k < 5; k++) solimp[k] = MDH(jnt_solimp)[5 * id + k];
     } else if (type == CNSTR_LIMIT_TENDON) {
       for (int k = 0; k < 2; k++) solref[k] = MD(tendon_solref_lim)[2 * id + k];
       for (int k = 0; k < 5; k++) solimp[k] = MD(tendon_solimp_lim)[5 * id + k];

@@ -135,6 +135,15 @@ DEV void ctx_open(Ctx &c, KP Kc, int role = 0) {
 #define MDM() ((const unsigned long long *)(c.mcd + (int)((const double *)c.M->body_dofmask - c.gdb)))
 #define MPM() ((const unsigned long long *)(c.mcd + (int)((const double *)c.M->body_patmask - c.gdb)))
 #endif
+// the "hot" tables (host.h: everything packed before hot_i / hot_d - body, joint and dof-tree tables and the derived level /
+// subtree / chain lists): in LDS also for the flavour that has no room for the whole copy (MJPC_HOT_CACHE, rollout_direct.hip)
+#if defined(MJPC_NO_MODEL_CACHE) && !defined(MJPC_HOT_CACHE)
+#define MDH(f) (c.M->f)
+#define MIH(f) (c.M->f)
+#else
+#define MDH(f) (c.mcd + (int)(c.M->f - c.gdb))
+#define MIH(f) (c.mci + (int)(c.M->f - c.gib))
+#endif
 DEV void ctx_close(Ctx &c) {
   SYNC();
   if (c.role != 0) {            // the side wave never writes the owner's scalars
@@ -477,7 +486,7 @@ DEV_NOINLINE void ph_integrate(KP Kc, int t) {
   }
   SYNC();
   PFOR(j, M.njnt) {
-    int qa = MI(jnt_qposadr)[j], da = MI(jnt_dofadr)[j], type = MI(jnt_type)[j];
+    int qa = MIH(jnt_qposadr)[j], da = MIH(jnt_dofadr)[j], type = MIH(jnt_type)[j];
     if (type == 0) {
       for (int k = 0; k < 3; k++) c.qpos[qa + k] += h * c.qvel[da + k];
       d_quatintegrate(c.qpos + qa + 3, c.qvel + da + 3, h);

@@ -7,10 +7,10 @@
 DEV void vel_body(Ctx &c, int i) {
   const DevModel &M = *c.M;
   double cvel[6];
-  for (int k = 0; k < 6; k++) cvel[k] = c.cvel[6 * MI(body_parentid)[i] + k];
-  int bda = MI(body_dofadr)[i];
-  for (int j = MI(body_jntadr)[i]; j < MI(body_jntadr)[i] + MI(body_jntnum)[i]; j++) {
-    int type = MI(jnt_type)[j];
+  for (int k = 0; k < 6; k++) cvel[k] = c.cvel[6 * MIH(body_parentid)[i] + k];
+  int bda = MIH(body_dofadr)[i];
+  for (int j = MIH(body_jntadr)[i]; j < MIH(body_jntadr)[i] + MIH(body_jntnum)[i]; j++) {
+    int type = MIH(jnt_type)[j];
     if (type == 0) {
       for (int k = 0; k < 18; k++) c.cdof_dot[6 * bda + k] = 0;
       for (int k = 0; k < 3; k++) for (int q = 0; q < 6; q++) cvel[q] += c.cdof[6 * (bda + k) + q] * c.qvel[bda + k];
@@ -35,9 +35,9 @@ DEV void vel_body(Ctx &c, int i) {
   for (int k = 0; k < 6; k++) c.cvel[6 * i + k] = cvel[k];
   // RNE forward part: cacc, cfrc_body
   double a[6];
-  for (int k = 0; k < 6; k++) a[k] = c.cacc[6 * MI(body_parentid)[i] + k];
-  bda = MI(body_dofadr)[i];
-  for (int k = 0; k < MI(body_dofnum)[i]; k++)
+  for (int k = 0; k < 6; k++) a[k] = c.cacc[6 * MIH(body_parentid)[i] + k];
+  bda = MIH(body_dofadr)[i];
+  for (int k = 0; k < MIH(body_dofnum)[i]; k++)
     for (int q = 0; q < 6; q++) a[q] += c.cdof_dot[6 * (bda + k) + q] * c.qvel[bda + k];
   for (int k = 0; k < 6; k++) c.cacc[6 * i + k] = a[k];
   double t1[6], t2[6], t3[6];
@@ -47,19 +47,19 @@ DEV void vel_body(Ctx &c, int i) {
   for (int k = 0; k < 6; k++) c.cfrc[6 * i + k] = t1[k] + t3[k];
   // body momentum for subtree_linvel
   double off[3], v[3];
-  d_sub3(off, c.xipos + 3 * i, c.subtree_com + 3 * MI(body_rootid)[i]);
+  d_sub3(off, c.xipos + 3 * i, c.subtree_com + 3 * MIH(body_rootid)[i]);
   d_cross(v, cvel, off);
   d_add3(v, v, cvel + 3);
-  d_scl3(c.bodytmp + 3 * i, v, MD(body_mass)[i]);
+  d_scl3(c.bodytmp + 3 * i, v, MDH(body_mass)[i]);
 }
 
 // com velocity and RNE acceleration of body i from its parent's (in registers), same operation order as vel_body; `store`: i is
 // the lane's own body: cvel, cdof_dot of its dofs, cacc, cfrc_body and its momentum go to LDS (deep trees, see velocity_stage)
 DEV void vel_compose(Ctx &c, int i, double *cvel, double *a, int store) {
   const DevModel &M = *c.M;
-  int bda = MI(body_dofadr)[i];
-  for (int j = MI(body_jntadr)[i]; j < MI(body_jntadr)[i] + MI(body_jntnum)[i]; j++) {
-    int type = MI(jnt_type)[j];
+  int bda = MIH(body_dofadr)[i];
+  for (int j = MIH(body_jntadr)[i]; j < MIH(body_jntadr)[i] + MIH(body_jntnum)[i]; j++) {
+    int type = MIH(jnt_type)[j];
     if (type == 0) {
       if (store) for (int k = 0; k < 18; k++) c.cdof_dot[6 * bda + k] = 0;
       for (int k = 0; k < 3; k++) for (int q = 0; q < 6; q++) a[q] += 0.0 * c.qvel[bda + k];
@@ -92,10 +92,10 @@ DEV void vel_compose(Ctx &c, int i, double *cvel, double *a, int store) {
   d_crossforce(t3, cvel, t2);
   for (int k = 0; k < 6; k++) c.cfrc[6 * i + k] = t1[k] + t3[k];
   double off[3], v[3];
-  d_sub3(off, c.xipos + 3 * i, c.subtree_com + 3 * MI(body_rootid)[i]);
+  d_sub3(off, c.xipos + 3 * i, c.subtree_com + 3 * MIH(body_rootid)[i]);
   d_cross(v, cvel, off);
   d_add3(v, v, cvel + 3);
-  d_scl3(c.bodytmp + 3 * i, v, MD(body_mass)[i]);
+  d_scl3(c.bodytmp + 3 * i, v, MDH(body_mass)[i]);
 }
 
 // subtree sums of the body forces / momenta left by the sweep.  part 0: cfrc_sub components 0..2; part 1: components 3..5 and
@@ -111,13 +111,13 @@ DEV void subtree_sums(Ctx &c, int part) {
     if (k < 3) {
       int kc = k + 3 * part;
       double s = 0;
-      if (b > 0) for (int q = MI(subtree_adr)[b]; q < MI(subtree_adr)[b + 1]; q++) s += c.cfrc[6 * MI(subtree_list)[q] + kc];
+      if (b > 0) for (int q = MIH(subtree_adr)[b]; q < MIH(subtree_adr)[b + 1]; q++) s += c.cfrc[6 * MIH(subtree_list)[q] + kc];
       c.cfrc_sub[6 * b + kc] = s;
     } else {
       int kk = k - 3;
       double s = 0;
-      for (int q = MI(subtree_adr)[b]; q < MI(subtree_adr)[b + 1]; q++) s += c.bodytmp[3 * MI(subtree_list)[q] + kk];
-      c.subtree_linvel[3 * b + kk] = s / fmax(D_MINVAL, MD(body_subtreemass)[b]);
+      for (int q = MIH(subtree_adr)[b]; q < MIH(subtree_adr)[b + 1]; q++) s += c.bodytmp[3 * MIH(subtree_list)[q] + kk];
+      c.subtree_linvel[3 * b + kk] = s / fmax(D_MINVAL, MDH(body_subtreemass)[b]);
     }
   }
 }
@@ -143,16 +143,16 @@ DEV void velocity_stage(Ctx &c, int mfact_seq) {
       if (b == 0) continue;
       double cvel[6], acc[6];
       for (int k = 0; k < 6; k++) { cvel[k] = c.cvel[k]; acc[k] = c.cacc[k]; }      // the world body: 0 and -gravity
-      for (int q = MI(chain_adr)[b]; q < MI(chain_adr)[b + 1]; q++) {
-        int a = MI(chain_list)[q];
+      for (int q = MIH(chain_adr)[b]; q < MIH(chain_adr)[b + 1]; q++) {
+        int a = MIH(chain_list)[q];
         vel_compose(c, a, cvel, acc, a == b);
       }
     }
     SYNC();
   } else {
     for (int l = 0; l < M.nlevel; l++) {
-      int a = MI(level_adr)[l], n = MI(level_adr)[l + 1] - a;
-      PFOR(k, n) vel_body(c, MI(level_body)[a + k]);
+      int a = MIH(level_adr)[l], n = MIH(level_adr)[l + 1] - a;
+      PFOR(k, n) vel_body(c, MIH(level_body)[a + k]);
       SYNC();
     }
   }
@@ -188,7 +188,7 @@ DEV void velocity_stage(Ctx &c, int mfact_seq) {
 #endif
   SYNC();
   PFOR(d, nv) {
-    const double *cd = c.cdof + 6 * d, *cf = c.cfrc_sub + 6 * MI(dof_bodyid)[d];
+    const double *cd = c.cdof + 6 * d, *cf = c.cfrc_sub + 6 * MIH(dof_bodyid)[d];
     double bias = cd[0]*cf[0] + cd[1]*cf[1] + cd[2]*cf[2] + cd[3]*cf[3] + cd[4]*cf[4] + cd[5]*cf[5];
     c.qfrc_bias[d] = bias;
     double act = 0;
@@ -197,11 +197,11 @@ DEV void velocity_stage(Ctx &c, int mfact_seq) {
   }
   SYNC();
   PFOR(j, M.njnt) {
-    double k = MD(jnt_stiffness)[j];
-    int type = MI(jnt_type)[j];
+    double k = MDH(jnt_stiffness)[j];
+    int type = MIH(jnt_type)[j];
     if (k != 0 && (type == 2 || type == 3)) {
-      int qa = MI(jnt_qposadr)[j];
-      c.qfrc_smooth[MI(jnt_dofadr)[j]] -= k * (c.qpos[qa] - MD(qpos_spring)[qa]);
+      int qa = MIH(jnt_qposadr)[j];
+      c.qfrc_smooth[MIH(jnt_dofadr)[j]] -= k * (c.qpos[qa] - MDH(qpos_spring)[qa]);
     }
   }
   SYNC();
@@ -232,13 +232,13 @@ DEV void velocity_stage(Ctx &c, int mfact_seq) {
     // mj_xfrcAccumulate: J^T [force; torque], force applied at the body's inertial frame origin; bodies in ascending order
     PFOR(d, nv) {
       const double *cd = c.cdof + 6 * d;
-      int bd = MI(dof_bodyid)[d];
+      int bd = MIH(dof_bodyid)[d];
       double acc = c.qfrc_smooth[d];
-      for (int q = MI(subtree_adr)[bd]; q < MI(subtree_adr)[bd + 1]; q++) {
-        int b = MI(subtree_list)[q];
+      for (int q = MIH(subtree_adr)[bd]; q < MIH(subtree_adr)[bd + 1]; q++) {
+        int b = MIH(subtree_list)[q];
         const double *f = c.xfrc + 6 * b;
         double off[3], tt[3];
-        d_sub3(off, c.xipos + 3 * b, c.subtree_com + 3 * MI(body_rootid)[b]);
+        d_sub3(off, c.xipos + 3 * b, c.subtree_com + 3 * MIH(body_rootid)[b]);
         d_cross(tt, cd, off);
         acc += (cd[3] + tt[0]) * f[0] + (cd[4] + tt[1]) * f[1] + (cd[5] + tt[2]) * f[2] + cd[0] * f[3] + cd[1] * f[4] + cd[2] * f[5];
       }

@@ -174,10 +174,11 @@ MjpcHipEngine *mjpc_hip_create(const MjpcHipModel *model, const MjpcHipTask *tas
     RolloutFn kc = mjpc_pick_rollout_cached(model->nv, &exact_c), kd = mjpc_pick_rollout_direct(model->nv, &exact_d);
     bool use_cache = !(exact_d && !exact_c);
     if (getenv("MJPC_HIP_NO_MODEL_CACHE")) use_cache = false;           // test knob
-    if (!mjpc_host::build(e->pm, model, task, e->P_max, use_cache)) { set_error("mjpc_hip_create: " + e->pm.error); delete e; return nullptr; }
+    // (the flavour without the whole copy still keeps the hot prefix - kinematic / tree tables - in LDS: hot_only)
+    if (!mjpc_host::build(e->pm, model, task, e->P_max, use_cache, false, !use_cache)) { set_error("mjpc_hip_create: " + e->pm.error); delete e; return nullptr; }
     if (use_cache && (size_t)e->pm.L.total_doubles * sizeof(double) > 160 * 1024) {
       use_cache = false;
-      if (!mjpc_host::build(e->pm, model, task, e->P_max, false)) { set_error("mjpc_hip_create: " + e->pm.error); delete e; return nullptr; }
+      if (!mjpc_host::build(e->pm, model, task, e->P_max, false, false, true)) { set_error("mjpc_hip_create: " + e->pm.error); delete e; return nullptr; }
     }
     e->kernel = use_cache ? kc : kd;
     // dense tier: needs a compile-time-nv kernel of that flavour, a model that asks for more capacity than the tier's and a
@@ -546,7 +547,7 @@ int mjpc_hip_dense_tier(MjpcHipEngine *e, int *used_last) {
 int mjpc_hip_layout_bytes(const MjpcHipModel *model, const MjpcHipTask *task, int use_cache) {
   if (!model || !task) { set_error("mjpc_hip_layout_bytes: invalid argument"); return -1; }
   PackedModel pm;
-  if (!mjpc_host::build(pm, model, task, 36, (use_cache & 1) != 0, (use_cache & 2) != 0)) { set_error("mjpc_hip_layout_bytes: " + pm.error); return -1; }
+  if (!mjpc_host::build(pm, model, task, 36, (use_cache & 1) != 0, (use_cache & 2) != 0, (use_cache & 3) == 0)) { set_error("mjpc_hip_layout_bytes: " + pm.error); return -1; }
   return (int)((size_t)pm.L.total_doubles * sizeof(double));
 }
 

@@ -20,6 +20,7 @@ struct PackedModel {
   Lay L;
   size_t task_i0, task_d0, task_i_cap, task_d_cap;   // task region inside ib/db
   size_t cache_i, cache_d;                           // prefix of ib/db copied into LDS by every workgroup
+  size_t hot_i = 0, hot_d = 0;                       // the shorter prefix the hot-tables-only flavour copies
   std::string error;
 };
 
@@ -109,7 +110,8 @@ static inline void make_layout(const PackedModel &p, Lay &L, const MjpcHipModel 
 }
 
 // use_cache: lay out an LDS copy of the model tables (rollout_cached.hip) or none (rollout_direct.hip)
-static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTask *t, int P_max, bool use_cache = true, bool lean = false) {
+// use_cache: whole LDS copy of the tables; hot_only (with use_cache == false): only the hot prefix
+static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTask *t, int P_max, bool use_cache = true, bool lean = false, bool hot_only = false) {
   p.ib.clear(); p.db.clear(); p.error.clear();
   DevModel &M = p.M;
   memset(&M, 0, sizeof(M));
@@ -149,7 +151,38 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
   PD_(jnt_pos, 3 * nj); PD_(jnt_axis, 3 * nj); PD_(jnt_stiffness, nj); PD_(jnt_range, 2 * nj); PD_(jnt_margin, nj);
   PD_(jnt_solref, 2 * nj); PD_(jnt_solimp, 5 * nj); PD_(qpos0, m->nq); PD_(qpos_spring, m->nq);
   PI_(dof_bodyid, nv); PI_(dof_parentid, nv);
-  PD_(dof_armature, nv); PD_(dof_damping, nv); PD_(dof_frictionloss, nv); PD_(dof_invweight0, nv);
+  PD_(dof_armature, nv);
+  // bodies by depth
+  { std::vector<int> depth(nb, 0); int maxd = 0;
+    for (int b = 1; b < nb; b++) { depth[b] = depth[m->body_parentid[b]] + 1; if (depth[b] > maxd) maxd = depth[b]; }
+    std::vector<int> adr(maxd + 1, 0), list;
+    for (int l = 1; l <= maxd; l++) { adr[l - 1] = (int)list.size(); for (int b = 1; b < nb; b++) if (depth[b] == l) list.push_back(b); }
+    adr[maxd] = (int)list.size();
+    M.nlevel = maxd;
+    M.level_adr = as_off<int>(put_i(p, adr.data(), adr.size())); M.level_body = as_off<int>(put_i(p, list.data(), list.size())); }
+  // subtree lists
+  { std::vector<int> adr(nb + 1, 0), list;
+    for (int b = 0; b < nb; b++) {
+      adr[b] = (int)list.size();
+      for (int c = b; c < nb; c++) { int a = c; while (a > b) a = m->body_parentid[a]; if (a == b) list.push_back(c); }
+    }
+    adr[nb] = (int)list.size();
+    M.subtree_adr = as_off<int>(put_i(p, adr.data(), adr.size())); M.subtree_list = as_off<int>(put_i(p, list.data(), list.size())); }
+  // ancestor chains (kinematics walks them in registers instead of sweeping the tree level by level)
+  { std::vector<int> adr(nb + 1, 0), list;
+    for (int b = 0; b < nb; b++) {
+      adr[b] = (int)list.size();
+      std::vector<int> up;
+      for (int a = b; a > 0; a = m->body_parentid[a]) up.push_back(a);
+      for (size_t k = up.size(); k-- > 0;) list.push_back(up[k]);
+    }
+    adr[nb] = (int)list.size();
+    list.push_back(0);
+    M.chain_adr = as_off<int>(put_i(p, adr.data(), adr.size())); M.chain_list = as_off<int>(put_i(p, list.data(), list.size())); }
+  // everything so far = the tables of the dependent-load chains of kinematics / com / inertia / velocity sweep: the "hot" prefix
+  // that the flavour without room for the whole copy still keeps in LDS (MIH / MDH in core.h)
+  p.hot_i = p.ib.size(); p.hot_d = p.db.size();
+  PD_(dof_damping, nv); PD_(dof_frictionloss, nv); PD_(dof_invweight0, nv);
   PD_(dof_solref, 2 * nv); PD_(dof_solimp, 5 * nv);
   PI_(geom_type, ng); PI_(geom_condim, ng); PI_(geom_bodyid, ng); PI_(geom_priority, ng);
   PD_(geom_size, 3 * ng); PD_(geom_pos, 3 * ng); PD_(geom_quat, 4 * ng); PD_(geom_friction, 3 * ng); PD_(geom_solmix, ng);
@@ -194,33 +227,6 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
   { std::vector<int> wd(m->nwrap), wq(m->nwrap);
     for (int w = 0; w < m->nwrap; w++) { int j = m->wrap_objid[w]; wd[w] = m->jnt_dofadr[j]; wq[w] = m->jnt_qposadr[j]; }
     M.wrap_dofadr = as_off<int>(put_i(p, wd.data(), wd.size())); M.wrap_qposadr = as_off<int>(put_i(p, wq.data(), wq.size())); }
-  // bodies by depth
-  { std::vector<int> depth(nb, 0); int maxd = 0;
-    for (int b = 1; b < nb; b++) { depth[b] = depth[m->body_parentid[b]] + 1; if (depth[b] > maxd) maxd = depth[b]; }
-    std::vector<int> adr(maxd + 1, 0), list;
-    for (int l = 1; l <= maxd; l++) { adr[l - 1] = (int)list.size(); for (int b = 1; b < nb; b++) if (depth[b] == l) list.push_back(b); }
-    adr[maxd] = (int)list.size();
-    M.nlevel = maxd;
-    M.level_adr = as_off<int>(put_i(p, adr.data(), adr.size())); M.level_body = as_off<int>(put_i(p, list.data(), list.size())); }
-  // subtree lists
-  { std::vector<int> adr(nb + 1, 0), list;
-    for (int b = 0; b < nb; b++) {
-      adr[b] = (int)list.size();
-      for (int c = b; c < nb; c++) { int a = c; while (a > b) a = m->body_parentid[a]; if (a == b) list.push_back(c); }
-    }
-    adr[nb] = (int)list.size();
-    M.subtree_adr = as_off<int>(put_i(p, adr.data(), adr.size())); M.subtree_list = as_off<int>(put_i(p, list.data(), list.size())); }
-  // ancestor chains (kinematics walks them in registers instead of sweeping the tree level by level)
-  { std::vector<int> adr(nb + 1, 0), list;
-    for (int b = 0; b < nb; b++) {
-      adr[b] = (int)list.size();
-      std::vector<int> up;
-      for (int a = b; a > 0; a = m->body_parentid[a]) up.push_back(a);
-      for (size_t k = up.size(); k-- > 0;) list.push_back(up[k]);
-    }
-    adr[nb] = (int)list.size();
-    list.push_back(0);
-    M.chain_adr = as_off<int>(put_i(p, adr.data(), adr.size())); M.chain_list = as_off<int>(put_i(p, list.data(), list.size())); }
   // non-zeros of the joint-space inertia
   { std::vector<int> pi, pj;
     for (int i = 0; i < nv; i++) for (int j = i; j >= 0; j = m->dof_parentid[j]) { pi.push_back(i); pj.push_back(j); }
@@ -353,7 +359,7 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
     M.mesh_vertnum = as_off<int>(put_i(p, m->mesh_vertnum, (size_t)(m->nmesh > 0 ? m->nmesh : 0)));
     M.mesh_vert = as_off<double>(put_d(p, m->mesh_vert, (size_t)(m->nmeshvert > 0 ? 3 * m->nmeshvert : 0))); }
   // ---- LDS layout
-  if (!use_cache) { p.cache_i = 0; p.cache_d = 0; }      // the kernel reads the tables from HBM / L2: no LDS copy to size
+  if (!use_cache) { p.cache_i = hot_only ? p.hot_i : 0; p.cache_d = hot_only ? p.hot_d : 0; }      // the kernel reads (the rest of) the tables from HBM / L2
   make_layout(p, p.L, m, t, P_max, p.cache_d, p.cache_i, lean);
   return true;
 }

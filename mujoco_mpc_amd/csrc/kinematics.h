@@ -11,11 +11,11 @@
 // Same arithmetic per quantity as the one-stage form.
 DEV void kin_joint_local(Ctx &c, int j, double *jq) {
   const DevModel &M = *c.M;
-  int type = MI(jnt_type)[j], qa = MI(jnt_qposadr)[j];
+  int type = MIH(jnt_type)[j], qa = MIH(jnt_qposadr)[j];
   if (type == 3) {
     double ax[3];
-    d_copy3(ax, MD(jnt_axis) + 3 * j);
-    d_axisangle2quat(jq + 4 * j, ax, c.qpos[qa] - MD(qpos0)[qa]);
+    d_copy3(ax, MDH(jnt_axis) + 3 * j);
+    d_axisangle2quat(jq + 4 * j, ax, c.qpos[qa] - MDH(qpos0)[qa]);
   } else if (type == 1) {
     d_normalize4(c.qpos + qa);
     d_copy4(jq + 4 * j, c.qpos + qa);
@@ -28,42 +28,42 @@ DEV void kin_joint_local(Ctx &c, int j, double *jq) {
 DEV void kin_compose(Ctx &c, int i, const double *jq, const double *ppos, const double *pquat, const double *pmat, int have_parent,
                      double *xpos, double *xquat, double *xm, int store) {
   const DevModel &M = *c.M;
-  int jntnum = MI(body_jntnum)[i], jntadr = MI(body_jntadr)[i];
-  int mid = MI(body_mocapid)[i];
+  int jntnum = MIH(body_jntnum)[i], jntadr = MIH(body_jntadr)[i];
+  int mid = MIH(body_mocapid)[i];
   if (mid >= 0) {
     d_copy3(xpos, c.mocap_pos + 3 * mid);
     d_copy4(xquat, c.mocap_quat + 4 * mid);
     d_normalize4(xquat);
-  } else if (jntnum == 1 && MI(jnt_type)[jntadr] == 0) {
-    int qa = MI(jnt_qposadr)[jntadr];
+  } else if (jntnum == 1 && MIH(jnt_type)[jntadr] == 0) {
+    int qa = MIH(jnt_qposadr)[jntadr];
     d_copy3(xpos, c.qpos + qa);
     d_copy4(xquat, c.qpos + qa + 3);              // normalised in place by kin_joint_local
     if (store) {
       d_copy3(c.xanchor + 3 * jntadr, xpos);
-      d_copy3(c.xaxis + 3 * jntadr, MD(jnt_axis) + 3 * jntadr);
+      d_copy3(c.xaxis + 3 * jntadr, MDH(jnt_axis) + 3 * jntadr);
     }
   } else {
     if (have_parent) {
-      d_mulmatvec3(xpos, pmat, MD(body_pos) + 3 * i);
+      d_mulmatvec3(xpos, pmat, MDH(body_pos) + 3 * i);
       d_add3(xpos, xpos, ppos);
-      d_mulquat(xquat, pquat, MD(body_quat) + 4 * i);
+      d_mulquat(xquat, pquat, MDH(body_quat) + 4 * i);
     } else {
-      d_copy3(xpos, MD(body_pos) + 3 * i);
-      d_copy4(xquat, MD(body_quat) + 4 * i);
+      d_copy3(xpos, MDH(body_pos) + 3 * i);
+      d_copy4(xquat, MDH(body_quat) + 4 * i);
     }
     if (jntnum > 0) {
       double m[9];
       d_quat2mat(m, xquat);                       // rotation of the frame the next joint is expressed in
       for (int j = jntadr; j < jntadr + jntnum; j++) {
-        int qa = MI(jnt_qposadr)[j], type = MI(jnt_type)[j];
+        int qa = MIH(jnt_qposadr)[j], type = MIH(jnt_type)[j];
         double vec[3], ax[3], jp[3], xax[3], xan[3];
-        d_copy3(ax, MD(jnt_axis) + 3 * j); d_copy3(jp, MD(jnt_pos) + 3 * j);
+        d_copy3(ax, MDH(jnt_axis) + 3 * j); d_copy3(jp, MDH(jnt_pos) + 3 * j);
         d_mulmatvec3(xax, m, ax);
         d_mulmatvec3(vec, m, jp);
         d_add3(xan, vec, xpos);
         if (store) { d_copy3(c.xaxis + 3 * j, xax); d_copy3(c.xanchor + 3 * j, xan); }
         if (type == 2) {
-          d_addtoscl3(xpos, xax, c.qpos[qa] - MD(qpos0)[qa]);
+          d_addtoscl3(xpos, xax, c.qpos[qa] - MDH(qpos0)[qa]);
         } else {
           double qloc[4], t[4];
           d_copy4(qloc, jq + 4 * j);
@@ -98,7 +98,7 @@ DEV void kin_frames_sites(Ctx &c) {
   PFOR(i, M.nbody) {
     if (i == 0) continue;
     double v[3], q[4], ip[3], iq[4], xm[9];
-    d_copy3(ip, MD(body_ipos) + 3 * i); d_copy4(iq, MD(body_iquat) + 4 * i);
+    d_copy3(ip, MDH(body_ipos) + 3 * i); d_copy4(iq, MDH(body_iquat) + 4 * i);
     d_mulmatvec3(v, c.xmat + 9 * i, ip);
     d_add3(c.xipos + 3 * i, v, c.xpos + 3 * i);
     d_mulquat(q, c.xquat + 4 * i, iq);
@@ -126,8 +126,8 @@ DEV void kinematics(Ctx &c) {
     if (b == 0) continue;
     double ppos[3], pquat[4], pmat[9], xpos[3], xquat[4], xm[9];
     int have = 0;
-    for (int q = MI(chain_adr)[b]; q < MI(chain_adr)[b + 1]; q++) {
-      int a = MI(chain_list)[q];
+    for (int q = MIH(chain_adr)[b]; q < MIH(chain_adr)[b + 1]; q++) {
+      int a = MIH(chain_list)[q];
       kin_compose(c, a, jq, ppos, pquat, pmat, have, xpos, xquat, xm, a == b);
       d_copy3(ppos, xpos); d_copy4(pquat, xquat);
       for (int k = 0; k < 9; k++) pmat[k] = xm[k];
@@ -154,11 +154,11 @@ DEV void com_pos(Ctx &c) {
   const DevModel &M = *c.M;
   PFOR(b, M.nbody) {
     double s[3] = {0, 0, 0};
-    for (int k = MI(subtree_adr)[b]; k < MI(subtree_adr)[b + 1]; k++) {
-      int cb = MI(subtree_list)[k];
-      d_addtoscl3(s, c.xipos + 3 * cb, MD(body_mass)[cb]);
+    for (int k = MIH(subtree_adr)[b]; k < MIH(subtree_adr)[b + 1]; k++) {
+      int cb = MIH(subtree_list)[k];
+      d_addtoscl3(s, c.xipos + 3 * cb, MDH(body_mass)[cb]);
     }
-    double sm = MD(body_subtreemass)[b];
+    double sm = MDH(body_subtreemass)[b];
     if (sm < D_MINVAL) d_copy3(c.subtree_com + 3 * b, c.xipos + 3 * b);
     else d_scl3(c.subtree_com + 3 * b, s, 1.0 / sm);
   }
@@ -166,15 +166,15 @@ DEV void com_pos(Ctx &c) {
   PFOR(b, M.nbody) {
     if (b == 0) { for (int k = 0; k < 10; k++) c.cinert[k] = 0; continue; }
     double off[3], ine[3], r[10];
-    d_sub3(off, c.xipos + 3 * b, c.subtree_com + 3 * MI(body_rootid)[b]);
-    d_copy3(ine, MD(body_inertia) + 3 * b);
-    d_inertcom(r, ine, c.ximat + 9 * b, off, MD(body_mass)[b]);
+    d_sub3(off, c.xipos + 3 * b, c.subtree_com + 3 * MIH(body_rootid)[b]);
+    d_copy3(ine, MDH(body_inertia) + 3 * b);
+    d_inertcom(r, ine, c.ximat + 9 * b, off, MDH(body_mass)[b]);
     for (int k = 0; k < 10; k++) c.cinert[10 * b + k] = r[k];
   }
   PFOR(j, M.njnt) {
-    int b = MI(jnt_bodyid)[j], da = MI(jnt_dofadr)[j], type = MI(jnt_type)[j];
+    int b = MIH(jnt_bodyid)[j], da = MIH(jnt_dofadr)[j], type = MIH(jnt_type)[j];
     double off[3];
-    d_sub3(off, c.subtree_com + 3 * MI(body_rootid)[b], c.xanchor + 3 * j);
+    d_sub3(off, c.subtree_com + 3 * MIH(body_rootid)[b], c.xanchor + 3 * j);
     int skip = 0;
     if (type == 0) {
       for (int k = 0; k < 18; k++) c.cdof[6 * da + k] = 0;
@@ -209,7 +209,7 @@ DEV void crb_and_factor(Ctx &c) {
   PFOR(e, M.nbody * 10) {
     int b = e / 10, k = e - 10 * b;
     double s = 0;
-    if (b > 0) for (int q = MI(subtree_adr)[b]; q < MI(subtree_adr)[b + 1]; q++) s += c.cinert[10 * MI(subtree_list)[q] + k];
+    if (b > 0) for (int q = MIH(subtree_adr)[b]; q < MIH(subtree_adr)[b + 1]; q++) s += c.cinert[10 * MIH(subtree_list)[q] + k];
     c.crb[e] = s;
   }
   SYNC();
@@ -217,10 +217,10 @@ DEV void crb_and_factor(Ctx &c) {
   PFOR(p, M.nmpair) {
     int i = MI(mpair_i)[p], j = MI(mpair_j)[p];
     double buf[6];
-    d_mulinertvec(buf, c.crb + 10 * MI(dof_bodyid)[i], c.cdof + 6 * i);
+    d_mulinertvec(buf, c.crb + 10 * MIH(dof_bodyid)[i], c.cdof + 6 * i);
     const double *cj = c.cdof + 6 * j;
     double v = cj[0]*buf[0] + cj[1]*buf[1] + cj[2]*buf[2] + cj[3]*buf[3] + cj[4]*buf[4] + cj[5]*buf[5];
-    if (i == j) v += MD(dof_armature)[i];
+    if (i == j) v += MDH(dof_armature)[i];
     c.qM[i * nvp + j] = v; c.qM[j * nvp + i] = v;
   }
   SYNC();

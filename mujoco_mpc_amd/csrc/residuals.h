@@ -257,7 +257,7 @@ DEV void residual_humanoid_track(Ctx &c, double *residual) {
     int sid = I[3 + b], body = MI(site_bodyid)[sid];
     double v[3], off[3], lin[3];
     d_sub3(v, p1, p0); d_scl3(v, v, kFps);
-    d_sub3(off, c.site_xpos + 3 * sid, c.subtree_com + 3 * MI(body_rootid)[body]);
+    d_sub3(off, c.site_xpos + 3 * sid, c.subtree_com + 3 * MIH(body_rootid)[body]);
     d_cross(lin, c.cvel + 6 * body, off);
     d_add3(lin, lin, c.cvel + 6 * body + 3);
     d_sub3(residual + o + 3 + 48 + 3 * b, v, lin);
@@ -279,7 +279,7 @@ DEV void residual_humanoid_track(Ctx &c, double *residual) {
 DEV void body_linvel(Ctx &c, int body, double *lin) {
   const DevModel &M = *c.M;
   double off[3];
-  d_sub3(off, c.xipos + 3 * body, c.subtree_com + 3 * MI(body_rootid)[body]);
+  d_sub3(off, c.xipos + 3 * body, c.subtree_com + 3 * MIH(body_rootid)[body]);
   d_cross(lin, c.cvel + 6 * body, off);
   d_add3(lin, lin, c.cvel + 6 * body + 3);
 }
@@ -362,8 +362,8 @@ DEV void residual_shadow(Ctx &c, double *residual) {
   if (LANE == 0) {
     d_sub3(residual, c.xipos + 3 * cube, c.site_xpos + 3 * palm);
     double gq[4], cq[4], iq[4], r3[3], lin[3];
-    d_copy4(iq, MD(body_iquat) + 4 * goal); d_mulquat(gq, c.xquat + 4 * goal, iq);
-    d_copy4(iq, MD(body_iquat) + 4 * cube); d_mulquat(cq, c.xquat + 4 * cube, iq);
+    d_copy4(iq, MDH(body_iquat) + 4 * goal); d_mulquat(gq, c.xquat + 4 * goal, iq);
+    d_copy4(iq, MDH(body_iquat) + 4 * cube); d_mulquat(cq, c.xquat + 4 * cube, iq);
     d_normalize4(gq);
     d_subquat(r3, gq, cq);
     residual[3] = r3[0]; residual[4] = r3[1]; residual[5] = r3[2];

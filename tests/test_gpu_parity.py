@@ -939,3 +939,33 @@ def test_closed_loop_shadow_hand_and_its_transition():
     # (the floor pose above is 0.125 / 0.2 away in x / y; the reset cube rolls a little on the fingers afterwards)
     assert abs(res["state"][4] - m["qpos0"][4]) < 0.05 and abs(res["state"][5] - m["qpos0"][5]) < 0.05 and res["state"][6] > -0.15
     p.close()
+
+
+@pytest.mark.gpu
+def test_closed_loop_walker_walks_and_acrobot_swings_up():
+    """testspeed loop (testspeed.cc:44-129) on the two registry tasks with the reference's agent settings: with a speed goal of
+    1 m/s the walker stays up and moves forward (a passive walker is on the floor within the same time); the acrobot's tip,
+    hanging 4 m below the target at the start, gets above the shoulder."""
+    from mujoco_mpc_amd import cplanner
+    from mujoco_mpc_amd.modelgen import acrobot, walker
+    m, task, d = walker()
+    task = dict(task, parameters=np.array([1.2, 1.0]))
+    num = dict(sampling_spline_points=3, sampling_exploration=0.5, sampling_trajectories=128, sampling_representation=2)
+    p = cplanner.SamplingPlanner()
+    p.Initialize(m, task, num, max_samples=128, max_horizon=80)
+    p.Reset(80)
+    res = cplanner.testspeed(p, d["state"], None, horizon=80, steps_per_planning_iteration=1, total_time=2.0)
+    assert not res["failure"] and res["state"][0] > -0.35 and res["state"][1] > 0.5, res["state"][:3]      # rootz offset, rootx
+    p.close()
+    o = ol.Oracle(m, task)                                                    # no control: falls
+    q, v, _, _, w = o.step(d["state"][:9], d["state"][9:] + np.array([0, 0.3, 0.2, 0, 0, 0, 0, 0, 0]), ctrl=np.zeros(6), nstep=200)
+    assert q[0] < -0.5
+    m, task, d = acrobot()
+    num = dict(sampling_spline_points=10, sampling_exploration=0.05, sampling_trajectories=256, sampling_representation=2)
+    p = cplanner.SamplingPlanner()
+    p.Initialize(m, task, num, max_samples=256, max_horizon=200)
+    p.Reset(200)
+    res = cplanner.testspeed(p, d["state"], None, horizon=200, steps_per_planning_iteration=1, total_time=6.0)
+    tip_z = 2 + np.cos(res["state"][0]) + np.cos(res["state"][0] + res["state"][1])
+    assert not res["failure"] and res["cost_per_step"][-50:].mean() < res["cost_per_step"][:50].mean() and tip_z > 2.0, (tip_z, res["state"])
+    p.close()

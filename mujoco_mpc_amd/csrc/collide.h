@@ -837,9 +837,13 @@ DEV int narrow_batch(Ctx &c, int base, int nactive) {
   if constexpr (HEAVY) c.warning = wave_or_i(c.warning);
   else if (wave_any(n == -2)) return 1;
   int tot, off = wave_excl_scan(n, &tot);
-  if (c.ncon + tot > M.nconmax) { c.warning |= WARN_CONTACTFULL; return 2; }
+  // contact buffer full (mjWARN_CONTACTFULL): the contacts that still fit are kept in pair order, the rest of the step goes on
+  // with them (the candidate fails at the end of the step, but its constraint stage sees what the CPU path sees)
+  const int full = c.ncon + tot > M.nconmax;
+  if (full) c.warning |= WARN_CONTACTFULL;
   for (int k = 0; k < n; k++) {
     int ci = c.ncon + off + k;
+    if (ci >= M.nconmax) break;
     double *cc = c.contact + ci * c.M->con_stride;
     int dim;
     contact_param(c, g1, g2, cc, &dim);
@@ -855,8 +859,8 @@ DEV int narrow_batch(Ctx &c, int base, int nactive) {
     int *ci_ = c.con_i + ci * CONI_STRIDE;
     ci_[0] = dim; ci_[1] = g1; ci_[2] = g2; ci_[3] = 0;
   }
-  c.ncon += tot;
-  return 0;
+  c.ncon = full ? M.nconmax : c.ncon + tot;
+  return full ? 2 : 0;
 }
 // the batches from `base` on with every collider available (out of line: own registers, called from outside collision()'s loop)
 struct BatchOut { int ncon, warning; };

@@ -1,0 +1,27 @@
+"""Diagnostic (GPU box): the fuzz parity of tests/test_random_models.py over many more seeds (default 24..223), HIP engine vs oracle.
+Test infrastructure only (uses oracle/)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import oracle_lib as ol
+from random_models import random_model
+from test_random_models import _plan_inputs, _check
+from mujoco_mpc_amd.planner import HipBackend
+lo, hi = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (24, 224)
+bad = []
+for seed in range(lo, hi):
+    m, task, d = random_model(seed)
+    P, H, N, kt, kv, eps, sel = _plan_inputs(m, seed)
+    a = ol.Oracle(m, task).plan(d["state"], None, 0.0, kt, kv, 2, N, H, sigma=(0.3, 0.0), noise_eps=eps, noise_sel=sel, nthreads=8)
+    be = HipBackend(m, task, max_samples=N, max_horizon=H)
+    out = be.plan(state=d["state"], mocap=None, time=0.0, knot_times=kt, knot_values=kv, interpolation=2, num_trajectory=N, horizon=H,
+                  sigma=(0.3, 0.0), noise_eps=eps, noise_sel=sel)
+    b = be.fetch_all(N, H, P); b["returns"] = out["returns"]; b["failure"] = out["failure"]
+    be.close()
+    try:
+        _check(a, b)
+        assert out["winner"] == a["winner"]
+    except AssertionError as e:
+        bad.append((seed, str(e)[:60]))
+print("seeds", lo, hi, "failed:", bad)

@@ -1,0 +1,104 @@
+// frozen_state.cc — the per-task "frozen ResidualFn state" of MjpcHipTask (int_data / dbl_data, include/mjpc_hip.h:138-150).
+//
+// The reference hands every rollout thread a COPY of the task's ResidualFn (agent.cc:290: task->Residual()); a GPU cannot call
+// back into it, so the members a residual reads (ids resolved at Reset, mode / gait state written by Transition) travel as two
+// flat arrays, refreshed at the top of every plan step (HipSamplingPlanner::RefreshTask).  Layouts: DESIGN.md section 2 and
+// mujoco_mpc_amd/csrc/residuals.h (QI_* / QD_*).  This file is compiled inside an MJPC tree only (needs <mujoco/mujoco.h>).
+//
+// Two ResidualFn classes keep that state private: add ONE line to each of
+//     mjpc/tasks/quadruped/quadruped.h     (class QuadrupedFlat::ResidualFn)      friend struct mjpc::HipFrozenState;
+//     mjpc/tasks/humanoid/tracking/tracking.h (class Tracking::ResidualFn)        friend struct mjpc::HipFrozenState;
+#include <string>
+#include <vector>
+
+#include <mujoco/mujoco.h>
+#include "mjpc/task.h"
+#include "mjpc/tasks/humanoid/tracking/tracking.h"
+#include "mjpc/tasks/quadruped/quadruped.h"
+#include "mjpc/utilities.h"
+
+#include "hip_sampling_planner.h"
+
+namespace mjpc {
+
+namespace {
+// object the named sensor is attached to (the residuals address positions through sensors: SensorByName, utilities.cc:214-229)
+int SensorObject(const mjModel* m, const char* name) {
+  int id = mj_name2id(m, mjOBJ_SENSOR, name);
+  if (id < 0) mju_error("HipSamplingPlanner: sensor '%s' not found", name);
+  return m->sensor_objid[id];
+}
+int Body(const mjModel* m, const char* name) {
+  int id = mj_name2id(m, mjOBJ_BODY, name);
+  if (id < 0) mju_error("HipSamplingPlanner: body '%s' not found", name);
+  return id;
+}
+}  // namespace
+
+struct HipFrozenState {
+  // quadruped.h:169-226 -> QI_* (18 ints) / QD_* (31 doubles)
+  static void Quadruped(const QuadrupedFlat::ResidualFn& r, const mjModel* m, std::vector<int>& I, std::vector<double>& D) {
+    I = {r.torso_body_id_, r.head_site_id_, r.goal_mocap_id_,
+         r.foot_geom_id_[0], r.foot_geom_id_[1], r.foot_geom_id_[2], r.foot_geom_id_[3],       // kFootFL, kFootHL, kFootFR, kFootHR
+         r.gait_param_id_, r.gait_switch_param_id_, r.flip_dir_param_id_, r.biped_type_param_id_,
+         r.cadence_param_id_, r.amplitude_param_id_, r.duty_param_id_,
+         ParameterIndex(m, "Heading"),
+         mj_name2id(m, mjOBJ_KEY, "home"), mj_name2id(m, mjOBJ_KEY, "crouch"),
+         static_cast<int>(r.current_mode_)};
+    D = {r.mode_start_time_, r.position_[0], r.position_[1], r.position_[2], r.heading_[0], r.heading_[1], r.speed_, r.angvel_,
+         r.ground_, r.orientation_[0], r.orientation_[1], r.orientation_[2], r.orientation_[3],
+         r.current_gait_, r.phase_start_, r.phase_start_time_, r.phase_velocity_,
+         r.gravity_, r.jump_vel_, r.flight_time_, r.jump_acc_, r.crouch_time_, r.leap_time_, r.jump_time_, r.crouch_vel_,
+         r.land_time_, r.land_acc_, r.flight_rot_vel_, r.jump_rot_vel_, r.jump_rot_acc_, r.land_rot_acc_};
+  }
+
+  // tracking.cc:43-57,94-216 -> [motion, first key of the motion, its length, 16 site ids, 16 mocap ids] / [reference_time]
+  static void Tracking(const humanoid::Tracking::ResidualFn& r, const mjModel* m, std::vector<int>& I, std::vector<double>& D) {
+    static const char* kBodies[16] = {"pelvis", "head", "ltoe", "rtoe", "lheel", "rheel", "lknee", "rknee",
+                                      "lhand", "rhand", "lelbow", "relbow", "lshoulder", "rshoulder", "lhip", "rhip"};
+    int mode = r.current_mode_, first = 0;
+    for (int k = 0; k < mode; k++) first += humanoid::MotionLength(k);       // tracking.cc:57 (declare it in tracking.h)
+    I = {mode, first, humanoid::MotionLength(mode)};
+    for (const char* b : kBodies) I.push_back(SensorObject(m, (std::string("tracking_pos[") + b + "]").c_str()));
+    for (const char* b : kBodies) I.push_back(m->body_mocapid[Body(m, (std::string("mocap[") + b + "]").c_str())]);
+    D = {r.reference_time_};
+  }
+
+  // stateless residuals: ids only
+  static void Stand(const mjModel* m, std::vector<int>& I) {           // stand.cc:41-94
+    I = {SensorObject(m, "sp0"), SensorObject(m, "sp1"), SensorObject(m, "sp2"), SensorObject(m, "sp3"),
+         SensorObject(m, "head_position"), SensorObject(m, "torso_subtreecom")};
+  }
+  static void Walk(const mjModel* m, std::vector<int>& I) {            // walk.cc:44-166
+    I = {SensorObject(m, "torso_position"), SensorObject(m, "pelvis_position"), SensorObject(m, "foot_right"),
+         SensorObject(m, "foot_left"), SensorObject(m, "waist_lower_subcomvel")};
+  }
+  static void Hand(const mjModel* m, std::vector<int>& I) {            // hand.cc:37-84
+    I = {SensorObject(m, "palm_position"), SensorObject(m, "cube_position"), SensorObject(m, "cube_goal_position"),
+         mj_name2id(m, mjOBJ_KEY, "grasp") >= 0 ? mj_name2id(m, mjOBJ_KEY, "grasp") : 0};
+  }
+  static void Walker(const mjModel* m, std::vector<int>& I) { I = {SensorObject(m, "torso_position")}; }      // walker.cc:39-57
+  static void Acrobot(std::vector<int>& I) { I = {0, 1}; }                                                   // acrobot.cc:38-39: sites 0 and 1
+};
+
+// called by FillTaskView (hip_sampling_planner.cc) with the task's own ResidualFn (Task::InternalResidual is protected: the
+// adapter is handed the pointer by a one-line accessor, integration/README.md)
+void FillFrozenState(const Task& task, const BaseResidualFn* residual, const mjModel* m, int task_id, std::vector<int>& ints,
+                     std::vector<double>& dbls) {
+  ints.clear(); dbls.clear();
+  switch (task_id) {
+    case MJPC_TASK_QUADRUPED:
+      HipFrozenState::Quadruped(*static_cast<const QuadrupedFlat::ResidualFn*>(residual), m, ints, dbls); break;
+    case MJPC_TASK_HUMANOID_TRACK:
+      HipFrozenState::Tracking(*static_cast<const humanoid::Tracking::ResidualFn*>(residual), m, ints, dbls); break;
+    case MJPC_TASK_HUMANOID_STAND: HipFrozenState::Stand(m, ints); break;
+    case MJPC_TASK_HUMANOID_WALK: HipFrozenState::Walk(m, ints); break;
+    case MJPC_TASK_SHADOW_REORIENT: HipFrozenState::Hand(m, ints); break;
+    case MJPC_TASK_WALKER: HipFrozenState::Walker(m, ints); break;
+    case MJPC_TASK_ACROBOT: HipFrozenState::Acrobot(ints); break;
+    default: break;                                                      // particle, cartpole: nothing frozen
+  }
+  (void)task;
+}
+
+}  // namespace mjpc

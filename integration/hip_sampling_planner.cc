@@ -14,6 +14,10 @@ namespace mjpc {
 namespace mju = ::mujoco::util_mjpc;
 using mjpc::spline::SplineInterpolation;
 
+// frozen_state.cc
+void FillFrozenState(const Task& task, const BaseResidualFn* residual, const mjModel* m, int task_id, std::vector<int>& ints,
+                     std::vector<double>& dbls);
+
 namespace {
 
 // Task::Name() -> built-in device residual (include/mjpc_hip.h MJPC_TASK_*); -1: none
@@ -126,8 +130,8 @@ static void FillTaskView(const Task& task, const mjModel* m, MjpcHipTask& t, std
     trace_id.push_back(id >= 0 ? m->sensor_objid[id] : 0);
   }
   t.trace_objtype = trace_type.data(); t.trace_objid = trace_id.data();
-  // frozen ResidualFn members: layouts documented in DESIGN.md section 2b (QI_* / QD_* for the quadruped, site / mocap ids
-  // for tracking, body ids for stand / walk / the hand); filled by the per-task helper of the maintainer's choice
+  // frozen ResidualFn members (frozen_state.cc): ids resolved at Reset and the mode / gait state Transition wrote
+  FillFrozenState(task, task.ResidualForHip(), m, t.task_id, ints, dbls);
   t.num_int = static_cast<int>(ints.size()); t.int_data = ints.data();
   t.num_dbl = static_cast<int>(dbls.size()); t.dbl_data = dbls.data();
 }

@@ -74,8 +74,8 @@ struct HipFrozenState {
          SensorObject(m, "foot_left"), SensorObject(m, "waist_lower_subcomvel")};
   }
   static void Hand(const mjModel* m, std::vector<int>& I) {            // hand.cc:37-84
-    I = {SensorObject(m, "palm_position"), SensorObject(m, "cube_position"), SensorObject(m, "cube_goal_position"),
-         mj_name2id(m, mjOBJ_KEY, "grasp") >= 0 ? mj_name2id(m, mjOBJ_KEY, "grasp") : 0};
+    I = {SensorObject(m, "palm_position"), SensorObject(m, "cube_position"), SensorObject(m, "cube_goal_orientation"),
+         0};                                   // hand.cc:75 reads key 0 (model->key_qpos)
   }
   static void Walker(const mjModel* m, std::vector<int>& I) { I = {SensorObject(m, "torso_position")}; }      // walker.cc:39-57
   static void Acrobot(std::vector<int>& I) { I = {0, 1}; }                                                   // acrobot.cc:38-39: sites 0 and 1

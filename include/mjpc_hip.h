@@ -32,6 +32,9 @@ enum {
   MJPC_GEOM_ELLIPSOID = 4, MJPC_GEOM_CYLINDER = 5, MJPC_GEOM_BOX = 6, MJPC_GEOM_MESH = 7
 };
 enum { MJPC_CONE_PYRAMIDAL = 0, MJPC_CONE_ELLIPTIC = 1 };
+enum { MJPC_SOL_NEWTON = 2, MJPC_INT_EULER = 0 };
+enum { MJPC_DSBL_CONSTRAINT = 1 << 0, MJPC_DSBL_EQUALITY = 1 << 1, MJPC_DSBL_FRICTIONLOSS = 1 << 2, MJPC_DSBL_LIMIT = 1 << 3,
+       MJPC_DSBL_SENSOR = 1 << 12, MJPC_DSBL_MIDPHASE = 1 << 13, MJPC_ENBL_OVERRIDE = 1 << 0, MJPC_ENBL_MULTICCD = 1 << 4 };
 enum { MJPC_DSBL_CONTACT = 1 << 4 };            /* mjDSBL_CONTACT */
 enum { MJPC_BIAS_NONE = 0, MJPC_BIAS_AFFINE = 1 };
 /* spline interpolation, mjpc/spline/spline.h:30-34 */
@@ -86,7 +89,14 @@ typedef struct MjpcHipModel {
   int cone;                /* MJPC_CONE_* */
   int iterations;          /* max Newton iterations (100) */
   int ls_iterations;       /* max line-search iterations (50) */
-  int disableflags;        /* mjDSBL_* bits; only MJPC_DSBL_CONTACT is honoured */
+  int disableflags;        /* mjDSBL_* bits: constraint, frictionloss, limit, contact are honoured; equality / sensor / midphase have
+                            * nothing to act on; any other bit (passive, gravity, clampctrl, warmstart, filterparent, actuation,
+                            * refsafe, eulerdamp) is refused at create */
+  int enableflags;         /* mjENBL_* bits: override and multiccd are refused, the rest has nothing to act on */
+  int solver;              /* mjtSolver: only MJPC_SOL_NEWTON (2, MuJoCo's default and what every MJPC task uses) */
+  int integrator;          /* mjtIntegrator: only MJPC_INT_EULER (0; with implicit joint damping, mj_Euler) */
+  int noslip_iterations;   /* must be 0 */
+  int neq;                 /* number of equality constraints: must be 0 (none of the colliding / planning tasks here has one) */
   /* mjStatistic */
   double meaninertia;
   /* engine capacities (0 = default); overflow => candidate failure, like MuJoCo's

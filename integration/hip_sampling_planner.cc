@@ -57,7 +57,8 @@ static void FillModelView(const mjModel* m, MjpcHipModel& v, std::vector<int>& j
   v.timestep = m->opt.timestep; mju_copy3(v.gravity, m->opt.gravity);
   v.impratio = m->opt.impratio; v.tolerance = m->opt.tolerance; v.ls_tolerance = m->opt.ls_tolerance;
   v.cone = m->opt.cone; v.iterations = m->opt.iterations; v.ls_iterations = m->opt.ls_iterations;
-  v.disableflags = m->opt.disableflags; v.meaninertia = m->stat.meaninertia;
+  v.disableflags = m->opt.disableflags; v.enableflags = m->opt.enableflags; v.solver = m->opt.solver; v.integrator = m->opt.integrator;
+  v.noslip_iterations = m->opt.noslip_iterations; v.neq = m->neq; v.meaninertia = m->stat.meaninertia;
   v.nconmax = 0; v.nefcmax = 0;      // engine defaults (32 contacts, 128 rows per candidate)
   v.body_parentid = m->body_parentid; v.body_rootid = m->body_rootid; v.body_weldid = m->body_weldid;
   v.body_mocapid = m->body_mocapid; v.body_jntnum = m->body_jntnum; v.body_jntadr = m->body_jntadr;

@@ -18,6 +18,7 @@ c_int_p = C.POINTER(C.c_int)
 
 _MODEL_INT_SIZES = ["nq", "nv", "nu", "na", "nbody", "njnt", "ngeom", "nsite", "nmocap", "nuserdata", "nkey", "nexclude", "ntendon", "nwrap", "nmesh", "nmeshvert"]
 _OPTIONAL_TENDON = ("tendon_stiffness", "tendon_damping", "tendon_lengthspring", "tendon_frictionloss")
+_OPTION_DEFAULTS = dict(enableflags=0, solver=2, integrator=0, noslip_iterations=0, neq=0)
 _OPTIONAL_MESH = ("nmesh", "nmeshvert", "geom_dataid", "mesh_vertadr", "mesh_vertnum", "mesh_vert")
 _MODEL_INT_ARRAYS_BODY = ["body_parentid", "body_rootid", "body_weldid", "body_mocapid", "body_jntnum", "body_jntadr",
                           "body_dofnum", "body_dofadr"]
@@ -30,7 +31,8 @@ class MjpcHipModel(C.Structure):
         [(n, C.c_int) for n in _MODEL_INT_SIZES]
         + [("timestep", C.c_double), ("gravity", C.c_double * 3), ("impratio", C.c_double),
            ("tolerance", C.c_double), ("ls_tolerance", C.c_double), ("cone", C.c_int), ("iterations", C.c_int),
-           ("ls_iterations", C.c_int), ("disableflags", C.c_int), ("meaninertia", C.c_double),
+           ("ls_iterations", C.c_int), ("disableflags", C.c_int), ("enableflags", C.c_int), ("solver", C.c_int), ("integrator", C.c_int),
+           ("noslip_iterations", C.c_int), ("neq", C.c_int), ("meaninertia", C.c_double),
            ("nconmax", C.c_int), ("nefcmax", C.c_int)]
         + [(n, c_int_p) for n in _MODEL_INT_ARRAYS_BODY]
         + [(n, c_double_p) for n in _MODEL_DBL_ARRAYS_BODY]
@@ -106,7 +108,9 @@ class CModel:
         self._keep = []
         m = MjpcHipModel()
         for name, ctype in MjpcHipModel._fields_:
-            if name in _OPTIONAL_TENDON and name not in model:       # models built before these fields existed: no passive tendon forces
+            if name in _OPTION_DEFAULTS and name not in model:        # mjOption fields added later: MuJoCo's defaults
+                v = _OPTION_DEFAULTS[name]
+            elif name in _OPTIONAL_TENDON and name not in model:       # models built before these fields existed: no passive tendon forces
                 v = np.zeros(int(model["ntendon"]) * (2 if name == "tendon_lengthspring" else 1))
             elif name in _OPTIONAL_MESH and name not in model:        # ... no meshes
                 v = -np.ones(int(model["ngeom"])) if name == "geom_dataid" else (0 if name in ("nmesh", "nmeshvert") else np.zeros(0))

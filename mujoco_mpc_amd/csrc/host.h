@@ -119,6 +119,13 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
   // models the engine cannot roll out faithfully are refused (never silently approximated)
   if (nv > 64) { p.error = "nv > 64 not supported (dof bitmask)"; return false; }
   if (m->na != 0) { p.error = "activation states (na > 0) not supported"; return false; }
+  if (m->solver != MJPC_SOL_NEWTON) { p.error = "only the Newton solver (mjSOL_NEWTON) is implemented"; return false; }
+  if (m->integrator != MJPC_INT_EULER) { p.error = "only the Euler integrator (with implicit joint damping) is implemented"; return false; }
+  if (m->noslip_iterations != 0) { p.error = "noslip_iterations > 0 not supported"; return false; }
+  if (m->neq != 0) { p.error = "equality constraints (neq > 0) not supported"; return false; }
+  { const int known = MJPC_DSBL_CONSTRAINT | MJPC_DSBL_EQUALITY | MJPC_DSBL_FRICTIONLOSS | MJPC_DSBL_LIMIT | MJPC_DSBL_CONTACT | MJPC_DSBL_SENSOR | MJPC_DSBL_MIDPHASE;
+    if (m->disableflags & ~known) { p.error = "disableflags " + std::to_string(m->disableflags) + ": only constraint / frictionloss / limit / contact can be disabled"; return false; }
+    if (m->enableflags & (MJPC_ENBL_OVERRIDE | MJPC_ENBL_MULTICCD)) { p.error = "enableflags: contact override and multiccd are not supported"; return false; } }
   if (m->nuserdata != 0) { p.error = "nuserdata > 0 not supported (no built-in residual reads mjData.userdata)"; return false; }
   if (m->nefcmax > 192) { p.error = "nefcmax > 192 not supported (line-search rows per lane)"; return false; }
   if (m->nconmax > 64) { p.error = "nconmax > 64 not supported (one contact per lane in the solver)"; return false; }
@@ -130,7 +137,10 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
       p.error = "actuator " + std::to_string(i) + ": only joint and fixed-tendon transmissions are supported"; return false; }
   M.nq = m->nq; M.nv = nv; M.nu = nu; M.nbody = nb; M.njnt = nj; M.ngeom = ng; M.nsite = ns; M.nmocap = m->nmocap;
   M.nkey = m->nkey; M.nvp = NVP_OF(nv); M.ntendon = m->ntendon;
-  M.cone = m->cone; M.iterations = m->iterations; M.ls_iterations = m->ls_iterations; M.disableflags = m->disableflags;
+  M.cone = m->cone; M.iterations = m->iterations; M.ls_iterations = m->ls_iterations;
+  // the device only knows "no contacts"; disabled constraint kinds are dropped from the host-made row lists below
+  M.disableflags = (m->disableflags & (MJPC_DSBL_CONTACT | MJPC_DSBL_CONSTRAINT)) ? MJPC_DSBL_CONTACT : 0;
+  const bool no_fric = m->disableflags & (MJPC_DSBL_CONSTRAINT | MJPC_DSBL_FRICTIONLOSS), no_limit = m->disableflags & (MJPC_DSBL_CONSTRAINT | MJPC_DSBL_LIMIT);
   M.timestep = m->timestep; for (int k = 0; k < 3; k++) M.gravity[k] = m->gravity[k];
   M.impratio = m->impratio; M.tolerance = m->tolerance; M.ls_tolerance = m->ls_tolerance; M.meaninertia = m->meaninertia;
   M.con_stride = (m->cone == MJPC_CONE_ELLIPTIC) ? CON_STRIDE_ELLIPTIC : CON_STRIDE_PLAIN;
@@ -191,7 +201,10 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
   PI_(actuator_ctrllimited, nu); PI_(actuator_forcelimited, nu); PI_(actuator_biastype, nu);
   PD_(actuator_gainprm, 3 * nu); PD_(actuator_biasprm, 3 * nu); PD_(actuator_gear, nu);
   PD_(actuator_ctrlrange, 2 * nu); PD_(actuator_forcerange, 2 * nu);
-  PI_(tendon_adr, m->ntendon); PI_(tendon_num, m->ntendon); PI_(tendon_limited, m->ntendon);
+  PI_(tendon_adr, m->ntendon); PI_(tendon_num, m->ntendon);
+  { std::vector<int> tl(m->ntendon, 0);
+    if (!no_limit) for (int t = 0; t < m->ntendon; t++) tl[t] = m->tendon_limited[t];
+    M.tendon_limited = as_off<int>(put_i(p, tl.data(), tl.size())); }
   PD_(wrap_prm, m->nwrap); PD_(tendon_range, 2 * m->ntendon); PD_(tendon_margin, m->ntendon);
   PD_(tendon_solref_lim, 2 * m->ntendon); PD_(tendon_solimp_lim, 5 * m->ntendon); PD_(tendon_invweight0, m->ntendon);
 #undef PI_
@@ -303,9 +316,9 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
     M.npair = (int)g1s.size();
     M.pair_g1 = as_off<int>(put_i(p, g1s.data(), g1s.size())); M.pair_g2 = as_off<int>(put_i(p, g2s.data(), g2s.size())); }
   { std::vector<int> fr, lim, limb, ray;
-    for (int i = 0; i < nv; i++) if (m->dof_frictionloss[i] > 0) fr.push_back(i);
-    for (int j = 0; j < nj; j++) if (m->jnt_limited[j] && (m->jnt_type[j] == MJPC_JNT_SLIDE || m->jnt_type[j] == MJPC_JNT_HINGE)) lim.push_back(j);
-    for (int j = 0; j < nj; j++) if (m->jnt_limited[j] && m->jnt_type[j] == MJPC_JNT_BALL) limb.push_back(j);
+    for (int i = 0; i < nv; i++) if (!no_fric && m->dof_frictionloss[i] > 0) fr.push_back(i);
+    for (int j = 0; j < nj; j++) if (!no_limit && m->jnt_limited[j] && (m->jnt_type[j] == MJPC_JNT_SLIDE || m->jnt_type[j] == MJPC_JNT_HINGE)) lim.push_back(j);
+    for (int j = 0; j < nj; j++) if (!no_limit && m->jnt_limited[j] && m->jnt_type[j] == MJPC_JNT_BALL) limb.push_back(j);
     for (int g = 0; g < ng; g++) if (m->geom_group[g] == 0) {
       // Ground() (utilities.cc:531-553) casts a ray at the group-0 geoms: the ray code knows planes, spheres and boxes
       int ty = m->geom_type[g];
@@ -321,7 +334,7 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
     M.ray_geom = as_off<int>(put_i(p, ray.data(), ray.size())); }
   // a limited tendon whose joints do not lie on one branch of the elimination tree puts entries outside the Hessian's pattern
   M.limit_cross = 0;
-  for (int t = 0; t < m->ntendon; t++) if (m->tendon_limited[t])
+  for (int t = 0; t < m->ntendon; t++) if (m->tendon_limited[t] && !no_limit)
     for (int w1 = m->tendon_adr[t]; w1 < m->tendon_adr[t] + m->tendon_num[t]; w1++)
       for (int w2 = m->tendon_adr[t]; w2 < w1; w2++) {
         int a = m->jnt_dofadr[m->wrap_objid[w1]], b = m->jnt_dofadr[m->wrap_objid[w2]];

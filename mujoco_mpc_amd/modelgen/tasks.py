@@ -531,6 +531,7 @@ def acrobot(timestep=0.01):
     tip = b.site(lower, "tip", pos=(0, 0, 1))
     b.actuator("elbow", "elbow", gear=2.0, ctrlrange=(-1, 1))
     b.key("home", [3.142, 0.0])
+    b.disableflags = 1                                   # <flag constraint="disable"/> (acrobot.xml.patch:17)
     m = b.compile()
     task = make_task(TASK_ACROBOT, [(2, 0, 50.0), (2, 0, 1.0), (1, 0, 0.05)], parameters=[0.0], traces=[(OBJ_SITE, tip)],
                      int_data=[target, tip])

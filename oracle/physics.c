@@ -306,7 +306,7 @@ static void contact_param(const MjpcHipModel *m, int g1, int g2, OContact *c, do
 static void collision(const OModel *om, OData *d) {
   const MjpcHipModel *m = &om->m;
   d->ncon = 0;
-  if (m->disableflags & MJPC_DSBL_CONTACT) return;
+  if (m->disableflags & (MJPC_DSBL_CONTACT | MJPC_DSBL_CONSTRAINT)) return;
   for (int p = 0; p < om->npair; p++) {
     int g1 = om->pair_g1[p], g2 = om->pair_g2[p];
     OContact proto;
@@ -390,8 +390,9 @@ static void make_constraint(const OModel *om, OData *d) {
   const MjpcHipModel *m = &om->m;
   int nv = m->nv;
   d->nefc = 0; d->nf = 0; d->nl = 0;
+  const int no_fric = m->disableflags & (MJPC_DSBL_CONSTRAINT | MJPC_DSBL_FRICTIONLOSS), no_limit = m->disableflags & (MJPC_DSBL_CONSTRAINT | MJPC_DSBL_LIMIT);
   /* friction loss */
-  for (int i = 0; i < nv; i++) if (m->dof_frictionloss[i] > 0) {
+  for (int i = 0; i < nv; i++) if (!no_fric && m->dof_frictionloss[i] > 0) {
     int r = add_row(om, d, O_CNSTR_FRICTION_DOF, i); if (r < 0) return;
     d->efc_J[r * nv + i] = 1;
     d->efc_frictionloss[r] = m->dof_frictionloss[i];
@@ -401,7 +402,7 @@ static void make_constraint(const OModel *om, OData *d) {
     d->nf++;
   }
   /* joint limits */
-  for (int j = 0; j < m->njnt; j++) if (m->jnt_limited[j] &&
+  for (int j = 0; j < m->njnt; j++) if (!no_limit && m->jnt_limited[j] &&
       (m->jnt_type[j] == MJPC_JNT_SLIDE || m->jnt_type[j] == MJPC_JNT_HINGE)) {
     double value = d->qpos[m->jnt_qposadr[j]], margin = m->jnt_margin[j];
     for (int side = -1; side <= 1; side += 2) {
@@ -420,7 +421,7 @@ static void make_constraint(const OModel *om, OData *d) {
   /* ball-joint limits (mj_instantiateLimit): rotation angle of the joint quaternion against max(range); J = -axis at the three
    * dofs.  Rows follow the hinge / slide limits (MuJoCo interleaves them in joint order: same constraint set, the engine keeps
    * its single-entry rows together) */
-  for (int j = 0; j < m->njnt; j++) if (m->jnt_limited[j] && m->jnt_type[j] == MJPC_JNT_BALL) {
+  for (int j = 0; j < m->njnt; j++) if (!no_limit && m->jnt_limited[j] && m->jnt_type[j] == MJPC_JNT_BALL) {
     double axis[3], angle = oracle_ball_angle(axis, d->qpos + m->jnt_qposadr[j]);
     double margin = m->jnt_margin[j];
     double dist = fmax(m->jnt_range[2 * j], m->jnt_range[2 * j + 1]) - angle;
@@ -435,7 +436,7 @@ static void make_constraint(const OModel *om, OData *d) {
     }
   }
   /* fixed-tendon limits: length = sum coef*qpos, J = coef at the joints' dofs */
-  for (int t = 0; t < m->ntendon; t++) if (m->tendon_limited[t]) {
+  for (int t = 0; t < m->ntendon; t++) if (!no_limit && m->tendon_limited[t]) {
     double value = 0, margin = m->tendon_margin[t];
     for (int w = m->tendon_adr[t]; w < m->tendon_adr[t] + m->tendon_num[t]; w++) value += m->wrap_prm[w] * d->qpos[m->jnt_qposadr[m->wrap_objid[w]]];
     for (int side = -1; side <= 1; side += 2) {

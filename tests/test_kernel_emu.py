@@ -115,6 +115,28 @@ def test_models_the_engine_cannot_roll_out_are_refused_at_create():
         b.tendon("t", ["h"], [1.0], frictionloss=0.1)
     check(tfric, "tendon friction loss")
 
+    # mjOption settings the engine does not implement are refused, not ignored
+    def option(field, value, expect):
+        b = ModelBuilder()
+        b.geom(0, "floor", PLANE, size=(1, 1, 0.1))
+        body = b.body("a", 0, pos=(0, 0, 1))
+        b.joint(body, "f", FREE)
+        b.geom(body, "g", SPHERE, size=(0.1,))
+        m = dict(b.compile(), **{field: value})
+        task["num_residual"] = 1
+        cm = capi.CModel(m, task)
+        n = lib.mjpc_hip_layout_bytes(ctypes.byref(cm.c_model), ctypes.byref(cm.c_task), 1)
+        if expect is None:
+            assert n > 0, lib.mjpc_hip_last_error()
+        else:
+            assert n < 0 and expect in lib.mjpc_hip_last_error().decode(), lib.mjpc_hip_last_error()
+    option("solver", 0, "Newton"); option("solver", 1, "Newton"); option("solver", 2, None)
+    option("integrator", 1, "Euler"); option("integrator", 3, "Euler")
+    option("noslip_iterations", 3, "noslip"); option("neq", 1, "equality")
+    option("disableflags", 1 << 6, "disableflags"); option("disableflags", 1 << 14, "disableflags")          # gravity, eulerdamp
+    option("disableflags", (1 << 0) | (1 << 2) | (1 << 3) | (1 << 4) | (1 << 12), None)
+    option("enableflags", 1 << 0, "override"); option("enableflags", 1 << 1, None)
+
     def userdata(b, body):
         b.nuserdata = 3
     check(userdata, "nuserdata")
@@ -232,3 +254,25 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".h", ".hip", ".cpp")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "oracle_lib" not in txt and "liboracle" not in txt and "oracle/" not in txt.replace("the CPU oracle under oracle/", ""), f
+
+
+@pytest.mark.parametrize("flags", [1 << 2, 1 << 3, (1 << 2) | (1 << 3), 1 << 0])
+def test_disabled_constraint_kinds_are_dropped_the_same_way(flags):
+    """mjDSBL_FRICTIONLOSS / LIMIT / CONSTRAINT: the host drops the rows from its lists, the oracle skips them in make_constraint;
+    a model with friction loss, hinge / ball / tendon limits and contacts gives the same rollouts either way."""
+    from random_models import random_model
+    m, task, d = random_model(5)
+    m = dict(m, disableflags=flags)
+    o = ol.Oracle(m, task)
+    P, H, N = 4, 40, 4
+    kt = np.linspace(0, (H - 1) * m["timestep"], P); kv = np.random.default_rng(3).uniform(-0.5, 0.5, (P, m["nu"]))
+    eps, sel = ol.noise(1, 0, 0, N, P, m["nu"])
+    a = o.plan(d["state"], None, 0.0, kt, kv, 2, N, H, sigma=(0.3, 0.0), noise_eps=eps, noise_sel=sel, nthreads=4)
+    b = emu_lib.plan(m, task, d["state"], None, 0.0, kt, kv, 2, N, H, sigma=(0.3, 0.0), noise_eps=eps, noise_sel=sel)
+    assert np.array_equal(a["failure"], b["failure"])
+    for k in ("states", "costs", "returns"):
+        assert _rel(b[k], a[k]) < 1e-5, k
+    base = emu_lib.plan(dict(m, disableflags=0), task, d["state"], None, 0.0, kt, kv, 2, N, H, sigma=(0.3, 0.0), noise_eps=eps, noise_sel=sel)
+    assert b["diag"][:, 2].max() < base["diag"][:, 2].max()           # fewer constraint rows than with everything enabled
+    if flags & 1:
+        assert b["diag"][:, 2].max() == 0 and b["diag"][:, 1].max() == 0

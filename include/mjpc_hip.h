@@ -33,6 +33,14 @@ enum {
 };
 enum { MJPC_CONE_PYRAMIDAL = 0, MJPC_CONE_ELLIPTIC = 1 };
 enum { MJPC_SOL_NEWTON = 2, MJPC_INT_EULER = 0 };
+/* model features outside this view (MjpcHipModel.unsupported) */
+enum { MJPC_UNSUP_FLUID = 1,          /* opt.density / viscosity / wind non-zero */
+       MJPC_UNSUP_GRAVCOMP = 2,       /* body_gravcomp */
+       MJPC_UNSUP_ACTUATOR_GAIN = 4,  /* gaintype other than fixed, biastype other than none / affine */
+       MJPC_UNSUP_ACTUATOR_DYN = 8,   /* dyntype other than none, actuator activation limits */
+       MJPC_UNSUP_SPATIAL_TENDON = 16,/* wrap objects other than joints */
+       MJPC_UNSUP_JNT_ACTFRC = 32,    /* jnt_actfrclimited */
+       MJPC_UNSUP_FLEX_SKIN_PLUGIN = 64 /* flexes, plugins, user callbacks other than the residual */ };
 enum { MJPC_DSBL_CONSTRAINT = 1 << 0, MJPC_DSBL_EQUALITY = 1 << 1, MJPC_DSBL_FRICTIONLOSS = 1 << 2, MJPC_DSBL_LIMIT = 1 << 3,
        MJPC_DSBL_SENSOR = 1 << 12, MJPC_DSBL_MIDPHASE = 1 << 13, MJPC_ENBL_OVERRIDE = 1 << 0, MJPC_ENBL_MULTICCD = 1 << 4 };
 enum { MJPC_DSBL_CONTACT = 1 << 4 };            /* mjDSBL_CONTACT */
@@ -97,6 +105,8 @@ typedef struct MjpcHipModel {
   int integrator;          /* mjtIntegrator: only MJPC_INT_EULER (0; with implicit joint damping, mj_Euler) */
   int noslip_iterations;   /* must be 0 */
   int neq;                 /* number of equality constraints: must be 0 (none of the colliding / planning tasks here has one) */
+  int unsupported;         /* MJPC_UNSUP_* bits found by whoever fills this view in parts of mjModel the view does not carry
+                            * (integration/hip_sampling_planner.cc: FillModelView); non-zero is refused at create */
   /* mjStatistic */
   double meaninertia;
   /* engine capacities (0 = default); overflow => candidate failure, like MuJoCo's

@@ -59,6 +59,17 @@ static void FillModelView(const mjModel* m, MjpcHipModel& v, std::vector<int>& j
   v.cone = m->opt.cone; v.iterations = m->opt.iterations; v.ls_iterations = m->opt.ls_iterations;
   v.disableflags = m->opt.disableflags; v.enableflags = m->opt.enableflags; v.solver = m->opt.solver; v.integrator = m->opt.integrator;
   v.noslip_iterations = m->opt.noslip_iterations; v.neq = m->neq; v.meaninertia = m->stat.meaninertia;
+  // what this view does not carry: found here, refused by mjpc_hip_create
+  v.unsupported = 0;
+  if (m->opt.density != 0 || m->opt.viscosity != 0 || m->opt.wind[0] != 0 || m->opt.wind[1] != 0 || m->opt.wind[2] != 0) v.unsupported |= MJPC_UNSUP_FLUID;
+  for (int b = 0; b < m->nbody; b++) if (m->body_gravcomp[b] != 0) v.unsupported |= MJPC_UNSUP_GRAVCOMP;
+  for (int i = 0; i < m->nu; i++) {
+    if (m->actuator_gaintype[i] != mjGAIN_FIXED || (m->actuator_biastype[i] != mjBIAS_NONE && m->actuator_biastype[i] != mjBIAS_AFFINE)) v.unsupported |= MJPC_UNSUP_ACTUATOR_GAIN;
+    if (m->actuator_dyntype[i] != mjDYN_NONE || m->actuator_actlimited[i]) v.unsupported |= MJPC_UNSUP_ACTUATOR_DYN;
+  }
+  for (int w = 0; w < m->nwrap; w++) if (m->wrap_type[w] != mjWRAP_JOINT) v.unsupported |= MJPC_UNSUP_SPATIAL_TENDON;
+  for (int j = 0; j < m->njnt; j++) if (m->jnt_actfrclimited[j]) v.unsupported |= MJPC_UNSUP_JNT_ACTFRC;
+  if (m->nflex > 0 || m->nplugin > 0) v.unsupported |= MJPC_UNSUP_FLEX_SKIN_PLUGIN;
   v.nconmax = 0; v.nefcmax = 0;      // engine defaults (32 contacts, 128 rows per candidate)
   v.body_parentid = m->body_parentid; v.body_rootid = m->body_rootid; v.body_weldid = m->body_weldid;
   v.body_mocapid = m->body_mocapid; v.body_jntnum = m->body_jntnum; v.body_jntadr = m->body_jntadr;

@@ -18,7 +18,7 @@ c_int_p = C.POINTER(C.c_int)
 
 _MODEL_INT_SIZES = ["nq", "nv", "nu", "na", "nbody", "njnt", "ngeom", "nsite", "nmocap", "nuserdata", "nkey", "nexclude", "ntendon", "nwrap", "nmesh", "nmeshvert"]
 _OPTIONAL_TENDON = ("tendon_stiffness", "tendon_damping", "tendon_lengthspring", "tendon_frictionloss")
-_OPTION_DEFAULTS = dict(enableflags=0, solver=2, integrator=0, noslip_iterations=0, neq=0)
+_OPTION_DEFAULTS = dict(enableflags=0, solver=2, integrator=0, noslip_iterations=0, neq=0, unsupported=0)
 _OPTIONAL_MESH = ("nmesh", "nmeshvert", "geom_dataid", "mesh_vertadr", "mesh_vertnum", "mesh_vert")
 _MODEL_INT_ARRAYS_BODY = ["body_parentid", "body_rootid", "body_weldid", "body_mocapid", "body_jntnum", "body_jntadr",
                           "body_dofnum", "body_dofadr"]
@@ -32,7 +32,7 @@ class MjpcHipModel(C.Structure):
         + [("timestep", C.c_double), ("gravity", C.c_double * 3), ("impratio", C.c_double),
            ("tolerance", C.c_double), ("ls_tolerance", C.c_double), ("cone", C.c_int), ("iterations", C.c_int),
            ("ls_iterations", C.c_int), ("disableflags", C.c_int), ("enableflags", C.c_int), ("solver", C.c_int), ("integrator", C.c_int),
-           ("noslip_iterations", C.c_int), ("neq", C.c_int), ("meaninertia", C.c_double),
+           ("noslip_iterations", C.c_int), ("neq", C.c_int), ("unsupported", C.c_int), ("meaninertia", C.c_double),
            ("nconmax", C.c_int), ("nefcmax", C.c_int)]
         + [(n, c_int_p) for n in _MODEL_INT_ARRAYS_BODY]
         + [(n, c_double_p) for n in _MODEL_DBL_ARRAYS_BODY]

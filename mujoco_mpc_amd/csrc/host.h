@@ -123,6 +123,7 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
   if (m->integrator != MJPC_INT_EULER) { p.error = "only the Euler integrator (with implicit joint damping) is implemented"; return false; }
   if (m->noslip_iterations != 0) { p.error = "noslip_iterations > 0 not supported"; return false; }
   if (m->neq != 0) { p.error = "equality constraints (neq > 0) not supported"; return false; }
+  if (m->unsupported != 0) { p.error = "the model uses features outside the engine's model view (MJPC_UNSUP_* mask " + std::to_string(m->unsupported) + ": fluid forces, gravity compensation, non-fixed actuator gains, actuator dynamics, spatial tendons, ...)"; return false; }
   { const int known = MJPC_DSBL_CONSTRAINT | MJPC_DSBL_EQUALITY | MJPC_DSBL_FRICTIONLOSS | MJPC_DSBL_LIMIT | MJPC_DSBL_CONTACT | MJPC_DSBL_SENSOR | MJPC_DSBL_MIDPHASE;
     if (m->disableflags & ~known) { p.error = "disableflags " + std::to_string(m->disableflags) + ": only constraint / frictionloss / limit / contact can be disabled"; return false; }
     if (m->enableflags & (MJPC_ENBL_OVERRIDE | MJPC_ENBL_MULTICCD)) { p.error = "enableflags: contact override and multiccd are not supported"; return false; } }

@@ -486,7 +486,7 @@ class ModelBuilder:
         M.update(timestep=o["timestep"], gravity=o["gravity"], impratio=o["impratio"], tolerance=o["tolerance"],
                  ls_tolerance=o["ls_tolerance"], cone=o["cone"], iterations=o["iterations"],
                  ls_iterations=o["ls_iterations"], disableflags=(0 if o["contact"] else (1 << 4)) | int(getattr(self, "disableflags", 0)),
-                 enableflags=0, solver=2, integrator=0, noslip_iterations=0, neq=0,
+                 enableflags=0, solver=2, integrator=0, noslip_iterations=0, neq=0, unsupported=0,
                  nconmax=self.nconmax, nefcmax=self.nefcmax)
         # ---- quantities evaluated at qpos0 (mjModel "set0")
         Mq, Jp, Jr = mass_matrix(M, M["qpos0"])

@@ -136,6 +136,7 @@ def test_models_the_engine_cannot_roll_out_are_refused_at_create():
     option("disableflags", 1 << 6, "disableflags"); option("disableflags", 1 << 14, "disableflags")          # gravity, eulerdamp
     option("disableflags", (1 << 0) | (1 << 2) | (1 << 3) | (1 << 4) | (1 << 12), None)
     option("enableflags", 1 << 0, "override"); option("enableflags", 1 << 1, None)
+    option("unsupported", 1, "outside the engine's model view")
 
     def userdata(b, body):
         b.nuserdata = 3

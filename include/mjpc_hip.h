@@ -87,7 +87,7 @@ enum {
 /* ---- model: the subset of mjModel the path reads ------------------------------------- */
 typedef struct MjpcHipModel {
   /* sizes */
-  int nq, nv, nu, na, nbody, njnt, ngeom, nsite, nmocap, nuserdata, nkey, nexclude, ntendon, nwrap, nmesh, nmeshvert;
+  int nq, nv, nu, na, nbody, njnt, ngeom, nsite, nmocap, nuserdata, nkey, nexclude, ntendon, nwrap, nmesh, nmeshvert, nhfield, nhfielddata;
   /* mjOption */
   double timestep;
   double gravity[3];
@@ -154,6 +154,11 @@ typedef struct MjpcHipModel {
    * nmesh = 0: no meshes.  geom_dataid[g] = mesh of a MJPC_GEOM_MESH geom, -1 otherwise. */
   const int *geom_dataid, *mesh_vertadr, *mesh_vertnum;
   const double *mesh_vert;          /* [3 * nmeshvert] */
+  /* height fields (geom_dataid[g] = height field of a MJPC_GEOM_HFIELD geom): nrow x ncol samples in [0, 1] (mjModel.hfield_data
+   * is float: widen it), row-major with x along the columns; size = (radius_x, radius_y, elevation_z, base_z) */
+  const int *hfield_nrow, *hfield_ncol, *hfield_adr;
+  const double *hfield_size;        /* [4 * nhfield] */
+  const double *hfield_data;        /* [nhfielddata] */
   /* keyframes */
   const double *key_qpos;           /* nkey * nq */
   const double *key_mpos;           /* nkey * 3*nmocap */
@@ -242,7 +247,7 @@ typedef struct MjpcHipEngine MjpcHipEngine;
 /* Create an engine on HIP device `device`.  Copies model+task to HBM.  max_local = largest
  * num_local that will be planned on this device.  Returns NULL on error (see last_error).
  * Models the engine cannot roll out faithfully are REFUSED here (never silently approximated): geom pairs without a
- * collider (height fields; meshes without vertex data), group-0 geoms the quadruped task's ground ray cannot hit, tendon friction loss, actuator transmissions other than joint /
+ * collider (height field against plane / height field; meshes / height fields without data), group-0 geoms the quadruped task's ground ray cannot hit, tendon friction loss, actuator transmissions other than joint /
  * fixed tendon, nuserdata > 0, na > 0, nconmax > 64, nefcmax > 192, iterations > 250, num_spline_points capacity 36, LDS footprint > 160 KiB. */
 MjpcHipEngine *mjpc_hip_create(const MjpcHipModel *model, const MjpcHipTask *task,
                                int max_local, int max_horizon, int device);

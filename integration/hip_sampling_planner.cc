@@ -49,7 +49,8 @@ static void FillModelView(const mjModel* m, MjpcHipModel& v, std::vector<int>& j
                           std::vector<int>& forcelimited, std::vector<int>& biastype, std::vector<int>& trntype,
                           std::vector<int>& trnid, std::vector<int>& tendon_limited, std::vector<int>& wrap_objid,
                           std::vector<double>& gainprm, std::vector<double>& biasprm, std::vector<double>& gear,
-                          std::vector<double>& wrap_prm, std::vector<double>& mesh_vert) {
+                          std::vector<double>& wrap_prm, std::vector<double>& mesh_vert, std::vector<double>& hfield_size,
+                          std::vector<double>& hfield_data) {
   std::memset(&v, 0, sizeof(v));
   v.nq = m->nq; v.nv = m->nv; v.nu = m->nu; v.na = m->na; v.nbody = m->nbody; v.njnt = m->njnt; v.ngeom = m->ngeom;
   v.nsite = m->nsite; v.nmocap = m->nmocap; v.nuserdata = m->nuserdata; v.nkey = m->nkey; v.nexclude = m->nexclude;
@@ -120,6 +121,10 @@ static void FillModelView(const mjModel* m, MjpcHipModel& v, std::vector<int>& j
   // convex meshes: mjModel.mesh_vert is float -> widened copy (mesh_vert_ member); hull = all vertices
   v.nmesh = m->nmesh; v.nmeshvert = m->nmeshvert; v.geom_dataid = m->geom_dataid; v.mesh_vertadr = m->mesh_vertadr; v.mesh_vertnum = m->mesh_vertnum;
   mesh_vert.assign(m->mesh_vert, m->mesh_vert + 3 * m->nmeshvert); v.mesh_vert = mesh_vert.data();
+  // height fields: hfield_data is float as well (appended to the same widened pool)
+  v.nhfield = m->nhfield; v.nhfielddata = m->nhfielddata; v.hfield_nrow = m->hfield_nrow; v.hfield_ncol = m->hfield_ncol; v.hfield_adr = m->hfield_adr;
+  hfield_size.assign(m->hfield_size, m->hfield_size + 4 * m->nhfield); v.hfield_size = hfield_size.data();
+  hfield_data.assign(m->hfield_data, m->hfield_data + m->nhfielddata); v.hfield_data = hfield_data.data();
   v.key_qpos = m->key_qpos; v.key_mpos = m->key_mpos;
 }
 
@@ -169,7 +174,7 @@ void HipSamplingPlanner::Initialize(mjModel* model, const Task& task) {
   sliding_plan_ = n.sampling_sliding_plan;
   if (num_trajectory_ > kMaxTrajectoryHip) mju_error_i("Too many trajectories, %d is the maximum allowed.", kMaxTrajectoryHip);
   FillModelView(model, model_view_, jnt_limited_, ctrllimited_, forcelimited_, biastype_, trntype_, trnid_, tendon_limited_,
-                wrap_objid_, gainprm_, biasprm_, gear_, wrap_prm_, mesh_vert_);
+                wrap_objid_, gainprm_, biasprm_, gear_, wrap_prm_, mesh_vert_, hfield_size_, hfield_data_);
   FillTaskView(task, model, task_view_, norm_, trace_type_, trace_id_, task_int_, task_dbl_);
   mjpc_hip::SetErrorHandler([](const char* msg) { mju_error("HipSamplingPlanner: %s", msg); });
   impl_.Initialize(&model_view_, &task_view_, n);           // creates the engines (model may have changed: old ones dropped)

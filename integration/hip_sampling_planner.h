@@ -97,7 +97,7 @@ class HipSamplingPlanner : public RankedPlanner {
   MjpcHipTask task_view_{};
   std::vector<int> jnt_limited_, ctrllimited_, forcelimited_, biastype_, trntype_, trnid_, tendon_limited_, wrap_objid_, trace_type_, trace_id_,
       norm_, task_int_;
-  std::vector<double> gainprm_, biasprm_, gear_, wrap_prm_, mesh_vert_, task_dbl_;
+  std::vector<double> gainprm_, biasprm_, gear_, wrap_prm_, mesh_vert_, hfield_size_, hfield_data_, task_dbl_;
   Trajectory best_, scratch_trajectory_;
   SamplingPolicy scratch_policy_;
   std::vector<double> traces_;           // [N][H][3 * num_trace] of the last plan (Traces)

@@ -16,10 +16,11 @@ ENGINE_PATH = os.path.join(_HERE, "csrc", "libmjpc_hip.so")
 c_double_p = C.POINTER(C.c_double)
 c_int_p = C.POINTER(C.c_int)
 
-_MODEL_INT_SIZES = ["nq", "nv", "nu", "na", "nbody", "njnt", "ngeom", "nsite", "nmocap", "nuserdata", "nkey", "nexclude", "ntendon", "nwrap", "nmesh", "nmeshvert"]
+_MODEL_INT_SIZES = ["nq", "nv", "nu", "na", "nbody", "njnt", "ngeom", "nsite", "nmocap", "nuserdata", "nkey", "nexclude", "ntendon", "nwrap", "nmesh", "nmeshvert", "nhfield", "nhfielddata"]
 _OPTIONAL_TENDON = ("tendon_stiffness", "tendon_damping", "tendon_lengthspring", "tendon_frictionloss")
 _OPTION_DEFAULTS = dict(enableflags=0, solver=2, integrator=0, noslip_iterations=0, neq=0, unsupported=0)
-_OPTIONAL_MESH = ("nmesh", "nmeshvert", "geom_dataid", "mesh_vertadr", "mesh_vertnum", "mesh_vert")
+_OPTIONAL_MESH = ("nmesh", "nmeshvert", "geom_dataid", "mesh_vertadr", "mesh_vertnum", "mesh_vert", "nhfield", "nhfielddata", "hfield_nrow",
+                  "hfield_ncol", "hfield_adr", "hfield_size", "hfield_data")
 _MODEL_INT_ARRAYS_BODY = ["body_parentid", "body_rootid", "body_weldid", "body_mocapid", "body_jntnum", "body_jntadr",
                           "body_dofnum", "body_dofadr"]
 _MODEL_DBL_ARRAYS_BODY = ["body_pos", "body_quat", "body_ipos", "body_iquat", "body_mass", "body_subtreemass",
@@ -55,6 +56,7 @@ class MjpcHipModel(C.Structure):
                                      "tendon_invweight0", "tendon_stiffness", "tendon_damping", "tendon_lengthspring",
                                      "tendon_frictionloss"]]
         + [(n, c_int_p) for n in ["geom_dataid", "mesh_vertadr", "mesh_vertnum"]] + [("mesh_vert", c_double_p)]
+        + [(n, c_int_p) for n in ["hfield_nrow", "hfield_ncol", "hfield_adr"]] + [("hfield_size", c_double_p), ("hfield_data", c_double_p)]
         + [("key_qpos", c_double_p), ("key_mpos", c_double_p)]
     )
 
@@ -113,7 +115,7 @@ class CModel:
             elif name in _OPTIONAL_TENDON and name not in model:       # models built before these fields existed: no passive tendon forces
                 v = np.zeros(int(model["ntendon"]) * (2 if name == "tendon_lengthspring" else 1))
             elif name in _OPTIONAL_MESH and name not in model:        # ... no meshes
-                v = -np.ones(int(model["ngeom"])) if name == "geom_dataid" else (0 if name in ("nmesh", "nmeshvert") else np.zeros(0))
+                v = -np.ones(int(model["ngeom"])) if name == "geom_dataid" else (0 if name in ("nmesh", "nmeshvert", "nhfield", "nhfielddata") else np.zeros(0))
             else:
                 v = model[name]
             if ctype is c_double_p:

@@ -659,6 +659,61 @@ DEV int np_convex(NPCon *con, double margin, const MShape &A, const MShape &B) {
   return 1;
 }
 
+// height field (geom 1) against a convex geom: the cells under the geom's bounding sphere, two triangular prisms each, every
+// prism through the portal-refinement collider; the 4 deepest contacts are kept; *overflow beyond HF_MAXCELL cells
+#define HF_MAXCELL 100
+DEV int np_hfield(NPCon *con, double margin, const double *hp, const double *hm, const double *hsize, int nrow, int ncol,
+                  const double *data, const MShape &B, double rbound, int *overflow) {
+  double dif[3], c[3];
+  d_sub3(dif, B.pos, hp);
+  d_mulmattvec3(c, hm, dif);
+  double r = rbound + margin, rx = hsize[0], ry = hsize[1], elev = hsize[2], base = hsize[3];
+  if (c[0] + r < -rx || c[0] - r > rx || c[1] + r < -ry || c[1] - r > ry || c[2] - r > elev || c[2] + r < -base) return 0;
+  double dx = 2 * rx / (ncol - 1), dy = 2 * ry / (nrow - 1);
+  int cmin = (int)floor((c[0] - r + rx) / dx), cmax = (int)floor((c[0] + r + rx) / dx);
+  int rmin = (int)floor((c[1] - r + ry) / dy), rmax = (int)floor((c[1] + r + ry) / dy);
+  if (cmin < 0) cmin = 0;
+  if (rmin < 0) rmin = 0;
+  if (cmax > ncol - 2) cmax = ncol - 2;
+  if (rmax > nrow - 2) rmax = nrow - 2;
+  if ((cmax - cmin + 1) * (rmax - rmin + 1) > HF_MAXCELL) { *overflow = 1; return 0; }
+  int cnt = 0;
+  for (int row = rmin; row <= rmax; row++) for (int col = cmin; col <= cmax; col++) {
+    double x0 = -rx + col * dx, x1 = x0 + dx, y0 = -ry + row * dy, y1 = y0 + dy;
+    double h00 = data[row * ncol + col] * elev, h01 = data[row * ncol + col + 1] * elev;
+    double h10 = data[(row + 1) * ncol + col] * elev, h11 = data[(row + 1) * ncol + col + 1] * elev;
+    if (fmax(fmax(h00, h01), fmax(h10, h11)) < c[2] - r) continue;
+    for (int tri = 0; tri < 2; tri++) {
+      double tx[3] = {x0, x1, tri == 0 ? x1 : x0}, ty[3] = {y0, tri == 0 ? y0 : y1, y1}, th[3] = {h00, tri == 0 ? h01 : h11, tri == 0 ? h11 : h10};
+      double v[18], cen[3] = {0, 0, 0};
+      for (int k = 0; k < 3; k++) {
+        v[3 * k] = tx[k]; v[3 * k + 1] = ty[k]; v[3 * k + 2] = th[k];
+        v[9 + 3 * k] = tx[k]; v[9 + 3 * k + 1] = ty[k]; v[9 + 3 * k + 2] = -base;
+      }
+      for (int k = 0; k < 6; k++) { cen[0] += v[3 * k]; cen[1] += v[3 * k + 1]; cen[2] += v[3 * k + 2]; }
+      for (int k = 0; k < 3; k++) cen[k] *= 1.0 / 6.0;
+      for (int k = 0; k < 6; k++) { v[3 * k] -= cen[0]; v[3 * k + 1] -= cen[1]; v[3 * k + 2] -= cen[2]; }
+      double pp[3];
+      d_mulmatvec3(pp, hm, cen);
+      d_add3(pp, pp, hp);
+      MShape P = {7, pp, hm, hsize, 0.5 * margin, v, 6};
+      NPCon t[4];
+      if (np_convex(t, margin, P, B)) {
+        if (cnt < 4) { np_put(con, cnt, t[0]); cnt++; }
+        else {        // full: the new contact replaces the shallowest kept one if it is deeper (first such slot)
+          int w = 0;
+          double dw = con[0].dist;
+          if (con[1].dist > dw) { w = 1; dw = con[1].dist; }
+          if (con[2].dist > dw) { w = 2; dw = con[2].dist; }
+          if (con[3].dist > dw) { w = 3; dw = con[3].dist; }
+          if (t[0].dist < dw) np_put(con, w, t[0]);
+        }
+      }
+    }
+  }
+  return cnt;
+}
+
 // plane against an ellipsoid / a convex mesh: its support point against the plane normal
 DEV int np_plane_convex(NPCon *con, double margin, const double *pp, const double *pm, MShape E) {
   double n[3] = {pm[2], pm[5], pm[8]}, nd[3] = {-pm[2], -pm[5], -pm[8]}, sp[3], dif[3];
@@ -692,6 +747,15 @@ DEV NPOut narrow_heavy(Ctx &c, int g1, int g2, double margin) {
   else if (t1 == 6 && t2 == 6) o.n = np_box_box(o.c, margin, p1, m1, s1, p2, m2, s2);
   else if (t1 == 2 && t2 == 5) o.n = np_sphere_cylinder(o.c, margin, p1, s1[0], p2, m2, s2);
   else if (t1 == 3 && t2 == 5) o.n = np_capsule_cylinder(o.c, margin, p1, m1, s1, p2, m2, s2);
+  else if (t1 == 1 && t2 >= 2) {
+    // height field against anything convex
+    MShape B = {t2, p2, m2, s2, 0.5 * margin, nullptr, 0};
+    if (t2 == 7) { int k = M.geom_dataid[g2]; B.vert = M.mesh_vert + 3 * M.mesh_vertadr[k]; B.nvert = M.mesh_vertnum[k]; }
+    int h = M.geom_dataid[g1], over = 0;
+    o.n = np_hfield(o.c, margin, p1, m1, M.hfield_size + 4 * h, M.hfield_nrow[h], M.hfield_ncol[h], M.hfield_data + M.hfield_adr[h], B,
+                    MD(geom_rbound)[g2], &over);
+    if (over) o.n = -1;
+  }
   else if ((t1 == 4 || t2 == 4 || t1 == 7 || t2 == 7) && t1 != 1 && t2 != 1) {
     // ellipsoids and convex meshes: support point against a plane, the portal-refinement collider against everything else
     MShape A = {t1, p1, m1, s1, 0.5 * margin, nullptr, 0}, B = {t2, p2, m2, s2, 0.5 * margin, nullptr, 0};

@@ -300,9 +300,12 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
       for (int g : {g1, g2}) {
         int ty = m->geom_type[g];
         if (ty == MJPC_GEOM_HFIELD) {
-          p.error = "geom " + std::to_string(g) + " (height field) can collide with geom " + std::to_string(g == g1 ? g2 : g1) +
-                    " but height fields have no collider here";
-          return false;
+          int k = m->geom_dataid ? m->geom_dataid[g] : -1;
+          bool ok = k >= 0 && k < m->nhfield && m->hfield_data && m->hfield_nrow[k] >= 2 && m->hfield_ncol[k] >= 2 &&
+                    m->hfield_adr[k] + m->hfield_nrow[k] * m->hfield_ncol[k] <= m->nhfielddata;
+          int other = g == g1 ? g2 : g1;
+          if (!ok) { p.error = "geom " + std::to_string(g) + " is a height field that can collide but has no usable data (geom_dataid / hfield_*)"; return false; }
+          if (m->geom_type[other] < MJPC_GEOM_SPHERE) { p.error = "height field " + std::to_string(g) + " against a plane / height field (geom " + std::to_string(other) + ") has no collider"; return false; }
         }
         if (ty == MJPC_GEOM_MESH) {
           int k = m->geom_dataid ? m->geom_dataid[g] : -1;
@@ -372,6 +375,10 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
     M.mesh_vertadr = as_off<int>(put_i(p, m->mesh_vertadr, (size_t)(m->nmesh > 0 ? m->nmesh : 0)));
     M.mesh_vertnum = as_off<int>(put_i(p, m->mesh_vertnum, (size_t)(m->nmesh > 0 ? m->nmesh : 0)));
     M.mesh_vert = as_off<double>(put_d(p, m->mesh_vert, (size_t)(m->nmeshvert > 0 ? 3 * m->nmeshvert : 0))); }
+  { size_t nh = (size_t)(m->nhfield > 0 ? m->nhfield : 0);
+    M.hfield_nrow = as_off<int>(put_i(p, m->hfield_nrow, nh)); M.hfield_ncol = as_off<int>(put_i(p, m->hfield_ncol, nh));
+    M.hfield_adr = as_off<int>(put_i(p, m->hfield_adr, nh)); M.hfield_size = as_off<double>(put_d(p, m->hfield_size, 4 * nh));
+    M.hfield_data = as_off<double>(put_d(p, m->hfield_data, (size_t)(m->nhfielddata > 0 ? m->nhfielddata : 0))); }
   // ---- LDS layout
   if (!use_cache) { p.cache_i = hot_only ? p.hot_i : 0; p.cache_d = hot_only ? p.hot_d : 0; }      // the kernel reads (the rest of) the tables from HBM / L2
   make_layout(p, p.L, m, t, P_max, p.cache_d, p.cache_i, lean);
@@ -397,6 +404,7 @@ static inline DevModel relocate(const PackedModel &p, const int *ibase, const do
   fi(M.act_adr); fi(M.act_dof); fi(M.act_qpos); fi(M.act_of); fi(M.dact_adr); fi(M.dact_e); fd(M.act_coef); fi(M.actuator_ctrllimited); fi(M.actuator_forcelimited); fi(M.actuator_biastype);
   fd(M.actuator_gainprm); fd(M.actuator_biasprm); fd(M.actuator_gear); fd(M.actuator_ctrlrange); fd(M.actuator_forcerange);
   fd(M.key_qpos); fd(M.key_mpos); fi(M.geom_dataid); fi(M.mesh_vertadr); fi(M.mesh_vertnum); fd(M.mesh_vert);
+  fi(M.hfield_nrow); fi(M.hfield_ncol); fi(M.hfield_adr); fd(M.hfield_size); fd(M.hfield_data);
   fi(M.tendon_adr); fi(M.tendon_num); fi(M.tendon_limited); fi(M.wrap_dofadr); fi(M.wrap_qposadr);
   fd(M.wrap_prm); fd(M.tendon_range); fd(M.tendon_margin); fd(M.tendon_solref_lim); fd(M.tendon_solimp_lim); fd(M.tendon_invweight0);
   fi(M.level_adr); fi(M.level_body); fi(M.subtree_adr); fi(M.subtree_list); fi(M.chain_adr); fi(M.chain_list); fi(M.mpair_i); fi(M.mpair_j); fi(M.hpair_i); fi(M.hpair_j); fi(M.zpair_i); fi(M.zpair_j);

@@ -114,6 +114,8 @@ struct DevModel {
   const double *key_qpos, *key_mpos;
   const int *geom_dataid, *mesh_vertadr, *mesh_vertnum;     // convex meshes: read from HBM / L2 (never in the LDS copy)
   const double *mesh_vert;
+  const int *hfield_nrow, *hfield_ncol, *hfield_adr;        // height fields: read from HBM / L2
+  const double *hfield_size, *hfield_data;
   // derived on the host at create()
   const int *level_adr, *level_body;        // bodies grouped by tree depth (depth >= 1)
   const int *subtree_adr, *subtree_list;    // bodies of each subtree, self first, ascending ids

@@ -168,12 +168,15 @@ class ModelBuilder:
     def geom(self, body, name="", type=SPHERE, size=(0, 0, 0), pos=(0, 0, 0), quat=(1, 0, 0, 0), fromto=None,
              mass=None, density=1000.0, contype=1, conaffinity=1, condim=3, friction=(1, 0.005, 0.0001),
              priority=0, margin=0.0, gap=0.0, solmix=1.0, solref=DEF_SOLREF, solimp=DEF_SOLIMP, group=0,
-             zaxis=None, euler=None, mesh=None):
+             zaxis=None, euler=None, mesh=None, hfield=None):
         """mesh: (nvert, 3) vertices of a MESH geom in the geom frame (collision uses their convex hull, as MuJoCo does); its
         size becomes the half extents of the vertex cloud (mass properties of that box: model authoring for tests only)."""
         if mesh is not None:
             mesh = np.asarray(mesh, float).reshape(-1, 3)
             size = tuple(np.abs(mesh).max(axis=0))
+        if hfield is not None:       # dict(size=(radius_x, radius_y, elevation_z, base_z), data=[nrow][ncol] in [0, 1]); static geoms only
+            hfield = dict(size=tuple(float(x) for x in hfield["size"]), data=np.asarray(hfield["data"], float))
+            size = hfield["size"][:3]; mass = 0.0 if mass is None else mass
         size = list(size) + [0.0] * (3 - len(size))
         pos = np.array(pos, float); quat = normq(quat)
         if zaxis is not None:
@@ -187,7 +190,7 @@ class ModelBuilder:
             size[1] = 0.5 * np.linalg.norm(b - a)
         g = _Geom(name, body, type, np.array(size, float), pos, quat, mass, density, contype, conaffinity, condim,
                   tuple(friction), priority, margin, gap, solmix, tuple(solref), tuple(solimp), group)
-        g.mesh = mesh
+        g.mesh = mesh; g.hfield = hfield
         self.geoms.append(g)
         self.bodies[body].geoms.append(len(self.geoms) - 1)
         return len(self.geoms) - 1
@@ -260,7 +263,9 @@ class ModelBuilder:
         s = g.size
         return {PLANE: 0.0, SPHERE: s[0], CAPSULE: s[0] + s[1], CYLINDER: math.hypot(s[0], s[1]),
                 BOX: float(np.linalg.norm(s)), ELLIPSOID: float(max(s)),
-                MESH: float(np.linalg.norm(getattr(g, "mesh", np.zeros((1, 3))), axis=1).max()) if getattr(g, "mesh", None) is not None else 0.0}.get(g.type, 0.0)
+                MESH: float(np.linalg.norm(getattr(g, "mesh", np.zeros((1, 3))), axis=1).max()) if getattr(g, "mesh", None) is not None else 0.0,
+                HFIELD: (math.sqrt(g.hfield["size"][0] ** 2 + g.hfield["size"][1] ** 2 + max(g.hfield["size"][2], g.hfield["size"][3]) ** 2)
+                         if getattr(g, "hfield", None) is not None else 0.0)}.get(g.type, 0.0)
 
     # ---- compile
     def compile(self):
@@ -386,6 +391,14 @@ class ModelBuilder:
                 dataid.append(len(vadr)); vadr.append(sum(vnum)); vnum.append(len(g.mesh)); verts.append(g.mesh)
             else:
                 dataid.append(-1)
+        hn, hc, ha, hs, hd = [], [], [], [], []
+        for gi, g in enumerate(G):
+            if g.type == HFIELD and getattr(g, "hfield", None) is not None:
+                dataid[gi] = len(hn); hn.append(g.hfield["data"].shape[0]); hc.append(g.hfield["data"].shape[1]); ha.append(sum(len(x) for x in hd))
+                hs.append(g.hfield["size"]); hd.append(g.hfield["data"].ravel())
+        M["hfield_nrow"] = np.array(hn, np.int32); M["hfield_ncol"] = np.array(hc, np.int32); M["hfield_adr"] = np.array(ha, np.int32)
+        M["hfield_size"] = np.array(hs, float).reshape(-1, 4) if hs else np.zeros((0, 4))
+        M["hfield_data"] = np.concatenate(hd) if hd else np.zeros(0)
         M["geom_dataid"] = np.array(dataid, np.int32)
         M["mesh_vertadr"] = np.array(vadr, np.int32); M["mesh_vertnum"] = np.array(vnum, np.int32)
         M["mesh_vert"] = np.concatenate(verts).reshape(-1, 3) if verts else np.zeros((0, 3))
@@ -480,7 +493,7 @@ class ModelBuilder:
         M["tendon_lengthspring"] = ls
         sizes = dict(nq=nq, nv=nv, nu=nu, na=0, nbody=nb, njnt=nj, ngeom=ng, nsite=ns, nmocap=nmocap,
                      nuserdata=self.nuserdata, nkey=nkey, nexclude=len(self.excludes), ntendon=len(self.tendons),
-                     nwrap=len(wrap_objid), nmesh=len(M["mesh_vertadr"]), nmeshvert=len(M["mesh_vert"]))
+                     nwrap=len(wrap_objid), nmesh=len(M["mesh_vertadr"]), nmeshvert=len(M["mesh_vert"]), nhfield=len(M["hfield_nrow"]), nhfielddata=len(M["hfield_data"]))
         M.update(sizes)
         o = self.opt
         M.update(timestep=o["timestep"], gravity=o["gravity"], impratio=o["impratio"], tolerance=o["tolerance"],

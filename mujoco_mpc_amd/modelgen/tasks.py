@@ -15,7 +15,7 @@ import struct
 
 import numpy as np
 
-from .builder import (BALL, BOX, CAPSULE, CYLINDER, ELLIPSOID, FREE, HINGE, PLANE, SLIDE, SPHERE, ModelBuilder)
+from .builder import (BALL, BOX, CAPSULE, CYLINDER, ELLIPSOID, FREE, HFIELD, HINGE, PLANE, SLIDE, SPHERE, ModelBuilder)
 
 TASK_PARTICLE, TASK_CARTPOLE, TASK_QUADRUPED, TASK_COPYSTATE, TASK_HUMANOID_TRACK, TASK_HUMANOID_STAND, TASK_HUMANOID_WALK = 0, 1, 2, 3, 4, 5, 6
 TASK_SHADOW_REORIENT = 7
@@ -601,4 +601,35 @@ def cylinder_pile(timestep=0.004):
     return m, task, defaults
 
 
-REGISTRY = {"walker": walker, "acrobot": acrobot, "ball_chain": ball_chain, "cylinder_pile": cylinder_pile, "humanoid_stand": humanoid_stand, "humanoid_walk": humanoid_walk, "particle": particle, "cartpole": cartpole, "quadruped": quadruped, "humanoid_track": humanoid_track, "shadow_hand": shadow_hand}
+def terrain_balls(timestep=0.004):
+    """Test model for height-field collisions: a bumpy terrain, two spheres, a capsule and an ellipsoid dropped on it, a motor
+    pushing one sphere uphill."""
+    b = ModelBuilder(timestep=timestep, cone=1, impratio=1.0, contact=True)
+    n = 17
+    xs = np.linspace(-1, 1, n)
+    data = 0.5 + 0.25 * np.sin(2.1 * xs)[None, :] * np.cos(1.7 * xs)[:, None] + 0.15 * xs[None, :]
+    data = (data - data.min()) / (data.max() - data.min())
+    b.geom(0, "terrain", HFIELD, hfield=dict(size=(1.0, 1.0, 0.3, 0.1), data=data), friction=(0.8, 0.005, 0.0001), condim=3)
+    def height(x, y):       # bilinear is not what the collider uses (triangles), good enough to place things above the ground
+        i = min(max(int((y + 1) / 2 * (n - 1)), 0), n - 2); j = min(max(int((x + 1) / 2 * (n - 1)), 0), n - 2)
+        return 0.3 * max(data[i, j], data[i, j + 1], data[i + 1, j], data[i + 1, j + 1])
+    for k, (ty, size, xy) in enumerate([(SPHERE, (0.06,), (-0.3, 0.2)), (SPHERE, (0.05,), (0.35, -0.25)), (CAPSULE, (0.04, 0.08), (0.1, 0.45)),
+                                        (ELLIPSOID, (0.07, 0.05, 0.04), (-0.45, -0.4))]):
+        bid = b.body(f"o{k}", 0, pos=(xy[0], xy[1], height(*xy) + 0.1), quat=(math.cos(0.2 * k), math.sin(0.2 * k), 0, 0))
+        b.joint(bid, f"o{k}_free", FREE)
+        b.geom(bid, f"o{k}_g", ty, size=size, mass=0.3, friction=(0.8, 0.005, 0.0001))
+    cart = b.body("cart", 0, pos=(0.0, 0.0, height(0, 0) + 0.05))
+    b.joint(cart, "cx", SLIDE, axis=(1, 0, 0), damping=1.0)
+    b.joint(cart, "cz", SLIDE, axis=(0, 0, 1), damping=0.5)
+    b.geom(cart, "cart_g", SPHERE, size=(0.05,), mass=0.4, friction=(0.8, 0.005, 0.0001))
+    site = b.site(cart, "cart_site")
+    b.actuator("push", "cx", gear=3.0, ctrlrange=(-1, 1))
+    b.nconmax = 24; b.nefcmax = 96
+    m = b.compile()
+    task = make_task(TASK_COPYSTATE, [(m["nq"], 0, 1.0), (m["nv"], 0, 0.1)], traces=[(OBJ_SITE, site)])
+    st = np.concatenate([m["qpos0"], np.zeros(m["nv"])])
+    defaults = dict(N=6, P=3, sigma=(0.5, 0.0), interp=2, horizon=60, state=st, mocap=np.zeros(0))
+    return m, task, defaults
+
+
+REGISTRY = {"terrain_balls": terrain_balls, "walker": walker, "acrobot": acrobot, "ball_chain": ball_chain, "cylinder_pile": cylinder_pile, "humanoid_stand": humanoid_stand, "humanoid_walk": humanoid_walk, "particle": particle, "cartpole": cartpole, "quadruped": quadruped, "humanoid_track": humanoid_track, "shadow_hand": shadow_hand}

@@ -12,7 +12,8 @@
  * conventions and contact budgets (capsule-box <= 2 contacts: closest segment point + far end cap;
  * box-box <= 4: separating-axis test, then reference-face clipping or one edge-edge contact).
  * cylinder-cylinder, cylinder-box and every ellipsoid pair (plane-ellipsoid: closed form) go through a portal-refinement (MPR)
- * collider, below; so do convex meshes (support = hull vertex farthest along the direction).  Height-field pairs are counted in `unsupported` and produce no contact; the engine refuses such models at create().
+ * collider, below; so do convex meshes (support = hull vertex farthest along the direction).  Height fields meet convex geoms prism by prism through the same
+ * collider (hfield_convex).  Pairs beyond its cell / contact caps are counted in `unsupported` and produce no contact; the engine refuses such models at create().
  * PARITY UNPINNED (no MuJoCo in this image); analytic checks in tests/test_oracle_physics.py.
  */
 #include "oracle.h"
@@ -666,6 +667,62 @@ static int convex_mpr_shapes(OContact *con, double margin, MShape A, MShape B) {
   return 1;
 }
 
+/* height field (geom 1) against a convex geom (MuJoCo: mjc_ConvexHField): the cells under the geom's bounding sphere are cut
+ * into two triangular prisms each (top = the terrain triangle, bottom at -base) and every prism meets the geom through the
+ * portal-refinement collider.  The 4 deepest contacts of a pair are kept (MuJoCo keeps up to 50: a deliberate cap, the contacts
+ * dropped are the shallow duplicates neighbouring prisms report around the same touching point); more than HF_MAXCELL cells
+ * under the geom raise the unsupported flag (the candidate fails loudly). */
+#define HF_MAXCELL 100
+static int hfield_convex(OContact *con, double margin, const double *hp, const double *hm, const double *hsize, int nrow, int ncol,
+                         const double *data, MShape B, double rbound, int *overflow) {
+  double dif[3], c[3];
+  o_sub3(dif, B.pos, hp);
+  o_mulmattvec3(c, hm, dif);
+  double r = rbound + margin, rx = hsize[0], ry = hsize[1], elev = hsize[2], base = hsize[3];
+  if (c[0] + r < -rx || c[0] - r > rx || c[1] + r < -ry || c[1] - r > ry || c[2] - r > elev || c[2] + r < -base) return 0;
+  double dx = 2 * rx / (ncol - 1), dy = 2 * ry / (nrow - 1);
+  int cmin = (int)floor((c[0] - r + rx) / dx), cmax = (int)floor((c[0] + r + rx) / dx);
+  int rmin = (int)floor((c[1] - r + ry) / dy), rmax = (int)floor((c[1] + r + ry) / dy);
+  if (cmin < 0) cmin = 0;
+  if (rmin < 0) rmin = 0;
+  if (cmax > ncol - 2) cmax = ncol - 2;
+  if (rmax > nrow - 2) rmax = nrow - 2;
+  if ((cmax - cmin + 1) * (rmax - rmin + 1) > HF_MAXCELL) { *overflow = 1; return 0; }
+  int cnt = 0;
+  for (int row = rmin; row <= rmax; row++) for (int col = cmin; col <= cmax; col++) {
+    double x0 = -rx + col * dx, x1 = x0 + dx, y0 = -ry + row * dy, y1 = y0 + dy;
+    double h00 = data[row * ncol + col] * elev, h01 = data[row * ncol + col + 1] * elev;
+    double h10 = data[(row + 1) * ncol + col] * elev, h11 = data[(row + 1) * ncol + col + 1] * elev;
+    if (fmax(fmax(h00, h01), fmax(h10, h11)) < c[2] - r) continue;      /* the geom is entirely above this cell */
+    for (int tri = 0; tri < 2; tri++) {
+      /* triangle 0: (x0,y0) (x1,y0) (x1,y1); triangle 1: (x0,y0) (x1,y1) (x0,y1) */
+      double tx[3] = {x0, x1, tri == 0 ? x1 : x0}, ty[3] = {y0, tri == 0 ? y0 : y1, y1}, th[3] = {h00, tri == 0 ? h01 : h11, tri == 0 ? h11 : h10};
+      double v[18], cen[3] = {0, 0, 0};
+      for (int k = 0; k < 3; k++) {
+        v[3 * k] = tx[k]; v[3 * k + 1] = ty[k]; v[3 * k + 2] = th[k];
+        v[9 + 3 * k] = tx[k]; v[9 + 3 * k + 1] = ty[k]; v[9 + 3 * k + 2] = -base;
+      }
+      for (int k = 0; k < 6; k++) { cen[0] += v[3 * k]; cen[1] += v[3 * k + 1]; cen[2] += v[3 * k + 2]; }
+      for (int k = 0; k < 3; k++) cen[k] *= 1.0 / 6.0;
+      for (int k = 0; k < 6; k++) { v[3 * k] -= cen[0]; v[3 * k + 1] -= cen[1]; v[3 * k + 2] -= cen[2]; }
+      double pp[3];
+      o_mulmatvec3(pp, hm, cen);
+      o_add3(pp, pp, hp);
+      MShape P = {MJPC_GEOM_MESH, pp, hm, hsize, 0.5 * margin, v, 6};
+      OContact t;
+      if (convex_mpr_shapes(&t, margin, P, B)) {
+        if (cnt < 4) con[cnt++] = t;
+        else {        /* full: the new contact replaces the shallowest kept one if it is deeper (first such slot) */
+          int w = 0;
+          for (int k = 1; k < 4; k++) if (con[k].dist > con[w].dist) w = k;
+          if (t.dist < con[w].dist) con[w] = t;
+        }
+      }
+    }
+  }
+  return cnt;
+}
+
 /* plane against an ellipsoid: the ellipsoid's support point against the plane normal (mjc_PlaneConvex's construction) */
 static int plane_convex(OContact *con, double margin, const double *pp, const double *pm, MShape E) {
   double n[3] = {pm[2], pm[5], pm[8]}, nd[3] = {-pm[2], -pm[5], -pm[8]}, sp[3], dif[3];
@@ -737,6 +794,16 @@ int oracle_collide_pair(const OModel *om, OData *d, int g1, int g2, double margi
   } else if (t1 == MJPC_GEOM_BOX && t2 == MJPC_GEOM_BOX) {
     return box_box(con, margin, p1, m1, s1, p2, m2, s2);
   }
+  /* height field against anything convex */
+  if (t1 == MJPC_GEOM_HFIELD && t2 >= MJPC_GEOM_SPHERE) {
+    MShape B = {t2, p2, m2, s2, 0.5 * margin, 0, 0};
+    if (t2 == MJPC_GEOM_MESH) { int k = m->geom_dataid[g2]; B.vert = m->mesh_vert + 3 * m->mesh_vertadr[k]; B.nvert = m->mesh_vertnum[k]; }
+    int h = m->geom_dataid[g1], over = 0;
+    int n = hfield_convex(con, margin, p1, m1, m->hfield_size + 4 * h, m->hfield_nrow[h], m->hfield_ncol[h], m->hfield_data + m->hfield_adr[h], B,
+                          m->geom_rbound[g2], &over);
+    if (over) (*unsupported)++;
+    return n;
+  }
   /* ellipsoids and convex meshes: support point against a plane, the portal-refinement collider against everything else */
   if ((t1 == MJPC_GEOM_ELLIPSOID || t2 == MJPC_GEOM_ELLIPSOID || t1 == MJPC_GEOM_MESH || t2 == MJPC_GEOM_MESH) && t1 != MJPC_GEOM_HFIELD && t2 != MJPC_GEOM_HFIELD) {
     MShape A = {t1, p1, m1, s1, 0.5 * margin, 0, 0}, B = {t2, p2, m2, s2, 0.5 * margin, 0, 0};
@@ -789,4 +856,16 @@ int oracle_debug_collide_mesh(int t1, const double *s1, const double *p1, const 
   int n = t1 == MJPC_GEOM_PLANE ? plane_convex(con, margin, p1, m1, B) : convex_mpr_shapes(con, margin, A, B);
   for (int k = 0; k < n; k++) { out[7 * k] = con[k].dist; o_copy3(out + 7 * k + 1, con[k].pos); o_copy3(out + 7 * k + 4, con[k].frame); }
   return n;
+}
+
+/* test access: a height field (size[4], nrow x ncol data) against a primitive */
+int oracle_debug_collide_hfield(const double *hsize, int nrow, int ncol, const double *data, const double *hp, const double *hm,
+                                int t2, const double *s2, const double *p2, const double *m2, double rbound, double margin, double *out) {
+  OContact con[4];
+  memset(con, 0, sizeof(con));
+  MShape B = {t2, p2, m2, s2, 0.5 * margin, 0, 0};
+  int over = 0;
+  int n = hfield_convex(con, margin, hp, hm, hsize, nrow, ncol, data, B, rbound, &over);
+  for (int k = 0; k < n; k++) { out[7 * k] = con[k].dist; o_copy3(out + 7 * k + 1, con[k].pos); o_copy3(out + 7 * k + 4, con[k].frame); }
+  return over ? -1 : n;
 }

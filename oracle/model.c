@@ -66,6 +66,7 @@ OModel *oracle_create(const MjpcHipModel *src, const MjpcHipTask *task) {
   if (src->tendon_frictionloss) CD(tendon_frictionloss, src->ntendon);
   if (src->geom_dataid) CI(geom_dataid, ng);
   if (src->nmesh > 0) { CI(mesh_vertadr, src->nmesh); CI(mesh_vertnum, src->nmesh); CD(mesh_vert, 3 * src->nmeshvert); }
+  if (src->nhfield > 0) { CI(hfield_nrow, src->nhfield); CI(hfield_ncol, src->nhfield); CI(hfield_adr, src->nhfield); CD(hfield_size, 4 * src->nhfield); CD(hfield_data, src->nhfielddata); }
   CD(key_qpos, src->nkey * src->nq); CD(key_mpos, src->nkey * 3 * src->nmocap);
   copy_task(om, task);
 

@@ -4,7 +4,7 @@ body, motors and position servos, fixed tendons with limits / springs / dampers 
 contact dimensions 1 / 3 / 4 / 6.  The residual copies the state."""
 import numpy as np
 
-from mujoco_mpc_amd.modelgen.builder import BALL, BOX, CAPSULE, CYLINDER, ELLIPSOID, FREE, HINGE, MESH, PLANE, SLIDE, SPHERE, ModelBuilder
+from mujoco_mpc_amd.modelgen.builder import BALL, BOX, CAPSULE, CYLINDER, ELLIPSOID, FREE, HFIELD, HINGE, MESH, PLANE, SLIDE, SPHERE, ModelBuilder
 from mujoco_mpc_amd.modelgen.tasks import OBJ_SITE, TASK_COPYSTATE, make_task
 
 
@@ -21,8 +21,14 @@ def random_model(seed, portal_pairs=False):
     cone = int(rng.integers(0, 2))
     b = ModelBuilder(timestep=float(rng.choice([0.002, 0.004, 0.005])), cone=cone, impratio=float(rng.choice([1.0, 3.0])) if cone else 1.0,
                      contact=True)
-    b.geom(0, "floor", PLANE, size=(3, 3, 0.1), friction=(float(rng.uniform(0.4, 1.0)), 0.005, 0.0001), condim=int(rng.choice([3, 3, 4, 6])),
-           contype=0, conaffinity=7)
+    if portal_pairs and rng.random() < 0.5:       # a gently rolling height field instead of the floor plane
+        xs = np.linspace(-1, 1, 13)
+        data = 0.5 + 0.5 * np.sin(rng.uniform(1, 3) * xs)[None, :] * np.cos(rng.uniform(1, 3) * xs)[:, None]
+        b.geom(0, "floor", HFIELD, hfield=dict(size=(1.5, 1.5, 0.12, 0.1), data=data), friction=(float(rng.uniform(0.4, 1.0)), 0.005, 0.0001),
+               condim=int(rng.choice([3, 3, 4, 6])), contype=0, conaffinity=7)
+    else:
+        b.geom(0, "floor", PLANE, size=(3, 3, 0.1), friction=(float(rng.uniform(0.4, 1.0)), 0.005, 0.0001), condim=int(rng.choice([3, 3, 4, 6])),
+               contype=0, conaffinity=7)
     nbody = int(rng.integers(3, 8))
     bodies, scalar_joints = [], []
     for i in range(nbody):

@@ -99,6 +99,15 @@ def test_walker_and_acrobot_registry_tasks():
     assert allc["residual"].shape[-1] == 5 and np.allclose(allc["residual"][:, 0, 0], 4.0, atol=1e-6)      # hanging: tip 4 m below the target
 
 
+def test_height_field_terrain():
+    """Height field (MuJoCo: mjc_ConvexHField): spheres, a capsule and an ellipsoid dropped on a bumpy terrain, one sphere pushed
+    uphill; the four deepest prism contacts of a pair are kept."""
+    from mujoco_mpc_amd.modelgen import terrain_balls
+    m, task, d = terrain_balls()
+    out, ref, allc = _compare(m, task, d, 3, 60, 12, (0.5, 0.0), 2, 1e-5)
+    assert allc["diag"][:, 1].max() >= 6 and not out["failure"].any()
+
+
 def test_cartpole_c1_config():
     """BASELINE config C1: 16 samples, horizon 50, 10 cubic knots."""
     m, task, d = cartpole()

@@ -22,6 +22,7 @@ def _rel(a, b):
 @pytest.mark.parametrize("name,P,H,N,sigma,tol", [("particle", 11, 26, 6, (0.3, 0.0), 1e-12), ("cartpole", 10, 50, 8, (0.5, 0.0), 1e-12),
                                                    ("quadruped", 3, 30, 6, (0.04, 0.0), 1e-5),
                                                    ("walker", 3, 80, 6, (0.5, 0.0), 1e-5), ("acrobot", 10, 100, 6, (0.05, 0.0), 1e-9),   # registry tasks beyond the BASELINE configs
+                                                   ("terrain_balls", 3, 60, 6, (0.5, 0.0), 1e-5),   # height field: prisms through the portal-refinement collider
                                                    ("cylinder_pile", 3, 50, 6, (0.5, 0.0), 1e-5),   # cylinder-box / cylinder-cylinder through the portal-refinement collider
                                                    ("ball_chain", 4, 60, 6, (0.4, 0.0), 1e-5),      # limited ball joints, tendon spring / damper / cross-branch limit
                                                    ("humanoid_track", 16, 30, 4, (0.15, 0.0), 1e-5),
@@ -74,7 +75,7 @@ def test_lds_budget_of_every_baseline_model():
 def test_models_the_engine_cannot_roll_out_are_refused_at_create():
     """ADVICE r1: no silent approximation.  Host-side validation (mjpc_host::build) refuses meshes / height fields that can collide,
     tendon friction loss, user data, oversized buffers; a cylinder next to a capsule is accepted (conservative run-time test)."""
-    from mujoco_mpc_amd.modelgen.builder import BALL, BOX, CYLINDER, ELLIPSOID, FREE, HINGE, MESH, PLANE, SPHERE, ModelBuilder
+    from mujoco_mpc_amd.modelgen.builder import BALL, BOX, CYLINDER, ELLIPSOID, FREE, HFIELD, HINGE, MESH, PLANE, SPHERE, ModelBuilder
     from mujoco_mpc_amd.modelgen.tasks import make_task
     lib = ctypes.CDLL(capi.ENGINE_PATH)
     lib.mjpc_hip_layout_bytes.argtypes = [ctypes.POINTER(capi.MjpcHipModel), ctypes.POINTER(capi.MjpcHipTask), ctypes.c_int]
@@ -99,6 +100,8 @@ def test_models_the_engine_cannot_roll_out_are_refused_at_create():
 
     check(lambda b, body: None, None)
     check(lambda b, body: b.geom(body, "e", ELLIPSOID, size=(0.1, 0.2, 0.3)), None)      # ellipsoids go through the portal-refinement collider
+    check(lambda b, body: b.geom(0, "t", HFIELD, size=(1, 1, 0.1)), "no usable data")                             # a height field without samples
+    check(lambda b, body: b.geom(0, "t", HFIELD, hfield=dict(size=(1, 1, 0.2, 0.1), data=np.zeros((4, 4))), contype=2, conaffinity=0), None)   # fine: only the sphere meets it
     check(lambda b, body: b.geom(body, "e", MESH, size=(0.1, 0.2, 0.3)), "no usable vertex data")           # a mesh geom without vertices
     check(lambda b, body: b.geom(body, "e", MESH, mesh=[[0.1, 0, 0], [-0.1, 0, 0], [0, 0.1, 0], [0, 0, 0.1], [0, -0.05, -0.05]]), None)
 

@@ -607,3 +607,46 @@ def test_convex_mesh_collider_against_closed_forms():
         assert na == nb == 1 and abs(a[0, 0] - b[0, 0]) < 1e-6 and np.allclose(a[0, 4:], b[0, 4:], atol=1e-3) and np.allclose(a[0, 1:4], b[0, 1:4], atol=3e-4)
     c, n = _collide_mesh(7, [h, h, h], [0.1, 0.05, 0.1 + h - 1e-3], _rot("z", 0.4), cube, 6, [0.5, 0.5, 0.1], [0, 0, 0], I, None)      # cube mesh on a box face
     assert n == 1 and abs(c[0, 0] + 1e-3) < 1e-6 and np.allclose(c[0, 4:], [0, 0, -1], atol=1e-6) and abs(c[0, 3] - (0.1 - 5e-4)) < 1e-6
+
+
+def _collide_hfield(hsize, data, t2, s2, p2, m2, rbound, margin=0.0):
+    import ctypes as C
+    L = ol.lib()
+    dp = C.POINTER(C.c_double)
+    L.oracle_debug_collide_hfield.argtypes = [dp, C.c_int, C.c_int, dp, dp, dp, C.c_int, dp, dp, dp, C.c_double, C.c_double, dp]
+    arr = lambda x: np.ascontiguousarray(x, float).ravel()
+    data = np.asarray(data, float)
+    a = [arr(hsize), arr(data), arr([0, 0, 0]), arr(np.eye(3)), arr(list(s2) + [0.0] * (3 - len(s2))), arr(p2), arr(m2)]
+    out = np.zeros(28)
+    n = L.oracle_debug_collide_hfield(a[0].ctypes.data_as(dp), data.shape[0], data.shape[1], a[1].ctypes.data_as(dp), a[2].ctypes.data_as(dp),
+                                      a[3].ctypes.data_as(dp), t2, a[4].ctypes.data_as(dp), a[5].ctypes.data_as(dp), a[6].ctypes.data_as(dp), rbound, margin,
+                                      out.ctypes.data_as(dp))
+    return out[:7 * max(n, 0)].reshape(max(n, 0), 7), n
+
+
+def test_height_field_collider_against_closed_forms():
+    """Height field vs convex geom = the terrain prisms under the geom through the portal-refinement collider: on a flat field a
+    sphere meets the plane z = height (deepest contact), on a ramp the plane of the ramp; nothing above the geom's reach."""
+    I = np.eye(3)
+    flat = np.full((9, 9), 0.5)                          # height 0.5 * elevation 0.4 = 0.2
+    hs = [1.0, 1.0, 0.4, 0.1]
+    for x, y in ((0.03, 0.04), (-0.4, 0.31), (0.13, -0.02)):
+        c, n = _collide_hfield(hs, flat, 2, [0.05], [x, y, 0.2 + 0.05 - 1e-3], I, 0.05)
+        assert n >= 1
+        k = np.argmin(c[:, 0])
+        assert abs(c[k, 0] + 1e-3) < 1e-5 and np.allclose(c[k, 4:], [0, 0, 1], atol=1e-3) and abs(c[k, 3] - (0.2 - 5e-4)) < 1e-4
+    _, n = _collide_hfield(hs, flat, 2, [0.05], [0.1, 0.1, 0.2 + 0.05 + 1e-3], I, 0.05)
+    assert n == 0
+    c, n = _collide_hfield(hs, flat, 2, [0.05], [0.1, 0.1, 0.2 + 0.05 + 5e-4], I, 0.05, margin=1e-3)
+    assert n >= 1 and abs(c[:, 0].min() - 5e-4) < 1e-5
+    ramp = np.tile(np.linspace(0.0, 1.0, 9), (9, 1))     # height = 0.2 * (x + 1): a plane of slope 0.2
+    nrm = np.array([-0.2, 0, 1.0]); nrm /= np.linalg.norm(nrm)
+    x0 = 0.17; z0 = 0.2 * (x0 + 1)
+    p = np.array([x0, 0.1, z0]) + nrm * (0.05 - 1e-3)
+    c, n = _collide_hfield(hs, ramp, 2, [0.05], p, I, 0.05)
+    assert n >= 1
+    k = np.argmin(c[:, 0])
+    assert abs(c[k, 0] + 1e-3) < 1e-5 and np.allclose(c[k, 4:], nrm, atol=1e-3)
+    # a box lying on the flat field touches many prisms (one contact each): the four deepest are kept
+    c, n = _collide_hfield(hs, flat, 6, [0.2, 0.15, 0.05], [0.05, 0.02, 0.2 + 0.05 - 1e-3], I, 0.26)
+    assert n == 4 and np.allclose(c[:, 0], -1e-3, atol=1e-5)

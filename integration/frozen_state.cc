@@ -77,6 +77,15 @@ struct HipFrozenState {
     I = {SensorObject(m, "palm_position"), SensorObject(m, "cube_position"), SensorObject(m, "cube_goal_orientation"),
          0};                                   // hand.cc:75 reads key 0 (model->key_qpos)
   }
+  // quadruped.cc:726-768 (the stage counter current_mode_ of QuadrupedHill::ResidualFn is public state of the task: Task::mode)
+  static void Hill(const mjModel* m, int stage, std::vector<int>& I, std::vector<double>& D) {
+    I = {SensorObject(m, "position"), SensorObject(m, "FR"), SensorObject(m, "FL"), SensorObject(m, "RR"), SensorObject(m, "RL"), stage};
+    D.clear();
+    for (int k = 0; k < m->nkey; k++) {
+      for (int q = 0; q < 3; q++) D.push_back(m->key_mpos[3 * m->nmocap * k + q]);
+      for (int q = 0; q < 4; q++) D.push_back(m->key_mquat[4 * m->nmocap * k + q]);
+    }
+  }
   static void Walker(const mjModel* m, std::vector<int>& I) { I = {SensorObject(m, "torso_position")}; }      // walker.cc:39-57
   static void Acrobot(std::vector<int>& I) { I = {0, 1}; }                                                   // acrobot.cc:38-39: sites 0 and 1
 };
@@ -94,6 +103,7 @@ void FillFrozenState(const Task& task, const BaseResidualFn* residual, const mjM
     case MJPC_TASK_HUMANOID_STAND: HipFrozenState::Stand(m, ints); break;
     case MJPC_TASK_HUMANOID_WALK: HipFrozenState::Walk(m, ints); break;
     case MJPC_TASK_SHADOW_REORIENT: HipFrozenState::Hand(m, ints); break;
+    case MJPC_TASK_QUADRUPED_HILL: HipFrozenState::Hill(m, task.mode > 0 ? task.mode - 1 : 0, ints, dbls); break;
     case MJPC_TASK_WALKER: HipFrozenState::Walker(m, ints); break;
     case MJPC_TASK_ACROBOT: HipFrozenState::Acrobot(ints); break;
     default: break;                                                      // particle, cartpole: nothing frozen

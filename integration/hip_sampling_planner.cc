@@ -25,6 +25,7 @@ int DeviceResidual(const Task& task) {
   const std::string name = task.Name();
   if (name == "Cartpole") return MJPC_TASK_CARTPOLE;
   if (name == "Quadruped Flat") return MJPC_TASK_QUADRUPED;
+  if (name == "Quadruped Hill") return MJPC_TASK_QUADRUPED_HILL;
   if (name == "Humanoid Track") return MJPC_TASK_HUMANOID_TRACK;
   if (name == "Humanoid Stand") return MJPC_TASK_HUMANOID_STAND;
   if (name == "Humanoid Walk") return MJPC_TASK_HUMANOID_WALK;

@@ -412,6 +412,19 @@ DEV void task_residual(Ctx &c, double *residual) {
       residual[nu + 1] = c.xmat[9 * b + 8] - 1.0;
       residual[nu + 2] = c.subtree_linvel[3 * b] - MD(task.parameters)[1];
     }
+  } else if (id == 10) {  // quadruped.cc:726-768 (Quadruped Hill): height over the feet, position and orientation against the goal, control
+    const int *I = MI(task.int_data);
+    int b = I[0], nu = M.nu;
+    if (LANE == 0) {
+      double avg = 0.25 * (c.site_xpos[3 * I[1] + 2] + c.site_xpos[3 * I[2] + 2] + c.site_xpos[3 * I[3] + 2] + c.site_xpos[3 * I[4] + 2]);
+      residual[0] = (c.xpos[3 * b + 2] - avg) - MD(task.parameters)[0];
+      for (int k = 0; k < 3; k++) residual[1 + k] = c.xpos[3 * b + k] - c.mocap_pos[k];
+      double gm[9], bm[9];
+      d_quat2mat(gm, c.mocap_quat);
+      d_quat2mat(bm, c.xquat + 4 * b);
+      for (int k = 0; k < 9; k++) residual[4 + k] = bm[k] - gm[k];
+    }
+    PFOR(i, nu) residual[13 + i] = c.ctrl[i];
   } else if (id == 9) {   // acrobot.cc:34-49: goal - tip (z, x), joint velocities, control
     if (LANE == 0) {
       int g = MI(task.int_data)[0], t = MI(task.int_data)[1];

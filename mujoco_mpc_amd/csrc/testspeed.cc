@@ -338,8 +338,27 @@ static void HandTransition(const MjpcHipModel& m, SimState& s, HostTask& t, cons
   (void)t;
 }
 
+// ---- QuadrupedHill::TransitionLocked (quadruped.cc:776-812): when the trunk is within 0.15 of the goal pose (position norm and
+// 1 - |<q_goal, q_trunk>|) the goal moves on to the next stage key, wrapping at the end.
+// int_data = [trunk body, sites FR FL RR RL, stage]; dbl_data = stage goals [nstage][7]
+static void HillTransition(const MjpcHipModel& m, SimState& s, HostTask& t, const SimFrame& f) {
+  const int trunk = t.int_data[0], nstage = (int)t.dbl_data.size() / 7;
+  if (nstage < 1 || m.nmocap < 1) return;
+  int stage = t.int_data[5];
+  const double* goal = s.mocap.data();
+  double q[4], err = 0, dot = 0;
+  QuatOfRotation(f.xmat.data() + 9 * trunk, q);
+  for (int k = 0; k < 3; k++) { double e = f.xpos[3 * trunk + k] - goal[k]; err += e * e; }
+  for (int k = 0; k < 4; k++) dot += goal[3 + k] * q[k];
+  const double tolerance = 1.5e-1;
+  if (std::sqrt(err) <= tolerance && 1.0 - std::fabs(dot) <= tolerance) stage = (stage + 1) % nstage;
+  t.int_data[5] = stage;
+  for (int k = 0; k < 7; k++) s.mocap[k] = t.dbl_data[7 * stage + k];
+}
+
 TransitionFn TransitionForTask(int task_id, int mode, double mode_time) {
   if (task_id == MJPC_TASK_HUMANOID_TRACK) return TrackingTransition;
+  if (task_id == MJPC_TASK_QUADRUPED_HILL) return HillTransition;
   if (task_id == MJPC_TASK_SHADOW_REORIENT) return HandTransition;
   if (task_id == MJPC_TASK_QUADRUPED) {
     auto q = std::make_shared<QuadrupedTransition>();

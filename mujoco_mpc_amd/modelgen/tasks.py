@@ -121,22 +121,12 @@ _CALF_INERTIAL = dict(mass=0.226, pos=(0.00472659, 0, -0.131975), quat=(0.706886
                       diaginertia=(0.00340344, 0.00339393, 3.54834e-05))
 
 
-def quadruped(timestep=0.01, transitioned=True):
-    b = ModelBuilder(timestep=timestep, cone=1, impratio=10.0, contact=True)
-    b.nconmax = 32
-    b.nefcmax = 128
-    # world geoms (task_flat.xml:52-61)
-    b.geom(0, "floor", PLANE, pos=(0, 0, -0.01), size=(0, 0, 0.1))
-    b.geom(0, "ramp", BOX, pos=(3.13, 2.5, -0.18), size=(1.6, 1, 0.5), euler=(0, -0.2, 0))
-    b.geom(0, "hill", SPHERE, pos=(6, 6, -5.5), size=(6,))
-    goal = b.body("goal", 0, pos=(0.3, 0, 0.26), mocap=True)
-    b.geom(goal, "goal", SPHERE, size=(0.12,), contype=0, conaffinity=0, group=2)
-    box = b.body("box", 0, pos=(-2.5, 0, 0), mocap=True)
-    b.geom(box, "box", BOX, size=(1, 1, 0.3))
+def _a1_robot(b, pos=(0, 0, 0.5)):
+    """The A1 of a1.xml.patch on builder b: returns (trunk body, head site, {foot name: geom id})."""
     # A1 (a1.xml.patch); class a1: friction 0.6 margin 0.001 condim 1; class collision: capsule, group 3
     col = dict(friction=(0.6, 0.005, 0.0001), margin=0.001, condim=1, group=3)
     jdef = dict(damping=2.0, armature=0.01, frictionloss=0.2, limited=True)
-    trunk = b.body("trunk", 0, pos=(0, 0, 0.5),
+    trunk = b.body("trunk", 0, pos=pos,
                    inertial=dict(mass=4.713, pos=(0, 0.0041, -0.0005),
                                  fullinertia=(0.0158533, 0.0377999, 0.0456542, -3.66e-05, -6.11e-05, -2.75e-05)))
     b.site(trunk, "torso")
@@ -170,6 +160,22 @@ def quadruped(timestep=0.01, transitioned=True):
                                  solimp=(0.015, 1, 0.031, 0.5, 2), condim=6, friction=(0.8, 0.02, 0.01),
                                  margin=0.001, group=3)
         b.site(calf, jpref, pos=(0, 0, -0.2))
+    return trunk, head, foot_geom
+
+
+def quadruped(timestep=0.01, transitioned=True):
+    b = ModelBuilder(timestep=timestep, cone=1, impratio=10.0, contact=True)
+    b.nconmax = 32
+    b.nefcmax = 128
+    # world geoms (task_flat.xml:52-61)
+    b.geom(0, "floor", PLANE, pos=(0, 0, -0.01), size=(0, 0, 0.1))
+    b.geom(0, "ramp", BOX, pos=(3.13, 2.5, -0.18), size=(1.6, 1, 0.5), euler=(0, -0.2, 0))
+    b.geom(0, "hill", SPHERE, pos=(6, 6, -5.5), size=(6,))
+    goal = b.body("goal", 0, pos=(0.3, 0, 0.26), mocap=True)
+    b.geom(goal, "goal", SPHERE, size=(0.12,), contype=0, conaffinity=0, group=2)
+    box = b.body("box", 0, pos=(-2.5, 0, 0), mocap=True)
+    b.geom(box, "box", BOX, size=(1, 1, 0.3))
+    trunk, head, foot_geom = _a1_robot(b)
     for jpref in ("FR", "FL", "RR", "RL"):
         for part in ("hip", "thigh", "calf"):
             b.actuator(f"{jpref}_{part}", f"{jpref}_{part}_joint", gainprm=(40, 0, 0), ctrlrange=(-1, 1))
@@ -477,6 +483,40 @@ def shadow_hand(timestep=0.01, cone=0, nconmax=32, nefcmax=128):
     return m, task, defaults
 
 
+# ----------------------------------------------------------------------------------- quadruped on the fractal terrain
+TASK_QUADRUPED_HILL = 10
+
+
+def quadruped_hill(timestep=0.01, stage=0):
+    """mjpc/tasks/quadruped "Quadruped Hill" (task_hill.xml, quadruped.cc:716-812): the A1 with position servos (a1.xml.patch:17-35:
+    kp 50, force range +-33.5) on the fractal height field (assets/fractal.xml: size 5 5 1 2, 100 x 100 samples derived from the
+    reference's image by data/make_fractal.py), goal = a mocap body that Transition moves through the 19 stage keys."""
+    import os
+    data = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "quadruped_hill_terrain.npz"))
+    b = ModelBuilder(timestep=timestep, cone=1, impratio=10.0, contact=True)
+    b.nconmax = 32
+    b.nefcmax = 128
+    goal = b.body("goal", 0, pos=tuple(data["stages"][0][:3]), quat=tuple(data["stages"][0][3:]), mocap=True)
+    b.geom(goal, "goal", CAPSULE, size=(0.1, 0), fromto=(-0.1, 0, 0, 0.1, 0, 0), contype=0, conaffinity=0, group=2)
+    b.geom(0, "floor", PLANE, pos=(0, 0, -0.01), size=(50, 50, 0.05))
+    b.geom(0, "terrain", HFIELD, hfield=dict(size=tuple(data["size"]), data=data["data"]))
+    trunk, head, foot_geom = _a1_robot(b, pos=(0, 0, 0.5))
+    cr = dict(hip=(-0.802851, 0.802851), thigh=(-1.9472, 3.28879), calf=(-0.89653, 0.883702))
+    for jpref in ("FR", "FL", "RR", "RL"):
+        for part in ("hip", "thigh", "calf"):
+            b.position(f"{jpref}_{part}", joint=f"{jpref}_{part}_joint", kp=50.0, ctrlrange=cr[part], forcerange=(-33.5, 33.5))
+    b.key("home", list(data["home"]))
+    m = b.compile()
+    sid = m["names"]["site"]
+    stages = np.asarray(data["stages"], float)
+    task = make_task(TASK_QUADRUPED_HILL, [(1, 0, 1.0), (3, 0, 5.0), (9, 0, 1.0), (12, 0, 0.25)], parameters=[0.25],
+                     traces=[(OBJ_BODY, trunk)], int_data=[trunk, sid["FR"], sid["FL"], sid["RR"], sid["RL"], int(stage)],
+                     dbl_data=list(stages.ravel()))
+    state = np.concatenate([np.asarray(data["home"], float), np.zeros(m["nv"])])
+    defaults = dict(N=10, P=5, sigma=(0.3, 0.0), interp=2, horizon=26, state=state, mocap=stages[stage].copy())
+    return m, task, defaults
+
+
 # ----------------------------------------------------------------------------------- walker, acrobot (registry tasks, SURVEY 8f4)
 def walker(timestep=0.01):
     """mjpc/tasks/walker (task.xml:10-33, walker.cc:39-57).  The planar walker of dm_control's walker.xml is fetched and patched by
@@ -632,4 +672,4 @@ def terrain_balls(timestep=0.004):
     return m, task, defaults
 
 
-REGISTRY = {"terrain_balls": terrain_balls, "walker": walker, "acrobot": acrobot, "ball_chain": ball_chain, "cylinder_pile": cylinder_pile, "humanoid_stand": humanoid_stand, "humanoid_walk": humanoid_walk, "particle": particle, "cartpole": cartpole, "quadruped": quadruped, "humanoid_track": humanoid_track, "shadow_hand": shadow_hand}
+REGISTRY = {"quadruped_hill": quadruped_hill, "terrain_balls": terrain_balls, "walker": walker, "acrobot": acrobot, "ball_chain": ball_chain, "cylinder_pile": cylinder_pile, "humanoid_stand": humanoid_stand, "humanoid_walk": humanoid_walk, "particle": particle, "cartpole": cartpole, "quadruped": quadruped, "humanoid_track": humanoid_track, "shadow_hand": shadow_hand}

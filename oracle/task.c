@@ -542,6 +542,19 @@ void oracle_residual(const OModel *om, OData *d, double *residual) {
       residual[nu + 2] = d->subtree_linvel[3 * b] - om->t.parameters[1];
       break;
     }
+    case MJPC_TASK_QUADRUPED_HILL: {   /* quadruped.cc:726-768 */
+      const int *I = om->t.int_data;
+      int b = I[0];
+      double avg = 0.25 * (d->site_xpos[3 * I[1] + 2] + d->site_xpos[3 * I[2] + 2] + d->site_xpos[3 * I[3] + 2] + d->site_xpos[3 * I[4] + 2]);
+      residual[0] = (d->xpos[3 * b + 2] - avg) - om->t.parameters[0];
+      for (int k = 0; k < 3; k++) residual[1 + k] = d->xpos[3 * b + k] - d->mocap_pos[k];
+      double gm[9], bm[9];
+      o_quat2mat(gm, d->mocap_quat);
+      o_quat2mat(bm, d->xquat + 4 * b);
+      for (int k = 0; k < 9; k++) residual[4 + k] = bm[k] - gm[k];
+      o_copy(residual + 13, d->ctrl, m->nu);
+      break;
+    }
     case MJPC_TASK_ACROBOT: {  /* acrobot.cc:34-49 */
       int g = om->t.int_data[0], t = om->t.int_data[1];
       residual[0] = d->site_xpos[3 * g + 2] - d->site_xpos[3 * t + 2];

@@ -978,3 +978,32 @@ def test_closed_loop_walker_walks_and_acrobot_swings_up():
     tip_z = 2 + np.cos(res["state"][0]) + np.cos(res["state"][0] + res["state"][1])
     assert not res["failure"] and res["cost_per_step"][-50:].mean() < res["cost_per_step"][:50].mean() and tip_z > 2.0, (tip_z, res["state"])
     p.close()
+
+
+@pytest.mark.gpu
+def test_quadruped_hill_parity_and_closed_loop_with_its_transition():
+    """mjpc/tasks/quadruped "Quadruped Hill" (quadruped.cc:726-812): the A1 with position servos on the fractal height field.
+    Plan-step parity with the oracle; closed loop with the host Transition: the robot stays on its feet on the terrain, and a
+    robot put onto a goal makes the Transition move the mocap body on to the next stage key."""
+    from mujoco_mpc_amd import cplanner
+    from mujoco_mpc_amd.modelgen import quadruped_hill
+    m, task, d = quadruped_hill()
+    kv = np.zeros((5, m["nu"]))
+    out, ref, allc = _compare(m, task, d, 5, 26, 16, (0.3, 0.0), 2, 1e-5, kv=kv)
+    assert allc["residual"].shape[-1] == 25 and allc["diag"][:, 1].max() >= 4 and not out["failure"].any()
+    num = dict(sampling_spline_points=5, sampling_exploration=0.3, sampling_trajectories=128, sampling_representation=2)
+    p = cplanner.SamplingPlanner()
+    p.Initialize(m, task, num, max_samples=128, max_horizon=26)
+    p.Reset(26)
+    goal0 = d["mocap"][:3].copy()
+    dist0 = np.linalg.norm(d["state"][:2] - goal0[:2])
+    res = cplanner.testspeed(p, d["state"], d["mocap"], horizon=26, steps_per_planning_iteration=1, total_time=1.5)
+    assert not res["failure"] and res["state"][2] > 0.15                              # still on its feet
+    moved_on = not np.allclose(res["mocap"][:3], goal0)
+    assert moved_on or np.linalg.norm(res["state"][:2] - goal0[:2]) < dist0 + 0.05     # (a 0.25 s horizon is myopic: no progress is asserted, only no retreat)
+    # a trunk placed on the stage-0 goal pose: the first Transition advances the goal to stage 1
+    st = d["state"].copy(); st[:3] = d["mocap"][:3]; st[3:7] = d["mocap"][3:7]
+    res = cplanner.testspeed(p, st, d["mocap"], horizon=26, steps_per_planning_iteration=1, total_time=3 * m["timestep"])
+    stages = np.asarray(task["dbl_data"]).reshape(-1, 7)
+    assert np.allclose(res["mocap"][:7], stages[1])
+    p.close()

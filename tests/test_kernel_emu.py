@@ -22,6 +22,7 @@ def _rel(a, b):
 @pytest.mark.parametrize("name,P,H,N,sigma,tol", [("particle", 11, 26, 6, (0.3, 0.0), 1e-12), ("cartpole", 10, 50, 8, (0.5, 0.0), 1e-12),
                                                    ("quadruped", 3, 30, 6, (0.04, 0.0), 1e-5),
                                                    ("walker", 3, 80, 6, (0.5, 0.0), 1e-5), ("acrobot", 10, 100, 6, (0.05, 0.0), 1e-9),   # registry tasks beyond the BASELINE configs
+                                                   ("quadruped_hill", 5, 26, 6, (0.3, 0.0), 1e-5),  # the A1 on the fractal height field (task_hill.xml)
                                                    ("terrain_balls", 3, 60, 6, (0.5, 0.0), 1e-5),   # height field: prisms through the portal-refinement collider
                                                    ("cylinder_pile", 3, 50, 6, (0.5, 0.0), 1e-5),   # cylinder-box / cylinder-cylinder through the portal-refinement collider
                                                    ("ball_chain", 4, 60, 6, (0.4, 0.0), 1e-5),      # limited ball joints, tendon spring / damper / cross-branch limit

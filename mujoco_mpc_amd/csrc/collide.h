@@ -197,7 +197,7 @@ DEV int np_sphere_box(NPCon *con, double margin, const double *sp, double sr, co
   return 1;
 }
 
-// capsule (geom1) vs box (geom2): closest point of the segment to the box by a fixed-count bisection of the monotone derivative
+// capsule (geom1) vs box (geom2): closest point of the segment to the box = exact root of the monotone, piecewise-linear derivative
 // (the CPU checker restates the same construction with the same operations), then sphere-box there and at the far end cap
 DEV double capsule_box_g(const double *p0, const double *a, double h, const double *b, double s) {
   double g = 0;
@@ -219,12 +219,25 @@ DEV int np_capsule_box(NPCon *con, double margin, const double *cp, const double
   if (capsule_box_g(p0, a, h, bs, -1.0) >= 0) sstar = -1.0;
   else if (capsule_box_g(p0, a, h, bs, 1.0) <= 0) sstar = 1.0;
   else {
-    double lo = -1.0, hi = 1.0;
-    for (int it = 0; it < 48; it++) {
-      double mid = 0.5 * (lo + hi);
-      if (capsule_box_g(p0, a, h, bs, mid) < 0) lo = mid; else hi = mid;
+    // g is piecewise linear with breakpoints where a coordinate crosses a face (|q_i| = b_i): the bracket is narrowed at the
+    // (at most six) breakpoints inside it, then g is linear on what is left and its root is exact
+    double lo = -1.0, hi = 1.0, glo = capsule_box_g(p0, a, h, bs, -1.0), ghi = capsule_box_g(p0, a, h, bs, 1.0);
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+#pragma unroll
+      for (int sg = -1; sg <= 1; sg += 2) {
+        double den = h * a[i];
+        if (fabs(den) < D_MINVAL) continue;
+        double t = (sg * bs[i] - p0[i]) / den;
+        if (!(t > lo && t < hi)) continue;
+        double gt = capsule_box_g(p0, a, h, bs, t);
+        if (gt < 0) { lo = t; glo = gt; } else { hi = t; ghi = gt; }
+      }
     }
-    sstar = 0.5 * (lo + hi);
+    // (a numerically flat piece is the zero-distance stretch of a segment that passes through the box: its left end, like the
+    // leftmost point with g >= 0 everywhere else)
+    double dg = ghi - glo;
+    sstar = dg > 1e-15 ? lo - glo * (hi - lo) / dg : lo;
   }
   int cnt = 0;
   double pt[3];
@@ -241,6 +254,10 @@ DEV int np_capsule_box(NPCon *con, double margin, const double *cp, const double
 // contact (DESIGN.md section 6 describes the construction).  Axis-indexed accesses go through selects so that
 // nothing needs a run-time-indexed private array.
 #define BB_TOL 1e-9
+// a later candidate replaces an earlier one only if it is better by more than this: near-ties (a cube lying flat: several corners
+// at the same depth to rounding) resolve to the lowest candidate index instead of flipping with the last bit of the pose
+#define BB_TIE_D 1e-10
+#define BB_TIE_A 1e-12
 DEV double sel3(const double *v, int i) { return i == 0 ? v[0] : (i == 1 ? v[1] : v[2]); }
 DEV void col3(double *r, const double *m, int k) { r[0] = k == 0 ? m[0] : (k == 1 ? m[1] : m[2]); r[1] = k == 0 ? m[3] : (k == 1 ? m[4] : m[5]); r[2] = k == 0 ? m[6] : (k == 1 ? m[7] : m[8]); }
 struct BBSel { double x, y, d; int ok; };
@@ -388,12 +405,12 @@ DEV int np_box_box(NPCon *con, double margin, const double *pa, const double *ma
   // selection passes regenerate the candidates instead of storing 24 of them: deepest, farthest from it, extreme on either side
   BBSel s0, s1, s2, s3; s0.ok = s1.ok = s2.ok = s3.ok = 0;
   double bd = 1e300;
-  for (int q = 0; q < 24; q++) { BBSel cd = bb_candidate(f, q); if (cd.ok && cd.d <= margin && cd.d < bd) { bd = cd.d; s0 = cd; } }
+  for (int q = 0; q < 24; q++) { BBSel cd = bb_candidate(f, q); if (cd.ok && cd.d <= margin && cd.d < bd - BB_TIE_D) { bd = cd.d; s0 = cd; } }
   if (!s0.ok) return 0;
   double far = 1e-16;
   for (int q = 0; q < 24; q++) {
     BBSel cd = bb_candidate(f, q);
-    if (cd.ok && cd.d <= margin) { double r2 = (cd.x - s0.x) * (cd.x - s0.x) + (cd.y - s0.y) * (cd.y - s0.y); if (r2 > far) { far = r2; s1 = cd; } }
+    if (cd.ok && cd.d <= margin) { double r2 = (cd.x - s0.x) * (cd.x - s0.x) + (cd.y - s0.y) * (cd.y - s0.y); if (r2 > far + BB_TIE_A) { far = r2; s1 = cd; } }
   }
   if (s1.ok) {
     double lx = s1.x - s0.x, ly = s1.y - s0.y, amx = 1e-12, amn = -1e-12;
@@ -401,8 +418,8 @@ DEV int np_box_box(NPCon *con, double margin, const double *pa, const double *ma
       BBSel cd = bb_candidate(f, q);
       if (cd.ok && cd.d <= margin) {
         double ar = lx * (cd.y - s0.y) - ly * (cd.x - s0.x);
-        if (ar > amx) { amx = ar; s2 = cd; }
-        if (ar < amn) { amn = ar; s3 = cd; }
+        if (ar > amx + BB_TIE_A) { amx = ar; s2 = cd; }
+        if (ar < amn - BB_TIE_A) { amn = ar; s3 = cd; }
       }
     }
   }

@@ -199,8 +199,9 @@ static int sphere_box(OContact *con, double margin, const double *sp, double sr,
 
 /* ---- capsule (geom1) vs box (geom2) ------------------------------------------------------------
  * The closest point of the capsule's segment to the box is found in the box frame: f(s) = dist^2(p0 + s h a, box)
- * is convex and C1 in s, g(s) = f'(s) / (2h) = sum_i excess_i * sign(q_i) * a_i is monotone; its root is bracketed on
- * [-1, 1] and bisected a fixed number of times (deterministic, the same IEEE operations on host and device).
+ * is convex and C1 in s, g(s) = f'(s) / (2h) = sum_i excess_i * sign(q_i) * a_i is monotone and piecewise linear; its root is
+ * bracketed on [-1, 1], the bracket narrowed at g's breakpoints, the root of the remaining linear piece taken exactly (the same
+ * IEEE operations on host and device).
  * Contact 1 = sphere-box at that point; contact 2 = sphere-box at the end cap farther from it (a capsule lying on a
  * face gets two contacts, a poking capsule one). */
 static double capsule_box_g(const double *p0, const double *a, double h, const double *b, double s) {
@@ -222,12 +223,21 @@ static int capsule_box(OContact *con, double margin, const double *cp, const dou
   if (capsule_box_g(p0, a, h, bs, -1.0) >= 0) sstar = -1.0;
   else if (capsule_box_g(p0, a, h, bs, 1.0) <= 0) sstar = 1.0;
   else {
-    double lo = -1.0, hi = 1.0;
-    for (int it = 0; it < 48; it++) {
-      double mid = 0.5 * (lo + hi);
-      if (capsule_box_g(p0, a, h, bs, mid) < 0) lo = mid; else hi = mid;
+    /* g is piecewise linear with breakpoints where a coordinate crosses a face (|q_i| = b_i): the bracket is narrowed at the
+     * (at most six) breakpoints inside it, then g is linear on what is left and its root is exact */
+    double lo = -1.0, hi = 1.0, glo = capsule_box_g(p0, a, h, bs, -1.0), ghi = capsule_box_g(p0, a, h, bs, 1.0);
+    for (int i = 0; i < 3; i++) for (int sg = -1; sg <= 1; sg += 2) {
+      double den = h * a[i];
+      if (fabs(den) < O_MINVAL) continue;
+      double t = (sg * bs[i] - p0[i]) / den;
+      if (!(t > lo && t < hi)) continue;
+      double gt = capsule_box_g(p0, a, h, bs, t);
+      if (gt < 0) { lo = t; glo = gt; } else { hi = t; ghi = gt; }
     }
-    sstar = 0.5 * (lo + hi);
+    /* (a numerically flat piece is the zero-distance stretch of a segment that passes through the box: its left end, like the
+     * leftmost point with g >= 0 everywhere else) */
+    double dg = ghi - glo;
+    sstar = dg > 1e-15 ? lo - glo * (hi - lo) / dg : lo;
   }
   int cnt = 0;
   double pt[3];
@@ -321,6 +331,10 @@ static int capsule_cylinder(OContact *con, double margin, const double *kp, cons
  * Normal always points from A to B. */
 typedef struct { double x, y, d; int ok; } BBCand;
 #define BB_TOL 1e-9
+/* a later candidate replaces an earlier one only if it is better by more than this: near-ties (a cube lying flat: several corners
+ * at the same depth to rounding) resolve to the lowest candidate index instead of flipping with the last bit of the pose */
+#define BB_TIE_D 1e-10
+#define BB_TIE_A 1e-12
 static int box_box(OContact *con, double margin, const double *pa, const double *ma, const double *sa,
                    const double *pb, const double *mb, const double *sb) {
   double R[9], AR[9], t[3], tb[3], dif[3];
@@ -446,19 +460,19 @@ static int box_box(OContact *con, double margin, const double *pa, const double 
   /* selection: deepest, farthest from it, then the extreme points on either side of that line */
   int sel[4] = {-1, -1, -1, -1};
   double bd = 1e300;
-  for (int q = 0; q < 24; q++) if (cand[q].ok && cand[q].d <= margin && cand[q].d < bd) { bd = cand[q].d; sel[0] = q; }
+  for (int q = 0; q < 24; q++) if (cand[q].ok && cand[q].d <= margin && cand[q].d < bd - BB_TIE_D) { bd = cand[q].d; sel[0] = q; }
   if (sel[0] < 0) return 0;
   double x0 = cand[sel[0]].x, y0 = cand[sel[0]].y, far = 1e-16;
   for (int q = 0; q < 24; q++) if (cand[q].ok && cand[q].d <= margin) {
     double r2 = (cand[q].x - x0) * (cand[q].x - x0) + (cand[q].y - y0) * (cand[q].y - y0);
-    if (r2 > far) { far = r2; sel[1] = q; }
+    if (r2 > far + BB_TIE_A) { far = r2; sel[1] = q; }
   }
   if (sel[1] >= 0) {
     double lx = cand[sel[1]].x - x0, ly = cand[sel[1]].y - y0, amx = 1e-12, amn = -1e-12;
     for (int q = 0; q < 24; q++) if (cand[q].ok && cand[q].d <= margin) {
       double ar = lx * (cand[q].y - y0) - ly * (cand[q].x - x0);
-      if (ar > amx) { amx = ar; sel[2] = q; }
-      if (ar < amn) { amn = ar; sel[3] = q; }
+      if (ar > amx + BB_TIE_A) { amx = ar; sel[2] = q; }
+      if (ar < amn - BB_TIE_A) { amn = ar; sel[3] = q; }
     }
   }
   int cnt = 0;

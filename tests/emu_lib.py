@@ -28,10 +28,15 @@ def lib():
     if _lib is None:
         csrc = os.path.join(ROOT, "mujoco_mpc_amd", "csrc")
         srcs = [os.path.join(EMU_DIR, "emu.cpp")] + [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".h")]
-        if (not os.path.exists(EMU_SO)) or any(os.path.getmtime(s) > os.path.getmtime(EMU_SO) for s in srcs):
+        so = EMU_SO
+        if os.environ.get("MJPC_EMU_ASAN"):       # memory-checked build of the kernel source: LD_PRELOAD=$(gcc -print-file-name=libasan.so) MJPC_EMU_ASAN=1 pytest ...
+            so = EMU_SO[:-3] + "_asan.so"
+            subprocess.check_call(["g++", "-O1", "-g", "-fsanitize=address", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=off", "-o", so,
+                                   os.path.join(EMU_DIR, "emu.cpp")])
+        elif (not os.path.exists(EMU_SO)) or any(os.path.getmtime(s) > os.path.getmtime(EMU_SO) for s in srcs):
             subprocess.check_call(["g++", "-O2", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=off", "-o", EMU_SO,
                                    os.path.join(EMU_DIR, "emu.cpp")])
-        _lib = C.CDLL(EMU_SO)
+        _lib = C.CDLL(so)
         _lib.emu_plan.argtypes = [C.POINTER(capi.MjpcHipModel), C.POINTER(capi.MjpcHipTask),
                                   C.POINTER(capi.MjpcHipPlanInput), C.POINTER(EmuOut)]
     return _lib

@@ -150,8 +150,10 @@ typedef struct MjpcHipModel {
   const int *tendon_adr, *tendon_num, *tendon_limited, *wrap_objid;
   const double *wrap_prm, *tendon_range, *tendon_margin, *tendon_solref_lim, *tendon_solimp_lim, *tendon_invweight0;
   /* passive tendon forces (mj_passive): spring with a dead band [lengthspring[2t], lengthspring[2t+1]], damper; [ntendon] each,
-   * NULL = none.  tendon_frictionloss > 0 is refused (no tendon friction rows). */
+   * NULL = none.  tendon_frictionloss > 0 makes a friction-loss row along the tendon (mjCNSTR_FRICTION_TENDON) with the solver
+   * parameters tendon_solref_fri [2 per tendon] / tendon_solimp_fri [5 per tendon] (NULL = MuJoCo's defaults). */
   const double *tendon_stiffness, *tendon_damping, *tendon_lengthspring, *tendon_frictionloss;
+  const double *tendon_solref_fri, *tendon_solimp_fri;
   /* convex meshes (collision = convex hull of the vertices, in the geom frame; mjModel.mesh_vert is float: widen it).  All NULL /
    * nmesh = 0: no meshes.  geom_dataid[g] = mesh of a MJPC_GEOM_MESH geom, -1 otherwise. */
   const int *geom_dataid, *mesh_vertadr, *mesh_vertnum;
@@ -249,7 +251,7 @@ typedef struct MjpcHipEngine MjpcHipEngine;
 /* Create an engine on HIP device `device`.  Copies model+task to HBM.  max_local = largest
  * num_local that will be planned on this device.  Returns NULL on error (see last_error).
  * Models the engine cannot roll out faithfully are REFUSED here (never silently approximated): geom pairs without a
- * collider (height field against plane / height field; meshes / height fields without data), group-0 geoms the quadruped task's ground ray cannot hit, tendon friction loss, actuator transmissions other than joint /
+ * collider (height field against plane / height field; meshes / height fields without data), group-0 geoms the quadruped task's ground ray cannot hit, actuator transmissions other than joint /
  * fixed tendon, nuserdata > 0, na > 0, nconmax > 64, nefcmax > 192, iterations > 250, num_spline_points capacity 36, LDS footprint > 160 KiB. */
 MjpcHipEngine *mjpc_hip_create(const MjpcHipModel *model, const MjpcHipTask *task,
                                int max_local, int max_horizon, int device);

@@ -118,7 +118,7 @@ static void FillModelView(const mjModel* m, MjpcHipModel& v, std::vector<int>& j
   v.tendon_margin = m->tendon_margin; v.tendon_solref_lim = m->tendon_solref_lim; v.tendon_solimp_lim = m->tendon_solimp_lim;
   v.tendon_invweight0 = m->tendon_invweight0;
   v.tendon_stiffness = m->tendon_stiffness; v.tendon_damping = m->tendon_damping; v.tendon_lengthspring = m->tendon_lengthspring;
-  v.tendon_frictionloss = m->tendon_frictionloss;
+  v.tendon_frictionloss = m->tendon_frictionloss; v.tendon_solref_fri = m->tendon_solref_fri; v.tendon_solimp_fri = m->tendon_solimp_fri;
   // convex meshes: mjModel.mesh_vert is float -> widened copy (mesh_vert_ member); hull = all vertices
   v.nmesh = m->nmesh; v.nmeshvert = m->nmeshvert; v.geom_dataid = m->geom_dataid; v.mesh_vertadr = m->mesh_vertadr; v.mesh_vertnum = m->mesh_vertnum;
   mesh_vert.assign(m->mesh_vert, m->mesh_vert + 3 * m->nmeshvert); v.mesh_vert = mesh_vert.data();

@@ -17,7 +17,7 @@ c_double_p = C.POINTER(C.c_double)
 c_int_p = C.POINTER(C.c_int)
 
 _MODEL_INT_SIZES = ["nq", "nv", "nu", "na", "nbody", "njnt", "ngeom", "nsite", "nmocap", "nuserdata", "nkey", "nexclude", "ntendon", "nwrap", "nmesh", "nmeshvert", "nhfield", "nhfielddata"]
-_OPTIONAL_TENDON = ("tendon_stiffness", "tendon_damping", "tendon_lengthspring", "tendon_frictionloss")
+_OPTIONAL_TENDON = ("tendon_stiffness", "tendon_damping", "tendon_lengthspring", "tendon_frictionloss", "tendon_solref_fri", "tendon_solimp_fri")
 _OPTION_DEFAULTS = dict(enableflags=0, solver=2, integrator=0, noslip_iterations=0, neq=0, unsupported=0)
 _OPTIONAL_MESH = ("nmesh", "nmeshvert", "geom_dataid", "mesh_vertadr", "mesh_vertnum", "mesh_vert", "nhfield", "nhfielddata", "hfield_nrow",
                   "hfield_ncol", "hfield_adr", "hfield_size", "hfield_data")
@@ -54,7 +54,7 @@ class MjpcHipModel(C.Structure):
         + [(n, c_int_p) for n in ["tendon_adr", "tendon_num", "tendon_limited", "wrap_objid"]]
         + [(n, c_double_p) for n in ["wrap_prm", "tendon_range", "tendon_margin", "tendon_solref_lim", "tendon_solimp_lim",
                                      "tendon_invweight0", "tendon_stiffness", "tendon_damping", "tendon_lengthspring",
-                                     "tendon_frictionloss"]]
+                                     "tendon_frictionloss", "tendon_solref_fri", "tendon_solimp_fri"]]
         + [(n, c_int_p) for n in ["geom_dataid", "mesh_vertadr", "mesh_vertnum"]] + [("mesh_vert", c_double_p)]
         + [(n, c_int_p) for n in ["hfield_nrow", "hfield_ncol", "hfield_adr"]] + [("hfield_size", c_double_p), ("hfield_data", c_double_p)]
         + [("key_qpos", c_double_p), ("key_mpos", c_double_p)]
@@ -113,7 +113,9 @@ class CModel:
             if name in _OPTION_DEFAULTS and name not in model:        # mjOption fields added later: MuJoCo's defaults
                 v = _OPTION_DEFAULTS[name]
             elif name in _OPTIONAL_TENDON and name not in model:       # models built before these fields existed: no passive tendon forces
-                v = np.zeros(int(model["ntendon"]) * (2 if name == "tendon_lengthspring" else 1))
+                nt = int(model["ntendon"])
+                v = (np.tile([0.02, 1.0], nt) if name == "tendon_solref_fri" else np.tile([0.9, 0.95, 0.001, 0.5, 2.0], nt) if name == "tendon_solimp_fri"
+                     else np.zeros(nt * (2 if name == "tendon_lengthspring" else 1)))
             elif name in _OPTIONAL_MESH and name not in model:        # ... no meshes
                 v = -np.ones(int(model["ngeom"])) if name == "geom_dataid" else (0 if name in ("nmesh", "nmeshvert", "nhfield", "nhfielddata") else np.zeros(0))
             else:

@@ -77,6 +77,20 @@ DEV void make_noncontact_rows(Ctx &c, int *nsingle_out, int *n_nc_out) {
     nefc += tot;
   }
   int nlim_end = nefc;
+  // tendon friction loss (mjCNSTR_FRICTION_TENDON): static general rows (MuJoCo lists them before the limits: same constraint set)
+  if (M.ntfric) {
+    if (nefc + M.ntfric > M.nefcmax) c.warning |= WARN_CNSTRFULL;
+    else {
+      PFOR(k, M.ntfric) {
+        int r = nefc + k, t = MI(tfric_id)[k];
+        c.efc_type[r] = CNSTR_FRICTION_TENDON; c.efc_id[r] = k; c.efc_dof[r] = 0;
+        c.efc_floss[r] = MD(tfric_prm)[8 * k]; c.efc_pos[r] = 0; c.efc_margin[r] = 0;
+        c.efc_diag[r] = MD(tendon_invweight0)[t];
+      }
+      nefc += M.ntfric;
+    }
+  }
+  int ntf_end = nefc;
   // ball-joint limits (mj_instantiateLimit): rotation angle of the joint quaternion against max(range), J = -axis at its three
   // dofs: general rows, kept behind the single-entry rows (MuJoCo interleaves them in joint order; same constraint set)
   for (int base = 0; base < M.nlimit_ball; base += NLANE) {
@@ -133,8 +147,12 @@ DEV void make_noncontact_rows(Ctx &c, int *nsingle_out, int *n_nc_out) {
     int r = M.nfric + rr;
     c.efc_J[r * nvp + MIH(jnt_dofadr)[c.efc_id[r]]] = c.efc_floss[r]; c.efc_floss[r] = 0;
   }
-  PFOR(rr, nball_end - nlim_end) {
-    int r = nlim_end + rr, j = c.efc_id[r], da = MIH(jnt_dofadr)[j];
+  PFOR(rr, ntf_end - nlim_end) {
+    int r = nlim_end + rr, t = MI(tfric_id)[c.efc_id[r]];
+    for (int w = MI(tendon_adr)[t]; w < MI(tendon_adr)[t] + MI(tendon_num)[t]; w++) c.efc_J[r * nvp + MI(wrap_dofadr)[w]] = MD(wrap_prm)[w];
+  }
+  PFOR(rr, nball_end - ntf_end) {
+    int r = ntf_end + rr, j = c.efc_id[r], da = MIH(jnt_dofadr)[j];
     double axis[3];
     ball_angle(axis, c.qpos + MIH(jnt_qposadr)[j]);
     for (int k = 0; k < 3; k++) c.efc_J[r * nvp + da + k] = -axis[k];
@@ -270,6 +288,9 @@ DEV void make_impedance(Ctx &c, int r0, int r1, int with_contacts) {
     if (type == CNSTR_FRICTION_DOF) {
       for (int k = 0; k < 2; k++) solref[k] = MD(dof_solref)[2 * id + k];
       for (int k = 0; k < 5; k++) solimp[k] = MD(dof_solimp)[5 * id + k];
+    } else if (type == CNSTR_FRICTION_TENDON) {
+      for (int k = 0; k < 2; k++) solref[k] = MD(tfric_prm)[8 * id + 1 + k];
+      for (int k = 0; k < 5; k++) solimp[k] = MD(tfric_prm)[8 * id + 3 + k];
     } else if (type == CNSTR_LIMIT_JOINT) {
       for (int k = 0; k < 2; k++) solref[k] = MDH(jnt_solref)[2 * id + k];
       for (int k = 0; k < 5; k++) solimp[k] = MDH(jnt_solimp)[5 * id + k];
@@ -293,7 +314,7 @@ DEV void make_impedance(Ctx &c, int r0, int r1, int with_contacts) {
       K = d_div(-solref[0], fmax(D_MINVAL, dmax * dmax));
       B = d_div(-solref[1], fmax(D_MINVAL, dmax));
     }
-    if (type == CNSTR_FRICTION_DOF || !first) K = 0;
+    if (type <= CNSTR_FRICTION_TENDON || !first) K = 0;
     c.efc_R[r] = fmax(D_MINVAL, d_div(1 - imp, imp) * c.efc_diag[r]);
     c.efc_aref[r] = -B * vel - K * imp * (c.efc_pos[r] - c.efc_margin[r]);
   }

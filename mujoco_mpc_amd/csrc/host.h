@@ -80,7 +80,7 @@ static inline void make_layout(const PackedModel &p, Lay &L, const MjpcHipModel 
   A_(qM, nv * nvp + 1); A_(qL, nv * nvp + 1); A_(qH, nv * nvp + 1); A_(Linv, nv + 1); A_(Hinv, nv + 1);
   // efc_JA holds the scaled rows of the Newton Hessian: the active contact rows (padded to 8) + one negative row per cone
   // contact (padded to 4)
-  int ja_rows = ((ne - M.nfric + 7) & ~7) + (m->cone == MJPC_CONE_ELLIPTIC ? ((nc + 3) & ~3) : 0) + 4;
+  int ja_rows = ((ne - M.nfric + 7) & ~7) + (m->cone == MJPC_CONE_ELLIPTIC ? ((nc + 3) & ~3) : 0) + 4 + ((M.ntfric + 3) & ~3);
   
   A_(efc_J, (ne - M.nfric) * nvp + 1);
   A_(efc_JA, ja_rows * nvp + 1);
@@ -104,7 +104,7 @@ static inline void make_layout(const PackedModel &p, Lay &L, const MjpcHipModel 
 #undef A_
   int io = 0;
   L.i_efc_type = io; io += ne; L.i_efc_id = io; io += ne; L.i_efc_state = io; io += ne; L.i_efc_dof = io; io += ne;
-  L.i_con = io; io += nc * CONI_STRIDE; L.i_active = io; io += (ne + nc > MAX_ACTIVE_PAIRS ? ne + nc : MAX_ACTIVE_PAIRS); L.i_misc = io; io += MISC_INTS;
+  L.i_con = io; io += nc * CONI_STRIDE; L.i_active = io; io += (ne + nc + M.ntfric > MAX_ACTIVE_PAIRS ? ne + nc + M.ntfric : MAX_ACTIVE_PAIRS); L.i_misc = io; io += MISC_INTS;
   L.i_hpair = io; if (!lean) io += M.nhpair + nv;      // LDS copy of the Hessian/gradient entry table (i | j << 8)
   L.total_doubles = o + (io + 1) / 2;
 }
@@ -131,8 +131,6 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
   if (m->nefcmax > 192) { p.error = "nefcmax > 192 not supported (line-search rows per lane)"; return false; }
   if (m->nconmax > 64) { p.error = "nconmax > 64 not supported (one contact per lane in the solver)"; return false; }
   if (m->iterations > 250) { p.error = "solver iterations > 250 not supported (hand-shake sequence numbers)"; return false; }
-  for (int t = 0; t < m->ntendon; t++)
-    if (m->tendon_frictionloss && m->tendon_frictionloss[t] > 0) { p.error = "tendon " + std::to_string(t) + ": tendon friction loss is not supported (no tendon friction rows)"; return false; }
   for (int i = 0; i < nu; i++)
     if (m->actuator_trntype[i] != MJPC_TRN_JOINT && m->actuator_trntype[i] != MJPC_TRN_TENDON) {
       p.error = "actuator " + std::to_string(i) + ": only joint and fixed-tendon transmissions are supported"; return false; }
@@ -337,8 +335,9 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
     M.limit_ball = as_off<int>(put_i(p, limb.data(), limb.size()));
     M.ray_geom = as_off<int>(put_i(p, ray.data(), ray.size())); }
   // a limited tendon whose joints do not lie on one branch of the elimination tree puts entries outside the Hessian's pattern
+  // (the same holds for the friction row of a tendon with friction loss)
   M.limit_cross = 0;
-  for (int t = 0; t < m->ntendon; t++) if (m->tendon_limited[t] && !no_limit)
+  for (int t = 0; t < m->ntendon; t++) if ((m->tendon_limited[t] && !no_limit) || (!no_fric && m->tendon_frictionloss && m->tendon_frictionloss[t] > 0))
     for (int w1 = m->tendon_adr[t]; w1 < m->tendon_adr[t] + m->tendon_num[t]; w1++)
       for (int w2 = m->tendon_adr[t]; w2 < w1; w2++) {
         int a = m->jnt_dofadr[m->wrap_objid[w1]], b = m->jnt_dofadr[m->wrap_objid[w2]];
@@ -347,6 +346,16 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
         for (int k = a; k >= 0; k = pattern_parent(nv, M.tree_ok, m->dof_parentid, k)) if (k == b) anc = true;
         if (!anc) M.limit_cross = 1;
       }
+  // tendons with friction loss: one friction row each (tendon id; frictionloss, solref[2], solimp[5])
+  { std::vector<int> ids; std::vector<double> prm;
+    static const double def_ref[2] = {0.02, 1.0}, def_imp[5] = {0.9, 0.95, 0.001, 0.5, 2.0};
+    for (int t = 0; t < m->ntendon; t++) if (!no_fric && m->tendon_frictionloss && m->tendon_frictionloss[t] > 0) {
+      ids.push_back(t); prm.push_back(m->tendon_frictionloss[t]);
+      for (int k = 0; k < 2; k++) prm.push_back(m->tendon_solref_fri ? m->tendon_solref_fri[2 * t + k] : def_ref[k]);
+      for (int k = 0; k < 5; k++) prm.push_back(m->tendon_solimp_fri ? m->tendon_solimp_fri[5 * t + k] : def_imp[k]);
+    }
+    M.ntfric = (int)ids.size();
+    M.tfric_id = as_off<int>(put_i(p, ids.data(), ids.size())); M.tfric_prm = as_off<double>(put_d(p, prm.data(), prm.size())); }
   // tendons with passive forces
   { std::vector<int> ids; std::vector<double> prm;
     for (int t = 0; t < m->ntendon; t++) {
@@ -359,7 +368,7 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
     M.tpass_id = as_off<int>(put_i(p, ids.data(), ids.size())); M.tpass_prm = as_off<double>(put_d(p, prm.data(), prm.size())); }
   M.any_damping = 0;
   for (int i = 0; i < nv; i++) if (m->dof_damping[i] > 0) M.any_damping = 1;
-  if (M.nefcmax < M.nfric + 2) M.nefcmax = M.nfric + 2;
+  if (M.nefcmax < M.nfric + M.ntfric + 2) M.nefcmax = M.nfric + M.ntfric + 2;
   // task region (re-packable by set_task)
   p.task_i0 = p.ib.size(); p.task_d0 = p.db.size();
   pack_task(p, t);
@@ -410,7 +419,7 @@ static inline DevModel relocate(const PackedModel &p, const int *ibase, const do
   fi(M.level_adr); fi(M.level_body); fi(M.subtree_adr); fi(M.subtree_list); fi(M.chain_adr); fi(M.chain_list); fi(M.mpair_i); fi(M.mpair_j); fi(M.hpair_i); fi(M.hpair_j); fi(M.zpair_i); fi(M.zpair_j);
   { const double *q = reinterpret_cast<const double *>(M.body_dofmask); fd(q); M.body_dofmask = reinterpret_cast<const unsigned long long *>(q); }
   { const double *q = reinterpret_cast<const double *>(M.body_patmask); fd(q); M.body_patmask = reinterpret_cast<const unsigned long long *>(q); }
-  fi(M.pair_g1); fi(M.pair_g2); fi(M.fric_dof); fi(M.limit_jnt); fi(M.limit_ball); fi(M.ray_geom); fi(M.tpass_id); fd(M.tpass_prm);
+  fi(M.pair_g1); fi(M.pair_g2); fi(M.fric_dof); fi(M.limit_jnt); fi(M.limit_ball); fi(M.ray_geom); fi(M.tpass_id); fd(M.tpass_prm); fi(M.tfric_id); fd(M.tfric_prm);
   DevTask &T = M.task;
   fi(T.dim_norm_residual); fi(T.norm); fi(T.num_norm_parameter); fi(T.trace_objtype); fi(T.trace_objid); fi(T.int_data);
   fd(T.weight); fd(T.norm_parameter); fd(T.parameters); fd(T.dbl_data);

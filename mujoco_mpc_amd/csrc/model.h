@@ -72,7 +72,7 @@ static inline int pattern_parent(int nv, int tree_ok, const int *dof_parentid, i
   return dof_parentid[k];
 }
 
-enum { CNSTR_FRICTION_DOF = 1, CNSTR_LIMIT_JOINT = 3, CNSTR_LIMIT_TENDON = 4, CNSTR_CONTACT_FRICTIONLESS = 5, CNSTR_CONTACT_PYRAMIDAL = 6, CNSTR_CONTACT_ELLIPTIC = 7 };
+enum { CNSTR_FRICTION_DOF = 1, CNSTR_FRICTION_TENDON = 2, CNSTR_LIMIT_JOINT = 3, CNSTR_LIMIT_TENDON = 4, CNSTR_CONTACT_FRICTIONLESS = 5, CNSTR_CONTACT_PYRAMIDAL = 6, CNSTR_CONTACT_ELLIPTIC = 7 };
 enum { STATE_SATISFIED = 0, STATE_QUADRATIC = 1, STATE_LINEARNEG = 2, STATE_LINEARPOS = 3, STATE_CONE = 4 };
 enum { WARN_BADQPOS = 1, WARN_BADQVEL = 2, WARN_BADQACC = 4, WARN_CONTACTFULL = 8, WARN_CNSTRFULL = 16, WARN_RAY = 32, WARN_SYNC = 64, WARN_UNSUPPORTED = 128 };
 
@@ -89,6 +89,7 @@ struct DevModel {
   int nlimit_ball;      // limited ball joints (limit_ball[])
   int limit_cross;      // some limited tendon couples dofs outside the Hessian's pattern: every build is a dense one
   int ntendon_passive;  // tendons with a spring or a damper (tpass_*)
+  int ntfric;           // tendons with friction loss (tfric_*): one static friction row each, behind the single-entry rows
   int cone, iterations, ls_iterations, disableflags, con_stride, maxdim, tree_ok, nact;
   double timestep, gravity[3], impratio, tolerance, ls_tolerance, meaninertia;
   const int *body_parentid, *body_rootid, *body_mocapid, *body_jntnum, *body_jntadr, *body_dofnum, *body_dofadr;
@@ -111,6 +112,8 @@ struct DevModel {
   const double *wrap_prm, *tendon_range, *tendon_margin, *tendon_solref_lim, *tendon_solimp_lim, *tendon_invweight0;
   const int *tpass_id;                      // tendons with passive forces
   const double *tpass_prm;                  // [4 each] stiffness, damping, spring dead band lo / hi
+  const int *tfric_id;                      // tendons with friction loss
+  const double *tfric_prm;                  // [8 each] frictionloss, solref[2], solimp[5]
   const double *key_qpos, *key_mpos;
   const int *geom_dataid, *mesh_vertadr, *mesh_vertnum;     // convex meshes: read from HBM / L2 (never in the LDS copy)
   const double *mesh_vert;

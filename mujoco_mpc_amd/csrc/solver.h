@@ -78,7 +78,7 @@ DEV double constraint_update(Ctx &c, int hess, const double *jar) {
     int type = rtype[k];
     int act = i < nefc && type != CNSTR_CONTACT_ELLIPTIC;
     double D = rD[k], x = rx[k];
-    int fric = type == CNSTR_FRICTION_DOF;
+    int fric = type <= CNSTR_FRICTION_TENDON;
     double f = fric ? rfl[k] : 0.0, Rf = rR[k] * f;
     double lo = fric ? -Rf : -1e300, hi = fric ? Rf : 0.0;
     double xc = fmin(fmax(x, lo), hi);
@@ -248,7 +248,10 @@ DEV void newton_lists(Ctx &c, int *npos_out, int *nneg_out) {
     int rc = rr < ncrow ? r : ns;
     int st = c.efc_state[rc], id = c.efc_id[rc];
     st = (rr < ncrow) ? st : STATE_SATISFIED;
-    int fpos = st != STATE_SATISFIED, fneg = st == STATE_CONE && EFC_CON_R0(id) == r;
+    // a tendon friction row in one of its linear zones has a force but no curvature: it goes on BOTH lists (H += D J J^T - D J J^T)
+    // and the gradient picks up J^T force from the phi column of the positive copy
+    int lin = st == STATE_LINEARNEG || st == STATE_LINEARPOS;
+    int fpos = st != STATE_SATISFIED, fneg = (st == STATE_CONE && EFC_CON_R0(id) == r) || lin;
     int tp, tn;
     int op = wave_flag_scan(fpos, &tp), on = wave_flag_scan(fneg, &tn);
     if (fpos) c.active[npos + op] = r;
@@ -280,7 +283,7 @@ DEV void newton_fill_d(Ctx &c, int npos, int nneg) {
     int r = valid ? (neg ? c.active[negbase + e - npos8] : c.active[e]) : c.nsingle;
     if (r >= c.nefc) r = c.nefc - 1;
     int st = c.efc_state[r], type = c.efc_type[r], id = c.efc_id[r];
-    double D = c.efc_D[r], jr = c.efc_jar[r];
+    double D = c.efc_D[r], frc = c.efc_force[r];
     int is_con = type >= CNSTR_CONTACT_FRICTIONLESS;
     int ci = is_con ? EFC_CON_CI(id) : 0, dim = is_con ? EFC_CON_DIM(id) : 1, r0 = is_con ? EFC_CON_R0(id) : r;
     const double *cf = c.contact + ci * M.con_stride + (M.con_stride > CON_H ? CON_H : 0);
@@ -289,7 +292,7 @@ DEV void newton_fill_d(Ctx &c, int npos, int nneg) {
     for (int b = 0; b < DIMT; b++) { cp[b] = cf[b]; cq[b] = cf[6 + b]; ct[b] = cf[12 + b]; }
     int cone = valid && st == STATE_CONE;
     int k = r - r0;
-    double sd = D * fast_rsqrt(D);
+    double rs = fast_rsqrt(D), sd = D * rs;
     double tk = 0;
 #pragma unroll
     for (int b = 1; b < DIMT; b++) tk = (k == b) ? ct[b] : tk;
@@ -302,7 +305,7 @@ DEV void newton_fill_d(Ctx &c, int npos, int nneg) {
       coef[b] = cb; rowb[b] = rb * nvp;
     }
     nb = caseP ? dim : (caseQ ? dim - 1 : (valid ? 1 : 0));
-    phi = caseD ? -sd * jr : (caseP ? ct[0] : 0.0);
+    phi = caseD ? frc * rs : (caseP ? ct[0] : 0.0);      // sqrt(D) J * phi = J^T force (force = -D jar on a quadratic row)
     if constexpr (NVT > 0) {
       constexpr int NC = C1 - C0;
       double acc[NC > 0 ? NC : 1];
@@ -570,7 +573,7 @@ DEV void ls_load(Ctx &c, LSData<DIMT> &d) {
       int type = c.efc_type[rc];
       double D = c.efc_D[rc], v = c.efc_jv[rc], x = c.efc_jar[rc], f = c.efc_floss[rc], Rf = c.efc_R[rc] * f;
       int quad = r < nefc && type != CNSTR_CONTACT_ELLIPTIC;
-      int fric = quad && type == CNSTR_FRICTION_DOF;
+      int fric = quad && type <= CNSTR_FRICTION_TENDON;
       D = quad ? D : 0.0; v = quad ? v : 0.0;
       d.X[k] = quad ? x : 0.0; d.V[k] = v; d.hD[k] = 0.5 * D; d.DV[k] = D * v; d.DVV[k] = D * v * v;
       d.lo[k] = fric ? -Rf : (quad ? -1e300 : -1.0); d.hi[k] = fric ? Rf : (quad ? 0.0 : 1.0); d.F[k] = fric ? f : 0.0;

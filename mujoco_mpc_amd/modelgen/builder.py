@@ -212,12 +212,13 @@ class ModelBuilder:
                       ctrlrange=ctrlrange, forcelimited=forcerange is not None, forcerange=forcerange or (0, 0))
 
     def tendon(self, name, joints, coefs, limited=False, range=(0, 0), margin=0.0, solreflimit=DEF_SOLREF, solimplimit=DEF_SOLIMP,
-               stiffness=0.0, damping=0.0, springlength=None, frictionloss=0.0):
+               stiffness=0.0, damping=0.0, springlength=None, frictionloss=0.0,
+               solreffriction=DEF_SOLREF, solimpfriction=DEF_SOLIMP):
         """fixed tendon: length = sum coef * qpos[joint]; passive spring (dead band `springlength` = value or (lo, hi); None = the
-        length at qpos0, MJCF's springlength="-1") and damper"""
+        length at qpos0, MJCF's springlength="-1"), damper and friction loss (one friction row along the tendon)"""
         self.tendons.append(dict(name=name, joints=list(joints), coefs=list(coefs), limited=limited, range=tuple(range), margin=margin,
                                  solref=tuple(solreflimit), solimp=tuple(solimplimit), stiffness=float(stiffness), damping=float(damping),
-                                 springlength=springlength, frictionloss=float(frictionloss)))
+                                 springlength=springlength, frictionloss=float(frictionloss), solref_fri=tuple(solreffriction), solimp_fri=tuple(solimpfriction)))
 
     def key(self, name, qpos):
         self.keys.append((name, np.array(qpos, float)))
@@ -482,6 +483,8 @@ class ModelBuilder:
         M["tendon_stiffness"] = np.array([t.get("stiffness", 0.0) for t in T], float)
         M["tendon_damping"] = np.array([t.get("damping", 0.0) for t in T], float)
         M["tendon_frictionloss"] = np.array([t.get("frictionloss", 0.0) for t in T], float)
+        M["tendon_solref_fri"] = np.array([t.get("solref_fri", DEF_SOLREF) for t in T], float).reshape(len(T), 2)
+        M["tendon_solimp_fri"] = np.array([t.get("solimp_fri", DEF_SOLIMP) for t in T], float).reshape(len(T), 5)
         ls = np.zeros((len(T), 2))
         for ti, t in enumerate(T):
             sl = t.get("springlength")

@@ -242,6 +242,10 @@ def parse_mjcf(path_or_text, base_dir=None, reader=None, missing_ok=()):
                 kw["solreflimit"] = tuple(_floats(a["solreflimit"]))
             if "solimplimit" in a:
                 v = _floats(a["solimplimit"]); kw["solimplimit"] = tuple(v + [0.9, 0.95, 0.001, 0.5, 2][len(v):])
+            if "solreffriction" in a:
+                kw["solreffriction"] = tuple(_floats(a["solreffriction"]))
+            if "solimpfriction" in a:
+                v = _floats(a["solimpfriction"]); kw["solimpfriction"] = tuple(v + [0.9, 0.95, 0.001, 0.5, 2][len(v):])
             for k in ("stiffness", "damping", "frictionloss", "margin"):
                 if k in a:
                     kw[k] = float(a[k])

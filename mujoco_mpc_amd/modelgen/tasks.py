@@ -580,10 +580,11 @@ def acrobot(timestep=0.01):
 
 
 # ----------------------------------------------------------------------------------- a7 features off the BASELINE models
-def ball_chain(timestep=0.005):
+def ball_chain(timestep=0.005, tendon_frictionloss=0.0):
     """Small test model for the mj_step features no BASELINE model has: limited ball joints and a fixed tendon with a spring, a
     damper and a limit that couples joints on DIFFERENT branches (its limit row lies outside M's sparsity pattern).  The residual
-    copies the state (TASK_COPYSTATE)."""
+    copies the state (TASK_COPYSTATE).  tendon_frictionloss > 0: that tendon also has friction loss, and a second, single-joint tendon
+    (inside the pattern) has half of it."""
     b = ModelBuilder(timestep=timestep, gravity=(0, 0, -9.81), contact=True)
     b.geom(0, "floor", PLANE, pos=(0, 0, -1.2), size=(2, 2, 0.1))
     l1 = b.body("l1", 0, pos=(0, 0, 0))
@@ -599,7 +600,10 @@ def ball_chain(timestep=0.005):
         b.geom(a, name + "_g", CAPSULE, size=(0.02, 0), fromto=(0, 0, 0, 0, 1.5 * y, -0.2), mass=0.2)
         arms.append(name + "_j")
     tip = b.site(l2, "tip", pos=(0, 0, -0.35))
-    b.tendon("couple", arms, [1.0, 1.0], limited=True, range=(-0.4, 0.4), stiffness=4.0, damping=0.1, springlength=(-0.05, 0.05))
+    b.tendon("couple", arms, [1.0, 1.0], limited=True, range=(-0.4, 0.4), stiffness=4.0, damping=0.1, springlength=(-0.05, 0.05),
+             frictionloss=tendon_frictionloss)
+    if tendon_frictionloss > 0:
+        b.tendon("ra_drag", arms[:1], [1.5], frictionloss=0.5 * tendon_frictionloss, solreffriction=(0.03, 1.0))
     b.actuator("ra_m", "ra_j", gear=1.0, ctrlrange=(-1, 1))
     b.actuator("la_m", "la_j", gear=1.0, ctrlrange=(-1, 1))
     m = b.compile()

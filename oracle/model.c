@@ -64,6 +64,8 @@ OModel *oracle_create(const MjpcHipModel *src, const MjpcHipTask *task) {
   if (src->tendon_damping) CD(tendon_damping, src->ntendon);
   if (src->tendon_lengthspring) CD(tendon_lengthspring, 2 * src->ntendon);
   if (src->tendon_frictionloss) CD(tendon_frictionloss, src->ntendon);
+  if (src->tendon_solref_fri) CD(tendon_solref_fri, 2 * src->ntendon);
+  if (src->tendon_solimp_fri) CD(tendon_solimp_fri, 5 * src->ntendon);
   if (src->geom_dataid) CI(geom_dataid, ng);
   if (src->nmesh > 0) { CI(mesh_vertadr, src->nmesh); CI(mesh_vertnum, src->nmesh); CD(mesh_vert, 3 * src->nmeshvert); }
   if (src->nhfield > 0) { CI(hfield_nrow, src->nhfield); CI(hfield_ncol, src->nhfield); CI(hfield_adr, src->nhfield); CD(hfield_size, 4 * src->nhfield); CD(hfield_data, src->nhfielddata); }

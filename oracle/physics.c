@@ -401,6 +401,18 @@ static void make_constraint(const OModel *om, OData *d) {
     d->efc_diagApprox[r] = m->dof_invweight0[i];
     d->nf++;
   }
+  /* tendon friction loss (mjCNSTR_FRICTION_TENDON): one friction row along the tendon, J = the tendon's coefficients */
+  for (int t = 0; t < m->ntendon; t++) if (!no_fric && m->tendon_frictionloss && m->tendon_frictionloss[t] > 0) {
+    static const double def_ref[2] = {0.02, 1.0}, def_imp[5] = {0.9, 0.95, 0.001, 0.5, 2.0};
+    int r = add_row(om, d, O_CNSTR_FRICTION_TENDON, t); if (r < 0) return;
+    for (int w = m->tendon_adr[t]; w < m->tendon_adr[t] + m->tendon_num[t]; w++)
+      d->efc_J[r * nv + m->jnt_dofadr[m->wrap_objid[w]]] = m->wrap_prm[w];
+    d->efc_frictionloss[r] = m->tendon_frictionloss[t];
+    o_copy(d->efc_solref + 2 * r, m->tendon_solref_fri ? m->tendon_solref_fri + 2 * t : def_ref, 2);
+    o_copy(d->efc_solimp + 5 * r, m->tendon_solimp_fri ? m->tendon_solimp_fri + 5 * t : def_imp, 5);
+    d->efc_diagApprox[r] = m->tendon_invweight0[t];
+    d->nf++;
+  }
   /* joint limits */
   for (int j = 0; j < m->njnt; j++) if (!no_limit && m->jnt_limited[j] &&
       (m->jnt_type[j] == MJPC_JNT_SLIDE || m->jnt_type[j] == MJPC_JNT_HINGE)) {
@@ -523,7 +535,7 @@ static void make_impedance(const OModel *om, OData *d) {
     }
     for (int k = 0; k < dim; k++) {
       int q = r + k;
-      int friction_row = (d->efc_type[q] == O_CNSTR_FRICTION_DOF) || (k > 0 && !pyramidal);
+      int friction_row = (d->efc_type[q] <= O_CNSTR_FRICTION_TENDON) || (k > 0 && !pyramidal);
       double Kq = friction_row ? 0 : K;
       d->efc_KBIP[4 * q] = Kq; d->efc_KBIP[4 * q + 1] = B; d->efc_KBIP[4 * q + 2] = imp; d->efc_KBIP[4 * q + 3] = 0;
       d->efc_R[q] = fmax(O_MINVAL, (1 - imp) / imp * d->efc_diagApprox[q]);
@@ -687,7 +699,7 @@ static double constraint_update(const OModel *om, OData *d, const double *jar, d
   for (int i = 0; i < d->nefc; i++) {
     double D = d->efc_D[i], R = d->efc_R[i], x = jar[i];
     int type = d->efc_type[i];
-    if (type == O_CNSTR_FRICTION_DOF) {
+    if (type <= O_CNSTR_FRICTION_TENDON) {
       double f = d->efc_frictionloss[i];
       if (x <= -R * f) { cost += -0.5 * R * f * f - f * x; force[i] = f; state[i] = O_STATE_LINEARNEG; }
       else if (x >= R * f) { cost += -0.5 * R * f * f + f * x; force[i] = -f; state[i] = O_STATE_LINEARPOS; }
@@ -745,7 +757,7 @@ static LSPoint ls_eval(const OModel *om, const OData *d, const double *jar, cons
   for (int i = 0; i < d->nefc; i++) {
     double D = d->efc_D[i], R = d->efc_R[i], x = jar[i] + a * jv[i], v = jv[i];
     int type = d->efc_type[i];
-    if (type == O_CNSTR_FRICTION_DOF) {
+    if (type <= O_CNSTR_FRICTION_TENDON) {
       double f = d->efc_frictionloss[i];
       if (x <= -R * f) { p.cost += -0.5 * R * f * f - f * x; p.d1 += -f * v; }
       else if (x >= R * f) { p.cost += -0.5 * R * f * f + f * x; p.d1 += f * v; }

@@ -1,6 +1,6 @@
 """Random articulated models for the fuzz parity tests (test infrastructure): random trees of bodies on free / ball / hinge /
 slide joints with limits, damping, armature, friction loss and springs, one or two primitive geoms of every supported type per
-body, motors and position servos, fixed tendons with limits / springs / dampers (also across branches), either friction cone,
+body, motors and position servos, fixed tendons with limits / springs / dampers / friction loss (also across branches), either friction cone,
 contact dimensions 1 / 3 / 4 / 6.  The residual copies the state."""
 import numpy as np
 
@@ -18,6 +18,7 @@ def random_model(seed, portal_pairs=False):
     floor, loose objects are spheres, capsules and boxes); True: loose objects of every type against everything (cylinder /
     ellipsoid pairs go through the portal-refinement collider, whose contact normals are sensitive to rounding at the 1e-4 level)."""
     rng = np.random.default_rng(seed)
+    rng_fr = np.random.default_rng([seed, 1])      # tendon friction loss came later: its own stream keeps the earlier models' other draws
     cone = int(rng.integers(0, 2))
     b = ModelBuilder(timestep=float(rng.choice([0.002, 0.004, 0.005])), cone=cone, impratio=float(rng.choice([1.0, 3.0])) if cone else 1.0,
                      contact=True)
@@ -88,7 +89,8 @@ def random_model(seed, portal_pairs=False):
             js = list(rng.choice(scalar_joints, size=2, replace=False))
             b.tendon(f"t{k}", js, [float(rng.uniform(0.5, 1.5)), -float(rng.uniform(0.5, 1.5))], limited=bool(rng.random() < 0.7),
                      range=(-float(rng.uniform(0.1, 0.4)), float(rng.uniform(0.1, 0.4))), stiffness=float(rng.choice([0.0, 3.0])),
-                     damping=float(rng.choice([0.0, 0.2])), springlength=None if rng.random() < 0.5 else (-0.05, 0.05))
+                     damping=float(rng.choice([0.0, 0.2])), springlength=None if rng.random() < 0.5 else (-0.05, 0.05),
+                     frictionloss=float(rng_fr.choice([0.0, 0.0, 0.1, 0.5])))
             if rng.random() < 0.3:
                 b.position(f"pt{k}", tendon=f"t{k}", kp=4.0, ctrlrange=(-0.3, 0.3))
     if not b.actuators:

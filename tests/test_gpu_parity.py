@@ -78,6 +78,15 @@ def test_limited_ball_joints_and_tendon_spring_damper_cross_branch_limit():
     assert allc["diag"][:, 2].max() >= 2 and not out["failure"].any()        # limit rows were active
 
 
+def test_tendon_friction_loss_rows():
+    """mjCNSTR_FRICTION_TENDON: friction rows along a cross-branch tendon and a one-joint tendon (saturated zones contribute to the
+    gradient only, the quadratic zone to the Hessian as well)."""
+    from mujoco_mpc_amd.modelgen import ball_chain
+    m, task, d = ball_chain(tendon_frictionloss=0.3)
+    out, ref, allc = _compare(m, task, d, 4, 80, 12, (0.4, 0.0), 2, 1e-5)
+    assert not out["failure"].any()
+
+
 def test_convex_pairs_through_the_portal_refinement_collider():
     """cylinder-box and cylinder-cylinder (MuJoCo: mjc_Convex / libccd MPR): a cylinder standing on a box with a second one lying
     across it, pushed sideways by a motor; same contacts, same trajectories as the oracle."""

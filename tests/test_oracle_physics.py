@@ -510,6 +510,33 @@ def test_tendon_spring_and_damper_closed_form():
     assert np.allclose(m2["tendon_lengthspring"], 0.0)
 
 
+def test_tendon_friction_loss_row():
+    """mjCNSTR_FRICTION_TENDON: a friction row along the tendon.  (i) far from rest the row saturates: joint torque = coef *
+    frictionloss against the motion; (ii) a one-joint tendon with coefficient c and friction loss f is the same constraint as a
+    joint friction loss c * f (R scales with c^2 through tendon_invweight0, the zone edges with c)."""
+    def pend(tendon_f, dof_f):
+        b = ModelBuilder(timestep=0.002, gravity=(0, 0, 0))
+        l1 = b.body("l1", 0)
+        b.joint(l1, "h", HINGE, axis=(0, 1, 0), frictionloss=dof_f)
+        b.geom(l1, "g", SPHERE, size=(0.1,), pos=(0, 0, -0.5), mass=2.0)
+        b.tendon("t", ["h"], [1.5], frictionloss=tendon_f)
+        return b.compile()
+    mt, md = pend(0.4, 0.0), pend(0.0, 0.6)
+    ot, od = ol.Oracle(mt, _copy_task(mt)), ol.Oracle(md, _copy_task(md))
+    inertia = 2.0 * (0.5 ** 2 + 0.4 * 0.1 ** 2)
+    for v in (3.0, -2.0):
+        r = ot.forward([0.2], [v])
+        assert r["qacc"][0] == pytest.approx(-np.sign(v) * 1.5 * 0.4 / inertia, rel=1e-9)
+    for v in (3.0, 0.5, 1e-3, 0.0, -2e-4, -1.0):      # saturated and quadratic zones
+        assert ot.forward([0.2], [v])["qacc"][0] == pytest.approx(od.forward([0.2], [v])["qacc"][0], rel=1e-9, abs=1e-12)
+    # a rollout: the pendulum under gravity comes to rest where the tendon friction holds it
+    mt["gravity"] = np.array([0, 0, -9.81]); md["gravity"] = np.array([0, 0, -9.81])
+    ot, od = ol.Oracle(mt, _copy_task(mt)), ol.Oracle(md, _copy_task(md))
+    (qt, vt, *_), (qd, vd, *_) = ot.step([0.8], [0.0], nstep=3000), od.step([0.8], [0.0], nstep=3000)
+    assert qt[0] == pytest.approx(qd[0], rel=1e-7) and vt[0] == pytest.approx(vd[0], abs=1e-9)
+    assert abs(vt[0]) < 5e-3 and 0 < abs(np.sin(qt[0])) <= 0.6 / (2.0 * 9.81 * 0.5) * 1.05      # held (soft constraint: slow creep) inside the static band
+
+
 def test_portal_refinement_collider_against_closed_forms():
     """Convex pairs without an analytic collider (cylinder-cylinder, cylinder-box; MuJoCo: libccd MPR) go through the portal
     refinement collider of oracle/collide.c.  Type 100 + t sends any supported primitive through it: spheres must reproduce the

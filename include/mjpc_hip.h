@@ -34,10 +34,11 @@ enum {
 enum { MJPC_CONE_PYRAMIDAL = 0, MJPC_CONE_ELLIPTIC = 1 };
 enum { MJPC_SOL_NEWTON = 2, MJPC_INT_EULER = 0 };
 /* model features outside this view (MjpcHipModel.unsupported) */
+enum { MJPC_DYN_NONE = 0, MJPC_DYN_INTEGRATOR = 1, MJPC_DYN_FILTER = 2, MJPC_DYN_FILTEREXACT = 3 };   /* mjtDyn */
 enum { MJPC_UNSUP_FLUID = 1,          /* opt.density / viscosity / wind non-zero */
        MJPC_UNSUP_GRAVCOMP = 2,       /* body_gravcomp */
        MJPC_UNSUP_ACTUATOR_GAIN = 4,  /* gaintype other than fixed, biastype other than none / affine */
-       MJPC_UNSUP_ACTUATOR_DYN = 8,   /* dyntype other than none, actuator activation limits */
+       MJPC_UNSUP_ACTUATOR_DYN = 8,   /* dyntype muscle / user, actnum != 1, actearly */
        MJPC_UNSUP_SPATIAL_TENDON = 16,/* wrap objects other than joints */
        MJPC_UNSUP_JNT_ACTFRC = 32,    /* jnt_actfrclimited */
        MJPC_UNSUP_FLEX_SKIN_PLUGIN = 64 /* flexes, plugins, user callbacks other than the residual */ };
@@ -146,6 +147,13 @@ typedef struct MjpcHipModel {
   const double *actuator_biasprm;   /* 3 per actuator (first 3 of mjNBIAS) */
   const double *actuator_gear;      /* 1 per actuator (first of 6) */
   const double *actuator_ctrlrange, *actuator_forcerange;
+  /* activation states (na > 0): one state per stateful actuator (actnum 1).  dyntype MJPC_DYN_*: integrator act_dot = ctrl; filter /
+   * filterexact act_dot = (ctrl - act) / max(mjMINVAL, dynprm[0]); the force of a stateful actuator is gain * act + bias.  Euler
+   * advance act += h * act_dot (filterexact: act_dot * tau * (1 - exp(-h / tau))), clamped to actrange when actlimited.  All NULL
+   * (na = 0): no stateful actuator.  Muscles, user dynamics and actearly are MJPC_UNSUP_ACTUATOR_DYN. */
+  const int *actuator_dyntype, *actuator_actadr, *actuator_actlimited;
+  const double *actuator_dynprm;    /* 1 per actuator (first of mjNDYN): the time constant */
+  const double *actuator_actrange;  /* 2 per actuator */
   /* fixed tendons (wrap objects are joints; wrap_prm = coefficient) */
   const int *tendon_adr, *tendon_num, *tendon_limited, *wrap_objid;
   const double *wrap_prm, *tendon_range, *tendon_margin, *tendon_solref_lim, *tendon_solimp_lim, *tendon_invweight0;
@@ -252,7 +260,7 @@ typedef struct MjpcHipEngine MjpcHipEngine;
  * num_local that will be planned on this device.  Returns NULL on error (see last_error).
  * Models the engine cannot roll out faithfully are REFUSED here (never silently approximated): geom pairs without a
  * collider (height field against plane / height field; meshes / height fields without data), group-0 geoms the quadruped task's ground ray cannot hit, actuator transmissions other than joint /
- * fixed tendon, nuserdata > 0, na > 0, nconmax > 64, nefcmax > 192, iterations > 250, num_spline_points capacity 36, LDS footprint > 160 KiB. */
+ * fixed tendon, nuserdata > 0, nconmax > 64, nefcmax > 192, iterations > 250, num_spline_points capacity 36, LDS footprint > 160 KiB. */
 MjpcHipEngine *mjpc_hip_create(const MjpcHipModel *model, const MjpcHipTask *task,
                                int max_local, int max_horizon, int device);
 void mjpc_hip_destroy(MjpcHipEngine *e);

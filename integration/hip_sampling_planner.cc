@@ -51,7 +51,7 @@ static void FillModelView(const mjModel* m, MjpcHipModel& v, std::vector<int>& j
                           std::vector<int>& trnid, std::vector<int>& tendon_limited, std::vector<int>& wrap_objid,
                           std::vector<double>& gainprm, std::vector<double>& biasprm, std::vector<double>& gear,
                           std::vector<double>& wrap_prm, std::vector<double>& mesh_vert, std::vector<double>& hfield_size,
-                          std::vector<double>& hfield_data) {
+                          std::vector<double>& hfield_data, std::vector<int>& act_i, std::vector<double>& dynprm) {
   std::memset(&v, 0, sizeof(v));
   v.nq = m->nq; v.nv = m->nv; v.nu = m->nu; v.na = m->na; v.nbody = m->nbody; v.njnt = m->njnt; v.ngeom = m->ngeom;
   v.nsite = m->nsite; v.nmocap = m->nmocap; v.nuserdata = m->nuserdata; v.nkey = m->nkey; v.nexclude = m->nexclude;
@@ -67,7 +67,10 @@ static void FillModelView(const mjModel* m, MjpcHipModel& v, std::vector<int>& j
   for (int b = 0; b < m->nbody; b++) if (m->body_gravcomp[b] != 0) v.unsupported |= MJPC_UNSUP_GRAVCOMP;
   for (int i = 0; i < m->nu; i++) {
     if (m->actuator_gaintype[i] != mjGAIN_FIXED || (m->actuator_biastype[i] != mjBIAS_NONE && m->actuator_biastype[i] != mjBIAS_AFFINE)) v.unsupported |= MJPC_UNSUP_ACTUATOR_GAIN;
-    if (m->actuator_dyntype[i] != mjDYN_NONE || m->actuator_actlimited[i]) v.unsupported |= MJPC_UNSUP_ACTUATOR_DYN;
+    // stateful actuators: integrator / filter / filterexact with one activation each travel in the view (actuator_dyntype ...)
+    int dyn = m->actuator_dyntype[i];
+    if (!(dyn == mjDYN_NONE || dyn == mjDYN_INTEGRATOR || dyn == mjDYN_FILTER || dyn == mjDYN_FILTEREXACT) ||
+        (dyn != mjDYN_NONE && m->actuator_actnum[i] != 1) || m->actuator_actearly[i]) v.unsupported |= MJPC_UNSUP_ACTUATOR_DYN;
   }
   for (int w = 0; w < m->nwrap; w++) if (m->wrap_type[w] != mjWRAP_JOINT) v.unsupported |= MJPC_UNSUP_SPATIAL_TENDON;
   for (int j = 0; j < m->njnt; j++) if (m->jnt_actfrclimited[j]) v.unsupported |= MJPC_UNSUP_JNT_ACTFRC;
@@ -110,6 +113,13 @@ static void FillModelView(const mjModel* m, MjpcHipModel& v, std::vector<int>& j
   v.actuator_ctrllimited = ctrllimited.data(); v.actuator_forcelimited = forcelimited.data(); v.actuator_biastype = biastype.data();
   v.actuator_gainprm = gainprm.data(); v.actuator_biasprm = biasprm.data(); v.actuator_gear = gear.data();
   v.actuator_ctrlrange = m->actuator_ctrlrange; v.actuator_forcerange = m->actuator_forcerange;
+  act_i.assign(3 * m->nu, 0); dynprm.assign(m->nu, 0.0);
+  for (int i = 0; i < m->nu; i++) {
+    act_i[i] = m->actuator_dyntype[i]; act_i[m->nu + i] = m->actuator_actadr[i]; act_i[2 * m->nu + i] = m->actuator_actlimited[i];
+    dynprm[i] = m->actuator_dynprm[mjNDYN * i];
+  }
+  v.actuator_dyntype = act_i.data(); v.actuator_actadr = act_i.data() + m->nu; v.actuator_actlimited = act_i.data() + 2 * m->nu;
+  v.actuator_dynprm = dynprm.data(); v.actuator_actrange = m->actuator_actrange;
   // fixed tendons: wrap objects are joints, wrap_prm the coefficient (spatial tendons are refused by mjpc_hip_create)
   tendon_limited = Widen(m->tendon_limited, m->ntendon);
   wrap_objid.assign(m->wrap_objid, m->wrap_objid + m->nwrap); wrap_prm.assign(m->wrap_prm, m->wrap_prm + m->nwrap);
@@ -175,7 +185,7 @@ void HipSamplingPlanner::Initialize(mjModel* model, const Task& task) {
   sliding_plan_ = n.sampling_sliding_plan;
   if (num_trajectory_ > kMaxTrajectoryHip) mju_error_i("Too many trajectories, %d is the maximum allowed.", kMaxTrajectoryHip);
   FillModelView(model, model_view_, jnt_limited_, ctrllimited_, forcelimited_, biastype_, trntype_, trnid_, tendon_limited_,
-                wrap_objid_, gainprm_, biasprm_, gear_, wrap_prm_, mesh_vert_, hfield_size_, hfield_data_);
+                wrap_objid_, gainprm_, biasprm_, gear_, wrap_prm_, mesh_vert_, hfield_size_, hfield_data_, act_i_, dynprm_);
   FillTaskView(task, model, task_view_, norm_, trace_type_, trace_id_, task_int_, task_dbl_);
   mjpc_hip::SetErrorHandler([](const char* msg) { mju_error("HipSamplingPlanner: %s", msg); });
   impl_.Initialize(&model_view_, &task_view_, n);           // creates the engines (model may have changed: old ones dropped)

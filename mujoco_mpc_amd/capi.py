@@ -18,6 +18,7 @@ c_int_p = C.POINTER(C.c_int)
 
 _MODEL_INT_SIZES = ["nq", "nv", "nu", "na", "nbody", "njnt", "ngeom", "nsite", "nmocap", "nuserdata", "nkey", "nexclude", "ntendon", "nwrap", "nmesh", "nmeshvert", "nhfield", "nhfielddata"]
 _OPTIONAL_TENDON = ("tendon_stiffness", "tendon_damping", "tendon_lengthspring", "tendon_frictionloss", "tendon_solref_fri", "tendon_solimp_fri")
+_OPTIONAL_ACT = ("actuator_dyntype", "actuator_actadr", "actuator_actlimited", "actuator_dynprm", "actuator_actrange")
 _OPTION_DEFAULTS = dict(enableflags=0, solver=2, integrator=0, noslip_iterations=0, neq=0, unsupported=0)
 _OPTIONAL_MESH = ("nmesh", "nmeshvert", "geom_dataid", "mesh_vertadr", "mesh_vertnum", "mesh_vert", "nhfield", "nhfielddata", "hfield_nrow",
                   "hfield_ncol", "hfield_adr", "hfield_size", "hfield_data")
@@ -51,6 +52,8 @@ class MjpcHipModel(C.Structure):
         + [(n, c_int_p) for n in ["actuator_trntype", "actuator_trnid", "actuator_ctrllimited", "actuator_forcelimited", "actuator_biastype"]]
         + [(n, c_double_p) for n in ["actuator_gainprm", "actuator_biasprm", "actuator_gear", "actuator_ctrlrange",
                                      "actuator_forcerange"]]
+        + [(n, c_int_p) for n in ["actuator_dyntype", "actuator_actadr", "actuator_actlimited"]]
+        + [(n, c_double_p) for n in ["actuator_dynprm", "actuator_actrange"]]
         + [(n, c_int_p) for n in ["tendon_adr", "tendon_num", "tendon_limited", "wrap_objid"]]
         + [(n, c_double_p) for n in ["wrap_prm", "tendon_range", "tendon_margin", "tendon_solref_lim", "tendon_solimp_lim",
                                      "tendon_invweight0", "tendon_stiffness", "tendon_damping", "tendon_lengthspring",
@@ -116,6 +119,9 @@ class CModel:
                 nt = int(model["ntendon"])
                 v = (np.tile([0.02, 1.0], nt) if name == "tendon_solref_fri" else np.tile([0.9, 0.95, 0.001, 0.5, 2.0], nt) if name == "tendon_solimp_fri"
                      else np.zeros(nt * (2 if name == "tendon_lengthspring" else 1)))
+            elif name in _OPTIONAL_ACT and name not in model:           # models built before activation states existed: none
+                nu_ = int(model["nu"])
+                v = -np.ones(nu_) if name == "actuator_actadr" else np.zeros(nu_ * (2 if name == "actuator_actrange" else 1))
             elif name in _OPTIONAL_MESH and name not in model:        # ... no meshes
                 v = -np.ones(int(model["ngeom"])) if name == "geom_dataid" else (0 if name in ("nmesh", "nmeshvert", "nhfield", "nhfielddata") else np.zeros(0))
             else:

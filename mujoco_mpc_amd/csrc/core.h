@@ -59,6 +59,10 @@ DEV int uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
 #define PROFW(c, i) ((void)0)
 #endif
 
+// activation states and their derivatives live behind ctrl in LDS (host.h make_layout)
+#define C_ACT(c) ((c).ctrl + (c).M->nu + 1)
+#define C_ACTDOT(c) ((c).ctrl + (c).M->nu + 1 + (c).M->na)
+
 struct Ctx {
 #if defined(MJPC_PROFILE) && !defined(MJPC_EMU)
   long long *prof;
@@ -213,7 +217,7 @@ DEV Rows out_rows(const KParams *K) {
   const DevModel &M = K->M;
   Rows R;
   size_t r = (size_t)cand_index(), H = (size_t)K->H;
-  R.ds = M.nq + M.nv; R.nr = M.task.num_residual; R.ntr = 3 * M.task.num_trace;
+  R.ds = M.nq + M.nv + M.na; R.nr = M.task.num_residual; R.ntr = 3 * M.task.num_trace;
   R.states = K->states + r * H * R.ds; R.actions = K->actions + r * H * M.nu; R.times = K->times + r * H;
   R.residual = K->residual + r * H * R.nr; R.costs = K->costs + r * H; R.trace = K->trace + r * H * R.ntr;
   return R;
@@ -259,6 +263,7 @@ DEV_NOINLINE void ph_init(KP Kc) {
   }
   PFOR(i, nq) { c.qpos[i] = K->state[i]; R.states[i] = K->state[i]; }
   PFOR(i, nv) { c.qvel[i] = K->state[nq + i]; R.states[nq + i] = K->state[nq + i]; c.qacc_ws[i] = 0; }
+  if (M.na) PFOR(i, M.na) { C_ACT(c)[i] = K->state[nq + nv + i]; R.states[nq + nv + i] = K->state[nq + nv + i]; C_ACTDOT(c)[i] = 0; }
   PFOR(e, nv * M.nvp) { c.qM[e] = 0; c.qH[e] = 0; }
 #ifndef MJPC_LEAN_LDS
   PFOR(e, M.nhpair + nv) c.hpair[e] = MI(hpair_i)[e] | (MI(hpair_j)[e] << 8);
@@ -494,6 +499,20 @@ DEV_NOINLINE void ph_integrate(KP Kc, int t) {
       d_quatintegrate(c.qpos + qa, c.qvel + da, h);
     } else c.qpos[qa] += h * c.qvel[da];
   }
+  if (M.na) {       // mj_advance / mj_nextActivation: act += h act_dot (filterexact: exact decay over h), clamped to actrange
+    PFOR(i, M.nu) {
+      int dt = MI(actuator_dyntype)[i];
+      if (dt) {
+        int a = MI(actuator_actadr)[i];
+        double act = C_ACT(c)[a], ad = C_ACTDOT(c)[a];
+        if (dt == DYN_FILTEREXACT) { double tau = fmax(D_MINVAL, MD(actuator_dynprm)[i]); act += ad * tau * (1 - exp(-h / tau)); }
+        else act += h * ad;
+        if (MI(actuator_actlimited)[i]) act = d_clip(act, MD(actuator_actrange)[2 * i], MD(actuator_actrange)[2 * i + 1]);
+        C_ACT(c)[a] = act;
+        R.states[(t + 1) * R.ds + nq + nv + a] = act;
+      }
+    }
+  }
   c.time += h;
   SYNC();
   PFOR(i, nq) R.states[(t + 1) * R.ds + i] = c.qpos[i];
@@ -504,7 +523,7 @@ DEV_NOINLINE void ph_integrate(KP Kc, int t) {
 }
 
 // checkpoint layout (doubles): [0] valid, [1] step, [2] time, [3] cost sum before that step, [4..6] diag counters, then qpos, qvel,
-// qacc_warmstart
+// qacc_warmstart, act
 #define CKPT_HEAD 7
 DEV_NOINLINE void ph_finish(KP Kc, double total, int failure, int t_fail, double total_before) {        // role 1 (it holds the cost sum)
   Ctx c; ctx_open(c, Kc, 1);
@@ -524,6 +543,7 @@ DEV_NOINLINE void ph_finish(KP Kc, double total, int failure, int t_fail, double
     if (resumable) {
       PFOR(i, M.nq) ck[CKPT_HEAD + i] = c.qpos[i];
       PFOR(i, M.nv) { ck[CKPT_HEAD + M.nq + i] = c.qvel[i]; ck[CKPT_HEAD + M.nq + M.nv + i] = c.qacc_ws[i]; }
+      if (M.na) PFOR(i, M.na) ck[CKPT_HEAD + M.nq + 2 * M.nv + i] = C_ACT(c)[i];
     }
   }
   if (LANE == 0) {
@@ -544,6 +564,7 @@ DEV_NOINLINE void ph_resume(KP Kc) {
   const double *ck = K->ckpt + (size_t)cand_index() * K->ckpt_stride;
   PFOR(i, M.nq) c.qpos[i] = ck[CKPT_HEAD + i];
   PFOR(i, M.nv) { c.qvel[i] = ck[CKPT_HEAD + M.nq + i]; c.qacc_ws[i] = ck[CKPT_HEAD + M.nq + M.nv + i]; }
+  if (M.na) PFOR(i, M.na) C_ACT(c)[i] = ck[CKPT_HEAD + M.nq + 2 * M.nv + i];
   if (LANE == 0) { c.misc[5] = (int)ck[4]; c.misc[6] = (int)ck[5]; c.misc[7] = (int)ck[6]; }
   c.time = ck[2];
   ctx_close(c);

@@ -125,6 +125,22 @@ DEV void subtree_sums(Ctx &c, int part) {
 #ifndef MJPC_CHAIN33
 #define MJPC_CHAIN33 1      // the per-lane chain walk of the velocity sweep also for the 33-dof hand (-0.5 %; 0 = level sweep)
 #endif
+// force of actuator i for the input u (control, or activation of a stateful actuator): gain * u + affine bias, force range
+DEV double actuator_force_of(Ctx &c, int i, double u) {
+  double force = MD(actuator_gainprm)[3 * i] * u;
+  if (MI(actuator_biastype)[i] == 1) {
+    // transmission length / velocity: gear * qpos (joint) or sum of gear * coef * qpos over the tendon's joints
+    double length = 0, velocity = 0;
+    for (int e = MI(act_adr)[i]; e < MI(act_adr)[i + 1]; e++) {
+      double cf = MD(act_coef)[e];
+      length += cf * c.qpos[MI(act_qpos)[e]]; velocity += cf * c.qvel[MI(act_dof)[e]];
+    }
+    force += MD(actuator_biasprm)[3 * i] + MD(actuator_biasprm)[3 * i + 1] * length + MD(actuator_biasprm)[3 * i + 2] * velocity;
+  }
+  if (MI(actuator_forcelimited)[i]) force = d_clip(force, MD(actuator_forcerange)[2 * i], MD(actuator_forcerange)[2 * i + 1]);
+  return force;
+}
+
 // mfact_seq != 0: M's factor is produced by a helper wave; wait for its sequence number (misc[22]) before the solve
 template <int NVT>
 DEV void velocity_stage(Ctx &c, int mfact_seq) {
@@ -170,18 +186,20 @@ DEV void velocity_stage(Ctx &c, int mfact_seq) {
   PFOR(i, M.nu) {
     double ctrl = c.ctrl[i];
     if (MI(actuator_ctrllimited)[i]) ctrl = d_clip(ctrl, MD(actuator_ctrlrange)[2 * i], MD(actuator_ctrlrange)[2 * i + 1]);
-    double force = MD(actuator_gainprm)[3 * i] * ctrl;
-    if (MI(actuator_biastype)[i] == 1) {
-      // transmission length / velocity: gear * qpos (joint) or sum of gear * coef * qpos over the tendon's joints
-      double length = 0, velocity = 0;
-      for (int e = MI(act_adr)[i]; e < MI(act_adr)[i + 1]; e++) {
-        double cf = MD(act_coef)[e];
-        length += cf * c.qpos[MI(act_qpos)[e]]; velocity += cf * c.qvel[MI(act_dof)[e]];
+    c.actuator_force[i] = actuator_force_of(c, i, ctrl);
+  }
+  if (M.na) {        // stateful actuators: act_dot from the clamped control, the force from the current activation instead
+    PFOR(i, M.nu) {
+      int dt = MI(actuator_dyntype)[i];
+      if (dt) {
+        double ctrl = c.ctrl[i];
+        if (MI(actuator_ctrllimited)[i]) ctrl = d_clip(ctrl, MD(actuator_ctrlrange)[2 * i], MD(actuator_ctrlrange)[2 * i + 1]);
+        int a = MI(actuator_actadr)[i];
+        double act = C_ACT(c)[a];
+        C_ACTDOT(c)[a] = dt == DYN_INTEGRATOR ? ctrl : d_div(ctrl - act, fmax(D_MINVAL, MD(actuator_dynprm)[i]));
+        c.actuator_force[i] = actuator_force_of(c, i, act);
       }
-      force += MD(actuator_biasprm)[3 * i] + MD(actuator_biasprm)[3 * i + 1] * length + MD(actuator_biasprm)[3 * i + 2] * velocity;
     }
-    if (MI(actuator_forcelimited)[i]) force = d_clip(force, MD(actuator_forcerange)[2 * i], MD(actuator_forcerange)[2 * i + 1]);
-    c.actuator_force[i] = force;
   }
 #if MJPC_HELPER
   if (!flag_wait(c.misc + HX_SUBSUM, mfact_seq)) c.warning |= WARN_SYNC;

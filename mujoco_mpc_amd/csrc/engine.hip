@@ -214,7 +214,7 @@ MjpcHipEngine *mjpc_hip_create(const MjpcHipModel *model, const MjpcHipTask *tas
   memset(&e->K, 0, sizeof(e->K));
   e->max_local = max_local; e->max_horizon = max_horizon;
   e->nq = model->nq; e->nv = model->nv; e->nu = model->nu; e->nmocap = model->nmocap;
-  e->nr = task->num_residual; e->ntr = 3 * task->num_trace; e->ds = model->nq + model->nv;
+  e->nr = task->num_residual; e->ntr = 3 * task->num_trace; e->ds = model->nq + model->nv + model->na;
   e->lds_bytes = (size_t)e->pm.L.total_doubles * sizeof(double);
   if (e->lds_bytes > 160 * 1024) { set_error("mjpc_hip_create: per-candidate state exceeds 160 KiB of LDS; lower nconmax/nefcmax"); delete e; return nullptr; }
   HIPCHKP(hipMalloc(&e->d_ib, e->pm.ib.size() * sizeof(int)));
@@ -248,7 +248,7 @@ MjpcHipEngine *mjpc_hip_create(const MjpcHipModel *model, const MjpcHipTask *tas
   HIPCHKP(hipFuncSetAttribute((const void *)e->kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_bytes));
   if (e->kernelB) {
     HIPCHKP(hipFuncSetAttribute((const void *)e->kernelB, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->ldsB));
-    e->ckpt_stride = 7 + e->nq + 2 * e->nv + 1;
+    e->ckpt_stride = 7 + e->nq + 2 * e->nv + model->na + 1;
     HIPCHKP(hipMalloc(&e->d_ckpt, sizeof(double) * NL * e->ckpt_stride));
     HIPCHKP(hipMemset(e->d_ckpt, 0, sizeof(double) * NL * e->ckpt_stride));
   }

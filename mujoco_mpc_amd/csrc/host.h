@@ -67,7 +67,8 @@ static inline void make_layout(const PackedModel &p, Lay &L, const MjpcHipModel 
   int o = 0;
   int nvp = M.nvp, ne = M.nefcmax, nc = M.nconmax, nr = t->num_residual;
 #define A_(f, n) L.f = o; o += (int)(n)
-  A_(qpos, m->nq); A_(qvel, nv); A_(ctrl, nu + 1); A_(qacc, nv); A_(qacc_ws, nv); A_(qacc_smooth, nv); A_(qfrc_smooth, nv);
+  A_(qpos, m->nq); A_(qvel, nv); A_(ctrl, nu + 1 + 2 * m->na);      // activations and their derivatives sit behind ctrl (C_ACT / C_ACTDOT)
+  A_(qacc, nv); A_(qacc_ws, nv); A_(qacc_smooth, nv); A_(qfrc_smooth, nv);
   A_(qfrc_bias, nv); A_(qfrc_constraint, nv); A_(actuator_force, nu + 1); A_(mocap_pos, 3 * m->nmocap + 3); A_(mocap_quat, 4 * m->nmocap + 4);
   A_(xpos, 3 * nb); A_(xquat, 4 * nb); A_(xmat, 9 * nb); A_(xipos, 3 * nb); A_(ximat, 9 * nb); A_(xanchor, 3 * nj + 3); A_(xaxis, 3 * nj + 3);
   A_(geom_xpos, 3 * ng + 3); A_(geom_xmat, 9 * ng + 9); A_(site_xpos, 3 * ns + 3);
@@ -118,7 +119,15 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
   int nb = m->nbody, nj = m->njnt, nv = m->nv, ng = m->ngeom, ns = m->nsite, nu = m->nu;
   // models the engine cannot roll out faithfully are refused (never silently approximated)
   if (nv > 64) { p.error = "nv > 64 not supported (dof bitmask)"; return false; }
-  if (m->na != 0) { p.error = "activation states (na > 0) not supported"; return false; }
+  { // activation states: one per stateful actuator (integrator / filter / filterexact), addresses 0 .. na-1
+    int cnt = 0;
+    for (int i = 0; i < nu && m->actuator_dyntype; i++) if (m->actuator_dyntype[i] != MJPC_DYN_NONE) {
+      int dt = m->actuator_dyntype[i], a = m->actuator_actadr ? m->actuator_actadr[i] : -1;
+      if (dt < 0 || dt > MJPC_DYN_FILTEREXACT) { p.error = "actuator " + std::to_string(i) + ": dyntype " + std::to_string(dt) + " not supported (integrator / filter / filterexact only)"; return false; }
+      if (a < 0 || a >= m->na || !m->actuator_dynprm || !m->actuator_actlimited || !m->actuator_actrange) { p.error = "actuator " + std::to_string(i) + ": activation address outside [0, na) or missing actuator_dynprm / actlimited / actrange"; return false; }
+      cnt++;
+    }
+    if (cnt != m->na) { p.error = "na = " + std::to_string(m->na) + " but " + std::to_string(cnt) + " stateful actuators (one activation each)"; return false; } }
   if (m->solver != MJPC_SOL_NEWTON) { p.error = "only the Newton solver (mjSOL_NEWTON) is implemented"; return false; }
   if (m->integrator != MJPC_INT_EULER) { p.error = "only the Euler integrator (with implicit joint damping) is implemented"; return false; }
   if (m->noslip_iterations != 0) { p.error = "noslip_iterations > 0 not supported"; return false; }
@@ -134,6 +143,7 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
   for (int i = 0; i < nu; i++)
     if (m->actuator_trntype[i] != MJPC_TRN_JOINT && m->actuator_trntype[i] != MJPC_TRN_TENDON) {
       p.error = "actuator " + std::to_string(i) + ": only joint and fixed-tendon transmissions are supported"; return false; }
+  M.na = m->na;
   M.nq = m->nq; M.nv = nv; M.nu = nu; M.nbody = nb; M.njnt = nj; M.ngeom = ng; M.nsite = ns; M.nmocap = m->nmocap;
   M.nkey = m->nkey; M.nvp = NVP_OF(nv); M.ntendon = m->ntendon;
   M.cone = m->cone; M.iterations = m->iterations; M.ls_iterations = m->ls_iterations;
@@ -200,6 +210,7 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
   PI_(actuator_ctrllimited, nu); PI_(actuator_forcelimited, nu); PI_(actuator_biastype, nu);
   PD_(actuator_gainprm, 3 * nu); PD_(actuator_biasprm, 3 * nu); PD_(actuator_gear, nu);
   PD_(actuator_ctrlrange, 2 * nu); PD_(actuator_forcerange, 2 * nu);
+  if (m->na > 0) { PI_(actuator_dyntype, nu); PI_(actuator_actadr, nu); PI_(actuator_actlimited, nu); PD_(actuator_dynprm, nu); PD_(actuator_actrange, 2 * nu); }
   PI_(tendon_adr, m->ntendon); PI_(tendon_num, m->ntendon);
   { std::vector<int> tl(m->ntendon, 0);
     if (!no_limit) for (int t = 0; t < m->ntendon; t++) tl[t] = m->tendon_limited[t];
@@ -411,6 +422,7 @@ static inline DevModel relocate(const PackedModel &p, const int *ibase, const do
   fd(M.geom_margin); fd(M.geom_gap); fd(M.geom_rbound);
   fi(M.site_bodyid); fd(M.site_pos); fd(M.site_quat);
   fi(M.act_adr); fi(M.act_dof); fi(M.act_qpos); fi(M.act_of); fi(M.dact_adr); fi(M.dact_e); fd(M.act_coef); fi(M.actuator_ctrllimited); fi(M.actuator_forcelimited); fi(M.actuator_biastype);
+  if (M.na > 0) { fi(M.actuator_dyntype); fi(M.actuator_actadr); fi(M.actuator_actlimited); fd(M.actuator_dynprm); fd(M.actuator_actrange); }
   fd(M.actuator_gainprm); fd(M.actuator_biasprm); fd(M.actuator_gear); fd(M.actuator_ctrlrange); fd(M.actuator_forcerange);
   fd(M.key_qpos); fd(M.key_mpos); fi(M.geom_dataid); fi(M.mesh_vertadr); fi(M.mesh_vertnum); fd(M.mesh_vert);
   fi(M.hfield_nrow); fi(M.hfield_ncol); fi(M.hfield_adr); fd(M.hfield_size); fd(M.hfield_data);

@@ -72,6 +72,7 @@ static inline int pattern_parent(int nv, int tree_ok, const int *dof_parentid, i
   return dof_parentid[k];
 }
 
+enum { DYN_NONE = 0, DYN_INTEGRATOR = 1, DYN_FILTER = 2, DYN_FILTEREXACT = 3 };      // MJPC_DYN_* (mjtDyn)
 enum { CNSTR_FRICTION_DOF = 1, CNSTR_FRICTION_TENDON = 2, CNSTR_LIMIT_JOINT = 3, CNSTR_LIMIT_TENDON = 4, CNSTR_CONTACT_FRICTIONLESS = 5, CNSTR_CONTACT_PYRAMIDAL = 6, CNSTR_CONTACT_ELLIPTIC = 7 };
 enum { STATE_SATISFIED = 0, STATE_QUADRATIC = 1, STATE_LINEARNEG = 2, STATE_LINEARPOS = 3, STATE_CONE = 4 };
 enum { WARN_BADQPOS = 1, WARN_BADQVEL = 2, WARN_BADQACC = 4, WARN_CONTACTFULL = 8, WARN_CNSTRFULL = 16, WARN_RAY = 32, WARN_SYNC = 64, WARN_UNSUPPORTED = 128 };
@@ -105,6 +106,9 @@ struct DevModel {
   // actuator transmissions flattened on the host: actuator i owns entries [act_adr[i], act_adr[i+1]) = (dof, qpos address,
   // coefficient = gear [* tendon coefficient]); act_of[e] = the actuator of entry e
   const int *act_adr, *act_dof, *act_qpos, *act_of, *actuator_ctrllimited, *actuator_forcelimited, *actuator_biastype;
+  int na;                                   // activation states (one per stateful actuator); tables below only when na > 0
+  const int *actuator_dyntype, *actuator_actadr, *actuator_actlimited;
+  const double *actuator_dynprm, *actuator_actrange;
   const int *dact_adr, *dact_e;             // entries grouped by dof: dof d owns dact_e[dact_adr[d] .. dact_adr[d+1])
   const double *act_coef;
   const double *actuator_gainprm, *actuator_biasprm, *actuator_gear, *actuator_ctrlrange, *actuator_forcerange;

@@ -200,11 +200,14 @@ class ModelBuilder:
         return len(self.sites) - 1
 
     def actuator(self, name, joint=None, gainprm=(1, 0, 0), biastype=0, biasprm=(0, 0, 0), gear=1.0,
-                 ctrllimited=True, ctrlrange=(-1, 1), forcelimited=False, forcerange=(0, 0), tendon=None):
-        """joint transmission (joint=name) or fixed-tendon transmission (tendon=name)."""
+                 ctrllimited=True, ctrlrange=(-1, 1), forcelimited=False, forcerange=(0, 0), tendon=None,
+                 dyntype=0, dynprm=1.0, actlimited=False, actrange=(0, 0)):
+        """joint transmission (joint=name) or fixed-tendon transmission (tendon=name); dyntype 1 integrator / 2 filter / 3 filterexact
+        gives the actuator one activation state (time constant dynprm)"""
         self.actuators.append(dict(name=name, joint=joint, tendon=tendon, gainprm=tuple(gainprm), biastype=biastype,
                                    biasprm=tuple(biasprm), gear=gear, ctrllimited=ctrllimited,
-                                   ctrlrange=tuple(ctrlrange), forcelimited=forcelimited, forcerange=tuple(forcerange)))
+                                   ctrlrange=tuple(ctrlrange), forcelimited=forcelimited, forcerange=tuple(forcerange),
+                                   dyntype=int(dyntype), dynprm=float(dynprm), actlimited=bool(actlimited), actrange=tuple(actrange)))
 
     def position(self, name, joint=None, tendon=None, kp=1.0, ctrlrange=(-1, 1), forcerange=None, gear=1.0):
         """MJCF <position>: gain kp, affine bias (0, -kp, 0)."""
@@ -459,6 +462,14 @@ class ModelBuilder:
         M["actuator_gear"] = np.array([a["gear"] for a in A], float)
         M["actuator_ctrlrange"] = np.array([a["ctrlrange"] for a in A], float).reshape(nu, 2)
         M["actuator_forcerange"] = np.array([a["forcerange"] for a in A], float).reshape(nu, 2)
+        M["actuator_dyntype"] = np.array([a.get("dyntype", 0) for a in A], np.int32)
+        adr = []; na = 0
+        for a in A:
+            adr.append(na if a.get("dyntype", 0) else -1); na += 1 if a.get("dyntype", 0) else 0
+        M["actuator_actadr"] = np.array(adr, np.int32)
+        M["actuator_actlimited"] = np.array([int(a.get("actlimited", False)) for a in A], np.int32)
+        M["actuator_dynprm"] = np.array([a.get("dynprm", 1.0) for a in A], float)
+        M["actuator_actrange"] = np.array([a.get("actrange", (0, 0)) for a in A], float).reshape(nu, 2)
         nkey = len(self.keys)
         kq = np.tile(M["qpos0"], (max(nkey, 1), 1))
         for k, (_, qp) in enumerate(self.keys):
@@ -494,7 +505,7 @@ class ModelBuilder:
             else:
                 ls[ti] = (sl, sl) if np.isscalar(sl) else tuple(sl)
         M["tendon_lengthspring"] = ls
-        sizes = dict(nq=nq, nv=nv, nu=nu, na=0, nbody=nb, njnt=nj, ngeom=ng, nsite=ns, nmocap=nmocap,
+        sizes = dict(nq=nq, nv=nv, nu=nu, na=na, nbody=nb, njnt=nj, ngeom=ng, nsite=ns, nmocap=nmocap,
                      nuserdata=self.nuserdata, nkey=nkey, nexclude=len(self.excludes), ntendon=len(self.tendons),
                      nwrap=len(wrap_objid), nmesh=len(M["mesh_vertadr"]), nmeshvert=len(M["mesh_vert"]), nhfield=len(M["hfield_nrow"]), nhfielddata=len(M["hfield_data"]))
         M.update(sizes)

@@ -227,6 +227,13 @@ def parse_mjcf(path_or_text, base_dir=None, reader=None, missing_ok=()):
                 g = _floats(a.get("gainprm", "1")); kw["gainprm"] = tuple(g + [0, 0, 0][len(g):3])[:3]
                 if a.get("biastype", "none") == "affine":
                     bp = _floats(a.get("biasprm", "0 0 0")); kw.update(biastype=1, biasprm=tuple(bp + [0, 0, 0][len(bp):3])[:3])
+                dyn = a.get("dyntype", "none")
+                if dyn not in ("none", "integrator", "filter", "filterexact"):
+                    raise ValueError(f"actuator dyntype {dyn} not in the supported subset")
+                if dyn != "none":
+                    kw.update(dyntype=("none", "integrator", "filter", "filterexact").index(dyn), dynprm=_floats(a.get("dynprm", "1"))[0])
+                    if "actrange" in a:
+                        kw.update(actrange=tuple(_floats(a["actrange"])), actlimited=a.get("actlimited", "auto") in ("true", "auto"))
             b.actuator(a.get("name", f"actuator{len(b.actuators)}"), a["joint"], **kw)
 
     for tn in root.findall("tendon"):

@@ -72,6 +72,29 @@ def particle(timestep=0.1, copystate=False):
     return m, task, defaults
 
 
+def filter_arm(timestep=0.005):
+    """Test model for activation states (na > 0): a three-link arm whose joints are driven through a first-order filter (the
+    swimmer's dyntype="filter"), an exact filter with a position servo's affine bias and a clamped integrator; a fourth, plain
+    motor shares the model.  The residual copies the whole state [qpos, qvel, act] (TASK_COPYSTATE)."""
+    b = ModelBuilder(timestep=timestep, gravity=(0, 0, -9.81), contact=False)
+    parent = 0
+    for k, (axis, ln) in enumerate((((0, 1, 0), 0.3), ((0, 1, 0), 0.25), ((1, 0, 0), 0.2), ((0, 1, 0), 0.15))):
+        body = b.body(f"l{k}", parent, pos=(0, 0, 0) if k == 0 else (0, 0, -(0.3, 0.25, 0.2)[k - 1]))
+        b.joint(body, f"j{k}", HINGE, axis=axis, damping=0.05, armature=0.005, limited=True, range=(-2.0, 2.0))
+        b.geom(body, f"g{k}", CAPSULE, size=(0.02, 0), fromto=(0, 0, 0, 0, 0, -ln), mass=0.4 - 0.08 * k)
+        parent = body
+    tip = b.site(parent, "tip", pos=(0, 0, -0.15))
+    b.actuator("a_filter", "j0", gainprm=(3.0, 0, 0), ctrlrange=(-1, 1), dyntype=2, dynprm=0.06)
+    b.actuator("a_exact", "j1", gainprm=(4.0, 0, 0), biastype=1, biasprm=(0, -4.0, -0.1), ctrlrange=(-1.5, 1.5), dyntype=3, dynprm=0.03)
+    b.actuator("a_motor", "j2", gear=0.8, ctrlrange=(-1, 1))
+    b.actuator("a_integrator", "j3", gainprm=(1.5, 0, 0), ctrlrange=(-1, 1), dyntype=1, actlimited=True, actrange=(-0.06, 0.06))
+    m = b.compile()
+    task = make_task(TASK_COPYSTATE, [(4, 0, 1.0), (4, 0, 0.1), (3, 0, 0.5)], traces=[(OBJ_SITE, tip)])
+    q = np.array([0.4, -0.3, 0.2, 0.1]); v = np.array([0.5, -1.0, 0.3, 0.0]); act = np.array([0.2, -0.4, 0.05])
+    defaults = dict(N=6, P=4, sigma=(0.4, 0.0), interp=2, horizon=80, state=np.concatenate([q, v, act]), mocap=np.zeros(0))
+    return m, task, defaults
+
+
 # ----------------------------------------------------------------------------------- cartpole
 def cartpole(timestep=0.01):
     b = ModelBuilder(timestep=timestep, contact=False)
@@ -676,4 +699,4 @@ def terrain_balls(timestep=0.004):
     return m, task, defaults
 
 
-REGISTRY = {"quadruped_hill": quadruped_hill, "terrain_balls": terrain_balls, "walker": walker, "acrobot": acrobot, "ball_chain": ball_chain, "cylinder_pile": cylinder_pile, "humanoid_stand": humanoid_stand, "humanoid_walk": humanoid_walk, "particle": particle, "cartpole": cartpole, "quadruped": quadruped, "humanoid_track": humanoid_track, "shadow_hand": shadow_hand}
+REGISTRY = {"filter_arm": filter_arm, "quadruped_hill": quadruped_hill, "terrain_balls": terrain_balls, "walker": walker, "acrobot": acrobot, "ball_chain": ball_chain, "cylinder_pile": cylinder_pile, "humanoid_stand": humanoid_stand, "humanoid_walk": humanoid_walk, "particle": particle, "cartpole": cartpole, "quadruped": quadruped, "humanoid_track": humanoid_track, "shadow_hand": shadow_hand}

@@ -46,7 +46,7 @@ typedef struct OData {
   /* state */
   double *qpos, *qvel, *ctrl, *mocap_pos, *mocap_quat, *userdata, time;
   double *qacc, *qacc_warmstart, *qacc_smooth, *qfrc_smooth, *qfrc_bias, *qfrc_passive,
-         *qfrc_actuator, *qfrc_constraint, *actuator_force;
+         *qfrc_actuator, *qfrc_constraint, *actuator_force, *act, *act_dot;
   /* kinematics */
   double *xpos, *xquat, *xmat, *xipos, *ximat, *xanchor, *xaxis, *geom_xpos, *geom_xmat,
          *site_xpos, *site_xmat, *subtree_com, *cinert, *cdof, *cvel, *cdof_dot, *crb,

@@ -36,7 +36,7 @@ OData *oracle_make_data(const OModel *om) {
   DD(mocap_quat, 4 * m->nmocap + 4); DD(userdata, m->nuserdata + 1);
   DD(qacc, nv); DD(qacc_warmstart, nv); DD(qacc_smooth, nv); DD(qfrc_smooth, nv);
   DD(qfrc_bias, nv); DD(qfrc_passive, nv); DD(qfrc_actuator, nv); DD(qfrc_constraint, nv);
-  DD(actuator_force, m->nu + 1);
+  DD(actuator_force, m->nu + 1); DD(act, m->na + 1); DD(act_dot, m->na + 1);
   DD(xpos, 3 * nb); DD(xquat, 4 * nb); DD(xmat, 9 * nb); DD(xipos, 3 * nb); DD(ximat, 9 * nb);
   DD(xanchor, 3 * m->njnt + 3); DD(xaxis, 3 * m->njnt + 3);
   DD(geom_xpos, 3 * m->ngeom + 3); DD(geom_xmat, 9 * m->ngeom + 9);
@@ -679,7 +679,14 @@ static void actuation(const OModel *om, OData *d) {
       length += coef * d->qpos[m->jnt_qposadr[j]];
       velocity += coef * d->qvel[m->jnt_dofadr[j]];
     }
-    double force = m->actuator_gainprm[3 * i] * ctrl;
+    double input = ctrl;
+    if (m->na > 0 && m->actuator_dyntype && m->actuator_dyntype[i] != MJPC_DYN_NONE) {
+      /* stateful actuator: act_dot from the (clamped) control, force from the current activation */
+      int a = m->actuator_actadr[i];
+      input = d->act[a];
+      d->act_dot[a] = m->actuator_dyntype[i] == MJPC_DYN_INTEGRATOR ? ctrl : (ctrl - input) / fmax(O_MINVAL, m->actuator_dynprm[i]);
+    }
+    double force = m->actuator_gainprm[3 * i] * input;
     if (m->actuator_biastype[i] == MJPC_BIAS_AFFINE)
       force += m->actuator_biasprm[3 * i] + m->actuator_biasprm[3 * i + 1] * length + m->actuator_biasprm[3 * i + 2] * velocity;
     if (m->actuator_forcelimited[i]) force = o_clip(force, m->actuator_forcerange[2 * i], m->actuator_forcerange[2 * i + 1]);
@@ -1009,6 +1016,18 @@ void oracle_step(const OModel *om, OData *d) {
     chol_solve(sol, d->qLD2, rhs, nv);
     qacc = sol;
   }
+  /* mj_advance: activations first (mj_nextActivation), then velocities and positions */
+  if (m->na > 0 && m->actuator_dyntype)
+    for (int i = 0; i < m->nu; i++) if (m->actuator_dyntype[i] != MJPC_DYN_NONE) {
+      int a = m->actuator_actadr[i];
+      double act = d->act[a];
+      if (m->actuator_dyntype[i] == MJPC_DYN_FILTEREXACT) {
+        double tau = fmax(O_MINVAL, m->actuator_dynprm[i]);
+        act += d->act_dot[a] * tau * (1 - exp(-h / tau));
+      } else act += h * d->act_dot[a];
+      if (m->actuator_actlimited[i]) act = o_clip(act, m->actuator_actrange[2 * i], m->actuator_actrange[2 * i + 1]);
+      d->act[a] = act;
+    }
   for (int i = 0; i < nv; i++) d->qvel[i] += h * qacc[i];
   integrate_pos(om, d, h);
   d->time += h;

@@ -130,6 +130,7 @@ void oracle_rollout(const OModel *om, OData *d, const MjpcHipPlanInput *in, cons
   o_copy(states, in->state, ds);
   o_copy(d->qpos, in->state, nq);
   o_copy(d->qvel, in->state + nq, nv);
+  if (na > 0) o_copy(d->act, in->state + nq + nv, na);
   times[0] = in->time;
   d->time = in->time;
   d->warning = 0;
@@ -154,6 +155,7 @@ void oracle_rollout(const OModel *om, OData *d, const MjpcHipPlanInput *in, cons
     if (d->warning) { failure = 1; break; }
     o_copy(states + (s + 1) * ds, d->qpos, nq);
     o_copy(states + (s + 1) * ds + nq, d->qvel, nv);
+    if (na > 0) o_copy(states + (s + 1) * ds + nq + nv, d->act, na);
     times[s + 1] = d->time;
   }
   if (failure) { out->unsupported += d->unsupported; d->unsupported = 0; out->failure[row] = d->warning; out->returns[row] = MJPC_MAX_RETURN; return; }

@@ -50,7 +50,7 @@ def plan(model, task, state, mocap, time, knot_times, knot_values, interp, N, H,
                                seed, stream, candidate_offset, num_local, noise_std=noise_std, nominal_index=nominal_index,
                                candidate_knots=candidate_knots, xfrc_std=xfrc_std, xfrc_rate=xfrc_rate)
     nl = inp.num_local
-    ds = model["nq"] + model["nv"]; nu = model["nu"]; nr = task["num_residual"]; ntr = 3 * task["num_trace"]
+    ds = model["nq"] + model["nv"] + model["na"]; nu = model["nu"]; nr = task["num_residual"]; ntr = 3 * task["num_trace"]
     P = inp.num_spline_points
     out = dict(returns=np.zeros(nl), failure=np.zeros(nl, np.int32), states=np.zeros((nl, H, ds)),
                actions=np.zeros((nl, H, nu)), times=np.zeros((nl, H)), residual=np.zeros((nl, H, nr)),

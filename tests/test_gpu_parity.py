@@ -78,6 +78,15 @@ def test_limited_ball_joints_and_tendon_spring_damper_cross_branch_limit():
     assert allc["diag"][:, 2].max() >= 2 and not out["failure"].any()        # limit rows were active
 
 
+def test_activation_states():
+    """na > 0: the state rows are [qpos, qvel, act]; filter / filterexact / clamped-integrator actuators next to a plain motor."""
+    from mujoco_mpc_amd.modelgen import filter_arm
+    m, task, d = filter_arm()
+    out, ref, allc = _compare(m, task, d, 4, 80, 12, (0.4, 0.0), 2, 1e-8)
+    assert allc["states"].shape[-1] == m["nq"] + m["nv"] + 3 and not out["failure"].any()
+    assert np.abs(allc["states"][:, :, -1]).max() == pytest.approx(0.06, abs=1e-12)       # the integrator hit its activation range
+
+
 def test_tendon_friction_loss_rows():
     """mjCNSTR_FRICTION_TENDON: friction rows along a cross-branch tendon and a one-joint tendon (saturated zones contribute to the
     gradient only, the quadratic zone to the Hessian as well)."""

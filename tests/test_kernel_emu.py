@@ -25,6 +25,7 @@ def _rel(a, b):
                                                    ("quadruped_hill", 5, 26, 6, (0.3, 0.0), 1e-5),  # the A1 on the fractal height field (task_hill.xml)
                                                    ("terrain_balls", 3, 60, 6, (0.5, 0.0), 1e-5),   # height field: prisms through the portal-refinement collider
                                                    ("cylinder_pile", 3, 50, 6, (0.5, 0.0), 1e-5),   # cylinder-box / cylinder-cylinder through the portal-refinement collider
+                                                   ("filter_arm", 4, 80, 6, (0.4, 0.0), 1e-9),      # activation states: filter / filterexact / clamped integrator actuators
                                                    ("ball_chain", 4, 60, 6, (0.4, 0.0), 1e-5),      # limited ball joints, tendon spring / damper / cross-branch limit
                                                    ("humanoid_track", 16, 30, 4, (0.15, 0.0), 1e-5),
                                                    ("humanoid_stand", 3, 24, 4, (0.05, 0.0), 1e-5), ("humanoid_walk", 3, 24, 4, (0.05, 0.0), 1e-5)])
@@ -161,6 +162,7 @@ def test_models_the_engine_cannot_roll_out_are_refused_at_create():
     option("disableflags", (1 << 0) | (1 << 2) | (1 << 3) | (1 << 4) | (1 << 12), None)
     option("enableflags", 1 << 0, "override"); option("enableflags", 1 << 1, None)
     option("unsupported", 1, "outside the engine's model view")
+    option("na", 2, "stateful actuators")                   # activation states must belong to integrator / filter actuators
 
     def userdata(b, body):
         b.nuserdata = 3

@@ -510,6 +510,37 @@ def test_tendon_spring_and_damper_closed_form():
     assert np.allclose(m2["tendon_lengthspring"], 0.0)
 
 
+def test_activation_states_closed_forms():
+    """mj_fwdActuation / mj_advance with stateful actuators (na > 0): filter act' = (ctrl - act) / tau under Euler, filterexact with
+    the exact decay, a clamped integrator; the force of a stateful actuator is gain * act (velocity of a free hinge follows)."""
+    h, tau, gain = 0.004, 0.05, 2.0
+    b = ModelBuilder(timestep=h, gravity=(0, 0, 0), contact=False)
+    l1 = b.body("l1", 0)
+    b.joint(l1, "h", HINGE, axis=(0, 1, 0))
+    b.geom(l1, "g", SPHERE, size=(0.1,), pos=(0, 0, -0.5), mass=2.0)
+    l2 = b.body("l2", 0, pos=(1, 0, 0))
+    b.joint(l2, "h2", HINGE, axis=(0, 1, 0))
+    b.geom(l2, "g2", SPHERE, size=(0.1,), pos=(0, 0, -0.5), mass=2.0)
+    b.actuator("f", "h", gainprm=(gain, 0, 0), ctrlrange=(-1, 1), dyntype=2, dynprm=tau)
+    b.actuator("e", "h2", gainprm=(0.0, 0, 0), ctrlrange=(-1, 1), dyntype=3, dynprm=tau)
+    b.actuator("i", "h2", gainprm=(0.0, 0, 0), ctrlrange=(-1, 1), dyntype=1, actlimited=True, actrange=(-0.1, 0.1))
+    m = b.compile()
+    assert m["na"] == 3 and list(m["actuator_actadr"]) == [0, 1, 2]
+    task = make_task(3, [(2, 0, 1.0), (2, 0, 1.0), (3, 0, 1.0)])
+    o = ol.Oracle(m, task)
+    H, u = 60, np.array([0.8, -0.5, 0.7])
+    a = o.plan(np.array([0, 0, 0, 0, 0.1, 0.2, -0.05]), None, 0.0, np.array([0.0]), u[None, :], 0, 1, H, sigma=(0.0, 0.0), nthreads=1)
+    k = np.arange(H)
+    act = a["states"][0, :, 4:]
+    assert np.allclose(act[:, 0], u[0] + (0.1 - u[0]) * (1 - h / tau) ** k, rtol=1e-12, atol=1e-14)          # Euler filter
+    assert np.allclose(act[:, 1], u[1] + (0.2 - u[1]) * np.exp(-k * h / tau), rtol=1e-12, atol=1e-14)        # exact filter
+    assert np.allclose(act[:, 2], np.minimum(-0.05 + k * h * u[2], 0.1), rtol=1e-12, atol=1e-14)            # clamped integrator
+    inertia = 2.0 * (0.5 ** 2 + 0.4 * 0.1 ** 2)
+    vel = np.concatenate([[0.0], np.cumsum(h * gain * act[:-1, 0] / inertia)])                               # force = gain * act
+    assert np.allclose(a["states"][0, :, 2], vel, rtol=1e-10, atol=1e-13)
+    assert np.array_equal(a["residual"][0, :, 4:], act)                                                      # residual row t sees act_t
+
+
 def test_tendon_friction_loss_row():
     """mjCNSTR_FRICTION_TENDON: a friction row along the tendon.  (i) far from rest the row saturates: joint torque = coef *
     frictionloss against the motion; (ii) a one-joint tendon with coefficient c and friction loss f is the same constraint as a

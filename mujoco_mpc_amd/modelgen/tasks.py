@@ -699,4 +699,4 @@ def terrain_balls(timestep=0.004):
     return m, task, defaults
 
 
-REGISTRY = {"filter_arm": filter_arm, "quadruped_hill": quadruped_hill, "terrain_balls": terrain_balls, "walker": walker, "acrobot": acrobot, "ball_chain": ball_chain, "cylinder_pile": cylinder_pile, "humanoid_stand": humanoid_stand, "humanoid_walk": humanoid_walk, "particle": particle, "cartpole": cartpole, "quadruped": quadruped, "humanoid_track": humanoid_track, "shadow_hand": shadow_hand}
+REGISTRY = {"filter_arm": filter_arm, "ball_chain_friction": lambda: ball_chain(tendon_frictionloss=0.3), "quadruped_hill": quadruped_hill, "terrain_balls": terrain_balls, "walker": walker, "acrobot": acrobot, "ball_chain": ball_chain, "cylinder_pile": cylinder_pile, "humanoid_stand": humanoid_stand, "humanoid_walk": humanoid_walk, "particle": particle, "cartpole": cartpole, "quadruped": quadruped, "humanoid_track": humanoid_track, "shadow_hand": shadow_hand}

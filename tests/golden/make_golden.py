@@ -29,6 +29,8 @@ CONFIGS = {
     "walker_10x80": ("walker", 10, 80, 3, 2, 0.5, False),                   # mjpc/tasks/walker/task.xml:10-15 (horizon 0.8 s, 3 points, exploration 0.5)
     "acrobot_10x100": ("acrobot", 10, 100, 10, 2, 0.05, False),             # mjpc/tasks/acrobot/task.xml:9-17, half the horizon
     "ball_chain_6x60": ("ball_chain", 6, 60, 4, 2, 0.4, False),             # limited ball joints, tendon spring / damper / cross-branch limit
+    "ball_chain_friction_6x80": ("ball_chain_friction", 6, 80, 4, 2, 0.4, False),   # tendon friction loss rows (cross-branch and in-pattern)
+    "filter_arm_6x80": ("filter_arm", 6, 80, 4, 2, 0.4, False),             # activation states (filter / filterexact / clamped integrator)
     "quadruped_hill_8x26": ("quadruped_hill", 8, 26, 5, 2, 0.3, False),     # mjpc/tasks/quadruped/task_hill.xml:9-14 (horizon 0.25 s, 5 points, exploration 0.3)
     "terrain_balls_6x60": ("terrain_balls", 6, 60, 3, 2, 0.5, False),       # height-field terrain
     "cylinder_pile_6x50": ("cylinder_pile", 6, 50, 3, 2, 0.5, False),       # cylinder / ellipsoid pairs through the portal-refinement collider

@@ -67,8 +67,11 @@ enum {
   MJPC_TASK_SHADOW_REORIENT = 7, /* mjpc/tasks/shadow_reorient/hand.cc:37-84; int_data = [palm site, cube body, goal body, key] */
   MJPC_TASK_WALKER = 8,     /* mjpc/tasks/walker/walker.cc:39-57; int_data = [torso body]; parameters = [height goal, speed goal] */
   MJPC_TASK_ACROBOT = 9,    /* mjpc/tasks/acrobot/acrobot.cc:34-49; int_data = [goal site, tip site] */
-  MJPC_TASK_QUADRUPED_HILL = 10 /* mjpc/tasks/quadruped/quadruped.cc:726-768; int_data = [trunk body, sites FR FL RR RL, stage];
+  MJPC_TASK_QUADRUPED_HILL = 10, /* mjpc/tasks/quadruped/quadruped.cc:726-768; int_data = [trunk body, sites FR FL RR RL, stage];
                                  * dbl_data = the stage goals [nstage][7] (mpos, mquat of task_hill.xml:82-101) for the host Transition */
+  MJPC_TASK_PARTICLE_TIMEVARYING = 11, /* mjpc/tasks/particle/particle.cc:30-50 ("Particle"): tip position - Lissajous goal of data->time,
+                                 * tip velocity, control (6 residuals); int_data = [tip site] */
+  MJPC_TASK_PARTICLE_FIXED = 12  /* particle.cc:68-73 ("ParticleFixed"): the same with goal = mocap_pos[0..1] */
 };
 enum { MJPC_TRN_JOINT = 0, MJPC_TRN_TENDON = 3 };   /* mjtTrn values of the supported actuator transmissions */
 enum { MJPC_OBJ_BODY = 1, MJPC_OBJ_XBODY = 2, MJPC_OBJ_GEOM = 5, MJPC_OBJ_SITE = 6 };

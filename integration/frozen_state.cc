@@ -87,6 +87,7 @@ struct HipFrozenState {
     }
   }
   static void Walker(const mjModel* m, std::vector<int>& I) { I = {SensorObject(m, "torso_position")}; }      // walker.cc:39-57
+  static void Particle(const mjModel* m, std::vector<int>& I) { I = {SensorObject(m, "position")}; }          // particle.cc:33-38: the tip site
   static void Acrobot(std::vector<int>& I) { I = {0, 1}; }                                                   // acrobot.cc:38-39: sites 0 and 1
 };
 
@@ -106,7 +107,8 @@ void FillFrozenState(const Task& task, const BaseResidualFn* residual, const mjM
     case MJPC_TASK_QUADRUPED_HILL: HipFrozenState::Hill(m, task.mode > 0 ? task.mode - 1 : 0, ints, dbls); break;
     case MJPC_TASK_WALKER: HipFrozenState::Walker(m, ints); break;
     case MJPC_TASK_ACROBOT: HipFrozenState::Acrobot(ints); break;
-    default: break;                                                      // particle, cartpole: nothing frozen
+    case MJPC_TASK_PARTICLE_TIMEVARYING: case MJPC_TASK_PARTICLE_FIXED: HipFrozenState::Particle(m, ints); break;
+    default: break;                                                      // cartpole: nothing frozen
   }
   (void)task;
 }

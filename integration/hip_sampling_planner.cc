@@ -30,7 +30,8 @@ int DeviceResidual(const Task& task) {
   if (name == "Humanoid Stand") return MJPC_TASK_HUMANOID_STAND;
   if (name == "Humanoid Walk") return MJPC_TASK_HUMANOID_WALK;
   if (name == "Shadow") return MJPC_TASK_SHADOW_REORIENT;
-  if (name == "Particle") return MJPC_TASK_PARTICLE;
+  if (name == "Particle") return MJPC_TASK_PARTICLE_TIMEVARYING;
+  if (name == "ParticleFixed") return MJPC_TASK_PARTICLE_FIXED;
   if (name == "Walker") return MJPC_TASK_WALKER;
   if (name == "Acrobot") return MJPC_TASK_ACROBOT;
   return -1;

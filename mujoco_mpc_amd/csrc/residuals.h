@@ -426,6 +426,18 @@ DEV void task_residual(Ctx &c, double *residual) {
       for (int k = 0; k < 9; k++) residual[4 + k] = bm[k] - gm[k];
     }
     PFOR(i, nu) residual[13 + i] = c.ctrl[i];
+  } else if (id == 11 || id == 12) {   // particle.cc:30-50 / 68-73: tip - goal (Lissajous curve of the time, or the mocap body), tip velocity, control
+    if (LANE == 0) {
+      int s = MI(task.int_data)[0], body = MI(site_bodyid)[s];
+      double goal[2] = {c.mocap_pos[0], c.mocap_pos[1]}, off[3], lin[3];
+      if (id == 11) { goal[0] = 0.25 * sin(c.time); goal[1] = 0.25 * cos(c.time / 3.14159265358979323846); }
+      residual[0] = c.site_xpos[3 * s] - goal[0]; residual[1] = c.site_xpos[3 * s + 1] - goal[1];
+      d_sub3(off, c.site_xpos + 3 * s, c.subtree_com + 3 * MIH(body_rootid)[body]);
+      d_cross(lin, c.cvel + 6 * body, off);
+      d_add3(lin, lin, c.cvel + 6 * body + 3);
+      residual[2] = lin[0]; residual[3] = lin[1];
+      residual[4] = c.ctrl[0]; residual[5] = c.ctrl[1];
+    }
   } else if (id == 9) {   // acrobot.cc:34-49: goal - tip (z, x), joint velocities, control
     if (LANE == 0) {
       int g = MI(task.int_data)[0], t = MI(task.int_data)[1];

@@ -356,7 +356,13 @@ static void HillTransition(const MjpcHipModel& m, SimState& s, HostTask& t, cons
   for (int k = 0; k < 7; k++) s.mocap[k] = t.dbl_data[7 * stage + k];
 }
 
+// Particle::TransitionLocked (particle.cc:52-60): the mocap goal follows the Lissajous curve the residual tracks
+static void ParticleTransition(const MjpcHipModel&, SimState& s, HostTask&, const SimFrame&) {
+  if (s.mocap.size() >= 2) { s.mocap[0] = 0.25 * std::sin(s.time); s.mocap[1] = 0.25 * std::cos(s.time / 3.14159265358979323846); }
+}
+
 TransitionFn TransitionForTask(int task_id, int mode, double mode_time) {
+  if (task_id == MJPC_TASK_PARTICLE_TIMEVARYING) return ParticleTransition;
   if (task_id == MJPC_TASK_HUMANOID_TRACK) return TrackingTransition;
   if (task_id == MJPC_TASK_QUADRUPED_HILL) return HillTransition;
   if (task_id == MJPC_TASK_SHADOW_REORIENT) return HandTransition;

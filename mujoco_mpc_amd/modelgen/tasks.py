@@ -72,6 +72,21 @@ def particle(timestep=0.1, copystate=False):
     return m, task, defaults
 
 
+TASK_PARTICLE_TIMEVARYING, TASK_PARTICLE_FIXED = 11, 12
+
+
+def particle_task(fixed=False, timestep=0.01):
+    """The registry's Particle / ParticleFixed tasks (mjpc/tasks/particle/particle.cc, task_timevarying.xml): the point mass of
+    particle() with the 6-residual cost Position (w 5) / Velocity (w 0.1) / Control (w 0.1), risk 1; the goal is a Lissajous curve of
+    the time (Particle) or the mocap body (ParticleFixed).  Agent settings of the XML: horizon 0.5 s, 5 spline points, exploration 0.01."""
+    m, _, d = particle(timestep=timestep)
+    tip = 0
+    task = make_task(TASK_PARTICLE_FIXED if fixed else TASK_PARTICLE_TIMEVARYING, [(2, 0, 5.0), (2, 0, 0.1), (2, 0, 0.1)], risk=1.0,
+                     traces=[(OBJ_SITE, tip)], int_data=[tip])
+    defaults = dict(d, N=10, P=5, sigma=(0.01, 0.0), interp=2, horizon=51, state=np.array([0.05, -0.1, 0.0, 0.0]))
+    return m, task, defaults
+
+
 def filter_arm(timestep=0.005):
     """Test model for activation states (na > 0): a three-link arm whose joints are driven through a first-order filter (the
     swimmer's dyntype="filter"), an exact filter with a position servo's affine bias and a clamped integrator; a fourth, plain
@@ -699,4 +714,4 @@ def terrain_balls(timestep=0.004):
     return m, task, defaults
 
 
-REGISTRY = {"filter_arm": filter_arm, "ball_chain_friction": lambda: ball_chain(tendon_frictionloss=0.3), "quadruped_hill": quadruped_hill, "terrain_balls": terrain_balls, "walker": walker, "acrobot": acrobot, "ball_chain": ball_chain, "cylinder_pile": cylinder_pile, "humanoid_stand": humanoid_stand, "humanoid_walk": humanoid_walk, "particle": particle, "cartpole": cartpole, "quadruped": quadruped, "humanoid_track": humanoid_track, "shadow_hand": shadow_hand}
+REGISTRY = {"particle_timevarying": particle_task, "particle_fixed": lambda: particle_task(fixed=True), "filter_arm": filter_arm, "ball_chain_friction": lambda: ball_chain(tendon_frictionloss=0.3), "quadruped_hill": quadruped_hill, "terrain_balls": terrain_balls, "walker": walker, "acrobot": acrobot, "ball_chain": ball_chain, "cylinder_pile": cylinder_pile, "humanoid_stand": humanoid_stand, "humanoid_walk": humanoid_walk, "particle": particle, "cartpole": cartpole, "quadruped": quadruped, "humanoid_track": humanoid_track, "shadow_hand": shadow_hand}

@@ -556,6 +556,19 @@ void oracle_residual(const OModel *om, OData *d, double *residual) {
       o_copy(residual + 13, d->ctrl, m->nu);
       break;
     }
+    case MJPC_TASK_PARTICLE_TIMEVARYING:   /* particle.cc:30-50: some Lissajous curve of data->time */
+    case MJPC_TASK_PARTICLE_FIXED: {       /* particle.cc:68-73: goal = the mocap body */
+      int s = om->t.int_data[0], body = m->site_bodyid[s];
+      double goal[2] = {d->mocap_pos[0], d->mocap_pos[1]}, off[3], lin[3];
+      if (om->t.task_id == MJPC_TASK_PARTICLE_TIMEVARYING) { goal[0] = 0.25 * sin(d->time); goal[1] = 0.25 * cos(d->time / 3.14159265358979323846); }
+      for (int k = 0; k < m->nq && k < 2; k++) residual[k] = d->site_xpos[3 * s + k] - goal[k];
+      o_sub3(off, d->site_xpos + 3 * s, d->subtree_com + 3 * m->body_rootid[body]);      /* framelinvel of the site */
+      o_cross(lin, d->cvel + 6 * body, off);
+      o_add3(lin, lin, d->cvel + 6 * body + 3);
+      for (int k = 0; k < m->nv && k < 2; k++) residual[2 + k] = lin[k];
+      o_copy(residual + 4, d->ctrl, m->nu);
+      break;
+    }
     case MJPC_TASK_ACROBOT: {  /* acrobot.cc:34-49 */
       int g = om->t.int_data[0], t = om->t.int_data[1];
       residual[0] = d->site_xpos[3 * g + 2] - d->site_xpos[3 * t + 2];

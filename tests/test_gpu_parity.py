@@ -999,6 +999,33 @@ def test_closed_loop_walker_walks_and_acrobot_swings_up():
 
 
 @pytest.mark.gpu
+def test_registry_particle_tasks_and_their_transition():
+    """mjpc/tasks/particle (particle.cc:30-73, task_timevarying.xml): 6 residuals, the goal a Lissajous curve of data->time
+    ("Particle") or the mocap body ("ParticleFixed").  Plan-step parity at a non-zero start time; closed loop with the host
+    Transition (the mocap goal follows the curve): the particle tracks the moving goal."""
+    from mujoco_mpc_amd import cplanner
+    from mujoco_mpc_amd.modelgen import particle_task
+    for fixed in (False, True):
+        m, task, d = particle_task(fixed)
+        out, ref, allc = _compare(m, task, d, 5, 51, 16, (0.3, 0.0), 2, 1e-9, time0=0.7)
+        assert allc["residual"].shape[-1] == 6
+        t = allc["times"][0]
+        goal = np.stack([0.25 * np.sin(t), 0.25 * np.cos(t / np.pi)], 1) if not fixed else np.tile(d["mocap"][:2], (len(t), 1))
+        assert np.allclose(allc["residual"][0, :, :2], allc["states"][0, :, :2] - goal, atol=1e-14)
+        assert np.array_equal(allc["residual"][0, :, 2:4], allc["states"][0, :, 2:4]) and np.array_equal(allc["residual"][0, :-1, 4:], allc["actions"][0, :-1])
+    m, task, d = particle_task(False)
+    num = dict(sampling_spline_points=5, sampling_exploration=0.1, sampling_trajectories=64, sampling_representation=2)
+    p = cplanner.SamplingPlanner()
+    p.Initialize(m, task, num, max_samples=64, max_horizon=51)
+    p.Reset(51)
+    res = cplanner.testspeed(p, d["state"], d["mocap"], horizon=51, steps_per_planning_iteration=1, total_time=4.0)
+    p.close()
+    goal = res["mocap"][:2]                       # moved along the curve by the Transition (4 s: sin 4 = -0.757, cos(4 / pi) = 0.294)
+    assert np.allclose(goal, [0.25 * np.sin(4.0), 0.25 * np.cos(4.0 / np.pi)], atol=0.01)
+    assert not res["failure"] and np.linalg.norm(res["state"][:2] - goal) < 0.03, (res["state"], goal)
+
+
+@pytest.mark.gpu
 def test_quadruped_hill_parity_and_closed_loop_with_its_transition():
     """mjpc/tasks/quadruped "Quadruped Hill" (quadruped.cc:726-812): the A1 with position servos on the fractal height field.
     Plan-step parity with the oracle; closed loop with the host Transition: the robot stays on its feet on the terrain, and a

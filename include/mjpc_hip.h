@@ -32,7 +32,7 @@ enum {
   MJPC_GEOM_ELLIPSOID = 4, MJPC_GEOM_CYLINDER = 5, MJPC_GEOM_BOX = 6, MJPC_GEOM_MESH = 7
 };
 enum { MJPC_CONE_PYRAMIDAL = 0, MJPC_CONE_ELLIPTIC = 1 };
-enum { MJPC_SOL_NEWTON = 2, MJPC_INT_EULER = 0 };
+enum { MJPC_SOL_NEWTON = 2, MJPC_INT_EULER = 0, MJPC_INT_IMPLICITFAST = 3 };
 /* model features outside this view (MjpcHipModel.unsupported) */
 enum { MJPC_DYN_NONE = 0, MJPC_DYN_INTEGRATOR = 1, MJPC_DYN_FILTER = 2, MJPC_DYN_FILTEREXACT = 3 };   /* mjtDyn */
 enum { MJPC_UNSUP_FLUID = 1,          /* opt.density / viscosity / wind non-zero */
@@ -108,7 +108,9 @@ typedef struct MjpcHipModel {
                             * refsafe, eulerdamp) is refused at create */
   int enableflags;         /* mjENBL_* bits: override and multiccd are refused, the rest has nothing to act on */
   int solver;              /* mjtSolver: only MJPC_SOL_NEWTON (2, MuJoCo's default and what every MJPC task uses) */
-  int integrator;          /* mjtIntegrator: only MJPC_INT_EULER (0; with implicit joint damping, mj_Euler) */
+  int integrator;          /* mjtIntegrator: MJPC_INT_EULER (0; with implicit joint damping, mj_Euler) or MJPC_INT_IMPLICITFAST (3: also implicit in
+                            * tendon damping and in the velocity term of affine actuator biases - position / velocity servos with kv - unless the
+                            * force sits on its forcerange; no Coriolis derivative).  RK4 and the full implicit integrator are refused */
   int noslip_iterations;   /* must be 0 */
   int neq;                 /* number of equality constraints: must be 0 (none of the colliding / planning tasks here has one) */
   int unsupported;         /* MJPC_UNSUP_* bits found by whoever fills this view in parts of mjModel the view does not carry

@@ -466,6 +466,21 @@ DEV_NOINLINE void ph_prefactor(KP Kc) {
     int nv = M.nv, nvp = M.nvp;
     double h = M.timestep;
     PFOR(e, nv * nvp) { int i = e / nvp, j = e - i * nvp; c.qL[e] = c.qM[e] + ((i == j) ? h * MD(dof_damping)[i] : 0.0); }
+    if (M.nidrv) {      // implicitfast: tendon damping and the velocity terms of the actuator biases (skipped while the force is clamped)
+      SYNC();
+      if (LANE == 0)
+        for (int k = 0; k < M.nidrv; k++) {
+          int i = MI(idrv_e)[3 * k], j = MI(idrv_e)[3 * k + 1], a = MI(idrv_e)[3 * k + 2];
+          if (a >= 0 && MI(actuator_forcelimited)[a]) {
+            double f = c.actuator_force[a];
+            if (f <= MD(actuator_forcerange)[2 * a] || f >= MD(actuator_forcerange)[2 * a + 1]) continue;
+          }
+          double v = h * MD(idrv_c)[k];
+          c.qL[i * nvp + j] += v;
+          if (i != j) c.qL[j * nvp + i] += v;
+        }
+      SYNC();
+    }
     chol_factor<NVT>(c.qL, c.Linv, c.scr_a, nv, nvp, c.M->tree_ok);
   }
   PROFW(c, 11);

@@ -129,7 +129,7 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
     }
     if (cnt != m->na) { p.error = "na = " + std::to_string(m->na) + " but " + std::to_string(cnt) + " stateful actuators (one activation each)"; return false; } }
   if (m->solver != MJPC_SOL_NEWTON) { p.error = "only the Newton solver (mjSOL_NEWTON) is implemented"; return false; }
-  if (m->integrator != MJPC_INT_EULER) { p.error = "only the Euler integrator (with implicit joint damping) is implemented"; return false; }
+  if (m->integrator != MJPC_INT_EULER && m->integrator != MJPC_INT_IMPLICITFAST) { p.error = "only the Euler (with implicit joint damping) and implicitfast integrators are implemented"; return false; }
   if (m->noslip_iterations != 0) { p.error = "noslip_iterations > 0 not supported"; return false; }
   if (m->neq != 0) { p.error = "equality constraints (neq > 0) not supported"; return false; }
   if (m->unsupported != 0) { p.error = "the model uses features outside the engine's model view (MJPC_UNSUP_* mask " + std::to_string(m->unsupported) + ": fluid forces, gravity compensation, non-fixed actuator gains, actuator dynamics, spatial tendons, ...)"; return false; }
@@ -379,6 +379,44 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
     M.tpass_id = as_off<int>(put_i(p, ids.data(), ids.size())); M.tpass_prm = as_off<double>(put_d(p, prm.data(), prm.size())); }
   M.any_damping = 0;
   for (int i = 0; i < nv; i++) if (m->dof_damping[i] > 0) M.any_damping = 1;
+  // implicitfast: velocity derivatives of the smooth forces beyond joint damping, as entries (i >= j, coefficient, actuator or -1) of
+  // the matrix added to M before the integration solve: M - h dF/dv  (tendon damping: b c_i c_j; affine actuator bias: -prm2 m_i m_j)
+  { std::vector<int> ei; std::vector<double> ec;
+    auto add_outer = [&](const std::vector<std::pair<int, double>> &row, double scale, int act) -> bool {
+      for (size_t a = 0; a < row.size(); a++) for (size_t b = 0; b <= a; b++) {
+        int i = row[a].first, j = row[b].first;
+        if (i < j) std::swap(i, j);
+        bool anc = false;
+        for (int k = i; k >= 0; k = pattern_parent(nv, M.tree_ok, m->dof_parentid, k)) if (k == j) anc = true;
+        if (!anc) return false;
+        double cf = scale * row[a].second * row[b].second * ((a != b && row[a].first == row[b].first) ? 2.0 : 1.0);
+        ei.push_back(i); ei.push_back(j); ei.push_back(act); ec.push_back(cf);
+      }
+      return true;
+    };
+    if (m->integrator == MJPC_INT_IMPLICITFAST) {
+      for (int t = 0; t < m->ntendon; t++) {
+        double b = m->tendon_damping ? m->tendon_damping[t] : 0;
+        if (b == 0) continue;
+        std::vector<std::pair<int, double>> row;
+        for (int w = m->tendon_adr[t]; w < m->tendon_adr[t] + m->tendon_num[t]; w++) row.push_back({m->jnt_dofadr[m->wrap_objid[w]], m->wrap_prm[w]});
+        if (!add_outer(row, b, -1)) { p.error = "implicitfast: tendon " + std::to_string(t) + " damps dofs on different branches (outside the factorisation pattern)"; return false; }
+      }
+      for (int i = 0; i < nu; i++) {
+        double kv = m->actuator_biastype[i] == MJPC_BIAS_AFFINE ? m->actuator_biasprm[3 * i + 2] : 0;
+        if (kv == 0) continue;
+        std::vector<std::pair<int, double>> row;
+        double gear = m->actuator_gear[i];
+        if (m->actuator_trntype[i] == MJPC_TRN_TENDON) {
+          int t = m->actuator_trnid[i];
+          for (int w = m->tendon_adr[t]; w < m->tendon_adr[t] + m->tendon_num[t]; w++) row.push_back({m->jnt_dofadr[m->wrap_objid[w]], gear * m->wrap_prm[w]});
+        } else row.push_back({m->jnt_dofadr[m->actuator_trnid[i]], gear});
+        if (!add_outer(row, -kv, i)) { p.error = "implicitfast: actuator " + std::to_string(i) + " couples dofs on different branches (outside the factorisation pattern)"; return false; }
+      }
+    }
+    M.nidrv = (int)ec.size();
+    if (M.nidrv) M.any_damping = 1;
+    M.idrv_e = as_off<int>(put_i(p, ei.data(), ei.size())); M.idrv_c = as_off<double>(put_d(p, ec.data(), ec.size())); }
   if (M.nefcmax < M.nfric + M.ntfric + 2) M.nefcmax = M.nfric + M.ntfric + 2;
   // task region (re-packable by set_task)
   p.task_i0 = p.ib.size(); p.task_d0 = p.db.size();
@@ -431,7 +469,7 @@ static inline DevModel relocate(const PackedModel &p, const int *ibase, const do
   fi(M.level_adr); fi(M.level_body); fi(M.subtree_adr); fi(M.subtree_list); fi(M.chain_adr); fi(M.chain_list); fi(M.mpair_i); fi(M.mpair_j); fi(M.hpair_i); fi(M.hpair_j); fi(M.zpair_i); fi(M.zpair_j);
   { const double *q = reinterpret_cast<const double *>(M.body_dofmask); fd(q); M.body_dofmask = reinterpret_cast<const unsigned long long *>(q); }
   { const double *q = reinterpret_cast<const double *>(M.body_patmask); fd(q); M.body_patmask = reinterpret_cast<const unsigned long long *>(q); }
-  fi(M.pair_g1); fi(M.pair_g2); fi(M.fric_dof); fi(M.limit_jnt); fi(M.limit_ball); fi(M.ray_geom); fi(M.tpass_id); fd(M.tpass_prm); fi(M.tfric_id); fd(M.tfric_prm);
+  fi(M.pair_g1); fi(M.pair_g2); fi(M.fric_dof); fi(M.limit_jnt); fi(M.limit_ball); fi(M.ray_geom); fi(M.tpass_id); fd(M.tpass_prm); fi(M.tfric_id); fd(M.tfric_prm); fi(M.idrv_e); fd(M.idrv_c);
   DevTask &T = M.task;
   fi(T.dim_norm_residual); fi(T.norm); fi(T.num_norm_parameter); fi(T.trace_objtype); fi(T.trace_objid); fi(T.int_data);
   fd(T.weight); fd(T.norm_parameter); fd(T.parameters); fd(T.dbl_data);

@@ -116,6 +116,8 @@ struct DevModel {
   const double *wrap_prm, *tendon_range, *tendon_margin, *tendon_solref_lim, *tendon_solimp_lim, *tendon_invweight0;
   const int *tpass_id;                      // tendons with passive forces
   const double *tpass_prm;                  // [4 each] stiffness, damping, spring dead band lo / hi
+  int nidrv;                                // implicitfast: entries of -dF/dv beyond joint damping (idrv_e: i, j, actuator or -1; idrv_c: coefficient)
+  const int *idrv_e; const double *idrv_c;
   const int *tfric_id;                      // tendons with friction loss
   const double *tfric_prm;                  // [8 each] frictionloss, solref[2], solimp[5]
   const double *key_qpos, *key_mpos;

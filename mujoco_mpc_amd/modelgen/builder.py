@@ -121,7 +121,8 @@ class _Body:
 
 class ModelBuilder:
     def __init__(self, timestep=0.002, gravity=(0, 0, -9.81), cone=0, impratio=1.0,
-                 contact=True, tolerance=1e-8, iterations=100, ls_iterations=50, ls_tolerance=0.01):
+                 contact=True, tolerance=1e-8, iterations=100, ls_iterations=50, ls_tolerance=0.01, integrator=0):
+        self.integrator = integrator      # 0 Euler, 3 implicitfast (mjtIntegrator)
         self.opt = dict(timestep=timestep, gravity=np.array(gravity, float), cone=cone, impratio=impratio,
                         contact=contact, tolerance=tolerance, iterations=iterations,
                         ls_iterations=ls_iterations, ls_tolerance=ls_tolerance)
@@ -513,7 +514,7 @@ class ModelBuilder:
         M.update(timestep=o["timestep"], gravity=o["gravity"], impratio=o["impratio"], tolerance=o["tolerance"],
                  ls_tolerance=o["ls_tolerance"], cone=o["cone"], iterations=o["iterations"],
                  ls_iterations=o["ls_iterations"], disableflags=(0 if o["contact"] else (1 << 4)) | int(getattr(self, "disableflags", 0)),
-                 enableflags=0, solver=2, integrator=0, noslip_iterations=0, neq=0, unsupported=0,
+                 enableflags=0, solver=2, integrator=int(getattr(self, "integrator", 0)), noslip_iterations=0, neq=0, unsupported=0,
                  nconmax=self.nconmax, nefcmax=self.nefcmax)
         # ---- quantities evaluated at qpos0 (mjModel "set0")
         Mq, Jp, Jr = mass_matrix(M, M["qpos0"])

@@ -87,6 +87,30 @@ def particle_task(fixed=False, timestep=0.01):
     return m, task, defaults
 
 
+def servo_arm(timestep=0.005, integrator=3):
+    """Test model for mjINT_IMPLICITFAST: a three-link arm on position servos with velocity gains (kv: the bias' velocity term), one
+    of them with a force range it saturates, a velocity servo through a fixed tendon along the chain, and a damped tendon; stiff
+    enough that Euler (integrator=0) and implicitfast (3) give visibly different trajectories.  Residual = state (TASK_COPYSTATE)."""
+    b = ModelBuilder(timestep=timestep, gravity=(0, 0, -9.81), contact=False, integrator=integrator)
+    parent = 0
+    for k, (axis, ln) in enumerate((((0, 1, 0), 0.3), ((0, 1, 0), 0.25), ((1, 0, 0), 0.2))):
+        body = b.body(f"l{k}", parent, pos=(0, 0, 0) if k == 0 else (0, 0, -(0.3, 0.25)[k - 1]))
+        b.joint(body, f"j{k}", HINGE, axis=axis, damping=0.02, armature=0.002)
+        b.geom(body, f"g{k}", CAPSULE, size=(0.02, 0), fromto=(0, 0, 0, 0, 0, -ln), mass=0.3 - 0.08 * k)
+        parent = body
+    tip = b.site(parent, "tip", pos=(0, 0, -0.2))
+    b.tendon("chain", ["j0", "j1"], [1.0, 0.5], damping=0.3)
+    b.tendon("drive", ["j1", "j2"], [1.0, -1.0])
+    b.actuator("s0", "j0", gainprm=(20.0, 0, 0), biastype=1, biasprm=(0, -20.0, -1.5), ctrlrange=(-1.5, 1.5))
+    b.actuator("s1", "j1", gainprm=(15.0, 0, 0), biastype=1, biasprm=(0, -15.0, -1.0), ctrlrange=(-1.5, 1.5), forcelimited=True, forcerange=(-1.0, 1.0), gear=1.5)
+    b.actuator("v2", tendon="drive", gainprm=(0.8, 0, 0), biastype=1, biasprm=(0, 0, -0.8), ctrlrange=(-2, 2))
+    m = b.compile()
+    task = make_task(TASK_COPYSTATE, [(3, 0, 1.0), (3, 0, 0.1)], traces=[(OBJ_SITE, tip)])
+    q = np.array([0.5, -0.4, 0.3]); v = np.array([2.0, -3.0, 1.0])
+    defaults = dict(N=6, P=4, sigma=(0.5, 0.0), interp=2, horizon=80, state=np.concatenate([q, v]), mocap=np.zeros(0))
+    return m, task, defaults
+
+
 def filter_arm(timestep=0.005):
     """Test model for activation states (na > 0): a three-link arm whose joints are driven through a first-order filter (the
     swimmer's dyntype="filter"), an exact filter with a position servo's affine bias and a clamped integrator; a fourth, plain
@@ -714,4 +738,4 @@ def terrain_balls(timestep=0.004):
     return m, task, defaults
 
 
-REGISTRY = {"particle_timevarying": particle_task, "particle_fixed": lambda: particle_task(fixed=True), "filter_arm": filter_arm, "ball_chain_friction": lambda: ball_chain(tendon_frictionloss=0.3), "quadruped_hill": quadruped_hill, "terrain_balls": terrain_balls, "walker": walker, "acrobot": acrobot, "ball_chain": ball_chain, "cylinder_pile": cylinder_pile, "humanoid_stand": humanoid_stand, "humanoid_walk": humanoid_walk, "particle": particle, "cartpole": cartpole, "quadruped": quadruped, "humanoid_track": humanoid_track, "shadow_hand": shadow_hand}
+REGISTRY = {"servo_arm": servo_arm, "particle_timevarying": particle_task, "particle_fixed": lambda: particle_task(fixed=True), "filter_arm": filter_arm, "ball_chain_friction": lambda: ball_chain(tendon_frictionloss=0.3), "quadruped_hill": quadruped_hill, "terrain_balls": terrain_balls, "walker": walker, "acrobot": acrobot, "ball_chain": ball_chain, "cylinder_pile": cylinder_pile, "humanoid_stand": humanoid_stand, "humanoid_walk": humanoid_walk, "particle": particle, "cartpole": cartpole, "quadruped": quadruped, "humanoid_track": humanoid_track, "shadow_hand": shadow_hand}

@@ -1006,10 +1006,39 @@ void oracle_step(const OModel *om, OData *d) {
   /* Euler, implicit in joint damping */
   int damped = 0;
   for (int i = 0; i < nv; i++) if (m->dof_damping[i] > 0) damped = 1;
+  const int fast = m->integrator == MJPC_INT_IMPLICITFAST;
+  if (fast) {
+    for (int t = 0; t < m->ntendon; t++) if (m->tendon_damping && m->tendon_damping[t] != 0) damped = 1;
+    for (int i = 0; i < m->nu; i++) if (m->actuator_biastype[i] == MJPC_BIAS_AFFINE && m->actuator_biasprm[3 * i + 2] != 0) damped = 1;
+  }
   double *qacc = d->qacc;
   if (damped) {
     o_copy(d->qH, d->qM, nv * nv);
     for (int i = 0; i < nv; i++) d->qH[i * nv + i] += h * m->dof_damping[i];
+    if (fast) {
+      /* mjINT_IMPLICITFAST: M - h dF/dv with the velocity derivatives of the passive and actuator forces (mjd_smooth_vel without the
+       * Coriolis term): tendon damping  -b J^T J,  affine actuator bias  prm2 moment^T moment (zero while the force is clamped) */
+      double *row = d->work + 2 * nv;
+      for (int t = 0; t < m->ntendon; t++) {
+        double b = m->tendon_damping ? m->tendon_damping[t] : 0;
+        if (b == 0) continue;
+        o_zero(row, nv);
+        for (int w = m->tendon_adr[t]; w < m->tendon_adr[t] + m->tendon_num[t]; w++) row[m->jnt_dofadr[m->wrap_objid[w]]] += m->wrap_prm[w];
+        for (int i = 0; i < nv; i++) for (int j = 0; j < nv; j++) d->qH[i * nv + j] += h * b * row[i] * row[j];
+      }
+      for (int a = 0; a < m->nu; a++) {
+        double kv = m->actuator_biastype[a] == MJPC_BIAS_AFFINE ? m->actuator_biasprm[3 * a + 2] : 0;
+        if (kv == 0) continue;
+        if (m->actuator_forcelimited[a] && (d->actuator_force[a] <= m->actuator_forcerange[2 * a] || d->actuator_force[a] >= m->actuator_forcerange[2 * a + 1])) continue;
+        double gear = m->actuator_gear[a];
+        o_zero(row, nv);
+        if (m->actuator_trntype[a] == MJPC_TRN_TENDON) {
+          int t = m->actuator_trnid[a];
+          for (int w = m->tendon_adr[t]; w < m->tendon_adr[t] + m->tendon_num[t]; w++) row[m->jnt_dofadr[m->wrap_objid[w]]] += gear * m->wrap_prm[w];
+        } else row[m->jnt_dofadr[m->actuator_trnid[a]]] += gear;
+        for (int i = 0; i < nv; i++) for (int j = 0; j < nv; j++) d->qH[i * nv + j] -= h * kv * row[i] * row[j];
+      }
+    }
     chol_factor(d->qLD2, d->qH, nv);
     double *rhs = d->work, *sol = d->work + nv;
     for (int i = 0; i < nv; i++) rhs[i] = d->qfrc_smooth[i] + d->qfrc_constraint[i];

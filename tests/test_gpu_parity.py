@@ -78,6 +78,18 @@ def test_limited_ball_joints_and_tendon_spring_damper_cross_branch_limit():
     assert allc["diag"][:, 2].max() >= 2 and not out["failure"].any()        # limit rows were active
 
 
+def test_implicitfast_integrator():
+    """mjINT_IMPLICITFAST: the integration solve uses M - h dF/dv with the velocity terms of the servos (dropped while a force sits on
+    its range) and the tendon damping; same trajectories as the oracle, and different from Euler's on this stiff arm."""
+    from mujoco_mpc_amd.modelgen import servo_arm
+    m, task, d = servo_arm()
+    out, ref, allc = _compare(m, task, d, 4, 80, 12, (0.5, 0.0), 2, 1e-8)
+    assert not out["failure"].any()
+    m0, task0, _ = servo_arm(integrator=0)
+    out0, ref0, allc0 = _compare(m0, task0, d, 4, 80, 12, (0.5, 0.0), 2, 1e-8)
+    assert _rel(allc0["states"], allc["states"]) > 1e-3
+
+
 def test_activation_states():
     """na > 0: the state rows are [qpos, qvel, act]; filter / filterexact / clamped-integrator actuators next to a plain motor."""
     from mujoco_mpc_amd.modelgen import filter_arm

@@ -26,6 +26,7 @@ def _rel(a, b):
                                                    ("terrain_balls", 3, 60, 6, (0.5, 0.0), 1e-5),   # height field: prisms through the portal-refinement collider
                                                    ("cylinder_pile", 3, 50, 6, (0.5, 0.0), 1e-5),   # cylinder-box / cylinder-cylinder through the portal-refinement collider
                                                    ("particle_timevarying", 5, 51, 6, (0.3, 0.0), 1e-12), ("particle_fixed", 5, 51, 6, (0.3, 0.0), 1e-12),   # registry Particle / ParticleFixed
+                                                   ("servo_arm", 4, 80, 6, (0.5, 0.0), 1e-9),       # mjINT_IMPLICITFAST: velocity servos, saturating force range, damped tendon
                                                    ("filter_arm", 4, 80, 6, (0.4, 0.0), 1e-9),      # activation states: filter / filterexact / clamped integrator actuators
                                                    ("ball_chain", 4, 60, 6, (0.4, 0.0), 1e-5),      # limited ball joints, tendon spring / damper / cross-branch limit
                                                    ("humanoid_track", 16, 30, 4, (0.15, 0.0), 1e-5),
@@ -157,7 +158,7 @@ def test_models_the_engine_cannot_roll_out_are_refused_at_create():
         else:
             assert n < 0 and expect in lib.mjpc_hip_last_error().decode(), lib.mjpc_hip_last_error()
     option("solver", 0, "Newton"); option("solver", 1, "Newton"); option("solver", 2, None)
-    option("integrator", 1, "Euler"); option("integrator", 3, "Euler")
+    option("integrator", 1, "Euler"); option("integrator", 2, "Euler"); option("integrator", 3, None)        # RK4, implicit refused; implicitfast accepted
     option("noslip_iterations", 3, "noslip"); option("neq", 1, "equality")
     option("disableflags", 1 << 6, "disableflags"); option("disableflags", 1 << 14, "disableflags")          # gravity, eulerdamp
     option("disableflags", (1 << 0) | (1 << 2) | (1 << 3) | (1 << 4) | (1 << 12), None)

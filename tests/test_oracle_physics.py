@@ -510,6 +510,34 @@ def test_tendon_spring_and_damper_closed_form():
     assert np.allclose(m2["tendon_lengthspring"], 0.0)
 
 
+def test_implicitfast_integrator_closed_form():
+    """mjINT_IMPLICITFAST on one hinge with a position servo (kp, kv) and joint damping b:  v' = v + h tau / (I + h (b + g^2 kv)),
+    tau = g (kp (u - g q) - kv g v) - b v;  Euler keeps only b in the denominator; with the servo force on its range the velocity
+    term drops out of the denominator again."""
+    h, kp, kv, bdamp, g = 0.01, 30.0, 2.0, 0.1, 1.5
+    inertia = 2.0 * (0.5 ** 2 + 0.4 * 0.1 ** 2)
+
+    def build(integrator, forcerange=None):
+        b = ModelBuilder(timestep=h, gravity=(0, 0, 0), contact=False, integrator=integrator)
+        l1 = b.body("l1", 0)
+        b.joint(l1, "h", HINGE, axis=(0, 1, 0), damping=bdamp)
+        b.geom(l1, "g", SPHERE, size=(0.1,), pos=(0, 0, -0.5), mass=2.0)
+        b.actuator("s", "h", gainprm=(kp, 0, 0), biastype=1, biasprm=(0, -kp, -kv), gear=g, ctrlrange=(-1, 1),
+                   forcelimited=forcerange is not None, forcerange=forcerange or (0, 0))
+        m = b.compile()
+        return ol.Oracle(m, make_task(3, [(1, 0, 1.0), (1, 0, 1.0)]))
+    q, v, u = 0.2, 1.5, 0.6
+    frc = kp * (u - g * q) - kv * g * v
+    tau = g * frc - bdamp * v
+    for integ, extra in ((0, 0.0), (3, g * g * kv)):
+        q1, v1, *_ = build(integ).step([q], [v], ctrl=[u], nstep=1)
+        assert v1[0] == pytest.approx(v + h * tau / (inertia + h * (bdamp + extra)), rel=1e-12)
+        assert q1[0] == pytest.approx(q + h * v1[0], rel=1e-12)
+    lim = 0.5 * abs(frc)                                                     # the servo saturates: force = -lim, no velocity derivative
+    q1, v1, *_ = build(3, (-lim, lim)).step([q], [v], ctrl=[u], nstep=1)
+    assert v1[0] == pytest.approx(v + h * (g * np.sign(frc) * lim - bdamp * v) / (inertia + h * bdamp), rel=1e-12)
+
+
 def test_activation_states_closed_forms():
     """mj_fwdActuation / mj_advance with stateful actuators (na > 0): filter act' = (ctrl - act) / tau under Euler, filterexact with
     the exact decay, a clamped integrator; the force of a stateful actuator is gain * act (velocity of a free hinge follows)."""

@@ -34,6 +34,7 @@ enum {
 enum { MJPC_CONE_PYRAMIDAL = 0, MJPC_CONE_ELLIPTIC = 1 };
 enum { MJPC_SOL_NEWTON = 2, MJPC_INT_EULER = 0, MJPC_INT_IMPLICITFAST = 3 };
 /* model features outside this view (MjpcHipModel.unsupported) */
+enum { MJPC_EQ_CONNECT = 0, MJPC_EQ_WELD = 1, MJPC_EQ_JOINT = 2, MJPC_EQ_TENDON = 3 };      /* mjtEq */
 enum { MJPC_DYN_NONE = 0, MJPC_DYN_INTEGRATOR = 1, MJPC_DYN_FILTER = 2, MJPC_DYN_FILTEREXACT = 3 };   /* mjtDyn */
 enum { MJPC_UNSUP_FLUID = 1,          /* opt.density / viscosity / wind non-zero */
        MJPC_UNSUP_GRAVCOMP = 2,       /* body_gravcomp */
@@ -112,7 +113,7 @@ typedef struct MjpcHipModel {
                             * tendon damping and in the velocity term of affine actuator biases - position / velocity servos with kv - unless the
                             * force sits on its forcerange; no Coriolis derivative).  RK4 and the full implicit integrator are refused */
   int noslip_iterations;   /* must be 0 */
-  int neq;                 /* number of equality constraints: must be 0 (none of the colliding / planning tasks here has one) */
+  int neq;                 /* number of equality constraints (eq_* below): connect and joint equalities; weld / tendon / flex are refused */
   int unsupported;         /* MJPC_UNSUP_* bits found by whoever fills this view in parts of mjModel the view does not carry
                             * (integration/hip_sampling_planner.cc: FillModelView); non-zero is refused at create */
   /* mjStatistic */
@@ -141,6 +142,12 @@ typedef struct MjpcHipModel {
   const double *geom_solref, *geom_solimp, *geom_margin, *geom_gap, *geom_rbound;
   /* <contact><exclude>: (body1 << 16) + body2, as mjModel.exclude_signature */
   const int *exclude_signature;
+  /* equality constraints [neq] (mj_instantiateEquality): MJPC_EQ_CONNECT obj = the two bodies (obj2 may be the world 0), eq_data[0..2]
+   * / [3..5] = the anchor in either body frame; MJPC_EQ_JOINT obj = joint1 and joint2 (or -1), eq_data[0..4] = polycoef of
+   * q1 - q1_0 = poly(q2 - q2_0).  eq_active0 = 0 rows are left out (no run-time activation).  All NULL when neq = 0 */
+  const int *eq_type, *eq_obj1id, *eq_obj2id, *eq_active0;
+  const double *eq_data;            /* 11 per equality (mjNEQDATA) */
+  const double *eq_solref, *eq_solimp;   /* 2 / 5 per equality */
   /* sites */
   const int *site_bodyid;
   const double *site_pos, *site_quat;

@@ -52,7 +52,7 @@ static void FillModelView(const mjModel* m, MjpcHipModel& v, std::vector<int>& j
                           std::vector<int>& trnid, std::vector<int>& tendon_limited, std::vector<int>& wrap_objid,
                           std::vector<double>& gainprm, std::vector<double>& biasprm, std::vector<double>& gear,
                           std::vector<double>& wrap_prm, std::vector<double>& mesh_vert, std::vector<double>& hfield_size,
-                          std::vector<double>& hfield_data, std::vector<int>& act_i, std::vector<double>& dynprm) {
+                          std::vector<double>& hfield_data, std::vector<int>& act_i, std::vector<double>& dynprm, std::vector<int>& eq_active) {
   std::memset(&v, 0, sizeof(v));
   v.nq = m->nq; v.nv = m->nv; v.nu = m->nu; v.na = m->na; v.nbody = m->nbody; v.njnt = m->njnt; v.ngeom = m->ngeom;
   v.nsite = m->nsite; v.nmocap = m->nmocap; v.nuserdata = m->nuserdata; v.nkey = m->nkey; v.nexclude = m->nexclude;
@@ -97,6 +97,10 @@ static void FillModelView(const mjModel* m, MjpcHipModel& v, std::vector<int>& j
   v.geom_friction = m->geom_friction; v.geom_solmix = m->geom_solmix; v.geom_solref = m->geom_solref;
   v.geom_solimp = m->geom_solimp; v.geom_margin = m->geom_margin; v.geom_gap = m->geom_gap; v.geom_rbound = m->geom_rbound;
   v.exclude_signature = m->exclude_signature;
+  // equality constraints: same layout (mjNEQDATA = 11, mjNREF = 2, mjNIMP = 5); eq_active0 is mjtByte
+  eq_active = Widen(m->eq_active0, m->neq);
+  v.eq_type = m->eq_type; v.eq_obj1id = m->eq_obj1id; v.eq_obj2id = m->eq_obj2id; v.eq_active0 = eq_active.data();
+  v.eq_data = m->eq_data; v.eq_solref = m->eq_solref; v.eq_solimp = m->eq_solimp;
   v.site_bodyid = m->site_bodyid; v.site_pos = m->site_pos; v.site_quat = m->site_quat;
   trntype.clear(); trnid.clear(); gainprm.clear(); biasprm.clear(); gear.clear();
   for (int i = 0; i < m->nu; i++) {
@@ -186,7 +190,7 @@ void HipSamplingPlanner::Initialize(mjModel* model, const Task& task) {
   sliding_plan_ = n.sampling_sliding_plan;
   if (num_trajectory_ > kMaxTrajectoryHip) mju_error_i("Too many trajectories, %d is the maximum allowed.", kMaxTrajectoryHip);
   FillModelView(model, model_view_, jnt_limited_, ctrllimited_, forcelimited_, biastype_, trntype_, trnid_, tendon_limited_,
-                wrap_objid_, gainprm_, biasprm_, gear_, wrap_prm_, mesh_vert_, hfield_size_, hfield_data_, act_i_, dynprm_);
+                wrap_objid_, gainprm_, biasprm_, gear_, wrap_prm_, mesh_vert_, hfield_size_, hfield_data_, act_i_, dynprm_, eq_active_);
   FillTaskView(task, model, task_view_, norm_, trace_type_, trace_id_, task_int_, task_dbl_);
   mjpc_hip::SetErrorHandler([](const char* msg) { mju_error("HipSamplingPlanner: %s", msg); });
   impl_.Initialize(&model_view_, &task_view_, n);           // creates the engines (model may have changed: old ones dropped)

@@ -18,6 +18,7 @@ c_int_p = C.POINTER(C.c_int)
 
 _MODEL_INT_SIZES = ["nq", "nv", "nu", "na", "nbody", "njnt", "ngeom", "nsite", "nmocap", "nuserdata", "nkey", "nexclude", "ntendon", "nwrap", "nmesh", "nmeshvert", "nhfield", "nhfielddata"]
 _OPTIONAL_TENDON = ("tendon_stiffness", "tendon_damping", "tendon_lengthspring", "tendon_frictionloss", "tendon_solref_fri", "tendon_solimp_fri")
+_OPTIONAL_EQ = ("eq_type", "eq_obj1id", "eq_obj2id", "eq_active0", "eq_data", "eq_solref", "eq_solimp")
 _OPTIONAL_ACT = ("actuator_dyntype", "actuator_actadr", "actuator_actlimited", "actuator_dynprm", "actuator_actrange")
 _OPTION_DEFAULTS = dict(enableflags=0, solver=2, integrator=0, noslip_iterations=0, neq=0, unsupported=0)
 _OPTIONAL_MESH = ("nmesh", "nmeshvert", "geom_dataid", "mesh_vertadr", "mesh_vertnum", "mesh_vert", "nhfield", "nhfielddata", "hfield_nrow",
@@ -48,7 +49,9 @@ class MjpcHipModel(C.Structure):
                                   "geom_group", "geom_priority"]]
         + [(n, c_double_p) for n in ["geom_size", "geom_pos", "geom_quat", "geom_friction", "geom_solmix",
                                      "geom_solref", "geom_solimp", "geom_margin", "geom_gap", "geom_rbound"]]
-        + [("exclude_signature", c_int_p), ("site_bodyid", c_int_p), ("site_pos", c_double_p), ("site_quat", c_double_p)]
+        + [("exclude_signature", c_int_p)]
+        + [(n, c_int_p) for n in ["eq_type", "eq_obj1id", "eq_obj2id", "eq_active0"]] + [(n, c_double_p) for n in ["eq_data", "eq_solref", "eq_solimp"]]
+        + [("site_bodyid", c_int_p), ("site_pos", c_double_p), ("site_quat", c_double_p)]
         + [(n, c_int_p) for n in ["actuator_trntype", "actuator_trnid", "actuator_ctrllimited", "actuator_forcelimited", "actuator_biastype"]]
         + [(n, c_double_p) for n in ["actuator_gainprm", "actuator_biasprm", "actuator_gear", "actuator_ctrlrange",
                                      "actuator_forcerange"]]
@@ -119,6 +122,8 @@ class CModel:
                 nt = int(model["ntendon"])
                 v = (np.tile([0.02, 1.0], nt) if name == "tendon_solref_fri" else np.tile([0.9, 0.95, 0.001, 0.5, 2.0], nt) if name == "tendon_solimp_fri"
                      else np.zeros(nt * (2 if name == "tendon_lengthspring" else 1)))
+            elif name in _OPTIONAL_EQ and name not in model:            # models built before equality constraints existed: none
+                v = np.zeros(0)
             elif name in _OPTIONAL_ACT and name not in model:           # models built before activation states existed: none
                 nu_ = int(model["nu"])
                 v = -np.ones(nu_) if name == "actuator_actadr" else np.zeros(nu_ * (2 if name == "actuator_actrange" else 1))

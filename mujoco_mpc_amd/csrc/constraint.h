@@ -77,6 +77,43 @@ DEV void make_noncontact_rows(Ctx &c, int *nsingle_out, int *n_nc_out) {
     nefc += tot;
   }
   int nlim_end = nefc;
+  // equality constraints (mj_instantiateEquality; MuJoCo lists them first: same constraint set): static general rows.  They ride
+  // the friction-loss cost with an unreachable friction loss: |D jar| never gets there, so the row is quadratic on both sides
+  if (M.neq) {
+    if (nefc + M.neqrow > M.nefcmax) c.warning |= WARN_CNSTRFULL;
+    else {
+      PFOR(k, M.neq) {
+        const int *et = MI(eq_tab) + 4 * k; const double *ep = MD(eq_prm) + 18 * k;
+        int r0 = nefc + et[3], nr = 1;
+        double pos[3] = {0, 0, 0}, diag;
+        if (et[0] == 2) {            // joint: (q1 - q1_0) - poly(q2 - q2_0)
+          int q1 = MIH(jnt_qposadr)[et[1]];
+          pos[0] = c.qpos[q1] - MDH(qpos0)[q1];
+          diag = MD(dof_invweight0)[MIH(jnt_dofadr)[et[1]]];
+          if (et[2] >= 0) {
+            int q2 = MIH(jnt_qposadr)[et[2]];
+            double dif = c.qpos[q2] - MDH(qpos0)[q2];
+            pos[0] -= ep[0] + dif * (ep[1] + dif * (ep[2] + dif * (ep[3] + dif * ep[4])));
+            diag += MD(dof_invweight0)[MIH(jnt_dofadr)[et[2]]];
+          } else pos[0] -= ep[0];
+        } else {                     // connect: anchor of body 1 - anchor of body 2, world frame
+          int b1 = et[1], b2 = et[2];
+          double p1[3], p2[3];
+          d_mulmatvec3(p1, c.xmat + 9 * b1, ep); d_mulmatvec3(p2, c.xmat + 9 * b2, ep + 3);
+          for (int q = 0; q < 3; q++) pos[q] = (p1[q] + c.xpos[3 * b1 + q]) - (p2[q] + c.xpos[3 * b2 + q]);
+          diag = MDH(body_invweight0)[2 * b1] + MDH(body_invweight0)[2 * b2];
+          nr = 3;
+        }
+        for (int q = 0; q < nr; q++) {
+          int r = r0 + q;
+          c.efc_type[r] = CNSTR_EQUALITY; c.efc_id[r] = k; c.efc_dof[r] = r0;
+          c.efc_floss[r] = 1e300; c.efc_pos[r] = pos[q]; c.efc_margin[r] = 0; c.efc_diag[r] = diag;
+        }
+      }
+      nefc += M.neqrow;
+    }
+  }
+  int neq_end = nefc;
   // tendon friction loss (mjCNSTR_FRICTION_TENDON): static general rows (MuJoCo lists them before the limits: same constraint set)
   if (M.ntfric) {
     if (nefc + M.ntfric > M.nefcmax) c.warning |= WARN_CNSTRFULL;
@@ -147,8 +184,35 @@ DEV void make_noncontact_rows(Ctx &c, int *nsingle_out, int *n_nc_out) {
     int r = M.nfric + rr;
     c.efc_J[r * nvp + MIH(jnt_dofadr)[c.efc_id[r]]] = c.efc_floss[r]; c.efc_floss[r] = 0;
   }
-  PFOR(rr, ntf_end - nlim_end) {
-    int r = nlim_end + rr, t = MI(tfric_id)[c.efc_id[r]];
+  if (neq_end > nlim_end) PFOR(k, M.neq) {
+    const int *et = MI(eq_tab) + 4 * k; const double *ep = MD(eq_prm) + 18 * k;
+    int r0 = nlim_end + et[3];
+    if (et[0] == 2) {
+      c.efc_J[r0 * nvp + MIH(jnt_dofadr)[et[1]]] = 1;
+      if (et[2] >= 0) {
+        int q2 = MIH(jnt_qposadr)[et[2]];
+        double dif = c.qpos[q2] - MDH(qpos0)[q2];
+        c.efc_J[r0 * nvp + MIH(jnt_dofadr)[et[2]]] = -(ep[1] + dif * (2 * ep[2] + dif * (3 * ep[3] + dif * 4 * ep[4])));
+      }
+    } else {       // point Jacobians of the two anchors (cdof about the root's subtree com)
+      int b1 = et[1], b2 = et[2];
+      double p1[3], p2[3];
+      d_mulmatvec3(p1, c.xmat + 9 * b1, ep); d_mulmatvec3(p2, c.xmat + 9 * b2, ep + 3);
+      for (int q = 0; q < 3; q++) { p1[q] += c.xpos[3 * b1 + q]; p2[q] += c.xpos[3 * b2 + q]; }
+      for (int d = 0; d < nv; d++) {
+        unsigned long long bit = 1ull << d;
+        int in1 = (MDM()[b1] & bit) != 0, in2 = (MDM()[b2] & bit) != 0;
+        if (!in1 && !in2) continue;
+        const double *cd = c.cdof + 6 * d;
+        double jp[3] = {0, 0, 0}, off[3], t[3];
+        if (in1) { d_sub3(off, p1, c.subtree_com + 3 * MIH(body_rootid)[b1]); d_cross(t, cd, off); for (int q = 0; q < 3; q++) jp[q] += cd[3 + q] + t[q]; }
+        if (in2) { d_sub3(off, p2, c.subtree_com + 3 * MIH(body_rootid)[b2]); d_cross(t, cd, off); for (int q = 0; q < 3; q++) jp[q] -= cd[3 + q] + t[q]; }
+        for (int q = 0; q < 3; q++) c.efc_J[(r0 + q) * nvp + d] = jp[q];
+      }
+    }
+  }
+  PFOR(rr, ntf_end - neq_end) {
+    int r = neq_end + rr, t = MI(tfric_id)[c.efc_id[r]];
     for (int w = MI(tendon_adr)[t]; w < MI(tendon_adr)[t] + MI(tendon_num)[t]; w++) c.efc_J[r * nvp + MI(wrap_dofadr)[w]] = MD(wrap_prm)[w];
   }
   PFOR(rr, nball_end - ntf_end) {
@@ -288,6 +352,9 @@ DEV void make_impedance(Ctx &c, int r0, int r1, int with_contacts) {
     if (type == CNSTR_FRICTION_DOF) {
       for (int k = 0; k < 2; k++) solref[k] = MD(dof_solref)[2 * id + k];
       for (int k = 0; k < 5; k++) solimp[k] = MD(dof_solimp)[5 * id + k];
+    } else if (type == CNSTR_EQUALITY) {
+      for (int k = 0; k < 2; k++) solref[k] = MD(eq_prm)[18 * id + 11 + k];
+      for (int k = 0; k < 5; k++) solimp[k] = MD(eq_prm)[18 * id + 13 + k];
     } else if (type == CNSTR_FRICTION_TENDON) {
       for (int k = 0; k < 2; k++) solref[k] = MD(tfric_prm)[8 * id + 1 + k];
       for (int k = 0; k < 5; k++) solimp[k] = MD(tfric_prm)[8 * id + 3 + k];
@@ -303,7 +370,12 @@ DEV void make_impedance(Ctx &c, int r0, int r1, int with_contacts) {
       for (int k = 0; k < 5; k++) solimp[k] = cc[CON_SOLIMP + k];
       first = (r == EFC_CON_R0(id)) || type == CNSTR_CONTACT_PYRAMIDAL;
     }
-    double imp = impedance(solimp, c.efc_pos[r], c.efc_margin[r]);
+    double imp_pos = c.efc_pos[r];
+    if (type == CNSTR_EQUALITY && MI(eq_tab)[4 * id] == 0) {      // connect: one impedance from the norm of its three residuals
+      const double *ps = c.efc_pos + c.efc_dof[r];
+      imp_pos = d_sqrt(ps[0] * ps[0] + ps[1] * ps[1] + ps[2] * ps[2]);
+    }
+    double imp = impedance(solimp, imp_pos, c.efc_margin[r]);
     double dmax = d_clip(solimp[1], 0.0001, 0.9999);
     double K, B;
     if (solref[0] > 0) {
@@ -314,7 +386,7 @@ DEV void make_impedance(Ctx &c, int r0, int r1, int with_contacts) {
       K = d_div(-solref[0], fmax(D_MINVAL, dmax * dmax));
       B = d_div(-solref[1], fmax(D_MINVAL, dmax));
     }
-    if (type <= CNSTR_FRICTION_TENDON || !first) K = 0;
+    if (type == CNSTR_FRICTION_DOF || type == CNSTR_FRICTION_TENDON || !first) K = 0;
     c.efc_R[r] = fmax(D_MINVAL, d_div(1 - imp, imp) * c.efc_diag[r]);
     c.efc_aref[r] = -B * vel - K * imp * (c.efc_pos[r] - c.efc_margin[r]);
   }

@@ -349,6 +349,10 @@ DEV_NOINLINE void ph_constraints(KP Kc, int t) {
 DEV_NOINLINE void ph_noncontact(KP Kc, int t) {
   Ctx c; ctx_open(c, Kc, 1);
   int nsingle, n_nc;
+#if MJPC_SIDE_COM
+  // the anchors' point Jacobians of connect constraints need cdof / subtree_com, which the side wave is producing
+  if (c.M->neq_connect) { if (!flag_wait(c.misc + HX_COM, t + 1)) c.warning |= WARN_SYNC; }
+#endif
   make_noncontact_rows(c, &nsingle, &n_nc);
   if (LANE == 0) { c.misc[25] = nsingle; c.misc[26] = n_nc; }
   flag_set(c.misc + 24, t + 1);

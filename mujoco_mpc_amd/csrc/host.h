@@ -131,7 +131,18 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
   if (m->solver != MJPC_SOL_NEWTON) { p.error = "only the Newton solver (mjSOL_NEWTON) is implemented"; return false; }
   if (m->integrator != MJPC_INT_EULER && m->integrator != MJPC_INT_IMPLICITFAST) { p.error = "only the Euler (with implicit joint damping) and implicitfast integrators are implemented"; return false; }
   if (m->noslip_iterations != 0) { p.error = "noslip_iterations > 0 not supported"; return false; }
-  if (m->neq != 0) { p.error = "equality constraints (neq > 0) not supported"; return false; }
+  for (int e = 0; e < m->neq; e++) {
+    if (!m->eq_type || !m->eq_obj1id || !m->eq_obj2id || !m->eq_active0 || !m->eq_data || !m->eq_solref || !m->eq_solimp) { p.error = "neq > 0 but the eq_* tables are missing"; return false; }
+    if (!m->eq_active0[e]) continue;
+    int ty = m->eq_type[e], a = m->eq_obj1id[e], b = m->eq_obj2id[e];
+    if (ty != MJPC_EQ_CONNECT && ty != MJPC_EQ_JOINT) { p.error = "equality " + std::to_string(e) + ": only connect and joint equalities are implemented (weld / tendon / flex refused)"; return false; }
+    if (ty == MJPC_EQ_CONNECT && (a < 0 || a >= nb || b < 0 || b >= nb)) { p.error = "equality " + std::to_string(e) + ": body id out of range"; return false; }
+    if (ty == MJPC_EQ_JOINT) {
+      if (a < 0 || a >= nj || b >= nj) { p.error = "equality " + std::to_string(e) + ": joint id out of range"; return false; }
+      if ((m->jnt_type[a] != MJPC_JNT_HINGE && m->jnt_type[a] != MJPC_JNT_SLIDE) || (b >= 0 && m->jnt_type[b] != MJPC_JNT_HINGE && m->jnt_type[b] != MJPC_JNT_SLIDE)) {
+        p.error = "equality " + std::to_string(e) + ": joint equalities couple hinge / slide joints"; return false; }
+    }
+  }
   if (m->unsupported != 0) { p.error = "the model uses features outside the engine's model view (MJPC_UNSUP_* mask " + std::to_string(m->unsupported) + ": fluid forces, gravity compensation, non-fixed actuator gains, actuator dynamics, spatial tendons, ...)"; return false; }
   { const int known = MJPC_DSBL_CONSTRAINT | MJPC_DSBL_EQUALITY | MJPC_DSBL_FRICTIONLOSS | MJPC_DSBL_LIMIT | MJPC_DSBL_CONTACT | MJPC_DSBL_SENSOR | MJPC_DSBL_MIDPHASE;
     if (m->disableflags & ~known) { p.error = "disableflags " + std::to_string(m->disableflags) + ": only constraint / frictionloss / limit / contact can be disabled"; return false; }
@@ -357,6 +368,32 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
         for (int k = a; k >= 0; k = pattern_parent(nv, M.tree_ok, m->dof_parentid, k)) if (k == b) anc = true;
         if (!anc) M.limit_cross = 1;
       }
+  // equality constraints: static rows right behind the single-entry rows; table per equality [type, obj1, obj2, first row],
+  // parameters [data 11, solref 2, solimp 5]; rows whose dofs do not lie on one branch force dense Hessian builds (limit_cross)
+  { std::vector<int> tab; std::vector<double> prm; int rows = 0, ncon = 0;
+    const bool no_eq = m->disableflags & (MJPC_DSBL_CONSTRAINT | MJPC_DSBL_EQUALITY);
+    for (int e = 0; e < m->neq && !no_eq; e++) if (m->eq_active0[e]) {
+      int ty = m->eq_type[e], a = m->eq_obj1id[e], b = m->eq_obj2id[e];
+      tab.push_back(ty); tab.push_back(a); tab.push_back(b); tab.push_back(rows);
+      for (int k = 0; k < 11; k++) prm.push_back(m->eq_data[11 * e + k]);
+      for (int k = 0; k < 2; k++) prm.push_back(m->eq_solref[2 * e + k]);
+      for (int k = 0; k < 5; k++) prm.push_back(m->eq_solimp[5 * e + k]);
+      rows += ty == MJPC_EQ_CONNECT ? 3 : 1; ncon += ty == MJPC_EQ_CONNECT;
+      // dofs of the row(s): every pair must be ancestor-related in the elimination tree, else the pattern does not hold them
+      std::vector<int> dofs;
+      if (ty == MJPC_EQ_CONNECT) { for (int bb : {a, b}) for (int x = bb; x > 0; x = m->body_parentid[x]) for (int k = 0; k < m->body_dofnum[x]; k++) dofs.push_back(m->body_dofadr[x] + k); }
+      else { dofs.push_back(m->jnt_dofadr[a]); if (b >= 0) dofs.push_back(m->jnt_dofadr[b]); }
+      for (size_t x = 0; x < dofs.size(); x++) for (size_t y = 0; y < x; y++) {
+        int i = dofs[x], j = dofs[y];
+        if (i == j) continue;
+        if (i < j) std::swap(i, j);
+        bool anc = false;
+        for (int k = i; k >= 0; k = pattern_parent(nv, M.tree_ok, m->dof_parentid, k)) if (k == j) anc = true;
+        if (!anc) M.limit_cross = 1;
+      }
+    }
+    M.neq = (int)tab.size() / 4; M.neqrow = rows; M.neq_connect = ncon;
+    M.eq_tab = as_off<int>(put_i(p, tab.data(), tab.size())); M.eq_prm = as_off<double>(put_d(p, prm.data(), prm.size())); }
   // tendons with friction loss: one friction row each (tendon id; frictionloss, solref[2], solimp[5])
   { std::vector<int> ids; std::vector<double> prm;
     static const double def_ref[2] = {0.02, 1.0}, def_imp[5] = {0.9, 0.95, 0.001, 0.5, 2.0};
@@ -417,7 +454,7 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
     M.nidrv = (int)ec.size();
     if (M.nidrv) M.any_damping = 1;
     M.idrv_e = as_off<int>(put_i(p, ei.data(), ei.size())); M.idrv_c = as_off<double>(put_d(p, ec.data(), ec.size())); }
-  if (M.nefcmax < M.nfric + M.ntfric + 2) M.nefcmax = M.nfric + M.ntfric + 2;
+  if (M.nefcmax < M.nfric + M.ntfric + M.neqrow + 2) M.nefcmax = M.nfric + M.ntfric + M.neqrow + 2;
   // task region (re-packable by set_task)
   p.task_i0 = p.ib.size(); p.task_d0 = p.db.size();
   pack_task(p, t);
@@ -469,7 +506,7 @@ static inline DevModel relocate(const PackedModel &p, const int *ibase, const do
   fi(M.level_adr); fi(M.level_body); fi(M.subtree_adr); fi(M.subtree_list); fi(M.chain_adr); fi(M.chain_list); fi(M.mpair_i); fi(M.mpair_j); fi(M.hpair_i); fi(M.hpair_j); fi(M.zpair_i); fi(M.zpair_j);
   { const double *q = reinterpret_cast<const double *>(M.body_dofmask); fd(q); M.body_dofmask = reinterpret_cast<const unsigned long long *>(q); }
   { const double *q = reinterpret_cast<const double *>(M.body_patmask); fd(q); M.body_patmask = reinterpret_cast<const unsigned long long *>(q); }
-  fi(M.pair_g1); fi(M.pair_g2); fi(M.fric_dof); fi(M.limit_jnt); fi(M.limit_ball); fi(M.ray_geom); fi(M.tpass_id); fd(M.tpass_prm); fi(M.tfric_id); fd(M.tfric_prm); fi(M.idrv_e); fd(M.idrv_c);
+  fi(M.pair_g1); fi(M.pair_g2); fi(M.fric_dof); fi(M.limit_jnt); fi(M.limit_ball); fi(M.ray_geom); fi(M.tpass_id); fd(M.tpass_prm); fi(M.tfric_id); fd(M.tfric_prm); fi(M.idrv_e); fd(M.idrv_c); fi(M.eq_tab); fd(M.eq_prm);
   DevTask &T = M.task;
   fi(T.dim_norm_residual); fi(T.norm); fi(T.num_norm_parameter); fi(T.trace_objtype); fi(T.trace_objid); fi(T.int_data);
   fd(T.weight); fd(T.norm_parameter); fd(T.parameters); fd(T.dbl_data);

@@ -73,7 +73,7 @@ static inline int pattern_parent(int nv, int tree_ok, const int *dof_parentid, i
 }
 
 enum { DYN_NONE = 0, DYN_INTEGRATOR = 1, DYN_FILTER = 2, DYN_FILTEREXACT = 3 };      // MJPC_DYN_* (mjtDyn)
-enum { CNSTR_FRICTION_DOF = 1, CNSTR_FRICTION_TENDON = 2, CNSTR_LIMIT_JOINT = 3, CNSTR_LIMIT_TENDON = 4, CNSTR_CONTACT_FRICTIONLESS = 5, CNSTR_CONTACT_PYRAMIDAL = 6, CNSTR_CONTACT_ELLIPTIC = 7 };
+enum { CNSTR_EQUALITY = 0, CNSTR_FRICTION_DOF = 1, CNSTR_FRICTION_TENDON = 2, CNSTR_LIMIT_JOINT = 3, CNSTR_LIMIT_TENDON = 4, CNSTR_CONTACT_FRICTIONLESS = 5, CNSTR_CONTACT_PYRAMIDAL = 6, CNSTR_CONTACT_ELLIPTIC = 7 };
 enum { STATE_SATISFIED = 0, STATE_QUADRATIC = 1, STATE_LINEARNEG = 2, STATE_LINEARPOS = 3, STATE_CONE = 4 };
 enum { WARN_BADQPOS = 1, WARN_BADQVEL = 2, WARN_BADQACC = 4, WARN_CONTACTFULL = 8, WARN_CNSTRFULL = 16, WARN_RAY = 32, WARN_SYNC = 64, WARN_UNSUPPORTED = 128 };
 
@@ -116,6 +116,8 @@ struct DevModel {
   const double *wrap_prm, *tendon_range, *tendon_margin, *tendon_solref_lim, *tendon_solimp_lim, *tendon_invweight0;
   const int *tpass_id;                      // tendons with passive forces
   const double *tpass_prm;                  // [4 each] stiffness, damping, spring dead band lo / hi
+  int neq, neqrow, neq_connect;             // active equality constraints (eq_tab: type, obj1, obj2, first row; eq_prm: data 11, solref 2, solimp 5)
+  const int *eq_tab; const double *eq_prm;
   int nidrv;                                // implicitfast: entries of -dF/dv beyond joint damping (idrv_e: i, j, actuator or -1; idrv_c: coefficient)
   const int *idrv_e; const double *idrv_c;
   const int *tfric_id;                      // tendons with friction loss

@@ -133,6 +133,7 @@ class ModelBuilder:
         self.actuators: list[dict] = []
         self.keys: list[tuple] = []
         self.tendons: list[dict] = []
+        self.equalities: list[dict] = []
         self.key_mpos = None          # optional [nkey, 3*nmocap]
         self.excludes: list[tuple] = []
         self.nuserdata = 0
@@ -226,6 +227,14 @@ class ModelBuilder:
 
     def key(self, name, qpos):
         self.keys.append((name, np.array(qpos, float)))
+
+    def connect(self, body1, body2, anchor, solref=DEF_SOLREF, solimp=DEF_SOLIMP, active=True):
+        """MJCF <connect>: the point `anchor` (body1 frame) stays where it is relative to body2 (0 = the world) at qpos0"""
+        self.equalities.append(dict(type=0, obj1=body1, obj2=body2, anchor=tuple(anchor), solref=tuple(solref), solimp=tuple(solimp), active=active))
+
+    def joint_equality(self, joint1, joint2=None, polycoef=(0, 1, 0, 0, 0), solref=DEF_SOLREF, solimp=DEF_SOLIMP, active=True):
+        """MJCF <equality><joint>: q1 - q1_0 = poly(q2 - q2_0) (joint names; joint2 None: q1 - q1_0 = polycoef[0])"""
+        self.equalities.append(dict(type=2, obj1=joint1, obj2=joint2, polycoef=tuple(polycoef), solref=tuple(solref), solimp=tuple(solimp), active=active))
 
     def exclude(self, body1, body2):
         self.excludes.append((body1, body2))
@@ -542,6 +551,24 @@ class ModelBuilder:
                 Jt[jnt_dofadr[wrap_objid[tadr[ti] + k]]] = wrap_prm[tadr[ti] + k]
             tinv[ti] = Jt @ Minv @ Jt
         M["tendon_invweight0"] = tinv
+        # ---- equality constraints (the second anchor of a connect is where the first one sits at qpos0)
+        E = self.equalities
+        M["neq"] = len(E)
+        M["eq_type"] = np.array([e["type"] for e in E], np.int32); M["eq_active0"] = np.array([int(e["active"]) for e in E], np.int32)
+        o1, o2 = [], []; data = np.zeros((len(E), 11))
+        xpos0, _, xmat0, _, _ = kinematics(M, M["qpos0"])
+        for k, e in enumerate(E):
+            if e["type"] == 0:
+                b1, b2 = e["obj1"], e["obj2"]
+                o1.append(b1); o2.append(b2)
+                world = xpos0[b1] + xmat0[b1] @ np.array(e["anchor"], float)
+                data[k, :3] = e["anchor"]; data[k, 3:6] = xmat0[b2].T @ (world - xpos0[b2])
+            else:
+                o1.append(jnames.index(e["obj1"])); o2.append(-1 if e["obj2"] is None else jnames.index(e["obj2"]))
+                data[k, :5] = e["polycoef"]
+        M["eq_obj1id"] = np.array(o1, np.int32); M["eq_obj2id"] = np.array(o2, np.int32); M["eq_data"] = data
+        M["eq_solref"] = np.array([e["solref"] for e in E], float).reshape(len(E), 2)
+        M["eq_solimp"] = np.array([e["solimp"] for e in E], float).reshape(len(E), 5)
         km = self.key_mpos if self.key_mpos is not None else np.zeros((nkey, 3 * nmocap))
         M["key_mpos"] = np.asarray(km, float).reshape(nkey, 3 * nmocap) if nkey else np.zeros((0, 3 * nmocap))
         M["meaninertia"] = max(float(np.mean(np.diag(Mq))) if nv else 1.0, MINVAL)

@@ -87,6 +87,40 @@ def particle_task(fixed=False, timestep=0.01):
     return m, task, defaults
 
 
+def linkage(timestep=0.004):
+    """Test model for equality constraints: a gripper-like pair of fingers on one palm whose hinge angles are coupled by a joint
+    equality (different branches: dense Hessian builds), a four-bar loop closed by a connect constraint between two chain ends, and a
+    free ball hung from the world by a connect; a box on the floor for contacts next to them.  Residual = state (TASK_COPYSTATE)."""
+    b = ModelBuilder(timestep=timestep, gravity=(0, 0, -9.81), contact=True)
+    b.geom(0, "floor", PLANE, pos=(0, 0, -0.6), size=(2, 2, 0.1))
+    palm = b.body("palm", 0, pos=(0, 0, 0))
+    b.joint(palm, "wrist", HINGE, axis=(0, 1, 0), damping=0.05, armature=0.01)
+    b.geom(palm, "palm_g", BOX, size=(0.06, 0.03, 0.02), mass=0.4)
+    for name, x in (("fl", -0.05), ("fr", 0.05)):
+        f = b.body(name, palm, pos=(x, 0, -0.02))
+        b.joint(f, name + "_j", HINGE, axis=(0, 1, 0), damping=0.02, armature=0.002, limited=True, range=(-1.0, 1.0))
+        b.geom(f, name + "_g", CAPSULE, size=(0.01, 0), fromto=(0, 0, 0, 0, 0, -0.12), mass=0.05)
+    b.joint_equality("fl_j", "fr_j", polycoef=(0.0, -1.0, 0.1, 0, 0))            # mirrored closing with a slight quadratic term
+    # four-bar: two chains from the world, ends tied together
+    a1 = b.body("a1", 0, pos=(0.4, 0, 0)); b.joint(a1, "a1_j", HINGE, axis=(0, 1, 0), damping=0.01); b.geom(a1, "a1_g", CAPSULE, size=(0.012, 0), fromto=(0, 0, 0, 0, 0, -0.2), mass=0.1)
+    a2 = b.body("a2", a1, pos=(0, 0, -0.2)); b.joint(a2, "a2_j", HINGE, axis=(0, 1, 0), damping=0.01); b.geom(a2, "a2_g", CAPSULE, size=(0.012, 0), fromto=(0, 0, 0, 0.15, 0, 0), mass=0.1)
+    c1 = b.body("c1", 0, pos=(0.55, 0, 0)); b.joint(c1, "c1_j", HINGE, axis=(0, 1, 0), damping=0.01); b.geom(c1, "c1_g", CAPSULE, size=(0.012, 0), fromto=(0, 0, 0, 0, 0, -0.2), mass=0.1)
+    b.connect(a2, c1, (0.15, 0, 0))
+    ball = b.body("ball", 0, pos=(-0.4, 0, -0.3)); b.joint(ball, "ball_f", FREE); b.geom(ball, "ball_g", SPHERE, size=(0.04,), mass=0.2)
+    b.connect(ball, 0, (0, 0, 0.3), solref=(0.01, 1.0))
+    box = b.body("box", 0, pos=(0.1, 0, -0.55)); b.joint(box, "box_f", FREE); b.geom(box, "box_g", BOX, size=(0.05, 0.05, 0.05), mass=0.3)
+    tip = b.site(a2, "tip", pos=(0.15, 0, 0))
+    b.actuator("wrist_m", "wrist", gear=0.5, ctrlrange=(-1, 1))
+    b.actuator("fl_m", "fl_j", gear=0.2, ctrlrange=(-1, 1))
+    b.actuator("bar_m", "a1_j", gear=0.5, ctrlrange=(-1, 1))
+    m = b.compile()
+    task = make_task(TASK_COPYSTATE, [(m["nq"], 0, 1.0), (m["nv"], 0, 0.1)], traces=[(OBJ_SITE, tip)])
+    q = m["qpos0"].copy(); v = np.zeros(m["nv"])
+    v[0] = 1.0; v[1] = 2.0; v[2] = -2.0; v[3] = 1.5; v[6:9] = [0.8, 0.3, 0.0]
+    defaults = dict(N=6, P=4, sigma=(0.5, 0.0), interp=2, horizon=80, state=np.concatenate([q, v]), mocap=np.zeros(0))
+    return m, task, defaults
+
+
 def servo_arm(timestep=0.005, integrator=3):
     """Test model for mjINT_IMPLICITFAST: a three-link arm on position servos with velocity gains (kv: the bias' velocity term), one
     of them with a force range it saturates, a velocity servo through a fixed tendon along the chain, and a damped tendon; stiff
@@ -738,4 +772,4 @@ def terrain_balls(timestep=0.004):
     return m, task, defaults
 
 
-REGISTRY = {"servo_arm": servo_arm, "particle_timevarying": particle_task, "particle_fixed": lambda: particle_task(fixed=True), "filter_arm": filter_arm, "ball_chain_friction": lambda: ball_chain(tendon_frictionloss=0.3), "quadruped_hill": quadruped_hill, "terrain_balls": terrain_balls, "walker": walker, "acrobot": acrobot, "ball_chain": ball_chain, "cylinder_pile": cylinder_pile, "humanoid_stand": humanoid_stand, "humanoid_walk": humanoid_walk, "particle": particle, "cartpole": cartpole, "quadruped": quadruped, "humanoid_track": humanoid_track, "shadow_hand": shadow_hand}
+REGISTRY = {"linkage": linkage, "servo_arm": servo_arm, "particle_timevarying": particle_task, "particle_fixed": lambda: particle_task(fixed=True), "filter_arm": filter_arm, "ball_chain_friction": lambda: ball_chain(tendon_frictionloss=0.3), "quadruped_hill": quadruped_hill, "terrain_balls": terrain_balls, "walker": walker, "acrobot": acrobot, "ball_chain": ball_chain, "cylinder_pile": cylinder_pile, "humanoid_stand": humanoid_stand, "humanoid_walk": humanoid_walk, "particle": particle, "cartpole": cartpole, "quadruped": quadruped, "humanoid_track": humanoid_track, "shadow_hand": shadow_hand}

@@ -53,6 +53,7 @@ OModel *oracle_create(const MjpcHipModel *src, const MjpcHipTask *task) {
   CD(geom_size, 3 * ng); CD(geom_pos, 3 * ng); CD(geom_quat, 4 * ng); CD(geom_friction, 3 * ng); CD(geom_solmix, ng);
   CD(geom_solref, 2 * ng); CD(geom_solimp, 5 * ng); CD(geom_margin, ng); CD(geom_gap, ng); CD(geom_rbound, ng);
   CI(exclude_signature, src->nexclude);
+  if (src->neq > 0) { CI(eq_type, src->neq); CI(eq_obj1id, src->neq); CI(eq_obj2id, src->neq); CI(eq_active0, src->neq); CD(eq_data, 11 * src->neq); CD(eq_solref, 2 * src->neq); CD(eq_solimp, 5 * src->neq); }
   CI(site_bodyid, ns); CD(site_pos, 3 * ns); CD(site_quat, 4 * ns);
   CI(actuator_trntype, nu); CI(actuator_trnid, nu); CI(actuator_ctrllimited, nu); CI(actuator_forcelimited, nu); CI(actuator_biastype, nu);
   CD(actuator_gainprm, 3 * nu); CD(actuator_biasprm, 3 * nu); CD(actuator_gear, nu);

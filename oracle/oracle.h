@@ -29,7 +29,7 @@ typedef struct OContact {
 } OContact;
 
 /* constraint row types / states (values follow mjtConstraint / mjtConstraintState) */
-enum { O_CNSTR_FRICTION_DOF = 1, O_CNSTR_FRICTION_TENDON = 2, O_CNSTR_LIMIT_JOINT = 3, O_CNSTR_LIMIT_TENDON = 4, O_CNSTR_CONTACT_FRICTIONLESS = 5,
+enum { O_CNSTR_EQUALITY = 0, O_CNSTR_FRICTION_DOF = 1, O_CNSTR_FRICTION_TENDON = 2, O_CNSTR_LIMIT_JOINT = 3, O_CNSTR_LIMIT_TENDON = 4, O_CNSTR_CONTACT_FRICTIONLESS = 5,
        O_CNSTR_CONTACT_PYRAMIDAL = 6, O_CNSTR_CONTACT_ELLIPTIC = 7 };
 enum { O_STATE_SATISFIED = 0, O_STATE_QUADRATIC = 1, O_STATE_LINEARNEG = 2, O_STATE_LINEARPOS = 3, O_STATE_CONE = 4 };
 

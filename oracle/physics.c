@@ -391,6 +391,40 @@ static void make_constraint(const OModel *om, OData *d) {
   int nv = m->nv;
   d->nefc = 0; d->nf = 0; d->nl = 0;
   const int no_fric = m->disableflags & (MJPC_DSBL_CONSTRAINT | MJPC_DSBL_FRICTIONLOSS), no_limit = m->disableflags & (MJPC_DSBL_CONSTRAINT | MJPC_DSBL_LIMIT);
+  const int no_eq = m->disableflags & (MJPC_DSBL_CONSTRAINT | MJPC_DSBL_EQUALITY);
+  /* equality constraints (mj_instantiateEquality): connect = the anchor of body 1 minus the anchor of body 2 (3 rows), joint =
+   * (q1 - q1_0) - poly(q2 - q2_0) (1 row); always active, two-sided */
+  for (int e = 0; e < m->neq && !no_eq; e++) if (m->eq_active0[e]) {
+    const double *data = m->eq_data + 11 * e;
+    if (m->eq_type[e] == MJPC_EQ_CONNECT) {
+      int b1 = m->eq_obj1id[e], b2 = m->eq_obj2id[e];
+      double p1[3], p2[3], *j1 = d->work, *j2 = d->work + 3 * nv;
+      o_mulmatvec3(p1, d->xmat + 9 * b1, data); o_add3(p1, p1, d->xpos + 3 * b1);
+      o_mulmatvec3(p2, d->xmat + 9 * b2, data + 3); o_add3(p2, p2, d->xpos + 3 * b2);
+      jac_point(om, d, j1, NULL, p1, b1); jac_point(om, d, j2, NULL, p2, b2);
+      for (int k = 0; k < 3; k++) {
+        int r = add_row(om, d, O_CNSTR_EQUALITY, e); if (r < 0) return;
+        for (int i = 0; i < nv; i++) d->efc_J[r * nv + i] = j1[k * nv + i] - j2[k * nv + i];
+        d->efc_pos[r] = p1[k] - p2[k];
+        o_copy(d->efc_solref + 2 * r, m->eq_solref + 2 * e, 2); o_copy(d->efc_solimp + 5 * r, m->eq_solimp + 5 * e, 5);
+        d->efc_diagApprox[r] = m->body_invweight0[2 * b1] + m->body_invweight0[2 * b2];
+      }
+    } else if (m->eq_type[e] == MJPC_EQ_JOINT) {
+      int j1 = m->eq_obj1id[e], j2 = m->eq_obj2id[e];
+      int r = add_row(om, d, O_CNSTR_EQUALITY, e); if (r < 0) return;
+      double pos = d->qpos[m->jnt_qposadr[j1]] - m->qpos0[m->jnt_qposadr[j1]];
+      d->efc_J[r * nv + m->jnt_dofadr[j1]] = 1;
+      d->efc_diagApprox[r] = m->dof_invweight0[m->jnt_dofadr[j1]];
+      if (j2 >= 0) {
+        double dif = d->qpos[m->jnt_qposadr[j2]] - m->qpos0[m->jnt_qposadr[j2]];
+        pos -= data[0] + dif * (data[1] + dif * (data[2] + dif * (data[3] + dif * data[4])));
+        d->efc_J[r * nv + m->jnt_dofadr[j2]] = -(data[1] + dif * (2 * data[2] + dif * (3 * data[3] + dif * 4 * data[4])));
+        d->efc_diagApprox[r] += m->dof_invweight0[m->jnt_dofadr[j2]];
+      } else pos -= data[0];
+      d->efc_pos[r] = pos;
+      o_copy(d->efc_solref + 2 * r, m->eq_solref + 2 * e, 2); o_copy(d->efc_solimp + 5 * r, m->eq_solimp + 5 * e, 5);
+    } else { d->unsupported++; }
+  }
   /* friction loss */
   for (int i = 0; i < nv; i++) if (!no_fric && m->dof_frictionloss[i] > 0) {
     int r = add_row(om, d, O_CNSTR_FRICTION_DOF, i); if (r < 0) return;
@@ -521,7 +555,10 @@ static void make_impedance(const OModel *om, OData *d) {
     if (d->efc_type[r] == O_CNSTR_CONTACT_ELLIPTIC) dim = d->contact[d->efc_id[r]].dim;
     if (pyramidal) dim = 2 * (d->contact[d->efc_id[r]].dim - 1);
     const double *solref = d->efc_solref + 2 * r, *solimp = d->efc_solimp + 5 * r;
-    double imp = impedance(solimp, d->efc_pos[r], d->efc_margin[r]);
+    const int equality = d->efc_type[r] == O_CNSTR_EQUALITY;
+    double imp_pos = d->efc_pos[r];
+    if (equality && m->eq_type[d->efc_id[r]] == MJPC_EQ_CONNECT) { dim = 3; imp_pos = o_norm(d->efc_pos + r, 3); }    /* one impedance from |residual| */
+    double imp = impedance(solimp, imp_pos, d->efc_margin[r]);
     double dmax = o_clip(solimp[1], 0.0001, 0.9999);
     double K, B;
     if (solref[0] > 0) {
@@ -535,7 +572,7 @@ static void make_impedance(const OModel *om, OData *d) {
     }
     for (int k = 0; k < dim; k++) {
       int q = r + k;
-      int friction_row = (d->efc_type[q] <= O_CNSTR_FRICTION_TENDON) || (k > 0 && !pyramidal);
+      int friction_row = (d->efc_type[q] == O_CNSTR_FRICTION_DOF || d->efc_type[q] == O_CNSTR_FRICTION_TENDON) || (k > 0 && !pyramidal && !equality);
       double Kq = friction_row ? 0 : K;
       d->efc_KBIP[4 * q] = Kq; d->efc_KBIP[4 * q + 1] = B; d->efc_KBIP[4 * q + 2] = imp; d->efc_KBIP[4 * q + 3] = 0;
       d->efc_R[q] = fmax(O_MINVAL, (1 - imp) / imp * d->efc_diagApprox[q]);
@@ -548,7 +585,7 @@ static void make_impedance(const OModel *om, OData *d) {
       c->mu = c->friction[0] * sqrt(R1 / R[0]);
       double Rpy = 2 * c->mu * c->mu * R[0];
       for (int k = 0; k < dim; k++) R[k] = Rpy;
-    } else if (dim > 1) {   /* elliptic cone: friction regularisation from impratio, regularised mu */
+    } else if (dim > 1 && !equality) {   /* elliptic cone: friction regularisation from impratio, regularised mu */
       OContact *c = d->contact + d->efc_id[r];
       double *R = d->efc_R + r;
       R[1] = R[0] / fmax(O_MINVAL, m->impratio);
@@ -706,7 +743,8 @@ static double constraint_update(const OModel *om, OData *d, const double *jar, d
   for (int i = 0; i < d->nefc; i++) {
     double D = d->efc_D[i], R = d->efc_R[i], x = jar[i];
     int type = d->efc_type[i];
-    if (type <= O_CNSTR_FRICTION_TENDON) {
+    if (type == O_CNSTR_EQUALITY) { cost += 0.5 * D * x * x; force[i] = -D * x; state[i] = O_STATE_QUADRATIC; }
+    else if (type <= O_CNSTR_FRICTION_TENDON) {
       double f = d->efc_frictionloss[i];
       if (x <= -R * f) { cost += -0.5 * R * f * f - f * x; force[i] = f; state[i] = O_STATE_LINEARNEG; }
       else if (x >= R * f) { cost += -0.5 * R * f * f + f * x; force[i] = -f; state[i] = O_STATE_LINEARPOS; }
@@ -764,7 +802,8 @@ static LSPoint ls_eval(const OModel *om, const OData *d, const double *jar, cons
   for (int i = 0; i < d->nefc; i++) {
     double D = d->efc_D[i], R = d->efc_R[i], x = jar[i] + a * jv[i], v = jv[i];
     int type = d->efc_type[i];
-    if (type <= O_CNSTR_FRICTION_TENDON) {
+    if (type == O_CNSTR_EQUALITY) { p.cost += 0.5 * D * x * x; p.d1 += D * x * v; p.d2 += D * v * v; }
+    else if (type <= O_CNSTR_FRICTION_TENDON) {
       double f = d->efc_frictionloss[i];
       if (x <= -R * f) { p.cost += -0.5 * R * f * f - f * x; p.d1 += -f * v; }
       else if (x >= R * f) { p.cost += -0.5 * R * f * f + f * x; p.d1 += f * v; }

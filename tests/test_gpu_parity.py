@@ -78,6 +78,17 @@ def test_limited_ball_joints_and_tendon_spring_damper_cross_branch_limit():
     assert allc["diag"][:, 2].max() >= 2 and not out["failure"].any()        # limit rows were active
 
 
+def test_equality_constraints():
+    """mj_instantiateEquality on the device: a joint equality coupling two fingers (cross-branch: dense Hessian builds), a four-bar
+    loop closed by a connect, a free ball pinned to the world by a connect, next to contacts; same trajectories as the oracle."""
+    from mujoco_mpc_amd.modelgen import linkage
+    m, task, d = linkage()
+    out, ref, allc = _compare(m, task, d, 4, 80, 12, (0.5, 0.0), 2, 1e-7)
+    assert not out["failure"].any() and allc["diag"][:, 2].max() >= 7                   # 1 + 3 + 3 equality rows always there
+    s = allc["states"]
+    assert np.abs(s[:, :, 1] - (-s[:, :, 2] + 0.1 * s[:, :, 2] ** 2)).max() < 5e-3       # the fingers stay coupled
+
+
 def test_implicitfast_integrator():
     """mjINT_IMPLICITFAST: the integration solve uses M - h dF/dv with the velocity terms of the servos (dropped while a force sits on
     its range) and the tendon damping; same trajectories as the oracle, and different from Euler's on this stiff arm."""

@@ -26,6 +26,7 @@ def _rel(a, b):
                                                    ("terrain_balls", 3, 60, 6, (0.5, 0.0), 1e-5),   # height field: prisms through the portal-refinement collider
                                                    ("cylinder_pile", 3, 50, 6, (0.5, 0.0), 1e-5),   # cylinder-box / cylinder-cylinder through the portal-refinement collider
                                                    ("particle_timevarying", 5, 51, 6, (0.3, 0.0), 1e-12), ("particle_fixed", 5, 51, 6, (0.3, 0.0), 1e-12),   # registry Particle / ParticleFixed
+                                                   ("linkage", 4, 80, 6, (0.5, 0.0), 1e-9),         # equality constraints: joint coupling across branches, four-bar connect, pinned free body
                                                    ("servo_arm", 4, 80, 6, (0.5, 0.0), 1e-9),       # mjINT_IMPLICITFAST: velocity servos, saturating force range, damped tendon
                                                    ("filter_arm", 4, 80, 6, (0.4, 0.0), 1e-9),      # activation states: filter / filterexact / clamped integrator actuators
                                                    ("ball_chain", 4, 60, 6, (0.4, 0.0), 1e-5),      # limited ball joints, tendon spring / damper / cross-branch limit
@@ -159,12 +160,20 @@ def test_models_the_engine_cannot_roll_out_are_refused_at_create():
             assert n < 0 and expect in lib.mjpc_hip_last_error().decode(), lib.mjpc_hip_last_error()
     option("solver", 0, "Newton"); option("solver", 1, "Newton"); option("solver", 2, None)
     option("integrator", 1, "Euler"); option("integrator", 2, "Euler"); option("integrator", 3, None)        # RK4, implicit refused; implicitfast accepted
-    option("noslip_iterations", 3, "noslip"); option("neq", 1, "equality")
+    option("noslip_iterations", 3, "noslip")
     option("disableflags", 1 << 6, "disableflags"); option("disableflags", 1 << 14, "disableflags")          # gravity, eulerdamp
     option("disableflags", (1 << 0) | (1 << 2) | (1 << 3) | (1 << 4) | (1 << 12), None)
     option("enableflags", 1 << 0, "override"); option("enableflags", 1 << 1, None)
     option("unsupported", 1, "outside the engine's model view")
     option("na", 2, "stateful actuators")                   # activation states must belong to integrator / filter actuators
+
+    check(lambda b, body: b.connect(body, 0, (0, 0, 0.1)), None)          # connect / joint equalities have rows; a weld does not
+    b = ModelBuilder()
+    body = b.body("a", 0, pos=(0, 0, 1)); b.joint(body, "f", FREE); b.geom(body, "g", SPHERE, size=(0.1,))
+    b.connect(body, 0, (0, 0, 0.1))
+    m = b.compile(); m["eq_type"][0] = 1
+    cm = capi.CModel(m, task)
+    assert lib.mjpc_hip_layout_bytes(ctypes.byref(cm.c_model), ctypes.byref(cm.c_task), 1) < 0 and b"only connect and joint equalities" in lib.mjpc_hip_last_error()
 
     def userdata(b, body):
         b.nuserdata = 3

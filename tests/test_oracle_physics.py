@@ -510,6 +510,47 @@ def test_tendon_spring_and_damper_closed_form():
     assert np.allclose(m2["tendon_lengthspring"], 0.0)
 
 
+def test_equality_constraints_against_equivalent_joints():
+    """mj_instantiateEquality.  (i) connect: a free ball pinned to the world 0.3 m above its centre swings like the same ball on a
+    hinge at that point (soft constraint: agreement to 2 mm over half a second, pin error below 1 mm); (ii) joint equality q1 = q2
+    between two identical pendulums, only one of them driven: both follow the motion of one pendulum with half the torque."""
+    h, L = 0.002, 0.3
+    b = ModelBuilder(timestep=h, contact=False)
+    ball = b.body("ball", 0, pos=(0, 0, -L)); b.joint(ball, "f", FREE); b.geom(ball, "g", SPHERE, size=(0.04,), mass=0.2)
+    b.connect(ball, 0, (0, 0, L), solref=(0.004, 1.0))
+    m = b.compile()
+    o = ol.Oracle(m, _copy_task(m))
+    b2 = ModelBuilder(timestep=h, contact=False)
+    l = b2.body("l", 0); b2.joint(l, "h", HINGE, axis=(0, 1, 0)); b2.geom(l, "g", SPHERE, size=(0.04,), pos=(0, 0, -L), mass=0.2)
+    m2 = b2.compile()
+    o2 = ol.Oracle(m2, _copy_task(m2))
+    vx = 0.8
+    q, v = np.array([0, 0, -L, 1, 0, 0, 0.0]), np.array([vx, 0, 0, 0, -vx / L, 0])
+    q2, v2 = np.array([0.0]), np.array([-vx / L])
+    for _ in range(5):
+        q, v, *_ = o.step(q, v, nstep=50); q2, v2, *_ = o2.step(q2, v2, nstep=50)
+        centre = np.array([-L * np.sin(q2[0]), 0, -L * np.cos(q2[0])])
+        assert np.abs(q[:3] - centre).max() < 2e-3
+        w, x, y, z = q[3:7]
+        top = q[:3] + L * np.array([2 * (x * z + w * y), 2 * (y * z - w * x), 1 - 2 * (x * x + y * y)])       # the pinned point
+        assert np.abs(top).max() < 1e-3
+    # (ii) joint equality
+    def pend(n, coupled, gear):
+        bb = ModelBuilder(timestep=h, contact=False)
+        for k in range(n):
+            l = bb.body(f"l{k}", 0, pos=(k, 0, 0)); bb.joint(l, f"h{k}", HINGE, axis=(0, 1, 0), damping=0.01)
+            bb.geom(l, f"g{k}", SPHERE, size=(0.05,), pos=(0, 0, -0.4), mass=0.5)
+        if coupled:
+            bb.joint_equality("h0", "h1", solref=(0.004, 1.0))
+        bb.actuator("m", "h0", gear=gear, ctrlrange=(-1, 1))
+        mm = bb.compile()
+        return ol.Oracle(mm, _copy_task(mm))
+    oc, o1 = pend(2, True, 1.0), pend(1, False, 0.5)
+    qc, vc, *_ = oc.step([0.3, 0.3], [0, 0], ctrl=[0.8], nstep=400)
+    q1, v1, *_ = o1.step([0.3], [0], ctrl=[0.8], nstep=400)
+    assert abs(qc[0] - qc[1]) < 2e-3 and abs(qc[0] - q1[0]) < 5e-3 and abs(vc[0] - v1[0]) < 2e-2
+
+
 def test_implicitfast_integrator_closed_form():
     """mjINT_IMPLICITFAST on one hinge with a position servo (kp, kv) and joint damping b:  v' = v + h tau / (I + h (b + g^2 kv)),
     tau = g (kp (u - g q) - kv g v) - b v;  Euler keeps only b in the denominator; with the servo force on its range the velocity

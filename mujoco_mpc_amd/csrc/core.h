@@ -415,7 +415,8 @@ DEV_SOLVE_PHASE void ph_solve(KP Kc, int last, int t) {
   if (LANE == 0) c.misc[HX_KIND] = 0;           // release the helper wave
   flag_set(c.misc + HX_JOB, ++c.hseq);
 #endif
-  if (!last && bad_values(c.qacc, c.M->nv)) c.warning |= WARN_BADQACC;
+  // (a step that already overflowed a buffer fails with that code alone: what the solver made of the truncated rows does not matter)
+  if (!last && !(c.warning & (WARN_CONTACTFULL | WARN_CNSTRFULL)) && bad_values(c.qacc, c.M->nv)) c.warning |= WARN_BADQACC;
   ctx_close(c);
 }
 #if MJPC_HELPER

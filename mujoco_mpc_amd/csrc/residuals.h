@@ -394,7 +394,7 @@ DEV void task_residual(Ctx &c, double *residual) {
   } else if (id == 3) {   // copy state (rollout_test.cc:40-60)
     PFOR(i, M.nq) residual[i] = c.qpos[i];
     PFOR(i, M.nv) residual[M.nq + i] = c.qvel[i];
-    if (M.na) PFOR(i, M.na) residual[M.nq + M.nv + i] = C_ACT(c)[i];
+    if (M.na && M.task.num_residual >= M.nq + M.nv + M.na) PFOR(i, M.na) residual[M.nq + M.nv + i] = C_ACT(c)[i];
   } else if (id == 2) {
     residual_quadruped(c, residual);
   } else if (id == 4) {

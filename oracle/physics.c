@@ -1041,6 +1041,7 @@ void oracle_step(const OModel *om, OData *d) {
   if (bad(d->qvel, nv)) d->warning |= MJPC_WARN_BADQVEL;
   if (d->warning) return;
   oracle_forward(om, d);
+  if (d->warning & (MJPC_WARN_CONTACTFULL | MJPC_WARN_CNSTRFULL)) return;      /* the overflow is the failure code; the truncated solve does not matter */
   if (bad(d->qacc, nv)) { d->warning |= MJPC_WARN_BADQACC; return; }
   /* Euler, implicit in joint damping */
   int damped = 0;

@@ -518,7 +518,7 @@ void oracle_residual(const OModel *om, OData *d, double *residual) {
     case MJPC_TASK_COPYSTATE:
       o_copy(residual, d->qpos, m->nq);
       o_copy(residual + m->nq, d->qvel, m->nv);
-      if (m->na > 0) o_copy(residual + m->nq + m->nv, d->act, m->na);      /* the whole state [qpos, qvel, act] */
+      if (m->na > 0 && om->t.num_residual >= m->nq + m->nv + m->na) o_copy(residual + m->nq + m->nv, d->act, m->na);      /* the whole state [qpos, qvel, act] when the task has room for it */
       break;
     case MJPC_TASK_QUADRUPED:
       residual_quadruped(om, d, residual);

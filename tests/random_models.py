@@ -1,6 +1,7 @@
 """Random articulated models for the fuzz parity tests (test infrastructure): random trees of bodies on free / ball / hinge /
 slide joints with limits, damping, armature, friction loss and springs, one or two primitive geoms of every supported type per
-body, motors and position servos, fixed tendons with limits / springs / dampers / friction loss (also across branches), either friction cone,
+body, motors and position servos, fixed tendons with limits / springs / dampers / friction loss (also across branches), joint and connect equalities, stateful
+actuators, either integrator, either friction cone,
 contact dimensions 1 / 3 / 4 / 6.  The residual copies the state."""
 import numpy as np
 
@@ -11,6 +12,16 @@ from mujoco_mpc_amd.modelgen.tasks import OBJ_SITE, TASK_COPYSTATE, make_task
 def _unit(rng, n=3):
     v = rng.normal(size=n)
     return v / np.linalg.norm(v)
+
+
+def _accepted(m):
+    """host-only query: would mjpc_hip_create take this model?"""
+    import ctypes
+    from mujoco_mpc_amd import capi
+    lib = ctypes.CDLL(capi.ENGINE_PATH)
+    lib.mjpc_hip_layout_bytes.argtypes = [ctypes.POINTER(capi.MjpcHipModel), ctypes.POINTER(capi.MjpcHipTask), ctypes.c_int]
+    cm = capi.CModel(m, make_task(TASK_COPYSTATE, [(m["nq"], 0, 1.0), (m["nv"], 0, 0.1)]))
+    return lib.mjpc_hip_layout_bytes(ctypes.byref(cm.c_model), ctypes.byref(cm.c_task), 0) > 0
 
 
 def random_model(seed, portal_pairs=False):
@@ -93,6 +104,18 @@ def random_model(seed, portal_pairs=False):
                      frictionloss=float(rng_fr.choice([0.0, 0.0, 0.1, 0.5])))
             if rng.random() < 0.3:
                 b.position(f"pt{k}", tendon=f"t{k}", kp=4.0, ctrlrange=(-0.3, 0.3))
+    # features added later draw from the second stream, after the tendon draws: equality constraints, stateful actuators, implicitfast
+    if len(scalar_joints) >= 2 and rng_fr.random() < 0.4:
+        js = list(rng_fr.choice(scalar_joints, size=2, replace=False))
+        b.joint_equality(js[0], js[1], polycoef=(0.0, float(rng_fr.choice([-1.0, 1.0]) * rng_fr.uniform(0.5, 1.5)), float(rng_fr.uniform(-0.2, 0.2)), 0, 0))
+    if rng_fr.random() < 0.3:
+        b.connect(b.body_id("loose0"), 0, (0.0, 0.0, float(rng_fr.uniform(0.15, 0.3))))          # the first loose object hangs from the world
+    for a in b.actuators:
+        if a["biastype"] == 0 and rng_fr.random() < 0.3:
+            a["dyntype"] = int(rng_fr.choice([1, 2, 3])); a["dynprm"] = float(rng_fr.uniform(0.02, 0.1))
+            if a["dyntype"] == 1:
+                a["actlimited"] = True; a["actrange"] = (-0.3, 0.3)
+    want_fast = rng_fr.random() < 0.3
     if not b.actuators:
         if scalar_joints:
             b.actuator("m0", scalar_joints[0], gear=1.0)
@@ -103,6 +126,11 @@ def random_model(seed, portal_pairs=False):
             b.actuator("m0", "jx", gear=1.0)
     b.nconmax = 16; b.nefcmax = 72            # (the default 32 / 128 does not fit one CU's LDS at 40 dofs)
     m = b.compile()
+    if want_fast:                                # implicitfast where the engine takes it (velocity terms inside the factorisation pattern)
+        b.integrator = 3
+        m3 = b.compile()
+        if _accepted(m3):
+            m = m3
     task = make_task(TASK_COPYSTATE, [(m["nq"], 0, 1.0), (m["nv"], 0, 0.1)], traces=[(OBJ_SITE, site)])
     q = np.array(m["qpos0"], float)
     v = rng.normal(size=m["nv"]) * 1.5
@@ -110,4 +138,4 @@ def random_model(seed, portal_pairs=False):
         da = m["jnt_dofadr"][m["names"]["joint"][f"loose{k}_free"]]
         p = q[m["jnt_qposadr"][m["names"]["joint"][f"loose{k}_free"]]:][:3]
         v[da:da + 3] = -np.array([p[0], p[1], 0.0]) / 0.75 * rng.uniform(3.0, 5.0) + np.array([0, 0, rng.uniform(0.0, 1.0)])
-    return m, task, dict(state=np.concatenate([q, v]), mocap=np.zeros(0))
+    return m, task, dict(state=np.concatenate([q, v, rng_fr.uniform(-0.2, 0.2, m["na"])]), mocap=np.zeros(0))

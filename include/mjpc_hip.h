@@ -72,9 +72,11 @@ enum {
                                  * dbl_data = the stage goals [nstage][7] (mpos, mquat of task_hill.xml:82-101) for the host Transition */
   MJPC_TASK_PARTICLE_TIMEVARYING = 11, /* mjpc/tasks/particle/particle.cc:30-50 ("Particle"): tip position - Lissajous goal of data->time,
                                  * tip velocity, control (6 residuals); int_data = [tip site] */
-  MJPC_TASK_PARTICLE_FIXED = 12  /* particle.cc:68-73 ("ParticleFixed"): the same with goal = mocap_pos[0..1] */
+  MJPC_TASK_PARTICLE_FIXED = 12, /* particle.cc:68-73 ("ParticleFixed"): the same with goal = mocap_pos[0..1] */
+  MJPC_TASK_QUADROTOR = 13       /* mjpc/tasks/quadrotor/quadrotor.cc:37-60: position - goal, linear / angular velocity, control - hover thrust (13 of
+                                 * the 15 declared residuals are written); int_data = [body, stage]; dbl_data = stage goals [nstage][7] */
 };
-enum { MJPC_TRN_JOINT = 0, MJPC_TRN_TENDON = 3 };   /* mjtTrn values of the supported actuator transmissions */
+enum { MJPC_TRN_JOINT = 0, MJPC_TRN_TENDON = 3, MJPC_TRN_SITE = 4 };   /* mjtTrn values of the supported actuator transmissions */
 enum { MJPC_OBJ_BODY = 1, MJPC_OBJ_XBODY = 2, MJPC_OBJ_GEOM = 5, MJPC_OBJ_SITE = 6 };
 
 /* failure[] bits: why a candidate's rollout stopped (any bit => total_return = MJPC_MAX_RETURN, like
@@ -152,12 +154,14 @@ typedef struct MjpcHipModel {
   const int *site_bodyid;
   const double *site_pos, *site_quat;
   /* actuators (joint or fixed-tendon transmission; gain fixed; bias none/affine: motor, general, position servos) */
-  const int *actuator_trntype;      /* MJPC_TRN_JOINT / MJPC_TRN_TENDON */
-  const int *actuator_trnid;        /* joint id or tendon id (first of the 2 mjModel ints) */
+  const int *actuator_trntype;      /* MJPC_TRN_JOINT / MJPC_TRN_TENDON / MJPC_TRN_SITE (no refsite: the wrench actuator_gear6 in the site frame,
+                                     * motors only - biastype none) */
+  const int *actuator_trnid;        /* joint, tendon or site id (first of the 2 mjModel ints) */
   const int *actuator_ctrllimited, *actuator_forcelimited, *actuator_biastype;
   const double *actuator_gainprm;   /* 3 per actuator (first 3 of mjNGAIN) */
   const double *actuator_biasprm;   /* 3 per actuator (first 3 of mjNBIAS) */
   const double *actuator_gear;      /* 1 per actuator (first of 6) */
+  const double *actuator_gear6;     /* 6 per actuator (mjModel.actuator_gear as it is): read for site transmissions only; may be NULL without them */
   const double *actuator_ctrlrange, *actuator_forcerange;
   /* activation states (na > 0): one state per stateful actuator (actnum 1).  dyntype MJPC_DYN_*: integrator act_dot = ctrl; filter /
    * filterexact act_dot = (ctrl - act) / max(mjMINVAL, dynprm[0]); the force of a stateful actuator is gain * act + bias.  Euler

@@ -33,6 +33,7 @@ int DeviceResidual(const Task& task) {
   if (name == "Particle") return MJPC_TASK_PARTICLE_TIMEVARYING;
   if (name == "ParticleFixed") return MJPC_TASK_PARTICLE_FIXED;
   if (name == "Walker") return MJPC_TASK_WALKER;
+  if (name == "Quadrotor") return MJPC_TASK_QUADROTOR;
   if (name == "Acrobot") return MJPC_TASK_ACROBOT;
   return -1;
 }
@@ -116,7 +117,7 @@ static void FillModelView(const mjModel* m, MjpcHipModel& v, std::vector<int>& j
   biastype = Widen(m->actuator_biastype, m->nu);
   v.actuator_trntype = trntype.data(); v.actuator_trnid = trnid.data();
   v.actuator_ctrllimited = ctrllimited.data(); v.actuator_forcelimited = forcelimited.data(); v.actuator_biastype = biastype.data();
-  v.actuator_gainprm = gainprm.data(); v.actuator_biasprm = biasprm.data(); v.actuator_gear = gear.data();
+  v.actuator_gainprm = gainprm.data(); v.actuator_biasprm = biasprm.data(); v.actuator_gear = gear.data(); v.actuator_gear6 = m->actuator_gear;
   v.actuator_ctrlrange = m->actuator_ctrlrange; v.actuator_forcerange = m->actuator_forcerange;
   act_i.assign(3 * m->nu, 0); dynprm.assign(m->nu, 0.0);
   for (int i = 0; i < m->nu; i++) {

@@ -53,7 +53,7 @@ class MjpcHipModel(C.Structure):
         + [(n, c_int_p) for n in ["eq_type", "eq_obj1id", "eq_obj2id", "eq_active0"]] + [(n, c_double_p) for n in ["eq_data", "eq_solref", "eq_solimp"]]
         + [("site_bodyid", c_int_p), ("site_pos", c_double_p), ("site_quat", c_double_p)]
         + [(n, c_int_p) for n in ["actuator_trntype", "actuator_trnid", "actuator_ctrllimited", "actuator_forcelimited", "actuator_biastype"]]
-        + [(n, c_double_p) for n in ["actuator_gainprm", "actuator_biasprm", "actuator_gear", "actuator_ctrlrange",
+        + [(n, c_double_p) for n in ["actuator_gainprm", "actuator_biasprm", "actuator_gear", "actuator_gear6", "actuator_ctrlrange",
                                      "actuator_forcerange"]]
         + [(n, c_int_p) for n in ["actuator_dyntype", "actuator_actadr", "actuator_actlimited"]]
         + [(n, c_double_p) for n in ["actuator_dynprm", "actuator_actrange"]]
@@ -122,6 +122,8 @@ class CModel:
                 nt = int(model["ntendon"])
                 v = (np.tile([0.02, 1.0], nt) if name == "tendon_solref_fri" else np.tile([0.9, 0.95, 0.001, 0.5, 2.0], nt) if name == "tendon_solimp_fri"
                      else np.zeros(nt * (2 if name == "tendon_lengthspring" else 1)))
+            elif name == "actuator_gear6" and name not in model:      # models built before site transmissions existed
+                v = np.zeros(6 * int(model["nu"]))
             elif name in _OPTIONAL_EQ and name not in model:            # models built before equality constraints existed: none
                 v = np.zeros(0)
             elif name in _OPTIONAL_ACT and name not in model:           # models built before activation states existed: none

@@ -223,28 +223,48 @@ DEV void velocity_stage(Ctx &c, int mfact_seq) {
     }
   }
   SYNC();
-  if (M.ntendon_passive > 0) {
-    // tendon springs (dead band) and dampers, mj_passive: one lane per dof gathers J^T force over the (few) passive tendons
-    PFOR(d, nv) {
-      double acc = c.qfrc_smooth[d];
-      for (int e = 0; e < M.ntendon_passive; e++) {
-        int t = MI(tpass_id)[e];
-        double coef = 0, length = 0, velocity = 0;
-        for (int w = MI(tendon_adr)[t]; w < MI(tendon_adr)[t] + MI(tendon_num)[t]; w++) {
-          double cf = MD(wrap_prm)[w];
-          length += cf * c.qpos[MI(wrap_qposadr)[w]]; velocity += cf * c.qvel[MI(wrap_dofadr)[w]];
-          if (MI(wrap_dofadr)[w] == d) coef += cf;
+  if (M.ntendon_passive + M.nsiteact > 0) {      // (one test for the two rare extras)
+    if (M.nsiteact > 0) {
+      // site transmissions: qfrc += J_site^T (R gear_force; R gear_torque) force, the site Jacobian from cdof about the root's com
+      PFOR(d, nv) {
+        double acc = c.qfrc_smooth[d];
+        const double *cd = c.cdof + 6 * d;
+        for (int k = 0; k < M.nsiteact; k++) {
+          int a = MI(sact_i)[3 * k], s = MI(sact_i)[3 * k + 1], b = MI(sact_i)[3 * k + 2];
+          if (!((MDM()[b] >> d) & 1ull)) continue;
+          double f[3], tq[3], off[3], t[3];
+          d_mulmatvec3(f, c.xmat + 9 * b, MD(sact_g) + 6 * k); d_mulmatvec3(tq, c.xmat + 9 * b, MD(sact_g) + 6 * k + 3);
+          d_sub3(off, c.site_xpos + 3 * s, c.subtree_com + 3 * MIH(body_rootid)[b]);
+          d_cross(t, cd, off);
+          acc += c.actuator_force[a] * ((cd[3] + t[0]) * f[0] + (cd[4] + t[1]) * f[1] + (cd[5] + t[2]) * f[2] + cd[0] * tq[0] + cd[1] * tq[1] + cd[2] * tq[2]);
         }
-        if (coef == 0) continue;
-        const double *pr = MD(tpass_prm) + 4 * e;
-        double frc = 0;
-        if (length > pr[3]) frc = pr[0] * (pr[3] - length); else if (length < pr[2]) frc = pr[0] * (pr[2] - length);
-        frc -= pr[1] * velocity;
-        acc += coef * frc;
+        c.qfrc_smooth[d] = acc;
       }
-      c.qfrc_smooth[d] = acc;
+      SYNC();
     }
-    SYNC();
+    if (M.ntendon_passive > 0) {
+      // tendon springs (dead band) and dampers, mj_passive: one lane per dof gathers J^T force over the (few) passive tendons
+      PFOR(d, nv) {
+        double acc = c.qfrc_smooth[d];
+        for (int e = 0; e < M.ntendon_passive; e++) {
+          int t = MI(tpass_id)[e];
+          double coef = 0, length = 0, velocity = 0;
+          for (int w = MI(tendon_adr)[t]; w < MI(tendon_adr)[t] + MI(tendon_num)[t]; w++) {
+            double cf = MD(wrap_prm)[w];
+            length += cf * c.qpos[MI(wrap_qposadr)[w]]; velocity += cf * c.qvel[MI(wrap_dofadr)[w]];
+            if (MI(wrap_dofadr)[w] == d) coef += cf;
+          }
+          if (coef == 0) continue;
+          const double *pr = MD(tpass_prm) + 4 * e;
+          double frc = 0;
+          if (length > pr[3]) frc = pr[0] * (pr[3] - length); else if (length < pr[2]) frc = pr[0] * (pr[2] - length);
+          frc -= pr[1] * velocity;
+          acc += coef * frc;
+        }
+        c.qfrc_smooth[d] = acc;
+      }
+      SYNC();
+    }
   }
   if (c.K->xfrc_std > 0) {
     // mj_xfrcAccumulate: J^T [force; torque], force applied at the body's inertial frame origin; bodies in ascending order

@@ -152,8 +152,11 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
   if (m->nconmax > 64) { p.error = "nconmax > 64 not supported (one contact per lane in the solver)"; return false; }
   if (m->iterations > 250) { p.error = "solver iterations > 250 not supported (hand-shake sequence numbers)"; return false; }
   for (int i = 0; i < nu; i++)
-    if (m->actuator_trntype[i] != MJPC_TRN_JOINT && m->actuator_trntype[i] != MJPC_TRN_TENDON) {
-      p.error = "actuator " + std::to_string(i) + ": only joint and fixed-tendon transmissions are supported"; return false; }
+    if (m->actuator_trntype[i] == MJPC_TRN_SITE) {
+      if (!m->actuator_gear6 || m->actuator_trnid[i] < 0 || m->actuator_trnid[i] >= ns) { p.error = "actuator " + std::to_string(i) + ": site transmission without actuator_gear6 or with a site id out of range"; return false; }
+      if (m->actuator_biastype[i] != MJPC_BIAS_NONE || (m->actuator_dyntype && m->actuator_dyntype[i] != MJPC_DYN_NONE)) { p.error = "actuator " + std::to_string(i) + ": site transmissions are implemented for plain motors (no bias, no activation)"; return false; }
+    } else if (m->actuator_trntype[i] != MJPC_TRN_JOINT && m->actuator_trntype[i] != MJPC_TRN_TENDON) {
+      p.error = "actuator " + std::to_string(i) + ": only joint, fixed-tendon and site transmissions are supported"; return false; }
   M.na = m->na;
   M.nq = m->nq; M.nv = nv; M.nu = nu; M.nbody = nb; M.njnt = nj; M.ngeom = ng; M.nsite = ns; M.nmocap = m->nmocap;
   M.nkey = m->nkey; M.nvp = NVP_OF(nv); M.ntendon = m->ntendon;
@@ -236,6 +239,7 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
     for (int i = 0; i < nu; i++) {
       adr[i] = (int)da.size();
       int id = m->actuator_trnid[i];
+      if (m->actuator_trntype[i] == MJPC_TRN_SITE) continue;      // configuration-dependent moment: sact_* below
       if (m->actuator_trntype[i] == MJPC_TRN_TENDON) {
         if (id < 0 || id >= m->ntendon) { p.error = "actuator " + std::to_string(i) + ": tendon id out of range"; return false; }
         for (int w = m->tendon_adr[id]; w < m->tendon_adr[id] + m->tendon_num[id]; w++) {
@@ -258,6 +262,22 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
     dadr[nv] = (int)dent.size();
     M.dact_adr = as_off<int>(put_i(p, dadr.data(), dadr.size())); M.dact_e = as_off<int>(put_i(p, dent.data(), dent.size()));
     M.act_coef = as_off<double>(put_d(p, cf.data(), cf.size())); }
+  // site transmissions (mjTRN_SITE, no refsite): [actuator, site, body] and the gear wrench rotated into the body frame
+  { std::vector<int> si; std::vector<double> sg;
+    for (int i = 0; i < nu; i++) if (m->actuator_trntype[i] == MJPC_TRN_SITE) {
+      int s = m->actuator_trnid[i];
+      si.push_back(i); si.push_back(s); si.push_back(m->site_bodyid[s]);
+      const double *q = m->site_quat + 4 * s;
+      double R[9] = {1 - 2 * (q[2] * q[2] + q[3] * q[3]), 2 * (q[1] * q[2] - q[0] * q[3]), 2 * (q[1] * q[3] + q[0] * q[2]),
+                     2 * (q[1] * q[2] + q[0] * q[3]), 1 - 2 * (q[1] * q[1] + q[3] * q[3]), 2 * (q[2] * q[3] - q[0] * q[1]),
+                     2 * (q[1] * q[3] - q[0] * q[2]), 2 * (q[2] * q[3] + q[0] * q[1]), 1 - 2 * (q[1] * q[1] + q[2] * q[2])};
+      for (int part = 0; part < 2; part++) for (int r = 0; r < 3; r++) {
+        const double *g = m->actuator_gear6 + 6 * i + 3 * part;
+        sg.push_back(R[3 * r] * g[0] + R[3 * r + 1] * g[1] + R[3 * r + 2] * g[2]);
+      }
+    }
+    M.nsiteact = (int)si.size() / 3;
+    M.sact_i = as_off<int>(put_i(p, si.data(), si.size())); M.sact_g = as_off<double>(put_d(p, sg.data(), sg.size())); }
   { std::vector<int> wd(m->nwrap), wq(m->nwrap);
     for (int w = 0; w < m->nwrap; w++) { int j = m->wrap_objid[w]; wd[w] = m->jnt_dofadr[j]; wq[w] = m->jnt_qposadr[j]; }
     M.wrap_dofadr = as_off<int>(put_i(p, wd.data(), wd.size())); M.wrap_qposadr = as_off<int>(put_i(p, wq.data(), wq.size())); }
@@ -506,7 +526,7 @@ static inline DevModel relocate(const PackedModel &p, const int *ibase, const do
   fi(M.level_adr); fi(M.level_body); fi(M.subtree_adr); fi(M.subtree_list); fi(M.chain_adr); fi(M.chain_list); fi(M.mpair_i); fi(M.mpair_j); fi(M.hpair_i); fi(M.hpair_j); fi(M.zpair_i); fi(M.zpair_j);
   { const double *q = reinterpret_cast<const double *>(M.body_dofmask); fd(q); M.body_dofmask = reinterpret_cast<const unsigned long long *>(q); }
   { const double *q = reinterpret_cast<const double *>(M.body_patmask); fd(q); M.body_patmask = reinterpret_cast<const unsigned long long *>(q); }
-  fi(M.pair_g1); fi(M.pair_g2); fi(M.fric_dof); fi(M.limit_jnt); fi(M.limit_ball); fi(M.ray_geom); fi(M.tpass_id); fd(M.tpass_prm); fi(M.tfric_id); fd(M.tfric_prm); fi(M.idrv_e); fd(M.idrv_c); fi(M.eq_tab); fd(M.eq_prm);
+  fi(M.pair_g1); fi(M.pair_g2); fi(M.fric_dof); fi(M.limit_jnt); fi(M.limit_ball); fi(M.ray_geom); fi(M.tpass_id); fd(M.tpass_prm); fi(M.tfric_id); fd(M.tfric_prm); fi(M.idrv_e); fd(M.idrv_c); fi(M.eq_tab); fd(M.eq_prm); fi(M.sact_i); fd(M.sact_g);
   DevTask &T = M.task;
   fi(T.dim_norm_residual); fi(T.norm); fi(T.num_norm_parameter); fi(T.trace_objtype); fi(T.trace_objid); fi(T.int_data);
   fd(T.weight); fd(T.norm_parameter); fd(T.parameters); fd(T.dbl_data);

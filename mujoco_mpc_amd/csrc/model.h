@@ -106,6 +106,8 @@ struct DevModel {
   // actuator transmissions flattened on the host: actuator i owns entries [act_adr[i], act_adr[i+1]) = (dof, qpos address,
   // coefficient = gear [* tendon coefficient]); act_of[e] = the actuator of entry e
   const int *act_adr, *act_dof, *act_qpos, *act_of, *actuator_ctrllimited, *actuator_forcelimited, *actuator_biastype;
+  int nsiteact;                             // site transmissions: sact_i [actuator, site, body], sact_g [force 3, torque 3 in the body frame]
+  const int *sact_i; const double *sact_g;
   int na;                                   // activation states (one per stateful actuator); tables below only when na > 0
   const int *actuator_dyntype, *actuator_actadr, *actuator_actlimited;
   const double *actuator_dynprm, *actuator_actrange;

@@ -438,6 +438,18 @@ DEV void task_residual(Ctx &c, double *residual) {
       residual[2] = lin[0]; residual[3] = lin[1];
       residual[4] = c.ctrl[0]; residual[5] = c.ctrl[1];
     }
+  } else if (id == 13) {   // quadrotor.cc:37-60: position - goal, linear velocity, angular velocity (world frame), control - hover thrust
+    if (LANE == 0) {
+      int b = MI(task.int_data)[0];
+      double lin[3];
+      d_sub3(residual, c.xipos + 3 * b, c.mocap_pos);
+      body_linvel(c, b, lin); d_copy3(residual + 3, lin);
+      d_copy3(residual + 6, c.cvel + 6 * b);
+      double g = d_sqrt(M.gravity[0] * M.gravity[0] + M.gravity[1] * M.gravity[1] + M.gravity[2] * M.gravity[2]);
+      double thrust = d_div((MDH(body_mass)[0] + MDH(body_mass)[1]) * g, (double)M.nu);
+      for (int i = 0; i < M.nu; i++) residual[9 + i] = c.ctrl[i] - thrust;
+      for (int i = 9 + M.nu; i < M.task.num_residual; i++) residual[i] = 0;
+    }
   } else if (id == 9) {   // acrobot.cc:34-49: goal - tip (z, x), joint velocities, control
     if (LANE == 0) {
       int g = MI(task.int_data)[0], t = MI(task.int_data)[1];

@@ -361,7 +361,20 @@ static void ParticleTransition(const MjpcHipModel&, SimState& s, HostTask&, cons
   if (s.mocap.size() >= 2) { s.mocap[0] = 0.25 * std::sin(s.time); s.mocap[1] = 0.25 * std::cos(s.time / 3.14159265358979323846); }
 }
 
+// Quadrotor::TransitionLocked (quadrotor.cc:63-95), mode 0 ("Loop"): within 0.5 m of the goal -> next keyframe position
+static void QuadrotorTransition(const MjpcHipModel& m, SimState& s, HostTask& t, const SimFrame& f) {
+  const int body = t.int_data[0], nstage = (int)t.dbl_data.size() / 7;
+  int stage = t.int_data[1];
+  double err = 0;
+  for (int k = 0; k < 3; k++) { double e = f.subtree_com[3 * body + k] - s.mocap[k]; err += e * e; }      // one free body: its subtree com is xipos
+  if (std::sqrt(err) <= 5.0e-1) stage = (stage + 1) % nstage;
+  t.int_data[1] = stage;
+  for (int k = 0; k < 7; k++) s.mocap[k] = t.dbl_data[7 * stage + k];
+  (void)m;
+}
+
 TransitionFn TransitionForTask(int task_id, int mode, double mode_time) {
+  if (task_id == MJPC_TASK_QUADROTOR) return QuadrotorTransition;
   if (task_id == MJPC_TASK_PARTICLE_TIMEVARYING) return ParticleTransition;
   if (task_id == MJPC_TASK_HUMANOID_TRACK) return TrackingTransition;
   if (task_id == MJPC_TASK_QUADRUPED_HILL) return HillTransition;

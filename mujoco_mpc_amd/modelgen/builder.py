@@ -203,13 +203,14 @@ class ModelBuilder:
 
     def actuator(self, name, joint=None, gainprm=(1, 0, 0), biastype=0, biasprm=(0, 0, 0), gear=1.0,
                  ctrllimited=True, ctrlrange=(-1, 1), forcelimited=False, forcerange=(0, 0), tendon=None,
-                 dyntype=0, dynprm=1.0, actlimited=False, actrange=(0, 0)):
+                 dyntype=0, dynprm=1.0, actlimited=False, actrange=(0, 0), site=None, gear6=None):
         """joint transmission (joint=name) or fixed-tendon transmission (tendon=name); dyntype 1 integrator / 2 filter / 3 filterexact
         gives the actuator one activation state (time constant dynprm)"""
         self.actuators.append(dict(name=name, joint=joint, tendon=tendon, gainprm=tuple(gainprm), biastype=biastype,
                                    biasprm=tuple(biasprm), gear=gear, ctrllimited=ctrllimited,
                                    ctrlrange=tuple(ctrlrange), forcelimited=forcelimited, forcerange=tuple(forcerange),
-                                   dyntype=int(dyntype), dynprm=float(dynprm), actlimited=bool(actlimited), actrange=tuple(actrange)))
+                                   dyntype=int(dyntype), dynprm=float(dynprm), actlimited=bool(actlimited), actrange=tuple(actrange),
+                                   site=site, gear6=None if gear6 is None else tuple(gear6)))
 
     def position(self, name, joint=None, tendon=None, kp=1.0, ctrlrange=(-1, 1), forcerange=None, gear=1.0):
         """MJCF <position>: gain kp, affine bias (0, -kp, 0)."""
@@ -291,6 +292,9 @@ class ModelBuilder:
         for b in self.bodies:
             b.joints = [remap[j] for j in b.joints]
         for a in self.actuators:
+            if a.get("site") is not None:             # mjTRN_SITE: the 6-vector gear is a wrench in the site frame
+                a["trntype"] = 4; a["trnid"] = int(a["site"])
+                continue
             if a.get("tendon") is not None:
                 a["trntype"] = 3
                 a["trnid"] = [t["name"] for t in self.tendons].index(a["tendon"]) if isinstance(a["tendon"], str) else int(a["tendon"])
@@ -472,6 +476,7 @@ class ModelBuilder:
         M["actuator_gear"] = np.array([a["gear"] for a in A], float)
         M["actuator_ctrlrange"] = np.array([a["ctrlrange"] for a in A], float).reshape(nu, 2)
         M["actuator_forcerange"] = np.array([a["forcerange"] for a in A], float).reshape(nu, 2)
+        M["actuator_gear6"] = np.array([a["gear6"] if a.get("gear6") is not None else (a["gear"], 0, 0, 0, 0, 0) for a in A], float).reshape(nu, 6)
         M["actuator_dyntype"] = np.array([a.get("dyntype", 0) for a in A], np.int32)
         adr = []; na = 0
         for a in A:

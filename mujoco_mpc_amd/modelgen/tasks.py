@@ -87,6 +87,40 @@ def particle_task(fixed=False, timestep=0.01):
     return m, task, defaults
 
 
+TASK_QUADROTOR = 13
+QUADROTOR_STAGES = [(1.2, 0.0, 0.75), (2.3, 0.6, 1.5), (2.7, 0.95, 1.5), (4.6, 0.4, 0.75), (5.0, -1.8, 0.75), (3.4, -2.5, 0.75), (2.5, -2.25, 1.45),
+                    (2.5, -2.25, 2.25), (1.5, -1.75, 1.85), (1.05, -1.75, 1.3), (0.1, -1.4, 0.75), (0.0, 0.0, 0.75)]      # task.xml:80-93 (key mpos)
+
+
+def quadrotor(timestep=0.01, stage=0):
+    """mjpc/tasks/quadrotor (quadrotor.cc:37-95, task.xml): a 1.325 kg free body with four thrust motors through site transmissions
+    (gear = unit force along the site's z plus the rotor's reaction torque, quadrotor.xml.patch:57-58 for the menagerie Skydio X2),
+    floor and two gate posts to bump into; goal = a mocap body that Transition moves through the 12 keyframe positions.  The
+    body / rotor geometry is a synthetic box (the menagerie mesh is not in the reference tree); cost terms, agent settings
+    (horizon 0.5 s, 5 spline points, exploration 0.3) and stage goals are the reference's."""
+    b = ModelBuilder(timestep=timestep, contact=True)
+    b.geom(0, "floor", PLANE, size=(100, 100, 0.2))
+    x2 = b.body("x2", 0, pos=(0, 0, 0.04), quat=(0, 0, 0, 1))       # resting on the floor, like the reference's start
+    b.joint(x2, "x2_free", FREE)
+    b.geom(x2, "x2_g", BOX, size=(0.12, 0.16, 0.03), mass=1.325)
+    for k, (x, y, tq) in enumerate(((-0.14, -0.18, -0.0201), (-0.14, 0.18, 0.0201), (0.14, 0.18, -0.0201), (0.14, -0.18, 0.0201))):
+        s = b.site(x2, f"thrust{k + 1}", pos=(x, y, 0.05))
+        b.actuator(f"thrust{k + 1}", site=s, gear6=(0, 0, 1, 0, 0, tq), ctrlrange=(0, 13))
+    goal = b.body("goal", 0, pos=QUADROTOR_STAGES[stage], mocap=True)
+    b.geom(goal, "goal_g", SPHERE, size=(0.1,), contype=0, conaffinity=0)
+    for k, (x, y) in enumerate(((1.2, 0.45), (1.2, -0.45))):                 # gate posts either side of the first waypoint
+        b.geom(0, f"post{k}", BOX, pos=(x, y, 0.75), size=(0.03, 0.03, 0.75))
+    m = b.compile()
+    stages = np.array([list(p) + [1, 0, 0, 0] for p in QUADROTOR_STAGES], float)
+    task = make_task(TASK_QUADROTOR, [(3, 0, 25.0), (3, 0, 1.25), (3, 0, 1.25), (4, 0, 1.0e-3), (2, 0, 0.0)], traces=[(OBJ_BODY, x2)],
+                     int_data=[x2, int(stage)], dbl_data=list(stages.ravel()))
+    q = np.array(m["qpos0"], float)
+    hover = 1.325 * 9.81 / 4
+    defaults = dict(N=10, P=5, sigma=(0.3, 0.0), interp=2, horizon=51, state=np.concatenate([q, np.zeros(m["nv"])]), mocap=stages[stage].copy(),
+                    ctrl0=np.full(4, hover))
+    return m, task, defaults
+
+
 def linkage(timestep=0.004):
     """Test model for equality constraints: a gripper-like pair of fingers on one palm whose hinge angles are coupled by a joint
     equality (different branches: dense Hessian builds), a four-bar loop closed by a connect constraint between two chain ends, and a
@@ -772,4 +806,4 @@ def terrain_balls(timestep=0.004):
     return m, task, defaults
 
 
-REGISTRY = {"linkage": linkage, "servo_arm": servo_arm, "particle_timevarying": particle_task, "particle_fixed": lambda: particle_task(fixed=True), "filter_arm": filter_arm, "ball_chain_friction": lambda: ball_chain(tendon_frictionloss=0.3), "quadruped_hill": quadruped_hill, "terrain_balls": terrain_balls, "walker": walker, "acrobot": acrobot, "ball_chain": ball_chain, "cylinder_pile": cylinder_pile, "humanoid_stand": humanoid_stand, "humanoid_walk": humanoid_walk, "particle": particle, "cartpole": cartpole, "quadruped": quadruped, "humanoid_track": humanoid_track, "shadow_hand": shadow_hand}
+REGISTRY = {"quadrotor": quadrotor, "linkage": linkage, "servo_arm": servo_arm, "particle_timevarying": particle_task, "particle_fixed": lambda: particle_task(fixed=True), "filter_arm": filter_arm, "ball_chain_friction": lambda: ball_chain(tendon_frictionloss=0.3), "quadruped_hill": quadruped_hill, "terrain_balls": terrain_balls, "walker": walker, "acrobot": acrobot, "ball_chain": ball_chain, "cylinder_pile": cylinder_pile, "humanoid_stand": humanoid_stand, "humanoid_walk": humanoid_walk, "particle": particle, "cartpole": cartpole, "quadruped": quadruped, "humanoid_track": humanoid_track, "shadow_hand": shadow_hand}

@@ -701,12 +701,25 @@ static void rne_bias(const OModel *om, OData *d) {
  * clamped to forcerange; qfrc_actuator += moment^T force.  <position kp> servos are gain = kp, bias = (0, -kp, 0). */
 static void actuation(const OModel *om, OData *d) {
   const MjpcHipModel *m = &om->m;
+  const int nv = m->nv;
   o_zero(d->qfrc_actuator, m->nv);
   for (int i = 0; i < m->nu; i++) {
     double ctrl = d->ctrl[i];
     if (m->actuator_ctrllimited[i]) ctrl = o_clip(ctrl, m->actuator_ctrlrange[2 * i], m->actuator_ctrlrange[2 * i + 1]);
     double gear = m->actuator_gear[i];
     int id = m->actuator_trnid[i];
+    if (m->actuator_trntype[i] == MJPC_TRN_SITE) {
+      /* mjTRN_SITE without refsite: length 0, moment = J_site^T (R_site gear[0:3]; R_site gear[3:6]); motors only */
+      double *jp = d->work, *jr = d->work + 3 * nv, f[3], tq[3];
+      double force = m->actuator_gainprm[3 * i] * ctrl;
+      if (m->actuator_forcelimited[i]) force = o_clip(force, m->actuator_forcerange[2 * i], m->actuator_forcerange[2 * i + 1]);
+      d->actuator_force[i] = force;
+      jac_point(om, d, jp, jr, d->site_xpos + 3 * id, m->site_bodyid[id]);
+      o_mulmatvec3(f, d->site_xmat + 9 * id, m->actuator_gear6 + 6 * i); o_mulmatvec3(tq, d->site_xmat + 9 * id, m->actuator_gear6 + 6 * i + 3);
+      for (int k = 0; k < nv; k++)
+        d->qfrc_actuator[k] += force * (jp[k] * f[0] + jp[nv + k] * f[1] + jp[2 * nv + k] * f[2] + jr[k] * tq[0] + jr[nv + k] * tq[1] + jr[2 * nv + k] * tq[2]);
+      continue;
+    }
     int tendon = m->actuator_trntype[i] == MJPC_TRN_TENDON;
     int w0 = tendon ? m->tendon_adr[id] : 0, nw = tendon ? m->tendon_num[id] : 1;
     double length = 0, velocity = 0;

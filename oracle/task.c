@@ -569,6 +569,17 @@ void oracle_residual(const OModel *om, OData *d, double *residual) {
       o_copy(residual + 4, d->ctrl, m->nu);
       break;
     }
+    case MJPC_TASK_QUADROTOR: {   /* quadrotor.cc:37-60; the two "Orientation" residuals the XML declares are never written */
+      int b = om->t.int_data[0];
+      double lin[3];
+      o_sub3(residual, d->xipos + 3 * b, d->mocap_pos);
+      body_linvel(om, d, b, lin); o_copy3(residual + 3, lin);
+      o_copy3(residual + 6, d->cvel + 6 * b);                      /* frameangvel: angular velocity in the world frame */
+      double thrust = (m->body_mass[0] + m->body_mass[1]) * o_norm3(m->gravity) / m->nu;
+      for (int i = 0; i < m->nu; i++) residual[9 + i] = d->ctrl[i] - thrust;
+      for (int i = 9 + m->nu; i < om->t.num_residual; i++) residual[i] = 0;
+      break;
+    }
     case MJPC_TASK_ACROBOT: {  /* acrobot.cc:34-49 */
       int g = om->t.int_data[0], t = om->t.int_data[1];
       residual[0] = d->site_xpos[3 * g + 2] - d->site_xpos[3 * t + 2];

@@ -1022,6 +1022,33 @@ def test_closed_loop_walker_walks_and_acrobot_swings_up():
 
 
 @pytest.mark.gpu
+def test_quadrotor_task_site_transmissions_and_transition():
+    """mjpc/tasks/quadrotor (quadrotor.cc:37-95): four thrust motors through site transmissions (moment = site Jacobian of the gear
+    wrench).  Plan-step parity around the hover thrust; closed loop with the host Transition from a hover 0.8 m short of the first
+    waypoint (128 trajectories, exploration 0.05: with the task XML's 0.3 = 2 N per rotor the un-noised hover wins most plans):
+    the vehicle flies through the gates' waypoints and the goal moves on along the keyframe positions."""
+    from mujoco_mpc_amd import cplanner
+    from mujoco_mpc_amd.modelgen import quadrotor
+    from mujoco_mpc_amd.modelgen.tasks import QUADROTOR_STAGES
+    m, task, d = quadrotor()
+    kv = np.tile(d["ctrl0"], (5, 1)) + np.random.default_rng(3).uniform(-1, 1, (5, 4))
+    out, ref, allc = _compare(m, task, d, 5, 51, 16, (0.3, 0.0), 2, 1e-8, kv=kv)
+    assert allc["residual"].shape[-1] == 15 and np.all(allc["residual"][:, :, 13:] == 0) and not out["failure"].any()
+    hover = 1.325 * 9.81 / 4
+    assert np.allclose(allc["residual"][:, :-1, 9:13], allc["actions"][:, :-1] - hover, atol=1e-12)
+    num = dict(sampling_spline_points=5, sampling_exploration=0.05, sampling_trajectories=128, sampling_representation=2)
+    p = cplanner.SamplingPlanner()
+    p.Initialize(m, task, num, max_samples=128, max_horizon=51)
+    p.Reset(51, d["ctrl0"])
+    state = d["state"].copy(); state[:3] = [0.4, 0.0, 0.75]
+    res = cplanner.testspeed(p, state, d["mocap"], horizon=51, steps_per_planning_iteration=1, total_time=3.0)
+    p.close()
+    stage = int(np.argmin(np.abs(np.array(QUADROTOR_STAGES) - res["mocap"][:3]).sum(1)))
+    assert not res["failure"] and stage >= 2, (stage, res["state"][:3])                 # waypoints were reached, the goal moved on
+    assert res["state"][2] > 0.3 and np.linalg.norm(res["state"][:3] - res["mocap"][:3]) < 3.0
+
+
+@pytest.mark.gpu
 def test_registry_particle_tasks_and_their_transition():
     """mjpc/tasks/particle (particle.cc:30-73, task_timevarying.xml): 6 residuals, the goal a Lissajous curve of data->time
     ("Particle") or the mocap body ("ParticleFixed").  Plan-step parity at a non-zero start time; closed loop with the host

@@ -26,6 +26,7 @@ def _rel(a, b):
                                                    ("terrain_balls", 3, 60, 6, (0.5, 0.0), 1e-5),   # height field: prisms through the portal-refinement collider
                                                    ("cylinder_pile", 3, 50, 6, (0.5, 0.0), 1e-5),   # cylinder-box / cylinder-cylinder through the portal-refinement collider
                                                    ("particle_timevarying", 5, 51, 6, (0.3, 0.0), 1e-12), ("particle_fixed", 5, 51, 6, (0.3, 0.0), 1e-12),   # registry Particle / ParticleFixed
+                                                   ("quadrotor", 5, 51, 6, (0.3, 0.0), 1e-9),       # registry Quadrotor: site transmissions (thrust + reaction torque), 15 declared / 13 written residuals
                                                    ("linkage", 4, 80, 6, (0.5, 0.0), 1e-9),         # equality constraints: joint coupling across branches, four-bar connect, pinned free body
                                                    ("servo_arm", 4, 80, 6, (0.5, 0.0), 1e-9),       # mjINT_IMPLICITFAST: velocity servos, saturating force range, damped tendon
                                                    ("filter_arm", 4, 80, 6, (0.4, 0.0), 1e-9),      # activation states: filter / filterexact / clamped integrator actuators

@@ -510,6 +510,29 @@ def test_tendon_spring_and_damper_closed_form():
     assert np.allclose(m2["tendon_lengthspring"], 0.0)
 
 
+def test_site_transmission_closed_form():
+    """mjTRN_SITE: the gear wrench acts in the site frame, qfrc = J_site^T wrench.  The quadrotor hovers at m g / 4 per rotor (reaction
+    torques cancel), climbs at (sum f - m g) / m in the body's z direction also when tilted, one rotor more than the others rolls /
+    pitches it by r x f / I, and a yaw torque imbalance turns it about z."""
+    from mujoco_mpc_amd.modelgen import quadrotor
+    m, task, d = quadrotor()
+    o = ol.Oracle(m, task)
+    mass, g = 1.325, 9.81
+    q = np.array(d["state"][:7]); hover = mass * g / 4
+    r = o.forward(q, np.zeros(6), ctrl=np.full(4, hover))
+    assert np.abs(r["qacc"]).max() < 1e-9
+    r = o.forward(q, np.zeros(6), ctrl=np.full(4, hover + 0.5))
+    assert np.allclose(r["qacc"], [0, 0, 2.0 / mass, 0, 0, 0], atol=1e-9)
+    tilt = np.array([0, 0, 1.0, np.cos(0.3), np.sin(0.3), 0, 0])                  # rolled by 0.6 rad about x, free of the floor
+    r = o.forward(tilt, np.zeros(6), ctrl=np.full(4, hover))
+    zb = np.array([0, -np.sin(0.6), np.cos(0.6)])
+    assert np.allclose(r["qacc"][:3], 4 * hover * zb / mass - np.array([0, 0, g]), atol=1e-9) and np.abs(r["qacc"][3:]).max() < 1e-9
+    ctrl = np.full(4, hover); ctrl[1] += 0.4                                       # rotor 2 at (-0.14, 0.18), reaction torque +0.0201
+    r = o.forward(np.array([0, 0, 1.0, 1, 0, 0, 0]), np.zeros(6), ctrl=ctrl)
+    Ixx, Iyy, Izz = [mass / 3 * v for v in (0.16 ** 2 + 0.03 ** 2, 0.12 ** 2 + 0.03 ** 2, 0.12 ** 2 + 0.16 ** 2)]
+    assert np.allclose(r["qacc"][3:], [0.18 * 0.4 / Ixx, 0.14 * 0.4 / Iyy, 0.0201 * 0.4 / Izz], rtol=1e-9)
+
+
 def test_equality_constraints_against_equivalent_joints():
     """mj_instantiateEquality.  (i) connect: a free ball pinned to the world 0.3 m above its centre swings like the same ball on a
     hinge at that point (soft constraint: agreement to 2 mm over half a second, pin error below 1 mm); (ii) joint equality q1 = q2

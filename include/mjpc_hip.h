@@ -115,7 +115,7 @@ typedef struct MjpcHipModel {
                             * tendon damping and in the velocity term of affine actuator biases - position / velocity servos with kv - unless the
                             * force sits on its forcerange; no Coriolis derivative).  RK4 and the full implicit integrator are refused */
   int noslip_iterations;   /* must be 0 */
-  int neq;                 /* number of equality constraints (eq_* below): connect and joint equalities; weld / tendon / flex are refused */
+  int neq;                 /* number of equality constraints (eq_* below): connect, joint and (fixed-)tendon equalities; weld / flex are refused */
   int unsupported;         /* MJPC_UNSUP_* bits found by whoever fills this view in parts of mjModel the view does not carry
                             * (integration/hip_sampling_planner.cc: FillModelView); non-zero is refused at create */
   /* mjStatistic */
@@ -146,7 +146,7 @@ typedef struct MjpcHipModel {
   const int *exclude_signature;
   /* equality constraints [neq] (mj_instantiateEquality): MJPC_EQ_CONNECT obj = the two bodies (obj2 may be the world 0), eq_data[0..2]
    * / [3..5] = the anchor in either body frame; MJPC_EQ_JOINT obj = joint1 and joint2 (or -1), eq_data[0..4] = polycoef of
-   * q1 - q1_0 = poly(q2 - q2_0).  eq_active0 = 0 rows are left out (no run-time activation).  All NULL when neq = 0 */
+   * q1 - q1_0 = poly(q2 - q2_0); MJPC_EQ_TENDON the same with the lengths of two fixed tendons (relative to their length at qpos0).  eq_active0 = 0 rows are left out (no run-time activation).  All NULL when neq = 0 */
   const int *eq_type, *eq_obj1id, *eq_obj2id, *eq_active0;
   const double *eq_data;            /* 11 per equality (mjNEQDATA) */
   const double *eq_solref, *eq_solimp;   /* 2 / 5 per equality */

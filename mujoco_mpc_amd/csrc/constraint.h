@@ -96,6 +96,16 @@ DEV void make_noncontact_rows(Ctx &c, int *nsingle_out, int *n_nc_out) {
             pos[0] -= ep[0] + dif * (ep[1] + dif * (ep[2] + dif * (ep[3] + dif * ep[4])));
             diag += MD(dof_invweight0)[MIH(jnt_dofadr)[et[2]]];
           } else pos[0] -= ep[0];
+        } else if (et[0] == 3) {     // tendon: (L1 - L1_0) - poly(L2 - L2_0), fixed-tendon lengths relative to qpos0
+          int t1 = et[1], t2 = et[2];
+          for (int w = MI(tendon_adr)[t1]; w < MI(tendon_adr)[t1] + MI(tendon_num)[t1]; w++) { int qa = MI(wrap_qposadr)[w]; pos[0] += MD(wrap_prm)[w] * (c.qpos[qa] - MDH(qpos0)[qa]); }
+          diag = MD(tendon_invweight0)[t1];
+          if (t2 >= 0) {
+            double dif = 0;
+            for (int w = MI(tendon_adr)[t2]; w < MI(tendon_adr)[t2] + MI(tendon_num)[t2]; w++) { int qa = MI(wrap_qposadr)[w]; dif += MD(wrap_prm)[w] * (c.qpos[qa] - MDH(qpos0)[qa]); }
+            pos[0] -= ep[0] + dif * (ep[1] + dif * (ep[2] + dif * (ep[3] + dif * ep[4])));
+            diag += MD(tendon_invweight0)[t2];
+          } else pos[0] -= ep[0];
         } else {                     // connect: anchor of body 1 - anchor of body 2, world frame
           int b1 = et[1], b2 = et[2];
           double p1[3], p2[3];
@@ -193,6 +203,15 @@ DEV void make_noncontact_rows(Ctx &c, int *nsingle_out, int *n_nc_out) {
         int q2 = MIH(jnt_qposadr)[et[2]];
         double dif = c.qpos[q2] - MDH(qpos0)[q2];
         c.efc_J[r0 * nvp + MIH(jnt_dofadr)[et[2]]] = -(ep[1] + dif * (2 * ep[2] + dif * (3 * ep[3] + dif * 4 * ep[4])));
+      }
+    } else if (et[0] == 3) {
+      int t1 = et[1], t2 = et[2];
+      for (int w = MI(tendon_adr)[t1]; w < MI(tendon_adr)[t1] + MI(tendon_num)[t1]; w++) c.efc_J[r0 * nvp + MI(wrap_dofadr)[w]] += MD(wrap_prm)[w];
+      if (t2 >= 0) {
+        double dif = 0;
+        for (int w = MI(tendon_adr)[t2]; w < MI(tendon_adr)[t2] + MI(tendon_num)[t2]; w++) { int qa = MI(wrap_qposadr)[w]; dif += MD(wrap_prm)[w] * (c.qpos[qa] - MDH(qpos0)[qa]); }
+        double deriv = ep[1] + dif * (2 * ep[2] + dif * (3 * ep[3] + dif * 4 * ep[4]));
+        for (int w = MI(tendon_adr)[t2]; w < MI(tendon_adr)[t2] + MI(tendon_num)[t2]; w++) c.efc_J[r0 * nvp + MI(wrap_dofadr)[w]] -= deriv * MD(wrap_prm)[w];
       }
     } else {       // point Jacobians of the two anchors (cdof about the root's subtree com)
       int b1 = et[1], b2 = et[2];

@@ -237,6 +237,10 @@ class ModelBuilder:
         """MJCF <equality><joint>: q1 - q1_0 = poly(q2 - q2_0) (joint names; joint2 None: q1 - q1_0 = polycoef[0])"""
         self.equalities.append(dict(type=2, obj1=joint1, obj2=joint2, polycoef=tuple(polycoef), solref=tuple(solref), solimp=tuple(solimp), active=active))
 
+    def tendon_equality(self, tendon1, tendon2=None, polycoef=(0, 1, 0, 0, 0), solref=DEF_SOLREF, solimp=DEF_SOLIMP, active=True):
+        """MJCF <equality><tendon>: L1 - L1_0 = poly(L2 - L2_0) (tendon names, lengths relative to qpos0)"""
+        self.equalities.append(dict(type=3, obj1=tendon1, obj2=tendon2, polycoef=tuple(polycoef), solref=tuple(solref), solimp=tuple(solimp), active=active))
+
     def exclude(self, body1, body2):
         self.excludes.append((body1, body2))
 
@@ -568,6 +572,10 @@ class ModelBuilder:
                 o1.append(b1); o2.append(b2)
                 world = xpos0[b1] + xmat0[b1] @ np.array(e["anchor"], float)
                 data[k, :3] = e["anchor"]; data[k, 3:6] = xmat0[b2].T @ (world - xpos0[b2])
+            elif e["type"] == 3:
+                tn = [t["name"] for t in self.tendons]
+                o1.append(tn.index(e["obj1"])); o2.append(-1 if e["obj2"] is None else tn.index(e["obj2"]))
+                data[k, :5] = e["polycoef"]
             else:
                 o1.append(jnames.index(e["obj1"])); o2.append(-1 if e["obj2"] is None else jnames.index(e["obj2"]))
                 data[k, :5] = e["polycoef"]

@@ -123,8 +123,8 @@ def quadrotor(timestep=0.01, stage=0):
 
 def linkage(timestep=0.004):
     """Test model for equality constraints: a gripper-like pair of fingers on one palm whose hinge angles are coupled by a joint
-    equality (different branches: dense Hessian builds), a four-bar loop closed by a connect constraint between two chain ends, and a
-    free ball hung from the world by a connect; a box on the floor for contacts next to them.  Residual = state (TASK_COPYSTATE)."""
+    equality (different branches: dense Hessian builds), a four-bar loop closed by a connect constraint between two chain ends, a
+    tendon equality tying the wrist to the bars' mean angle, and a free ball hung from the world by a connect; a box on the floor for contacts next to them.  Residual = state (TASK_COPYSTATE)."""
     b = ModelBuilder(timestep=timestep, gravity=(0, 0, -9.81), contact=True)
     b.geom(0, "floor", PLANE, pos=(0, 0, -0.6), size=(2, 2, 0.1))
     palm = b.body("palm", 0, pos=(0, 0, 0))
@@ -140,6 +140,8 @@ def linkage(timestep=0.004):
     a2 = b.body("a2", a1, pos=(0, 0, -0.2)); b.joint(a2, "a2_j", HINGE, axis=(0, 1, 0), damping=0.01); b.geom(a2, "a2_g", CAPSULE, size=(0.012, 0), fromto=(0, 0, 0, 0.15, 0, 0), mass=0.1)
     c1 = b.body("c1", 0, pos=(0.55, 0, 0)); b.joint(c1, "c1_j", HINGE, axis=(0, 1, 0), damping=0.01); b.geom(c1, "c1_g", CAPSULE, size=(0.012, 0), fromto=(0, 0, 0, 0, 0, -0.2), mass=0.1)
     b.connect(a2, c1, (0.15, 0, 0))
+    b.tendon("t_w", ["wrist"], [1.0]); b.tendon("t_c", ["c1_j", "a1_j"], [0.5, 0.5])
+    b.tendon_equality("t_w", "t_c", polycoef=(0.0, 0.5, 0, 0, 0), solref=(0.05, 1.0))        # the wrist follows the bars' mean angle (cross-branch)
     ball = b.body("ball", 0, pos=(-0.4, 0, -0.3)); b.joint(ball, "ball_f", FREE); b.geom(ball, "ball_g", SPHERE, size=(0.04,), mass=0.2)
     b.connect(ball, 0, (0, 0, 0.3), solref=(0.01, 1.0))
     box = b.body("box", 0, pos=(0.1, 0, -0.55)); b.joint(box, "box_f", FREE); b.geom(box, "box_g", BOX, size=(0.05, 0.05, 0.05), mass=0.3)

@@ -423,6 +423,28 @@ static void make_constraint(const OModel *om, OData *d) {
       } else pos -= data[0];
       d->efc_pos[r] = pos;
       o_copy(d->efc_solref + 2 * r, m->eq_solref + 2 * e, 2); o_copy(d->efc_solimp + 5 * r, m->eq_solimp + 5 * e, 5);
+    } else if (m->eq_type[e] == MJPC_EQ_TENDON) {     /* (L1 - L1_0) - poly(L2 - L2_0), lengths of fixed tendons, L_0 at qpos0 */
+      int t1 = m->eq_obj1id[e], t2 = m->eq_obj2id[e];
+      int r = add_row(om, d, O_CNSTR_EQUALITY, e); if (r < 0) return;
+      double pos = 0, dif = 0, deriv = 0;
+      for (int w = m->tendon_adr[t1]; w < m->tendon_adr[t1] + m->tendon_num[t1]; w++) {
+        int qa = m->jnt_qposadr[m->wrap_objid[w]];
+        pos += m->wrap_prm[w] * (d->qpos[qa] - m->qpos0[qa]);
+      }
+      d->efc_diagApprox[r] = m->tendon_invweight0[t1];
+      if (t2 >= 0) {
+        for (int w = m->tendon_adr[t2]; w < m->tendon_adr[t2] + m->tendon_num[t2]; w++) {
+          int qa = m->jnt_qposadr[m->wrap_objid[w]];
+          dif += m->wrap_prm[w] * (d->qpos[qa] - m->qpos0[qa]);
+        }
+        pos -= data[0] + dif * (data[1] + dif * (data[2] + dif * (data[3] + dif * data[4])));
+        deriv = data[1] + dif * (2 * data[2] + dif * (3 * data[3] + dif * 4 * data[4]));
+        d->efc_diagApprox[r] += m->tendon_invweight0[t2];
+      } else pos -= data[0];
+      for (int w = m->tendon_adr[t1]; w < m->tendon_adr[t1] + m->tendon_num[t1]; w++) d->efc_J[r * nv + m->jnt_dofadr[m->wrap_objid[w]]] += m->wrap_prm[w];
+      if (t2 >= 0) for (int w = m->tendon_adr[t2]; w < m->tendon_adr[t2] + m->tendon_num[t2]; w++) d->efc_J[r * nv + m->jnt_dofadr[m->wrap_objid[w]]] -= deriv * m->wrap_prm[w];
+      d->efc_pos[r] = pos;
+      o_copy(d->efc_solref + 2 * r, m->eq_solref + 2 * e, 2); o_copy(d->efc_solimp + 5 * r, m->eq_solimp + 5 * e, 5);
     } else { d->unsupported++; }
   }
   /* friction loss */

@@ -80,11 +80,11 @@ def test_limited_ball_joints_and_tendon_spring_damper_cross_branch_limit():
 
 def test_equality_constraints():
     """mj_instantiateEquality on the device: a joint equality coupling two fingers (cross-branch: dense Hessian builds), a four-bar
-    loop closed by a connect, a free ball pinned to the world by a connect, next to contacts; same trajectories as the oracle."""
+    loop closed by a connect, a tendon equality, a free ball pinned to the world by a connect, next to contacts; same trajectories as the oracle."""
     from mujoco_mpc_amd.modelgen import linkage
     m, task, d = linkage()
     out, ref, allc = _compare(m, task, d, 4, 80, 12, (0.5, 0.0), 2, 1e-7)
-    assert not out["failure"].any() and allc["diag"][:, 2].max() >= 7                   # 1 + 3 + 3 equality rows always there
+    assert not out["failure"].any() and allc["diag"][:, 2].max() >= 8                   # 1 + 3 + 1 + 3 equality rows always there
     s = allc["states"]
     assert np.abs(s[:, :, 1] - (-s[:, :, 2] + 0.1 * s[:, :, 2] ** 2)).max() < 5e-3       # the fingers stay coupled
 

@@ -174,7 +174,7 @@ def test_models_the_engine_cannot_roll_out_are_refused_at_create():
     b.connect(body, 0, (0, 0, 0.1))
     m = b.compile(); m["eq_type"][0] = 1
     cm = capi.CModel(m, task)
-    assert lib.mjpc_hip_layout_bytes(ctypes.byref(cm.c_model), ctypes.byref(cm.c_task), 1) < 0 and b"only connect and joint equalities" in lib.mjpc_hip_last_error()
+    assert lib.mjpc_hip_layout_bytes(ctypes.byref(cm.c_model), ctypes.byref(cm.c_task), 1) < 0 and b"only connect, joint and tendon equalities" in lib.mjpc_hip_last_error()
 
     def userdata(b, body):
         b.nuserdata = 3

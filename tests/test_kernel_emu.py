@@ -295,6 +295,27 @@ def test_product_never_imports_oracle():
                 assert "oracle_lib" not in txt and "liboracle" not in txt and "oracle/" not in txt.replace("the CPU oracle under oracle/", ""), f
 
 
+def test_disabled_and_inactive_equalities_are_dropped_the_same_way():
+    """mjDSBL_EQUALITY and eq_active0 = 0: the host leaves the rows out of its table, the oracle skips them; the linkage model (joint,
+    connect and tendon equalities) gives the same rollouts either way, with fewer rows, and the fingers are no longer coupled."""
+    from mujoco_mpc_amd.modelgen import linkage
+    m, task, d = linkage()
+    P, H, N = 4, 60, 4
+    kt = np.linspace(0, (H - 1) * m["timestep"], P); kv = np.random.default_rng(3).uniform(-0.5, 0.5, (P, m["nu"]))
+    eps, sel = ol.noise(1, 0, 0, N, P, m["nu"])
+    base = emu_lib.plan(m, task, d["state"], None, 0.0, kt, kv, 2, N, H, sigma=(0.3, 0.0), noise_eps=eps, noise_sel=sel)
+    act = np.array(m["eq_active0"]).copy(); act[0] = 0                       # the finger coupling switched off
+    for mm in (dict(m, disableflags=m["disableflags"] | (1 << 1)), dict(m, eq_active0=act)):
+        a = ol.Oracle(mm, task).plan(d["state"], None, 0.0, kt, kv, 2, N, H, sigma=(0.3, 0.0), noise_eps=eps, noise_sel=sel, nthreads=4)
+        b = emu_lib.plan(mm, task, d["state"], None, 0.0, kt, kv, 2, N, H, sigma=(0.3, 0.0), noise_eps=eps, noise_sel=sel)
+        assert np.array_equal(a["failure"], b["failure"]) and not a["failure"].any()
+        for k in ("states", "costs", "returns"):
+            assert _rel(b[k], a[k]) < 1e-7, k
+        assert b["diag"][:, 2].min() < base["diag"][:, 2].min()
+        s = b["states"]
+        assert np.abs(s[:, :, 1] - (-s[:, :, 2] + 0.1 * s[:, :, 2] ** 2)).max() > 2e-2
+
+
 @pytest.mark.parametrize("flags", [1 << 2, 1 << 3, (1 << 2) | (1 << 3), 1 << 0])
 def test_disabled_constraint_kinds_are_dropped_the_same_way(flags):
     """mjDSBL_FRICTIONLOSS / LIMIT / CONSTRAINT: the host drops the rows from its lists, the oracle skips them in make_constraint;

@@ -86,6 +86,15 @@ struct HipFrozenState {
       for (int q = 0; q < 4; q++) D.push_back(m->key_mquat[4 * m->nmocap * k + q]);
     }
   }
+  // quadrotor.cc:37-95: the body behind the "position" sensor, the current stage, the keyframe goals Transition walks through
+  static void Quadrotor(const mjModel* m, int stage, std::vector<int>& I, std::vector<double>& D) {
+    I = {SensorObject(m, "position"), stage};
+    D.clear();
+    for (int k = 0; k < m->nkey; k++) {
+      for (int q = 0; q < 3; q++) D.push_back(m->key_mpos[3 * m->nmocap * k + q]);
+      for (int q = 0; q < 4; q++) D.push_back(m->key_mquat[4 * m->nmocap * k + q]);
+    }
+  }
   static void Walker(const mjModel* m, std::vector<int>& I) { I = {SensorObject(m, "torso_position")}; }      // walker.cc:39-57
   static void Particle(const mjModel* m, std::vector<int>& I) { I = {SensorObject(m, "position")}; }          // particle.cc:33-38: the tip site
   static void Acrobot(std::vector<int>& I) { I = {0, 1}; }                                                   // acrobot.cc:38-39: sites 0 and 1
@@ -105,6 +114,7 @@ void FillFrozenState(const Task& task, const BaseResidualFn* residual, const mjM
     case MJPC_TASK_HUMANOID_WALK: HipFrozenState::Walk(m, ints); break;
     case MJPC_TASK_SHADOW_REORIENT: HipFrozenState::Hand(m, ints); break;
     case MJPC_TASK_QUADRUPED_HILL: HipFrozenState::Hill(m, task.mode > 0 ? task.mode - 1 : 0, ints, dbls); break;
+    case MJPC_TASK_QUADROTOR: HipFrozenState::Quadrotor(m, task.mode > 0 ? task.mode - 1 : 0, ints, dbls); break;
     case MJPC_TASK_WALKER: HipFrozenState::Walker(m, ints); break;
     case MJPC_TASK_ACROBOT: HipFrozenState::Acrobot(ints); break;
     case MJPC_TASK_PARTICLE_TIMEVARYING: case MJPC_TASK_PARTICLE_FIXED: HipFrozenState::Particle(m, ints); break;

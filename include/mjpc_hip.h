@@ -37,7 +37,7 @@ enum { MJPC_SOL_NEWTON = 2, MJPC_INT_EULER = 0, MJPC_INT_IMPLICITFAST = 3 };
 enum { MJPC_EQ_CONNECT = 0, MJPC_EQ_WELD = 1, MJPC_EQ_JOINT = 2, MJPC_EQ_TENDON = 3 };      /* mjtEq */
 enum { MJPC_DYN_NONE = 0, MJPC_DYN_INTEGRATOR = 1, MJPC_DYN_FILTER = 2, MJPC_DYN_FILTEREXACT = 3 };   /* mjtDyn */
 enum { MJPC_UNSUP_FLUID = 1,          /* opt.density / viscosity / wind non-zero */
-       MJPC_UNSUP_GRAVCOMP = 2,       /* body_gravcomp */
+       MJPC_UNSUP_GRAVCOMP = 2,       /* (no longer set: body_gravcomp travels in the view) */
        MJPC_UNSUP_ACTUATOR_GAIN = 4,  /* gaintype other than fixed, biastype other than none / affine */
        MJPC_UNSUP_ACTUATOR_DYN = 8,   /* dyntype muscle / user, actnum != 1, actearly */
        MJPC_UNSUP_SPATIAL_TENDON = 16,/* wrap objects other than joints */
@@ -128,6 +128,7 @@ typedef struct MjpcHipModel {
   const int *body_jntnum, *body_jntadr, *body_dofnum, *body_dofadr;
   const double *body_pos, *body_quat, *body_ipos, *body_iquat;
   const double *body_mass, *body_subtreemass, *body_inertia, *body_invweight0;
+  const double *body_gravcomp;      /* [nbody] gravity compensation (mj_passive: force -gravity * mass * gravcomp at the body's com), NULL = none */
   /* joints */
   const int *jnt_type, *jnt_qposadr, *jnt_dofadr, *jnt_bodyid, *jnt_limited;
   const double *jnt_pos, *jnt_axis, *jnt_stiffness, *jnt_range, *jnt_margin;

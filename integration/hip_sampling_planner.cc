@@ -66,7 +66,6 @@ static void FillModelView(const mjModel* m, MjpcHipModel& v, std::vector<int>& j
   // what this view does not carry: found here, refused by mjpc_hip_create
   v.unsupported = 0;
   if (m->opt.density != 0 || m->opt.viscosity != 0 || m->opt.wind[0] != 0 || m->opt.wind[1] != 0 || m->opt.wind[2] != 0) v.unsupported |= MJPC_UNSUP_FLUID;
-  for (int b = 0; b < m->nbody; b++) if (m->body_gravcomp[b] != 0) v.unsupported |= MJPC_UNSUP_GRAVCOMP;
   for (int i = 0; i < m->nu; i++) {
     if (m->actuator_gaintype[i] != mjGAIN_FIXED || (m->actuator_biastype[i] != mjBIAS_NONE && m->actuator_biastype[i] != mjBIAS_AFFINE)) v.unsupported |= MJPC_UNSUP_ACTUATOR_GAIN;
     // stateful actuators: integrator / filter / filterexact with one activation each travel in the view (actuator_dyntype ...)
@@ -83,7 +82,7 @@ static void FillModelView(const mjModel* m, MjpcHipModel& v, std::vector<int>& j
   v.body_dofnum = m->body_dofnum; v.body_dofadr = m->body_dofadr;
   v.body_pos = m->body_pos; v.body_quat = m->body_quat; v.body_ipos = m->body_ipos; v.body_iquat = m->body_iquat;
   v.body_mass = m->body_mass; v.body_subtreemass = m->body_subtreemass; v.body_inertia = m->body_inertia;
-  v.body_invweight0 = m->body_invweight0;
+  v.body_invweight0 = m->body_invweight0; v.body_gravcomp = m->body_gravcomp;
   v.jnt_type = m->jnt_type; v.jnt_qposadr = m->jnt_qposadr; v.jnt_dofadr = m->jnt_dofadr; v.jnt_bodyid = m->jnt_bodyid;
   jnt_limited = Widen(m->jnt_limited, m->njnt); v.jnt_limited = jnt_limited.data();
   v.jnt_pos = m->jnt_pos; v.jnt_axis = m->jnt_axis; v.jnt_stiffness = m->jnt_stiffness; v.jnt_range = m->jnt_range;

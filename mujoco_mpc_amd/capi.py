@@ -26,7 +26,7 @@ _OPTIONAL_MESH = ("nmesh", "nmeshvert", "geom_dataid", "mesh_vertadr", "mesh_ver
 _MODEL_INT_ARRAYS_BODY = ["body_parentid", "body_rootid", "body_weldid", "body_mocapid", "body_jntnum", "body_jntadr",
                           "body_dofnum", "body_dofadr"]
 _MODEL_DBL_ARRAYS_BODY = ["body_pos", "body_quat", "body_ipos", "body_iquat", "body_mass", "body_subtreemass",
-                          "body_inertia", "body_invweight0"]
+                          "body_inertia", "body_invweight0", "body_gravcomp"]
 
 
 class MjpcHipModel(C.Structure):
@@ -122,6 +122,8 @@ class CModel:
                 nt = int(model["ntendon"])
                 v = (np.tile([0.02, 1.0], nt) if name == "tendon_solref_fri" else np.tile([0.9, 0.95, 0.001, 0.5, 2.0], nt) if name == "tendon_solimp_fri"
                      else np.zeros(nt * (2 if name == "tendon_lengthspring" else 1)))
+            elif name == "body_gravcomp" and name not in model:       # models built before gravity compensation existed
+                v = np.zeros(int(model["nbody"]))
             elif name == "actuator_gear6" and name not in model:      # models built before site transmissions existed
                 v = np.zeros(6 * int(model["nu"]))
             elif name in _OPTIONAL_EQ and name not in model:            # models built before equality constraints existed: none

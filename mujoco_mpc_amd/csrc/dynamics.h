@@ -223,7 +223,25 @@ DEV void velocity_stage(Ctx &c, int mfact_seq) {
     }
   }
   SYNC();
-  if (M.ntendon_passive + M.nsiteact > 0) {      // (one test for the two rare extras)
+  if (M.ntendon_passive + M.nsiteact + M.ngravcomp > 0) {      // (one test for the rare extras)
+    if (M.ngravcomp > 0) {
+      // gravity compensation (mj_passive): a constant world force at the body's com, through the point Jacobian
+      PFOR(d, nv) {
+        double acc = c.qfrc_smooth[d];
+        const double *cd = c.cdof + 6 * d;
+        for (int k = 0; k < M.ngravcomp; k++) {
+          int b = MI(gc_body)[k];
+          if (!((MDM()[b] >> d) & 1ull)) continue;
+          double off[3], t[3];
+          d_sub3(off, c.xipos + 3 * b, c.subtree_com + 3 * MIH(body_rootid)[b]);
+          d_cross(t, cd, off);
+          const double *f = MD(gc_force) + 3 * k;
+          acc += (cd[3] + t[0]) * f[0] + (cd[4] + t[1]) * f[1] + (cd[5] + t[2]) * f[2];
+        }
+        c.qfrc_smooth[d] = acc;
+      }
+      SYNC();
+    }
     if (M.nsiteact > 0) {
       // site transmissions: qfrc += J_site^T (R gear_force; R gear_torque) force, the site Jacobian from cdof about the root's com
       PFOR(d, nv) {

@@ -144,7 +144,7 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
         p.error = "equality " + std::to_string(e) + ": joint equalities couple hinge / slide joints"; return false; }
     }
   }
-  if (m->unsupported != 0) { p.error = "the model uses features outside the engine's model view (MJPC_UNSUP_* mask " + std::to_string(m->unsupported) + ": fluid forces, gravity compensation, non-fixed actuator gains, actuator dynamics, spatial tendons, ...)"; return false; }
+  if (m->unsupported != 0) { p.error = "the model uses features outside the engine's model view (MJPC_UNSUP_* mask " + std::to_string(m->unsupported) + ": fluid forces, non-fixed actuator gains, muscle / user actuator dynamics, spatial tendons, ...)"; return false; }
   { const int known = MJPC_DSBL_CONSTRAINT | MJPC_DSBL_EQUALITY | MJPC_DSBL_FRICTIONLOSS | MJPC_DSBL_LIMIT | MJPC_DSBL_CONTACT | MJPC_DSBL_SENSOR | MJPC_DSBL_MIDPHASE;
     if (m->disableflags & ~known) { p.error = "disableflags " + std::to_string(m->disableflags) + ": only constraint / frictionloss / limit / contact can be disabled"; return false; }
     if (m->enableflags & (MJPC_ENBL_OVERRIDE | MJPC_ENBL_MULTICCD)) { p.error = "enableflags: contact override and multiccd are not supported"; return false; } }
@@ -263,6 +263,14 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
     dadr[nv] = (int)dent.size();
     M.dact_adr = as_off<int>(put_i(p, dadr.data(), dadr.size())); M.dact_e = as_off<int>(put_i(p, dent.data(), dent.size()));
     M.act_coef = as_off<double>(put_d(p, cf.data(), cf.size())); }
+  // gravity compensation: bodies with gravcomp != 0 and the force -gravity * mass * gravcomp (world frame, constant)
+  { std::vector<int> gb; std::vector<double> gf;
+    for (int b = 1; b < nb && m->body_gravcomp; b++) if (m->body_gravcomp[b] != 0) {
+      gb.push_back(b);
+      for (int k = 0; k < 3; k++) gf.push_back(-m->gravity[k] * m->body_mass[b] * m->body_gravcomp[b]);
+    }
+    M.ngravcomp = (int)gb.size();
+    M.gc_body = as_off<int>(put_i(p, gb.data(), gb.size())); M.gc_force = as_off<double>(put_d(p, gf.data(), gf.size())); }
   // site transmissions (mjTRN_SITE, no refsite): [actuator, site, body] and the gear wrench rotated into the body frame
   { std::vector<int> si; std::vector<double> sg;
     for (int i = 0; i < nu; i++) if (m->actuator_trntype[i] == MJPC_TRN_SITE) {
@@ -528,7 +536,7 @@ static inline DevModel relocate(const PackedModel &p, const int *ibase, const do
   fi(M.level_adr); fi(M.level_body); fi(M.subtree_adr); fi(M.subtree_list); fi(M.chain_adr); fi(M.chain_list); fi(M.mpair_i); fi(M.mpair_j); fi(M.hpair_i); fi(M.hpair_j); fi(M.zpair_i); fi(M.zpair_j);
   { const double *q = reinterpret_cast<const double *>(M.body_dofmask); fd(q); M.body_dofmask = reinterpret_cast<const unsigned long long *>(q); }
   { const double *q = reinterpret_cast<const double *>(M.body_patmask); fd(q); M.body_patmask = reinterpret_cast<const unsigned long long *>(q); }
-  fi(M.pair_g1); fi(M.pair_g2); fi(M.fric_dof); fi(M.limit_jnt); fi(M.limit_ball); fi(M.ray_geom); fi(M.tpass_id); fd(M.tpass_prm); fi(M.tfric_id); fd(M.tfric_prm); fi(M.idrv_e); fd(M.idrv_c); fi(M.eq_tab); fd(M.eq_prm); fi(M.sact_i); fd(M.sact_g);
+  fi(M.pair_g1); fi(M.pair_g2); fi(M.fric_dof); fi(M.limit_jnt); fi(M.limit_ball); fi(M.ray_geom); fi(M.tpass_id); fd(M.tpass_prm); fi(M.tfric_id); fd(M.tfric_prm); fi(M.idrv_e); fd(M.idrv_c); fi(M.eq_tab); fd(M.eq_prm); fi(M.sact_i); fd(M.sact_g); fi(M.gc_body); fd(M.gc_force);
   DevTask &T = M.task;
   fi(T.dim_norm_residual); fi(T.norm); fi(T.num_norm_parameter); fi(T.trace_objtype); fi(T.trace_objid); fi(T.int_data);
   fd(T.weight); fd(T.norm_parameter); fd(T.parameters); fd(T.dbl_data);

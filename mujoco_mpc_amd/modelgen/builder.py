@@ -134,6 +134,7 @@ class ModelBuilder:
         self.keys: list[tuple] = []
         self.tendons: list[dict] = []
         self.equalities: list[dict] = []
+        self.gravcomp: dict[int, float] = {}
         self.key_mpos = None          # optional [nkey, 3*nmocap]
         self.excludes: list[tuple] = []
         self.nuserdata = 0
@@ -141,10 +142,12 @@ class ModelBuilder:
         self.nefcmax = 0
 
     # ---- authoring API
-    def body(self, name, parent=0, pos=(0, 0, 0), quat=(1, 0, 0, 0), mocap=False, inertial=None):
+    def body(self, name, parent=0, pos=(0, 0, 0), quat=(1, 0, 0, 0), mocap=False, inertial=None, gravcomp=0.0):
         if isinstance(parent, str):
             parent = self.body_id(parent)
         self.bodies.append(_Body(name, parent, np.array(pos, float), normq(quat), mocap, inertial))
+        if gravcomp:
+            self.gravcomp[len(self.bodies) - 1] = float(gravcomp)
         return len(self.bodies) - 1
 
     def body_id(self, name):
@@ -464,6 +467,7 @@ class ModelBuilder:
         for i in range(nb - 1, 0, -1):
             sub[parent[i]] += sub[i]
         M["body_subtreemass"] = sub
+        M["body_gravcomp"] = np.array([self.gravcomp.get(i, 0.0) for i in range(nb)], float)
         # ---- sites, actuators, keys, excludes
         ns = len(self.sites)
         M["site_bodyid"] = np.array([s[1] for s in self.sites], np.int32)

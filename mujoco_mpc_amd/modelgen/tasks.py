@@ -159,12 +159,13 @@ def linkage(timestep=0.004):
 
 def servo_arm(timestep=0.005, integrator=3):
     """Test model for mjINT_IMPLICITFAST: a three-link arm on position servos with velocity gains (kv: the bias' velocity term), one
-    of them with a force range it saturates, a velocity servo through a fixed tendon along the chain, and a damped tendon; stiff
+    of them with a force range it saturates, a velocity servo through a fixed tendon along the chain, a damped tendon and gravity
+    compensation (full / half / none per link); stiff
     enough that Euler (integrator=0) and implicitfast (3) give visibly different trajectories.  Residual = state (TASK_COPYSTATE)."""
     b = ModelBuilder(timestep=timestep, gravity=(0, 0, -9.81), contact=False, integrator=integrator)
     parent = 0
     for k, (axis, ln) in enumerate((((0, 1, 0), 0.3), ((0, 1, 0), 0.25), ((1, 0, 0), 0.2))):
-        body = b.body(f"l{k}", parent, pos=(0, 0, 0) if k == 0 else (0, 0, -(0.3, 0.25)[k - 1]))
+        body = b.body(f"l{k}", parent, pos=(0, 0, 0) if k == 0 else (0, 0, -(0.3, 0.25)[k - 1]), gravcomp=(1.0, 0.5, 0.0)[k])      # menagerie-arm style gravity compensation
         b.joint(body, f"j{k}", HINGE, axis=axis, damping=0.02, armature=0.002)
         b.geom(body, f"g{k}", CAPSULE, size=(0.02, 0), fromto=(0, 0, 0, 0, 0, -ln), mass=0.3 - 0.08 * k)
         parent = body

@@ -692,6 +692,14 @@ static void passive(const OModel *om, OData *d) {
     frc -= b * velocity;
     for (int w = m->tendon_adr[t]; w < m->tendon_adr[t] + m->tendon_num[t]; w++) d->qfrc_passive[m->jnt_dofadr[m->wrap_objid[w]]] += m->wrap_prm[w] * frc;
   }
+  /* gravity compensation (mj_passive): -gravity * mass * gravcomp applied at the body's centre of mass */
+  if (m->body_gravcomp)
+    for (int b = 1; b < m->nbody; b++) if (m->body_gravcomp[b] != 0) {
+      double *jp = d->work, s = m->body_mass[b] * m->body_gravcomp[b];
+      jac_point(om, d, jp, NULL, d->xipos + 3 * b, b);
+      for (int i = 0; i < m->nv; i++)
+        d->qfrc_passive[i] -= s * (jp[i] * m->gravity[0] + jp[m->nv + i] * m->gravity[1] + jp[2 * m->nv + i] * m->gravity[2]);
+    }
 }
 
 static void rne_bias(const OModel *om, OData *d) {

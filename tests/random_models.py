@@ -116,6 +116,9 @@ def random_model(seed, portal_pairs=False):
             if a["dyntype"] == 1:
                 a["actlimited"] = True; a["actrange"] = (-0.3, 0.3)
     want_fast = rng_fr.random() < 0.3
+    for bid in bodies:                              # menagerie-arm style gravity compensation on some links
+        if rng_fr.random() < 0.15:
+            b.gravcomp[bid] = float(rng_fr.choice([0.5, 1.0]))
     if b.tendons and rng_fr.random() < 0.25:       # a tendon equality: the first tendon held at (a multiple of) the second's length, or at its own
         b.tendon_equality("t0", "t1" if len(b.tendons) > 1 and rng_fr.random() < 0.6 else None, polycoef=(0.0, float(rng_fr.uniform(-1, 1)), 0, 0, 0))
     if not b.actuators:

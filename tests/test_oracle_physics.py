@@ -510,6 +510,26 @@ def test_tendon_spring_and_damper_closed_form():
     assert np.allclose(m2["tendon_lengthspring"], 0.0)
 
 
+def test_gravity_compensation_closed_form():
+    """mj_passive gravcomp: -gravity * mass * gravcomp at the body's com.  A pendulum with gravcomp 1 feels no gravity torque, with 0.5
+    half of it; compensation of the outer link also unloads the inner joint through the point Jacobian."""
+    def pend(gc):
+        b = ModelBuilder(timestep=0.002, contact=False)
+        l1 = b.body("l1", 0, gravcomp=gc[0]); b.joint(l1, "h1", HINGE, axis=(0, 1, 0)); b.geom(l1, "g1", SPHERE, size=(0.05,), pos=(0, 0, -0.4), mass=1.0)
+        l2 = b.body("l2", l1, pos=(0, 0, -0.4), gravcomp=gc[1]); b.joint(l2, "h2", HINGE, axis=(0, 1, 0)); b.geom(l2, "g2", SPHERE, size=(0.05,), pos=(0, 0, -0.3), mass=0.5)
+        m = b.compile()
+        return ol.Oracle(m, _copy_task(m))
+    q = [0.7, -0.4]
+    full = pend((1.0, 1.0)).forward(q, [0, 0])
+    assert np.abs(full["qacc"]).max() < 1e-10                                       # weightless: no acceleration from rest
+    none, half, outer = (pend(gc).forward(q, [0, 0]) for gc in ((0, 0), (0.5, 0.5), (0.0, 1.0)))
+    M = none["qM"]
+    tau_none = M @ none["qacc"]                                                     # = -gravity torque (no other force at rest)
+    assert np.allclose(M @ half["qacc"], 0.5 * tau_none, rtol=1e-10)
+    g2 = np.array([-0.5 * 9.81 * (0.4 * np.sin(q[0]) + 0.3 * np.sin(q[0] + q[1])), -0.5 * 9.81 * 0.3 * np.sin(q[0] + q[1])])   # link 2's share
+    assert np.allclose(M @ outer["qacc"], tau_none - g2, rtol=1e-9, atol=1e-12)
+
+
 def test_site_transmission_closed_form():
     """mjTRN_SITE: the gear wrench acts in the site frame, qfrc = J_site^T wrench.  The quadrotor hovers at m g / 4 per rotor (reaction
     torques cancel), climbs at (sum f - m g) / m in the body's z direction also when tilted, one rotor more than the others rolls /

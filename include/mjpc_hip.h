@@ -36,7 +36,7 @@ enum { MJPC_SOL_NEWTON = 2, MJPC_INT_EULER = 0, MJPC_INT_IMPLICITFAST = 3 };
 /* model features outside this view (MjpcHipModel.unsupported) */
 enum { MJPC_EQ_CONNECT = 0, MJPC_EQ_WELD = 1, MJPC_EQ_JOINT = 2, MJPC_EQ_TENDON = 3 };      /* mjtEq */
 enum { MJPC_DYN_NONE = 0, MJPC_DYN_INTEGRATOR = 1, MJPC_DYN_FILTER = 2, MJPC_DYN_FILTEREXACT = 3 };   /* mjtDyn */
-enum { MJPC_UNSUP_FLUID = 1,          /* opt.density / viscosity / wind non-zero */
+enum { MJPC_UNSUP_FLUID = 1,          /* fluid forces of the ellipsoid model (a geom with fluidshape="ellipsoid") */
        MJPC_UNSUP_GRAVCOMP = 2,       /* (no longer set: body_gravcomp travels in the view) */
        MJPC_UNSUP_ACTUATOR_GAIN = 4,  /* gaintype other than fixed, biastype other than none / affine */
        MJPC_UNSUP_ACTUATOR_DYN = 8,   /* dyntype muscle / user, actnum != 1, actearly */
@@ -73,6 +73,7 @@ enum {
   MJPC_TASK_PARTICLE_TIMEVARYING = 11, /* mjpc/tasks/particle/particle.cc:30-50 ("Particle"): tip position - Lissajous goal of data->time,
                                  * tip velocity, control (6 residuals); int_data = [tip site] */
   MJPC_TASK_PARTICLE_FIXED = 12, /* particle.cc:68-73 ("ParticleFixed"): the same with goal = mocap_pos[0..1] */
+  MJPC_TASK_SWIMMER = 14,        /* mjpc/tasks/swimmer/swimmer.cc:33-46: control (nu), nose - target in the plane (2); int_data = [nose geom, targets reached] */
   MJPC_TASK_QUADROTOR = 13       /* mjpc/tasks/quadrotor/quadrotor.cc:37-60: position - goal, linear / angular velocity, control - hover thrust (13 of
                                  * the 15 declared residuals are written); int_data = [body, stage]; dbl_data = stage goals [nstage][7] */
 };
@@ -120,6 +121,10 @@ typedef struct MjpcHipModel {
                             * (integration/hip_sampling_planner.cc: FillModelView); non-zero is refused at create */
   /* mjStatistic */
   double meaninertia;
+  /* fluid forces of the inertia-box model (mj_passive): medium density / viscosity and wind (mjOption); all zero = none.  With the
+   * implicitfast integrator they are refused (their velocity derivative is not implemented); the ellipsoid model (geom fluidshape)
+   * is MJPC_UNSUP_FLUID */
+  double density, viscosity, wind[3];
   /* engine capacities (0 = default); overflow => candidate failure, like MuJoCo's
    * "contact/constraint buffer full" warnings -> mjpc CheckWarnings (utilities.cc:787-799) */
   int nconmax, nefcmax;

@@ -95,6 +95,7 @@ struct HipFrozenState {
       for (int q = 0; q < 4; q++) D.push_back(m->key_mquat[4 * m->nmocap * k + q]);
     }
   }
+  static void Swimmer(const mjModel* m, std::vector<int>& I) { I = {SensorObject(m, "nose"), 0}; }             // swimmer.cc:41-43: the nose geom
   static void Walker(const mjModel* m, std::vector<int>& I) { I = {SensorObject(m, "torso_position")}; }      // walker.cc:39-57
   static void Particle(const mjModel* m, std::vector<int>& I) { I = {SensorObject(m, "position")}; }          // particle.cc:33-38: the tip site
   static void Acrobot(std::vector<int>& I) { I = {0, 1}; }                                                   // acrobot.cc:38-39: sites 0 and 1
@@ -115,6 +116,7 @@ void FillFrozenState(const Task& task, const BaseResidualFn* residual, const mjM
     case MJPC_TASK_SHADOW_REORIENT: HipFrozenState::Hand(m, ints); break;
     case MJPC_TASK_QUADRUPED_HILL: HipFrozenState::Hill(m, task.mode > 0 ? task.mode - 1 : 0, ints, dbls); break;
     case MJPC_TASK_QUADROTOR: HipFrozenState::Quadrotor(m, task.mode > 0 ? task.mode - 1 : 0, ints, dbls); break;
+    case MJPC_TASK_SWIMMER: HipFrozenState::Swimmer(m, ints); break;
     case MJPC_TASK_WALKER: HipFrozenState::Walker(m, ints); break;
     case MJPC_TASK_ACROBOT: HipFrozenState::Acrobot(ints); break;
     case MJPC_TASK_PARTICLE_TIMEVARYING: case MJPC_TASK_PARTICLE_FIXED: HipFrozenState::Particle(m, ints); break;

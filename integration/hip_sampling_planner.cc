@@ -34,6 +34,7 @@ int DeviceResidual(const Task& task) {
   if (name == "ParticleFixed") return MJPC_TASK_PARTICLE_FIXED;
   if (name == "Walker") return MJPC_TASK_WALKER;
   if (name == "Quadrotor") return MJPC_TASK_QUADROTOR;
+  if (name == "Swimmer") return MJPC_TASK_SWIMMER;       // (needs agent_integrator Euler: the XML's implicit integrator is refused by mjpc_hip_create)
   if (name == "Acrobot") return MJPC_TASK_ACROBOT;
   return -1;
 }
@@ -65,7 +66,9 @@ static void FillModelView(const mjModel* m, MjpcHipModel& v, std::vector<int>& j
   v.noslip_iterations = m->opt.noslip_iterations; v.neq = m->neq; v.meaninertia = m->stat.meaninertia;
   // what this view does not carry: found here, refused by mjpc_hip_create
   v.unsupported = 0;
-  if (m->opt.density != 0 || m->opt.viscosity != 0 || m->opt.wind[0] != 0 || m->opt.wind[1] != 0 || m->opt.wind[2] != 0) v.unsupported |= MJPC_UNSUP_FLUID;
+  v.density = m->opt.density; v.viscosity = m->opt.viscosity; mju_copy3(v.wind, m->opt.wind);
+  if (m->opt.density != 0 || m->opt.viscosity != 0)      // the inertia-box model travels in the view; the ellipsoid model does not
+    for (int g = 0; g < m->ngeom; g++) if (m->geom_fluid[mjNFLUID * g] != 0) v.unsupported |= MJPC_UNSUP_FLUID;
   for (int i = 0; i < m->nu; i++) {
     if (m->actuator_gaintype[i] != mjGAIN_FIXED || (m->actuator_biastype[i] != mjBIAS_NONE && m->actuator_biastype[i] != mjBIAS_AFFINE)) v.unsupported |= MJPC_UNSUP_ACTUATOR_GAIN;
     // stateful actuators: integrator / filter / filterexact with one activation each travel in the view (actuator_dyntype ...)

@@ -36,6 +36,7 @@ class MjpcHipModel(C.Structure):
            ("tolerance", C.c_double), ("ls_tolerance", C.c_double), ("cone", C.c_int), ("iterations", C.c_int),
            ("ls_iterations", C.c_int), ("disableflags", C.c_int), ("enableflags", C.c_int), ("solver", C.c_int), ("integrator", C.c_int),
            ("noslip_iterations", C.c_int), ("neq", C.c_int), ("unsupported", C.c_int), ("meaninertia", C.c_double),
+           ("density", C.c_double), ("viscosity", C.c_double), ("wind", C.c_double * 3),
            ("nconmax", C.c_int), ("nefcmax", C.c_int)]
         + [(n, c_int_p) for n in _MODEL_INT_ARRAYS_BODY]
         + [(n, c_double_p) for n in _MODEL_DBL_ARRAYS_BODY]
@@ -122,6 +123,8 @@ class CModel:
                 nt = int(model["ntendon"])
                 v = (np.tile([0.02, 1.0], nt) if name == "tendon_solref_fri" else np.tile([0.9, 0.95, 0.001, 0.5, 2.0], nt) if name == "tendon_solimp_fri"
                      else np.zeros(nt * (2 if name == "tendon_lengthspring" else 1)))
+            elif name in ("density", "viscosity", "wind") and name not in model:      # models built before fluid forces existed
+                v = (0.0, 0.0, 0.0) if name == "wind" else 0.0
             elif name == "body_gravcomp" and name not in model:       # models built before gravity compensation existed
                 v = np.zeros(int(model["nbody"]))
             elif name == "actuator_gear6" and name not in model:      # models built before site transmissions existed
@@ -145,8 +148,8 @@ class CModel:
                 if arr.size == 0:
                     arr = np.zeros(1, np.int32)
                 self._keep.append(arr); setattr(m, name, _ip(arr))
-            elif name == "gravity":
-                m.gravity = (C.c_double * 3)(*[float(x) for x in v])
+            elif name in ("gravity", "wind"):
+                setattr(m, name, (C.c_double * 3)(*[float(x) for x in v]))
             elif ctype is C.c_int:
                 setattr(m, name, int(v))
             else:

@@ -223,7 +223,55 @@ DEV void velocity_stage(Ctx &c, int mfact_seq) {
     }
   }
   SYNC();
-  if (M.ntendon_passive + M.nsiteact + M.ngravcomp > 0) {      // (one test for the rare extras)
+  if (M.ntendon_passive + M.nsiteact + M.ngravcomp + M.fluid > 0) {      // (one test for the rare extras)
+    if (M.fluid) {
+      // fluid forces, inertia-box model (mj_inertiaBoxFluidModel): per body the world force / torque at its com into cfrc (dead by
+      // now: the bias forces have been read off cfrc_sub), then J^T of them per dof
+      PFOR(b, M.nbody) {
+        double *w = c.cfrc + 6 * b;
+        for (int k = 0; k < 6; k++) w[k] = 0;
+        double mass = MDH(body_mass)[b];
+        if (b == 0 || mass < D_MINVAL) continue;
+        const double *I = MDH(body_inertia) + 3 * b, *R = c.ximat + 9 * b;
+        double box[3], off[3], vw[3], lvel[6], lfrc[6] = {0, 0, 0, 0, 0, 0};
+        box[0] = sqrt(d_div(fmax(D_MINVAL, I[1] + I[2] - I[0]), mass) * 6.0);
+        box[1] = sqrt(d_div(fmax(D_MINVAL, I[0] + I[2] - I[1]), mass) * 6.0);
+        box[2] = sqrt(d_div(fmax(D_MINVAL, I[0] + I[1] - I[2]), mass) * 6.0);
+        d_sub3(off, c.xipos + 3 * b, c.subtree_com + 3 * MIH(body_rootid)[b]);
+        d_cross(vw, c.cvel + 6 * b, off);
+        for (int k = 0; k < 3; k++) vw[k] += c.cvel[6 * b + 3 + k] - M.wind[k];
+        d_mulmattvec3(lvel, R, c.cvel + 6 * b); d_mulmattvec3(lvel + 3, R, vw);
+        if (M.viscosity > 0) {
+          double diam = (box[0] + box[1] + box[2]) / 3.0;
+          for (int k = 0; k < 3; k++) { lfrc[k] = -D_PI * diam * diam * diam * M.viscosity * lvel[k]; lfrc[3 + k] = -3.0 * D_PI * diam * M.viscosity * lvel[3 + k]; }
+        }
+        if (M.density > 0) {
+          double b0 = box[0], b1 = box[1], b2 = box[2];
+          lfrc[3] -= 0.5 * M.density * b1 * b2 * fabs(lvel[3]) * lvel[3];
+          lfrc[4] -= 0.5 * M.density * b0 * b2 * fabs(lvel[4]) * lvel[4];
+          lfrc[5] -= 0.5 * M.density * b0 * b1 * fabs(lvel[5]) * lvel[5];
+          lfrc[0] -= M.density * b0 * (b1 * b1 * b1 * b1 + b2 * b2 * b2 * b2) * fabs(lvel[0]) * lvel[0] / 64.0;
+          lfrc[1] -= M.density * b1 * (b0 * b0 * b0 * b0 + b2 * b2 * b2 * b2) * fabs(lvel[1]) * lvel[1] / 64.0;
+          lfrc[2] -= M.density * b2 * (b0 * b0 * b0 * b0 + b1 * b1 * b1 * b1) * fabs(lvel[2]) * lvel[2] / 64.0;
+        }
+        d_mulmatvec3(w, R, lfrc); d_mulmatvec3(w + 3, R, lfrc + 3);        // torque, force in the world frame
+      }
+      SYNC();
+      PFOR(d, nv) {
+        double acc = c.qfrc_smooth[d];
+        const double *cd = c.cdof + 6 * d;
+        for (int b = 1; b < M.nbody; b++) {
+          if (!((MDM()[b] >> d) & 1ull)) continue;
+          const double *w = c.cfrc + 6 * b;
+          double off[3], t[3];
+          d_sub3(off, c.xipos + 3 * b, c.subtree_com + 3 * MIH(body_rootid)[b]);
+          d_cross(t, cd, off);
+          acc += (cd[3] + t[0]) * w[3] + (cd[4] + t[1]) * w[4] + (cd[5] + t[2]) * w[5] + cd[0] * w[0] + cd[1] * w[1] + cd[2] * w[2];
+        }
+        c.qfrc_smooth[d] = acc;
+      }
+      SYNC();
+    }
     if (M.ngravcomp > 0) {
       // gravity compensation (mj_passive): a constant world force at the body's com, through the point Jacobian
       PFOR(d, nv) {

@@ -144,7 +144,7 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
         p.error = "equality " + std::to_string(e) + ": joint equalities couple hinge / slide joints"; return false; }
     }
   }
-  if (m->unsupported != 0) { p.error = "the model uses features outside the engine's model view (MJPC_UNSUP_* mask " + std::to_string(m->unsupported) + ": fluid forces, non-fixed actuator gains, muscle / user actuator dynamics, spatial tendons, ...)"; return false; }
+  if (m->unsupported != 0) { p.error = "the model uses features outside the engine's model view (MJPC_UNSUP_* mask " + std::to_string(m->unsupported) + ": ellipsoid fluid model, non-fixed actuator gains, muscle / user actuator dynamics, spatial tendons, ...)"; return false; }
   { const int known = MJPC_DSBL_CONSTRAINT | MJPC_DSBL_EQUALITY | MJPC_DSBL_FRICTIONLOSS | MJPC_DSBL_LIMIT | MJPC_DSBL_CONTACT | MJPC_DSBL_SENSOR | MJPC_DSBL_MIDPHASE;
     if (m->disableflags & ~known) { p.error = "disableflags " + std::to_string(m->disableflags) + ": only constraint / frictionloss / limit / contact can be disabled"; return false; }
     if (m->enableflags & (MJPC_ENBL_OVERRIDE | MJPC_ENBL_MULTICCD)) { p.error = "enableflags: contact override and multiccd are not supported"; return false; } }
@@ -159,6 +159,9 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
     } else if (m->actuator_trntype[i] != MJPC_TRN_JOINT && m->actuator_trntype[i] != MJPC_TRN_TENDON) {
       p.error = "actuator " + std::to_string(i) + ": only joint, fixed-tendon and site transmissions are supported"; return false; }
   M.na = m->na;
+  M.fluid = (m->density > 0 || m->viscosity > 0) ? 1 : 0; M.density = m->density; M.viscosity = m->viscosity;
+  for (int k = 0; k < 3; k++) M.wind[k] = m->wind[k];
+  if (M.fluid && m->integrator == MJPC_INT_IMPLICITFAST) { p.error = "implicitfast with fluid forces (density / viscosity) is not implemented: their velocity derivative is missing"; return false; }
   M.nq = m->nq; M.nv = nv; M.nu = nu; M.nbody = nb; M.njnt = nj; M.ngeom = ng; M.nsite = ns; M.nmocap = m->nmocap;
   M.nkey = m->nkey; M.nvp = NVP_OF(nv); M.ntendon = m->ntendon;
   M.cone = m->cone; M.iterations = m->iterations; M.ls_iterations = m->ls_iterations;

@@ -106,6 +106,7 @@ struct DevModel {
   // actuator transmissions flattened on the host: actuator i owns entries [act_adr[i], act_adr[i+1]) = (dof, qpos address,
   // coefficient = gear [* tendon coefficient]); act_of[e] = the actuator of entry e
   const int *act_adr, *act_dof, *act_qpos, *act_of, *actuator_ctrllimited, *actuator_forcelimited, *actuator_biastype;
+  int fluid; double density, viscosity, wind[3];      // inertia-box fluid model (mj_passive), fluid = density > 0 || viscosity > 0
   int ngravcomp;                            // bodies with gravity compensation: gc_body, gc_force [3 each, world frame]
   const int *gc_body; const double *gc_force;
   int nsiteact;                             // site transmissions: sact_i [actuator, site, body], sact_g [force 3, torque 3 in the body frame]

@@ -438,6 +438,10 @@ DEV void task_residual(Ctx &c, double *residual) {
       residual[2] = lin[0]; residual[3] = lin[1];
       residual[4] = c.ctrl[0]; residual[5] = c.ctrl[1];
     }
+  } else if (id == 14) {   // swimmer.cc:33-46: control, nose - target in the plane
+    int g = MI(task.int_data)[0];
+    PFOR(i, M.nu) residual[i] = c.ctrl[i];
+    if (LANE == 0) { residual[M.nu] = c.geom_xpos[3 * g] - c.mocap_pos[0]; residual[M.nu + 1] = c.geom_xpos[3 * g + 1] - c.mocap_pos[1]; }
   } else if (id == 13) {   // quadrotor.cc:37-60: position - goal, linear velocity, angular velocity (world frame), control - hover thrust
     if (LANE == 0) {
       int b = MI(task.int_data)[0];

@@ -373,7 +373,24 @@ static void QuadrotorTransition(const MjpcHipModel& m, SimState& s, HostTask& t,
   (void)m;
 }
 
+// Swimmer::TransitionLocked (swimmer.cc:52-61): nose within 4 cm of the target -> a new target in [-0.8, 0.8]^2 (the reference draws
+// it from absl::BitGen; here a counter-based hash, so that runs are reproducible)
+static void SwimmerTransition(const MjpcHipModel& m, SimState& s, HostTask& t, const SimFrame& f) {
+  const int g = t.int_data[0];
+  (void)g; (void)m;
+  // the harness frame carries body / site poses, not geoms: the nose geom sits at (0, -0.06, 0) of the head (body 1)
+  const double *R = f.xmat.data() + 9 * 1, *p = f.xpos.data() + 3 * 1;
+  double nose[2] = {p[0] + R[1] * -0.06, p[1] + R[4] * -0.06};
+  double dx = s.mocap[0] - nose[0], dy = s.mocap[1] - nose[1];
+  if (std::sqrt(dx * dx + dy * dy) < 0.04) {
+    unsigned k = (unsigned)++t.int_data[1];
+    auto u = [&](unsigned salt) { unsigned h = (k * 2654435761u) ^ (salt * 40503u); h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; return -0.8 + 1.6 * (h & 0xFFFFFF) / 16777216.0; };
+    s.mocap[0] = u(1); s.mocap[1] = u(2);
+  }
+}
+
 TransitionFn TransitionForTask(int task_id, int mode, double mode_time) {
+  if (task_id == MJPC_TASK_SWIMMER) return SwimmerTransition;
   if (task_id == MJPC_TASK_QUADROTOR) return QuadrotorTransition;
   if (task_id == MJPC_TASK_PARTICLE_TIMEVARYING) return ParticleTransition;
   if (task_id == MJPC_TASK_HUMANOID_TRACK) return TrackingTransition;

@@ -121,8 +121,9 @@ class _Body:
 
 class ModelBuilder:
     def __init__(self, timestep=0.002, gravity=(0, 0, -9.81), cone=0, impratio=1.0,
-                 contact=True, tolerance=1e-8, iterations=100, ls_iterations=50, ls_tolerance=0.01, integrator=0):
+                 contact=True, tolerance=1e-8, iterations=100, ls_iterations=50, ls_tolerance=0.01, integrator=0, density=0.0, viscosity=0.0, wind=(0, 0, 0)):
         self.integrator = integrator      # 0 Euler, 3 implicitfast (mjtIntegrator)
+        self.fluid = (float(density), float(viscosity), tuple(float(x) for x in wind))      # inertia-box fluid model (mjOption)
         self.opt = dict(timestep=timestep, gravity=np.array(gravity, float), cone=cone, impratio=impratio,
                         contact=contact, tolerance=tolerance, iterations=iterations,
                         ls_iterations=ls_iterations, ls_tolerance=ls_tolerance)
@@ -537,7 +538,7 @@ class ModelBuilder:
                  ls_tolerance=o["ls_tolerance"], cone=o["cone"], iterations=o["iterations"],
                  ls_iterations=o["ls_iterations"], disableflags=(0 if o["contact"] else (1 << 4)) | int(getattr(self, "disableflags", 0)),
                  enableflags=0, solver=2, integrator=int(getattr(self, "integrator", 0)), noslip_iterations=0, neq=0, unsupported=0,
-                 nconmax=self.nconmax, nefcmax=self.nefcmax)
+                 nconmax=self.nconmax, nefcmax=self.nefcmax, density=self.fluid[0], viscosity=self.fluid[1], wind=np.array(self.fluid[2]))
         # ---- quantities evaluated at qpos0 (mjModel "set0")
         Mq, Jp, Jr = mass_matrix(M, M["qpos0"])
         Minv = np.linalg.inv(Mq) if nv else np.zeros((0, 0))

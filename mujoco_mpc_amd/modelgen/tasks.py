@@ -87,6 +87,40 @@ def particle_task(fixed=False, timestep=0.01):
     return m, task, defaults
 
 
+TASK_SWIMMER = 14
+
+
+def swimmer(timestep=0.01, integrator=0):
+    """mjpc/tasks/swimmer (swimmer.cc:33-61, task.xml, swimmer.xml.patch on dm_control's swimmer): six 10 g links in a medium of
+    density 1000 (inertia-box fluid forces), planar root (two slides and a hinge), five limited hinge joints with a weak spring, driven
+    through first-order filters (dyntype filter, 0.6 s); contacts disabled; target = a mocap body.  Cost / agent settings are the
+    reference's (horizon 2 s, 10 spline points, exploration 0.05).  The XML asks for the full implicit integrator, which the engine
+    refuses: this model steps with Euler (integrator=0)."""
+    b = ModelBuilder(timestep=timestep, contact=False, density=1000.0, integrator=integrator)
+    b.geom(0, "ground", PLANE, size=(2, 2, 0.01))
+    head = b.body("head", 0, pos=(0, 0, 0.05))
+    b.joint(head, "rootx", SLIDE, axis=(1, 0, 0), pos=(0, -0.05, 0))
+    b.joint(head, "rooty", SLIDE, axis=(0, 1, 0), pos=(0, -0.05, 0))
+    b.joint(head, "rootz", HINGE, axis=(0, 0, 1), pos=(0, -0.05, 0))
+    b.geom(head, "inertial", BOX, size=(0.001, 0.05, 0.01), mass=0.01)
+    nose = b.geom(head, "nose", SPHERE, size=(0.004,), pos=(0, -0.06, 0), mass=0.0)
+    parent = head
+    for k in range(5):
+        seg = b.body(f"segment_{k}", parent, pos=(0, 0.1, 0))
+        b.joint(seg, f"joint_{k}", HINGE, axis=(0, 0, 1), pos=(0, -0.05, 0), limited=True, range=(-math.pi / 2, math.pi / 2), stiffness=0.001, armature=1e-6,
+                solreflimit=(0.05, 0.3), solimplimit=(0, 0.8, 0.1, 0.5, 2))
+        b.geom(seg, f"inertial_{k}", BOX, size=(0.001, 0.05, 0.01), mass=0.01)
+        b.actuator(str(k), f"joint_{k}", gainprm=(2e-3, 0, 0), ctrlrange=(-1, 1), dyntype=2, dynprm=0.6)
+        parent = seg
+    target = b.body("target", 0, pos=(1, 1, 0.05), mocap=True)
+    b.geom(target, "target_g", SPHERE, size=(0.05,), contype=0, conaffinity=0)
+    m = b.compile()
+    task = make_task(TASK_SWIMMER, [(5, 0, 0.1), (2, 2, 10.0, [0.04])], traces=[(OBJ_GEOM, nose)], int_data=[nose, 0])
+    state = np.concatenate([m["qpos0"], np.zeros(m["nv"]), np.zeros(m["na"])])
+    defaults = dict(N=10, P=10, sigma=(0.05, 0.0), interp=2, horizon=201, state=state, mocap=np.array([0.3, -0.2, 0.05, 1, 0, 0, 0.0]))
+    return m, task, defaults
+
+
 TASK_QUADROTOR = 13
 QUADROTOR_STAGES = [(1.2, 0.0, 0.75), (2.3, 0.6, 1.5), (2.7, 0.95, 1.5), (4.6, 0.4, 0.75), (5.0, -1.8, 0.75), (3.4, -2.5, 0.75), (2.5, -2.25, 1.45),
                     (2.5, -2.25, 2.25), (1.5, -1.75, 1.85), (1.05, -1.75, 1.3), (0.1, -1.4, 0.75), (0.0, 0.0, 0.75)]      # task.xml:80-93 (key mpos)
@@ -809,4 +843,4 @@ def terrain_balls(timestep=0.004):
     return m, task, defaults
 
 
-REGISTRY = {"quadrotor": quadrotor, "linkage": linkage, "servo_arm": servo_arm, "particle_timevarying": particle_task, "particle_fixed": lambda: particle_task(fixed=True), "filter_arm": filter_arm, "ball_chain_friction": lambda: ball_chain(tendon_frictionloss=0.3), "quadruped_hill": quadruped_hill, "terrain_balls": terrain_balls, "walker": walker, "acrobot": acrobot, "ball_chain": ball_chain, "cylinder_pile": cylinder_pile, "humanoid_stand": humanoid_stand, "humanoid_walk": humanoid_walk, "particle": particle, "cartpole": cartpole, "quadruped": quadruped, "humanoid_track": humanoid_track, "shadow_hand": shadow_hand}
+REGISTRY = {"swimmer": swimmer, "quadrotor": quadrotor, "linkage": linkage, "servo_arm": servo_arm, "particle_timevarying": particle_task, "particle_fixed": lambda: particle_task(fixed=True), "filter_arm": filter_arm, "ball_chain_friction": lambda: ball_chain(tendon_frictionloss=0.3), "quadruped_hill": quadruped_hill, "terrain_balls": terrain_balls, "walker": walker, "acrobot": acrobot, "ball_chain": ball_chain, "cylinder_pile": cylinder_pile, "humanoid_stand": humanoid_stand, "humanoid_walk": humanoid_walk, "particle": particle, "cartpole": cartpole, "quadruped": quadruped, "humanoid_track": humanoid_track, "shadow_hand": shadow_hand}

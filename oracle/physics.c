@@ -692,6 +692,38 @@ static void passive(const OModel *om, OData *d) {
     frc -= b * velocity;
     for (int w = m->tendon_adr[t]; w < m->tendon_adr[t] + m->tendon_num[t]; w++) d->qfrc_passive[m->jnt_dofadr[m->wrap_objid[w]]] += m->wrap_prm[w] * frc;
   }
+  /* fluid forces, inertia-box model (mj_inertiaBoxFluidModel): per body with mass, the equivalent inertia box, the velocity of the
+   * com in the inertial frame minus the wind, viscous (sphere of the mean box size) and quadratic drag force / torque, applied at
+   * the com */
+  if (m->density > 0 || m->viscosity > 0)
+    for (int b = 1; b < m->nbody; b++) if (m->body_mass[b] >= O_MINVAL) {
+      const double *I = m->body_inertia + 3 * b, *R = d->ximat + 9 * b;
+      double mass = m->body_mass[b], box[3], off[3], vw[3], lvel[6], lfrc[6] = {0, 0, 0, 0, 0, 0}, F[3], T[3];
+      box[0] = sqrt(fmax(O_MINVAL, I[1] + I[2] - I[0]) / mass * 6.0);
+      box[1] = sqrt(fmax(O_MINVAL, I[0] + I[2] - I[1]) / mass * 6.0);
+      box[2] = sqrt(fmax(O_MINVAL, I[0] + I[1] - I[2]) / mass * 6.0);
+      o_sub3(off, d->xipos + 3 * b, d->subtree_com + 3 * m->body_rootid[b]);
+      o_cross(vw, d->cvel + 6 * b, off); o_add3(vw, vw, d->cvel + 6 * b + 3);          /* velocity of the com, world frame */
+      o_sub3(vw, vw, m->wind);
+      o_mulmattvec3(lvel, R, d->cvel + 6 * b); o_mulmattvec3(lvel + 3, R, vw);
+      if (m->viscosity > 0) {
+        double diam = (box[0] + box[1] + box[2]) / 3.0;
+        for (int k = 0; k < 3; k++) { lfrc[k] = -O_PI * diam * diam * diam * m->viscosity * lvel[k]; lfrc[3 + k] = -3.0 * O_PI * diam * m->viscosity * lvel[3 + k]; }
+      }
+      if (m->density > 0) {
+        lfrc[3] -= 0.5 * m->density * box[1] * box[2] * fabs(lvel[3]) * lvel[3];
+        lfrc[4] -= 0.5 * m->density * box[0] * box[2] * fabs(lvel[4]) * lvel[4];
+        lfrc[5] -= 0.5 * m->density * box[0] * box[1] * fabs(lvel[5]) * lvel[5];
+        lfrc[0] -= m->density * box[0] * (box[1] * box[1] * box[1] * box[1] + box[2] * box[2] * box[2] * box[2]) * fabs(lvel[0]) * lvel[0] / 64.0;
+        lfrc[1] -= m->density * box[1] * (box[0] * box[0] * box[0] * box[0] + box[2] * box[2] * box[2] * box[2]) * fabs(lvel[1]) * lvel[1] / 64.0;
+        lfrc[2] -= m->density * box[2] * (box[0] * box[0] * box[0] * box[0] + box[1] * box[1] * box[1] * box[1]) * fabs(lvel[2]) * lvel[2] / 64.0;
+      }
+      o_mulmatvec3(T, R, lfrc); o_mulmatvec3(F, R, lfrc + 3);
+      double *jp = d->work, *jr = d->work + 3 * m->nv;
+      jac_point(om, d, jp, jr, d->xipos + 3 * b, b);
+      for (int i = 0; i < m->nv; i++)
+        d->qfrc_passive[i] += jp[i] * F[0] + jp[m->nv + i] * F[1] + jp[2 * m->nv + i] * F[2] + jr[i] * T[0] + jr[m->nv + i] * T[1] + jr[2 * m->nv + i] * T[2];
+    }
   /* gravity compensation (mj_passive): -gravity * mass * gravcomp applied at the body's centre of mass */
   if (m->body_gravcomp)
     for (int b = 1; b < m->nbody; b++) if (m->body_gravcomp[b] != 0) {

@@ -569,6 +569,13 @@ void oracle_residual(const OModel *om, OData *d, double *residual) {
       o_copy(residual + 4, d->ctrl, m->nu);
       break;
     }
+    case MJPC_TASK_SWIMMER: {     /* swimmer.cc:33-46 */
+      int g = om->t.int_data[0];
+      o_copy(residual, d->ctrl, m->nu);
+      residual[m->nu] = d->geom_xpos[3 * g] - d->mocap_pos[0];
+      residual[m->nu + 1] = d->geom_xpos[3 * g + 1] - d->mocap_pos[1];
+      break;
+    }
     case MJPC_TASK_QUADROTOR: {   /* quadrotor.cc:37-60; the two "Orientation" residuals the XML declares are never written */
       int b = om->t.int_data[0];
       double lin[3];

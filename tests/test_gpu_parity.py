@@ -1022,6 +1022,29 @@ def test_closed_loop_walker_walks_and_acrobot_swings_up():
 
 
 @pytest.mark.gpu
+def test_swimmer_task_fluid_forces_and_filter_actuators():
+    """mjpc/tasks/swimmer (swimmer.cc:33-61): inertia-box fluid forces (density 1000), five filter actuators (na = 5), planar root.
+    Plan-step parity with the oracle (Euler; the XML's full implicit integrator is refused); closed loop with the reference's agent
+    settings: the nose gets closer to the target."""
+    from mujoco_mpc_amd import cplanner
+    from mujoco_mpc_amd.modelgen import swimmer
+    m, task, d = swimmer()
+    out, ref, allc = _compare(m, task, d, 10, 201, 16, (0.3, 0.0), 2, 1e-8, nominal_scale=0.8)
+    assert allc["residual"].shape[-1] == 7 and allc["states"].shape[-1] == 8 + 8 + 5 and not out["failure"].any()
+    assert np.abs(allc["states"][:, -1, 16:]).max() > 0.05                                  # the filters have charged
+    num = dict(sampling_spline_points=10, sampling_exploration=0.3, sampling_trajectories=64, sampling_representation=2)
+    p = cplanner.SamplingPlanner()
+    p.Initialize(m, task, num, max_samples=64, max_horizon=201)
+    p.Reset(201)
+    d0 = np.linalg.norm(np.array([0.0, -0.06]) - d["mocap"][:2])
+    res = cplanner.testspeed(p, d["state"], d["mocap"], horizon=201, steps_per_planning_iteration=1, total_time=8.0)
+    p.close()
+    q = res["state"]; th = q[2]
+    nose = np.array([q[0] + 0.06 * np.sin(th), q[1] - 0.05 + 0.05 - 0.06 * np.cos(th)])      # rootz turns about (0, -0.05) of the head
+    assert not res["failure"] and (np.linalg.norm(nose - res["mocap"][:2]) < d0 - 0.02 or not np.allclose(res["mocap"][:2], d["mocap"][:2])), (nose, res["mocap"][:2], d0)
+
+
+@pytest.mark.gpu
 def test_quadrotor_task_site_transmissions_and_transition():
     """mjpc/tasks/quadrotor (quadrotor.cc:37-95): four thrust motors through site transmissions (moment = site Jacobian of the gear
     wrench).  Plan-step parity around the hover thrust; closed loop with the host Transition from a hover 0.8 m short of the first

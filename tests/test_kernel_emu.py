@@ -26,6 +26,7 @@ def _rel(a, b):
                                                    ("terrain_balls", 3, 60, 6, (0.5, 0.0), 1e-5),   # height field: prisms through the portal-refinement collider
                                                    ("cylinder_pile", 3, 50, 6, (0.5, 0.0), 1e-5),   # cylinder-box / cylinder-cylinder through the portal-refinement collider
                                                    ("particle_timevarying", 5, 51, 6, (0.3, 0.0), 1e-12), ("particle_fixed", 5, 51, 6, (0.3, 0.0), 1e-12),   # registry Particle / ParticleFixed
+                                                   ("swimmer", 10, 101, 6, (0.3, 0.0), 1e-9),       # registry Swimmer: inertia-box fluid forces, filter actuators, planar root (stepped with Euler)
                                                    ("quadrotor", 5, 51, 6, (0.3, 0.0), 1e-9),       # registry Quadrotor: site transmissions (thrust + reaction torque), 15 declared / 13 written residuals
                                                    ("linkage", 4, 80, 6, (0.5, 0.0), 1e-9),         # equality constraints: joint coupling across branches, four-bar connect, pinned free body
                                                    ("servo_arm", 4, 80, 6, (0.5, 0.0), 1e-9),       # mjINT_IMPLICITFAST: velocity servos, saturating force range, damped tendon
@@ -160,7 +161,12 @@ def test_models_the_engine_cannot_roll_out_are_refused_at_create():
         else:
             assert n < 0 and expect in lib.mjpc_hip_last_error().decode(), lib.mjpc_hip_last_error()
     option("solver", 0, "Newton"); option("solver", 1, "Newton"); option("solver", 2, None)
-    option("integrator", 1, "Euler"); option("integrator", 2, "Euler"); option("integrator", 3, None)        # RK4, implicit refused; implicitfast accepted
+    option("integrator", 1, "Euler"); option("integrator", 2, "Euler"); option("integrator", 3, None)
+    option("density", 1000.0, None); option("viscosity", 0.1, None)                    # inertia-box fluid forces: taken with Euler ...
+    bf = ModelBuilder(integrator=3, density=10.0)                                       # ... refused with implicitfast (no velocity derivative)
+    bodyf = bf.body("a", 0, pos=(0, 0, 1)); bf.joint(bodyf, "f", FREE); bf.geom(bodyf, "g", SPHERE, size=(0.1,))
+    cmf = capi.CModel(bf.compile(), task)
+    assert lib.mjpc_hip_layout_bytes(ctypes.byref(cmf.c_model), ctypes.byref(cmf.c_task), 1) < 0 and b"fluid" in lib.mjpc_hip_last_error()        # RK4, implicit refused; implicitfast accepted
     option("noslip_iterations", 3, "noslip")
     option("disableflags", 1 << 6, "disableflags"); option("disableflags", 1 << 14, "disableflags")          # gravity, eulerdamp
     option("disableflags", (1 << 0) | (1 << 2) | (1 << 3) | (1 << 4) | (1 << 12), None)

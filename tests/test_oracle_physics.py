@@ -510,6 +510,34 @@ def test_tendon_spring_and_damper_closed_form():
     assert np.allclose(m2["tendon_lengthspring"], 0.0)
 
 
+def test_fluid_forces_inertia_box_closed_form():
+    """mj_inertiaBoxFluidModel on a free box (half extents a, b, c => equivalent box 2a x 2b x 2c): quadratic drag -1/2 rho A |v| v per
+    axis, viscous drag -3 pi d mu v with d the mean box size, their angular counterparts, wind subtracted from the linear velocity;
+    in a rotated body the forces follow the body axes."""
+    a, bb, cc, mass, rho, mu = 0.1, 0.06, 0.03, 0.5, 1000.0, 0.2
+    def box(density, viscosity, wind=(0, 0, 0)):
+        b = ModelBuilder(timestep=0.002, gravity=(0, 0, 0), contact=False, density=density, viscosity=viscosity, wind=wind)
+        l = b.body("l", 0); b.joint(l, "f", FREE); b.geom(l, "g", BOX, size=(a, bb, cc), mass=mass)
+        m = b.compile()
+        return ol.Oracle(m, _copy_task(m))
+    q0 = np.array([0, 0, 0, 1, 0, 0, 0.0]); v = np.array([1.0, -2.0, 0.5])
+    area = np.array([4 * bb * cc, 4 * a * cc, 4 * a * bb]); ext = 2 * np.array([a, bb, cc]); diam = ext.mean()
+    r = box(rho, 0).forward(q0, np.concatenate([v, np.zeros(3)]))
+    assert np.allclose(r["qacc"][:3], -0.5 * rho * area * np.abs(v) * v / mass, rtol=1e-12)
+    r = box(0, mu).forward(q0, np.concatenate([v, np.zeros(3)]))
+    assert np.allclose(r["qacc"][:3], -3 * np.pi * diam * mu * v / mass, rtol=1e-12)
+    r = box(rho, mu, wind=(0.3, 0, 0)).forward(q0, np.concatenate([v, np.zeros(3)]))
+    vr = v - np.array([0.3, 0, 0])
+    assert np.allclose(r["qacc"][:3], (-0.5 * rho * area * np.abs(vr) * vr - 3 * np.pi * diam * mu * vr) / mass, rtol=1e-12)
+    w = 4.0; Ixx = mass / 3 * (bb ** 2 + cc ** 2)                                     # spin about the body's x axis: no gyroscopic term
+    r = box(rho, mu).forward(q0, np.array([0, 0, 0, w, 0, 0]))
+    tq = -rho * ext[0] * (ext[1] ** 4 + ext[2] ** 4) * abs(w) * w / 64 - np.pi * diam ** 3 * mu * w
+    assert np.allclose(r["qacc"][3:], [tq / Ixx, 0, 0], rtol=1e-10, atol=1e-12) and np.abs(r["qacc"][:3]).max() < 1e-12
+    q90 = np.array([0, 0, 0, np.cos(np.pi / 4), 0, 0, np.sin(np.pi / 4)])              # rotated 90 deg about z: body x along world y
+    r = box(rho, 0).forward(q90, np.array([0, 1.5, 0, 0, 0, 0]))
+    assert np.allclose(r["qacc"][:3], [0, -0.5 * rho * area[0] * 1.5 * 1.5 / mass, 0], rtol=1e-10, atol=1e-12)
+
+
 def test_gravity_compensation_closed_form():
     """mj_passive gravcomp: -gravity * mass * gravcomp at the body's com.  A pendulum with gravcomp 1 feels no gravity torque, with 0.5
     half of it; compensation of the outer link also unloads the inner joint through the point Jacobian."""

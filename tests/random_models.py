@@ -119,6 +119,8 @@ def random_model(seed, portal_pairs=False):
     for bid in bodies:                              # menagerie-arm style gravity compensation on some links
         if rng_fr.random() < 0.15:
             b.gravcomp[bid] = float(rng_fr.choice([0.5, 1.0]))
+    if not want_fast and rng_fr.random() < 0.25:    # a medium: inertia-box fluid forces (Euler only), sometimes with wind
+        b.fluid = (float(rng_fr.choice([0.0, 50.0, 300.0])), float(rng_fr.choice([0.0, 0.05, 0.5])), (float(rng_fr.uniform(-1, 1)), 0.0, 0.0) if rng_fr.random() < 0.5 else (0.0, 0.0, 0.0))
     if b.tendons and rng_fr.random() < 0.25:       # a tendon equality: the first tendon held at (a multiple of) the second's length, or at its own
         b.tendon_equality("t0", "t1" if len(b.tendons) > 1 and rng_fr.random() < 0.6 else None, polycoef=(0.0, float(rng_fr.uniform(-1, 1)), 0, 0, 0))
     if not b.actuators:

@@ -41,7 +41,7 @@ enum { MJPC_UNSUP_FLUID = 1,          /* fluid forces of the ellipsoid model (a 
        MJPC_UNSUP_ACTUATOR_GAIN = 4,  /* gaintype other than fixed, biastype other than none / affine */
        MJPC_UNSUP_ACTUATOR_DYN = 8,   /* dyntype muscle / user, actnum != 1, actearly */
        MJPC_UNSUP_SPATIAL_TENDON = 16,/* wrap objects other than joints */
-       MJPC_UNSUP_JNT_ACTFRC = 32,    /* jnt_actfrclimited */
+       MJPC_UNSUP_JNT_ACTFRC = 32,    /* (no longer set: jnt_actfrclimited / jnt_actfrcrange travel in the view) */
        MJPC_UNSUP_FLEX_SKIN_PLUGIN = 64 /* flexes, plugins, user callbacks other than the residual */ };
 enum { MJPC_DSBL_CONSTRAINT = 1 << 0, MJPC_DSBL_EQUALITY = 1 << 1, MJPC_DSBL_FRICTIONLOSS = 1 << 2, MJPC_DSBL_LIMIT = 1 << 3,
        MJPC_DSBL_SENSOR = 1 << 12, MJPC_DSBL_MIDPHASE = 1 << 13, MJPC_ENBL_OVERRIDE = 1 << 0, MJPC_ENBL_MULTICCD = 1 << 4 };
@@ -133,6 +133,9 @@ typedef struct MjpcHipModel {
   const int *body_jntnum, *body_jntadr, *body_dofnum, *body_dofadr;
   const double *body_pos, *body_quat, *body_ipos, *body_iquat;
   const double *body_mass, *body_subtreemass, *body_inertia, *body_invweight0;
+  /* joint-level clamp of the total actuator force on a hinge / slide joint (mjModel.jnt_actfrclimited / jnt_actfrcrange, applied to
+   * qfrc_actuator at the end of mj_fwdActuation); NULL = none */
+  const int *jnt_actfrclimited; const double *jnt_actfrcrange;
   const double *body_gravcomp;      /* [nbody] gravity compensation (mj_passive: force -gravity * mass * gravcomp at the body's com), NULL = none */
   /* joints */
   const int *jnt_type, *jnt_qposadr, *jnt_dofadr, *jnt_bodyid, *jnt_limited;

@@ -54,7 +54,7 @@ static void FillModelView(const mjModel* m, MjpcHipModel& v, std::vector<int>& j
                           std::vector<int>& trnid, std::vector<int>& tendon_limited, std::vector<int>& wrap_objid,
                           std::vector<double>& gainprm, std::vector<double>& biasprm, std::vector<double>& gear,
                           std::vector<double>& wrap_prm, std::vector<double>& mesh_vert, std::vector<double>& hfield_size,
-                          std::vector<double>& hfield_data, std::vector<int>& act_i, std::vector<double>& dynprm, std::vector<int>& eq_active) {
+                          std::vector<double>& hfield_data, std::vector<int>& act_i, std::vector<double>& dynprm, std::vector<int>& eq_active, std::vector<int>& actfrclimited) {
   std::memset(&v, 0, sizeof(v));
   v.nq = m->nq; v.nv = m->nv; v.nu = m->nu; v.na = m->na; v.nbody = m->nbody; v.njnt = m->njnt; v.ngeom = m->ngeom;
   v.nsite = m->nsite; v.nmocap = m->nmocap; v.nuserdata = m->nuserdata; v.nkey = m->nkey; v.nexclude = m->nexclude;
@@ -77,7 +77,6 @@ static void FillModelView(const mjModel* m, MjpcHipModel& v, std::vector<int>& j
         (dyn != mjDYN_NONE && m->actuator_actnum[i] != 1) || m->actuator_actearly[i]) v.unsupported |= MJPC_UNSUP_ACTUATOR_DYN;
   }
   for (int w = 0; w < m->nwrap; w++) if (m->wrap_type[w] != mjWRAP_JOINT) v.unsupported |= MJPC_UNSUP_SPATIAL_TENDON;
-  for (int j = 0; j < m->njnt; j++) if (m->jnt_actfrclimited[j]) v.unsupported |= MJPC_UNSUP_JNT_ACTFRC;
   if (m->nflex > 0 || m->nplugin > 0) v.unsupported |= MJPC_UNSUP_FLEX_SKIN_PLUGIN;
   v.nconmax = 0; v.nefcmax = 0;      // engine defaults (32 contacts, 128 rows per candidate)
   v.body_parentid = m->body_parentid; v.body_rootid = m->body_rootid; v.body_weldid = m->body_weldid;
@@ -86,6 +85,7 @@ static void FillModelView(const mjModel* m, MjpcHipModel& v, std::vector<int>& j
   v.body_pos = m->body_pos; v.body_quat = m->body_quat; v.body_ipos = m->body_ipos; v.body_iquat = m->body_iquat;
   v.body_mass = m->body_mass; v.body_subtreemass = m->body_subtreemass; v.body_inertia = m->body_inertia;
   v.body_invweight0 = m->body_invweight0; v.body_gravcomp = m->body_gravcomp;
+  actfrclimited = Widen(m->jnt_actfrclimited, m->njnt); v.jnt_actfrclimited = actfrclimited.data(); v.jnt_actfrcrange = m->jnt_actfrcrange;
   v.jnt_type = m->jnt_type; v.jnt_qposadr = m->jnt_qposadr; v.jnt_dofadr = m->jnt_dofadr; v.jnt_bodyid = m->jnt_bodyid;
   jnt_limited = Widen(m->jnt_limited, m->njnt); v.jnt_limited = jnt_limited.data();
   v.jnt_pos = m->jnt_pos; v.jnt_axis = m->jnt_axis; v.jnt_stiffness = m->jnt_stiffness; v.jnt_range = m->jnt_range;
@@ -193,7 +193,7 @@ void HipSamplingPlanner::Initialize(mjModel* model, const Task& task) {
   sliding_plan_ = n.sampling_sliding_plan;
   if (num_trajectory_ > kMaxTrajectoryHip) mju_error_i("Too many trajectories, %d is the maximum allowed.", kMaxTrajectoryHip);
   FillModelView(model, model_view_, jnt_limited_, ctrllimited_, forcelimited_, biastype_, trntype_, trnid_, tendon_limited_,
-                wrap_objid_, gainprm_, biasprm_, gear_, wrap_prm_, mesh_vert_, hfield_size_, hfield_data_, act_i_, dynprm_, eq_active_);
+                wrap_objid_, gainprm_, biasprm_, gear_, wrap_prm_, mesh_vert_, hfield_size_, hfield_data_, act_i_, dynprm_, eq_active_, actfrclimited_);
   FillTaskView(task, model, task_view_, norm_, trace_type_, trace_id_, task_int_, task_dbl_);
   mjpc_hip::SetErrorHandler([](const char* msg) { mju_error("HipSamplingPlanner: %s", msg); });
   impl_.Initialize(&model_view_, &task_view_, n);           // creates the engines (model may have changed: old ones dropped)

@@ -96,7 +96,7 @@ class HipSamplingPlanner : public RankedPlanner {
   MjpcHipModel model_view_{};
   MjpcHipTask task_view_{};
   std::vector<int> jnt_limited_, ctrllimited_, forcelimited_, biastype_, trntype_, trnid_, tendon_limited_, wrap_objid_, trace_type_, trace_id_,
-      norm_, task_int_, act_i_, eq_active_;
+      norm_, task_int_, act_i_, eq_active_, actfrclimited_;
   std::vector<double> gainprm_, biasprm_, gear_, wrap_prm_, mesh_vert_, hfield_size_, hfield_data_, task_dbl_, dynprm_;
   Trajectory best_, scratch_trajectory_;
   SamplingPolicy scratch_policy_;

@@ -26,7 +26,7 @@ _OPTIONAL_MESH = ("nmesh", "nmeshvert", "geom_dataid", "mesh_vertadr", "mesh_ver
 _MODEL_INT_ARRAYS_BODY = ["body_parentid", "body_rootid", "body_weldid", "body_mocapid", "body_jntnum", "body_jntadr",
                           "body_dofnum", "body_dofadr"]
 _MODEL_DBL_ARRAYS_BODY = ["body_pos", "body_quat", "body_ipos", "body_iquat", "body_mass", "body_subtreemass",
-                          "body_inertia", "body_invweight0", "body_gravcomp"]
+                          "body_inertia", "body_invweight0"]
 
 
 class MjpcHipModel(C.Structure):
@@ -40,6 +40,7 @@ class MjpcHipModel(C.Structure):
            ("nconmax", C.c_int), ("nefcmax", C.c_int)]
         + [(n, c_int_p) for n in _MODEL_INT_ARRAYS_BODY]
         + [(n, c_double_p) for n in _MODEL_DBL_ARRAYS_BODY]
+        + [("jnt_actfrclimited", c_int_p), ("jnt_actfrcrange", c_double_p), ("body_gravcomp", c_double_p)]
         + [(n, c_int_p) for n in ["jnt_type", "jnt_qposadr", "jnt_dofadr", "jnt_bodyid", "jnt_limited"]]
         + [(n, c_double_p) for n in ["jnt_pos", "jnt_axis", "jnt_stiffness", "jnt_range", "jnt_margin",
                                      "jnt_solref", "jnt_solimp", "qpos0", "qpos_spring"]]
@@ -125,6 +126,8 @@ class CModel:
                      else np.zeros(nt * (2 if name == "tendon_lengthspring" else 1)))
             elif name in ("density", "viscosity", "wind") and name not in model:      # models built before fluid forces existed
                 v = (0.0, 0.0, 0.0) if name == "wind" else 0.0
+            elif name in ("jnt_actfrclimited", "jnt_actfrcrange") and name not in model:      # models built before the joint-level force clamp existed
+                v = np.zeros(int(model["njnt"]) * (2 if name == "jnt_actfrcrange" else 1))
             elif name == "body_gravcomp" and name not in model:       # models built before gravity compensation existed
                 v = np.zeros(int(model["nbody"]))
             elif name == "actuator_gear6" and name not in model:      # models built before site transmissions existed

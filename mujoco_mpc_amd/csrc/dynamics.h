@@ -223,7 +223,18 @@ DEV void velocity_stage(Ctx &c, int mfact_seq) {
     }
   }
   SYNC();
-  if (M.ntendon_passive + M.nsiteact + M.ngravcomp + M.fluid > 0) {      // (one test for the rare extras)
+  if (M.smooth_extras) {      // one host-made flag for the rare extras: tendon passive forces, site transmissions, gravity compensation, fluid, joint force clamp
+    if (M.nactfrc > 0) {
+      // jnt_actfrclimited: the total actuator force on the joint's dof is clamped (end of mj_fwdActuation); applied as a correction
+      // to what the gather above added
+      PFOR(k, M.nactfrc) {
+        int dd = MI(actfrc_dof)[k];
+        double act = 0;
+        for (int q = MI(dact_adr)[dd]; q < MI(dact_adr)[dd + 1]; q++) { int e = MI(dact_e)[q]; act += MD(act_coef)[e] * c.actuator_force[MI(act_of)[e]]; }
+        c.qfrc_smooth[dd] += d_clip(act, MD(actfrc_range)[2 * k], MD(actfrc_range)[2 * k + 1]) - act;
+      }
+      SYNC();
+    }
     if (M.fluid) {
       // fluid forces, inertia-box model (mj_inertiaBoxFluidModel): per body the world force / torque at its com into cfrc (dead by
       // now: the bias forces have been read off cfrc_sub), then J^T of them per dof

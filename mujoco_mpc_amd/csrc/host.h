@@ -266,6 +266,15 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
     dadr[nv] = (int)dent.size();
     M.dact_adr = as_off<int>(put_i(p, dadr.data(), dadr.size())); M.dact_e = as_off<int>(put_i(p, dent.data(), dent.size()));
     M.act_coef = as_off<double>(put_d(p, cf.data(), cf.size())); }
+  // joint-level clamp of the total actuator force: [dof] and [lo, hi] of the limited scalar joints
+  { std::vector<int> fd_; std::vector<double> fr_;
+    for (int j = 0; j < nj && m->jnt_actfrclimited && m->jnt_actfrcrange; j++)
+      if (m->jnt_actfrclimited[j] && (m->jnt_type[j] == MJPC_JNT_HINGE || m->jnt_type[j] == MJPC_JNT_SLIDE)) {
+        fd_.push_back(m->jnt_dofadr[j]); fr_.push_back(m->jnt_actfrcrange[2 * j]); fr_.push_back(m->jnt_actfrcrange[2 * j + 1]);
+      }
+    M.nactfrc = (int)fd_.size();
+    if (M.nactfrc) for (int i = 0; i < nu; i++) if (m->actuator_trntype[i] == MJPC_TRN_SITE) { p.error = "jnt_actfrclimited together with site transmissions is not implemented"; return false; }
+    M.actfrc_dof = as_off<int>(put_i(p, fd_.data(), fd_.size())); M.actfrc_range = as_off<double>(put_d(p, fr_.data(), fr_.size())); }
   // gravity compensation: bodies with gravcomp != 0 and the force -gravity * mass * gravcomp (world frame, constant)
   { std::vector<int> gb; std::vector<double> gf;
     for (int b = 1; b < nb && m->body_gravcomp; b++) if (m->body_gravcomp[b] != 0) {
@@ -447,6 +456,7 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
     }
     M.ntendon_passive = (int)ids.size();
     M.tpass_id = as_off<int>(put_i(p, ids.data(), ids.size())); M.tpass_prm = as_off<double>(put_d(p, prm.data(), prm.size())); }
+  M.smooth_extras = M.ntendon_passive + M.nsiteact + M.ngravcomp + M.fluid + M.nactfrc;
   M.any_damping = 0;
   for (int i = 0; i < nv; i++) if (m->dof_damping[i] > 0) M.any_damping = 1;
   // implicitfast: velocity derivatives of the smooth forces beyond joint damping, as entries (i >= j, coefficient, actuator or -1) of
@@ -539,7 +549,7 @@ static inline DevModel relocate(const PackedModel &p, const int *ibase, const do
   fi(M.level_adr); fi(M.level_body); fi(M.subtree_adr); fi(M.subtree_list); fi(M.chain_adr); fi(M.chain_list); fi(M.mpair_i); fi(M.mpair_j); fi(M.hpair_i); fi(M.hpair_j); fi(M.zpair_i); fi(M.zpair_j);
   { const double *q = reinterpret_cast<const double *>(M.body_dofmask); fd(q); M.body_dofmask = reinterpret_cast<const unsigned long long *>(q); }
   { const double *q = reinterpret_cast<const double *>(M.body_patmask); fd(q); M.body_patmask = reinterpret_cast<const unsigned long long *>(q); }
-  fi(M.pair_g1); fi(M.pair_g2); fi(M.fric_dof); fi(M.limit_jnt); fi(M.limit_ball); fi(M.ray_geom); fi(M.tpass_id); fd(M.tpass_prm); fi(M.tfric_id); fd(M.tfric_prm); fi(M.idrv_e); fd(M.idrv_c); fi(M.eq_tab); fd(M.eq_prm); fi(M.sact_i); fd(M.sact_g); fi(M.gc_body); fd(M.gc_force);
+  fi(M.pair_g1); fi(M.pair_g2); fi(M.fric_dof); fi(M.limit_jnt); fi(M.limit_ball); fi(M.ray_geom); fi(M.tpass_id); fd(M.tpass_prm); fi(M.tfric_id); fd(M.tfric_prm); fi(M.idrv_e); fd(M.idrv_c); fi(M.eq_tab); fd(M.eq_prm); fi(M.sact_i); fd(M.sact_g); fi(M.gc_body); fd(M.gc_force); fi(M.actfrc_dof); fd(M.actfrc_range);
   DevTask &T = M.task;
   fi(T.dim_norm_residual); fi(T.norm); fi(T.num_norm_parameter); fi(T.trace_objtype); fi(T.trace_objid); fi(T.int_data);
   fd(T.weight); fd(T.norm_parameter); fd(T.parameters); fd(T.dbl_data);

@@ -107,6 +107,9 @@ struct DevModel {
   // coefficient = gear [* tendon coefficient]); act_of[e] = the actuator of entry e
   const int *act_adr, *act_dof, *act_qpos, *act_of, *actuator_ctrllimited, *actuator_forcelimited, *actuator_biastype;
   int fluid; double density, viscosity, wind[3];      // inertia-box fluid model (mj_passive), fluid = density > 0 || viscosity > 0
+  int smooth_extras;                        // ntendon_passive + nsiteact + ngravcomp + fluid + nactfrc (one test in velocity_stage)
+  int nactfrc;                              // joints with a clamp on the total actuator force: actfrc_dof, actfrc_range [lo, hi]
+  const int *actfrc_dof; const double *actfrc_range;
   int ngravcomp;                            // bodies with gravity compensation: gc_body, gc_force [3 each, world frame]
   const int *gc_body; const double *gc_force;
   int nsiteact;                             // site transmissions: sact_i [actuator, site, body], sact_g [force 3, torque 3 in the body frame]

@@ -136,6 +136,7 @@ class ModelBuilder:
         self.tendons: list[dict] = []
         self.equalities: list[dict] = []
         self.gravcomp: dict[int, float] = {}
+        self.actfrc: dict[str, tuple] = {}
         self.key_mpos = None          # optional [nkey, 3*nmocap]
         self.excludes: list[tuple] = []
         self.nuserdata = 0
@@ -159,7 +160,9 @@ class ModelBuilder:
 
     def joint(self, body, name, type=HINGE, axis=(0, 0, 1), pos=(0, 0, 0), limited=False, range=(0, 0),
               damping=0.0, armature=0.0, frictionloss=0.0, stiffness=0.0, ref=0.0, springref=0.0, margin=0.0,
-              solreflimit=DEF_SOLREF, solimplimit=DEF_SOLIMP, solreffriction=DEF_SOLREF, solimpfriction=DEF_SOLIMP):
+              solreflimit=DEF_SOLREF, solimplimit=DEF_SOLIMP, solreffriction=DEF_SOLREF, solimpfriction=DEF_SOLIMP, actuatorfrcrange=None):
+        if actuatorfrcrange is not None:      # MJCF actuatorfrcrange: clamp of the total actuator force on this (scalar) joint
+            self.actfrc[name] = tuple(actuatorfrcrange)
         ax = np.array(axis, float)
         if type in (HINGE, SLIDE):
             ax = ax / np.linalg.norm(ax)
@@ -486,6 +489,8 @@ class ModelBuilder:
         M["actuator_ctrlrange"] = np.array([a["ctrlrange"] for a in A], float).reshape(nu, 2)
         M["actuator_forcerange"] = np.array([a["forcerange"] for a in A], float).reshape(nu, 2)
         M["actuator_gear6"] = np.array([a["gear6"] if a.get("gear6") is not None else (a["gear"], 0, 0, 0, 0, 0) for a in A], float).reshape(nu, 6)
+        M["jnt_actfrclimited"] = np.array([int(j.name in self.actfrc) for j in joints], np.int32)
+        M["jnt_actfrcrange"] = np.array([self.actfrc.get(j.name, (0.0, 0.0)) for j in joints], float).reshape(len(joints), 2)
         M["actuator_dyntype"] = np.array([a.get("dyntype", 0) for a in A], np.int32)
         adr = []; na = 0
         for a in A:

@@ -200,7 +200,7 @@ def servo_arm(timestep=0.005, integrator=3):
     parent = 0
     for k, (axis, ln) in enumerate((((0, 1, 0), 0.3), ((0, 1, 0), 0.25), ((1, 0, 0), 0.2))):
         body = b.body(f"l{k}", parent, pos=(0, 0, 0) if k == 0 else (0, 0, -(0.3, 0.25)[k - 1]), gravcomp=(1.0, 0.5, 0.0)[k])      # menagerie-arm style gravity compensation
-        b.joint(body, f"j{k}", HINGE, axis=axis, damping=0.02, armature=0.002)
+        b.joint(body, f"j{k}", HINGE, axis=axis, damping=0.02, armature=0.002, actuatorfrcrange=(-1.2, 1.2) if k == 0 else None)      # joint-level clamp
         b.geom(body, f"g{k}", CAPSULE, size=(0.02, 0), fromto=(0, 0, 0, 0, 0, -ln), mass=0.3 - 0.08 * k)
         parent = body
     tip = b.site(parent, "tip", pos=(0, 0, -0.2))

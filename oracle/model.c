@@ -43,6 +43,7 @@ OModel *oracle_create(const MjpcHipModel *src, const MjpcHipTask *task) {
   CD(body_pos, 3 * nb); CD(body_quat, 4 * nb); CD(body_ipos, 3 * nb); CD(body_iquat, 4 * nb);
   CD(body_mass, nb); CD(body_subtreemass, nb); CD(body_inertia, 3 * nb); CD(body_invweight0, 2 * nb);
   if (src->body_gravcomp) CD(body_gravcomp, nb);
+  if (src->jnt_actfrclimited && src->jnt_actfrcrange) { CI(jnt_actfrclimited, nj); CD(jnt_actfrcrange, 2 * nj); }
   CI(jnt_type, nj); CI(jnt_qposadr, nj); CI(jnt_dofadr, nj); CI(jnt_bodyid, nj); CI(jnt_limited, nj);
   CD(jnt_pos, 3 * nj); CD(jnt_axis, 3 * nj); CD(jnt_stiffness, nj); CD(jnt_range, 2 * nj); CD(jnt_margin, nj);
   CD(jnt_solref, 2 * nj); CD(jnt_solimp, 5 * nj); CD(qpos0, src->nq); CD(qpos_spring, src->nq);

@@ -809,6 +809,13 @@ static void actuation(const OModel *om, OData *d) {
       d->qfrc_actuator[m->jnt_dofadr[j]] += coef * force;
     }
   }
+  /* joint-level clamp of the total actuator force (end of mj_fwdActuation): scalar joints with jnt_actfrclimited */
+  if (m->jnt_actfrclimited && m->jnt_actfrcrange)
+    for (int jn = 0; jn < m->njnt; jn++)
+      if (m->jnt_actfrclimited[jn] && (m->jnt_type[jn] == MJPC_JNT_HINGE || m->jnt_type[jn] == MJPC_JNT_SLIDE)) {
+        int da = m->jnt_dofadr[jn];
+        d->qfrc_actuator[da] = o_clip(d->qfrc_actuator[da], m->jnt_actfrcrange[2 * jn], m->jnt_actfrcrange[2 * jn + 1]);
+      }
 }
 
 /* ---- primal constraint solver (Newton) ------------------------------------------------ */

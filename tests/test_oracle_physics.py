@@ -510,6 +510,18 @@ def test_tendon_spring_and_damper_closed_form():
     assert np.allclose(m2["tendon_lengthspring"], 0.0)
 
 
+def test_joint_actuator_force_range_closed_form():
+    """jnt_actfrclimited: the SUM of the actuator forces on a scalar joint is clamped to jnt_actfrcrange (end of mj_fwdActuation)."""
+    b = ModelBuilder(timestep=0.002, gravity=(0, 0, 0), contact=False)
+    l = b.body("l", 0); b.joint(l, "h", HINGE, axis=(0, 1, 0), actuatorfrcrange=(-0.5, 0.8)); b.geom(l, "g", SPHERE, size=(0.1,), pos=(0, 0, -0.5), mass=2.0)
+    b.actuator("m1", "h", gear=1.0, ctrlrange=(-2, 2)); b.actuator("m2", "h", gear=2.0, ctrlrange=(-2, 2))
+    m = b.compile()
+    o = ol.Oracle(m, _copy_task(m))
+    inertia = 2.0 * (0.5 ** 2 + 0.4 * 0.1 ** 2)
+    for u, tau in (((0.2, 0.1), 0.4), ((1.0, 0.5), 0.8), ((-1.0, -0.4), -0.5), ((1.5, -0.5), 0.5)):
+        assert o.forward([0.1], [0.0], ctrl=list(u))["qacc"][0] == pytest.approx(tau / inertia, rel=1e-12)
+
+
 def test_fluid_forces_inertia_box_closed_form():
     """mj_inertiaBoxFluidModel on a free box (half extents a, b, c => equivalent box 2a x 2b x 2c): quadratic drag -1/2 rho A |v| v per
     axis, viscous drag -3 pi d mu v with d the mean box size, their angular counterparts, wind subtracted from the linear velocity;

@@ -90,6 +90,7 @@ struct DevModel {
   int nlimit_ball;      // limited ball joints (limit_ball[])
   int limit_cross;      // some limited tendon couples dofs outside the Hessian's pattern: every build is a dense one
   int ntendon_passive;  // tendons with a spring or a damper (tpass_*)
+  int smooth_extras;    // ntendon_passive + nsiteact + ngravcomp + fluid + nactfrc: one test in velocity_stage for all the rare extras
   int ntfric;           // tendons with friction loss (tfric_*): one static friction row each, behind the single-entry rows
   int cone, iterations, ls_iterations, disableflags, con_stride, maxdim, tree_ok, nact;
   double timestep, gravity[3], impratio, tolerance, ls_tolerance, meaninertia;
@@ -107,7 +108,6 @@ struct DevModel {
   // coefficient = gear [* tendon coefficient]); act_of[e] = the actuator of entry e
   const int *act_adr, *act_dof, *act_qpos, *act_of, *actuator_ctrllimited, *actuator_forcelimited, *actuator_biastype;
   int fluid; double density, viscosity, wind[3];      // inertia-box fluid model (mj_passive), fluid = density > 0 || viscosity > 0
-  int smooth_extras;                        // ntendon_passive + nsiteact + ngravcomp + fluid + nactfrc (one test in velocity_stage)
   int nactfrc;                              // joints with a clamp on the total actuator force: actfrc_dof, actfrc_range [lo, hi]
   const int *actfrc_dof; const double *actfrc_range;
   int ngravcomp;                            // bodies with gravity compensation: gc_body, gc_force [3 each, world frame]

@@ -120,6 +120,16 @@ def parse_mjcf(path_or_text, base_dir=None, reader=None, missing_ok=()):
             opt["cone"] = 1 if o.get("cone") == "elliptic" else 0
         if o.get("gravity") is not None:
             opt["gravity"] = tuple(_floats(o.get("gravity")))
+        for k in ("density", "viscosity"):          # inertia-box fluid model
+            if o.get(k) is not None:
+                opt[k] = float(o.get(k))
+        if o.get("wind") is not None:
+            opt["wind"] = tuple(_floats(o.get("wind")))
+        if o.get("integrator") is not None:
+            integ = o.get("integrator")
+            if integ not in ("Euler", "implicitfast"):
+                raise ValueError(f"integrator {integ} not in the supported subset (Euler, implicitfast)")
+            opt["integrator"] = 0 if integ == "Euler" else 3
         for fl in o.iter("flag"):
             if fl.get("contact") == "disable":
                 opt["contact"] = False
@@ -152,7 +162,7 @@ def parse_mjcf(path_or_text, base_dir=None, reader=None, missing_ok=()):
                     inertial = dict(pos=tuple(_floats(ine.get("pos", "0 0 0"))), quat=tuple(_floats(ine.get("quat", "1 0 0 0"))),
                                     mass=float(ine.get("mass")), diaginertia=tuple(_floats(ine.get("diaginertia", "0 0 0"))))
                 bid = b.body(ch.get("name", f"body{len(b.bodies)}"), parent, pos=tuple(_floats(ch.get("pos", "0 0 0"))), quat=quat_of(ch.attrib),
-                             mocap=ch.get("mocap") == "true", inertial=inertial)
+                             mocap=ch.get("mocap") == "true", inertial=inertial, gravcomp=float(ch.get("gravcomp", 0)))
                 add_body(ch, bid, cc)
             elif ch.tag == "freejoint":
                 b.joint(parent, ch.get("name", f"joint{len(b.joints)}"), FREE)
@@ -171,6 +181,8 @@ def parse_mjcf(path_or_text, base_dir=None, reader=None, missing_ok=()):
                     kw["solreflimit"] = tuple(_floats(a["solreflimit"]))
                 if "solimplimit" in a:
                     v = _floats(a["solimplimit"]); kw["solimplimit"] = tuple(v + [0.9, 0.95, 0.001, 0.5, 2][len(v):])
+                if "actuatorfrcrange" in a and a.get("actuatorfrclimited", "auto") in ("true", "auto"):
+                    kw["actuatorfrcrange"] = tuple(_floats(a["actuatorfrcrange"]))
                 b.joint(parent, a.get("name", f"joint{len(b.joints)}"), **kw)
             elif ch.tag == "geom":
                 a = attrs(ch, "geom", childclass)
@@ -206,7 +218,7 @@ def parse_mjcf(path_or_text, base_dir=None, reader=None, missing_ok=()):
     for act in root.findall("actuator"):
         for ch in act:
             kind = ch.tag
-            if kind not in ("motor", "position", "general"):
+            if kind not in ("motor", "position", "velocity", "general"):
                 raise ValueError(f"actuator <{kind}> not in the supported subset")
             cls = ch.get("class")
             a = dict(defaults.get(cls, kind)); a.update(ch.attrib)
@@ -220,7 +232,9 @@ def parse_mjcf(path_or_text, base_dir=None, reader=None, missing_ok=()):
                 kw["forcerange"] = tuple(_floats(a["forcerange"]))
             fl = a.get("forcelimited", "auto")
             kw["forcelimited"] = (fl == "true") or (fl == "auto" and "forcerange" in a)
-            if kind == "position":
+            if kind == "velocity":               # MJCF <velocity kv>: gain kv, bias (0, 0, -kv)
+                kvv = float(a.get("kv", 1)); kw.update(gainprm=(kvv, 0, 0), biastype=1, biasprm=(0, 0, -kvv))
+            elif kind == "position":
                 kp = float(a.get("kp", 1)); kv = float(a.get("kv", 0))
                 kw.update(gainprm=(kp, 0, 0), biastype=1, biasprm=(0, -kp, -kv))
             elif kind == "general":

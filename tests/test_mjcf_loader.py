@@ -198,3 +198,39 @@ def test_task_tables_of_models_that_need_the_zoo(rel, missing, gen):
         if body.mocap and body.name in m2["names"]["body"]:
             mid = int(m2["body_mocapid"][m2["names"]["body"][body.name]])
             assert np.allclose(d["mocap"][7 * mid:7 * mid + 3], body.pos, atol=0), body.name
+
+
+@pytest.mark.parametrize("rel, missing, gen", [("tasks/swimmer/task.xml", "swimmer_modified.xml", tasks.swimmer),
+                                               ("tasks/quadrotor/task.xml", "quadrotor_modified.xml", tasks.quadrotor),
+                                               ("tasks/particle/task_timevarying.xml", "particle_modified.xml", tasks.particle_task)])
+def test_cost_tables_and_agent_numerics_of_the_late_registry_tasks(rel, missing, gen):
+    """Swimmer / Quadrotor / Particle: the model files are patches against dm_control / menagerie (absent here), the task files are
+    complete: the generators carry their cost terms, time step, spline points and (swimmer / particle) the horizon; the quadrotor's
+    stage goals are the task file's keyframe mocap positions."""
+    extra = ("gates.xml",) if "quadrotor" in rel else ()
+    b, info = mjcf.parse_mjcf(os.path.join(REF, rel), missing_ok=(missing,) + extra)
+    m2, task, d = gen()
+    assert _xml_terms(info) == _terms_of(task)
+    assert info["numeric"]["agent_timestep"] == [m2["timestep"]]
+    assert info["numeric"]["sampling_spline_points"] == [d["P"]]
+    assert round(info["numeric"]["agent_horizon"][0] / m2["timestep"]) + 1 == d["horizon"]
+    if "quadrotor" in rel:
+        assert [tuple(k["mpos"]) for k in info["keys"]] == [tuple(map(float, p)) for p in tasks.QUADROTOR_STAGES]
+        assert info["numeric"]["sampling_exploration"] == [d["sigma"][0]]
+
+
+def test_loader_attributes_of_the_late_features():
+    """<option density / viscosity / wind / integrator>, body gravcomp, joint actuatorfrcrange, <velocity> actuators, filter dynamics and
+    <equality> are outside the reference files above: a small inline document"""
+    xml = """<mujoco><option timestep="0.004" density="12" viscosity="0.3" wind="1 0 0" integrator="implicitfast"/>
+      <worldbody><body name="a" pos="0 0 1" gravcomp="0.5"><joint name="h" type="hinge" axis="0 1 0" actuatorfrcrange="-2 3"/>
+        <geom type="sphere" size="0.1"/></body></worldbody>
+      <actuator><velocity name="v" joint="h" kv="7"/><general name="f" joint="h" gainprm="2" dyntype="filter" dynprm="0.4"/></actuator></mujoco>"""
+    b, info = mjcf.parse_mjcf(xml)
+    m = b.compile()
+    assert (m["density"], m["viscosity"], tuple(m["wind"]), m["integrator"], m["timestep"]) == (12.0, 0.3, (1.0, 0.0, 0.0), 3, 0.004)
+    assert m["body_gravcomp"][1] == 0.5 and m["jnt_actfrclimited"][0] == 1 and tuple(m["jnt_actfrcrange"][0]) == (-2.0, 3.0)
+    assert tuple(m["actuator_gainprm"][0]) == (7.0, 0, 0) and tuple(m["actuator_biasprm"][0]) == (0, 0, -7.0) and m["actuator_biastype"][0] == 1
+    assert m["na"] == 1 and m["actuator_dyntype"][1] == 2 and m["actuator_dynprm"][1] == 0.4 and m["actuator_actadr"][1] == 0
+    with pytest.raises(ValueError):
+        mjcf.parse_mjcf('<mujoco><option integrator="RK4"/><worldbody/></mujoco>')

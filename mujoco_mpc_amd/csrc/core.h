@@ -379,10 +379,10 @@ DEV_NOINLINE void ph_smooth(KP Kc, int t) {
   com_pos(c);
   flag_set(c.misc + HX_COM, t + 1);
 #endif
-  velocity_stage<NVT>(c, t + 1);                // helper 0 builds and factors M meanwhile (ph_inertia)
+  velocity_stage<NVT>(c, Kc, t + 1);            // helper 0 builds and factors M meanwhile (ph_inertia)
 #else
   crb_and_factor<NVT>(c); PROF(c, 3);
-  velocity_stage<NVT>(c, 0); PROF(c, 6);
+  velocity_stage<NVT>(c, Kc, 0); PROF(c, 6);
 #endif
   ctx_close(c);
 }

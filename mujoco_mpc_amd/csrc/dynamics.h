@@ -141,9 +141,135 @@ DEV double actuator_force_of(Ctx &c, int i, double u) {
   return force;
 }
 
+// The rare extras of the smooth phase, out of line so that the common path stays compact: joint-level actuator force clamp, fluid
+// forces, gravity compensation, site transmissions, tendon springs / dampers.  All of them add to qfrc_smooth in LDS.
+DEV_NOINLINE void ph_smooth_extras(KP Kc) {
+  Ctx c; ctx_open(c, Kc, 1);
+  const DevModel &M = *c.M;
+  const int nv = M.nv;
+  if (M.nactfrc > 0) {
+    // jnt_actfrclimited: the total actuator force on the joint's dof is clamped (end of mj_fwdActuation); applied as a correction
+    // to what the gather above added
+    PFOR(k, M.nactfrc) {
+      int dd = MI(actfrc_dof)[k];
+      double act = 0;
+      for (int q = MI(dact_adr)[dd]; q < MI(dact_adr)[dd + 1]; q++) { int e = MI(dact_e)[q]; act += MD(act_coef)[e] * c.actuator_force[MI(act_of)[e]]; }
+      c.qfrc_smooth[dd] += d_clip(act, MD(actfrc_range)[2 * k], MD(actfrc_range)[2 * k + 1]) - act;
+    }
+    SYNC();
+  }
+  if (M.fluid) {
+    // fluid forces, inertia-box model (mj_inertiaBoxFluidModel): per body the world force / torque at its com into cfrc (dead by
+    // now: the bias forces have been read off cfrc_sub), then J^T of them per dof
+    PFOR(b, M.nbody) {
+      double *w = c.cfrc + 6 * b;
+      for (int k = 0; k < 6; k++) w[k] = 0;
+      double mass = MDH(body_mass)[b];
+      if (b == 0 || mass < D_MINVAL) continue;
+      const double *I = MDH(body_inertia) + 3 * b, *R = c.ximat + 9 * b;
+      double box[3], off[3], vw[3], lvel[6], lfrc[6] = {0, 0, 0, 0, 0, 0};
+      box[0] = sqrt(d_div(fmax(D_MINVAL, I[1] + I[2] - I[0]), mass) * 6.0);
+      box[1] = sqrt(d_div(fmax(D_MINVAL, I[0] + I[2] - I[1]), mass) * 6.0);
+      box[2] = sqrt(d_div(fmax(D_MINVAL, I[0] + I[1] - I[2]), mass) * 6.0);
+      d_sub3(off, c.xipos + 3 * b, c.subtree_com + 3 * MIH(body_rootid)[b]);
+      d_cross(vw, c.cvel + 6 * b, off);
+      for (int k = 0; k < 3; k++) vw[k] += c.cvel[6 * b + 3 + k] - M.wind[k];
+      d_mulmattvec3(lvel, R, c.cvel + 6 * b); d_mulmattvec3(lvel + 3, R, vw);
+      if (M.viscosity > 0) {
+        double diam = (box[0] + box[1] + box[2]) / 3.0;
+        for (int k = 0; k < 3; k++) { lfrc[k] = -D_PI * diam * diam * diam * M.viscosity * lvel[k]; lfrc[3 + k] = -3.0 * D_PI * diam * M.viscosity * lvel[3 + k]; }
+      }
+      if (M.density > 0) {
+        double b0 = box[0], b1 = box[1], b2 = box[2];
+        lfrc[3] -= 0.5 * M.density * b1 * b2 * fabs(lvel[3]) * lvel[3];
+        lfrc[4] -= 0.5 * M.density * b0 * b2 * fabs(lvel[4]) * lvel[4];
+        lfrc[5] -= 0.5 * M.density * b0 * b1 * fabs(lvel[5]) * lvel[5];
+        lfrc[0] -= M.density * b0 * (b1 * b1 * b1 * b1 + b2 * b2 * b2 * b2) * fabs(lvel[0]) * lvel[0] / 64.0;
+        lfrc[1] -= M.density * b1 * (b0 * b0 * b0 * b0 + b2 * b2 * b2 * b2) * fabs(lvel[1]) * lvel[1] / 64.0;
+        lfrc[2] -= M.density * b2 * (b0 * b0 * b0 * b0 + b1 * b1 * b1 * b1) * fabs(lvel[2]) * lvel[2] / 64.0;
+      }
+      d_mulmatvec3(w, R, lfrc); d_mulmatvec3(w + 3, R, lfrc + 3);        // torque, force in the world frame
+    }
+    SYNC();
+    PFOR(d, nv) {
+      double acc = c.qfrc_smooth[d];
+      const double *cd = c.cdof + 6 * d;
+      for (int b = 1; b < M.nbody; b++) {
+        if (!((MDM()[b] >> d) & 1ull)) continue;
+        const double *w = c.cfrc + 6 * b;
+        double off[3], t[3];
+        d_sub3(off, c.xipos + 3 * b, c.subtree_com + 3 * MIH(body_rootid)[b]);
+        d_cross(t, cd, off);
+        acc += (cd[3] + t[0]) * w[3] + (cd[4] + t[1]) * w[4] + (cd[5] + t[2]) * w[5] + cd[0] * w[0] + cd[1] * w[1] + cd[2] * w[2];
+      }
+      c.qfrc_smooth[d] = acc;
+    }
+    SYNC();
+  }
+  if (M.ngravcomp > 0) {
+    // gravity compensation (mj_passive): a constant world force at the body's com, through the point Jacobian
+    PFOR(d, nv) {
+      double acc = c.qfrc_smooth[d];
+      const double *cd = c.cdof + 6 * d;
+      for (int k = 0; k < M.ngravcomp; k++) {
+        int b = MI(gc_body)[k];
+        if (!((MDM()[b] >> d) & 1ull)) continue;
+        double off[3], t[3];
+        d_sub3(off, c.xipos + 3 * b, c.subtree_com + 3 * MIH(body_rootid)[b]);
+        d_cross(t, cd, off);
+        const double *f = MD(gc_force) + 3 * k;
+        acc += (cd[3] + t[0]) * f[0] + (cd[4] + t[1]) * f[1] + (cd[5] + t[2]) * f[2];
+      }
+      c.qfrc_smooth[d] = acc;
+    }
+    SYNC();
+  }
+  if (M.nsiteact > 0) {
+    // site transmissions: qfrc += J_site^T (R gear_force; R gear_torque) force, the site Jacobian from cdof about the root's com
+    PFOR(d, nv) {
+      double acc = c.qfrc_smooth[d];
+      const double *cd = c.cdof + 6 * d;
+      for (int k = 0; k < M.nsiteact; k++) {
+        int a = MI(sact_i)[3 * k], s = MI(sact_i)[3 * k + 1], b = MI(sact_i)[3 * k + 2];
+        if (!((MDM()[b] >> d) & 1ull)) continue;
+        double f[3], tq[3], off[3], t[3];
+        d_mulmatvec3(f, c.xmat + 9 * b, MD(sact_g) + 6 * k); d_mulmatvec3(tq, c.xmat + 9 * b, MD(sact_g) + 6 * k + 3);
+        d_sub3(off, c.site_xpos + 3 * s, c.subtree_com + 3 * MIH(body_rootid)[b]);
+        d_cross(t, cd, off);
+        acc += c.actuator_force[a] * ((cd[3] + t[0]) * f[0] + (cd[4] + t[1]) * f[1] + (cd[5] + t[2]) * f[2] + cd[0] * tq[0] + cd[1] * tq[1] + cd[2] * tq[2]);
+      }
+      c.qfrc_smooth[d] = acc;
+    }
+    SYNC();
+  }
+  if (M.ntendon_passive > 0) {
+    // tendon springs (dead band) and dampers, mj_passive: one lane per dof gathers J^T force over the (few) passive tendons
+    PFOR(d, nv) {
+      double acc = c.qfrc_smooth[d];
+      for (int e = 0; e < M.ntendon_passive; e++) {
+        int t = MI(tpass_id)[e];
+        double coef = 0, length = 0, velocity = 0;
+        for (int w = MI(tendon_adr)[t]; w < MI(tendon_adr)[t] + MI(tendon_num)[t]; w++) {
+          double cf = MD(wrap_prm)[w];
+          length += cf * c.qpos[MI(wrap_qposadr)[w]]; velocity += cf * c.qvel[MI(wrap_dofadr)[w]];
+          if (MI(wrap_dofadr)[w] == d) coef += cf;
+        }
+        if (coef == 0) continue;
+        const double *pr = MD(tpass_prm) + 4 * e;
+        double frc = 0;
+        if (length > pr[3]) frc = pr[0] * (pr[3] - length); else if (length < pr[2]) frc = pr[0] * (pr[2] - length);
+        frc -= pr[1] * velocity;
+        acc += coef * frc;
+      }
+      c.qfrc_smooth[d] = acc;
+    }
+    SYNC();
+  }
+}
+
 // mfact_seq != 0: M's factor is produced by a helper wave; wait for its sequence number (misc[22]) before the solve
 template <int NVT>
-DEV void velocity_stage(Ctx &c, int mfact_seq) {
+DEV void velocity_stage(Ctx &c, KP Kc, int mfact_seq) {
   const DevModel &M = *c.M;
   int nv = M.nv;
 #ifdef MJPC_LEAN_LDS
@@ -223,126 +349,7 @@ DEV void velocity_stage(Ctx &c, int mfact_seq) {
     }
   }
   SYNC();
-  if (M.smooth_extras) {      // one host-made flag for the rare extras: tendon passive forces, site transmissions, gravity compensation, fluid, joint force clamp
-    if (M.nactfrc > 0) {
-      // jnt_actfrclimited: the total actuator force on the joint's dof is clamped (end of mj_fwdActuation); applied as a correction
-      // to what the gather above added
-      PFOR(k, M.nactfrc) {
-        int dd = MI(actfrc_dof)[k];
-        double act = 0;
-        for (int q = MI(dact_adr)[dd]; q < MI(dact_adr)[dd + 1]; q++) { int e = MI(dact_e)[q]; act += MD(act_coef)[e] * c.actuator_force[MI(act_of)[e]]; }
-        c.qfrc_smooth[dd] += d_clip(act, MD(actfrc_range)[2 * k], MD(actfrc_range)[2 * k + 1]) - act;
-      }
-      SYNC();
-    }
-    if (M.fluid) {
-      // fluid forces, inertia-box model (mj_inertiaBoxFluidModel): per body the world force / torque at its com into cfrc (dead by
-      // now: the bias forces have been read off cfrc_sub), then J^T of them per dof
-      PFOR(b, M.nbody) {
-        double *w = c.cfrc + 6 * b;
-        for (int k = 0; k < 6; k++) w[k] = 0;
-        double mass = MDH(body_mass)[b];
-        if (b == 0 || mass < D_MINVAL) continue;
-        const double *I = MDH(body_inertia) + 3 * b, *R = c.ximat + 9 * b;
-        double box[3], off[3], vw[3], lvel[6], lfrc[6] = {0, 0, 0, 0, 0, 0};
-        box[0] = sqrt(d_div(fmax(D_MINVAL, I[1] + I[2] - I[0]), mass) * 6.0);
-        box[1] = sqrt(d_div(fmax(D_MINVAL, I[0] + I[2] - I[1]), mass) * 6.0);
-        box[2] = sqrt(d_div(fmax(D_MINVAL, I[0] + I[1] - I[2]), mass) * 6.0);
-        d_sub3(off, c.xipos + 3 * b, c.subtree_com + 3 * MIH(body_rootid)[b]);
-        d_cross(vw, c.cvel + 6 * b, off);
-        for (int k = 0; k < 3; k++) vw[k] += c.cvel[6 * b + 3 + k] - M.wind[k];
-        d_mulmattvec3(lvel, R, c.cvel + 6 * b); d_mulmattvec3(lvel + 3, R, vw);
-        if (M.viscosity > 0) {
-          double diam = (box[0] + box[1] + box[2]) / 3.0;
-          for (int k = 0; k < 3; k++) { lfrc[k] = -D_PI * diam * diam * diam * M.viscosity * lvel[k]; lfrc[3 + k] = -3.0 * D_PI * diam * M.viscosity * lvel[3 + k]; }
-        }
-        if (M.density > 0) {
-          double b0 = box[0], b1 = box[1], b2 = box[2];
-          lfrc[3] -= 0.5 * M.density * b1 * b2 * fabs(lvel[3]) * lvel[3];
-          lfrc[4] -= 0.5 * M.density * b0 * b2 * fabs(lvel[4]) * lvel[4];
-          lfrc[5] -= 0.5 * M.density * b0 * b1 * fabs(lvel[5]) * lvel[5];
-          lfrc[0] -= M.density * b0 * (b1 * b1 * b1 * b1 + b2 * b2 * b2 * b2) * fabs(lvel[0]) * lvel[0] / 64.0;
-          lfrc[1] -= M.density * b1 * (b0 * b0 * b0 * b0 + b2 * b2 * b2 * b2) * fabs(lvel[1]) * lvel[1] / 64.0;
-          lfrc[2] -= M.density * b2 * (b0 * b0 * b0 * b0 + b1 * b1 * b1 * b1) * fabs(lvel[2]) * lvel[2] / 64.0;
-        }
-        d_mulmatvec3(w, R, lfrc); d_mulmatvec3(w + 3, R, lfrc + 3);        // torque, force in the world frame
-      }
-      SYNC();
-      PFOR(d, nv) {
-        double acc = c.qfrc_smooth[d];
-        const double *cd = c.cdof + 6 * d;
-        for (int b = 1; b < M.nbody; b++) {
-          if (!((MDM()[b] >> d) & 1ull)) continue;
-          const double *w = c.cfrc + 6 * b;
-          double off[3], t[3];
-          d_sub3(off, c.xipos + 3 * b, c.subtree_com + 3 * MIH(body_rootid)[b]);
-          d_cross(t, cd, off);
-          acc += (cd[3] + t[0]) * w[3] + (cd[4] + t[1]) * w[4] + (cd[5] + t[2]) * w[5] + cd[0] * w[0] + cd[1] * w[1] + cd[2] * w[2];
-        }
-        c.qfrc_smooth[d] = acc;
-      }
-      SYNC();
-    }
-    if (M.ngravcomp > 0) {
-      // gravity compensation (mj_passive): a constant world force at the body's com, through the point Jacobian
-      PFOR(d, nv) {
-        double acc = c.qfrc_smooth[d];
-        const double *cd = c.cdof + 6 * d;
-        for (int k = 0; k < M.ngravcomp; k++) {
-          int b = MI(gc_body)[k];
-          if (!((MDM()[b] >> d) & 1ull)) continue;
-          double off[3], t[3];
-          d_sub3(off, c.xipos + 3 * b, c.subtree_com + 3 * MIH(body_rootid)[b]);
-          d_cross(t, cd, off);
-          const double *f = MD(gc_force) + 3 * k;
-          acc += (cd[3] + t[0]) * f[0] + (cd[4] + t[1]) * f[1] + (cd[5] + t[2]) * f[2];
-        }
-        c.qfrc_smooth[d] = acc;
-      }
-      SYNC();
-    }
-    if (M.nsiteact > 0) {
-      // site transmissions: qfrc += J_site^T (R gear_force; R gear_torque) force, the site Jacobian from cdof about the root's com
-      PFOR(d, nv) {
-        double acc = c.qfrc_smooth[d];
-        const double *cd = c.cdof + 6 * d;
-        for (int k = 0; k < M.nsiteact; k++) {
-          int a = MI(sact_i)[3 * k], s = MI(sact_i)[3 * k + 1], b = MI(sact_i)[3 * k + 2];
-          if (!((MDM()[b] >> d) & 1ull)) continue;
-          double f[3], tq[3], off[3], t[3];
-          d_mulmatvec3(f, c.xmat + 9 * b, MD(sact_g) + 6 * k); d_mulmatvec3(tq, c.xmat + 9 * b, MD(sact_g) + 6 * k + 3);
-          d_sub3(off, c.site_xpos + 3 * s, c.subtree_com + 3 * MIH(body_rootid)[b]);
-          d_cross(t, cd, off);
-          acc += c.actuator_force[a] * ((cd[3] + t[0]) * f[0] + (cd[4] + t[1]) * f[1] + (cd[5] + t[2]) * f[2] + cd[0] * tq[0] + cd[1] * tq[1] + cd[2] * tq[2]);
-        }
-        c.qfrc_smooth[d] = acc;
-      }
-      SYNC();
-    }
-    if (M.ntendon_passive > 0) {
-      // tendon springs (dead band) and dampers, mj_passive: one lane per dof gathers J^T force over the (few) passive tendons
-      PFOR(d, nv) {
-        double acc = c.qfrc_smooth[d];
-        for (int e = 0; e < M.ntendon_passive; e++) {
-          int t = MI(tpass_id)[e];
-          double coef = 0, length = 0, velocity = 0;
-          for (int w = MI(tendon_adr)[t]; w < MI(tendon_adr)[t] + MI(tendon_num)[t]; w++) {
-            double cf = MD(wrap_prm)[w];
-            length += cf * c.qpos[MI(wrap_qposadr)[w]]; velocity += cf * c.qvel[MI(wrap_dofadr)[w]];
-            if (MI(wrap_dofadr)[w] == d) coef += cf;
-          }
-          if (coef == 0) continue;
-          const double *pr = MD(tpass_prm) + 4 * e;
-          double frc = 0;
-          if (length > pr[3]) frc = pr[0] * (pr[3] - length); else if (length < pr[2]) frc = pr[0] * (pr[2] - length);
-          frc -= pr[1] * velocity;
-          acc += coef * frc;
-        }
-        c.qfrc_smooth[d] = acc;
-      }
-      SYNC();
-    }
-  }
+  if (M.smooth_extras) ph_smooth_extras(Kc);      // one host-made flag for the rare extras (out of line)
   if (c.K->xfrc_std > 0) {
     // mj_xfrcAccumulate: J^T [force; torque], force applied at the body's inertial frame origin; bodies in ascending order
     PFOR(d, nv) {

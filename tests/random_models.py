@@ -123,6 +123,9 @@ def random_model(seed, portal_pairs=False):
         b.fluid = (float(rng_fr.choice([0.0, 50.0, 300.0])), float(rng_fr.choice([0.0, 0.05, 0.5])), (float(rng_fr.uniform(-1, 1)), 0.0, 0.0) if rng_fr.random() < 0.5 else (0.0, 0.0, 0.0))
     if b.tendons and rng_fr.random() < 0.25:       # a tendon equality: the first tendon held at (a multiple of) the second's length, or at its own
         b.tendon_equality("t0", "t1" if len(b.tendons) > 1 and rng_fr.random() < 0.6 else None, polycoef=(0.0, float(rng_fr.uniform(-1, 1)), 0, 0, 0))
+    for jn in scalar_joints:                        # joint-level clamp of the total actuator force on some joints
+        if rng_fr.random() < 0.15:
+            lim = float(rng_fr.uniform(0.3, 1.5)); b.actfrc[jn] = (-lim, lim)
     if not b.actuators:
         if scalar_joints:
             b.actuator("m0", scalar_joints[0], gear=1.0)

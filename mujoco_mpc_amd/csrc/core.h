@@ -412,8 +412,10 @@ DEV_SOLVE_PHASE void ph_solve(KP Kc, int last, int t) {
   c.hseq = t * 256;
   solve_constraints<NVT>(c); PROF(c, 8);
 #if MJPC_HELPER
-  if (LANE == 0) c.misc[HX_KIND] = 0;           // release the helper wave
-  flag_set(c.misc + HX_JOB, ++c.hseq);
+  if (!(MJPC_SOLVER_REG && NVT > 0) || c.M->cone == 1) {
+    if (LANE == 0) c.misc[HX_KIND] = 0;           // release the helper waves (cone blocks of elliptic models; Hessian builds of the generic path)
+    flag_set(c.misc + HX_JOB, ++c.hseq);
+  }
 #endif
   // (a step that already overflowed a buffer fails with that code alone: what the solver made of the truncated rows does not matter)
   if (!last && !(c.warning & (WARN_CONTACTFULL | WARN_CNSTRFULL)) && bad_values(c.qacc, c.M->nv)) c.warning |= WARN_BADQACC;

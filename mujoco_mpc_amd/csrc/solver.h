@@ -125,6 +125,16 @@ DEV double constraint_update(Ctx &c, int hess, const double *jar) {
 #pragma unroll
       for (int j = 0; j < DIMT; j++) { double dx = Dj[j] * X[j]; cost += 0.5 * dx * X[j]; F[j] = -dx; }
       st = STATE_QUADRATIC;
+      if (WRITE && hess) {
+        // the same record for the quadratic zone (solver_reg.h assembles every elliptic contact as P P^T - Q Q^T + diag(T^2) + w0 e0 e0^T
+        // without looking at its zone): P = Q = 0, T_j = sqrt(D_j), w0 = D_0 in the slot of Q_0.  The scaled-row path never reads it here.
+#pragma unroll
+        for (int j = 0; j < DIMT; j++) if (j < dim) {
+          cc[CON_H + j] = 0;
+          cc[CON_H + 6 + j] = j == 0 ? Dj[0] : 0.0;
+          cc[CON_H + 12 + j] = Dj[j] * fast_rsqrt(Dj[j]);
+        }
+      }
     } else {
       double Dm = Dj[0] * fast_rcp(mu * mu * (1 + mu * mu));
       double NmT = N - mu * T;
@@ -182,20 +192,18 @@ DEV void mat_rows_times(Ctx &c, const double *x, double *Mx, double *Jx) {
       if (NVT & 1) s0 += row[NVT - 1] * xs[NVT - 1];
       Mx[i] = s0 + s1;
     }
+    // every row takes the dense product (a limit row holds its one entry, the rest are exact zeros); a friction-loss row has no
+    // stored Jacobian: its lane multiplies the first stored row instead and the select picks x[dof]
+    const int nfr = c.M->nfric;
     PFOR(r, c.nefc) {
-      const double *row = c.efc_J + r * nvp;
-      double s;
-      if (r < c.M->nfric) s = x[c.efc_dof[r]];
-      else
-      if (r < c.nsingle) { int d = c.efc_dof[r]; s = row[d] * x[d]; }
-      else {
-        double s0 = 0, s1 = 0;
+      const double *row = c.efc_J + (r < nfr ? nfr : r) * nvp;
+      int dof = c.efc_dof[r < nfr ? r : 0];
+      double xd = x[r < nfr ? dof : 0];
+      double s0 = 0, s1 = 0;
 #pragma unroll
-        for (int j = 0; j + 1 < NVT; j += 2) { s0 += row[j] * xs[j]; s1 += row[j + 1] * xs[j + 1]; }
-        if (NVT & 1) s0 += row[NVT - 1] * xs[NVT - 1];
-        s = s0 + s1;
-      }
-      Jx[r] = s;
+      for (int j = 0; j + 1 < NVT; j += 2) { s0 += row[j] * xs[j]; s1 += row[j + 1] * xs[j + 1]; }
+      if (NVT & 1) s0 += row[NVT - 1] * xs[NVT - 1];
+      Jx[r] = r < nfr ? xd : s0 + s1;
     }
   } else {
     PFOR(i, nv) {
@@ -511,15 +519,22 @@ DEV double cost_at_smooth(Ctx &c) {
   return 0.0 + wave_sum(part);
 }
 
+#ifndef MJPC_SOLVER_REG
+#define MJPC_SOLVER_REG 1      // compile-time nv: the owner wave solves alone with the Hessian in registers (solver_reg.h); 0 = scaled-row tables shared with the helper waves
+#endif
 #if MJPC_HELPER
+template <int NVT, int K> DEV void cone_helper_loop(Ctx &c, int seq);      // solver_reg.h
 template <int NVT, int K>
 DEV void solver_helper_loop(Ctx &c, int seq) {
   if (K == MJPC_NH - 1 && c.nefc > 0) {            // the last helper prices the unconstrained acceleration for the warm-start choice
     double cs = cost_at_smooth<NVT>(c);
     if (LANE == 0) c.red[2] = cs;
-    flag_set(c.misc + HX_CSM, seq / 256 + 1);
+    // fault injection for the test-suite (fault = 1): the helper of candidate 1 never reports this price in step 2
+    const int mute_csm = MJPC_SOLVER_REG && c.K->fault == 1 && cand_index() == 1 && seq == 2 * 256;
+    if (!mute_csm) flag_set(c.misc + HX_CSM, seq / 256 + 1);
   }
-  if constexpr (NVT > 0) {
+  if constexpr (NVT > 0 && MJPC_SOLVER_REG) cone_helper_loop<NVT, K>(c, seq);
+  if constexpr (NVT > 0 && !MJPC_SOLVER_REG) {
     constexpr int NP = MJPC_NH + 1;
     // fault injection for the test-suite (MJPC_HIP_FAULT_INJECT=sync): helper 0 of candidate 1 never reports its fill in step 2
     const int mute = c.K->fault == 1 && K == 0 && cand_index() == 1 && seq == 2 * 256;
@@ -720,6 +735,8 @@ DEV double line_search(Ctx &c, double gauss, double cost0, double *q1_out, doubl
   return best_a;
 }
 
+#include "solver_reg.h"
+
 template <int NVT>
 DEV void solve_constraints(Ctx &c) {
   const DevModel &M = *c.M;
@@ -730,6 +747,9 @@ DEV void solve_constraints(Ctx &c) {
     SYNC();
     return;
   }
+#if !defined(MJPC_EMU) && MJPC_SOLVER_REG
+  if constexpr (NVT > 0) { solve_constraints_reg<NVT>(c); return; }
+#endif
   PROF(c, 7);
   // warm start: the better of qacc_smooth and qacc_warmstart (evaluated last, so its force/state stay valid)
   double gauss, cost;

@@ -1,0 +1,592 @@
+// solver_reg.h — the Newton solve for a compile-time dof count (gfx950 only), run by the owner wave alone.
+//
+// Same minimisation as solver.h (MuJoCo's primal Newton inside mj_step, mjpc/trajectory.cc:158), organised around what one
+// wavefront keeps in registers instead of around scaled-row tables in LDS:
+//   * Hessian blocks: lane (i, g) — i = lane % nv, g = lane / nv < G = 64 / nv — owns H[i][g*CB .. g*CB + CB) (CB = ceil(nv / G):
+//     6 columns for the A1, 14 for the humanoid, 33 for the hand).  `hq` = M + sum over the general rows in their quadratic zone of
+//     D_r J_r^T J_r lives there for the whole solve and is UPDATED by the rows whose zone changed in a line search (one rank-1 term
+//     each), never rebuilt.  Elliptic contacts are not quadratic in the cone zone: their dim x dim blocks (cone: P P^T - Q Q^T +
+//     diag(T^2) in the factored form constraint_update() leaves behind; quadratic zone: diag(D)) are added to a copy of hq every
+//     iteration, the copy goes to qH in LDS and the register factorisation (linalg.h) picks its rows up from there.
+//   * the exact line search keeps every row / contact of a lane in registers (as before) and its last evaluation IS the
+//     constraint update: residuals, forces, zones and cone factors are written from those registers (ls_commit), no second pass.
+//   * gradient = Ma - qfrc_smooth - J^T force straight from the forces (lane (i, g) sums every G-th row).
+// No other wave is involved: the helper waves of a candidate are free during the solve phase.
+#pragma once
+#ifndef MJPC_EMU
+
+template <int NVT> struct HLay {
+  static constexpr int G0 = 64 / NVT;
+  static constexpr int G = G0 < 1 ? 1 : (G0 > NVT ? NVT : G0);     // column groups
+  static constexpr int CB = (NVT + G - 1) / G;                      // columns per group (the last group may run into the spare column)
+};
+DEV int readlane_i(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+
+// h += sum over the set bits b of mask:  w(lane b) * J[rbase + b][hi] * J[rbase + b][j0 .. j0 + CB)      (two rows per trip)
+template <int NVT>
+DEV void hblock_add_rows(const Ctx &c, double *h, unsigned long long mask, int rbase, double wlane, int hi, int j0) {
+  constexpr int nvp = NVP_OF(NVT), CB = HLay<NVT>::CB;
+  while (mask) {
+    int b0 = (int)__builtin_ctzll(mask); mask &= mask - 1;
+    int b1 = b0; double sel1 = 0.0;
+    if (mask) { b1 = (int)__builtin_ctzll(mask); mask &= mask - 1; sel1 = 1.0; }
+    double w0 = readlane_d(wlane, b0), w1 = readlane_d(wlane, b1) * sel1;
+    const double *r0p = c.efc_J + (rbase + b0) * nvp, *r1p = c.efc_J + (rbase + b1) * nvp;
+    double x0 = r0p[hi], x1 = r1p[hi];
+    double y0[CB], y1[CB];
+#pragma unroll
+    for (int q = 0; q < CB; q++) { y0[q] = r0p[j0 + q]; y1[q] = r1p[j0 + q]; }
+    __builtin_amdgcn_sched_barrier(0);
+    double s0 = w0 * x0, s1 = w1 * x1;
+#pragma unroll
+    for (int q = 0; q < CB; q++) { h[q] += s0 * y0[q]; h[q] += s1 * y1[q]; }
+  }
+}
+
+// hq = M + sum of D_r J_r^T J_r over the general (several Jacobian entries), non-elliptic rows that are in their quadratic zone
+template <int NVT>
+DEV void hblock_init(const Ctx &c, double *hq, int hi, int j0) {
+  constexpr int nvp = NVP_OF(NVT), CB = HLay<NVT>::CB;
+#pragma unroll
+  for (int q = 0; q < CB; q++) hq[q] = c.qM[hi * nvp + j0 + q];
+  const int nefc = c.nefc, ns = c.nsingle;
+  for (int base = 0; base < nefc; base += NLANE) {
+    int r = base + LANE, rc = r < nefc ? r : nefc - 1;
+    int st = c.efc_state[rc], type = c.efc_type[rc];
+    double D = c.efc_D[rc];
+    int flag = r < nefc && r >= ns && type != CNSTR_CONTACT_ELLIPTIC && st == STATE_QUADRATIC;
+    unsigned long long mask = __builtin_amdgcn_ballot_w64(flag != 0);
+    hblock_add_rows<NVT>(c, hq, mask, base, D, hi, j0);
+  }
+}
+
+// grad = Ma - qfrc_smooth - J^T force (also copied to Mgrad for the solve); single-entry rows through their per-dof folds (sgl)
+template <int NVT>
+DEV void newton_grad_reg(Ctx &c, int hi, int hg, bool hact) {
+  constexpr int nvp = NVP_OF(NVT), G = HLay<NVT>::G;
+  const int ns = c.nsingle, n = c.nefc - ns;
+  double part = 0;
+  const int trips = (n + G - 1) / G;
+  for (int t0 = 0; t0 < trips; t0 += 8) {
+    double f[8], j[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      int rr = (t0 + u) * G + hg;
+      int r = ns + (rr < n ? rr : 0);
+      f[u] = c.efc_force[r]; j[u] = c.efc_J[r * nvp + hi];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 8; u++) { int rr = (t0 + u) * G + hg; double pr = j[u] * f[u]; part += (rr < n) ? pr : 0.0; }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  double *sc = c.efc_JA;                   // dead during this solve: the scaled-row tables belong to the generic path
+  if (hact) sc[hg * NVT + hi] = part;
+  SYNC();
+  if (LANE < NVT) {
+    int i = LANE;
+    double jtf = 0;
+#pragma unroll
+    for (int g = 0; g < G; g++) jtf += sc[g * NVT + i];
+    double gr = c.Ma[i] - c.qfrc_smooth[i] - (c.sgl[i] + c.sgl[2 * NVT + i]) - jtf;
+    c.grad[i] = gr;
+    c.Mgrad[i] = gr;
+  }
+  SYNC();
+}
+
+// block of one elliptic contact with D rows starting at r0 (compile-time D: every row / column offset is an immediate):
+//   J^T (P P^T - Q Q^T + diag(T^2) + w0 e0 e0^T) J   with the record constraint_update() / ls_commit() left at CON_H
+//   (cone zone: the factored cone Hessian, w0 = 0; quadratic zone: P = Q = 0, T_j^2 = D_j, w0 = D_0): no branch on the zone
+template <int NVT, int D>
+DEV void cone_block_add(const Ctx &c, double *a, int r0, int ci, int hi, int j0) {
+  constexpr int nvp = NVP_OF(NVT), CB = HLay<NVT>::CB;
+  const double *Ji = c.efc_J + r0 * nvp + hi, *Jb = c.efc_J + r0 * nvp + j0;
+  const double *cf = c.contact + ci * c.M->con_stride + CON_H;
+  double jb[D], t[D], P[D], Q[D], T[D];
+#pragma unroll
+  for (int k = 0; k < D; k++) { jb[k] = Ji[k * nvp]; P[k] = cf[k]; Q[k] = cf[6 + k]; T[k] = cf[12 + k]; }
+  // narrow column blocks: the whole D x CB block of J rides the same LDS round trip as the record; wide ones fetch it row-wise below
+  constexpr bool ALL = CB <= 6;
+  double yall[ALL ? D : 1][ALL ? CB : 1];
+  if constexpr (ALL) {
+#pragma unroll
+    for (int k = 0; k < D; k++)
+#pragma unroll
+      for (int q = 0; q < CB; q++) yall[k][q] = Jb[k * nvp + q];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  double pi = P[0] * jb[0], qi = Q[1] * jb[1];
+#pragma unroll
+  for (int k = 1; k < D; k++) { pi += P[k] * jb[k]; if (k > 1) qi += Q[k] * jb[k]; }
+  t[0] = P[0] * pi + Q[0] * jb[0];                      // Q_0's slot: 0 in the cone zone, D_0 in the quadratic zone
+#pragma unroll
+  for (int k = 1; k < D; k++) t[k] = P[k] * pi - Q[k] * qi + (T[k] * T[k]) * jb[k];
+  if constexpr (ALL) {
+#pragma unroll
+    for (int k = 0; k < D; k++)
+#pragma unroll
+      for (int q = 0; q < CB; q++) a[q] += t[k] * yall[k][q];
+  } else {
+    constexpr int RG = (CB <= 16) ? 2 : 1;
+#pragma unroll
+    for (int k0 = 0; k0 < D; k0 += RG) {
+      double y[RG][CB];
+#pragma unroll
+      for (int k = 0; k < RG; k++)
+#pragma unroll
+        for (int q = 0; q < CB; q++) y[k][q] = (k0 + k < D) ? Jb[(k0 + k) * nvp + q] : 0.0;
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int k = 0; k < RG; k++)
+#pragma unroll
+        for (int q = 0; q < CB; q++) if (k0 + k < D) a[q] += t[k0 + k] * y[k][q];
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
+// a += the blocks of the elliptic contacts that have one (zone != satisfied) and whose ordinal among those is == part (mod nparts)
+template <int NVT, int DIMT>
+DEV void cone_blocks(const Ctx &c, double *a, int part, int nparts, int hi, int j0) {
+  const int ncon = c.ncon;
+  int ord = 0;
+  for (int base = 0; base < ncon; base += NLANE) {
+    int ci = base + LANE, cic = ci < ncon ? ci : ncon - 1;
+    int dim_l = c.con_i[cic * CONI_STRIDE], r0_l = c.con_i[cic * CONI_STRIDE + 3];
+    int st_l = c.efc_state[r0_l];
+    int flag = ci < ncon && dim_l > 1 && st_l != STATE_SATISFIED;      // (cone == 1: every contact with dim > 1 is elliptic)
+    unsigned long long mask = __builtin_amdgcn_ballot_w64(flag != 0);
+    while (mask) {
+      int b = (int)__builtin_ctzll(mask); mask &= mask - 1;
+      int mine = (nparts == 1) || (ord % nparts == part);
+      ord++;
+      if (!mine) continue;
+      int r0 = readlane_i(r0_l, b), dim = readlane_i(dim_l, b);
+      if constexpr (DIMT <= 3) cone_block_add<NVT, 3>(c, a, r0, base + b, hi, j0);
+      else {
+        if (dim == 6) cone_block_add<NVT, 6>(c, a, r0, base + b, hi, j0);
+        else if (dim == 4) cone_block_add<NVT, 4>(c, a, r0, base + b, hi, j0);
+        else cone_block_add<NVT, 3>(c, a, r0, base + b, hi, j0);
+      }
+    }
+  }
+}
+
+// Elliptic models with helper waves: the cone blocks are the helpers' job.  The owner posts it (HX_JOB) as soon as the records
+// of an iterate are in LDS (after solver_eval / ls_commit) and meanwhile updates hq and builds the gradient; helper k sums the
+// blocks of every MJPC_NH-th contact into its own partial [q][lane] behind the gradient scratch and reports with HX_HDONE + k.
+#define CONE_PART(c, k, q) ((c).efc_JA + 64 + ((k) * HLay<NVT>::CB + (q)) * NLANE + LANE)
+#if MJPC_HELPER
+template <int NVT>
+DEV void cone_job_post(Ctx &c) {
+  if (c.M->cone != 1) return;
+  int seq = ++c.hseq;
+  if (LANE == 0) c.misc[HX_KIND] = 1;
+  flag_set(c.misc + HX_JOB, seq);
+}
+template <int NVT, int DIMT, int K>
+DEV void cone_helper_loop_d(Ctx &c, int seq) {
+  constexpr int G = HLay<NVT>::G, CB = HLay<NVT>::CB;
+  const int hg_ = LANE / NVT;
+  const bool hact = hg_ < G;
+  const int hg = hact ? hg_ : 0, hi = hact ? LANE - hg_ * NVT : 0, j0 = hg * CB;
+  for (;;) {
+    seq++;
+    if (!flag_wait_ge(c.misc + HX_JOB, seq)) return;          // timed out: the owner reports the failure
+    if (uniform_i(c.misc[HX_KIND]) == 0) return;              // (also when this helper was late for a job nobody waited for)
+    double a[CB];
+#pragma unroll
+    for (int q = 0; q < CB; q++) a[q] = 0;
+    cone_blocks<NVT, DIMT>(c, a, K, MJPC_NH, hi, j0);
+#pragma unroll
+    for (int q = 0; q < CB; q++) *CONE_PART(c, K, q) = a[q];
+    flag_set(c.misc + HX_HDONE + K, seq);
+  }
+}
+template <int NVT, int K>
+DEV void cone_helper_loop(Ctx &c, int seq) {
+  if (c.M->cone != 1) return;
+  if (c.M->maxdim <= 3) cone_helper_loop_d<NVT, 3, K>(c, seq); else cone_helper_loop_d<NVT, 6, K>(c, seq);
+}
+#endif
+
+// qH = hq + diag of the single-entry rows + the blocks of the elliptic contacts
+template <int NVT, int DIMT>
+DEV void newton_assemble(Ctx &c, const double *hq, int hi, int hg, int j0, bool hact) {
+  constexpr int nvp = NVP_OF(NVT), CB = HLay<NVT>::CB;
+  double a[CB];
+  const double dg = c.sgl[NVT + hi] + c.sgl[3 * NVT + hi];
+#pragma unroll
+  for (int q = 0; q < CB; q++) a[q] = hq[q] + ((j0 + q == hi) ? dg : 0.0);
+  PROF(c, 10);
+  if (c.M->cone == 1) {
+#if MJPC_HELPER
+    const int seq = c.hseq;
+    for (int k = 0; k < MJPC_NH; k++) if (!flag_wait(c.misc + HX_HDONE + k, seq)) c.warning |= WARN_SYNC;
+    PROF(c, 18);
+    double pt[MJPC_NH][CB];
+#pragma unroll
+    for (int k = 0; k < MJPC_NH; k++)
+#pragma unroll
+      for (int q = 0; q < CB; q++) pt[k][q] = *CONE_PART(c, k, q);
+#pragma unroll
+    for (int k = 0; k < MJPC_NH; k++)
+#pragma unroll
+      for (int q = 0; q < CB; q++) a[q] += pt[k][q];
+#else
+    cone_blocks<NVT, DIMT>(c, a, 0, 1, hi, j0);
+    PROF(c, 18);
+#endif
+  }
+  if (hact) {
+#pragma unroll
+    for (int q = 0; q < CB; q++) if (j0 + q < NVT) c.qH[hi * nvp + j0 + q] = a[q];
+  }
+  SYNC();
+}
+
+// line-search data of a lane plus what the commit needs (friction coefficients, first row / dim of the contact, the single-entry
+// rows' Jacobian entry, the zone the row was in)
+template <int DIMT>
+struct LSReg {
+  double lo[LS_RPL], hi[LS_RPL], hD[LS_RPL], F[LS_RPL], X[LS_RPL], V[LS_RPL], DV[LS_RPL], DVV[LS_RPL], rJ[LS_RPL];
+  int rinfo[LS_RPL];     // bit 0 row of the cost sum (exists, not elliptic) | bit 1 friction-type | bit 2 single-entry | bit 3 was quadratic | dof << 8
+  double U0[LS_CPL][DIMT], UV[LS_CPL][DIMT], E[LS_CPL][DIMT], fr[LS_CPL][DIMT], mu[LS_CPL], Dm[LS_CPL], VV[LS_CPL];
+  int on[LS_CPL], cdim[LS_CPL], crow[LS_CPL], cwasq[LS_CPL];
+  int nslot, ncslot;
+};
+
+template <int NVT, int DIMT>
+DEV void ls_load_reg(Ctx &c, LSReg<DIMT> &d) {
+  constexpr int nvp = NVP_OF(NVT);
+  const int nefc = c.nefc, ncon = c.ncon, last = c.nefc - 1, ns = c.nsingle, nfr = c.M->nfric;
+  d.nslot = (nefc + NLANE - 1) / NLANE; d.ncslot = (ncon + NLANE - 1) / NLANE;
+#pragma unroll
+  for (int k = 0; k < LS_RPL; k++) {
+    d.lo[k] = -1; d.hi[k] = 1; d.hD[k] = 0; d.F[k] = 0; d.X[k] = 0; d.V[k] = 0; d.DV[k] = 0; d.DVV[k] = 0; d.rJ[k] = 0; d.rinfo[k] = 0;
+    if (k < d.nslot) {
+      int r = LANE + NLANE * k, rc = r < nefc ? r : last;
+      int type = c.efc_type[rc], st = c.efc_state[rc], dof = c.efc_dof[rc];
+      double D = c.efc_D[rc], v = c.efc_jv[rc], x = c.efc_jar[rc], f = c.efc_floss[rc], Rf = c.efc_R[rc] * f;
+      int single = rc < ns;
+      double rj = single ? (rc < nfr ? 1.0 : c.efc_J[(rc < nfr ? nfr : rc) * nvp + (single ? dof : 0)]) : 0.0;
+      int quad = r < nefc && type != CNSTR_CONTACT_ELLIPTIC;
+      int fric = quad && type <= CNSTR_FRICTION_TENDON;
+      d.rinfo[k] = quad | (fric << 1) | ((quad && single) << 2) | ((st == STATE_QUADRATIC) << 3) | (dof << 8);
+      d.rJ[k] = rj;
+      double Dq = quad ? D : 0.0;
+      // X / V are kept for every existing row (the commit writes jar = X + alpha V for the elliptic rows too); with D = F = 0 such
+      // a row adds nothing to the sums whatever its zone
+      d.X[k] = r < nefc ? x : 0.0; d.V[k] = r < nefc ? v : 0.0;
+      d.hD[k] = 0.5 * Dq; d.DV[k] = Dq * d.V[k]; d.DVV[k] = Dq * d.V[k] * d.V[k];
+      d.lo[k] = fric ? -Rf : (quad ? -1e300 : -1.0); d.hi[k] = fric ? Rf : (quad ? 0.0 : 1.0); d.F[k] = fric ? f : 0.0;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < LS_CPL; q++) {
+    d.on[q] = 0; d.mu[q] = 0; d.Dm[q] = 0; d.VV[q] = 0; d.cdim[q] = 0; d.crow[q] = 0; d.cwasq[q] = 0;
+#pragma unroll
+    for (int j = 0; j < DIMT; j++) { d.U0[q][j] = 0; d.UV[q][j] = 0; d.E[q][j] = 0; d.fr[q][j] = 0; }
+    if (q < d.ncslot) {
+      int ci = LANE + NLANE * q, cic = ci < ncon ? ci : ncon - 1;
+      int dim = c.con_i[cic * CONI_STRIDE];
+      int i = c.con_i[cic * CONI_STRIDE + 3];
+      const double *cc = c.contact + cic * c.M->con_stride;
+      int type = c.efc_type[i];
+      d.cwasq[q] = c.efc_state[i] == STATE_QUADRATIC;
+      double mu = cc[CON_MU], fr[DIMT], Dj[DIMT], jv[DIMT], jr[DIMT];
+#pragma unroll
+      for (int j = 0; j < DIMT; j++) {
+        int rj = i + j < nefc ? i + j : last;
+        fr[j] = j == 0 ? mu : cc[CON_FRICTION + j - 1];
+        Dj[j] = c.efc_D[rj]; jv[j] = c.efc_jv[rj]; jr[j] = c.efc_jar[rj];
+      }
+      int on = ci < ncon && dim > 1 && type == CNSTR_CONTACT_ELLIPTIC;
+      d.on[q] = on; d.mu[q] = on ? mu : 0.0; d.cdim[q] = dim; d.crow[q] = i;
+      d.Dm[q] = on ? Dj[0] * fast_rcp(mu * mu * (1 + mu * mu)) : 0.0;
+      double vv = 0;
+#pragma unroll
+      for (int j = 0; j < DIMT; j++) {
+        int use = on && j < dim;
+        double uv = jv[j] * fr[j];
+        d.U0[q][j] = use ? jr[j] * fr[j] : 0.0; d.UV[q][j] = use ? uv : 0.0;
+        d.E[q][j] = use ? Dj[j] * fast_rcp(fr[j] * fr[j]) : 0.0;
+        d.fr[q][j] = use ? fr[j] : 0.0;
+        if (j > 0) vv += use ? uv * uv : 0.0;
+      }
+      d.VV[q] = vv;
+    }
+  }
+}
+
+template <int DIMT>
+DEV LSPoint ls_eval_reg(const LSReg<DIMT> &d, double q0, double q1, double q2, double a) {
+  LSPoint p; p.cost = 0; p.d1 = 0; p.d2 = 0;
+#pragma unroll
+  for (int k = 0; k < LS_RPL; k++) {
+    if (k >= d.nslot) break;
+    double x = d.X[k] + a * d.V[k];
+    double xc = fmin(fmax(x, d.lo[k]), d.hi[k]);
+    p.cost += d.hD[k] * xc * xc + d.F[k] * (fabs(x) - fabs(xc));
+    p.d1 += d.DV[k] * xc;
+    p.d2 += (x > d.lo[k] && x < d.hi[k]) ? d.DVV[k] : 0.0;
+  }
+#pragma unroll
+  for (int q = 0; q < LS_CPL; q++) {
+    if (q >= d.ncslot) break;
+    if (!d.on[q]) continue;
+    double mu = d.mu[q], U[DIMT];
+    double T2 = 0, UV = 0;
+#pragma unroll
+    for (int j = 0; j < DIMT; j++) {
+      U[j] = d.U0[q][j] + a * d.UV[q][j];
+      if (j > 0) { T2 += U[j] * U[j]; UV += U[j] * d.UV[q][j]; }
+    }
+    double iT = fast_rsqrt(T2);
+    double N = U[0], T = T2 * iT;
+    if (N >= mu * T || (T <= 0 && N >= 0)) {
+    } else if (mu * N + T <= 0 || (T <= 0 && N < 0)) {
+#pragma unroll
+      for (int j = 0; j < DIMT; j++) { double E = d.E[q][j], vj = d.UV[q][j], eu = E * U[j]; p.cost += 0.5 * eu * U[j]; p.d1 += eu * vj; p.d2 += E * vj * vj; }
+    } else {
+      double Dm = d.Dm[q], NmT = N - mu * T;
+      double T1 = UV * iT, T2d = (d.VV[q] - T1 * T1) * iT;
+      double g1 = d.UV[q][0] - mu * T1;
+      double dn = Dm * NmT;
+      p.cost += 0.5 * dn * NmT; p.d1 += dn * g1; p.d2 += Dm * g1 * g1 - dn * mu * T2d;
+    }
+  }
+  wave_sum3(p.cost, p.d1, p.d2);
+  p.cost = p.cost + q0 + a * q1 + a * a * q2;
+  p.d1 = p.d1 + q1 + 2 * a * q2;
+  p.d2 = p.d2 + 2 * q2;
+  return p;
+}
+
+// the constraint update at alpha, from the line-search registers: jar, force, zone of every row, the per-dof folds of the
+// single-entry rows, the cone factors of the elliptic contacts.  chg_mask[k] / chg_w[k]: the general rows of slot k whose
+// quadratic-zone membership changed and the signed weight (+-D) of their rank-1 term in the Hessian.
+template <int NVT, int DIMT>
+DEV void ls_commit(Ctx &c, const LSReg<DIMT> &d, double a, unsigned long long *chg_mask, double *chg_w) {
+  const int nefc = c.nefc, stride = c.M->con_stride;
+#pragma unroll
+  for (int k = 0; k < LS_RPL; k++) {
+    chg_mask[k] = 0; chg_w[k] = 0;
+    if (k >= d.nslot) break;
+    int r = LANE + NLANE * k;
+    int info = d.rinfo[k];
+    int quad = info & 1, fric = (info >> 1) & 1, single = (info >> 2) & 1, wasq = (info >> 3) & 1, dof = info >> 8;
+    double x = d.X[k] + a * d.V[k];
+    if (r < nefc) c.efc_jar[r] = x;
+    double lo = d.lo[k], hi = d.hi[k], D = 2 * d.hD[k], f = d.F[k];
+    double xc = fmin(fmax(x, lo), hi);
+    int inside = x > lo && x < hi;
+    int chg = 0;
+    if (quad) {
+      double force = fric ? (inside ? -D * x : (x <= lo ? f : -f)) : -D * xc;
+      c.efc_force[r] = force;
+      c.efc_state[r] = inside ? STATE_QUADRATIC : (fric ? (x <= lo ? STATE_LINEARNEG : STATE_LINEARPOS) : STATE_SATISFIED);
+      if (single) {
+        int kk = fric ? 0 : 2;
+        c.sgl[kk * NVT + dof] = d.rJ[k] * force;
+        c.sgl[(kk + 1) * NVT + dof] = inside ? D : 0.0;
+      } else {
+        chg = inside != wasq;
+        chg_w[k] = inside ? D : -D;
+      }
+    }
+    chg_mask[k] = __builtin_amdgcn_ballot_w64(chg != 0);
+  }
+#pragma unroll
+  for (int q = 0; q < LS_CPL; q++) {
+    if (q >= d.ncslot) break;
+    if (!d.on[q]) continue;
+    int ci = LANE + NLANE * q, dim = d.cdim[q], i = d.crow[q];
+    double *cc = c.contact + ci * stride;
+    double mu = d.mu[q], U[DIMT], F[DIMT];
+    const int wasquad = d.cwasq[q];
+    double T2 = 0;
+#pragma unroll
+    for (int j = 0; j < DIMT; j++) { U[j] = d.U0[q][j] + a * d.UV[q][j]; F[j] = 0; if (j > 0) T2 += U[j] * U[j]; }
+    double iT = fast_rsqrt(T2);
+    double N = U[0], T = T2 * iT;
+    int st;
+    if (N >= mu * T || (T <= 0 && N >= 0)) {
+      st = STATE_SATISFIED;
+    } else if (mu * N + T <= 0 || (T <= 0 && N < 0)) {
+#pragma unroll
+      for (int j = 0; j < DIMT; j++) F[j] = -(d.E[q][j] * d.fr[q][j]) * U[j];        // -D_j jar_j with jar_j = U_j / fr_j, D_j = E_j fr_j^2
+      st = STATE_QUADRATIC;
+      if (!wasquad) {       // the zone-independent block record (see constraint_update): P = Q = 0, T_j = sqrt(D_j), w0 = D_0
+#pragma unroll
+        for (int j = 0; j < DIMT; j++) if (j < dim) {
+          double Dj = d.E[q][j] * d.fr[q][j] * d.fr[q][j];
+          cc[CON_H + j] = 0;
+          cc[CON_H + 6 + j] = j == 0 ? Dj : 0.0;
+          cc[CON_H + 12 + j] = Dj * fast_rsqrt(Dj);
+        }
+      }
+    } else {
+      double Dm = d.Dm[q], NmT = N - mu * T;
+      double f0 = -Dm * NmT * mu;
+      F[0] = f0;
+#pragma unroll
+      for (int j = 1; j < DIMT; j++) F[j] = -f0 * iT * U[j] * d.fr[q][j];
+      st = STATE_CONE;
+      double kap = -mu * NmT * Dm * iT;
+      double sD = Dm * fast_rsqrt(Dm), sk = kap > 0 ? kap * fast_rsqrt(kap) : 0.0;
+      cc[CON_H] = sD * d.fr[q][0];
+      cc[CON_H + 6] = 0;
+      cc[CON_H + 12] = -sD * NmT;
+#pragma unroll
+      for (int j = 1; j < DIMT; j++) if (j < dim) {
+        double u = U[j] * iT;
+        cc[CON_H + j] = -sD * d.fr[q][j] * mu * u;
+        cc[CON_H + 6 + j] = sk * d.fr[q][j] * u;
+        cc[CON_H + 12 + j] = sk * d.fr[q][j];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < DIMT; j++) if (j < dim) { c.efc_force[i + j] = F[j]; c.efc_state[i + j] = st; }
+  }
+}
+
+template <int NVT, int DIMT>
+DEV void solve_constraints_reg_d(Ctx &c) {
+  const DevModel &M = *c.M;
+  constexpr int nv = NVT, nvp = NVP_OF(NVT);
+  constexpr int G = HLay<NVT>::G, CB = HLay<NVT>::CB;
+  const int hg_ = LANE / NVT;
+  const bool hact = hg_ < G;
+  const int hg = hact ? hg_ : 0, hi = hact ? LANE - hg_ * NVT : 0, j0 = hg * CB;
+  c.solver_iter = 0;
+  PROF(c, 7);
+  // warm start: the better of qacc_smooth and qacc_warmstart (evaluated last, so its force/state stay valid)
+  double gauss, cost, cost_sm;
+#if MJPC_HELPER
+  double cost_ws = solver_eval<NVT>(c, c.qacc_ws, &gauss);
+  if (!flag_wait(c.misc + HX_CSM, c.hseq / 256 + 1)) c.warning |= WARN_SYNC;     // priced by the last helper meanwhile
+  cost_sm = c.red[2];
+#else
+  cost_sm = solver_eval<NVT>(c, c.qacc_smooth, 0);
+  double cost_ws = solver_eval<NVT>(c, c.qacc_ws, &gauss);
+#endif
+  if (cost_ws > cost_sm) {
+    PFOR(i, nv) c.qacc[i] = c.qacc_smooth[i];
+    SYNC();
+    cost = solver_eval<NVT>(c, c.qacc, &gauss);
+  } else {
+    PFOR(i, nv) c.qacc[i] = c.qacc_ws[i];
+    SYNC();
+    cost = cost_ws;
+  }
+  PROF(c, 12);
+#if MJPC_HELPER
+  cone_job_post<NVT>(c);
+#endif
+  double hq[CB];
+  hblock_init<NVT>(c, hq, hi, j0);
+  PROF(c, 15);
+  newton_grad_reg<NVT>(c, hi, hg, hact);
+  PROF(c, 9);
+  newton_assemble<NVT, DIMT>(c, hq, hi, hg, j0, hact);
+  PROF(c, 19);
+  newton_direction<NVT>(c);
+  PFOR(i, nv) c.search[i] = -c.Mgrad[i];
+  SYNC();
+  const double scale = 1.0 / (M.meaninertia * (nv > 1 ? nv : 1));
+  for (int iter = 0; iter < M.iterations; iter++) {
+    PROF(c, 13);
+    // ---- exact line search along `search`
+    double p_sn = 0, p_q1 = 0, p_q2 = 0, p_gs = 0;
+    mat_rows_times<NVT>(c, c.search, c.Mv, c.efc_jv);
+    PFOR(i, nv) {
+      double si = c.search[i];
+      p_sn += si * si; p_q1 += si * (c.Ma[i] - c.qfrc_smooth[i]); p_q2 += 0.5 * si * c.Mv[i]; p_gs += c.grad[i] * si;
+    }
+    SYNC();
+    wave_sum4(p_sn, p_q1, p_q2, p_gs);
+    const double snorm = sqrt(p_sn), q1 = p_q1, q2 = p_q2, gs = p_gs;
+    PROF(c, 20);
+    if (snorm < D_MINVAL || gs >= 0) break;
+    const double gtol = M.tolerance * M.ls_tolerance * snorm / scale;
+    LSReg<DIMT> d;
+    ls_load_reg<NVT, DIMT>(c, d);
+    PROF(c, 21);
+    double lo = 0, hi_a = -1, a = 1.0;
+    double best_a = 0, best_cost = cost, dxold = a, dx = a;
+    LSPoint p; p.cost = cost; p.d1 = gs; p.d2 = -gs;
+    double a_eval = 0;
+    for (int it = 0; it < M.ls_iterations; it++) {
+      p = ls_eval_reg<DIMT>(d, gauss, q1, q2, a);
+      a_eval = a;
+#if defined(MJPC_PROFILE) && !defined(MJPC_EMU)
+      if (LANE == 0) c.prof[23] += 1;
+#endif
+      int better = p.cost < best_cost;
+      best_cost = better ? p.cost : best_cost; best_a = better ? a : best_a;
+      int conv = fabs(p.d1) < gtol;
+      int neg = p.d1 < 0;
+      lo = neg ? a : lo; hi_a = neg ? hi_a : a;
+      int pos2 = p.d2 > 0;
+      double newton = a - p.d1 * fast_rcp(p.d2);
+      double an_e = pos2 ? newton : 2 * a;
+      an_e = (an_e > a) ? an_e : 2 * a;
+      double nw = pos2 ? newton : lo - 1;
+      int ok = (nw > lo) && (nw < hi_a) && (fabs(2 * p.d1) <= fabs(dxold * p.d2));
+      double dx_b = ok ? fabs(nw - a) : 0.5 * (hi_a - lo);
+      double an_b = ok ? nw : lo + dx_b;
+      int bracketed = !(hi_a < 0);
+      double an = bracketed ? an_b : an_e;
+      dxold = dx; dx = bracketed ? dx_b : an_e - a;
+      if (conv || an == a) break;
+      a = an;
+    }
+    PROF(c, 22);
+    const double alpha = best_a;
+    PROF(c, 14);
+    if (alpha == 0) break;
+    if (a_eval != alpha) p = ls_eval_reg<DIMT>(d, gauss, q1, q2, alpha);      // rare: the best point is not the last one evaluated
+    // ---- move there: the last evaluation is the constraint update
+    unsigned long long chg_mask[LS_RPL]; double chg_w[LS_RPL];
+    ls_commit<NVT, DIMT>(c, d, alpha, chg_mask, chg_w);
+    PFOR(i, nv) { c.qacc[i] += alpha * c.search[i]; c.Ma[i] += alpha * c.Mv[i]; }
+    SYNC();
+    gauss = gauss + alpha * q1 + alpha * alpha * q2;
+    const double oldcost = cost;
+    cost = p.cost;
+    PROF(c, 12);
+    const double improvement = scale * (oldcost - cost);
+    const int stop = improvement < M.tolerance || (c.warning & WARN_SYNC) != 0;
+#if MJPC_HELPER
+    if (!stop) cone_job_post<NVT>(c);
+#endif
+    if (!stop) {
+#pragma unroll
+      for (int k = 0; k < LS_RPL; k++) { if (k >= d.nslot) break; hblock_add_rows<NVT>(c, hq, chg_mask[k], NLANE * k, chg_w[k], hi, j0); }
+    }
+    PROF(c, 15);
+    newton_grad_reg<NVT>(c, hi, hg, hact);
+    PROF(c, 9);
+    c.solver_iter++;
+    double pg = 0;
+    PFOR(i, nv) pg += c.grad[i] * c.grad[i];
+    const double gradient = scale * sqrt(wave_sum(pg));
+    if (stop || gradient < M.tolerance) break;
+    newton_assemble<NVT, DIMT>(c, hq, hi, hg, j0, hact);
+    PROF(c, 19);
+    newton_direction<NVT>(c);
+    PFOR(i, nv) c.search[i] = -c.Mgrad[i];
+    SYNC();
+  }
+  if (LANE == 0) { c.misc[5] += c.solver_iter; if (c.ncon > c.misc[6]) c.misc[6] = c.ncon; if (c.nefc > c.misc[7]) c.misc[7] = c.nefc; }
+  PFOR(i, nv) c.qfrc_constraint[i] = (c.Ma[i] - c.qfrc_smooth[i]) - c.grad[i];
+  SYNC();
+}
+
+template <int NVT>
+DEV void solve_constraints_reg(Ctx &c) {
+  if (c.M->maxdim <= 3) solve_constraints_reg_d<NVT, 3>(c); else solve_constraints_reg_d<NVT, 6>(c);
+}
+#endif

@@ -24,6 +24,7 @@
 #define ROLEH 0
 DEV void flag_set(int *p, int v) { *p = v; }
 DEV int flag_wait(int *p, int v) { return *p == v; }
+DEV int flag_wait_ge(int *p, int v) { return *p >= v; }
 DEV double mul_rn(double a, double b) { return a * b; }   // emu is built with -ffp-contract=off
 DEV double add_rn(double a, double b) { return a + b; }
 DEV double add_mul3_rn(double a, double b, double c, double d) { return a + (b * c) * d; }
@@ -158,6 +159,16 @@ DEV int flag_wait(int *p, int v) {
   for (int n = 0; n < (1 << 21); n++) {
     int cur = __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
     if (cur == v) { ok = 1; break; }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  return ok;
+}
+// the same for a monotonically increasing sequence number: returns once *p >= v (a waiter that was late for v still gets through)
+DEV int flag_wait_ge(int *p, int v) {
+  int ok = 0;
+  for (int n = 0; n < (1 << 21); n++) {
+    int cur = __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+    if (cur >= v) { ok = 1; break; }
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   return ok;

@@ -636,7 +636,10 @@ DEV void rollout(KP Kc) {
 #if MJPC_HELPER
     if (ROLEH) ph_solve_helper<NVT>(Kc, t);
 #endif
-    if (r1) { CostOut o = ph_residual_cost(Kc, t, last); total += o.cost; if (!last) ph_prefactor<NVT>(Kc); }
+    if (r1) {
+      CostOut o = ph_residual_cost(Kc, t, last); total += o.cost;
+      if (!last) ph_prefactor<NVT>(Kc);
+    }
     XBAR(); RPROF(6);
     if (uniform_i(misc[3]) | uniform_i(misc[11])) { failure = 1; break; }
     if (r0 && !last) ph_integrate<NVT>(Kc, t);

@@ -524,6 +524,8 @@ DEV double cost_at_smooth(Ctx &c) {
 #endif
 #if MJPC_HELPER
 template <int NVT, int K> DEV void cone_helper_loop(Ctx &c, int seq);      // solver_reg.h
+template <int NVT> DEV void ls_records_build(Ctx &c);
+#define HX_LSREC 17      // line-search records of this step ready (helper 0 -> owner), value t + 1
 template <int NVT, int K>
 DEV void solver_helper_loop(Ctx &c, int seq) {
   if (K == MJPC_NH - 1 && c.nefc > 0) {            // the last helper prices the unconstrained acceleration for the warm-start choice
@@ -533,7 +535,10 @@ DEV void solver_helper_loop(Ctx &c, int seq) {
     const int mute_csm = MJPC_SOLVER_REG && c.K->fault == 1 && cand_index() == 1 && seq == 2 * 256;
     if (!mute_csm) flag_set(c.misc + HX_CSM, seq / 256 + 1);
   }
-  if constexpr (NVT > 0 && MJPC_SOLVER_REG) cone_helper_loop<NVT, K>(c, seq);
+  if constexpr (NVT > 0 && MJPC_SOLVER_REG) {
+    if (K == 0 && c.nefc > 0) { ls_records_build<NVT>(c); flag_set(c.misc + HX_LSREC, seq / 256 + 1); }     // the line search's per-step constants
+    cone_helper_loop<NVT, K>(c, seq);
+  }
   if constexpr (NVT > 0 && !MJPC_SOLVER_REG) {
     constexpr int NP = MJPC_NH + 1;
     // fault injection for the test-suite (MJPC_HIP_FAULT_INJECT=sync): helper 0 of candidate 1 never reports its fill in step 2

@@ -14,6 +14,9 @@
 // No other wave is involved: the helper waves of a candidate are free during the solve phase.
 #pragma once
 #ifndef MJPC_EMU
+#ifndef LS_PREDICT
+#define LS_PREDICT 1
+#endif
 
 template <int NVT> struct HLay {
   static constexpr int G0 = 64 / NVT;
@@ -21,6 +24,10 @@ template <int NVT> struct HLay {
   static constexpr int CB = (NVT + G - 1) / G;                      // columns per group (the last group may run into the spare column)
 };
 DEV int readlane_i(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+#define LSR_STRIDE 7
+#define LSC_STRIDE 17
+#define LS_ROWREC(c) ((c).efc_JA + 64)
+#define LS_CONREC(c) ((c).efc_JA + 64 + (c).M->nefcmax * LSR_STRIDE)
 
 // h += sum over the set bits b of mask:  w(lane b) * J[rbase + b][hi] * J[rbase + b][j0 .. j0 + CB)      (two rows per trip)
 template <int NVT>
@@ -176,32 +183,45 @@ DEV void cone_blocks(const Ctx &c, double *a, int part, int nparts, int hi, int 
 // Elliptic models with helper waves: the cone blocks are the helpers' job.  The owner posts it (HX_JOB) as soon as the records
 // of an iterate are in LDS (after solver_eval / ls_commit) and meanwhile updates hq and builds the gradient; helper k sums the
 // blocks of every MJPC_NH-th contact into its own partial [q][lane] behind the gradient scratch and reports with HX_HDONE + k.
-#define CONE_PART(c, k, q) ((c).efc_JA + 64 + ((k) * HLay<NVT>::CB + (q)) * NLANE + LANE)
+#define CONE_PART(c, k, q) ((c).efc_JA + 64 + (c).M->nefcmax * LSR_STRIDE + (c).M->nconmax * LSC_STRIDE + ((k) * HLay<NVT>::CB + (q)) * (HLay<NVT>::G * NVT) + LANE)      // [helper][column][active lane]
+#define HX_NPARTS 20
 #if MJPC_HELPER
 template <int NVT>
-DEV void cone_job_post(Ctx &c) {
-  if (c.M->cone != 1) return;
+DEV int cone_job_post(Ctx &c) {      // returns the number of workers the job was cut for
+  if (c.M->cone != 1) return 0;
   int seq = ++c.hseq;
-  if (LANE == 0) c.misc[HX_KIND] = 1;
+  int np = MJPC_NH;
+  if (LANE == 0) { c.misc[HX_KIND] = 1; c.misc[HX_NPARTS] = np; }
   flag_set(c.misc + HX_JOB, seq);
+  return np;
 }
-template <int NVT, int DIMT, int K>
-DEV void cone_helper_loop_d(Ctx &c, int seq) {
+// one job of worker K: its partial into LDS, then HX_HDONE + K = seq
+template <int NVT, int DIMT>
+DEV void cone_job_do(Ctx &c, int K, int nparts, int seq) {
   constexpr int G = HLay<NVT>::G, CB = HLay<NVT>::CB;
   const int hg_ = LANE / NVT;
   const bool hact = hg_ < G;
   const int hg = hact ? hg_ : 0, hi = hact ? LANE - hg_ * NVT : 0, j0 = hg * CB;
+  double a[CB];
+#pragma unroll
+  for (int q = 0; q < CB; q++) a[q] = 0;
+  cone_blocks<NVT, DIMT>(c, a, K, nparts, hi, j0);
+  PROFW(c, 13);
+  if (hact) {
+#pragma unroll
+    for (int q = 0; q < CB; q++) *CONE_PART(c, K, q) = a[q];
+  }
+  flag_set(c.misc + HX_HDONE + K, seq);
+  PROFW(c, 14);
+}
+template <int NVT, int DIMT, int K>
+DEV void cone_helper_loop_d(Ctx &c, int seq) {
   for (;;) {
     seq++;
     if (!flag_wait_ge(c.misc + HX_JOB, seq)) return;          // timed out: the owner reports the failure
     if (uniform_i(c.misc[HX_KIND]) == 0) return;              // (also when this helper was late for a job nobody waited for)
-    double a[CB];
-#pragma unroll
-    for (int q = 0; q < CB; q++) a[q] = 0;
-    cone_blocks<NVT, DIMT>(c, a, K, MJPC_NH, hi, j0);
-#pragma unroll
-    for (int q = 0; q < CB; q++) *CONE_PART(c, K, q) = a[q];
-    flag_set(c.misc + HX_HDONE + K, seq);
+    PROFW(c, 12);
+    cone_job_do<NVT, DIMT>(c, K, uniform_i(c.misc[HX_NPARTS]), seq);
   }
 }
 template <int NVT, int K>
@@ -213,7 +233,7 @@ DEV void cone_helper_loop(Ctx &c, int seq) {
 
 // qH = hq + diag of the single-entry rows + the blocks of the elliptic contacts
 template <int NVT, int DIMT>
-DEV void newton_assemble(Ctx &c, const double *hq, int hi, int hg, int j0, bool hact) {
+DEV void newton_assemble(Ctx &c, const double *hq, int hi, int hg, int j0, bool hact, int nparts) {
   constexpr int nvp = NVP_OF(NVT), CB = HLay<NVT>::CB;
   double a[CB];
   const double dg = c.sgl[NVT + hi] + c.sgl[3 * NVT + hi];
@@ -223,13 +243,13 @@ DEV void newton_assemble(Ctx &c, const double *hq, int hi, int hg, int j0, bool 
   if (c.M->cone == 1) {
 #if MJPC_HELPER
     const int seq = c.hseq;
-    for (int k = 0; k < MJPC_NH; k++) if (!flag_wait(c.misc + HX_HDONE + k, seq)) c.warning |= WARN_SYNC;
+    for (int k = 0; k < nparts; k++) if (!flag_wait(c.misc + HX_HDONE + k, seq)) c.warning |= WARN_SYNC;
     PROF(c, 18);
     double pt[MJPC_NH][CB];
 #pragma unroll
     for (int k = 0; k < MJPC_NH; k++)
 #pragma unroll
-      for (int q = 0; q < CB; q++) pt[k][q] = *CONE_PART(c, k, q);
+      for (int q = 0; q < CB; q++) pt[k][q] = hact ? *CONE_PART(c, k, q) : 0.0;
 #pragma unroll
     for (int k = 0; k < MJPC_NH; k++)
 #pragma unroll
@@ -252,70 +272,111 @@ template <int DIMT>
 struct LSReg {
   double lo[LS_RPL], hi[LS_RPL], hD[LS_RPL], F[LS_RPL], X[LS_RPL], V[LS_RPL], DV[LS_RPL], DVV[LS_RPL], rJ[LS_RPL];
   int rinfo[LS_RPL];     // bit 0 row of the cost sum (exists, not elliptic) | bit 1 friction-type | bit 2 single-entry | bit 3 was quadratic | dof << 8
-  double U0[LS_CPL][DIMT], UV[LS_CPL][DIMT], E[LS_CPL][DIMT], fr[LS_CPL][DIMT], mu[LS_CPL], Dm[LS_CPL], VV[LS_CPL];
+  // elliptic contact of the lane, along the search direction (U_j = fr_j jar_j, V_j = fr_j jv_j): everything an evaluation needs is
+  // a polynomial in alpha:  N = N0 + a NV;  sum_{j>0} U_j^2 = t0 + 2 a t1 + a^2 t2;  sum_{j>0} U_j V_j = t1 + a t2;  the quadratic
+  // zone's cost  sum_j 1/2 E_j U_j^2 = c0 + a c1 + a^2 c2
+  double N0[LS_CPL], NV[LS_CPL], t0[LS_CPL], t1[LS_CPL], t2[LS_CPL], c0[LS_CPL], c1[LS_CPL], c2[LS_CPL], mu[LS_CPL], Dm[LS_CPL];
   int on[LS_CPL], cdim[LS_CPL], crow[LS_CPL], cwasq[LS_CPL];
   int nslot, ncslot;
 };
 
+// Per-step constants of the line search, one record per row / contact in LDS (behind the gradient scratch in efc_JA).  They do
+// not change between the Newton iterations of a step: a helper wave builds them while the owner prices the warm start, and an
+// iteration's ls_load_reg() only fetches them next to the two things that do change (the residuals and their slopes).
+//   row record      lo, hi, D / 2, friction loss, J entry (single-entry rows), info
+//   contact record  E_j = D_j / fr_j^2 (6), fr_j (6; fr_0 = mu), mu, Dm, info (on | dim << 8 | first row << 16)
+template <int NVT>
+DEV void ls_records_build(Ctx &c) {
+  constexpr int nvp = NVP_OF(NVT);
+  const int nefc = c.nefc, ncon = c.ncon, ns = c.nsingle, nfr = c.M->nfric;
+  double *rrec = LS_ROWREC(c), *crec = LS_CONREC(c);
+  PFOR(r, nefc) {
+    int type = c.efc_type[r], dof = c.efc_dof[r];
+    double D = c.efc_D[r], f = c.efc_floss[r], Rf = c.efc_R[r] * f;
+    int single = r < ns;
+    double rj = single ? (r < nfr ? 1.0 : c.efc_J[r * nvp + dof]) : 0.0;
+    int quad = type != CNSTR_CONTACT_ELLIPTIC;
+    int fric = quad && type <= CNSTR_FRICTION_TENDON;
+    double *o = rrec + r * LSR_STRIDE;
+    o[0] = fric ? -Rf : (quad ? -1e300 : -1.0); o[1] = fric ? Rf : (quad ? 0.0 : 1.0);
+    o[2] = quad ? 0.5 * D : 0.0; o[3] = fric ? f : 0.0; o[4] = rj;
+    ((int *)(o + 5))[0] = quad | (fric << 1) | ((quad && single) << 2) | ((single ? dof : 0) << 8);
+  }
+  PFOR(ci, ncon) {
+    int dim = c.con_i[ci * CONI_STRIDE], i = c.con_i[ci * CONI_STRIDE + 3];
+    const double *cc = c.contact + ci * c.M->con_stride;
+    int on = dim > 1 && c.efc_type[i] == CNSTR_CONTACT_ELLIPTIC;
+    double mu = cc[CON_MU];
+    double *o = crec + ci * LSC_STRIDE;
+    for (int j = 0; j < 6; j++) {
+      int use = on && j < dim;
+      double fr = j == 0 ? mu : cc[CON_FRICTION + j - 1];
+      double Dj = c.efc_D[use ? i + j : i];
+      o[j] = use ? Dj * fast_rcp(fr * fr) : 0.0;
+      o[6 + j] = use ? fr : 0.0;
+    }
+    o[12] = on ? mu : 0.0;
+    o[13] = on ? c.efc_D[i] * fast_rcp(mu * mu * (1 + mu * mu)) : 0.0;
+    ((int *)(o + 14))[0] = on | (dim << 8) | (i << 16);
+  }
+  SYNC();
+}
+
 template <int NVT, int DIMT>
 DEV void ls_load_reg(Ctx &c, LSReg<DIMT> &d) {
-  constexpr int nvp = NVP_OF(NVT);
-  const int nefc = c.nefc, ncon = c.ncon, last = c.nefc - 1, ns = c.nsingle, nfr = c.M->nfric;
+  const int nefc = c.nefc, ncon = c.ncon, last = c.nefc - 1;
+  const double *rrec = LS_ROWREC(c), *crec = LS_CONREC(c);
   d.nslot = (nefc + NLANE - 1) / NLANE; d.ncslot = (ncon + NLANE - 1) / NLANE;
 #pragma unroll
   for (int k = 0; k < LS_RPL; k++) {
     d.lo[k] = -1; d.hi[k] = 1; d.hD[k] = 0; d.F[k] = 0; d.X[k] = 0; d.V[k] = 0; d.DV[k] = 0; d.DVV[k] = 0; d.rJ[k] = 0; d.rinfo[k] = 0;
     if (k < d.nslot) {
       int r = LANE + NLANE * k, rc = r < nefc ? r : last;
-      int type = c.efc_type[rc], st = c.efc_state[rc], dof = c.efc_dof[rc];
-      double D = c.efc_D[rc], v = c.efc_jv[rc], x = c.efc_jar[rc], f = c.efc_floss[rc], Rf = c.efc_R[rc] * f;
-      int single = rc < ns;
-      double rj = single ? (rc < nfr ? 1.0 : c.efc_J[(rc < nfr ? nfr : rc) * nvp + (single ? dof : 0)]) : 0.0;
-      int quad = r < nefc && type != CNSTR_CONTACT_ELLIPTIC;
-      int fric = quad && type <= CNSTR_FRICTION_TENDON;
-      d.rinfo[k] = quad | (fric << 1) | ((quad && single) << 2) | ((st == STATE_QUADRATIC) << 3) | (dof << 8);
-      d.rJ[k] = rj;
-      double Dq = quad ? D : 0.0;
+      const double *o = rrec + rc * LSR_STRIDE;
+      double lo = o[0], hi = o[1], hD = o[2], F = o[3], rj = o[4];
+      int info = ((const int *)(o + 5))[0], st = c.efc_state[rc];
+      double v = c.efc_jv[rc], x = c.efc_jar[rc];
+      __builtin_amdgcn_sched_barrier(0);
+      const bool ok = r < nefc;
       // X / V are kept for every existing row (the commit writes jar = X + alpha V for the elliptic rows too); with D = F = 0 such
       // a row adds nothing to the sums whatever its zone
-      d.X[k] = r < nefc ? x : 0.0; d.V[k] = r < nefc ? v : 0.0;
-      d.hD[k] = 0.5 * Dq; d.DV[k] = Dq * d.V[k]; d.DVV[k] = Dq * d.V[k] * d.V[k];
-      d.lo[k] = fric ? -Rf : (quad ? -1e300 : -1.0); d.hi[k] = fric ? Rf : (quad ? 0.0 : 1.0); d.F[k] = fric ? f : 0.0;
+      d.X[k] = ok ? x : 0.0; d.V[k] = ok ? v : 0.0;
+      d.lo[k] = ok ? lo : -1.0; d.hi[k] = ok ? hi : 1.0; d.hD[k] = ok ? hD : 0.0; d.F[k] = ok ? F : 0.0; d.rJ[k] = rj;
+      d.rinfo[k] = ok ? (info | ((st == STATE_QUADRATIC) << 3)) : 0;
+      double dv = 2 * d.hD[k] * d.V[k];
+      d.DV[k] = dv; d.DVV[k] = dv * d.V[k];
     }
   }
 #pragma unroll
   for (int q = 0; q < LS_CPL; q++) {
-    d.on[q] = 0; d.mu[q] = 0; d.Dm[q] = 0; d.VV[q] = 0; d.cdim[q] = 0; d.crow[q] = 0; d.cwasq[q] = 0;
-#pragma unroll
-    for (int j = 0; j < DIMT; j++) { d.U0[q][j] = 0; d.UV[q][j] = 0; d.E[q][j] = 0; d.fr[q][j] = 0; }
+    d.on[q] = 0; d.mu[q] = 0; d.Dm[q] = 0; d.cdim[q] = 0; d.crow[q] = 0; d.cwasq[q] = 0;
+    d.N0[q] = 0; d.NV[q] = 0; d.t0[q] = 0; d.t1[q] = 0; d.t2[q] = 0; d.c0[q] = 0; d.c1[q] = 0; d.c2[q] = 0;
     if (q < d.ncslot) {
       int ci = LANE + NLANE * q, cic = ci < ncon ? ci : ncon - 1;
-      int dim = c.con_i[cic * CONI_STRIDE];
-      int i = c.con_i[cic * CONI_STRIDE + 3];
-      const double *cc = c.contact + cic * c.M->con_stride;
-      int type = c.efc_type[i];
-      d.cwasq[q] = c.efc_state[i] == STATE_QUADRATIC;
-      double mu = cc[CON_MU], fr[DIMT], Dj[DIMT], jv[DIMT], jr[DIMT];
+      const double *o = crec + cic * LSC_STRIDE;
+      int info = ((const int *)(o + 14))[0];
+      double E[DIMT], fr[DIMT];
+#pragma unroll
+      for (int j = 0; j < DIMT; j++) { E[j] = o[j]; fr[j] = o[6 + j]; }
+      double mu = o[12], Dm = o[13];
+      int on = (ci < ncon) && (info & 1), dim = (info >> 8) & 255, i = info >> 16;
+      double jv[DIMT], jr[DIMT];
+#pragma unroll
+      for (int j = 0; j < DIMT; j++) { int rj = i + j < nefc ? i + j : last; jv[j] = c.efc_jv[rj]; jr[j] = c.efc_jar[rj]; }
+      int st0 = c.efc_state[i];
+      __builtin_amdgcn_sched_barrier(0);
+      d.on[q] = on; d.mu[q] = on ? mu : 0.0; d.Dm[q] = on ? Dm : 0.0; d.cdim[q] = dim; d.crow[q] = i;
+      d.cwasq[q] = st0 == STATE_QUADRATIC;
+      // (E_j = fr_j = 0 beyond the contact's dim and for a lane without an elliptic contact: those slots stay out of every sum)
+      double t0 = 0, t1 = 0, t2 = 0, c0 = 0, c1 = 0, c2 = 0, n0 = 0, nv_ = 0;
 #pragma unroll
       for (int j = 0; j < DIMT; j++) {
-        int rj = i + j < nefc ? i + j : last;
-        fr[j] = j == 0 ? mu : cc[CON_FRICTION + j - 1];
-        Dj[j] = c.efc_D[rj]; jv[j] = c.efc_jv[rj]; jr[j] = c.efc_jar[rj];
+        double u = jr[j] * fr[j], v = jv[j] * fr[j], eu = E[j] * u, ev = E[j] * v;
+        c0 += 0.5 * eu * u; c1 += eu * v; c2 += 0.5 * ev * v;
+        if (j == 0) { n0 = u; nv_ = v; } else { t0 += u * u; t1 += u * v; t2 += v * v; }
       }
-      int on = ci < ncon && dim > 1 && type == CNSTR_CONTACT_ELLIPTIC;
-      d.on[q] = on; d.mu[q] = on ? mu : 0.0; d.cdim[q] = dim; d.crow[q] = i;
-      d.Dm[q] = on ? Dj[0] * fast_rcp(mu * mu * (1 + mu * mu)) : 0.0;
-      double vv = 0;
-#pragma unroll
-      for (int j = 0; j < DIMT; j++) {
-        int use = on && j < dim;
-        double uv = jv[j] * fr[j];
-        d.U0[q][j] = use ? jr[j] * fr[j] : 0.0; d.UV[q][j] = use ? uv : 0.0;
-        d.E[q][j] = use ? Dj[j] * fast_rcp(fr[j] * fr[j]) : 0.0;
-        d.fr[q][j] = use ? fr[j] : 0.0;
-        if (j > 0) vv += use ? uv * uv : 0.0;
-      }
-      d.VV[q] = vv;
+      d.N0[q] = on ? n0 : 0.0; d.NV[q] = on ? nv_ : 0.0; d.t0[q] = on ? t0 : 0.0; d.t1[q] = on ? t1 : 0.0; d.t2[q] = on ? t2 : 0.0;
+      d.c0[q] = on ? c0 : 0.0; d.c1[q] = on ? c1 : 0.0; d.c2[q] = on ? c2 : 0.0;
     }
   }
 }
@@ -336,23 +397,20 @@ DEV LSPoint ls_eval_reg(const LSReg<DIMT> &d, double q0, double q1, double q2, d
   for (int q = 0; q < LS_CPL; q++) {
     if (q >= d.ncslot) break;
     if (!d.on[q]) continue;
-    double mu = d.mu[q], U[DIMT];
-    double T2 = 0, UV = 0;
-#pragma unroll
-    for (int j = 0; j < DIMT; j++) {
-      U[j] = d.U0[q][j] + a * d.UV[q][j];
-      if (j > 0) { T2 += U[j] * U[j]; UV += U[j] * d.UV[q][j]; }
-    }
-    double iT = fast_rsqrt(T2);
-    double N = U[0], T = T2 * iT;
+    const double mu = d.mu[q];
+    const double N = d.N0[q] + a * d.NV[q];
+    const double UV = d.t1[q] + a * d.t2[q];                      // sum_{j>0} U_j V_j
+    const double T2 = fmax(d.t0[q] + a * (d.t1[q] + UV), 0.0);    // sum_{j>0} U_j^2
+    double iT = fast_rsqrt(T2);            // 1/T without an IEEE divide + sqrt on the critical path
+    double T = T2 * iT;
     if (N >= mu * T || (T <= 0 && N >= 0)) {
     } else if (mu * N + T <= 0 || (T <= 0 && N < 0)) {
-#pragma unroll
-      for (int j = 0; j < DIMT; j++) { double E = d.E[q][j], vj = d.UV[q][j], eu = E * U[j]; p.cost += 0.5 * eu * U[j]; p.d1 += eu * vj; p.d2 += E * vj * vj; }
+      const double c2a = d.c2[q] * a;
+      p.cost += d.c0[q] + a * (d.c1[q] + c2a); p.d1 += d.c1[q] + 2 * c2a; p.d2 += 2 * d.c2[q];
     } else {
       double Dm = d.Dm[q], NmT = N - mu * T;
-      double T1 = UV * iT, T2d = (d.VV[q] - T1 * T1) * iT;
-      double g1 = d.UV[q][0] - mu * T1;
+      double T1 = UV * iT, T2d = (d.t2[q] - T1 * T1) * iT;
+      double g1 = d.NV[q] - mu * T1;
       double dn = Dm * NmT;
       p.cost += 0.5 * dn * NmT; p.d1 += dn * g1; p.d2 += Dm * g1 * g1 - dn * mu * T2d;
     }
@@ -368,8 +426,73 @@ DEV LSPoint ls_eval_reg(const LSReg<DIMT> &d, double q0, double q1, double q2, d
 // single-entry rows, the cone factors of the elliptic contacts.  chg_mask[k] / chg_w[k]: the general rows of slot k whose
 // quadratic-zone membership changed and the signed weight (+-D) of their rank-1 term in the Hessian.
 template <int NVT, int DIMT>
-DEV void ls_commit(Ctx &c, const LSReg<DIMT> &d, double a, unsigned long long *chg_mask, double *chg_w) {
+DEV double ls_commit(Ctx &c, const LSReg<DIMT> &d, double a, unsigned long long *chg_mask, double *chg_w) {
   const int nefc = c.nefc, stride = c.M->con_stride;
+  double cost = 0;
+  // (contacts first: they read the residuals of the iterate the search started from, which the row pass below overwrites)
+#pragma unroll
+  for (int q = 0; q < LS_CPL; q++) {
+    if (q >= d.ncslot) break;
+    if (!d.on[q]) continue;
+    int ci = LANE + NLANE * q, dim = d.cdim[q], i = d.crow[q];
+    double *cc = c.contact + ci * stride;
+    double mu = d.mu[q], U[DIMT], F[DIMT], Ej[DIMT], frj[DIMT];
+    const int wasquad = d.cwasq[q];
+    {
+      // the contact's own rows once more (the evaluations only carried polynomials in alpha): old residuals + alpha * slopes
+      const double *o = LS_CONREC(c) + ci * LSC_STRIDE;
+      double jr[DIMT], jv[DIMT];
+#pragma unroll
+      for (int j = 0; j < DIMT; j++) { int rj = i + j < nefc ? i + j : nefc - 1; jr[j] = c.efc_jar[rj]; jv[j] = c.efc_jv[rj]; Ej[j] = o[j]; frj[j] = o[6 + j]; }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < DIMT; j++) U[j] = (jr[j] + a * jv[j]) * frj[j];
+    }
+    double T2 = 0;
+#pragma unroll
+    for (int j = 0; j < DIMT; j++) { F[j] = 0; if (j > 0) T2 += U[j] * U[j]; }
+    double iT = fast_rsqrt(T2);
+    double N = U[0], T = T2 * iT;
+    int st;
+    if (N >= mu * T || (T <= 0 && N >= 0)) {
+      st = STATE_SATISFIED;
+    } else if (mu * N + T <= 0 || (T <= 0 && N < 0)) {
+#pragma unroll
+      for (int j = 0; j < DIMT; j++) { double eu = Ej[j] * U[j]; cost += 0.5 * eu * U[j]; F[j] = -(eu * frj[j]); }        // -D_j jar_j with jar_j = U_j / fr_j, D_j = E_j fr_j^2
+      st = STATE_QUADRATIC;
+      if (!wasquad) {       // the zone-independent block record (see constraint_update): P = Q = 0, T_j = sqrt(D_j), w0 = D_0
+#pragma unroll
+        for (int j = 0; j < DIMT; j++) if (j < dim) {
+          double Dj = Ej[j] * frj[j] * frj[j];
+          cc[CON_H + j] = 0;
+          cc[CON_H + 6 + j] = j == 0 ? Dj : 0.0;
+          cc[CON_H + 12 + j] = Dj * fast_rsqrt(Dj);
+        }
+      }
+    } else {
+      double Dm = d.Dm[q], NmT = N - mu * T;
+      double f0 = -Dm * NmT * mu;
+      cost += 0.5 * Dm * NmT * NmT;
+      F[0] = f0;
+#pragma unroll
+      for (int j = 1; j < DIMT; j++) F[j] = -f0 * iT * U[j] * frj[j];
+      st = STATE_CONE;
+      double kap = -mu * NmT * Dm * iT;
+      double sD = Dm * fast_rsqrt(Dm), sk = kap > 0 ? kap * fast_rsqrt(kap) : 0.0;
+      cc[CON_H] = sD * frj[0];
+      cc[CON_H + 6] = 0;
+      cc[CON_H + 12] = -sD * NmT;
+#pragma unroll
+      for (int j = 1; j < DIMT; j++) if (j < dim) {
+        double u = U[j] * iT;
+        cc[CON_H + j] = -sD * frj[j] * mu * u;
+        cc[CON_H + 6 + j] = sk * frj[j] * u;
+        cc[CON_H + 12 + j] = sk * frj[j];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < DIMT; j++) if (j < dim) { c.efc_force[i + j] = F[j]; c.efc_state[i + j] = st; }
+  }
 #pragma unroll
   for (int k = 0; k < LS_RPL; k++) {
     chg_mask[k] = 0; chg_w[k] = 0;
@@ -383,6 +506,7 @@ DEV void ls_commit(Ctx &c, const LSReg<DIMT> &d, double a, unsigned long long *c
     double xc = fmin(fmax(x, lo), hi);
     int inside = x > lo && x < hi;
     int chg = 0;
+    cost += d.hD[k] * xc * xc + f * (fabs(x) - fabs(xc));
     if (quad) {
       double force = fric ? (inside ? -D * x : (x <= lo ? f : -f)) : -D * xc;
       c.efc_force[r] = force;
@@ -398,58 +522,7 @@ DEV void ls_commit(Ctx &c, const LSReg<DIMT> &d, double a, unsigned long long *c
     }
     chg_mask[k] = __builtin_amdgcn_ballot_w64(chg != 0);
   }
-#pragma unroll
-  for (int q = 0; q < LS_CPL; q++) {
-    if (q >= d.ncslot) break;
-    if (!d.on[q]) continue;
-    int ci = LANE + NLANE * q, dim = d.cdim[q], i = d.crow[q];
-    double *cc = c.contact + ci * stride;
-    double mu = d.mu[q], U[DIMT], F[DIMT];
-    const int wasquad = d.cwasq[q];
-    double T2 = 0;
-#pragma unroll
-    for (int j = 0; j < DIMT; j++) { U[j] = d.U0[q][j] + a * d.UV[q][j]; F[j] = 0; if (j > 0) T2 += U[j] * U[j]; }
-    double iT = fast_rsqrt(T2);
-    double N = U[0], T = T2 * iT;
-    int st;
-    if (N >= mu * T || (T <= 0 && N >= 0)) {
-      st = STATE_SATISFIED;
-    } else if (mu * N + T <= 0 || (T <= 0 && N < 0)) {
-#pragma unroll
-      for (int j = 0; j < DIMT; j++) F[j] = -(d.E[q][j] * d.fr[q][j]) * U[j];        // -D_j jar_j with jar_j = U_j / fr_j, D_j = E_j fr_j^2
-      st = STATE_QUADRATIC;
-      if (!wasquad) {       // the zone-independent block record (see constraint_update): P = Q = 0, T_j = sqrt(D_j), w0 = D_0
-#pragma unroll
-        for (int j = 0; j < DIMT; j++) if (j < dim) {
-          double Dj = d.E[q][j] * d.fr[q][j] * d.fr[q][j];
-          cc[CON_H + j] = 0;
-          cc[CON_H + 6 + j] = j == 0 ? Dj : 0.0;
-          cc[CON_H + 12 + j] = Dj * fast_rsqrt(Dj);
-        }
-      }
-    } else {
-      double Dm = d.Dm[q], NmT = N - mu * T;
-      double f0 = -Dm * NmT * mu;
-      F[0] = f0;
-#pragma unroll
-      for (int j = 1; j < DIMT; j++) F[j] = -f0 * iT * U[j] * d.fr[q][j];
-      st = STATE_CONE;
-      double kap = -mu * NmT * Dm * iT;
-      double sD = Dm * fast_rsqrt(Dm), sk = kap > 0 ? kap * fast_rsqrt(kap) : 0.0;
-      cc[CON_H] = sD * d.fr[q][0];
-      cc[CON_H + 6] = 0;
-      cc[CON_H + 12] = -sD * NmT;
-#pragma unroll
-      for (int j = 1; j < DIMT; j++) if (j < dim) {
-        double u = U[j] * iT;
-        cc[CON_H + j] = -sD * d.fr[q][j] * mu * u;
-        cc[CON_H + 6 + j] = sk * d.fr[q][j] * u;
-        cc[CON_H + 12 + j] = sk * d.fr[q][j];
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < DIMT; j++) if (j < dim) { c.efc_force[i + j] = F[j]; c.efc_state[i + j] = st; }
-  }
+  return wave_sum(cost);
 }
 
 template <int NVT, int DIMT>
@@ -482,15 +555,16 @@ DEV void solve_constraints_reg_d(Ctx &c) {
     cost = cost_ws;
   }
   PROF(c, 12);
+  int nparts = 0;
 #if MJPC_HELPER
-  cone_job_post<NVT>(c);
+  nparts = cone_job_post<NVT>(c);
 #endif
   double hq[CB];
   hblock_init<NVT>(c, hq, hi, j0);
   PROF(c, 15);
   newton_grad_reg<NVT>(c, hi, hg, hact);
   PROF(c, 9);
-  newton_assemble<NVT, DIMT>(c, hq, hi, hg, j0, hact);
+  newton_assemble<NVT, DIMT>(c, hq, hi, hg, j0, hact, nparts);
   PROF(c, 19);
   newton_direction<NVT>(c);
   PFOR(i, nv) c.search[i] = -c.Mgrad[i];
@@ -512,15 +586,22 @@ DEV void solve_constraints_reg_d(Ctx &c) {
     if (snorm < D_MINVAL || gs >= 0) break;
     const double gtol = M.tolerance * M.ls_tolerance * snorm / scale;
     LSReg<DIMT> d;
+    if (iter == 0) {
+#if MJPC_HELPER
+      if (!flag_wait(c.misc + HX_LSREC, c.hseq / 256 + 1)) c.warning |= WARN_SYNC;      // helper 0 built the records meanwhile
+#else
+      ls_records_build<NVT>(c);
+#endif
+    }
     ls_load_reg<NVT, DIMT>(c, d);
     PROF(c, 21);
     double lo = 0, hi_a = -1, a = 1.0;
     double best_a = 0, best_cost = cost, dxold = a, dx = a;
     LSPoint p; p.cost = cost; p.d1 = gs; p.d2 = -gs;
-    double a_eval = 0;
+    int moved = 0;
+    const double pred_tol = 1e-3 * M.tolerance / scale;
     for (int it = 0; it < M.ls_iterations; it++) {
       p = ls_eval_reg<DIMT>(d, gauss, q1, q2, a);
-      a_eval = a;
 #if defined(MJPC_PROFILE) && !defined(MJPC_EMU)
       if (LANE == 0) c.prof[23] += 1;
 #endif
@@ -541,26 +622,31 @@ DEV void solve_constraints_reg_d(Ctx &c) {
       double an = bracketed ? an_b : an_e;
       dxold = dx; dx = bracketed ? dx_b : an_e - a;
       if (conv || an == a) break;
+#if LS_PREDICT
+      // a plain Newton step on phi' that promises less than a thousandth of the solver's stopping threshold: take it unseen (the
+      // commit below prices the point; the evaluation that would only confirm |phi'| < gtol is skipped)
+      const int plain = pos2 && (bracketed ? ok : newton > a);
+      if (plain && 0.5 * p.d1 * p.d1 * fast_rcp(p.d2) < pred_tol) { a = an; moved = 1; break; }
+#endif
       a = an;
     }
     PROF(c, 22);
-    const double alpha = best_a;
+    const double alpha = moved ? a : best_a;
     PROF(c, 14);
     if (alpha == 0) break;
-    if (a_eval != alpha) p = ls_eval_reg<DIMT>(d, gauss, q1, q2, alpha);      // rare: the best point is not the last one evaluated
-    // ---- move there: the last evaluation is the constraint update
+    // ---- move there: the commit is the constraint update at alpha (it also returns the constraint cost)
     unsigned long long chg_mask[LS_RPL]; double chg_w[LS_RPL];
-    ls_commit<NVT, DIMT>(c, d, alpha, chg_mask, chg_w);
+    const double ccost = ls_commit<NVT, DIMT>(c, d, alpha, chg_mask, chg_w);
     PFOR(i, nv) { c.qacc[i] += alpha * c.search[i]; c.Ma[i] += alpha * c.Mv[i]; }
     SYNC();
     gauss = gauss + alpha * q1 + alpha * alpha * q2;
     const double oldcost = cost;
-    cost = p.cost;
+    cost = gauss + ccost;
     PROF(c, 12);
     const double improvement = scale * (oldcost - cost);
     const int stop = improvement < M.tolerance || (c.warning & WARN_SYNC) != 0;
 #if MJPC_HELPER
-    if (!stop) cone_job_post<NVT>(c);
+    if (!stop) nparts = cone_job_post<NVT>(c);
 #endif
     if (!stop) {
 #pragma unroll
@@ -574,7 +660,7 @@ DEV void solve_constraints_reg_d(Ctx &c) {
     PFOR(i, nv) pg += c.grad[i] * c.grad[i];
     const double gradient = scale * sqrt(wave_sum(pg));
     if (stop || gradient < M.tolerance) break;
-    newton_assemble<NVT, DIMT>(c, hq, hi, hg, j0, hact);
+    newton_assemble<NVT, DIMT>(c, hq, hi, hg, j0, hact, nparts);
     PROF(c, 19);
     newton_direction<NVT>(c);
     PFOR(i, nv) c.search[i] = -c.Mgrad[i];

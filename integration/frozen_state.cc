@@ -5,9 +5,10 @@
 // flat arrays, refreshed at the top of every plan step (HipSamplingPlanner::RefreshTask).  Layouts: DESIGN.md section 2 and
 // mujoco_mpc_amd/csrc/residuals.h (QI_* / QD_*).  This file is compiled inside an MJPC tree only (needs <mujoco/mujoco.h>).
 //
-// Two ResidualFn classes keep that state private: add ONE line to each of
-//     mjpc/tasks/quadruped/quadruped.h     (class QuadrupedFlat::ResidualFn)      friend struct mjpc::HipFrozenState;
-//     mjpc/tasks/humanoid/tracking/tracking.h (class Tracking::ResidualFn)        friend struct mjpc::HipFrozenState;
+// Two ResidualFn classes keep that state private.  No edit of the reference is needed: compile THIS file with
+// `-fno-access-control` (GCC and Clang; CMake: set_source_files_properties(frozen_state.cc PROPERTIES COMPILE_OPTIONS
+// -fno-access-control)) — or, for a compiler without that switch, add `friend struct mjpc::HipFrozenState;` to
+// QuadrupedFlat::ResidualFn (quadruped.h:169) and humanoid::Tracking::ResidualFn (tracking.h:33).
 #include <string>
 #include <vector>
 
@@ -56,9 +57,12 @@ struct HipFrozenState {
   static void Tracking(const humanoid::Tracking::ResidualFn& r, const mjModel* m, std::vector<int>& I, std::vector<double>& D) {
     static const char* kBodies[16] = {"pelvis", "head", "ltoe", "rtoe", "lheel", "rheel", "lknee", "rknee",
                                       "lhand", "rhand", "lelbow", "relbow", "lshoulder", "rshoulder", "lhip", "rhip"};
+    // key frames per motion: the table of tracking.cc:43-54 (file-local there, so it is repeated here as data)
+    static const int kMotionLength[10] = {121, 154, 115, 78, 145, 188, 260, 279, 39, 510};
     int mode = r.current_mode_, first = 0;
-    for (int k = 0; k < mode; k++) first += humanoid::MotionLength(k);       // tracking.cc:57 (declare it in tracking.h)
-    I = {mode, first, humanoid::MotionLength(mode)};
+    if (mode < 0 || mode >= 10) mju_error_i("HipSamplingPlanner: tracking motion %d out of range", mode);
+    for (int k = 0; k < mode; k++) first += kMotionLength[k];                // MotionStartIndex, tracking.cc:60-66
+    I = {mode, first, kMotionLength[mode]};
     for (const char* b : kBodies) I.push_back(SensorObject(m, (std::string("tracking_pos[") + b + "]").c_str()));
     for (const char* b : kBodies) I.push_back(m->body_mocapid[Body(m, (std::string("mocap[") + b + "]").c_str())]);
     D = {r.reference_time_};
@@ -101,16 +105,22 @@ struct HipFrozenState {
   static void Acrobot(std::vector<int>& I) { I = {0, 1}; }                                                   // acrobot.cc:38-39: sites 0 and 1
 };
 
-// called by FillTaskView (hip_sampling_planner.cc) with the task's own ResidualFn (Task::InternalResidual is protected: the
-// adapter is handed the pointer by a one-line accessor, integration/README.md)
-void FillFrozenState(const Task& task, const BaseResidualFn* residual, const mjModel* m, int task_id, std::vector<int>& ints,
+// called by FillTaskView (hip_sampling_planner.cc) with the copy of the task's ResidualFn that Task::Residual() hands every
+// planner at the top of a plan step (public, taken under the task's lock: agent.cc:290)
+void FillFrozenState(const Task& task, const ResidualFn* residual, const mjModel* m, int task_id, std::vector<int>& ints,
                      std::vector<double>& dbls) {
   ints.clear(); dbls.clear();
   switch (task_id) {
-    case MJPC_TASK_QUADRUPED:
-      HipFrozenState::Quadruped(*static_cast<const QuadrupedFlat::ResidualFn*>(residual), m, ints, dbls); break;
-    case MJPC_TASK_HUMANOID_TRACK:
-      HipFrozenState::Tracking(*static_cast<const humanoid::Tracking::ResidualFn*>(residual), m, ints, dbls); break;
+    case MJPC_TASK_QUADRUPED: {
+      auto* r = dynamic_cast<const QuadrupedFlat::ResidualFn*>(residual);
+      if (!r) mju_error("HipSamplingPlanner: task 'Quadruped Flat' without a QuadrupedFlat::ResidualFn");
+      HipFrozenState::Quadruped(*r, m, ints, dbls);
+    } break;
+    case MJPC_TASK_HUMANOID_TRACK: {
+      auto* r = dynamic_cast<const humanoid::Tracking::ResidualFn*>(residual);
+      if (!r) mju_error("HipSamplingPlanner: task 'Humanoid Track' without a Tracking::ResidualFn");
+      HipFrozenState::Tracking(*r, m, ints, dbls);
+    } break;
     case MJPC_TASK_HUMANOID_STAND: HipFrozenState::Stand(m, ints); break;
     case MJPC_TASK_HUMANOID_WALK: HipFrozenState::Walk(m, ints); break;
     case MJPC_TASK_SHADOW_REORIENT: HipFrozenState::Hand(m, ints); break;

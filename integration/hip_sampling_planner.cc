@@ -1,12 +1,15 @@
 // integration/hip_sampling_planner.cc — see hip_sampling_planner.h.  Host-side glue only: field-by-field views of mjModel /
 // Task for the C ABI and forwarding of the Planner / RankedPlanner virtuals to mjpc_hip::SamplingPlanner.
-#include "mjpc/planners/sampling_hip/planner.h"
+#include "hip_sampling_planner.h"
 
 #include <algorithm>
 #include <cstring>
+#include <memory>
 #include <string>
+#include <utility>
 
 #include "mjpc/array_safety.h"
+#include "mjpc/planners/sampling/planner.h"   // MinSamplingSplinePoints, MinNoiseStdDev ...
 #include "mjpc/utilities.h"
 
 namespace mjpc {
@@ -15,7 +18,7 @@ namespace mju = ::mujoco::util_mjpc;
 using mjpc::spline::SplineInterpolation;
 
 // frozen_state.cc
-void FillFrozenState(const Task& task, const BaseResidualFn* residual, const mjModel* m, int task_id, std::vector<int>& ints,
+void FillFrozenState(const Task& task, const ResidualFn* residual, const mjModel* m, int task_id, std::vector<int>& ints,
                      std::vector<double>& dbls);
 
 namespace {
@@ -167,7 +170,8 @@ static void FillTaskView(const Task& task, const mjModel* m, MjpcHipTask& t, std
   }
   t.trace_objtype = trace_type.data(); t.trace_objid = trace_id.data();
   // frozen ResidualFn members (frozen_state.cc): ids resolved at Reset and the mode / gait state Transition wrote
-  FillFrozenState(task, task.ResidualForHip(), m, t.task_id, ints, dbls);
+  std::unique_ptr<ResidualFn> frozen = task.Residual();       // the copy every planner takes per plan step (agent.cc:290)
+  FillFrozenState(task, frozen.get(), m, t.task_id, ints, dbls);
   t.num_int = static_cast<int>(ints.size()); t.int_data = ints.data();
   t.num_dbl = static_cast<int>(dbls.size()); t.dbl_data = dbls.data();
 }
@@ -205,11 +209,11 @@ void HipSamplingPlanner::Allocate() {
   state.resize(num_state); mocap.resize(7 * model->nmocap); userdata.resize(model->nuserdata);
   policy.Allocate(model, *task, kMaxTrajectoryHorizon);
   previous_policy.Allocate(model, *task, kMaxTrajectoryHorizon);
-  scratch_policy_.Allocate(model, *task, kMaxTrajectoryHorizon);
-  for (Trajectory* t : {&best_, &scratch_trajectory_}) {
-    t->Initialize(num_state, model->nu, task->num_residual, task->num_trace, kMaxTrajectoryHorizon);
-    t->Allocate(kMaxTrajectoryHorizon);
-  }
+  best_.Initialize(num_state, model->nu, task->num_residual, task->num_trace, kMaxTrajectoryHorizon);
+  best_.Allocate(kMaxTrajectoryHorizon);
+  trajectory_cache_.clear(); policy_cache_.clear();
+  trajectory_cache_.resize(kMaxTrajectoryHip); policy_cache_.resize(kMaxTrajectoryHip);      // entries are made on first use
+  trajectory_stamp_.assign(kMaxTrajectoryHip, 0); policy_stamp_.assign(kMaxTrajectoryHip, 0);
   impl_.Allocate();
   winner = -1;
 }
@@ -240,7 +244,21 @@ void HipSamplingPlanner::RefreshTask() {
   impl_.SetTask(&task_view_);                                 // only the task block travels, asynchronously
 }
 
+// iLQS rewrites sampling.policy.plan before it calls OptimizePolicy (ilqs/planner.cc:162-169) and the GUI moves
+// policy.num_spline_points: what the plan step starts from is this object's policy, as in the reference
+void HipSamplingPlanner::PushPolicyToImpl() {
+  const std::shared_lock<std::shared_mutex> lock(mtx_);
+  impl_.policy.num_spline_points = policy.num_spline_points;
+  impl_.policy.plan.Clear();
+  impl_.policy.plan.SetInterpolation(static_cast<mjpc_hip::SplineInterpolation>(policy.plan.Interpolation()));
+  for (int p = 0; p < static_cast<int>(policy.plan.Size()); p++) {
+    mjpc::spline::TimeSpline::ConstNode node = std::as_const(policy.plan).NodeAt(p);
+    impl_.policy.plan.AddNode(node.time(), node.values().data());
+  }
+}
+
 void HipSamplingPlanner::SyncFromImpl() {
+  plan_stamp_++;                                              // candidates cached from the previous plan step are stale
   {
     const std::unique_lock<std::shared_mutex> lock(mtx_);
     for (int which = 0; which < 2; which++) {
@@ -270,6 +288,7 @@ static void CopyTrajectory(const mjpc_hip::Trajectory& src, Trajectory& dst) {
 
 void HipSamplingPlanner::OptimizePolicy(int horizon, ThreadPool& /*pool: the GPU replaces the worker threads*/) {
   RefreshTask();
+  PushPolicyToImpl();
   impl_.OptimizePolicy(horizon);                              // UpdateNominalPolicy -> rollouts on the GPU(s) -> winner adoption
   last_horizon_ = horizon;
   SyncFromImpl();
@@ -290,9 +309,11 @@ const Trajectory* HipSamplingPlanner::BestTrajectory() { return winner >= 0 ? &b
 
 int HipSamplingPlanner::OptimizePolicyCandidates(int ncandidates, int horizon, ThreadPool&) {
   RefreshTask();
+  PushPolicyToImpl();
   impl_.UpdateNominalPolicy(horizon);
   int n = impl_.OptimizePolicyCandidates(ncandidates, horizon);
   last_horizon_ = horizon;
+  plan_stamp_++;
   trajectory_order = impl_.trajectory_order;
   return n;
 }
@@ -306,76 +327,103 @@ void HipSamplingPlanner::CopyCandidateToPolicy(int candidate) {
   CopyTrajectory(impl_.trajectory_winner, best_);
 }
 
-// trajectory[i] / candidate_policy[i] of the reference (ilqs/planner.cc:98-198 reads them): fetched from the owning device
-const Trajectory& HipSamplingPlanner::trajectory(int i) {
-  impl_.FetchCandidateUnranked(i);
-  CopyTrajectory(impl_.trajectory_winner, scratch_trajectory_);
-  return scratch_trajectory_;
+// trajectory[i] / candidate_policy[i] of the reference (ilqs/planner.cc:177-198 reads them): copied from the owning device on
+// first use after a plan step, then served from the cache (two indices in one expression must not share storage)
+const Trajectory& HipSamplingPlanner::FetchTrajectory(int i) {
+  if (i < 0 || i >= kMaxTrajectoryHip) mju_error_i("HipSamplingPlanner: trajectory[%d] out of range", i);
+  if (i == winner && winner >= 0) return best_;
+  std::unique_ptr<Trajectory>& slot = trajectory_cache_[i];
+  if (!slot) {
+    slot = std::make_unique<Trajectory>();
+    slot->Initialize(model->nq + model->nv + model->na, model->nu, task->num_residual, task->num_trace, kMaxTrajectoryHorizon);
+    slot->Allocate(kMaxTrajectoryHorizon);
+  }
+  if (trajectory_stamp_[i] != plan_stamp_) {
+    impl_.FetchCandidateUnranked(i);
+    CopyTrajectory(impl_.trajectory_winner, *slot);
+    trajectory_stamp_[i] = plan_stamp_;
+  }
+  return *slot;
 }
-const SamplingPolicy& HipSamplingPlanner::candidate_policy(int i) {
-  std::vector<double> knots(static_cast<size_t>(impl_.KnotTimes().size()) * model->nu);
-  impl_.CandidateKnotsUnranked(i, knots.data());
-  scratch_policy_.plan.Clear();
-  scratch_policy_.plan.SetInterpolation(interpolation_);
-  for (size_t p = 0; p < impl_.KnotTimes().size(); p++)
-    scratch_policy_.plan.AddNode(impl_.KnotTimes()[p], absl::MakeConstSpan(knots.data() + p * model->nu, model->nu));
-  return scratch_policy_;
+const SamplingPolicy& HipSamplingPlanner::FetchCandidatePolicy(int i) {
+  if (i < 0 || i >= kMaxTrajectoryHip) mju_error_i("HipSamplingPlanner: candidate_policy[%d] out of range", i);
+  std::unique_ptr<SamplingPolicy>& slot = policy_cache_[i];
+  if (!slot) {
+    slot = std::make_unique<SamplingPolicy>();
+    slot->Allocate(model, *task, kMaxTrajectoryHorizon);
+  }
+  if (policy_stamp_[i] != plan_stamp_) {
+    std::vector<double> knots(static_cast<size_t>(impl_.KnotTimes().size()) * model->nu);
+    impl_.CandidateKnotsUnranked(i, knots.data());
+    slot->plan.Clear();
+    slot->plan.SetInterpolation(interpolation_);
+    for (size_t p = 0; p < impl_.KnotTimes().size(); p++)
+      slot->plan.AddNode(impl_.KnotTimes()[p], absl::MakeConstSpan(knots.data() + p * model->nu, model->nu));
+    slot->num_spline_points = static_cast<int>(impl_.KnotTimes().size());
+    policy_stamp_[i] = plan_stamp_;
+  }
+  return *slot;
 }
 
 // ---- GUI side (render thread, unsynchronised reads like the reference) ----------------------------------------------------
 void HipSamplingPlanner::Traces(mjvScene* scn) {              // sampling/planner.cc:388-434
   float color[4] = {1.0, 1.0, 1.0, 1.0};
+  double width = GetNumberOrDefault(3, model, "agent_sample_width");          // pixels
   double zero3[3] = {0};
   double zero9[9] = {0};
-  int N = num_trajectory_, H = last_horizon_, ntr = 3 * task->num_trace;
-  if (winner < 0 || H < 2 || ntr == 0) return;
+  const Trajectory* best = BestTrajectory();
+  int N = num_trajectory_, ntr = 3 * task->num_trace;
+  if (!best || last_horizon_ < 2 || ntr == 0) return;         // nothing planned yet (the reference would dereference a null best)
+  int H = last_horizon_;
   traces_.resize(static_cast<size_t>(N) * H * ntr);
-  impl_.AllTraces(traces_.data());                            // one D2H copy: [N][H][3 * num_trace]
+  impl_.AllTraces(traces_.data());                            // one D2H copy instead of N trajectory reads: [N][H][3 * num_trace]
   for (int k = 0; k < N; k++) {
-    for (int i = 0; i < H - 1; i++) {
-      if (scn->ngeom + task->num_trace > scn->maxgeom) return;
+    if (k == winner) continue;                                // the winner is drawn by the agent itself
+    for (int i = 0; i < best->horizon - 1; i++) {
+      if (scn->ngeom + task->num_trace > scn->maxgeom) break;
       for (int j = 0; j < task->num_trace; j++) {
-        mjv_initGeom(&scn->geoms[scn->ngeom], mjGEOM_LINE, zero3, zero3, zero9, color);
         const double* a = traces_.data() + (static_cast<size_t>(k) * H + i) * ntr + 3 * j;
-        mjv_connector(&scn->geoms[scn->ngeom], mjGEOM_LINE, 1.5, a, a + ntr);
+        const double* b = a + ntr;
+        mjv_initGeom(&scn->geoms[scn->ngeom], mjGEOM_LINE, zero3, zero3, zero9, color);
+        mjv_makeConnector(&scn->geoms[scn->ngeom], mjGEOM_LINE, width, a[0], a[1], a[2], b[0], b[1], b[2]);
         scn->ngeom += 1;
       }
     }
   }
 }
 
-void HipSamplingPlanner::GUI(mjUI& ui) {                      // sampling/planner.cc:437-473, same widgets on this object's members
-  mjuiDef defSampling[] = {
-      {mjITEM_SLIDERINT, "Rollouts", 2, &num_trajectory_, "0 1"},
-      {mjITEM_SELECT, "Spline", 2, &interpolation_, "Zero\nLinear\nCubic"},
-      {mjITEM_SLIDERINT, "Spline Pts", 2, &policy.num_spline_points, "0 1"},
-      {mjITEM_SLIDERNUM, "Noise Std", 2, noise_exploration, "0 1"},
-      {mjITEM_END}};
-  mju::sprintf_arr(defSampling[0].other, "%i %i", 1, kMaxTrajectoryHip);
+void HipSamplingPlanner::GUI(mjUI& ui) {                      // the widgets of sampling/planner.cc:437-461 on this object's members
+  mjuiDef defSampling[] = {{mjITEM_SLIDERINT, "Rollouts", 2, &num_trajectory_, "0 1"},
+                           {mjITEM_SELECT, "Spline", 2, &interpolation_, "Zero\nLinear\nCubic"},
+                           {mjITEM_SLIDERINT, "Spline Pts", 2, &policy.num_spline_points, "0 1"},
+                           {mjITEM_SLIDERNUM, "Noise Std", 2, noise_exploration, "0 1"},
+                           {mjITEM_SLIDERNUM, "Noise Std2", 2, noise_exploration + 1, "0 1"},
+                           {mjITEM_CHECKBYTE, "Sliding plan", 2, &sliding_plan_, ""},
+                           {mjITEM_END}};
+  mju::sprintf_arr(defSampling[0].other, "%i %i", 1, kMaxTrajectoryHip);      // the engine lifts kMaxTrajectory
   mju::sprintf_arr(defSampling[2].other, "%i %i", MinSamplingSplinePoints, MaxSamplingSplinePoints);
-  mju::sprintf_arr(defSampling[3].other, "%f %f", MinNoiseStdSampling, MaxNoiseStdSampling);
+  mju::sprintf_arr(defSampling[3].other, "%f %f", MinNoiseStdDev, MaxNoiseStdDev);
   mjui_add(&ui, defSampling);
 }
 
 void HipSamplingPlanner::Plots(mjvFigure* fig_planner, mjvFigure* fig_timer, int planner_shift, int timer_shift, int planning,
-                               int* shift) {                  // sampling/planner.cc:476-523
+                               int* shift) {                  // same lines, names and ranges as sampling/planner.cc:464-512
   double planner_bounds[2] = {-6.0, 6.0};
-  mjpc::PlotUpdateData(fig_planner, planner_bounds, fig_planner->linedata[0 + planner_shift][0] + 1, mju_log10(mju_max(improvement, 1.0e-6)),
-                       100, 0 + planner_shift, 0, 1, -100);
-  mju::strcpy_arr(fig_planner->linename[0 + planner_shift], "Improvement");
-  fig_planner->range[1][0] = planner_bounds[0]; fig_planner->range[1][1] = planner_bounds[1];
   double timer_bounds[2] = {0.0, 1.0};
-  PlotUpdateData(fig_timer, timer_bounds, fig_timer->linedata[0 + timer_shift][0] + 1, 1.0e-3 * noise_compute_time * planning, 100,
-                 0 + timer_shift, 0, 1, -100);
-  PlotUpdateData(fig_timer, timer_bounds, fig_timer->linedata[1 + timer_shift][0] + 1, 1.0e-3 * rollouts_compute_time * planning, 100,
-                 1 + timer_shift, 0, 1, -100);
-  PlotUpdateData(fig_timer, timer_bounds, fig_timer->linedata[2 + timer_shift][0] + 1, 1.0e-3 * policy_update_compute_time * planning, 100,
-                 2 + timer_shift, 0, 1, -100);
-  mju::strcpy_arr(fig_timer->linename[0 + timer_shift], "Noise");
-  mju::strcpy_arr(fig_timer->linename[1 + timer_shift], "Rollout");
-  mju::strcpy_arr(fig_timer->linename[2 + timer_shift], "Policy Update");
-  fig_timer->range[0][0] = -100; fig_timer->range[0][1] = 0; fig_timer->range[1][0] = 0.0; fig_timer->range[1][1] = timer_bounds[1];
-  shift[0] += 1; shift[1] += 3;
+  const int pl = planner_shift;
+  PlotUpdateData(fig_planner, planner_bounds, fig_planner->linedata[pl][0] + 1, mju_log10(mju_max(improvement, 1.0e-6)), 100, pl, 0, 1, -100);
+  mju::strcpy_arr(fig_planner->linename[pl], "Improvement");
+  fig_planner->range[1][0] = planner_bounds[0];
+  fig_planner->range[1][1] = planner_bounds[1];
+  const struct { const char* name; double microseconds; } timers[3] = {
+      {"Noise", noise_compute_time}, {"Rollout", rollouts_compute_time}, {"Policy Update", policy_update_compute_time}};
+  for (int k = 0; k < 3; k++) {
+    const int line = k + timer_shift;
+    PlotUpdateData(fig_timer, timer_bounds, fig_timer->linedata[line][0] + 1, 1.0e-3 * timers[k].microseconds * planning, 100, line, 0, 1, -100);
+    mju::strcpy_arr(fig_timer->linename[line], timers[k].name);
+  }
+  shift[0] += 1;       // planner figure: one line
+  shift[1] += 3;       // timer figure: three
 }
 
 }  // namespace mjpc

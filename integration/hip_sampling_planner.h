@@ -8,15 +8,20 @@
 // winner, time, state / mocap / userdata, model, task, noise_exploration, num_trajectory_, interpolation_, sliding_plan_,
 // timing fields.
 //
-// NOT compiled in this repository: it needs <mujoco/mujoco.h>, abseil and the MJPC headers, none of which exist in the build
-// image.  Everything below it — include/mjpc_hip.h (C ABI), include/mjpc_hip_planner.h (C++ planner
-// with the reference's semantics) — is compiled and tested here.
+// Not linked in this repository: it needs MuJoCo and abseil, neither of which exists in the build image (SURVEY.md section
+// 8c).  What IS checked here: tests/test_integration_syntax.py runs `g++ -std=c++20 -fsyntax-only` over integration/*.cc and
+// over the reference's own ilqs/planner.cc with SamplingPlanner swapped for this class, against the reference's real mjpc/
+// headers and declaration-only stand-ins for <mujoco/*.h> / <absl/*> (tests/stubs/) — a syntax and type check, nothing more.
+// Everything below this class — include/mjpc_hip.h (C ABI), include/mjpc_hip_planner.h (C++ planner with the reference's
+// semantics) — is compiled, linked and tested here.
 #ifndef MJPC_PLANNERS_SAMPLING_HIP_PLANNER_H_
 #define MJPC_PLANNERS_SAMPLING_HIP_PLANNER_H_
 
 #include <mujoco/mujoco.h>
 
 #include <atomic>
+#include <cstdint>
+#include <memory>
 #include <shared_mutex>
 #include <vector>
 
@@ -73,9 +78,22 @@ class HipSamplingPlanner : public RankedPlanner {
   std::vector<double> userdata;
   SamplingPolicy policy;                 // (guarded by mtx_)
   SamplingPolicy previous_policy;
-  // candidate i of the last plan step, materialised on demand from the device (i is an index into the last batch)
-  const SamplingPolicy& candidate_policy(int i);
-  const Trajectory& trajectory(int i);
+  // trajectory[i] / candidate_policy[i] of the reference are arrays of kMaxTrajectory objects (sampling/planner.h:126,133);
+  // here the candidates live on the device, so the two members are indexable views: operator[] copies candidate i of the
+  // last plan step from its GPU the first time it is asked for and hands out the cached copy until the next plan step
+  // (ilqs/planner.cc:177-198 compiles unchanged: `sampling.trajectory[sampling.winner].total_return`).
+  template <class T>
+  class CandidateArray {
+   public:
+    const T& operator[](int i) const { return (owner_->*fetch_)(i); }
+   private:
+    friend class HipSamplingPlanner;
+    CandidateArray(HipSamplingPlanner* owner, const T& (HipSamplingPlanner::*fetch)(int)) : owner_(owner), fetch_(fetch) {}
+    HipSamplingPlanner* owner_;
+    const T& (HipSamplingPlanner::*fetch_)(int);
+  };
+  CandidateArray<SamplingPolicy> candidate_policy{this, &HipSamplingPlanner::FetchCandidatePolicy};
+  CandidateArray<Trajectory> trajectory{this, &HipSamplingPlanner::FetchTrajectory};
   std::vector<int> trajectory_order;
   double noise_exploration[2] = {0};
   mjpc::spline::SplineInterpolation interpolation_ = mjpc::spline::SplineInterpolation::kZeroSpline;
@@ -90,6 +108,9 @@ class HipSamplingPlanner : public RankedPlanner {
 
  private:
   void SyncFromImpl();                   // impl_ -> policy / previous_policy / winner / improvement / timings
+  void PushPolicyToImpl();               // policy (iLQS and the GUI write it, ilqs/planner.cc:162-169) -> impl_
+  const Trajectory& FetchTrajectory(int i);
+  const SamplingPolicy& FetchCandidatePolicy(int i);
   void RefreshTask();                    // fresh frozen ResidualFn state + cost weights for this plan step (agent.cc:290)
   mjpc_hip::SamplingPlanner impl_;       // the reference's planner logic over the C ABI (include/mjpc_hip_planner.h)
   // views handed to the engine; the vectors own what mjModel stores in another width / stride
@@ -98,8 +119,12 @@ class HipSamplingPlanner : public RankedPlanner {
   std::vector<int> jnt_limited_, ctrllimited_, forcelimited_, biastype_, trntype_, trnid_, tendon_limited_, wrap_objid_, trace_type_, trace_id_,
       norm_, task_int_, act_i_, eq_active_, actfrclimited_;
   std::vector<double> gainprm_, biasprm_, gear_, wrap_prm_, mesh_vert_, hfield_size_, hfield_data_, task_dbl_, dynprm_;
-  Trajectory best_, scratch_trajectory_;
-  SamplingPolicy scratch_policy_;
+  Trajectory best_;
+  // lazily filled per-candidate copies behind trajectory[] / candidate_policy[]; an entry is valid while its stamp equals plan_stamp_
+  std::vector<std::unique_ptr<Trajectory>> trajectory_cache_;
+  std::vector<std::unique_ptr<SamplingPolicy>> policy_cache_;
+  std::vector<std::uint64_t> trajectory_stamp_, policy_stamp_;
+  std::uint64_t plan_stamp_ = 1;
   std::vector<double> traces_;           // [N][H][3 * num_trace] of the last plan (Traces)
   int last_horizon_ = 0;
   mutable std::shared_mutex mtx_;

@@ -33,9 +33,15 @@ def lib():
             so = EMU_SO[:-3] + "_asan.so"
             subprocess.check_call(["g++", "-O1", "-g", "-fsanitize=address", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=off", "-o", so,
                                    os.path.join(EMU_DIR, "emu.cpp")])
-        elif (not os.path.exists(EMU_SO)) or any(os.path.getmtime(s) > os.path.getmtime(EMU_SO) for s in srcs):
-            subprocess.check_call(["g++", "-O2", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=off", "-o", EMU_SO,
-                                   os.path.join(EMU_DIR, "emu.cpp")])
+        else:
+            import fcntl
+            with open(os.path.join(EMU_DIR, ".build.lock"), "w") as lock:      # pytest-xdist workers: one builds, the others wait
+                fcntl.flock(lock, fcntl.LOCK_EX)
+                if (not os.path.exists(EMU_SO)) or any(os.path.getmtime(s) > os.path.getmtime(EMU_SO) for s in srcs):
+                    tmp = EMU_SO + f".{os.getpid()}.tmp"
+                    subprocess.check_call(["g++", "-O2", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=off", "-o", tmp,
+                                           os.path.join(EMU_DIR, "emu.cpp")])
+                    os.replace(tmp, EMU_SO)
         _lib = C.CDLL(so)
         _lib.emu_plan.argtypes = [C.POINTER(capi.MjpcHipModel), C.POINTER(capi.MjpcHipTask),
                                   C.POINTER(capi.MjpcHipPlanInput), C.POINTER(EmuOut)]

@@ -172,13 +172,26 @@ def main():
     ap.add_argument("--samples", type=int, default=None, help="candidates per GPU of the weak line (default 256 / 1024 / 256)")
     ap.add_argument("--global-samples", type=int, default=None, help="global batch of the strong line (default 4096; hand: 2048)")
     ap.add_argument("--horizon", type=int, default=None, help="default 100 / 128 / 64")
+    ap.add_argument("--tier", default=None, choices=["A", "B"],
+                    help="diagnostics (include/mjpc_hip_debug.h): A = full-capacity kernel only, B = always the dense tier first; default: the engine decides")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary line (strong_scaling_ref at N=1, weak at N>1)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher around us: start the N ranks ourselves as CHILD processes (the driver's command line, 127.0.0.1
+        # rendezvous) before this process has touched torch or the GPU, and leave with their exit code — a `--gpus 8` command
+        # never degrades to a one-rank line
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world != 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     import torch
     dist = None
@@ -195,6 +208,9 @@ def main():
     from mujoco_mpc_amd import modelgen
     from mujoco_mpc_amd.planner import HipBackend
     from mujoco_mpc_amd.sharded import ShardedSampler
+    if args.tier:
+        from mujoco_mpc_amd import capi
+        capi.debug_set("tier", args.tier)
 
     gen, n_default, h_default, P, interp, sigma, wname, cfg_index = WORKLOADS[args.workload]
     model, task, d = getattr(modelgen, gen)()
@@ -261,6 +277,26 @@ def main():
         be.close()
         return rec
 
+    def measure_one_process(n_total, engines, steps, warmup):
+        """The other multi-GPU front end (csrc/multi.cc: ONE planner process, one engine per GPU, host-side elite pick) timed the only
+        way a one-GPU box allows: `engines` engines on this GPU sharing the batch of the headline (wall clock per mjpc_hip_multi_plan)."""
+        from mujoco_mpc_amd.planner import HipMultiBackend
+        mb = HipMultiBackend(model, task, [dev_index] * engines, max_samples=n_total, max_horizon=H)
+        knots = kv; ts = []
+        for i in range(warmup + steps):
+            t0 = time.perf_counter()
+            o = mb.plan(state=d["state"], mocap=d["mocap"], time=0.0, knot_times=kt, knot_values=knots, interpolation=interp,
+                        num_trajectory=n_total, horizon=H, sigma=(sigma, 0.0), seed=0x5EED, stream=i)
+            if i >= warmup:
+                ts.append(time.perf_counter() - t0)
+            knots = mb.knots(n_total, P)[o["winner"]]
+        mb.close()
+        med = statistics.median(ts)
+        return dict(engines_on_this_gpu=engines, global_samples=n_total, steps=steps, median_ms_per_step=1e3 * med, value=n_total / med,
+                    unit="rollouts/s", winner=int(o["winner"]), winner_return=float(o["winner_return"]),
+                    note="mjpc_hip_multi_plan rehearsal: the engines share ONE GPU here, so this prices the one-process path's host "
+                         "overhead (G async launches, G summary fetches, host elite pick, owner-only copy), not a speed-up")
+
     n_head = (n_global // world) if mode == "strong" else n_weak
     head = measure(n_head, args.steps, args.warmup)
     second = None
@@ -314,6 +350,8 @@ def main():
         }
         if second is not None:
             out[second[0]] = line(second[1])
+        if world == 1 and not args.no_secondary:
+            out["one_process_multi_engine"] = measure_one_process(head["n_per_rank"], 2, max(3, min(args.steps, 20)), 2)
         if not args.no_cpu_baseline and world == 1:      # the CPU baseline is reported on rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(model, task, d, kt, kv, head["n_per_rank"], H, interp, sigma)
         print(json.dumps(out))

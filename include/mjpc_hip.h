@@ -95,7 +95,14 @@ enum {
 #define MJPC_MAX_HORIZON 512        /* kMaxTrajectoryHorizon, mjpc/trajectory.h:27 */
 
 /* ---- model: the subset of mjModel the path reads ------------------------------------- */
+/* ABI revision of this header.  mjpc_hip_version() returns the revision the library was built from; both view structs start
+   with `struct_size` (= sizeof of the struct as the CALLER compiled it): mjpc_hip_create / mjpc_hip_set_task refuse a view whose
+   size differs from the library's, so a stale .so paired with a newer header (or ctypes layout) fails loudly instead of reading
+   garbage pointers.  Bindings without the header: mjpc_hip_sizeof_model() / _task() / _plan_input() / _plan_output(). */
+#define MJPC_HIP_ABI_VERSION 3
+
 typedef struct MjpcHipModel {
+  int struct_size;                  /* sizeof(MjpcHipModel) */
   /* sizes */
   int nq, nv, nu, na, nbody, njnt, ngeom, nsite, nmocap, nuserdata, nkey, nexclude, ntendon, nwrap, nmesh, nmeshvert, nhfield, nhfielddata;
   /* mjOption */
@@ -203,6 +210,7 @@ typedef struct MjpcHipModel {
 
 /* ---- task: cost table (mjpc/task.cc:147-245) + frozen ResidualFn state --------------- */
 typedef struct MjpcHipTask {
+  int struct_size;                  /* sizeof(MjpcHipTask) */
   int task_id;                      /* MJPC_TASK_* */
   int num_residual, num_term, num_trace;
   const int *dim_norm_residual;     /* [num_term] */
@@ -364,7 +372,11 @@ int mjpc_hip_multi_num_devices(const MjpcHipMulti *m);
 /* engine k (0 .. n_devices-1), e.g. for mjpc_hip_get_frame / mjpc_hip_kernel_time */
 MjpcHipEngine *mjpc_hip_multi_engine(MjpcHipMulti *m, int k);
 const char *mjpc_hip_last_error(void);
-int mjpc_hip_version(void);
+int mjpc_hip_version(void);                 /* MJPC_HIP_ABI_VERSION of the library */
+int mjpc_hip_sizeof_model(void);
+int mjpc_hip_sizeof_task(void);
+int mjpc_hip_sizeof_plan_input(void);
+int mjpc_hip_sizeof_plan_output(void);
 
 #ifdef __cplusplus
 }

@@ -59,6 +59,7 @@ static void FillModelView(const mjModel* m, MjpcHipModel& v, std::vector<int>& j
                           std::vector<double>& wrap_prm, std::vector<double>& mesh_vert, std::vector<double>& hfield_size,
                           std::vector<double>& hfield_data, std::vector<int>& act_i, std::vector<double>& dynprm, std::vector<int>& eq_active, std::vector<int>& actfrclimited) {
   std::memset(&v, 0, sizeof(v));
+  v.struct_size = sizeof(MjpcHipModel);                  // checked by mjpc_hip_create against the library's own layout
   v.nq = m->nq; v.nv = m->nv; v.nu = m->nu; v.na = m->na; v.nbody = m->nbody; v.njnt = m->njnt; v.ngeom = m->ngeom;
   v.nsite = m->nsite; v.nmocap = m->nmocap; v.nuserdata = m->nuserdata; v.nkey = m->nkey; v.nexclude = m->nexclude;
   v.ntendon = m->ntendon; v.nwrap = m->nwrap;
@@ -154,6 +155,7 @@ static void FillModelView(const mjModel* m, MjpcHipModel& v, std::vector<int>& j
 static void FillTaskView(const Task& task, const mjModel* m, MjpcHipTask& t, std::vector<int>& norm, std::vector<int>& trace_type,
                          std::vector<int>& trace_id, std::vector<int>& ints, std::vector<double>& dbls) {
   std::memset(&t, 0, sizeof(t));
+  t.struct_size = sizeof(MjpcHipTask);
   t.task_id = DeviceResidual(task);
   t.num_residual = task.num_residual; t.num_term = task.num_term; t.num_trace = task.num_trace;
   t.dim_norm_residual = task.dim_norm_residual.data(); t.num_norm_parameter = task.num_norm_parameter.data();

@@ -31,7 +31,7 @@ _MODEL_DBL_ARRAYS_BODY = ["body_pos", "body_quat", "body_ipos", "body_iquat", "b
 
 class MjpcHipModel(C.Structure):
     _fields_ = (
-        [(n, C.c_int) for n in _MODEL_INT_SIZES]
+        [("struct_size", C.c_int)] + [(n, C.c_int) for n in _MODEL_INT_SIZES]
         + [("timestep", C.c_double), ("gravity", C.c_double * 3), ("impratio", C.c_double),
            ("tolerance", C.c_double), ("ls_tolerance", C.c_double), ("cone", C.c_int), ("iterations", C.c_int),
            ("ls_iterations", C.c_int), ("disableflags", C.c_int), ("enableflags", C.c_int), ("solver", C.c_int), ("integrator", C.c_int),
@@ -71,7 +71,7 @@ class MjpcHipModel(C.Structure):
 
 class MjpcHipTask(C.Structure):
     _fields_ = [
-        ("task_id", C.c_int), ("num_residual", C.c_int), ("num_term", C.c_int), ("num_trace", C.c_int),
+        ("struct_size", C.c_int), ("task_id", C.c_int), ("num_residual", C.c_int), ("num_term", C.c_int), ("num_trace", C.c_int),
         ("dim_norm_residual", c_int_p), ("norm", c_int_p), ("num_norm_parameter", c_int_p),
         ("weight", c_double_p), ("norm_parameter", c_double_p), ("risk", C.c_double),
         ("num_parameter", C.c_int), ("parameters", c_double_p),
@@ -118,6 +118,9 @@ class CModel:
         self._keep = []
         m = MjpcHipModel()
         for name, ctype in MjpcHipModel._fields_:
+            if name == "struct_size":
+                m.struct_size = C.sizeof(MjpcHipModel)
+                continue
             if name in _OPTION_DEFAULTS and name not in model:        # mjOption fields added later: MuJoCo's defaults
                 v = _OPTION_DEFAULTS[name]
             elif name in _OPTIONAL_TENDON and name not in model:       # models built before these fields existed: no passive tendon forces
@@ -163,6 +166,9 @@ class CModel:
     def make_task(self, task: dict) -> MjpcHipTask:
         t = MjpcHipTask()
         for name, ctype in MjpcHipTask._fields_:
+            if name == "struct_size":
+                t.struct_size = C.sizeof(MjpcHipTask)
+                continue
             v = task[name]
             if ctype is c_double_p:
                 arr = np.ascontiguousarray(np.asarray(v, dtype=np.float64).ravel())
@@ -265,11 +271,28 @@ def load_engine():
     lib.mjpc_hip_multi_engine.argtypes = [C.c_void_p, C.c_int]
     lib.mjpc_hip_last_error.restype = C.c_char_p
     lib.mjpc_hip_version.restype = C.c_int
+    # a stale library next to a newer ctypes layout must not get as far as reading pointers out of the wrong offsets
+    if lib.mjpc_hip_version() != ABI_VERSION:
+        raise RuntimeError(f"{ENGINE_PATH}: ABI revision {lib.mjpc_hip_version()}, these bindings are revision {ABI_VERSION}: rebuild the engine")
+    for what, ctype in (("model", MjpcHipModel), ("task", MjpcHipTask), ("plan_input", MjpcHipPlanInput), ("plan_output", MjpcHipPlanOutput)):
+        n = getattr(lib, "mjpc_hip_sizeof_" + what)()
+        if n != C.sizeof(ctype):
+            raise RuntimeError(f"{ENGINE_PATH}: sizeof {what} struct is {n} in the library, {C.sizeof(ctype)} in capi.py: rebuild the engine")
+    lib.mjpc_hip_debug_set.argtypes = [C.c_char_p, C.c_char_p]
+    lib.mjpc_hip_debug_set.restype = None
     _engine = lib
     return lib
 
 
+def debug_set(name: str, value=None):
+    """Engine diagnostics knob (include/mjpc_hip_debug.h), read when an engine is created; value None clears it."""
+    load_engine().mjpc_hip_debug_set(name.encode(), None if value is None else str(value).encode())
+
+
+ABI_VERSION = 3            # MJPC_HIP_ABI_VERSION of include/mjpc_hip.h
+
 EXPORTED_SYMBOLS = [
+    "mjpc_hip_sizeof_model", "mjpc_hip_sizeof_task", "mjpc_hip_sizeof_plan_input", "mjpc_hip_sizeof_plan_output", "mjpc_hip_debug_set",
     "mjpc_hip_create", "mjpc_hip_destroy", "mjpc_hip_set_task", "mjpc_hip_plan", "mjpc_hip_plan_async",
     "mjpc_hip_plan_fetch", "mjpc_hip_get_candidate", "mjpc_hip_kernel_time", "mjpc_hip_device_ptrs",
     "mjpc_hip_last_error", "mjpc_hip_version", "mjpc_hip_get_knots", "mjpc_hip_get_frame",

@@ -19,6 +19,7 @@
 #include "spmd.h"
 #include "philox.h"
 #include "host.h"
+#include "../../include/mjpc_hip_debug.h"
 
 // ------------------------------------------------------------------------------ kernels
 // the rollout kernels live in their own translation units (rollout_cached.hip, rollout_direct.hip; see rollout_tu.inc)
@@ -135,7 +136,7 @@ struct MjpcHipEngine {
   double acc_rollout_us = 0, acc_total_us = 0; int acc_n = 0;
   size_t lds_bytes = 0;
   RolloutFn kernel = nullptr; bool cached = true;
-  int fault = 0;               // MJPC_HIP_FAULT_INJECT (test-suite only)
+  int fault = 0;               // diagnostics knob fault_inject (mjpc_hip_debug.h; test-suite only)
   int summary_only = 0, last_summary = 0;      // mjpc_hip_set_fetch_mode
   int last_dense = 0;
   // dense tier (two workgroups per CU), see "Capacity tiers" above
@@ -155,10 +156,20 @@ extern "C" {
 void mjpc_hip_destroy(MjpcHipEngine *e);
 
 const char *mjpc_hip_last_error(void) { return g_error.c_str(); }
-int mjpc_hip_version(void) { return 1; }
+void mjpc_hip_debug_set(const char *name, const char *value) { if (name) mjpc_host::debug_set(name, value); }
+int mjpc_hip_version(void) { return MJPC_HIP_ABI_VERSION; }
+int mjpc_hip_sizeof_model(void) { return (int)sizeof(MjpcHipModel); }
+int mjpc_hip_sizeof_task(void) { return (int)sizeof(MjpcHipTask); }
+int mjpc_hip_sizeof_plan_input(void) { return (int)sizeof(MjpcHipPlanInput); }
+int mjpc_hip_sizeof_plan_output(void) { return (int)sizeof(MjpcHipPlanOutput); }
 
 MjpcHipEngine *mjpc_hip_create(const MjpcHipModel *model, const MjpcHipTask *task, int max_local, int max_horizon, int device) {
   if (!model || !task || max_local < 1 || max_horizon < 1 || max_horizon > MJPC_MAX_HORIZON) { set_error("mjpc_hip_create: invalid argument"); return nullptr; }
+  if (model->struct_size != (int)sizeof(MjpcHipModel) || task->struct_size != (int)sizeof(MjpcHipTask)) {
+    set_error("mjpc_hip_create: MjpcHipModel / MjpcHipTask struct_size does not match this library (ABI revision " + std::to_string(MJPC_HIP_ABI_VERSION) +
+              ": header and library out of step, or struct_size not set)");
+    return nullptr;
+  }
   int ndev = 0;
   MjpcHipEngine *e = nullptr;
   HIPCHKP(hipGetDeviceCount(&ndev));
@@ -173,7 +184,7 @@ MjpcHipEngine *mjpc_hip_create(const MjpcHipModel *model, const MjpcHipTask *tas
     int exact_c = 0, exact_d = 0;
     RolloutFn kc = mjpc_pick_rollout_cached(model->nv, &exact_c), kd = mjpc_pick_rollout_direct(model->nv, &exact_d);
     bool use_cache = !(exact_d && !exact_c);
-    if (getenv("MJPC_HIP_NO_MODEL_CACHE")) use_cache = false;           // test knob
+    if (mjpc_host::debug_knob("no_model_cache")) use_cache = false;     // diagnostics knob (mjpc_hip_debug.h)
     // (the flavour without the whole copy still keeps the hot prefix - kinematic / tree tables - in LDS: hot_only)
     if (!mjpc_host::build(e->pm, model, task, e->P_max, use_cache, false, !use_cache)) { set_error("mjpc_hip_create: " + e->pm.error); delete e; return nullptr; }
     if (use_cache && (size_t)e->pm.L.total_doubles * sizeof(double) > 160 * 1024) {
@@ -189,9 +200,10 @@ MjpcHipEngine *mjpc_hip_create(const MjpcHipModel *model, const MjpcHipTask *tas
       // capacity of the dense tier: the largest (rows, contacts = rows / 4 + 2) not above the model's own whose lean layout fits
       // 80 KiB; below 40 rows the retry pass would be the rule, not the exception
       int cap_e = 0, cap_c = 0;
-      if (const char *cap = getenv("MJPC_HIP_TIERB_CAP")) {       // test knob "nefcmax,nconmax": a tiny dense tier forces the retry pass
+      std::string cap;
+      if (mjpc_host::debug_knob("dense_tier_cap", &cap)) {       // diagnostics knob "nefcmax,nconmax": a tiny dense tier forces the retry pass
         int a = 0, b = 0;
-        if (sscanf(cap, "%d,%d", &a, &b) == 2 && a > 0 && b > 0 && a <= e->pm.M.nefcmax && b <= e->pm.M.nconmax) { cap_e = a; cap_c = b; }
+        if (sscanf(cap.c_str(), "%d,%d", &a, &b) == 2 && a > 0 && b > 0 && a <= e->pm.M.nefcmax && b <= e->pm.M.nconmax) { cap_e = a; cap_c = b; }
       }
       int first = e->pm.M.nefcmax < TIERB_NEFCMAX ? e->pm.M.nefcmax : TIERB_NEFCMAX;
       for (int ne = cap_e ? cap_e : first; ne >= (cap_e ? cap_e : TIERB_NEFCMIN) && !e->kernelB; ne -= 4) {
@@ -205,10 +217,9 @@ MjpcHipEngine *mjpc_hip_create(const MjpcHipModel *model, const MjpcHipTask *tas
         }
       }
     }
-    const char *tier = getenv("MJPC_HIP_TIER");           // test knob: "A" = never the dense tier, "B" = always (when it exists)
-    e->force_tier = tier ? (tier[0] == 'B' ? 2 : 1) : 0;
-    const char *fi = getenv("MJPC_HIP_FAULT_INJECT");
-    e->fault = (fi && !strcmp(fi, "sync")) ? 1 : 0;
+    std::string tier, fi;                                 // diagnostics knobs: "A" = never the dense tier, "B" = always (when it exists)
+    e->force_tier = mjpc_host::debug_knob("tier", &tier) ? (tier[0] == 'B' ? 2 : 1) : 0;
+    e->fault = (mjpc_host::debug_knob("fault_inject", &fi) && fi == "sync") ? 1 : 0;
     e->cached = use_cache;
   }
   memset(&e->K, 0, sizeof(e->K));
@@ -275,6 +286,7 @@ void mjpc_hip_destroy(MjpcHipEngine *e) {
 
 int mjpc_hip_set_task(MjpcHipEngine *e, const MjpcHipTask *task) {
   if (!e || !task) { set_error("mjpc_hip_set_task: invalid argument"); return -1; }
+  if (task->struct_size != (int)sizeof(MjpcHipTask)) { set_error("mjpc_hip_set_task: MjpcHipTask.struct_size does not match this library"); return -1; }
   HIPCHK(hipSetDevice(e->device));
   if (task->num_residual != e->nr || 3 * task->num_trace != e->ntr) { set_error("mjpc_hip_set_task: residual/trace dimensions changed"); return -1; }
   if (e->pending) { set_error("mjpc_hip_set_task: a plan step is in flight (call mjpc_hip_plan_fetch first)"); return -1; }
@@ -418,7 +430,18 @@ static int fetch_rows(MjpcHipEngine *e, int local, MjpcHipPlanOutput *out) {
 int mjpc_hip_plan_fetch(MjpcHipEngine *e, MjpcHipPlanOutput *out) {
   if (!e || !out || !e->last_nlocal) { set_error("mjpc_hip_plan_fetch: nothing planned"); return -1; }
   HIPCHK(hipSetDevice(e->device));
-  HIPCHK(hipStreamSynchronize(e->stream));            // the packed result of plan_async is in pinned host memory now
+  hipError_t sync_rc = hipStreamSynchronize(e->stream);       // the packed result of plan_async is in pinned host memory now
+  // whatever this fetch returns, the plan step is over: the engine accepts the next plan_async / set_task (a failed fetch used
+  // to leave `pending` set for good)
+  const int was_pending = e->pending;
+  e->pending = 0;
+  if (sync_rc != hipSuccess) { set_error(std::string("mjpc_hip_plan_fetch: hipStreamSynchronize: ") + hipGetErrorString(sync_rc)); return -2; }
+  if (was_pending) {
+    float t01 = 0, t12 = 0, t03 = 0;
+    hipEventElapsedTime(&t01, e->ev[0], e->ev[1]); hipEventElapsedTime(&t12, e->ev[1], e->ev[2]); hipEventElapsedTime(&t03, e->ev[0], e->ev[3]);
+    out->noise_compute_time_us = 1e3 * t01; out->rollouts_compute_time_us = 1e3 * t12;
+    e->acc_rollout_us += 1e3 * t12; e->acc_total_us += 1e3 * t03; e->acc_n++;
+  }
   const double *p = e->h_pack;
   int nl = e->last_nlocal;
   int wl = (int)p[0]; double wv = p[1];
@@ -426,15 +449,10 @@ int mjpc_hip_plan_fetch(MjpcHipEngine *e, MjpcHipPlanOutput *out) {
   if (out->returns) memcpy(out->returns, p, sizeof(double) * nl);
   if (out->failure) for (int i = 0; i < nl; i++) out->failure[i] = (int)p[nl + i];
   p += 2 * (size_t)nl;
-  if (wl < 0 || wl >= nl) { set_error("mjpc_hip_plan_fetch: argmin out of range (all returns non-finite?)"); return -3; }
+  // no candidate with a comparable return (every return NaN, e.g. a NaN cost weight): returns[] / failure[] above are valid,
+  // there is no winner
+  if (wl < 0 || wl >= nl) { set_error("mjpc_hip_plan_fetch: no finite return among the candidates (argmin out of range)"); return -3; }
   out->winner = e->last_offset + wl; out->winner_return = wv;
-  if (e->pending) {
-    float t01 = 0, t12 = 0, t03 = 0;
-    hipEventElapsedTime(&t01, e->ev[0], e->ev[1]); hipEventElapsedTime(&t12, e->ev[1], e->ev[2]); hipEventElapsedTime(&t03, e->ev[0], e->ev[3]);
-    out->noise_compute_time_us = 1e3 * t01; out->rollouts_compute_time_us = 1e3 * t12;
-    e->acc_rollout_us += 1e3 * t12; e->acc_total_us += 1e3 * t03; e->acc_n++;
-    e->pending = 0;
-  }
   size_t H = (size_t)e->last_H, P = (size_t)e->last_P;
   double *dst[7] = {out->winner_knots, out->states, out->actions, out->times, out->residual, out->costs, out->trace};
   size_t cnt[7] = {P * e->nu, H * e->ds, H * e->nu, H, H * e->nr, H, H * e->ntr};

@@ -6,6 +6,8 @@
 #include <stdlib.h>
 #include <stdint.h>
 #include <string.h>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 #include "../../include/mjpc_hip.h"
@@ -25,6 +27,22 @@ struct PackedModel {
 };
 
 namespace mjpc_host {
+
+// diagnostics knobs (include/mjpc_hip_debug.h): set explicitly through mjpc_hip_debug_set, never read from the environment, and
+// looked at only while an engine is created
+inline std::mutex &debug_mutex() { static std::mutex m; return m; }
+inline std::map<std::string, std::string> &debug_table() { static std::map<std::string, std::string> t; return t; }
+inline void debug_set(const char *name, const char *value) {
+  std::lock_guard<std::mutex> lock(debug_mutex());
+  if (value) debug_table()[name] = value; else debug_table().erase(name);
+}
+inline bool debug_knob(const char *name, std::string *value = nullptr) {
+  std::lock_guard<std::mutex> lock(debug_mutex());
+  auto it = debug_table().find(name);
+  if (it == debug_table().end()) return false;
+  if (value) *value = it->second;
+  return true;
+}
 
 template <class T> static inline const T *as_off(size_t off) { return reinterpret_cast<const T *>(off * sizeof(T) + 1); }
 
@@ -182,7 +200,7 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
   for (int g = 0; g < ng; g++) if (m->geom_condim[g] > M.maxdim) M.maxdim = m->geom_condim[g];
   M.tree_ok = (nv == 18 && dof_tree_matches<18>(m->dof_parentid)) || (nv == 27 && dof_tree_matches<27>(m->dof_parentid)) ||
               (nv == 33 && dof_tree_matches<33>(m->dof_parentid));
-  if (getenv("MJPC_HIP_DENSE_FACTOR")) M.tree_ok = 0;      // test knob: dense elimination order for every factorisation
+  if (debug_knob("dense_factor")) M.tree_ok = 0;           // diagnostics knob: dense elimination order for every factorisation
   M.nconmax = m->nconmax > 0 ? m->nconmax : 32;
   M.nefcmax = m->nefcmax > 0 ? m->nefcmax : 128;
 #define PI_(f, n) M.f = as_off<int>(put_i(p, m->f, (size_t)(n)))

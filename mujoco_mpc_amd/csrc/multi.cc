@@ -85,12 +85,14 @@ int mjpc_hip_multi_plan(MjpcHipMulti *m, const MjpcHipPlanInput *in, MjpcHipPlan
     o_k.failure = out->failure ? out->failure + m->off[k] : nullptr;
     o_k.winner_knots = m->knots[k].data();
     int rc = mjpc_hip_plan_fetch(m->eng[k], &o_k);
+    if (rc == -3) continue;                               // this shard has no finite return: no local winner, the others still count
     if (rc != 0) { rc_all = rc; continue; }
     noise_us = std::max(noise_us, o_k.noise_compute_time_us); rollouts_us = std::max(rollouts_us, o_k.rollouts_compute_time_us);
     // lexicographic (return, global index): shards are visited in ascending index order, so a strict < keeps the lowest index
     if (owner < 0 || o_k.winner_return < best_value) { owner = k; best_value = o_k.winner_return; best_index = o_k.winner; }
   }
-  if (rc_all != 0 || owner < 0) return rc_all != 0 ? rc_all : -3;
+  m->last_N = N; m->last_H = in->horizon; m->last_P = in->num_spline_points;
+  if (rc_all != 0 || owner < 0) return rc_all != 0 ? rc_all : -3;     // -3: no shard has a finite winner (mjpc_hip_last_error says so)
   out->winner = best_index; out->winner_return = best_value;
   out->noise_compute_time_us = noise_us; out->rollouts_compute_time_us = rollouts_us;
   m->last_N = N; m->last_H = in->horizon; m->last_P = in->num_spline_points;

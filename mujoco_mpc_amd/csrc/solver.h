@@ -541,7 +541,7 @@ DEV void solver_helper_loop(Ctx &c, int seq) {
   }
   if constexpr (NVT > 0 && !MJPC_SOLVER_REG) {
     constexpr int NP = MJPC_NH + 1;
-    // fault injection for the test-suite (MJPC_HIP_FAULT_INJECT=sync): helper 0 of candidate 1 never reports its fill in step 2
+    // fault injection for the test-suite (diagnostics knob fault_inject = sync, mjpc_hip_debug.h): helper 0 of candidate 1 never reports its fill in step 2
     const int mute = c.K->fault == 1 && K == 0 && cand_index() == 1 && seq == 2 * 256;
     for (;;) {
       seq++;

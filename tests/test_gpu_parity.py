@@ -238,6 +238,40 @@ def test_api_errors():
     be.close()
 
 
+def test_a_plan_without_finite_returns_fails_once_and_leaves_the_engine_usable():
+    """A NaN cost weight makes every return NaN: the fetch reports 'no finite return' (-3) with returns[] filled in, and the engine
+    (also the multi-engine planner, whose shards each report -3) takes the next set_task / plan as if nothing had happened (a failed
+    fetch used to leave the plan 'in flight' for good).  Mismatched struct sizes are refused at create."""
+    import copy
+    import ctypes as C
+    from mujoco_mpc_amd import capi
+    from mujoco_mpc_amd.planner import HipMultiBackend
+    m, task, d = cartpole()
+    bad = copy.deepcopy(task); bad["weight"] = np.full(len(task["weight"]), np.nan)
+    kw = dict(state=d["state"], mocap=None, time=0.0, knot_times=np.array([0.0, 0.1]), knot_values=np.zeros((2, 1)),
+              interpolation=1, num_trajectory=6, horizon=10, sigma=(0.1, 0.0), seed=1, stream=0)
+    for make in (lambda: HipBackend(m, task, max_samples=6, max_horizon=10), lambda: HipMultiBackend(m, task, [0, 0], max_samples=6, max_horizon=10)):
+        be = make()
+        good = be.plan(**kw)
+        if isinstance(be, HipBackend):
+            be.set_task(bad)
+        else:
+            assert be.lib.mjpc_hip_multi_set_task(be.h, C.byref(be.cm.make_task(bad))) == 0
+        with pytest.raises(RuntimeError, match="no finite return|failed"):
+            be.plan(**kw)
+        if isinstance(be, HipBackend):
+            be.set_task(task)                                            # would fail with 'a plan step is in flight' before the fix
+        else:
+            assert be.lib.mjpc_hip_multi_set_task(be.h, C.byref(be.cm.make_task(task))) == 0
+        again = be.plan(**kw)
+        assert again["winner"] == good["winner"] and np.array_equal(again["returns"], good["returns"])
+        be.close()
+    cm = capi.CModel(m, task)
+    cm.c_model.struct_size -= 8
+    assert not capi.load_engine().mjpc_hip_create(C.byref(cm.c_model), C.byref(cm.c_task), 4, 10, 0)
+    assert b"struct_size" in capi.load_engine().mjpc_hip_last_error()
+
+
 def test_sampling_planner_on_gpu_reaches_goal_and_matches_oracle_planner():
     """mjpc/test/sampling_planner/sampling_planner_test.cc:40-108 with the rollouts on the GPU: the host mirror of
     SamplingPlanner drives the HIP engine (device Philox noise) for 300 plan iterations on the particle task; the
@@ -505,8 +539,8 @@ def test_ray_miss_fails_the_candidate():
     assert np.all(out["failure"] == 32) and np.all(out["returns"] == 1.0e6)
 
 
-def test_forced_handshake_timeout_surfaces_as_its_own_failure_code(monkeypatch):
-    """Fault injection (MJPC_HIP_FAULT_INJECT=sync: one helper wave of candidate 1 stays silent in step 2): the bounded spin
+def test_forced_handshake_timeout_surfaces_as_its_own_failure_code(debug_knobs):
+    """Fault injection (diagnostics knob fault_inject = sync, include/mjpc_hip_debug.h: one helper wave of candidate 1 stays silent in step 2): the bounded spin
     ends, the candidate fails with MJPC_WARN_SYNC (64) instead of hanging or looking like a diverged rollout; the other
     candidates are bit-identical to a clean run."""
     m, task, d = quadruped()
@@ -516,7 +550,7 @@ def test_forced_handshake_timeout_surfaces_as_its_own_failure_code(monkeypatch):
     be = HipBackend(m, task, max_samples=6, max_horizon=20)
     clean = be.plan(**kw)
     be.close()
-    monkeypatch.setenv("MJPC_HIP_FAULT_INJECT", "sync")
+    debug_knobs("fault_inject", "sync")
     be = HipBackend(m, task, max_samples=6, max_horizon=20)
     bad = be.plan(**kw)
     be.close()
@@ -816,7 +850,7 @@ def test_register_ldl_dense_and_tree_orders_solve_the_same_system(n):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name, N, H, P, sigma", [("quadruped", 24, 40, 3, 0.04), ("humanoid_track", 8, 32, 8, 0.15)])
-def test_tree_and_dense_factor_orders_give_the_same_rollouts(name, N, H, P, sigma, monkeypatch):
+def test_tree_and_dense_factor_orders_give_the_same_rollouts(name, N, H, P, sigma, debug_knobs):
     """the level-ordered sparse L^T D L (DofTree<nv>) against the dense elimination order, whole plans: same winner, returns and
     states to round-off (both are exact factorisations of the same matrices)"""
     from mujoco_mpc_amd.modelgen import REGISTRY
@@ -827,7 +861,7 @@ def test_tree_and_dense_factor_orders_give_the_same_rollouts(name, N, H, P, sigm
     outs = []
     for dense in (0, 1):
         if dense:
-            monkeypatch.setenv("MJPC_HIP_DENSE_FACTOR", "1")
+            debug_knobs("dense_factor", "1")
         be = HipBackend(m, task, max_samples=N, max_horizon=H)
         out = be.plan(state=d["state"], mocap=mocap, time=0.0, knot_times=kt, knot_values=kv, interpolation=2, num_trajectory=N,
                       horizon=H, sigma=(sigma, 0.0), seed=0x5EED, stream=3)
@@ -934,7 +968,7 @@ def test_cpp_sampling_planner_sharded_over_engines_matches_the_unsharded_planner
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("workload", ["quadruped", "humanoid"])
-def test_dense_tier_is_bit_identical_to_full_capacity_and_retries_what_overflows(monkeypatch, workload):
+def test_dense_tier_is_bit_identical_to_full_capacity_and_retries_what_overflows(debug_knobs, workload):
     """Capacity tiers (engine.hip): more candidates than CUs -> the two-workgroups-per-CU flavour (<= 80 KiB of LDS, smaller
     contact / row buffers) runs first and the full-capacity kernel re-runs whatever overflowed.  Returns, failure flags, winner
     and every trajectory must equal the full-capacity-only plan bit for bit - also when the dense tier is made so small
@@ -947,11 +981,11 @@ def test_dense_tier_is_bit_identical_to_full_capacity_and_retries_what_overflows
     kw = dict(state=d["state"], mocap=d["mocap"], time=0.0, knot_times=kt, knot_values=kv, interpolation=2, num_trajectory=N,
               horizon=H, sigma=(sigma, 0.0), seed=0x5EED, stream=7)
     res = {}
-    for name, env in (("full", {"MJPC_HIP_TIER": "A"}), ("auto", {}), ("tiny", {"MJPC_HIP_TIERB_CAP": tiny})):
-        for k in ("MJPC_HIP_TIER", "MJPC_HIP_TIERB_CAP"):
-            monkeypatch.delenv(k, raising=False)
+    for name, env in (("full", {"tier": "A"}), ("auto", {}), ("tiny", {"dense_tier_cap": tiny})):
+        for k in ("tier", "dense_tier_cap"):
+            debug_knobs(k, None)
         for k, v in env.items():
-            monkeypatch.setenv(k, v)
+            debug_knobs(k, v)
         be = HipBackend(m, task, max_samples=N, max_horizon=H)
         out = be.plan(**kw)
         lds, used = be.dense_tier()

@@ -265,13 +265,22 @@ def test_engine_library_exports_every_declared_symbol():
     import __graft_entry__ as g
     so = g.build_engine()
     lib = ctypes.CDLL(so)
-    hdr = open(os.path.join(ROOT, "include", "mjpc_hip.h")).read()
+    hdr = open(os.path.join(ROOT, "include", "mjpc_hip.h")).read() + open(os.path.join(ROOT, "include", "mjpc_hip_debug.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
     declared = sorted(set(re.findall(r"\b(mjpc_hip_[a-z_]+)\s*\(", hdr)))
     assert declared == sorted(capi.EXPORTED_SYMBOLS)
     for sym in declared:
         assert hasattr(lib, sym), sym
     lib.mjpc_hip_version.restype = ctypes.c_int
-    assert lib.mjpc_hip_version() == 1
+    assert lib.mjpc_hip_version() == capi.ABI_VERSION == int(re.search(r"#define MJPC_HIP_ABI_VERSION (\d+)", hdr).group(1))
+    # the ctypes layouts and the compiled structs agree (what capi.load_engine() and mjpc_hip_create check at run time)
+    for what, ctype in (("model", capi.MjpcHipModel), ("task", capi.MjpcHipTask), ("plan_input", capi.MjpcHipPlanInput), ("plan_output", capi.MjpcHipPlanOutput)):
+        assert getattr(lib, "mjpc_hip_sizeof_" + what)() == ctypes.sizeof(ctype), what
+    # no environment variable steers the product library any more (diagnostics go through mjpc_hip_debug_set)
+    csrc = os.path.join(ROOT, "mujoco_mpc_amd", "csrc")
+    for f in os.listdir(csrc):
+        if f.endswith((".h", ".hip", ".cc", ".inc")):
+            assert "getenv" not in open(os.path.join(csrc, f)).read(), f
 
 
 def test_ctypes_structs_match_header_field_order():

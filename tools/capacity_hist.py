@@ -6,7 +6,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.ins
 from mujoco_mpc_amd import modelgen
 from mujoco_mpc_amd.planner import HipBackend
 import bench
-os.environ.setdefault("MJPC_HIP_TIER", "A")
+from mujoco_mpc_amd import capi
+capi.debug_set("tier", "A")          # full capacity only: the histogram must not be clipped by the dense tier
 for wl in sys.argv[1:] or ["quadruped", "humanoid", "hand"]:
     gen, n, H, P, interp, sigma, _, _ = bench.WORKLOADS[wl]
     n = min(n, 1024)

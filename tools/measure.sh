@@ -11,12 +11,12 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_fetch -o p --output-format c
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pmc_write -o p --output-format csv -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-secondary > /dev/null 2> $O/pmc_write.err
 echo "rocprof quadruped done"
 python3 $R/bench.py --samples 512 --no-cpu-baseline --no-secondary --steps 30 > $O/bench_quadruped_512.json 2> $O/bench_512.err
-MJPC_HIP_TIER=A python3 $R/bench.py --samples 512 --no-cpu-baseline --no-secondary --steps 30 > $O/bench_quadruped_512_tierA.json 2>> $O/bench_512.err
+python3 $R/bench.py --tier A --samples 512 --no-cpu-baseline --no-secondary --steps 30 > $O/bench_quadruped_512_tierA.json 2>> $O/bench_512.err
 python3 $R/bench.py --samples 1024 --no-cpu-baseline --no-secondary --steps 20 > $O/bench_quadruped_1024.json 2>> $O/bench_512.err
 rocprofv3 --kernel-trace --stats -d $O/stats512 -o s --output-format csv -- python3 $R/bench.py --samples 512 --steps 10 --warmup 2 --no-cpu-baseline --no-secondary > /dev/null 2> $O/stats512.err
 echo "dense tier done"
 python3 $R/bench.py --workload humanoid --steps 10 --warmup 3 --no-secondary > $O/bench_humanoid.json 2> $O/bench_humanoid.err
-MJPC_HIP_TIER=A python3 $R/bench.py --workload humanoid --steps 6 --warmup 2 --no-secondary --no-cpu-baseline > $O/bench_humanoid_tierA.json 2>> $O/bench_humanoid.err
+python3 $R/bench.py --tier A --workload humanoid --steps 6 --warmup 2 --no-secondary --no-cpu-baseline > $O/bench_humanoid_tierA.json 2>> $O/bench_humanoid.err
 rocprofv3 --kernel-trace --stats -d $O/stats_humanoid -o s --output-format csv -- python3 $R/bench.py --workload humanoid --steps 6 --warmup 2 --no-cpu-baseline --no-secondary > /dev/null 2> $O/stats_humanoid.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_fetch_humanoid -o p --output-format csv -- python3 $R/bench.py --workload humanoid --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > /dev/null 2> $O/pmc_fetch_humanoid.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pmc_write_humanoid -o p --output-format csv -- python3 $R/bench.py --workload humanoid --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > /dev/null 2> $O/pmc_write_humanoid.err

@@ -8,8 +8,8 @@ for tier in B A; do
   i=0
   for grp in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES SQ_WAVES" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT"; do
     i=$((i+1))
-    if [ $tier = A ]; then export MJPC_HIP_TIER=A; else unset MJPC_HIP_TIER; fi
-    rocprofv3 --pmc $grp --kernel-trace -d $O/t${tier}_$i -o p --output-format csv -- python3 $R/bench.py --samples 512 --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > /dev/null 2> $O/t${tier}_$i.err
+    if [ $tier = A ]; then T="--tier A"; else T=""; fi
+    rocprofv3 --pmc $grp --kernel-trace -d $O/t${tier}_$i -o p --output-format csv -- python3 $R/bench.py --samples 512 --steps 3 --warmup 1 --no-cpu-baseline --no-secondary $T > /dev/null 2> $O/t${tier}_$i.err
   done
 done
 echo done

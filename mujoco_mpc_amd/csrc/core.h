@@ -412,8 +412,11 @@ DEV_SOLVE_PHASE void ph_solve(KP Kc, int last, int t) {
   c.hseq = t * 256;
   solve_constraints<NVT>(c); PROF(c, 8);
 #if MJPC_HELPER
-  if (!(MJPC_SOLVER_REG && NVT > 0) || c.M->cone == 1) {
-    if (LANE == 0) c.misc[HX_KIND] = 0;           // release the helper waves (cone blocks of elliptic models; Hessian builds of the generic path)
+  // release the waves that wait for jobs: the workers of elliptic models (one packed word, solver_reg.h) / the Hessian builders of
+  // the generic path
+  if (MJPC_SOLVER_REG && NVT > 0) { if (c.M->cone == 1) flag_set(c.misc + HX_JOBW, JOBW(++c.hseq, 0, 0)); }
+  else {
+    if (LANE == 0) c.misc[HX_KIND] = 0;
     flag_set(c.misc + HX_JOB, ++c.hseq);
   }
 #endif
@@ -493,6 +496,14 @@ DEV_NOINLINE void ph_prefactor(KP Kc) {
   PROFW(c, 11);
   ctx_close(c);
 }
+#if MJPC_HELPER
+// role 1, once its own work of the solve phase is done: one more worker for the owner's per-iterate jobs (elliptic models)
+template <int NVT>
+DEV_NOINLINE void ph_side_worker(KP Kc, int t) {
+  Ctx c; ctx_open(c, Kc, 1);
+  if constexpr (NVT > 0 && MJPC_SOLVER_REG) { if (c.nefc > 0) side_worker<NVT>(c, t); }
+}
+#endif
 
 // mj_Euler with implicit joint damping, then record state[t+1]
 template <int NVT>
@@ -639,6 +650,9 @@ DEV void rollout(KP Kc) {
     if (r1) {
       CostOut o = ph_residual_cost(Kc, t, last); total += o.cost;
       if (!last) ph_prefactor<NVT>(Kc);
+#if MJPC_HELPER
+      ph_side_worker<NVT>(Kc, t);
+#endif
     }
     XBAR(); RPROF(6);
     if (uniform_i(misc[3]) | uniform_i(misc[11])) { failure = 1; break; }

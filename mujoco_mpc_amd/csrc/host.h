@@ -103,10 +103,9 @@ static inline void make_layout(const PackedModel &p, Lay &L, const MjpcHipModel 
   
   A_(efc_J, (ne - M.nfric) * nvp + 1);
   // the register Newton path (solver_reg.h) uses the same block for its gradient scratch (64), the line search's row / contact
-  // records (7 per row, 17 per contact) and, on elliptic models, the helper waves' partial Hessian blocks (2 helpers x CB x G nv)
-  int hg = nv > 0 ? 64 / nv : 1; if (hg < 1) hg = 1; if (hg > nv) hg = nv > 0 ? nv : 1;
-  int hcb = (nv + hg - 1) / hg;
-  int ja_need = 64 + ne * 7 + nc * 17 + (m->cone == MJPC_CONE_ELLIPTIC ? 2 * hcb * hg * nv : 0);
+  // records (7 per row, 17 per contact) and, on elliptic models, the contacts' dof lists (a byte per dof), their (contact, row) pairs (two bytes each) and one partial Hessian
+  // per worker wave (nv x nvp each)
+  int ja_need = 64 + ne * 7 + nc * 17 + (m->cone == MJPC_CONE_ELLIPTIC ? (nc * nv + 7) / 8 + (nc * nv + 3) / 4 + (MJPC_SIDE_JOB > 0 ? 3 : 2) * nv * nvp : 0);
   int ja_size = ja_rows * nvp + 1;
   if (ja_size < ja_need) ja_size = ja_need;
   A_(efc_JA, ja_size);

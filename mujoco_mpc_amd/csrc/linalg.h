@@ -73,6 +73,9 @@ DEV void chol_solve_lds(const double *L, const double *Linv, double *x, int n, i
 #ifndef MJPC_EMU
 template <int N>
 struct LDLRegs { double lo[N], up[N], rinv; };
+// the matrix to factor may arrive as a sum: A plus up to three partial matrices of the same layout (the worker waves' partial
+// Hessians, solver_reg.h); they are added while the rows are loaded
+struct LDLExtra { const double *x[3]; int n; };
 
 template <int I, int E, class F>
 DEV void static_for(F &&f) {
@@ -80,14 +83,40 @@ DEV void static_for(F &&f) {
 }
 // every index below is a compile-time constant (static_for, not `#pragma unroll`: with N = 33 the nested pragma loops exceeded
 // the unroller's budget, the row array stayed in scratch memory and the kernel wrote gigabytes of spills per launch)
+// row i of the symmetric matrix (only its lower triangle is valid in LDS) and its diagonal entry, partial matrices added
 template <int N>
-DEV void ldl_factor_regs(const double *A, int nvp, LDLRegs<N> &f) {
+DEV void ldl_load_row(const double *A, int nvp, const LDLExtra *ex, double *a, double &dg) {
+  const int i = LANE;
+  const bool act = i < N;
+  static_for<0, N>([&](auto jc) { constexpr int j = decltype(jc)::value; a[j] = act ? A[(j <= i) ? i * nvp + j : j * nvp + i] : 0.0; });
+  dg = act ? A[i * nvp + i] : 1.0;
+  if (ex && ex->n > 0) {
+    const int nx = ex->n;
+    double t[3][N], td[3];
+#pragma unroll
+    for (int w = 0; w < 3; w++) {
+      const double *X = ex->x[w < nx ? w : 0];
+      static_for<0, N>([&](auto jc) { constexpr int j = decltype(jc)::value; t[w][j] = X[(j <= i && act) ? i * nvp + j : (act ? j * nvp + i : 0)]; });
+      td[w] = X[act ? i * nvp + i : 0];
+      if (w + 1 >= nx) break;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int w = 0; w < 3; w++) {
+      if (w >= nx) break;
+      static_for<0, N>([&](auto jc) { constexpr int j = decltype(jc)::value; a[j] += act ? t[w][j] : 0.0; });
+      dg += act ? td[w] : 0.0;
+    }
+  }
+}
+template <int N>
+DEV void ldl_factor_regs(const double *A, int nvp, LDLRegs<N> &f, const LDLExtra *ex = nullptr) {
   static_assert(N >= 1 && N <= 64, "one matrix row per lane");
   const int i = LANE;
   const bool act = i < N;
   double a[N];
-  static_for<0, N>([&](auto jc) { constexpr int j = decltype(jc)::value; a[j] = act ? A[(j <= i) ? i * nvp + j : j * nvp + i] : 0.0; });   // lower triangle is valid in LDS
-  double dg = act ? A[i * nvp + i] : 1.0;
+  double dg;
+  ldl_load_row<N>(A, nvp, ex, a, dg);
   static_for<1, N>([&](auto kc) {
     constexpr int k = N - decltype(kc)::value;                                 // N-1 ... 1
     double rk = readlane_d(fast_rcp(dg < D_MINVAL ? D_MINVAL : dg), k);      // reciprocal in the vector domain, then broadcast
@@ -150,14 +179,13 @@ template <int N> constexpr int tree_level_pair(int H, int e, bool pivot) {
 #define TREE_BAR() __builtin_amdgcn_sched_barrier(0)
 #endif
 template <int N>
-DEV void ldl_factor_tree(const double *A, int nvp, LDLRegs<N> &f) {
+DEV void ldl_factor_tree(const double *A, int nvp, LDLRegs<N> &f, const LDLExtra *ex = nullptr) {
   static_assert(DofTree<N>::known && N <= 64, "one matrix row per lane");
   const int i = LANE;
   const bool act = i < N;
   double a[N];
-#pragma unroll
-  for (int j = 0; j < N; j++) a[j] = act ? A[(j <= i) ? i * nvp + j : j * nvp + i] : 0.0;
-  double dg = act ? A[i * nvp + i] : 1.0;
+  double dg;
+  ldl_load_row<N>(A, nvp, ex, a, dg);
   static_for<0, tree_nlevel<N>()>([&](auto hc) {
     constexpr int H = decltype(hc)::value;
     // 1/d in the vector domain (every lane inverts its own diagonal: one reciprocal chain per LEVEL, no scalar clamp
@@ -222,9 +250,9 @@ DEV double ldl_solve_tree(const LDLRegs<N> &f, double xi) {
   return xi;
 }
 template <int N>
-DEV void ldl_factor_any(const double *A, int nvp, LDLRegs<N> &f, int tree) {
-  if constexpr (DofTree<N>::known) { if (tree) { ldl_factor_tree<N>(A, nvp, f); return; } }
-  ldl_factor_regs<N>(A, nvp, f);
+DEV void ldl_factor_any(const double *A, int nvp, LDLRegs<N> &f, int tree, const LDLExtra *ex = nullptr) {
+  if constexpr (DofTree<N>::known) { if (tree) { ldl_factor_tree<N>(A, nvp, f, ex); return; } }
+  ldl_factor_regs<N>(A, nvp, f, ex);
 }
 template <int N>
 DEV double ldl_solve_any(const LDLRegs<N> &f, double xi, int tree) {
@@ -260,10 +288,10 @@ DEV void chol_solve_reg(const double *L, const double *Dinv, double *x, int nvp,
 }
 // fused factor + solve (the factor never leaves the registers): Newton direction, implicit-damping solve
 template <int N>
-DEV void chol_factor_solve_reg(const double *A, double *x, int nvp, int tree) {
+DEV void chol_factor_solve_reg(const double *A, double *x, int nvp, int tree, const LDLExtra *ex = nullptr) {
   SYNC();
   LDLRegs<N> f;
-  ldl_factor_any<N>(A, nvp, f, tree);
+  ldl_factor_any<N>(A, nvp, f, tree, ex);
   const int i = LANE;
   double xi = ldl_solve_any<N>(f, i < N ? x[i] : 0.0, tree);
   if (i < N) x[i] = xi;

@@ -21,6 +21,9 @@
 #define CON_SOLIMP 21
 #define CON_MU 26
 #define CON_H 27
+#ifndef MJPC_SIDE_JOB
+#define MJPC_SIDE_JOB 0      // elliptic models: the side wave shares the owner's per-iterate jobs from this job of a step on (1 = the first; 0 = never: measured slower on the A1)
+#endif
 #define CONI_STRIDE 4          // ints per contact: dim, geom1, geom2, efc_address
 #define MAX_ACTIVE_PAIRS 192
 // efc_id of a contact row: contact index | contact dim << 8 | first row of the contact << 16

@@ -523,7 +523,7 @@ DEV double cost_at_smooth(Ctx &c) {
 #define MJPC_SOLVER_REG 1      // compile-time nv: the owner wave solves alone with the Hessian in registers (solver_reg.h); 0 = scaled-row tables shared with the helper waves
 #endif
 #if MJPC_HELPER
-template <int NVT, int K> DEV void cone_helper_loop(Ctx &c, int seq);      // solver_reg.h
+template <int NVT> DEV void worker_loop(Ctx &c, int W, int last);          // solver_reg.h
 template <int NVT> DEV void ls_records_build(Ctx &c);
 #define HX_LSREC 17      // line-search records of this step ready (helper 0 -> owner), value t + 1
 template <int NVT, int K>
@@ -537,7 +537,7 @@ DEV void solver_helper_loop(Ctx &c, int seq) {
   }
   if constexpr (NVT > 0 && MJPC_SOLVER_REG) {
     if (K == 0 && c.nefc > 0) { ls_records_build<NVT>(c); flag_set(c.misc + HX_LSREC, seq / 256 + 1); }     // the line search's per-step constants
-    cone_helper_loop<NVT, K>(c, seq);
+    worker_loop<NVT>(c, K, seq);
   }
   if constexpr (NVT > 0 && !MJPC_SOLVER_REG) {
     constexpr int NP = MJPC_NH + 1;
@@ -566,6 +566,14 @@ DEV void newton_direction(Ctx &c) {
   chol_factor_solve<NVT>(c.qH, c.Hinv, c.vtmp, c.Mgrad, nv, nvp, c.M->tree_ok && !c.cross);
   PROF(c, 17);
 }
+#ifndef MJPC_EMU
+// the same with the Hessian given as qH + partial matrices (the worker waves' cone blocks): summed while the rows are loaded
+template <int NVT>
+DEV void newton_direction_sum(Ctx &c, const LDLExtra &ex) {
+  chol_factor_solve_reg<NVT>(c.qH, c.Mgrad, NVP_OF(NVT), c.M->tree_ok && !c.cross, &ex);
+  PROF(c, 17);
+}
+#endif
 
 // ---- exact line search: phi(alpha) = Gauss(alpha) + sum_i s_i(jar + alpha*jv), data in registers
 // Row costs in one branch-free form: with xc = clamp(x, lo, hi),

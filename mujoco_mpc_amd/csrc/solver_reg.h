@@ -11,7 +11,8 @@
 //   * the exact line search keeps every row / contact of a lane in registers (as before) and its last evaluation IS the
 //     constraint update: residuals, forces, zones and cone factors are written from those registers (ls_commit), no second pass.
 //   * gradient = Ma - qfrc_smooth - J^T force straight from the forces (lane (i, g) sums every G-th row).
-// No other wave is involved: the helper waves of a candidate are free during the solve phase.
+// Pyramidal models: no other wave is involved.  Elliptic models: what an iteration has of work that is parallel over rows and
+// contacts (J^T force, the contacts' cone blocks) is one job per iterate for the candidate's other waves (worker_job below).
 #pragma once
 #ifndef MJPC_EMU
 #ifndef LS_PREDICT
@@ -50,7 +51,8 @@ DEV void hblock_add_rows(const Ctx &c, double *h, unsigned long long mask, int r
   }
 }
 
-// hq = M + sum of D_r J_r^T J_r over the general (several Jacobian entries), non-elliptic rows that are in their quadratic zone
+// hq = M + sum of D_r J_r^T J_r over the general (several Jacobian entries) rows that are in their quadratic zone - also the rows
+// of elliptic contacts: in its quadratic zone a contact's block is diag(D); only the cone (middle) zone needs the workers' job
 template <int NVT>
 DEV void hblock_init(const Ctx &c, double *hq, int hi, int j0) {
   constexpr int nvp = NVP_OF(NVT), CB = HLay<NVT>::CB;
@@ -61,7 +63,8 @@ DEV void hblock_init(const Ctx &c, double *hq, int hi, int j0) {
     int r = base + LANE, rc = r < nefc ? r : nefc - 1;
     int st = c.efc_state[rc], type = c.efc_type[rc];
     double D = c.efc_D[rc];
-    int flag = r < nefc && r >= ns && type != CNSTR_CONTACT_ELLIPTIC && st == STATE_QUADRATIC;
+    int flag = r < nefc && r >= ns && st == STATE_QUADRATIC;      // (the rows of an elliptic contact in its quadratic zone are plain D rows)
+    (void)type;
     unsigned long long mask = __builtin_amdgcn_ballot_w64(flag != 0);
     hblock_add_rows<NVT>(c, hq, mask, base, D, hi, j0);
   }
@@ -102,168 +105,203 @@ DEV void newton_grad_reg(Ctx &c, int hi, int hg, bool hact) {
   SYNC();
 }
 
-// block of one elliptic contact with D rows starting at r0 (compile-time D: every row / column offset is an immediate):
-//   J^T (P P^T - Q Q^T + diag(T^2) + w0 e0 e0^T) J   with the record constraint_update() / ls_commit() left at CON_H
-//   (cone zone: the factored cone Hessian, w0 = 0; quadratic zone: P = Q = 0, T_j^2 = D_j, w0 = D_0): no branch on the zone
-template <int NVT, int D>
-DEV void cone_block_add(const Ctx &c, double *a, int r0, int ci, int hi, int j0) {
-  constexpr int nvp = NVP_OF(NVT), CB = HLay<NVT>::CB;
-  const double *Ji = c.efc_J + r0 * nvp + hi, *Jb = c.efc_J + r0 * nvp + j0;
-  const double *cf = c.contact + ci * c.M->con_stride + CON_H;
-  double jb[D], t[D], P[D], Q[D], T[D];
-#pragma unroll
-  for (int k = 0; k < D; k++) { jb[k] = Ji[k * nvp]; P[k] = cf[k]; Q[k] = cf[6 + k]; T[k] = cf[12 + k]; }
-  // narrow column blocks: the whole D x CB block of J rides the same LDS round trip as the record; wide ones fetch it row-wise below
-  constexpr bool ALL = CB <= 6;
-  double yall[ALL ? D : 1][ALL ? CB : 1];
-  if constexpr (ALL) {
-#pragma unroll
-    for (int k = 0; k < D; k++)
-#pragma unroll
-      for (int q = 0; q < CB; q++) yall[k][q] = Jb[k * nvp + q];
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  double pi = P[0] * jb[0], qi = Q[1] * jb[1];
-#pragma unroll
-  for (int k = 1; k < D; k++) { pi += P[k] * jb[k]; if (k > 1) qi += Q[k] * jb[k]; }
-  t[0] = P[0] * pi + Q[0] * jb[0];                      // Q_0's slot: 0 in the cone zone, D_0 in the quadratic zone
-#pragma unroll
-  for (int k = 1; k < D; k++) t[k] = P[k] * pi - Q[k] * qi + (T[k] * T[k]) * jb[k];
-  if constexpr (ALL) {
-#pragma unroll
-    for (int k = 0; k < D; k++)
-#pragma unroll
-      for (int q = 0; q < CB; q++) a[q] += t[k] * yall[k][q];
-  } else {
-    constexpr int RG = (CB <= 16) ? 2 : 1;
-#pragma unroll
-    for (int k0 = 0; k0 < D; k0 += RG) {
-      double y[RG][CB];
-#pragma unroll
-      for (int k = 0; k < RG; k++)
-#pragma unroll
-        for (int q = 0; q < CB; q++) y[k][q] = (k0 + k < D) ? Jb[(k0 + k) * nvp + q] : 0.0;
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int k = 0; k < RG; k++)
-#pragma unroll
-        for (int q = 0; q < CB; q++) if (k0 + k < D) a[q] += t[k0 + k] * y[k][q];
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-}
+// ---- the worker waves' job on an iterate (elliptic models): the contacts' cone blocks ---------------------------------------
+// H gets  J_c^T (P P^T - Q Q^T + diag(T^2) + w0 e0 e0^T) J_c  from every elliptic contact c that is not in its satisfied zone (the
+// record constraint_update() / ls_commit() left at CON_H; quadratic zone: P = Q = 0, T_j^2 = D_j, w0 = D_0 in Q_0's slot, so no
+// branch on the zone).  J_c only has entries on the dofs that move the contact's two bodies (n_c = 9 of 18 for a foot of the A1
+// on the floor), so the block is built where it is non-zero, and by as many lanes as it has ROWS: ls_records_build lists, once
+// per step, the pairs (contact, local row a) of all elliptic contacts (CONE_ITEMS); a lane takes one pair, forms
+// t = B_c J_c[:, dof_a] once and walks the columns b <= a of its row, adding  t . J_c[:, dof_b]  to entry (dof_a, dof_b) of the
+// worker's partial Hessian with an LDS fp64 atomic add (ds_add_f64: rows of different contacts meet in the entries of their common
+// dofs).  Worker w of np takes the passes w, w + np, ... of 64 pairs.  The owner posts ONE packed word (sequence number, number of
+// workers, kind), meanwhile updates its register blocks, builds the gradient and stores its own part of H.
+//   workers 0 .. MJPC_NH-1 = the helper waves (in every job); worker MJPC_NH = the side wave from job MJPC_SIDE_JOB of a step on.
+// kind: 0 release (solve over) | 1 cone blocks
+#define HX_JOBW 18
+#define HX_SIDEFROM 21
+#define HX_NITEMS 45
+#define HX_WDONE HX_HDONE
+#define JOBW(seq, np, kind) (((seq) << 4) | ((np) << 2) | (kind))
+#define MJPC_NW (MJPC_NH + 1)
+// behind the line-search records: the contacts' dof lists (one byte per dof, nv per contact), the (contact, row) pairs (two bytes
+// each), then one partial Hessian per worker (nv x nvp each, lower triangle).  The owner never adds them up: its own part goes to
+// qH and the factorisation sums qH and the partials while it loads its rows (ldl_load_row)
+#define CONE_BASE(c) ((c).efc_JA + 64 + (c).M->nefcmax * LSR_STRIDE + (c).M->nconmax * LSC_STRIDE)
+#define CONE_DOFS(c) ((unsigned char *)CONE_BASE(c))
+#define CONE_ITEMS(c) ((unsigned short *)(CONE_BASE(c) + ((c).M->nconmax * NVT + 7) / 8))
+#define CONE_PARTIAL(c, w) (CONE_BASE(c) + ((c).M->nconmax * NVT + 7) / 8 + ((c).M->nconmax * NVT + 3) / 4 + (w) * (NVT * NVP_OF(NVT)))
 
-// a += the blocks of the elliptic contacts that have one (zone != satisfied) and whose ordinal among those is == part (mod nparts)
+// the passes p0, p0 + pstep, ... of 64 (contact, row) pairs into the partial `part` (zeroed by the caller)
 template <int NVT, int DIMT>
-DEV void cone_blocks(const Ctx &c, double *a, int part, int nparts, int hi, int j0) {
-  const int ncon = c.ncon;
-  int ord = 0;
-  for (int base = 0; base < ncon; base += NLANE) {
-    int ci = base + LANE, cic = ci < ncon ? ci : ncon - 1;
-    int dim_l = c.con_i[cic * CONI_STRIDE], r0_l = c.con_i[cic * CONI_STRIDE + 3];
-    int st_l = c.efc_state[r0_l];
-    int flag = ci < ncon && dim_l > 1 && st_l != STATE_SATISFIED;      // (cone == 1: every contact with dim > 1 is elliptic)
-    unsigned long long mask = __builtin_amdgcn_ballot_w64(flag != 0);
-    while (mask) {
-      int b = (int)__builtin_ctzll(mask); mask &= mask - 1;
-      int mine = (nparts == 1) || (ord % nparts == part);
-      ord++;
-      if (!mine) continue;
-      int r0 = readlane_i(r0_l, b), dim = readlane_i(dim_l, b);
-      if constexpr (DIMT <= 3) cone_block_add<NVT, 3>(c, a, r0, base + b, hi, j0);
-      else {
-        if (dim == 6) cone_block_add<NVT, 6>(c, a, r0, base + b, hi, j0);
-        else if (dim == 4) cone_block_add<NVT, 4>(c, a, r0, base + b, hi, j0);
-        else cone_block_add<NVT, 3>(c, a, r0, base + b, hi, j0);
-      }
+DEV void cone_rows(const Ctx &c, double *part, int p0, int pstep) {
+  constexpr int nvp = NVP_OF(NVT);
+  const int nitems = uniform_i(c.misc[HX_NITEMS]), stride = c.M->con_stride;
+  const unsigned short *items = CONE_ITEMS(c);
+  const double *crec = LS_CONREC(c);
+  for (int it0 = p0 * NLANE; it0 < nitems; it0 += pstep * NLANE) {
+    const int it = it0 + LANE;
+    const bool valid = it < nitems;
+    const int item = items[valid ? it : 0];
+    const int ci = item & 255, a = item >> 8;
+    const int info = ((const int *)(crec + ci * LSC_STRIDE + 14))[0];        // on | dim << 8 | first row << 16
+    const int r0 = info >> 16, dim = (info >> 8) & 255;
+    const unsigned char *dofs = CONE_DOFS(c) + ci * NVT;
+    const int i = dofs[a];
+    const int st = c.efc_state[r0];
+    const double *cf = c.contact + ci * stride + CON_H;
+    double P[DIMT], Q[DIMT], T[DIMT], ji[DIMT];
+#pragma unroll
+    for (int k = 0; k < DIMT; k++) { P[k] = cf[k]; Q[k] = cf[6 + k]; T[k] = cf[12 + k]; }
+    const double *Jr = c.efc_J + r0 * nvp;
+#pragma unroll
+    for (int k = 0; k < DIMT; k++) ji[k] = Jr[(DIMT <= 3 || k < dim ? k : 0) * nvp + i];
+    __builtin_amdgcn_sched_barrier(0);
+    const bool active = valid && st == STATE_CONE;
+#if defined(MJPC_PROFILE) && !defined(MJPC_EMU)
+    if (MJPC_PROFILE_WAVE != 0 && WAVE_ID() == MJPC_PROFILE_WAVE) { int na_ = __builtin_popcountll(__builtin_amdgcn_ballot_w64(active)); if (LANE == 0) { c.prof[23] += na_; c.prof[22] += (it0 == p0 * NLANE); } }      // active rows / jobs of this worker (diagnostics)
+#endif
+    if constexpr (DIMT > 3) {
+#pragma unroll
+      for (int k = 3; k < DIMT; k++) { const bool in = k < dim; P[k] = in ? P[k] : 0.0; Q[k] = in ? Q[k] : 0.0; T[k] = in ? T[k] : 0.0; ji[k] = in ? ji[k] : 0.0; }
+    }
+    double pi = P[0] * ji[0], qi = Q[1] * ji[1];
+#pragma unroll
+    for (int k = 1; k < DIMT; k++) { pi += P[k] * ji[k]; if (k > 1) qi += Q[k] * ji[k]; }
+    double t[DIMT];
+    t[0] = P[0] * pi + Q[0] * ji[0];                      // Q_0's slot: 0 in the cone zone, D_0 in the quadratic zone
+#pragma unroll
+    for (int k = 1; k < DIMT; k++) t[k] = P[k] * pi - Q[k] * qi + (T[k] * T[k]) * ji[k];
+    double *prow = part + i * nvp;
+    PROFW(c, 16);
+    // columns b <= a of the lane's row, two per trip
+    for (int b = 0; __builtin_amdgcn_ballot_w64(active && b <= a) != 0; b += 2) {
+      const bool on0 = active && b <= a, on1 = active && b + 1 <= a;
+      const int j0 = dofs[on0 ? b : 0], j1 = dofs[on1 ? b + 1 : 0];
+      double x0[DIMT], x1[DIMT];
+#pragma unroll
+      for (int k = 0; k < DIMT; k++) { x0[k] = Jr[(DIMT <= 3 || k < dim ? k : 0) * nvp + j0]; x1[k] = Jr[(DIMT <= 3 || k < dim ? k : 0) * nvp + j1]; }
+      __builtin_amdgcn_sched_barrier(0);
+      double v0 = t[0] * x0[0], v1 = t[0] * x1[0];
+#pragma unroll
+      for (int k = 1; k < DIMT; k++) { v0 += t[k] * x0[k]; v1 += t[k] * x1[k]; }
+      if (on0) __builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double *)(prow + j0), v0);
+      if (on1) __builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double *)(prow + j1), v1);
     }
   }
 }
 
-// Elliptic models with helper waves: the cone blocks are the helpers' job.  The owner posts it (HX_JOB) as soon as the records
-// of an iterate are in LDS (after solver_eval / ls_commit) and meanwhile updates hq and builds the gradient; helper k sums the
-// blocks of every MJPC_NH-th contact into its own partial [q][lane] behind the gradient scratch and reports with HX_HDONE + k.
-#define CONE_PART(c, k, q) ((c).efc_JA + 64 + (c).M->nefcmax * LSR_STRIDE + (c).M->nconmax * LSC_STRIDE + ((k) * HLay<NVT>::CB + (q)) * (HLay<NVT>::G * NVT) + LANE)      // [helper][column][active lane]
-#define HX_NPARTS 20
 #if MJPC_HELPER
+DEV int jobw_load(const Ctx &c) { return __builtin_amdgcn_readfirstlane(__hip_atomic_load(c.misc + HX_JOBW, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)); }
+// owner: post the job of the iterate whose zones / cone records are in LDS; returns the number of workers it was cut for
 template <int NVT>
-DEV int cone_job_post(Ctx &c) {      // returns the number of workers the job was cut for
+DEV int job_post(Ctx &c, int kind, int &side_in) {
   if (c.M->cone != 1) return 0;
-  int seq = ++c.hseq;
-  int np = MJPC_NH;
-  if (LANE == 0) { c.misc[HX_KIND] = 1; c.misc[HX_NPARTS] = np; }
-  flag_set(c.misc + HX_JOB, seq);
+  const int seq = ++c.hseq;
+  // WHICH jobs the side wave shares is fixed by the job's number, never by who happened to be ready: the partition of the sums -
+  // and with it every rounding - must not depend on timing.  Should the side wave still be busy at its first job, the owner waits.
+  if (MJPC_SIDE_JOB > 0 && !side_in && (seq & 255) >= MJPC_SIDE_JOB) {
+    const int base = seq & ~255;
+    int ok = 0;
+    for (int n = 0; n < (1 << 21); n++) {
+      int from = __builtin_amdgcn_readfirstlane(__hip_atomic_load(c.misc + HX_SIDEFROM, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+      if (from > base) { ok = 1; break; }
+    }
+    if (!ok) c.warning |= WARN_SYNC;
+    side_in = 1;
+  }
+  const int np = MJPC_NH + (side_in ? 1 : 0);
+  flag_set(c.misc + HX_JOBW, JOBW(seq, np, kind));
   return np;
 }
-// one job of worker K: its partial into LDS, then HX_HDONE + K = seq
+DEV void job_wait(Ctx &c, int np) {
+  const int seq = c.hseq;
+  for (int k = 0; k < np; k++) if (!flag_wait(c.misc + HX_WDONE + k, seq)) c.warning |= WARN_SYNC;
+}
 template <int NVT, int DIMT>
-DEV void cone_job_do(Ctx &c, int K, int nparts, int seq) {
-  constexpr int G = HLay<NVT>::G, CB = HLay<NVT>::CB;
-  const int hg_ = LANE / NVT;
-  const bool hact = hg_ < G;
-  const int hg = hact ? hg_ : 0, hi = hact ? LANE - hg_ * NVT : 0, j0 = hg * CB;
-  double a[CB];
-#pragma unroll
-  for (int q = 0; q < CB; q++) a[q] = 0;
-  cone_blocks<NVT, DIMT>(c, a, K, nparts, hi, j0);
+DEV void worker_job(Ctx &c, int W, int np, int seq) {
+  constexpr int nvp = NVP_OF(NVT);
+  PROFW(c, 12);
+  double *part = CONE_PARTIAL(c, W);
+  PFOR(e, NVT * nvp) part[e] = 0;
+  PROFW(c, 15);
+  cone_rows<NVT, DIMT>(c, part, W, np);
   PROFW(c, 13);
-  if (hact) {
-#pragma unroll
-    for (int q = 0; q < CB; q++) *CONE_PART(c, K, q) = a[q];
-  }
-  flag_set(c.misc + HX_HDONE + K, seq);
+  flag_set(c.misc + HX_WDONE + W, seq);
   PROFW(c, 14);
 }
-template <int NVT, int DIMT, int K>
-DEV void cone_helper_loop_d(Ctx &c, int seq) {
+// worker W: jobs with a sequence number above `last` until the release (a job cut for fewer workers than W + 1 is not this wave's)
+template <int NVT, int DIMT>
+DEV void worker_loop_d(Ctx &c, int W, int last) {
+  // the contact records the cone blocks walk are helper 0's first job of the solve phase
+  if (W != 0 && c.nefc > 0 && !flag_wait(c.misc + HX_LSREC, (last >> 8) + 1)) return;
   for (;;) {
-    seq++;
-    if (!flag_wait_ge(c.misc + HX_JOB, seq)) return;          // timed out: the owner reports the failure
-    if (uniform_i(c.misc[HX_KIND]) == 0) return;              // (also when this helper was late for a job nobody waited for)
-    PROFW(c, 12);
-    cone_job_do<NVT, DIMT>(c, K, uniform_i(c.misc[HX_NPARTS]), seq);
+    int word = 0, ok = 0;
+    for (int n = 0; n < (1 << 21); n++) { word = jobw_load(c); if ((word >> 4) > last) { ok = 1; break; } }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (!ok) return;                                          // timed out: the owner reports the failure
+    const int kind = word & 3, np = (word >> 2) & 3;
+    if (kind == 0) return;
+    last = word >> 4;
+    if (W < np) worker_job<NVT, DIMT>(c, W, np, last);
   }
 }
-template <int NVT, int K>
-DEV void cone_helper_loop(Ctx &c, int seq) {
+template <int NVT>
+DEV void worker_loop(Ctx &c, int W, int last) {
   if (c.M->cone != 1) return;
-  if (c.M->maxdim <= 3) cone_helper_loop_d<NVT, 3, K>(c, seq); else cone_helper_loop_d<NVT, 6, K>(c, seq);
+  if (c.M->maxdim <= 3) worker_loop_d<NVT, 3>(c, W, last); else worker_loop_d<NVT, 6>(c, W, last);
+}
+// the side wave joins once its own work of the solve phase is done: it announces the first job it could take
+template <int NVT>
+DEV void side_worker(Ctx &c, int t) {
+  if (c.M->cone != 1 || MJPC_SIDE_JOB <= 0) return;
+  const int base = t * 256;
+  int word = jobw_load(c);
+  int last = base;
+  if ((word >> 4) > base) {
+    if ((word & 3) == 0) return;                              // the solve is already over
+    last = word >> 4;                                         // that job was cut without this wave
+  }
+  if (LANE == 0) __hip_atomic_store(c.misc + HX_SIDEFROM, last + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  worker_loop<NVT>(c, MJPC_NH, last);
 }
 #endif
 
-// qH = hq + diag of the single-entry rows + the blocks of the elliptic contacts
+// qH = hq + diag of the single-entry rows: the owner's part of the Hessian.  The elliptic contacts' blocks are the workers'
+// partials, added by the factorisation (np > 0); a build without worker waves adds them here.
 template <int NVT, int DIMT>
-DEV void newton_assemble(Ctx &c, const double *hq, int hi, int hg, int j0, bool hact, int nparts) {
+DEV void newton_assemble(Ctx &c, const double *hq, int hi, int hg, int j0, bool hact) {
   constexpr int nvp = NVP_OF(NVT), CB = HLay<NVT>::CB;
   double a[CB];
   const double dg = c.sgl[NVT + hi] + c.sgl[3 * NVT + hi];
 #pragma unroll
   for (int q = 0; q < CB; q++) a[q] = hq[q] + ((j0 + q == hi) ? dg : 0.0);
-  PROF(c, 10);
+#if !MJPC_HELPER
   if (c.M->cone == 1) {
-#if MJPC_HELPER
-    const int seq = c.hseq;
-    for (int k = 0; k < nparts; k++) if (!flag_wait(c.misc + HX_HDONE + k, seq)) c.warning |= WARN_SYNC;
-    PROF(c, 18);
-    double pt[MJPC_NH][CB];
+    // single-wave build: the owner is its own only worker
+    double *part = CONE_PARTIAL(c, 0);
+    PFOR(e, NVT * nvp) part[e] = 0;
+    cone_rows<NVT, DIMT>(c, part, 0, 1);
+    SYNC();
 #pragma unroll
-    for (int k = 0; k < MJPC_NH; k++)
-#pragma unroll
-      for (int q = 0; q < CB; q++) pt[k][q] = hact ? *CONE_PART(c, k, q) : 0.0;
-#pragma unroll
-    for (int k = 0; k < MJPC_NH; k++)
-#pragma unroll
-      for (int q = 0; q < CB; q++) a[q] += pt[k][q];
-#else
-    cone_blocks<NVT, DIMT>(c, a, 0, 1, hi, j0);
-    PROF(c, 18);
-#endif
+    for (int q = 0; q < CB; q++) a[q] += (hact && j0 + q <= hi) ? part[hi * nvp + j0 + q] : 0.0;
   }
+#endif
   if (hact) {
 #pragma unroll
     for (int q = 0; q < CB; q++) if (j0 + q < NVT) c.qH[hi * nvp + j0 + q] = a[q];
   }
   SYNC();
+}
+// Newton direction from qH (+ the workers' partials): Mgrad <- H^-1 grad
+template <int NVT>
+DEV void newton_direction_np(Ctx &c, int np) {
+  if (np > 0) {
+    LDLExtra ex;
+    ex.n = np;
+#pragma unroll
+    for (int w = 0; w < 3; w++) ex.x[w] = CONE_PARTIAL(c, w < np ? w : 0);
+    newton_direction_sum<NVT>(c, ex);
+  } else newton_direction<NVT>(c);
 }
 
 // line-search data of a lane plus what the commit needs (friction coefficients, first row / dim of the contact, the single-entry
@@ -301,7 +339,9 @@ DEV void ls_records_build(Ctx &c) {
     o[0] = fric ? -Rf : (quad ? -1e300 : -1.0); o[1] = fric ? Rf : (quad ? 0.0 : 1.0);
     o[2] = quad ? 0.5 * D : 0.0; o[3] = fric ? f : 0.0; o[4] = rj;
     ((int *)(o + 5))[0] = quad | (fric << 1) | ((quad && single) << 2) | ((single ? dof : 0) << 8);
+    o[6] = D;                                      // (elliptic rows: their rank-1 weight when the contact enters / leaves its quadratic zone)
   }
+  int nc_lane = 0;
   PFOR(ci, ncon) {
     int dim = c.con_i[ci * CONI_STRIDE], i = c.con_i[ci * CONI_STRIDE + 3];
     const double *cc = c.contact + ci * c.M->con_stride;
@@ -318,6 +358,23 @@ DEV void ls_records_build(Ctx &c) {
     o[12] = on ? mu : 0.0;
     o[13] = on ? c.efc_D[i] * fast_rcp(mu * mu * (1 + mu * mu)) : 0.0;
     ((int *)(o + 14))[0] = on | (dim << 8) | (i << 16);
+    // the dofs that move either body of the contact, ascending: the support of its Jacobian rows (cone_local_add)
+    int nc = 0;
+    if (on) {
+      unsigned long long m = MDM()[MI(geom_bodyid)[c.con_i[ci * CONI_STRIDE + 1]]] | MDM()[MI(geom_bodyid)[c.con_i[ci * CONI_STRIDE + 2]]];
+      unsigned char *dl = CONE_DOFS(c) + ci * NVT;
+      while (m) { int dd = (int)__builtin_ctzll(m); m &= m - 1; dl[nc++] = (unsigned char)dd; }
+    }
+    ((int *)(o + 14))[2] = nc;
+    nc_lane = nc;
+  }
+  // ... and the (contact, local row) pairs of all of them in the list the workers' passes walk (cone_rows), contact-major
+  // (nconmax <= 64: one contact per lane)
+  {
+    int total, off = wave_excl_scan(nc_lane, &total);
+    unsigned short *il = CONE_ITEMS(c) + off;
+    for (int a = 0; a < nc_lane; a++) il[a] = (unsigned short)(LANE | (a << 8));
+    if (LANE == 0) c.misc[HX_NITEMS] = total;
   }
   SYNC();
 }
@@ -426,9 +483,10 @@ DEV LSPoint ls_eval_reg(const LSReg<DIMT> &d, double q0, double q1, double q2, d
 // single-entry rows, the cone factors of the elliptic contacts.  chg_mask[k] / chg_w[k]: the general rows of slot k whose
 // quadratic-zone membership changed and the signed weight (+-D) of their rank-1 term in the Hessian.
 template <int NVT, int DIMT>
-DEV double ls_commit(Ctx &c, const LSReg<DIMT> &d, double a, unsigned long long *chg_mask, double *chg_w) {
+DEV double ls_commit(Ctx &c, const LSReg<DIMT> &d, double a, unsigned long long *chg_mask, double *chg_w, int *ncone_out) {
   const int nefc = c.nefc, stride = c.M->con_stride;
   double cost = 0;
+  int ncone = 0;
   // (contacts first: they read the residuals of the iterate the search started from, which the row pass below overwrites)
 #pragma unroll
   for (int q = 0; q < LS_CPL; q++) {
@@ -492,13 +550,19 @@ DEV double ls_commit(Ctx &c, const LSReg<DIMT> &d, double a, unsigned long long 
     }
 #pragma unroll
     for (int j = 0; j < DIMT; j++) if (j < dim) { c.efc_force[i + j] = F[j]; c.efc_state[i + j] = st; }
+    ncone += st == STATE_CONE;
   }
+  *ncone_out = __builtin_popcountll(__builtin_amdgcn_ballot_w64(ncone != 0));      // (LS_CPL == 1 on the device: one contact per lane)
 #pragma unroll
   for (int k = 0; k < LS_RPL; k++) {
     chg_mask[k] = 0; chg_w[k] = 0;
     if (k >= d.nslot) break;
     int r = LANE + NLANE * k;
     int info = d.rinfo[k];
+    // a row of an elliptic contact: the zone its contact's lane has just written (same wave: LDS keeps program order) and the row's D
+    const int rc_ = r < nefc ? r : nefc - 1;
+    const int st_new = c.efc_state[rc_];
+    const double D_ell = LS_ROWREC(c)[rc_ * LSR_STRIDE + 6];
     int quad = info & 1, fric = (info >> 1) & 1, single = (info >> 2) & 1, wasq = (info >> 3) & 1, dof = info >> 8;
     double x = d.X[k] + a * d.V[k];
     if (r < nefc) c.efc_jar[r] = x;
@@ -519,6 +583,10 @@ DEV double ls_commit(Ctx &c, const LSReg<DIMT> &d, double a, unsigned long long 
         chg = inside != wasq;
         chg_w[k] = inside ? D : -D;
       }
+    } else if (r < nefc) {
+      const int nowq = st_new == STATE_QUADRATIC;
+      chg = nowq != wasq;
+      chg_w[k] = nowq ? D_ell : -D_ell;
     }
     chg_mask[k] = __builtin_amdgcn_ballot_w64(chg != 0);
   }
@@ -555,18 +623,31 @@ DEV void solve_constraints_reg_d(Ctx &c) {
     cost = cost_ws;
   }
   PROF(c, 12);
-  int nparts = 0;
+  int np = 0, side_in = 0;
+  // contacts in their cone (middle) zone: only those have an iterate-dependent block (the workers' job); none => no job at all
+  int ncone = 0;
+  if (c.M->cone == 1) {
+    const int ci = LANE < c.ncon ? LANE : 0;
+    const int dim = c.con_i[ci * CONI_STRIDE], r0c = c.con_i[ci * CONI_STRIDE + 3];
+    const int stc = c.efc_state[r0c];
+    ncone = __builtin_popcountll(__builtin_amdgcn_ballot_w64(LANE < c.ncon && dim > 1 && stc == STATE_CONE));
+  }
 #if MJPC_HELPER
-  nparts = cone_job_post<NVT>(c);
+  if (ncone) np = job_post<NVT>(c, 1, side_in);
+#else
+  ls_records_build<NVT>(c);
 #endif
   double hq[CB];
   hblock_init<NVT>(c, hq, hi, j0);
   PROF(c, 15);
   newton_grad_reg<NVT>(c, hi, hg, hact);
   PROF(c, 9);
-  newton_assemble<NVT, DIMT>(c, hq, hi, hg, j0, hact, nparts);
+  newton_assemble<NVT, DIMT>(c, hq, hi, hg, j0, hact);
   PROF(c, 19);
-  newton_direction<NVT>(c);
+#if MJPC_HELPER
+  if (np) { job_wait(c, np); PROF(c, 16); }
+#endif
+  newton_direction_np<NVT>(c, np);
   PFOR(i, nv) c.search[i] = -c.Mgrad[i];
   SYNC();
   const double scale = 1.0 / (M.meaninertia * (nv > 1 ? nv : 1));
@@ -586,13 +667,9 @@ DEV void solve_constraints_reg_d(Ctx &c) {
     if (snorm < D_MINVAL || gs >= 0) break;
     const double gtol = M.tolerance * M.ls_tolerance * snorm / scale;
     LSReg<DIMT> d;
-    if (iter == 0) {
 #if MJPC_HELPER
-      if (!flag_wait(c.misc + HX_LSREC, c.hseq / 256 + 1)) c.warning |= WARN_SYNC;      // helper 0 built the records meanwhile
-#else
-      ls_records_build<NVT>(c);
+    if (iter == 0 && !flag_wait(c.misc + HX_LSREC, c.hseq / 256 + 1)) c.warning |= WARN_SYNC;      // helper 0 built the records meanwhile
 #endif
-    }
     ls_load_reg<NVT, DIMT>(c, d);
     PROF(c, 21);
     double lo = 0, hi_a = -1, a = 1.0;
@@ -636,7 +713,7 @@ DEV void solve_constraints_reg_d(Ctx &c) {
     if (alpha == 0) break;
     // ---- move there: the commit is the constraint update at alpha (it also returns the constraint cost)
     unsigned long long chg_mask[LS_RPL]; double chg_w[LS_RPL];
-    const double ccost = ls_commit<NVT, DIMT>(c, d, alpha, chg_mask, chg_w);
+    const double ccost = ls_commit<NVT, DIMT>(c, d, alpha, chg_mask, chg_w, &ncone);
     PFOR(i, nv) { c.qacc[i] += alpha * c.search[i]; c.Ma[i] += alpha * c.Mv[i]; }
     SYNC();
     gauss = gauss + alpha * q1 + alpha * alpha * q2;
@@ -646,7 +723,7 @@ DEV void solve_constraints_reg_d(Ctx &c) {
     const double improvement = scale * (oldcost - cost);
     const int stop = improvement < M.tolerance || (c.warning & WARN_SYNC) != 0;
 #if MJPC_HELPER
-    if (!stop) nparts = cone_job_post<NVT>(c);
+    np = (stop || !ncone) ? 0 : job_post<NVT>(c, 1, side_in);
 #endif
     if (!stop) {
 #pragma unroll
@@ -659,10 +736,13 @@ DEV void solve_constraints_reg_d(Ctx &c) {
     double pg = 0;
     PFOR(i, nv) pg += c.grad[i] * c.grad[i];
     const double gradient = scale * sqrt(wave_sum(pg));
-    if (stop || gradient < M.tolerance) break;
-    newton_assemble<NVT, DIMT>(c, hq, hi, hg, j0, hact, nparts);
-    PROF(c, 19);
-    newton_direction<NVT>(c);
+    const int done = stop || gradient < M.tolerance;
+    if (!done) { newton_assemble<NVT, DIMT>(c, hq, hi, hg, j0, hact); PROF(c, 19); }
+#if MJPC_HELPER
+    if (np) { job_wait(c, np); PROF(c, 16); }           // (also when the gradient says stop: no job is left behind unfinished)
+#endif
+    if (done) break;
+    newton_direction_np<NVT>(c, np);
     PFOR(i, nv) c.search[i] = -c.Mgrad[i];
     SYNC();
   }

@@ -460,16 +460,25 @@ def _full_size(fn, N, H, P, sigma, interp, tol, shards=4, hold_ctrl=False):
     ref = o.plan(d["state"], mocap, 0.0, kt, kv, interp, N, H, sigma=(sigma, 0.0), seed=0x5EED, stream=0, nthreads=NCPU)
     assert ref["unsupported"] == 0
     assert np.array_equal(out["failure"], ref["failure"])
-    # Tolerance (north_star): 1e-5 relative on returns and cost traces.  Contact dynamics are chaotic: over thousands of
-    # candidates x 100 steps a last-bit difference (FMA contraction, reduction order) occasionally flips a discrete decision
-    # (a contact entering the margin, a solver stopping test) and that one trajectory departs.  Measured at C4 (4096 x 100):
-    # 99.9 % of the candidates agree to 1e-8, ONE of 4096 differs by 1.7e-5.  The bar therefore is: every candidate within
-    # 1e-3, at most one candidate per thousand beyond 1e-5, and the argmin index exact.
+    # Tolerance (north_star): 1e-5 relative on returns and cost traces, argmin index exact.
     rerr = np.abs(out["returns"] - ref["returns"]) / np.abs(ref["returns"])
     cerr = np.abs(allc["costs"][ok] - ref["costs"][ok]).max(axis=1) / np.abs(ref["costs"][ok]).max(axis=1)
-    allowed = max(1, N // 1000) if N >= 1000 else 0
-    assert rerr.max() < 1e-3 and int((rerr > tol).sum()) <= allowed, (rerr.max(), int((rerr > tol).sum()))
-    assert int((cerr > tol).sum()) <= allowed, int((cerr > tol).sum())
+    # Contact dynamics amplify last-bit differences: a discrete decision that flips (a contact made one step earlier) moves a
+    # whole rollout at the 1e-5 level.  How often that happens is a property of the batch and is MEASURED, not assumed: the
+    # oracle runs the same batch once more from a state whose qpos is moved by ONE ulp.  Candidates beyond the bar are allowed
+    # only in proportion to the candidates on which the oracle fails to reproduce ITSELF (measured at C4 size: the oracle
+    # differs from itself by up to 1.8e-5 on 1 of 4096, the kernel from the oracle by up to 4.3e-5 on 2 of 4096, with the
+    # same medians and 99th percentiles, tools/diag_c4_hill.py); with a reproducible oracle the allowance is zero.
+    allowed = 0
+    if N >= 1000:
+        st1 = d["state"].copy(); st1[:m["nq"]] = np.nextafter(st1[:m["nq"]], np.inf)
+        ref1 = o.plan(st1, mocap, 0.0, kt, kv, interp, N, H, sigma=(sigma, 0.0), seed=0x5EED, stream=0, nthreads=NCPU)
+        self_err = np.abs(ref1["returns"] - ref["returns"]) / np.abs(ref["returns"])
+        n_self = int((self_err > tol / 10).sum())
+        allowed = min(N // 1000, 2 * n_self + 1) if n_self else 0
+        assert np.percentile(rerr, 99) <= 10 * np.percentile(self_err, 99) + 1e-12, (np.percentile(rerr, 99), np.percentile(self_err, 99))
+    assert rerr.max() < 1e-3 and int((rerr > tol).sum()) <= allowed, (rerr.max(), int((rerr > tol).sum()), allowed)
+    assert int((cerr > tol).sum()) <= allowed, (int((cerr > tol).sum()), allowed)
     assert np.percentile(rerr, 99) < 1e-7                                                               # the bulk sits far below the bar
     assert np.abs(allc["knots"] - ref["knots"]).max() < 1e-14        # Box-Muller log/cos: device libm vs glibc, last ulp
     assert out["winner"] == ref["winner"]                                                               # argmin index: exact
@@ -1149,10 +1158,11 @@ def test_quadruped_hill_parity_and_closed_loop_with_its_transition():
     p.Reset(26)
     goal0 = d["mocap"][:3].copy()
     dist0 = np.linalg.norm(d["state"][:2] - goal0[:2])
-    res = cplanner.testspeed(p, d["state"], d["mocap"], horizon=26, steps_per_planning_iteration=1, total_time=1.5)
+    res = cplanner.testspeed(p, d["state"], d["mocap"], horizon=26, steps_per_planning_iteration=1, total_time=4.0)
     assert not res["failure"] and res["state"][2] > 0.15                              # still on its feet
-    moved_on = not np.allclose(res["mocap"][:3], goal0)
-    assert moved_on or np.linalg.norm(res["state"][:2] - goal0[:2]) < dist0 + 0.05     # (a 0.25 s horizon is myopic: no progress is asserted, only no retreat)
+    # progress: within 4 s the robot has reached the first stage goal (0.63 m away) and the Transition has moved the mocap body on
+    # to the next one (measured: reached inside 4 s with horizons 26 and 51, 128 and 256 samples; 1.5 s is too short for any of them)
+    assert not np.allclose(res["mocap"][:3], goal0), (dist0, np.linalg.norm(res["state"][:2] - goal0[:2]))
     # a trunk placed on the stage-0 goal pose: the first Transition advances the goal to stage 1
     st = d["state"].copy(); st[:3] = d["mocap"][:3]; st[3:7] = d["mocap"][3:7]
     res = cplanner.testspeed(p, st, d["mocap"], horizon=26, steps_per_planning_iteration=1, total_time=3 * m["timestep"])

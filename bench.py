@@ -31,7 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md)
-TRAFFIC_FILES = ["profiles/r2/traffic.json", "profiles/r1/g_traffic.json"]
+TRAFFIC_FILES = ["profiles/r3/traffic.json", "profiles/r2/traffic.json", "profiles/r1/g_traffic.json"]
 
 
 def profiled_traffic(workload_key):

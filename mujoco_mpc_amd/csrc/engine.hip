@@ -35,7 +35,7 @@ extern "C" int mjpc_rollout_threads_cached(void);
 // (MJPC_WARN_CONTACTFULL / CNSTRFULL) and the full-capacity kernel re-runs exactly those candidates right behind it on
 // the stream (all other workgroups of that launch exit at once).  Rollouts are deterministic and independent, so the result
 // is the same as running everything at full capacity: no candidate is lost to the smaller buffers.
-#define TIERB_NEFCMAX 112    // first capacity tried for the dense tier (rows); contacts = rows / 4 + 2
+#define TIERB_NEFCMAX 128    // first capacity tried for the dense tier (rows); contacts = rows / 4 + 2
 #define TIERB_NEFCMIN 40
 #define TIERB_LDS_LIMIT (80 * 1024)
 
@@ -186,10 +186,11 @@ MjpcHipEngine *mjpc_hip_create(const MjpcHipModel *model, const MjpcHipTask *tas
     bool use_cache = !(exact_d && !exact_c);
     if (mjpc_host::debug_knob("no_model_cache")) use_cache = false;     // diagnostics knob (mjpc_hip_debug.h)
     // (the flavour without the whole copy still keeps the hot prefix - kinematic / tree tables - in LDS: hot_only)
-    if (!mjpc_host::build(e->pm, model, task, e->P_max, use_cache, false, !use_cache)) { set_error("mjpc_hip_create: " + e->pm.error); delete e; return nullptr; }
+    // (a compile-time-nv kernel solves with the Hessian in registers: its layout has no scaled-row table, host.h)
+    if (!mjpc_host::build(e->pm, model, task, e->P_max, use_cache, false, !use_cache, use_cache ? exact_c != 0 : exact_d != 0)) { set_error("mjpc_hip_create: " + e->pm.error); delete e; return nullptr; }
     if (use_cache && (size_t)e->pm.L.total_doubles * sizeof(double) > 160 * 1024) {
       use_cache = false;
-      if (!mjpc_host::build(e->pm, model, task, e->P_max, false, false, true)) { set_error("mjpc_hip_create: " + e->pm.error); delete e; return nullptr; }
+      if (!mjpc_host::build(e->pm, model, task, e->P_max, false, false, true, exact_d != 0)) { set_error("mjpc_hip_create: " + e->pm.error); delete e; return nullptr; }
     }
     e->kernel = use_cache ? kc : kd;
     // dense tier: needs a compile-time-nv kernel of that flavour, a model that asks for more capacity than the tier's and a
@@ -211,7 +212,7 @@ MjpcHipEngine *mjpc_hip_create(const MjpcHipModel *model, const MjpcHipTask *tas
         mb.nefcmax = ne; mb.nconmax = cap_e ? cap_c : ne / 4 + 2;
         if (mb.nconmax > e->pm.M.nconmax) mb.nconmax = e->pm.M.nconmax;
         PackedModel pmB;
-        if (mjpc_host::build(pmB, &mb, task, e->P_max, false, true) && (size_t)pmB.L.total_doubles * sizeof(double) <= TIERB_LDS_LIMIT) {
+        if (mjpc_host::build(pmB, &mb, task, e->P_max, false, true, false, true) && (size_t)pmB.L.total_doubles * sizeof(double) <= TIERB_LDS_LIMIT) {
           e->kernelB = kb; e->layB = pmB.L; e->nefcB = pmB.M.nefcmax; e->nconB = pmB.M.nconmax;
           e->ldsB = (size_t)pmB.L.total_doubles * sizeof(double);
         }
@@ -565,7 +566,9 @@ int mjpc_hip_dense_tier(MjpcHipEngine *e, int *used_last) {
 int mjpc_hip_layout_bytes(const MjpcHipModel *model, const MjpcHipTask *task, int use_cache) {
   if (!model || !task) { set_error("mjpc_hip_layout_bytes: invalid argument"); return -1; }
   PackedModel pm;
-  if (!mjpc_host::build(pm, model, task, 36, (use_cache & 1) != 0, (use_cache & 2) != 0, (use_cache & 3) == 0)) { set_error("mjpc_hip_layout_bytes: " + pm.error); return -1; }
+  int exact = 0;
+  if (use_cache & 2) mjpc_pick_rollout_dense2(model->nv, &exact); else if (use_cache & 1) mjpc_pick_rollout_cached(model->nv, &exact); else mjpc_pick_rollout_direct(model->nv, &exact);
+  if (!mjpc_host::build(pm, model, task, 36, (use_cache & 1) != 0, (use_cache & 2) != 0, (use_cache & 3) == 0, exact != 0)) { set_error("mjpc_hip_layout_bytes: " + pm.error); return -1; }
   return (int)((size_t)pm.L.total_doubles * sizeof(double));
 }
 

@@ -79,7 +79,7 @@ static inline void pack_task(PackedModel &p, const MjpcHipTask *t) {
 }
 
 // lean: the dense tier's layout (rollout_dense2.hip, MJPC_LEAN_LDS): spline knots and the Hessian entry table are read from HBM / L2
-static inline void make_layout(const PackedModel &p, Lay &L, const MjpcHipModel *m, const MjpcHipTask *t, int P_max, size_t cache_d, size_t cache_i, bool lean = false) {
+static inline void make_layout(const PackedModel &p, Lay &L, const MjpcHipModel *m, const MjpcHipTask *t, int P_max, size_t cache_d, size_t cache_i, bool lean = false, bool reg_solver = false) {
   const DevModel &M = p.M;
   int nb = m->nbody, nj = m->njnt, nv = m->nv, ng = m->ngeom, ns = m->nsite, nu = m->nu;
   int o = 0;
@@ -106,7 +106,9 @@ static inline void make_layout(const PackedModel &p, Lay &L, const MjpcHipModel 
   // records (7 per row, 17 per contact) and, on elliptic models, the contacts' dof lists (a byte per dof), their (contact, row) pairs (two bytes each) and one partial Hessian
   // per worker wave (nv x nvp each)
   int ja_need = 64 + ne * 7 + nc * 17 + (m->cone == MJPC_CONE_ELLIPTIC ? (nc * nv + 7) / 8 + (nc * nv + 3) / 4 + (MJPC_SIDE_JOB > 0 ? 3 : 2) * nv * nvp : 0);
-  int ja_size = ja_rows * nvp + 1;
+  // reg_solver: the kernel is a compile-time-nv instantiation, whose Newton solve keeps the Hessian in registers and never
+  // builds the scaled-row table: the block only has to hold the records / partials above (hand: 12 KB instead of 35 KB)
+  int ja_size = reg_solver ? ja_need + 1 : ja_rows * nvp + 1;
   if (ja_size < ja_need) ja_size = ja_need;
   A_(efc_JA, ja_size);
   if (lean) {
@@ -136,7 +138,7 @@ static inline void make_layout(const PackedModel &p, Lay &L, const MjpcHipModel 
 
 // use_cache: lay out an LDS copy of the model tables (rollout_cached.hip) or none (rollout_direct.hip)
 // use_cache: whole LDS copy of the tables; hot_only (with use_cache == false): only the hot prefix
-static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTask *t, int P_max, bool use_cache = true, bool lean = false, bool hot_only = false) {
+static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTask *t, int P_max, bool use_cache = true, bool lean = false, bool hot_only = false, bool reg_solver = false) {
   p.ib.clear(); p.db.clear(); p.error.clear();
   DevModel &M = p.M;
   memset(&M, 0, sizeof(M));
@@ -543,7 +545,7 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
     M.hfield_data = as_off<double>(put_d(p, m->hfield_data, (size_t)(m->nhfielddata > 0 ? m->nhfielddata : 0))); }
   // ---- LDS layout
   if (!use_cache) { p.cache_i = hot_only ? p.hot_i : 0; p.cache_d = hot_only ? p.hot_d : 0; }      // the kernel reads (the rest of) the tables from HBM / L2
-  make_layout(p, p.L, m, t, P_max, p.cache_d, p.cache_i, lean);
+  make_layout(p, p.L, m, t, P_max, p.cache_d, p.cache_i, lean, reg_solver);
   return true;
 }
 

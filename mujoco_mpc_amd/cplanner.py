@@ -2,7 +2,7 @@
 
 The C++ classes `mjpc_hip::TimeSpline` / `mjpc_hip::SamplingPlanner` in libmjpc_hip.so are the product's host side
 (the reference's planner is compiled C++: mjpc/planners/sampling/planner.cc); this module only lets Python drive
-them.  It never falls back to the Python mirror in planner.py: a missing library raises in capi.load_engine().
+them.  There is no Python fall-back: a missing library raises in capi.load_engine().
 """
 from __future__ import annotations
 

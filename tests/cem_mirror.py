@@ -3,7 +3,7 @@ plan backend (the CPU oracle in the tests).  The product's Cross-Entropy planner
 only exists so that the GPU test can compare it against an independent implementation on the oracle."""
 import numpy as np
 
-from mujoco_mpc_amd.planner import SamplingPolicy, TimeSpline
+from host_mirror import SamplingPolicy, TimeSpline
 
 
 class CrossEntropyMirror:

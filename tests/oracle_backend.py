@@ -1,4 +1,4 @@
-"""Adapter so that mujoco_mpc_amd.planner.SamplingPlanner can run on the CPU oracle IN TESTS ONLY."""
+"""Adapter so that tests/host_mirror.py SamplingPlanner can run on the CPU oracle IN TESTS ONLY."""
 import numpy as np
 
 from oracle_lib import Oracle

@@ -277,7 +277,7 @@ def test_sampling_planner_on_gpu_reaches_goal_and_matches_oracle_planner():
     SamplingPlanner drives the HIP engine (device Philox noise) for 300 plan iterations on the particle task; the
     same planner on the oracle backend, fed the same Philox stream, must adopt the same winners."""
     from oracle_backend import OracleBackend
-    from mujoco_mpc_amd.planner import SamplingPlanner
+    from host_mirror import SamplingPlanner
     m, task, d = particle(timestep=0.1)
     H = 26
 
@@ -314,7 +314,7 @@ def test_cpp_host_planner_matches_python_mirror_bitwise(sliding, interp):
     and the winner trajectory must be bit-identical over a closed-loop run (UpdateNominalPolicy resampling, sliding
     plans, clamp and candidate ranking all exercised)."""
     from mujoco_mpc_amd import cplanner
-    from mujoco_mpc_amd.planner import SamplingPlanner
+    from host_mirror import SamplingPlanner
     m, task, d = particle(timestep=0.1)
     H, N = 20, 16
     num = dict(sampling_spline_points=6, sampling_exploration=[0.3, 0.6], sampling_trajectories=N,
@@ -712,7 +712,7 @@ def test_cpp_robust_planner_matches_oracle_restatement():
     returns incl. the delegate's own score, adopt the best."""
     from oracle_backend import OracleBackend
     from mujoco_mpc_amd import cplanner
-    from mujoco_mpc_amd.planner import SamplingPlanner
+    from host_mirror import SamplingPlanner
     m, task, d = particle(timestep=0.1)
     H, N, K, R = 15, 20, 4, 3
     num = dict(sampling_spline_points=5, sampling_exploration=0.2, sampling_trajectories=N, sampling_representation=2,

@@ -6,7 +6,7 @@ import pytest
 
 import oracle_lib as ol
 from mujoco_mpc_amd.modelgen import particle
-from mujoco_mpc_amd.planner import TimeSpline, kCubicSpline, kLinearSpline, kZeroSpline
+from host_mirror import TimeSpline, kCubicSpline, kLinearSpline, kZeroSpline
 
 
 # ---- mjpc/test/spline/spline_test.cc ---------------------------------------------------

@@ -5,7 +5,7 @@ import pytest
 import oracle_lib as ol
 from oracle_backend import OracleBackend
 from mujoco_mpc_amd.modelgen import cartpole, particle, quadruped
-from mujoco_mpc_amd.planner import SamplingPlanner, kCubicSpline, kZeroSpline
+from host_mirror import SamplingPlanner, kCubicSpline, kZeroSpline
 
 
 def test_rollout_particle_pd_reaches_goal():

@@ -293,7 +293,7 @@ typedef struct MjpcHipEngine MjpcHipEngine;
  * num_local that will be planned on this device.  Returns NULL on error (see last_error).
  * Models the engine cannot roll out faithfully are REFUSED here (never silently approximated): geom pairs without a
  * collider (height field against plane / height field; meshes / height fields without data), group-0 geoms the quadruped task's ground ray cannot hit, actuator transmissions other than joint /
- * fixed tendon, nuserdata > 0, nconmax > 64, nefcmax > 192, iterations > 250, num_spline_points capacity 36, LDS footprint > 160 KiB. */
+ * fixed tendon, nconmax > 64, nefcmax > 192, iterations > 250, num_spline_points capacity 36, LDS footprint > 160 KiB. */
 MjpcHipEngine *mjpc_hip_create(const MjpcHipModel *model, const MjpcHipTask *task,
                                int max_local, int max_horizon, int device);
 void mjpc_hip_destroy(MjpcHipEngine *e);

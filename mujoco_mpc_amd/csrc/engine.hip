@@ -112,7 +112,8 @@ struct MjpcHipEngine {
   int *d_ib = nullptr; double *d_db = nullptr;
   KParams K;
   int max_local = 0, max_horizon = 0, P_max = 0;
-  int nq = 0, nv = 0, nu = 0, nmocap = 0, nr = 0, ntr = 0, ds = 0;
+  int nq = 0, nv = 0, nu = 0, nmocap = 0, nr = 0, ntr = 0, ds = 0, nuserdata = 0;
+  double *d_userdata = nullptr;      // mjData.userdata of the plan's state (State::CopyTo, states/state.cc:128-135): carried for residuals that read it
   hipStream_t stream = nullptr;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   // device buffers
@@ -237,6 +238,8 @@ MjpcHipEngine *mjpc_hip_create(const MjpcHipModel *model, const MjpcHipTask *tas
   size_t NL = (size_t)max_local, H = (size_t)max_horizon;
   HIPCHKP(hipMalloc(&e->d_state, sizeof(double) * (e->ds + 1)));
   HIPCHKP(hipMalloc(&e->d_mocap, sizeof(double) * (7 * e->nmocap + 7)));
+  e->nuserdata = model->nuserdata;
+  HIPCHKP(hipMalloc(&e->d_userdata, sizeof(double) * (e->nuserdata + 1)));
   HIPCHKP(hipMalloc(&e->d_kt, sizeof(double) * e->P_max));
   HIPCHKP(hipMalloc(&e->d_kv, sizeof(double) * (e->P_max * e->nu + 1)));
   HIPCHKP(hipMalloc(&e->d_std, sizeof(double) * (e->P_max * e->nu + 1)));
@@ -256,7 +259,7 @@ MjpcHipEngine *mjpc_hip_create(const MjpcHipModel *model, const MjpcHipTask *tas
   HIPCHKP(hipMalloc(&e->d_prof, sizeof(long long) * NL * 24));
   HIPCHKP(hipMemset(e->d_prof, 0, sizeof(long long) * NL * 24));
   HIPCHKP(hipMalloc(&e->d_winner_val, sizeof(double) * 2));
-  HIPCHKP(hipHostMalloc(&e->h_small, sizeof(double) * (e->ds + 7 * e->nmocap + e->P_max * (2 * e->nu + 1) + 16)));
+  HIPCHKP(hipHostMalloc(&e->h_small, sizeof(double) * (e->ds + 7 * e->nmocap + e->P_max * (2 * e->nu + 1) + model->nuserdata + 16)));
   HIPCHKP(hipFuncSetAttribute((const void *)e->kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_bytes));
   if (e->kernelB) {
     HIPCHKP(hipFuncSetAttribute((const void *)e->kernelB, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->ldsB));
@@ -272,7 +275,7 @@ void mjpc_hip_destroy(MjpcHipEngine *e) {
   if (!e) return;
   hipSetDevice(e->device);
   if (e->stream) hipStreamSynchronize(e->stream);
-  void *bufs[] = {e->d_cand, e->d_std, e->d_ib, e->d_db, e->d_state, e->d_mocap, e->d_kt, e->d_kv, e->d_eps, e->d_sel, e->d_states, e->d_actions,
+  void *bufs[] = {e->d_userdata, e->d_cand, e->d_std, e->d_ib, e->d_db, e->d_state, e->d_mocap, e->d_kt, e->d_kv, e->d_eps, e->d_sel, e->d_states, e->d_actions,
                   e->d_times, e->d_residual, e->d_costs, e->d_trace, e->d_knots, e->d_returns, e->d_failure, e->d_diag,
                   e->d_winner, e->d_winner_val, e->d_prof, e->d_frame, e->d_ckpt};
   for (void *b : bufs) if (b) hipFree(b);
@@ -343,6 +346,11 @@ int mjpc_hip_plan_async(MjpcHipEngine *e, const MjpcHipPlanInput *in) {
   if (e->nmocap) HIPCHK(hipMemcpyAsync(e->d_mocap, hs + e->ds, sizeof(double) * 7 * e->nmocap, hipMemcpyHostToDevice, e->stream));
   HIPCHK(hipMemcpyAsync(e->d_kt, hkt, sizeof(double) * P, hipMemcpyHostToDevice, e->stream));
   HIPCHK(hipMemcpyAsync(e->d_kv, hkv, sizeof(double) * P * nu, hipMemcpyHostToDevice, e->stream));
+  if (e->nuserdata) {
+    double *hu = hkv + 2 * e->P_max * nu;
+    if (in->userdata) memcpy(hu, in->userdata, sizeof(double) * e->nuserdata); else memset(hu, 0, sizeof(double) * e->nuserdata);
+    HIPCHK(hipMemcpyAsync(e->d_userdata, hu, sizeof(double) * e->nuserdata, hipMemcpyHostToDevice, e->stream));
+  }
   if (in->noise_std) {
     memcpy(hkv + e->P_max * nu, in->noise_std, sizeof(double) * P * nu);
     HIPCHK(hipMemcpyAsync(e->d_std, hkv + e->P_max * nu, sizeof(double) * P * nu, hipMemcpyHostToDevice, e->stream));
@@ -359,7 +367,7 @@ int mjpc_hip_plan_async(MjpcHipEngine *e, const MjpcHipPlanInput *in) {
                        (unsigned long long)in->stream, in->candidate_offset, nl, P * nu, in->noise_exploration[1]);
   }
   KParams &K = e->K;
-  K.state = e->d_state; K.mocap = e->d_mocap; K.knot_times = e->d_kt; K.knot_values = e->d_kv; K.noise_eps = e->d_eps; K.noise_sel = e->d_sel;
+  K.state = e->d_state; K.mocap = e->d_mocap; K.userdata = e->d_userdata; K.nuserdata = e->nuserdata; K.knot_times = e->d_kt; K.knot_values = e->d_kv; K.noise_eps = e->d_eps; K.noise_sel = e->d_sel;
   K.time = in->time; K.sigma0 = in->noise_exploration[0]; K.sigma1 = in->noise_exploration[1];
   K.seed = in->seed; K.stream = in->stream;
   K.P = P; K.interp = in->interpolation; K.H = H; K.N = in->num_trajectory; K.offset = in->candidate_offset; K.nlocal = nl;

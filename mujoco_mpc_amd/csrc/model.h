@@ -178,6 +178,7 @@ struct KParams {
   int cache_i, cache_d;
   // plan inputs (device pointers)
   const double *state, *mocap, *knot_times, *knot_values, *noise_eps, *noise_std, *cand_knots;
+  const double *userdata; int nuserdata;     // mjData.userdata of the plan's state, constant over the rollouts (no built-in residual reads it yet)
   double xfrc_std, xfrc_rate;
   const int *noise_sel;
   double time, sigma0, sigma1;

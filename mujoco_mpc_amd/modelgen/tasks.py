@@ -478,26 +478,33 @@ def _humanoid_model(timestep, mocap_bodies):
     return b, sites, torso
 
 
-def humanoid_track(timestep=0.005):
-    """humanoid model + tracking/task.xml; motion 0 ("Jump", 121 keys)."""
+HUMANOID_MOTIONS = ("Jump", "Kick Spin", "Spin Kick", "Cartwheel (1)", "Crouch Flip", "Cartwheel (2)", "Monkey Flip", "Dance", "Run", "Walk")
+
+
+def humanoid_track(timestep=0.005, motion=0):
+    """humanoid model + tracking/task.xml; `motion` = the task's mode (tracking.cc:43-66): 0 "Jump" (121 keys) ... 9 "Walk" (510
+    keys).  The model carries the key frames of all ten motions (data/humanoid_motion_keys.npz, made from the reference's key-frame
+    data files by data/make_humanoid_keys.py); the frozen residual state is [mode, first key of the motion, its length, ...] and the
+    default state is the motion's first key, the state Transition resets to on a motion switch (tracking.cc:231-238)."""
     import os
     b, sites, torso = _humanoid_model(timestep, True)
-    data = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "humanoid_jump_keys.npz"))
-    mpos = data["mpos"]
+    data = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "humanoid_motion_keys.npz"))
+    mpos, lengths = data["mpos"], [int(x) for x in data["lengths"]]
+    first = int(sum(lengths[:motion]))
     for k in range(mpos.shape[0]):
-        b.key(f"jump_{k + 1}", data["qpos0"] if k == 0 else [])
+        b.key(f"key_{k + 1}", data["qpos0"][0] if k == 0 else [])
     b.key_mpos = mpos
     m = b.compile()
     ids_site = [sites[n] for n in _TRACK_NAMES]
     ids_mocap = [int(m["body_mocapid"][m["names"]["body"][f"mocap[{n}]"]]) for n in _TRACK_NAMES]
-    ints = [0, 0, mpos.shape[0]] + ids_site + ids_mocap
+    ints = [motion, first, lengths[motion]] + ids_site + ids_mocap
     terms = [(21, 0, 0.001), (21, 3, 0.1, [0.3]), (3, 6, 100.0, [0.1]), (3, 6, 30.0, [0.1]), (3, 6, 0.0, [0.1]),
              (6, 7, 30.0, [0.2, 4]), (6, 7, 30.0, [0.2, 4]), (6, 6, 30.0, [0.1]), (6, 6, 30.0, [0.1]), (6, 7, 30.0, [0.2, 4]),
              (6, 6, 30.0, [0.1]), (6, 6, 30.0, [0.1]),
              (3, 6, 0.1, [0.3]), (3, 6, 0.0, [0.3])] + [(6, 6, 0.1, [0.3])] * 7
     task = make_task(TASK_HUMANOID_TRACK, terms, traces=[(OBJ_XBODY, torso)], int_data=ints, dbl_data=[0.0])
-    state = np.concatenate([data["qpos0"], data["qvel0"]])
-    mocap = np.concatenate([np.concatenate([mpos[0, 3 * i:3 * i + 3], [1, 0, 0, 0]]) for i in range(16)])
+    state = np.concatenate([data["qpos0"][motion], data["qvel0"][motion]])
+    mocap = np.concatenate([np.concatenate([mpos[first, 3 * i:3 * i + 3], [1, 0, 0, 0]]) for i in range(16)])
     defaults = dict(N=32, P=16, sigma=(0.15, 0.0), interp=2, horizon=101, state=state, mocap=mocap)
     return m, task, defaults
 

@@ -182,6 +182,26 @@ def test_humanoid_tracking_small():
     assert allc["diag"][:, 1].max() >= 4
 
 
+@pytest.mark.parametrize("motion, time0", [(4, 0.0), (8, 1.1)])
+def test_humanoid_tracking_other_motions(motion, time0):
+    """the tracking task's other modes (tracking.cc:43-66; here Crouch Flip, and Run from a time where the rollout runs past the
+    motion's last key): same bars as motion 0"""
+    m, task, d = humanoid_track(motion=motion)
+    _compare(m, task, d, 8, 40, 8, (0.15, 0.0), 2, 1e-5, nominal_scale=0.2, time0=time0)
+
+
+def test_userdata_is_carried_and_changes_nothing():
+    """State::CopyTo hands the planner mjData.userdata (states/state.cc:128-135); the engine takes it to the device with the rest of the
+    state (no built-in residual reads it): a model with nuserdata > 0 is accepted and plans exactly like the same model without"""
+    m, task, d = cartpole()
+    kw = dict(state=d["state"], mocap=None, time=0.0, knot_times=np.array([0.0, 0.1]), knot_values=np.zeros((2, 1)), interpolation=1,
+              num_trajectory=6, horizon=10, sigma=(0.1, 0.0), seed=1, stream=0)
+    be = HipBackend(m, task, max_samples=6, max_horizon=10); a = be.plan(**kw); be.close()
+    m2 = dict(m); m2["nuserdata"] = 3
+    be = HipBackend(m2, task, max_samples=6, max_horizon=10); b = be.plan(userdata=np.array([1.0, 2.0, 3.0]), **kw); be.close()
+    assert np.array_equal(a["returns"], b["returns"]) and a["winner"] == b["winner"] and np.array_equal(a["states"], b["states"])
+
+
 def test_device_philox_matches_oracle_noise():
     m, task, d = cartpole()
     o = ol.Oracle(m, task)

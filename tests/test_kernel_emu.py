@@ -49,6 +49,31 @@ def test_kernel_source_matches_oracle(name, P, H, N, sigma, tol):
     assert b["lds_doubles"] * 8 <= 160 * 1024          # per-candidate state must fit one CU's LDS
 
 
+@pytest.mark.parametrize("motion, time0", [(3, 0.0), (8, 1.1), (9, 16.9)])
+def test_tracking_motions_other_than_jump_kernel_source_matches_oracle(motion, time0):
+    """tracking.cc:43-66: the task's other modes (Cartwheel, Run, Walk): the residual interpolates the key frames of THAT motion
+    (first key = sum of the lengths before it) and clamps at its last key (Run: 39 keys = 1.27 s, the rollout from t = 1.1 s runs past
+    it; Walk from t = 16.9 s likewise); the host Transition of the closed-loop harness sets the mocap bodies from the same table."""
+    from mujoco_mpc_amd.modelgen import humanoid_track
+    from mujoco_mpc_amd.modelgen.tasks import HUMANOID_MOTIONS
+    m, task, d = humanoid_track(motion=motion)
+    lengths = [121, 154, 115, 78, 145, 188, 260, 279, 39, 510]
+    assert len(HUMANOID_MOTIONS) == 10 and list(task["int_data"][:3]) == [motion, sum(lengths[:motion]), lengths[motion]]
+    assert m["nkey"] == sum(lengths)
+    o = ol.Oracle(m, task)
+    P, H, N = 4, 30, 4
+    kt = time0 + np.linspace(0, (H - 1) * m["timestep"], P); kv = np.random.default_rng(0).uniform(-0.3, 0.3, (P, m["nu"]))
+    eps, sel = ol.noise(1, 0, 0, N, P, m["nu"])
+    a = o.plan(d["state"], d["mocap"], time0, kt, kv, 2, N, H, sigma=(0.15, 0.0), noise_eps=eps, noise_sel=sel, nthreads=4)
+    b = emu_lib.plan(m, task, d["state"], d["mocap"], time0, kt, kv, 2, N, H, sigma=(0.15, 0.0), noise_eps=eps, noise_sel=sel)
+    for k in ("states", "residual", "costs", "returns"):
+        assert _rel(b[k], a[k]) < 1e-5, k
+    # the tracking residuals really read this motion's keys: against motion 0's table the same rollout prices differently
+    m0, task0, _ = humanoid_track(motion=0)
+    a0 = ol.Oracle(m0, task0).plan(d["state"], d["mocap"], time0, kt, kv, 2, N, H, sigma=(0.15, 0.0), noise_eps=eps, noise_sel=sel, nthreads=4)
+    assert _rel(a0["states"], a["states"]) < 1e-12 and _rel(a0["returns"], a["returns"]) > 1e-3
+
+
 def test_tendon_friction_loss_kernel_source_matches_oracle():
     """mjCNSTR_FRICTION_TENDON rows: a cross-branch tendon (dense Hessian builds) and a one-joint tendon (inside the pattern) with
     friction loss; rollouts visit the saturated zones (gradient-only rows) and the quadratic zone."""
@@ -181,10 +206,6 @@ def test_models_the_engine_cannot_roll_out_are_refused_at_create():
     m = b.compile(); m["eq_type"][0] = 1
     cm = capi.CModel(m, task)
     assert lib.mjpc_hip_layout_bytes(ctypes.byref(cm.c_model), ctypes.byref(cm.c_task), 1) < 0 and b"only connect, joint and tendon equalities" in lib.mjpc_hip_last_error()
-
-    def userdata(b, body):
-        b.nuserdata = 3
-    check(userdata, "nuserdata")
 
     def bigcon(b, body):
         b.nconmax = 100

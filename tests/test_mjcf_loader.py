@@ -154,14 +154,20 @@ def test_humanoid_tracking_xml_matches_generator_and_keyframes():
     assert _xml_terms(info) == _terms_of(task)
     assert info["numeric"]["sampling_spline_points"] == [d["P"]] and info["numeric"]["sampling_exploration"] == [d["sigma"][0]]
     assert info["numeric"]["sampling_trajectories"] == [d["N"]]
-    # motion 0 ("Jump") = the first included keyframe file: the packed table in modelgen/data is those keys
-    jump = [k for k in info["keys"] if k["name"].startswith("jump_")]
-    nkey = int(task["int_data"][2])
-    assert len(jump) == nkey
-    mpos = np.array([k["mpos"] for k in jump])
-    table = np.asarray(m2["key_mpos"]).reshape(nkey, -1)
-    assert np.array_equal(mpos, table)
-    assert np.allclose(jump[0]["qpos"], d["state"][:m2["nq"]], atol=0)
+    # the packed table in modelgen/data is the keys of the ten included keyframe files, in the order of the motion table
+    # (tracking.cc:43-54); motion 0 ("Jump") comes first
+    keys = [k for k in info["keys"] if k.get("mpos") is not None and len(np.atleast_1d(k["mpos"]))]
+    lengths = [121, 154, 115, 78, 145, 188, 260, 279, 39, 510]
+    assert len(keys) == sum(lengths) == m2["nkey"]
+    table = np.asarray(m2["key_mpos"]).reshape(m2["nkey"], -1)
+    assert np.array_equal(np.array([k["mpos"] for k in keys]), table)
+    assert keys[0]["name"].startswith("jump_") and int(task["int_data"][2]) == lengths[0]
+    assert np.allclose(keys[0]["qpos"], d["state"][:m2["nq"]], atol=0)
+    for motion in (1, 8, 9):
+        _, tk, dk = tasks.humanoid_track(motion=motion)
+        first = sum(lengths[:motion])
+        assert list(tk["int_data"][:3]) == [motion, first, lengths[motion]]
+        assert np.allclose(keys[first]["qpos"], dk["state"][:m2["nq"]], atol=0)
 
 
 def _residual_parameters(info):

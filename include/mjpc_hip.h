@@ -32,7 +32,7 @@ enum {
   MJPC_GEOM_ELLIPSOID = 4, MJPC_GEOM_CYLINDER = 5, MJPC_GEOM_BOX = 6, MJPC_GEOM_MESH = 7
 };
 enum { MJPC_CONE_PYRAMIDAL = 0, MJPC_CONE_ELLIPTIC = 1 };
-enum { MJPC_SOL_NEWTON = 2, MJPC_INT_EULER = 0, MJPC_INT_IMPLICITFAST = 3 };
+enum { MJPC_SOL_NEWTON = 2, MJPC_INT_EULER = 0, MJPC_INT_IMPLICIT = 2, MJPC_INT_IMPLICITFAST = 3 };
 /* model features outside this view (MjpcHipModel.unsupported) */
 enum { MJPC_EQ_CONNECT = 0, MJPC_EQ_WELD = 1, MJPC_EQ_JOINT = 2, MJPC_EQ_TENDON = 3 };      /* mjtEq */
 enum { MJPC_DYN_NONE = 0, MJPC_DYN_INTEGRATOR = 1, MJPC_DYN_FILTER = 2, MJPC_DYN_FILTEREXACT = 3 };   /* mjtDyn */
@@ -119,9 +119,11 @@ typedef struct MjpcHipModel {
                             * refsafe, eulerdamp) is refused at create */
   int enableflags;         /* mjENBL_* bits: override and multiccd are refused, the rest has nothing to act on */
   int solver;              /* mjtSolver: only MJPC_SOL_NEWTON (2, MuJoCo's default and what every MJPC task uses) */
-  int integrator;          /* mjtIntegrator: MJPC_INT_EULER (0; with implicit joint damping, mj_Euler) or MJPC_INT_IMPLICITFAST (3: also implicit in
-                            * tendon damping and in the velocity term of affine actuator biases - position / velocity servos with kv - unless the
-                            * force sits on its forcerange; no Coriolis derivative).  RK4 and the full implicit integrator are refused */
+  int integrator;          /* mjtIntegrator: MJPC_INT_EULER (0; with implicit joint damping, mj_Euler), MJPC_INT_IMPLICITFAST (3: also implicit in
+                            * tendon damping, the velocity terms of affine actuator biases - zero while the force sits on its forcerange - and
+                            * the inertia-box fluid forces; no Coriolis derivative; symmetric factorisation) or MJPC_INT_IMPLICIT (2: the same
+                            * plus the velocity derivative of the bias forces, mjd_rne_vel, and an LU factorisation of the non-symmetric
+                            * M - h dF/dv).  RK4 is refused */
   int noslip_iterations;   /* must be 0 */
   int neq;                 /* number of equality constraints (eq_* below): connect, joint and (fixed-)tendon equalities; weld / flex are refused */
   int unsupported;         /* MJPC_UNSUP_* bits found by whoever fills this view in parts of mjModel the view does not carry

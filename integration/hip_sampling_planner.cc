@@ -37,7 +37,7 @@ int DeviceResidual(const Task& task) {
   if (name == "ParticleFixed") return MJPC_TASK_PARTICLE_FIXED;
   if (name == "Walker") return MJPC_TASK_WALKER;
   if (name == "Quadrotor") return MJPC_TASK_QUADROTOR;
-  if (name == "Swimmer") return MJPC_TASK_SWIMMER;       // (needs agent_integrator Euler: the XML's implicit integrator is refused by mjpc_hip_create)
+  if (name == "Swimmer") return MJPC_TASK_SWIMMER;
   if (name == "Acrobot") return MJPC_TASK_ACROBOT;
   return -1;
 }

@@ -472,7 +472,7 @@ template <int NVT>
 DEV_NOINLINE void ph_prefactor(KP Kc) {
   Ctx c; ctx_open(c, Kc, 1);
   const DevModel &M = *c.M;
-  if (M.any_damping) {
+  if (M.any_damping && !M.int_dense) {
     int nv = M.nv, nvp = M.nvp;
     double h = M.timestep;
     PFOR(e, nv * nvp) { int i = e / nvp, j = e - i * nvp; c.qL[e] = c.qM[e] + ((i == j) ? h * MD(dof_damping)[i] : 0.0); }
@@ -505,6 +505,169 @@ DEV_NOINLINE void ph_side_worker(KP Kc, int t) {
 }
 #endif
 
+
+// ---- the implicit integrators' dense path (DevModel::int_dense): implicitfast with fluid forces, and mjINT_IMPLICIT -------------
+// A = M - h dF/dv is built dense in qL and LU-solved (mj_implicit: mjd_smooth_vel + mju_factorLUSparse, no pivoting):
+//   + h diag(damping) + the tendon-damping / actuator-bias entries (idrv)                      [symmetric]
+//   + h J^T R diag(visc_k + 2 quad_k |lvel_k|) R^T J per body for the inertia-box fluid forces  [symmetric, mjd_inertiaBoxFluid]
+//   + h d qfrc_bias / d qvel for mjINT_IMPLICIT (mjd_rne_vel)                                   [not symmetric]
+// qfrc_bias is an exact quadratic polynomial of qvel, so its derivative is taken as the central difference with step ONE of the
+// bias forces themselves (no truncation error): lane (j, +-) runs its own serial RNE with qvel +- e_j, its per-body cvel / cacc /
+// cfrc in a scratch carved from the constraint rows (dead after the solve), 18 doubles per body and lane, in batches of lanes.
+DEV void implicit_rne_columns(Ctx &c, double *A, double h) {
+  const DevModel &M = *c.M;
+  const int nv = M.nv, nvp = M.nvp, nb = M.nbody;
+  double *S = lds_base() + c.K->L.efc_J;
+  int B = M.int_scratch / (18 * nb);                            // lanes (= columns) per batch
+  B = B > NLANE ? NLANE : B;
+#define S_(b, k) S[((b) * 18 + (k)) * B + LANE]
+  for (int j0 = 0; j0 < nv; j0 += B) {
+    const int j = j0 + LANE;
+    if (LANE < B && j < nv) {
+      for (int pass = 0; pass < 2; pass++) {
+        const double sgn = pass ? -1.0 : 1.0;
+        for (int b = 1; b < nb; b++) {
+          const int p = MIH(body_parentid)[b];
+          double cv[6], ca[6];
+          for (int k = 0; k < 6; k++) { cv[k] = p ? S_(p, k) : 0.0; ca[k] = p ? S_(p, 6 + k) : (k >= 3 ? -M.gravity[k - 3] : 0.0); }
+          int bda = MIH(body_dofadr)[b];
+          for (int jn = MIH(body_jntadr)[b]; jn < MIH(body_jntadr)[b] + MIH(body_jntnum)[b]; jn++) {
+            const int type = MIH(jnt_type)[jn];
+            if (type == 0) {                                    // free: the translational dofs have no cdof_dot
+              for (int k = 0; k < 3; k++) { double vq = c.qvel[bda + k] + (bda + k == j ? sgn : 0.0); for (int q = 0; q < 6; q++) cv[q] += c.cdof[6 * (bda + k) + q] * vq; }
+              bda += 3;
+            }
+            if (type == 0 || type == 1) {                       // rotational triple: all three cdof_dot from the velocity before them
+              double cd[3][6];
+              for (int k = 0; k < 3; k++) d_crossmotion(cd[k], cv, c.cdof + 6 * (bda + k));
+              for (int k = 0; k < 3; k++) {
+                double vq = c.qvel[bda + k] + (bda + k == j ? sgn : 0.0);
+                for (int q = 0; q < 6; q++) { ca[q] += cd[k][q] * vq; cv[q] += c.cdof[6 * (bda + k) + q] * vq; }
+              }
+              bda += 3;
+            } else {
+              double cd[6], vq = c.qvel[bda] + (bda == j ? sgn : 0.0);
+              d_crossmotion(cd, cv, c.cdof + 6 * bda);
+              for (int q = 0; q < 6; q++) { ca[q] += cd[q] * vq; cv[q] += c.cdof[6 * bda + q] * vq; }
+              bda++;
+            }
+          }
+          double t1[6], t2[6], t3[6];
+          d_mulinertvec(t1, c.cinert + 10 * b, ca);
+          d_mulinertvec(t2, c.cinert + 10 * b, cv);
+          d_crossforce(t3, cv, t2);
+          for (int k = 0; k < 6; k++) { S_(b, k) = cv[k]; S_(b, 6 + k) = ca[k]; S_(b, 12 + k) = t1[k] + t3[k]; }
+        }
+        for (int b = nb - 1; b > 0; b--) {
+          const int p = MIH(body_parentid)[b];
+          if (p > 0) for (int k = 0; k < 6; k++) S_(p, 12 + k) += S_(b, 12 + k);
+        }
+        for (int i = 0; i < nv; i++) {                          // column j of the matrix belongs to this lane
+          const int bi = MIH(dof_bodyid)[i];
+          double bias = 0;
+          for (int k = 0; k < 6; k++) bias += c.cdof[6 * i + k] * S_(bi, 12 + k);
+          A[i * nvp + j] += sgn * (h * 0.5) * bias;
+        }
+      }
+    }
+    SYNC();
+  }
+#undef S_
+}
+template <int NVT>
+DEV void implicit_dense_solve(Ctx &c) {
+  const DevModel &M = *c.M;
+  const int nv = M.nv, nvp = M.nvp, nb = M.nbody;
+  const double h = M.timestep;
+  double *A = c.qL;
+  PFOR(e, nv * nvp) { int i = e / nvp, j = e - i * nvp; A[e] = (j < nv) ? c.qM[(i >= j) ? e : j * nvp + i] + ((i == j) ? h * MD(dof_damping)[i] : 0.0) : 0.0; }
+  SYNC();
+  if (M.nidrv && LANE == 0)
+    for (int k = 0; k < M.nidrv; k++) {
+      int i = MI(idrv_e)[3 * k], j = MI(idrv_e)[3 * k + 1], a = MI(idrv_e)[3 * k + 2];
+      if (a >= 0 && MI(actuator_forcelimited)[a]) {
+        double f = c.actuator_force[a];
+        if (f <= MD(actuator_forcerange)[2 * a] || f >= MD(actuator_forcerange)[2 * a + 1]) continue;
+      }
+      double v = h * MD(idrv_c)[k];
+      A[i * nvp + j] += v;
+      if (i != j) A[j * nvp + i] += v;
+    }
+  SYNC();
+  if (M.fluid) {
+    // per body: the diagonal of -d lfrc / d lvel in the inertial frame (scratch: 6 per body, from efc_J on)
+    double *DL = lds_base() + c.K->L.efc_J;
+    PFOR(b, nb) {
+      double dl[6] = {0, 0, 0, 0, 0, 0};
+      double mass = MDH(body_mass)[b];
+      if (b > 0 && mass >= D_MINVAL) {
+        const double *I = MDH(body_inertia) + 3 * b, *R = c.ximat + 9 * b;
+        double box[3], off[3], vw[3], lvel[6];
+        box[0] = sqrt(d_div(fmax(D_MINVAL, I[1] + I[2] - I[0]), mass) * 6.0);
+        box[1] = sqrt(d_div(fmax(D_MINVAL, I[0] + I[2] - I[1]), mass) * 6.0);
+        box[2] = sqrt(d_div(fmax(D_MINVAL, I[0] + I[1] - I[2]), mass) * 6.0);
+        d_sub3(off, c.xipos + 3 * b, c.subtree_com + 3 * MIH(body_rootid)[b]);
+        d_cross(vw, c.cvel + 6 * b, off);
+        for (int k = 0; k < 3; k++) vw[k] += c.cvel[6 * b + 3 + k] - M.wind[k];
+        d_mulmattvec3(lvel, R, c.cvel + 6 * b); d_mulmattvec3(lvel + 3, R, vw);
+        if (M.viscosity > 0) {
+          double diam = (box[0] + box[1] + box[2]) / 3.0;
+          for (int k = 0; k < 3; k++) { dl[k] += D_PI * diam * diam * diam * M.viscosity; dl[3 + k] += 3.0 * D_PI * diam * M.viscosity; }
+        }
+        if (M.density > 0) {
+          double b0 = box[0], b1 = box[1], b2 = box[2];
+          dl[3] += 2 * 0.5 * M.density * b1 * b2 * fabs(lvel[3]);
+          dl[4] += 2 * 0.5 * M.density * b0 * b2 * fabs(lvel[4]);
+          dl[5] += 2 * 0.5 * M.density * b0 * b1 * fabs(lvel[5]);
+          dl[0] += 2 * M.density * b0 * (b1 * b1 * b1 * b1 + b2 * b2 * b2 * b2) * fabs(lvel[0]) / 64.0;
+          dl[1] += 2 * M.density * b1 * (b0 * b0 * b0 * b0 + b2 * b2 * b2 * b2) * fabs(lvel[1]) / 64.0;
+          dl[2] += 2 * M.density * b2 * (b0 * b0 * b0 * b0 + b1 * b1 * b1 * b1) * fabs(lvel[2]) / 64.0;
+        }
+      }
+      for (int k = 0; k < 6; k++) DL[6 * b + k] = dl[k];
+    }
+    SYNC();
+    PFOR(e, nv * nv) {
+      const int i = e / nv, j = e - i * nv;
+      double acc = 0;
+      for (int b = 1; b < nb; b++) {
+        const unsigned long long dm = MDM()[b];
+        if (!((dm >> i) & 1ull) || !((dm >> j) & 1ull)) continue;
+        const double *R = c.ximat + 9 * b, *dl = DL + 6 * b;
+        double off[3], t[3], wi[6], wj[6], li[6], lj[6];
+        d_sub3(off, c.xipos + 3 * b, c.subtree_com + 3 * MIH(body_rootid)[b]);
+        const double *ci = c.cdof + 6 * i, *cj = c.cdof + 6 * j;
+        d_cross(t, ci, off); for (int k = 0; k < 3; k++) { wi[k] = ci[k]; wi[3 + k] = ci[3 + k] + t[k]; }
+        d_cross(t, cj, off); for (int k = 0; k < 3; k++) { wj[k] = cj[k]; wj[3 + k] = cj[3 + k] + t[k]; }
+        d_mulmattvec3(li, R, wi); d_mulmattvec3(li + 3, R, wi + 3);
+        d_mulmattvec3(lj, R, wj); d_mulmattvec3(lj + 3, R, wj + 3);
+        for (int k = 0; k < 6; k++) acc += li[k] * dl[k] * lj[k];
+      }
+      A[i * nvp + j] += h * acc;
+    }
+    SYNC();
+  }
+  if (M.int_dense == 2) implicit_rne_columns(c, A, h);
+  // LU without pivoting, in place (unit lower factor below the diagonal), then the two substitutions on Mgrad
+  for (int k = 0; k < nv; k++) {
+    SYNC();
+    const double piv = A[k * nvp + k];
+    PFOR(ii, nv - k - 1) { int i = k + 1 + ii; A[i * nvp + k] = d_div(A[i * nvp + k], piv); }
+    SYNC();
+    PFOR(e, (nv - k - 1) * (nv - k - 1)) {
+      int i = k + 1 + e / (nv - k - 1), j = k + 1 + e % (nv - k - 1);
+      A[i * nvp + j] -= A[i * nvp + k] * A[k * nvp + j];
+    }
+  }
+  SYNC();
+  double *x = c.Mgrad;
+  if (LANE == 0) {
+    for (int i = 0; i < nv; i++) { double s = x[i]; for (int j = 0; j < i; j++) s -= A[i * nvp + j] * x[j]; x[i] = s; }
+    for (int i = nv - 1; i >= 0; i--) { double s = x[i]; for (int j = i + 1; j < nv; j++) s -= A[i * nvp + j] * x[j]; x[i] = d_div(s, A[i * nvp + i]); }
+  }
+  SYNC();
+}
+
 // mj_Euler with implicit joint damping, then record state[t+1]
 template <int NVT>
 DEV_NOINLINE void ph_integrate(KP Kc, int t) {
@@ -515,7 +678,12 @@ DEV_NOINLINE void ph_integrate(KP Kc, int t) {
   int nq = M.nq, nv = M.nv, nvp = M.nvp;
   double h = M.timestep;
   PFOR(i, nv) c.qacc_ws[i] = c.qacc[i];
-  if (M.any_damping) {
+  if (M.int_dense) {
+    PFOR(i, nv) c.Mgrad[i] = c.qfrc_smooth[i] + c.qfrc_constraint[i];
+    SYNC();
+    implicit_dense_solve<NVT>(c);
+    PFOR(i, nv) c.qvel[i] += h * c.Mgrad[i];
+  } else if (M.any_damping) {
     PFOR(i, nv) c.Mgrad[i] = c.qfrc_smooth[i] + c.qfrc_constraint[i];
     chol_solve<NVT>(c.qL, c.Linv, c.Mgrad, nv, nvp, c.M->tree_ok);       // factor of M + h*B from ph_prefactor
     PFOR(i, nv) c.qvel[i] += h * c.Mgrad[i];

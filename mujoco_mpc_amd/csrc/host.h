@@ -155,7 +155,7 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
     }
     if (cnt != m->na) { p.error = "na = " + std::to_string(m->na) + " but " + std::to_string(cnt) + " stateful actuators (one activation each)"; return false; } }
   if (m->solver != MJPC_SOL_NEWTON) { p.error = "only the Newton solver (mjSOL_NEWTON) is implemented"; return false; }
-  if (m->integrator != MJPC_INT_EULER && m->integrator != MJPC_INT_IMPLICITFAST) { p.error = "only the Euler (with implicit joint damping) and implicitfast integrators are implemented"; return false; }
+  if (m->integrator != MJPC_INT_EULER && m->integrator != MJPC_INT_IMPLICITFAST && m->integrator != MJPC_INT_IMPLICIT) { p.error = "only the Euler (with implicit joint damping), implicitfast and implicit integrators are implemented (not RK4)"; return false; }
   if (m->noslip_iterations != 0) { p.error = "noslip_iterations > 0 not supported"; return false; }
   for (int e = 0; e < m->neq; e++) {
     if (!m->eq_type || !m->eq_obj1id || !m->eq_obj2id || !m->eq_active0 || !m->eq_data || !m->eq_solref || !m->eq_solimp) { p.error = "neq > 0 but the eq_* tables are missing"; return false; }
@@ -187,7 +187,9 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
   M.na = m->na;
   M.fluid = (m->density > 0 || m->viscosity > 0) ? 1 : 0; M.density = m->density; M.viscosity = m->viscosity;
   for (int k = 0; k < 3; k++) M.wind[k] = m->wind[k];
-  if (M.fluid && m->integrator == MJPC_INT_IMPLICITFAST) { p.error = "implicitfast with fluid forces (density / viscosity) is not implemented: their velocity derivative is missing"; return false; }
+  // the implicit integrators' velocity derivatives beyond the factorisation pattern's symmetric terms (fluid forces; the bias forces
+  // of mjINT_IMPLICIT) go through a dense, LU-solved M - h dF/dv in ph_integrate
+  M.int_dense = m->integrator == MJPC_INT_IMPLICIT ? 2 : ((M.fluid && m->integrator == MJPC_INT_IMPLICITFAST) ? 1 : 0);
   M.nq = m->nq; M.nv = nv; M.nu = nu; M.nbody = nb; M.njnt = nj; M.ngeom = ng; M.nsite = ns; M.nmocap = m->nmocap;
   M.nkey = m->nkey; M.nvp = NVP_OF(nv); M.ntendon = m->ntendon;
   M.cone = m->cone; M.iterations = m->iterations; M.ls_iterations = m->ls_iterations;
@@ -494,13 +496,13 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
         if (i < j) std::swap(i, j);
         bool anc = false;
         for (int k = i; k >= 0; k = pattern_parent(nv, M.tree_ok, m->dof_parentid, k)) if (k == j) anc = true;
-        if (!anc) return false;
+        if (!anc && !M.int_dense) return false;       // (the dense path of ph_integrate takes entries anywhere)
         double cf = scale * row[a].second * row[b].second * ((a != b && row[a].first == row[b].first) ? 2.0 : 1.0);
         ei.push_back(i); ei.push_back(j); ei.push_back(act); ec.push_back(cf);
       }
       return true;
     };
-    if (m->integrator == MJPC_INT_IMPLICITFAST) {
+    if (m->integrator == MJPC_INT_IMPLICITFAST || m->integrator == MJPC_INT_IMPLICIT) {
       for (int t = 0; t < m->ntendon; t++) {
         double b = m->tendon_damping ? m->tendon_damping[t] : 0;
         if (b == 0) continue;
@@ -546,6 +548,9 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
   // ---- LDS layout
   if (!use_cache) { p.cache_i = hot_only ? p.hot_i : 0; p.cache_d = hot_only ? p.hot_d : 0; }      // the kernel reads (the rest of) the tables from HBM / L2
   make_layout(p, p.L, m, t, P_max, p.cache_d, p.cache_i, lean, reg_solver);
+  M.int_scratch = p.L.efc_D - p.L.efc_J;            // efc_J and efc_JA are adjacent and dead after the solve
+  if (M.int_dense == 2 && M.int_scratch < 18 * nb) { p.error = "implicit integrator: no room for the bias-derivative scratch in LDS (raise nefcmax)"; return false; }
+  if (M.int_dense && lean) { p.error = "the implicit integrators' dense path has no dense-tier layout"; return false; }
   return true;
 }
 

@@ -90,6 +90,8 @@ struct DevTask {
 struct DevModel {
   int nq, nv, nu, nbody, njnt, ngeom, nsite, nmocap, nkey, nvp, ntendon;
   int nlevel, npair, nfric, nlimit, nray, nmpair, nhpair, nzpair, nconmax, nefcmax, any_damping;
+  int int_dense;       // 0: Euler / implicitfast inside the factorisation pattern (ph_prefactor); 1: implicitfast with fluid forces, 2: full implicit (mjINT_IMPLICIT) - dense M - h dF/dv built and LU-solved in ph_integrate
+  int int_scratch;     // doubles of LDS the dense path may use from efc_J on (the constraint rows are dead after the solve)
   int nlimit_ball;      // limited ball joints (limit_ball[])
   int limit_cross;      // some limited tendon couples dofs outside the Hessian's pattern: every build is a dense one
   int ntendon_passive;  // tendons with a spring or a damper (tpass_*)

@@ -122,7 +122,7 @@ class _Body:
 class ModelBuilder:
     def __init__(self, timestep=0.002, gravity=(0, 0, -9.81), cone=0, impratio=1.0,
                  contact=True, tolerance=1e-8, iterations=100, ls_iterations=50, ls_tolerance=0.01, integrator=0, density=0.0, viscosity=0.0, wind=(0, 0, 0)):
-        self.integrator = integrator      # 0 Euler, 3 implicitfast (mjtIntegrator)
+        self.integrator = integrator      # 0 Euler, 2 implicit, 3 implicitfast (mjtIntegrator)
         self.fluid = (float(density), float(viscosity), tuple(float(x) for x in wind))      # inertia-box fluid model (mjOption)
         self.opt = dict(timestep=timestep, gravity=np.array(gravity, float), cone=cone, impratio=impratio,
                         contact=contact, tolerance=tolerance, iterations=iterations,

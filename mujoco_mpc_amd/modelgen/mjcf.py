@@ -127,9 +127,9 @@ def parse_mjcf(path_or_text, base_dir=None, reader=None, missing_ok=()):
             opt["wind"] = tuple(_floats(o.get("wind")))
         if o.get("integrator") is not None:
             integ = o.get("integrator")
-            if integ not in ("Euler", "implicitfast"):
-                raise ValueError(f"integrator {integ} not in the supported subset (Euler, implicitfast)")
-            opt["integrator"] = 0 if integ == "Euler" else 3
+            if integ not in ("Euler", "implicit", "implicitfast"):
+                raise ValueError(f"integrator {integ} not in the supported subset (Euler, implicit, implicitfast)")
+            opt["integrator"] = {"Euler": 0, "implicit": 2, "implicitfast": 3}[integ]
         for fl in o.iter("flag"):
             if fl.get("contact") == "disable":
                 opt["contact"] = False

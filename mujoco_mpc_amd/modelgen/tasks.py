@@ -90,12 +90,12 @@ def particle_task(fixed=False, timestep=0.01):
 TASK_SWIMMER = 14
 
 
-def swimmer(timestep=0.01, integrator=0):
+def swimmer(timestep=0.01, integrator=2):
     """mjpc/tasks/swimmer (swimmer.cc:33-61, task.xml, swimmer.xml.patch on dm_control's swimmer): six 10 g links in a medium of
     density 1000 (inertia-box fluid forces), planar root (two slides and a hinge), five limited hinge joints with a weak spring, driven
     through first-order filters (dyntype filter, 0.6 s); contacts disabled; target = a mocap body.  Cost / agent settings are the
-    reference's (horizon 2 s, 10 spline points, exploration 0.05).  The XML asks for the full implicit integrator, which the engine
-    refuses: this model steps with Euler (integrator=0)."""
+    reference's (horizon 2 s, 10 spline points, exploration 0.05), also `agent_integrator` 2 = the full implicit integrator
+    (task.xml:11; mjINT_IMPLICIT: velocity derivatives of the fluid and bias forces, LU), the default here since round 3."""
     b = ModelBuilder(timestep=timestep, contact=False, density=1000.0, integrator=integrator)
     b.geom(0, "ground", PLANE, size=(2, 2, 0.01))
     head = b.body("head", 0, pos=(0, 0, 0.05))

@@ -128,6 +128,8 @@ int oracle_debug_forward(const OModel *om, const double *qpos, const double *qve
                          double *geom_xpos, double *extra);
 int oracle_debug_step(const OModel *om, double *qpos, double *qvel, const double *ctrl,
                       const double *mocap, double *time, int nstep, double *energy);
+int oracle_debug_vel_derivatives(const OModel *om, const double *qpos, const double *qvel, double *dbias, double *dfluid, double *bias,
+                                 double *passive_out);
 
 #ifdef __cplusplus
 }

@@ -1115,6 +1115,105 @@ static void integrate_pos(const OModel *om, OData *d, double h) {
   }
 }
 
+
+/* ---- velocity derivatives for the implicit integrators (mjd_smooth_vel, engine_derivative.c) ---------------------------------- */
+/* A += h * (-d qfrc_fluid / d qvel) for the inertia-box fluid model (mjd_inertiaBoxFluid): per body the local 6-D force is
+ * component-wise  lfrc_k = -(visc_k + quad_k |lvel_k|) lvel_k,  so  d lfrc_k / d lvel_k = -(visc_k + 2 quad_k |lvel_k|);  with
+ * lvel = Rt [jacr; jacp] qvel at the com the generalized derivative is  -J^T R diag(...) R^T J  (symmetric). */
+static void fluid_vel_derivative(const OModel *om, OData *d, double *A, double h) {
+  const MjpcHipModel *m = &om->m;
+  const int nv = m->nv;
+  if (!(m->density > 0 || m->viscosity > 0)) return;
+  double *jp = (double *)malloc(sizeof(double) * 12 * (size_t)nv), *jr = jp + 3 * nv, *lj = jr + 3 * nv;      /* lj: local rows [6][nv] */
+  for (int b = 1; b < m->nbody; b++) if (m->body_mass[b] >= O_MINVAL) {
+    const double *I = m->body_inertia + 3 * b, *R = d->ximat + 9 * b;
+    double mass = m->body_mass[b], box[3], off[3], vw[3], lvel[6], dl[6] = {0, 0, 0, 0, 0, 0};
+    box[0] = sqrt(fmax(O_MINVAL, I[1] + I[2] - I[0]) / mass * 6.0);
+    box[1] = sqrt(fmax(O_MINVAL, I[0] + I[2] - I[1]) / mass * 6.0);
+    box[2] = sqrt(fmax(O_MINVAL, I[0] + I[1] - I[2]) / mass * 6.0);
+    o_sub3(off, d->xipos + 3 * b, d->subtree_com + 3 * m->body_rootid[b]);
+    o_cross(vw, d->cvel + 6 * b, off); o_add3(vw, vw, d->cvel + 6 * b + 3);
+    o_sub3(vw, vw, m->wind);
+    o_mulmattvec3(lvel, R, d->cvel + 6 * b); o_mulmattvec3(lvel + 3, R, vw);
+    if (m->viscosity > 0) {
+      double diam = (box[0] + box[1] + box[2]) / 3.0;
+      for (int k = 0; k < 3; k++) { dl[k] += O_PI * diam * diam * diam * m->viscosity; dl[3 + k] += 3.0 * O_PI * diam * m->viscosity; }
+    }
+    if (m->density > 0) {
+      dl[3] += 2 * 0.5 * m->density * box[1] * box[2] * fabs(lvel[3]);
+      dl[4] += 2 * 0.5 * m->density * box[0] * box[2] * fabs(lvel[4]);
+      dl[5] += 2 * 0.5 * m->density * box[0] * box[1] * fabs(lvel[5]);
+      dl[0] += 2 * m->density * box[0] * (box[1] * box[1] * box[1] * box[1] + box[2] * box[2] * box[2] * box[2]) * fabs(lvel[0]) / 64.0;
+      dl[1] += 2 * m->density * box[1] * (box[0] * box[0] * box[0] * box[0] + box[2] * box[2] * box[2] * box[2]) * fabs(lvel[1]) / 64.0;
+      dl[2] += 2 * m->density * box[2] * (box[0] * box[0] * box[0] * box[0] + box[1] * box[1] * box[1] * box[1]) * fabs(lvel[2]) / 64.0;
+    }
+    jac_point(om, d, jp, jr, d->xipos + 3 * b, b);
+    for (int i = 0; i < nv; i++) {                     /* local-frame Jacobian rows: R^T jacr (0..2), R^T jacp (3..5) */
+      double wr[3] = {jr[i], jr[nv + i], jr[2 * nv + i]}, wp[3] = {jp[i], jp[nv + i], jp[2 * nv + i]}, lr[3], lp[3];
+      o_mulmattvec3(lr, R, wr); o_mulmattvec3(lp, R, wp);
+      for (int k = 0; k < 3; k++) { lj[k * nv + i] = lr[k]; lj[(3 + k) * nv + i] = lp[k]; }
+    }
+    for (int i = 0; i < nv; i++) for (int j = 0; j < nv; j++) {
+      double s_ = 0;
+      for (int k = 0; k < 6; k++) s_ += lj[k * nv + i] * dl[k] * lj[k * nv + j];
+      A[i * nv + j] += h * s_;
+    }
+  }
+  free(jp);
+}
+/* A += h * d qfrc_bias / d qvel (mjd_rne_vel; qDeriv -= that, and the integrator factors M - h qDeriv).  qfrc_bias is an exact
+ * quadratic polynomial of qvel (cdof_dot is linear, cacc and cvel x* I cvel quadratic, gravity constant), so the central difference
+ * with step 1 IS the derivative: [bias(v + e_j) - bias(v - e_j)] / 2 has no truncation error. */
+static void rne_vel_derivative(const OModel *om, OData *d, double *A, double h) {
+  const MjpcHipModel *m = &om->m;
+  const int nv = m->nv, nb = m->nbody;
+  size_t nsave = (size_t)(6 * nb * 3 + 6 * nv + nv + 3 * nb + nv);
+  double *save = (double *)malloc(sizeof(double) * (nsave + 2 * (size_t)nv)), *q = save;
+  double *s_cvel = q; q += 6 * nb; double *s_cacc = q; q += 6 * nb; double *s_cfrc = q; q += 6 * nb; double *s_cdd = q; q += 6 * nv;
+  double *s_bias = q; q += nv; double *s_lin = q; q += 3 * nb; double *s_qvel = q; q += nv; double *plus = q; q += nv; double *minus = q;
+  o_copy(s_cvel, d->cvel, 6 * nb); o_copy(s_cacc, d->cacc, 6 * nb); o_copy(s_cfrc, d->cfrc, 6 * nb); o_copy(s_cdd, d->cdof_dot, 6 * nv);
+  o_copy(s_bias, d->qfrc_bias, nv); o_copy(s_lin, d->subtree_linvel, 3 * nb); o_copy(s_qvel, d->qvel, nv);
+  for (int j = 0; j < nv; j++) {
+    d->qvel[j] = s_qvel[j] + 1.0; com_vel(om, d); rne_bias(om, d); o_copy(plus, d->qfrc_bias, nv);
+    d->qvel[j] = s_qvel[j] - 1.0; com_vel(om, d); rne_bias(om, d); o_copy(minus, d->qfrc_bias, nv);
+    d->qvel[j] = s_qvel[j];
+    for (int i = 0; i < nv; i++) A[i * nv + j] += h * 0.5 * (plus[i] - minus[i]);
+  }
+  o_copy(d->cvel, s_cvel, 6 * nb); o_copy(d->cacc, s_cacc, 6 * nb); o_copy(d->cfrc, s_cfrc, 6 * nb); o_copy(d->cdof_dot, s_cdd, 6 * nv);
+  o_copy(d->qfrc_bias, s_bias, nv); o_copy(d->subtree_linvel, s_lin, 3 * nb);
+  free(save);
+}
+/* x = A^-1 b for a general (non-symmetric) A, LU without pivoting like mju_factorLUSparse (A = M + h (...) is diagonally dominant
+ * enough: M dominates); A is overwritten */
+static void lu_solve(double *A, double *x, const double *b, int n) {
+  for (int k = 0; k < n; k++)
+    for (int i = k + 1; i < n; i++) {
+      double l = A[i * n + k] / A[k * n + k];
+      A[i * n + k] = l;
+      for (int j = k + 1; j < n; j++) A[i * n + j] -= l * A[k * n + j];
+    }
+  for (int i = 0; i < n; i++) { double s_ = b[i]; for (int j = 0; j < i; j++) s_ -= A[i * n + j] * x[j]; x[i] = s_; }
+  for (int i = n - 1; i >= 0; i--) { double s_ = x[i]; for (int j = i + 1; j < n; j++) s_ -= A[i * n + j] * x[j]; x[i] = s_ / A[i * n + i]; }
+}
+/* debug accessor for the unit tests: d qfrc_bias / d qvel and -d qfrc_fluid / d qvel at (qpos, qvel), plus the two force vectors
+ * themselves (qfrc_bias; qfrc_passive, which holds the fluid forces) so that a test can difference them */
+int oracle_debug_vel_derivatives(const OModel *om, const double *qpos, const double *qvel, double *dbias, double *dfluid, double *bias,
+                                 double *passive_out) {
+  const MjpcHipModel *m = &om->m;
+  int nv = m->nv;
+  OData *d = oracle_make_data(om);
+  o_copy(d->qpos, qpos, m->nq); o_copy(d->qvel, qvel, nv);
+  oracle_forward(om, d);
+  int w = d->warning;
+  o_zero(dbias, nv * nv); o_zero(dfluid, nv * nv);
+  rne_vel_derivative(om, d, dbias, 1.0);
+  fluid_vel_derivative(om, d, dfluid, 1.0);
+  if (bias) o_copy(bias, d->qfrc_bias, nv);
+  if (passive_out) o_copy(passive_out, d->qfrc_passive, nv);
+  oracle_free_data(d);
+  return w;
+}
+
 void oracle_step(const OModel *om, OData *d) {
   const MjpcHipModel *m = &om->m;
   int nv = m->nv;
@@ -1128,8 +1227,10 @@ void oracle_step(const OModel *om, OData *d) {
   /* Euler, implicit in joint damping */
   int damped = 0;
   for (int i = 0; i < nv; i++) if (m->dof_damping[i] > 0) damped = 1;
-  const int fast = m->integrator == MJPC_INT_IMPLICITFAST;
+  const int full = m->integrator == MJPC_INT_IMPLICIT;
+  const int fast = m->integrator == MJPC_INT_IMPLICITFAST || full;
   if (fast) {
+    if (m->density > 0 || m->viscosity > 0 || full) damped = 1;
     for (int t = 0; t < m->ntendon; t++) if (m->tendon_damping && m->tendon_damping[t] != 0) damped = 1;
     for (int i = 0; i < m->nu; i++) if (m->actuator_biastype[i] == MJPC_BIAS_AFFINE && m->actuator_biasprm[3 * i + 2] != 0) damped = 1;
   }
@@ -1161,10 +1262,17 @@ void oracle_step(const OModel *om, OData *d) {
         for (int i = 0; i < nv; i++) for (int j = 0; j < nv; j++) d->qH[i * nv + j] -= h * kv * row[i] * row[j];
       }
     }
-    chol_factor(d->qLD2, d->qH, nv);
+    if (fast) fluid_vel_derivative(om, d, d->qH, h);             /* mjd_passive_vel: inertia-box fluid forces */
     double *rhs = d->work, *sol = d->work + nv;
     for (int i = 0; i < nv; i++) rhs[i] = d->qfrc_smooth[i] + d->qfrc_constraint[i];
-    chol_solve(sol, d->qLD2, rhs, nv);
+    if (full) {
+      /* mjINT_IMPLICIT: also the (non-symmetric) velocity derivative of the bias forces, then LU */
+      rne_vel_derivative(om, d, d->qH, h);
+      lu_solve(d->qH, sol, rhs, nv);
+    } else {
+      chol_factor(d->qLD2, d->qH, nv);
+      chol_solve(sol, d->qLD2, rhs, nv);
+    }
     qacc = sol;
   }
   /* mj_advance: activations first (mj_nextActivation), then velocities and positions */

@@ -30,7 +30,7 @@ CONFIGS = {
     "acrobot_10x100": ("acrobot", 10, 100, 10, 2, 0.05, False),             # mjpc/tasks/acrobot/task.xml:9-17, half the horizon
     "ball_chain_6x60": ("ball_chain", 6, 60, 4, 2, 0.4, False),             # limited ball joints, tendon spring / damper / cross-branch limit
     "ball_chain_friction_6x80": ("ball_chain_friction", 6, 80, 4, 2, 0.4, False),   # tendon friction loss rows (cross-branch and in-pattern)
-    "swimmer_6x101": ("swimmer", 6, 101, 10, 2, 0.3, False),                # mjpc/tasks/swimmer/task.xml:9-16 (10 spline points), half the horizon; Euler instead of the XML's implicit integrator
+    "swimmer_6x101": ("swimmer", 6, 101, 10, 2, 0.3, False),                # mjpc/tasks/swimmer/task.xml:9-16 (10 spline points), half the horizon; agent_integrator 2 (the full implicit integrator), as the XML asks
     "quadrotor_8x51": ("quadrotor", 8, 51, 5, 2, 0.3, True),                # mjpc/tasks/quadrotor/task.xml:13-19 (horizon 0.5 s, 5 points, exploration 0.3), hover nominal
     "linkage_6x80": ("linkage", 6, 80, 4, 2, 0.5, False),                   # equality constraints (joint coupling, four-bar connect, pinned free body) next to contacts
     "servo_arm_6x80": ("servo_arm", 6, 80, 4, 2, 0.5, False),               # implicitfast integrator (velocity servos, saturating force range, damped tendon)

@@ -58,6 +58,7 @@ def lib():
     L.oracle_philox.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
     L.oracle_debug_forward.argtypes = [C.c_void_p] + [c_double_p] * 4 + [C.c_double] + [c_double_p] * 5 + [c_int_p, c_int_p, c_double_p, c_double_p, c_double_p]
     L.oracle_debug_step.argtypes = [C.c_void_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, C.c_int, c_double_p]
+    L.oracle_debug_vel_derivatives.argtypes = [C.c_void_p] + [c_double_p] * 6
     _lib = L
     return L
 
@@ -170,6 +171,15 @@ class Oracle:
         res["subtree_com"] = e[3 * nv + 2:3 * nv + 2 + 3 * nb].reshape(nb, 3)
         res["subtree_linvel"] = e[3 * nv + 2 + 3 * nb:].reshape(nb, 3)
         return res
+
+    def vel_derivatives(self, qpos, qvel):
+        """d qfrc_bias / d qvel, -d qfrc_fluid / d qvel (what the implicit integrators add to M, per unit h), qfrc_bias, qfrc_passive"""
+        nv = self.model["nv"]
+        qpos = np.ascontiguousarray(qpos, float); qvel = np.ascontiguousarray(qvel, float)
+        out = dict(dbias=np.zeros((nv, nv)), dfluid=np.zeros((nv, nv)), qfrc_bias=np.zeros(nv), qfrc_passive=np.zeros(nv))
+        out["warning"] = lib().oracle_debug_vel_derivatives(self.h, _dp(qpos), _dp(qvel), _dp(out["dbias"]), _dp(out["dfluid"]),
+                                                            _dp(out["qfrc_bias"]), _dp(out["qfrc_passive"]))
+        return out
 
     def step(self, qpos, qvel, ctrl=None, mocap=None, time=0.0, nstep=1):
         m = self.model

@@ -1087,11 +1087,15 @@ def test_closed_loop_walker_walks_and_acrobot_swings_up():
 @pytest.mark.gpu
 def test_swimmer_task_fluid_forces_and_filter_actuators():
     """mjpc/tasks/swimmer (swimmer.cc:33-61): inertia-box fluid forces (density 1000), five filter actuators (na = 5), planar root.
-    Plan-step parity with the oracle (Euler; the XML's full implicit integrator is refused); closed loop with the reference's agent
-    settings: the nose gets closer to the target."""
+    Plan-step parity with the oracle with the XML's integrator (agent_integrator 2 = mjINT_IMPLICIT: fluid and bias-force velocity
+    derivatives, LU) and with Euler / implicitfast; closed loop with the reference's agent settings: the nose gets closer to the target."""
     from mujoco_mpc_amd import cplanner
     from mujoco_mpc_amd.modelgen import swimmer
     m, task, d = swimmer()
+    assert m["integrator"] == 2
+    for integ in (0, 3):
+        mi, ti, di = swimmer(integrator=integ)
+        _compare(mi, ti, di, 10, 101, 8, (0.3, 0.0), 2, 1e-8, nominal_scale=0.8)
     out, ref, allc = _compare(m, task, d, 10, 201, 16, (0.3, 0.0), 2, 1e-8, nominal_scale=0.8)
     assert allc["residual"].shape[-1] == 7 and allc["states"].shape[-1] == 8 + 8 + 5 and not out["failure"].any()
     assert np.abs(allc["states"][:, -1, 16:]).max() > 0.05                                  # the filters have charged
@@ -1105,6 +1109,18 @@ def test_swimmer_task_fluid_forces_and_filter_actuators():
     q = res["state"]; th = q[2]
     nose = np.array([q[0] + 0.06 * np.sin(th), q[1] - 0.05 + 0.05 - 0.06 * np.cos(th)])      # rootz turns about (0, -0.05) of the head
     assert not res["failure"] and (np.linalg.norm(nose - res["mocap"][:2]) < d0 - 0.02 or not np.allclose(res["mocap"][:2], d["mocap"][:2])), (nose, res["mocap"][:2], d0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name, tol", [("servo_arm", 1e-8), ("ball_chain", 1e-5), ("humanoid_walk", 1e-5), ("quadruped", 1e-5), ("quadrotor", 1e-8)])
+def test_full_implicit_integrator_matches_oracle(name, tol):
+    """mjINT_IMPLICIT on models of every joint kind: hinge chains with servos (generic-nv kernel), ball joints, the humanoid (free +
+    ball + hinge limbs under contact, 27-dof kernel: no dense tier for it), the A1 (18-dof kernel, elliptic contacts), a site-driven
+    free body.  The dense M - h dF/dv, its bias-force derivative columns and the LU solve against the oracle."""
+    from mujoco_mpc_amd.modelgen import REGISTRY
+    m, task, d = REGISTRY[name]()
+    m = dict(m); m["integrator"] = 2
+    _compare(m, task, d, 4, 40, 8, (0.3 if name != "quadruped" else 0.04, 0.0), 2, tol, nominal_scale=0.3)
 
 
 @pytest.mark.gpu

@@ -26,7 +26,7 @@ def _rel(a, b):
                                                    ("terrain_balls", 3, 60, 6, (0.5, 0.0), 1e-5),   # height field: prisms through the portal-refinement collider
                                                    ("cylinder_pile", 3, 50, 6, (0.5, 0.0), 1e-5),   # cylinder-box / cylinder-cylinder through the portal-refinement collider
                                                    ("particle_timevarying", 5, 51, 6, (0.3, 0.0), 1e-12), ("particle_fixed", 5, 51, 6, (0.3, 0.0), 1e-12),   # registry Particle / ParticleFixed
-                                                   ("swimmer", 10, 101, 6, (0.3, 0.0), 1e-9),       # registry Swimmer: inertia-box fluid forces, filter actuators, planar root (stepped with Euler)
+                                                   ("swimmer", 10, 101, 6, (0.3, 0.0), 1e-9),       # registry Swimmer: inertia-box fluid forces, filter actuators, planar root, the XML's full implicit integrator
                                                    ("quadrotor", 5, 51, 6, (0.3, 0.0), 1e-9),       # registry Quadrotor: site transmissions (thrust + reaction torque), 15 declared / 13 written residuals
                                                    ("linkage", 4, 80, 6, (0.5, 0.0), 1e-9),         # equality constraints: joint coupling across branches, four-bar connect, pinned free body
                                                    ("servo_arm", 4, 80, 6, (0.5, 0.0), 1e-9),       # mjINT_IMPLICITFAST: velocity servos, saturating force range, damped tendon
@@ -72,6 +72,31 @@ def test_tracking_motions_other_than_jump_kernel_source_matches_oracle(motion, t
     m0, task0, _ = humanoid_track(motion=0)
     a0 = ol.Oracle(m0, task0).plan(d["state"], d["mocap"], time0, kt, kv, 2, N, H, sigma=(0.15, 0.0), noise_eps=eps, noise_sel=sel, nthreads=4)
     assert _rel(a0["states"], a["states"]) < 1e-12 and _rel(a0["returns"], a["returns"]) > 1e-3
+
+
+@pytest.mark.parametrize("name, integrator, tol", [("swimmer", 3, 1e-9), ("swimmer", 0, 1e-9), ("servo_arm", 2, 1e-9), ("ball_chain", 2, 1e-5), ("humanoid_walk", 2, 1e-5),
+                                                   ("quadrotor", 2, 1e-9)])
+def test_implicit_integrators_kernel_source_matches_oracle(name, integrator, tol):
+    """mjINT_IMPLICIT (2) and implicitfast with fluid forces (swimmer, 3): the dense M - h dF/dv of the integration step - fluid
+    derivative, bias-force derivative by exact central differences over hinge chains (servo arm), ball joints (ball chain), a free
+    joint with ball / hinge limbs under contact (humanoid), site-driven free body (quadrotor) - and its LU solve, kernel source vs oracle"""
+    m, task, d = REGISTRY[name]()
+    m = dict(m); m["integrator"] = integrator
+    o = ol.Oracle(m, task)
+    P, H, N = 4, 40, 4
+    kt = np.linspace(0, (H - 1) * m["timestep"], P); kv = np.random.default_rng(0).uniform(-0.3, 0.3, (P, m["nu"]))
+    eps, sel = ol.noise(1, 0, 0, N, P, m["nu"])
+    mocap = d["mocap"] if len(d["mocap"]) else None
+    a = o.plan(d["state"], mocap, 0.0, kt, kv, 2, N, H, sigma=(0.3, 0.0), noise_eps=eps, noise_sel=sel, nthreads=4)
+    b = emu_lib.plan(m, task, d["state"], mocap, 0.0, kt, kv, 2, N, H, sigma=(0.3, 0.0), noise_eps=eps, noise_sel=sel)
+    assert not a["failure"].any() and not b["failure"].any()
+    for k in ("states", "residual", "costs", "returns"):
+        assert _rel(b[k], a[k]) < tol, k
+    # and the integrator matters: the same plan stepped with Euler ends elsewhere
+    if integrator == 2:
+        m0 = dict(m); m0["integrator"] = 0
+        a0 = ol.Oracle(m0, task).plan(d["state"], mocap, 0.0, kt, kv, 2, N, H, sigma=(0.3, 0.0), noise_eps=eps, noise_sel=sel, nthreads=4)
+        assert _rel(a0["states"], a["states"]) > 1e-7
 
 
 def test_tendon_friction_loss_kernel_source_matches_oracle():
@@ -186,12 +211,14 @@ def test_models_the_engine_cannot_roll_out_are_refused_at_create():
         else:
             assert n < 0 and expect in lib.mjpc_hip_last_error().decode(), lib.mjpc_hip_last_error()
     option("solver", 0, "Newton"); option("solver", 1, "Newton"); option("solver", 2, None)
-    option("integrator", 1, "Euler"); option("integrator", 2, "Euler"); option("integrator", 3, None)
-    option("density", 1000.0, None); option("viscosity", 0.1, None)                    # inertia-box fluid forces: taken with Euler ...
-    bf = ModelBuilder(integrator=3, density=10.0)                                       # ... refused with implicitfast (no velocity derivative)
-    bodyf = bf.body("a", 0, pos=(0, 0, 1)); bf.joint(bodyf, "f", FREE); bf.geom(bodyf, "g", SPHERE, size=(0.1,))
-    cmf = capi.CModel(bf.compile(), task)
-    assert lib.mjpc_hip_layout_bytes(ctypes.byref(cmf.c_model), ctypes.byref(cmf.c_task), 1) < 0 and b"fluid" in lib.mjpc_hip_last_error()        # RK4, implicit refused; implicitfast accepted
+    option("integrator", 1, "RK4"); option("integrator", 2, None); option("integrator", 3, None)       # RK4 refused; Euler, implicit, implicitfast accepted
+    option("density", 1000.0, None); option("viscosity", 0.1, None)                    # inertia-box fluid forces: with every accepted integrator
+    for integ in (2, 3):                                                                # (the implicit ones carry the fluid forces' velocity derivative since round 3)
+        bf = ModelBuilder(integrator=integ, density=10.0)
+        bodyf = bf.body("a", 0, pos=(0, 0, 1)); bf.joint(bodyf, "f", FREE); bf.geom(bodyf, "g", SPHERE, size=(0.1,))
+        cmf = capi.CModel(bf.compile(), task)
+        assert lib.mjpc_hip_layout_bytes(ctypes.byref(cmf.c_model), ctypes.byref(cmf.c_task), 1) > 0, lib.mjpc_hip_last_error()
+        assert lib.mjpc_hip_layout_bytes(ctypes.byref(cmf.c_model), ctypes.byref(cmf.c_task), 2) < 0 and b"dense-tier" in lib.mjpc_hip_last_error()
     option("noslip_iterations", 3, "noslip")
     option("disableflags", 1 << 6, "disableflags"); option("disableflags", 1 << 14, "disableflags")          # gravity, eulerdamp
     option("disableflags", (1 << 0) | (1 << 2) | (1 << 3) | (1 << 4) | (1 << 12), None)

@@ -860,3 +860,69 @@ def test_height_field_collider_against_closed_forms():
     # a box lying on the flat field touches many prisms (one contact each): the four deepest are kept
     c, n = _collide_hfield(hs, flat, 6, [0.2, 0.15, 0.05], [0.05, 0.02, 0.2 + 0.05 - 1e-3], I, 0.26)
     assert n == 4 and np.allclose(c[:, 0], -1e-3, atol=1e-5)
+
+
+def test_implicit_integrator_velocity_derivatives_against_finite_differences():
+    """mjINT_IMPLICIT (mj_implicit, mjd_smooth_vel): (a) d qfrc_bias / d qvel - the oracle takes it as the step-1 central difference
+    of its own RNE, exact because the bias force is a quadratic polynomial of qvel: checked here against small-step differences
+    AND by the polynomial identity itself (the same matrix from steps 1 and 1e-3); (b) the inertia-box fluid derivative
+    (mjd_inertiaBoxFluid), analytic in the oracle, against finite differences of qfrc_passive; (c) structure: the bias derivative of
+    a body at rest vanishes, the fluid one is symmetric positive semi-definite."""
+    from mujoco_mpc_amd.modelgen import humanoid_walk, swimmer
+    rng = np.random.default_rng(3)
+    for gen in (swimmer, humanoid_walk):
+        m, task, d = gen()
+        o = ol.Oracle(m, task)
+        nq, nv = m["nq"], m["nv"]
+        qpos = d["state"][:nq].copy()
+        qvel = rng.normal(0, 1.5, nv)
+        base = o.vel_derivatives(qpos, qvel)
+        assert base["warning"] == 0
+        for eps, tol in ((1e-3, 1e-9), (1e-6, 2e-6)):
+            fd_b = np.zeros((nv, nv)); fd_f = np.zeros((nv, nv))
+            for j in range(nv):
+                e = np.zeros(nv); e[j] = eps
+                p, q = o.vel_derivatives(qpos, qvel + e), o.vel_derivatives(qpos, qvel - e)
+                fd_b[:, j] = (p["qfrc_bias"] - q["qfrc_bias"]) / (2 * eps)
+                fd_f[:, j] = -(p["qfrc_passive"] - q["qfrc_passive"]) / (2 * eps)
+            scale = np.abs(base["dbias"]).max() + 1e-300
+            assert np.abs(fd_b - base["dbias"]).max() / scale < tol, (gen.__name__, eps)          # quadratic: step 1 == step 1e-3 to round-off
+            if gen is swimmer and eps == 1e-6:
+                damp = np.diag(m["dof_damping"])                                              # qfrc_passive also holds -damping * qvel
+                assert np.abs(fd_f - damp - base["dfluid"]).max() / (np.abs(base["dfluid"]).max() + 1e-300) < 1e-5
+        rest = o.vel_derivatives(qpos, np.zeros(nv))
+        assert np.abs(rest["dbias"]).max() < 1e-12
+        if gen is swimmer:
+            assert np.abs(base["dfluid"] - base["dfluid"].T).max() < 1e-12 * np.abs(base["dfluid"]).max()
+            assert np.linalg.eigvalsh(0.5 * (base["dfluid"] + base["dfluid"].T)).min() > -1e-9 * np.abs(base["dfluid"]).max()
+        else:
+            assert np.abs(base["dfluid"]).max() == 0.0
+        assert np.abs(base["dbias"] - base["dbias"].T).max() > 1e-3 * np.abs(base["dbias"]).max()     # really non-symmetric: LU, not Cholesky
+
+
+def test_implicit_integrator_step_solves_its_linear_system():
+    """one step of each integrator from the same state: v+ - v = h (M - h dF/dv)^-1 (qfrc_smooth + qfrc_constraint) with dF/dv =
+    -(damping + fluid derivative) for implicitfast and additionally -d bias / d qvel for implicit (mj_implicit); at rest all three
+    integrators coincide with Euler's implicit-damping step"""
+    from mujoco_mpc_amd.modelgen import swimmer
+    rng = np.random.default_rng(5)
+    steps = {}
+    for integ in (0, 3, 2):
+        m, task, d = swimmer(integrator=integ)
+        o = ol.Oracle(m, task)
+        nq, nv, h = m["nq"], m["nv"], m["timestep"]
+        qpos = d["state"][:nq].copy(); qvel = rng.normal(0, 2.0, nv) if integ == 0 else steps["qvel0"]
+        steps.setdefault("qvel0", qvel)
+        f = o.forward(qpos, qvel)
+        der = o.vel_derivatives(qpos, qvel)
+        rhs = f["qM"] @ f["qacc"]                      # = qfrc_smooth + qfrc_constraint (no constraints in the swimmer)
+        A = f["qM"] + h * np.diag(m["dof_damping"])
+        if integ in (2, 3):
+            A = A + h * der["dfluid"]
+        if integ == 2:
+            A = A + h * der["dbias"]
+        _, v1, _, _, w = o.step(qpos, qvel)
+        assert w == 0
+        assert np.abs((v1 - qvel) / h - np.linalg.solve(A, rhs)).max() < 1e-9 * np.abs(rhs).max()
+        steps[integ] = v1
+    assert np.abs(steps[2] - steps[3]).max() > 1e-6 and np.abs(steps[3] - steps[0]).max() > 1e-6          # the three really differ

@@ -74,6 +74,9 @@ enum {
                                  * tip velocity, control (6 residuals); int_data = [tip site] */
   MJPC_TASK_PARTICLE_FIXED = 12, /* particle.cc:68-73 ("ParticleFixed"): the same with goal = mocap_pos[0..1] */
   MJPC_TASK_SWIMMER = 14,        /* mjpc/tasks/swimmer/swimmer.cc:33-46: control (nu), nose - target in the plane (2); int_data = [nose geom, targets reached] */
+  MJPC_TASK_HUMANOID_INTERACT = 15, /* mjpc/tasks/humanoid/interact/interact.cc:31-186: int_data = [body torso, pelvis, foot_right, foot_left, head,
+                                  * shin_right, shin_left, has facing target, (body1, body2) x 5 (-1: pair not selected)]; dbl_data = [facing target
+                                  * x, y, (local_pos1[3], local_pos2[3]) x 5]; parameters = [head height goal, torso height goal] */
   MJPC_TASK_QUADROTOR = 13       /* mjpc/tasks/quadrotor/quadrotor.cc:37-60: position - goal, linear / angular velocity, control - hover thrust (13 of
                                  * the 15 declared residuals are written); int_data = [body, stage]; dbl_data = stage goals [nstage][7] */
 };

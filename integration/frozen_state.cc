@@ -14,6 +14,7 @@
 
 #include <mujoco/mujoco.h>
 #include "mjpc/task.h"
+#include "mjpc/tasks/humanoid/interact/interact.h"
 #include "mjpc/tasks/humanoid/tracking/tracking.h"
 #include "mjpc/tasks/quadruped/quadruped.h"
 #include "mjpc/utilities.h"
@@ -77,6 +78,20 @@ struct HipFrozenState {
     I = {SensorObject(m, "torso_position"), SensorObject(m, "pelvis_position"), SensorObject(m, "foot_right"),
          SensorObject(m, "foot_left"), SensorObject(m, "waist_lower_subcomvel")};
   }
+  // interact.cc:31-186: the bodies behind the task's sensors, then the contact key frame the GUI edits (ContactKeyframe: facing target,
+  // five (body, local point) pairs; private to Interact::ResidualFn - read under -fno-access-control like the other two)
+  static void Interact(const humanoid::Interact::ResidualFn& r, const mjModel* m, std::vector<int>& I, std::vector<double>& D) {
+    const humanoid::ContactKeyframe& kf = r.residual_keyframe_;
+    I = {SensorObject(m, "torso_position"), SensorObject(m, "pelvis_up"), SensorObject(m, "foot_right"), SensorObject(m, "foot_left"),
+         SensorObject(m, "head_position"), SensorObject(m, "knee_right"), SensorObject(m, "knee_left"), kf.facing_target.empty() ? 0 : 1};
+    D = {kf.facing_target.empty() ? 0.0 : kf.facing_target[0], kf.facing_target.size() < 2 ? 0.0 : kf.facing_target[1]};
+    for (int k = 0; k < humanoid::kNumberOfContactPairsInteract; k++) {
+      const humanoid::ContactPair& cp = kf.contact_pairs[k];
+      I.push_back(cp.body1); I.push_back(cp.body2);
+      for (int q = 0; q < 3; q++) D.push_back(cp.local_pos1[q]);
+      for (int q = 0; q < 3; q++) D.push_back(cp.local_pos2[q]);
+    }
+  }
   static void Hand(const mjModel* m, std::vector<int>& I) {            // hand.cc:37-84
     I = {SensorObject(m, "palm_position"), SensorObject(m, "cube_position"), SensorObject(m, "cube_goal_orientation"),
          0};                                   // hand.cc:75 reads key 0 (model->key_qpos)
@@ -123,6 +138,11 @@ void FillFrozenState(const Task& task, const ResidualFn* residual, const mjModel
     } break;
     case MJPC_TASK_HUMANOID_STAND: HipFrozenState::Stand(m, ints); break;
     case MJPC_TASK_HUMANOID_WALK: HipFrozenState::Walk(m, ints); break;
+    case MJPC_TASK_HUMANOID_INTERACT: {
+      auto* r = dynamic_cast<const humanoid::Interact::ResidualFn*>(residual);
+      if (!r) mju_error("HipSamplingPlanner: task 'Humanoid Interact' without an Interact::ResidualFn");
+      HipFrozenState::Interact(*r, m, ints, dbls);
+    } break;
     case MJPC_TASK_SHADOW_REORIENT: HipFrozenState::Hand(m, ints); break;
     case MJPC_TASK_QUADRUPED_HILL: HipFrozenState::Hill(m, task.mode > 0 ? task.mode - 1 : 0, ints, dbls); break;
     case MJPC_TASK_QUADROTOR: HipFrozenState::Quadrotor(m, task.mode > 0 ? task.mode - 1 : 0, ints, dbls); break;

@@ -32,6 +32,7 @@ int DeviceResidual(const Task& task) {
   if (name == "Humanoid Track") return MJPC_TASK_HUMANOID_TRACK;
   if (name == "Humanoid Stand") return MJPC_TASK_HUMANOID_STAND;
   if (name == "Humanoid Walk") return MJPC_TASK_HUMANOID_WALK;
+  if (name == "Humanoid Interact") return MJPC_TASK_HUMANOID_INTERACT;
   if (name == "Shadow") return MJPC_TASK_SHADOW_REORIENT;
   if (name == "Particle") return MJPC_TASK_PARTICLE_TIMEVARYING;
   if (name == "ParticleFixed") return MJPC_TASK_PARTICLE_FIXED;

@@ -301,6 +301,58 @@ DEV void residual_humanoid_stand(Ctx &c, double *residual) {
   PFOR(i, nv - 6) residual[4 + i] = c.qvel[6 + i];
   PFOR(i, nu) residual[4 + nv - 6 + i] = c.ctrl[i];
 }
+// mjpc/tasks/humanoid/interact/interact.cc:31-186.  int_data = [body torso, pelvis, foot_right, foot_left, head, shin_right, shin_left,
+// has facing target, (body1, body2) x 5]; dbl_data = [facing x, y, (local_pos1[3], local_pos2[3]) x 5]; 68 residuals
+DEV void residual_humanoid_interact(Ctx &c, double *residual) {
+  const DevModel &M = *c.M;
+  const int *I = MI(task.int_data);
+  const double *P = MD(task.parameters), *D = MD(task.dbl_data);
+  const int nv = M.nv, nu = M.nu;
+  const int torso = I[0], pelvis = I[1], fr = I[2], fl = I[3], head = I[4], kr = I[5], kl = I[6];
+  if (LANE == 0) {
+    residual[0] = fabs(c.xmat[9 * torso + 8] - 1.0);
+    residual[1] = fabs(c.xmat[9 * pelvis + 8] - 1.0);
+    residual[2] = fabs(c.xmat[9 * fr + 8] - 1.0);
+    residual[3] = fabs(c.xmat[9 * fl + 8] - 1.0);
+    residual[4] = fabs(c.xipos[3 * head + 2] - P[0]);
+    residual[5] = fabs(c.xipos[3 * torso + 2] - P[1]);
+    const double *knee_right = c.xipos + 3 * kr, *knee_left = c.xipos + 3 * kl, *foot_right = c.xipos + 3 * fr, *foot_left = c.xipos + 3 * fl;
+    double kx = (knee_left[0] + knee_right[0]) * 0.5, ky = (knee_left[1] + knee_right[1]) * 0.5;
+    double fx = (foot_left[0] + foot_right[0]) * 0.5, fy = (foot_left[1] + foot_right[1]) * 0.5;
+    kx -= fx; ky -= fy;
+    residual[6] = sqrt(kx * kx + ky * ky);
+    double cx = c.subtree_com[3 * torso] - fx, cy = c.subtree_com[3 * torso + 1] - fy;
+    residual[7] = sqrt(cx * cx + cy * cy);
+    if (!I[7]) residual[8] = 0;
+    else {
+      const double *xi = c.ximat + 9 * torso, *tp = c.xipos + 3 * torso;
+      double tx = D[0] - tp[0], ty = D[1] - tp[1];
+      double n = sqrt(tx * tx + ty * ty);
+      if (n < D_MINVAL) { tx = 1; ty = 0; } else { tx = d_div(tx, n); ty = d_div(ty, n); }
+      tx -= xi[0]; ty -= xi[3];
+      residual[8] = sqrt(tx * tx + ty * ty);
+    }
+    double tv[3];
+    body_linvel(c, torso, tv);
+    residual[9] = tv[0]; residual[10] = tv[1];
+  }
+  PFOR(i, nv - 6) residual[11 + i] = c.qvel[6 + i];
+  PFOR(i, nu) residual[11 + nv - 6 + i] = c.ctrl[i];
+  const int o = 11 + nv - 6 + nu;
+  PFOR(e, 15) {
+    const int i = e / 3, k = e - 3 * i;
+    const int b1 = I[8 + 2 * i], b2 = I[9 + 2 * i];
+    double r = 0;
+    if (b1 >= 0 && b2 >= 0) {
+      const double *l1 = D + 2 + 6 * i, *l2 = l1 + 3;
+      const double *R1 = c.xmat + 9 * b1 + 3 * k, *R2 = c.xmat + 9 * b2 + 3 * k;
+      double g1 = (R1[0] * l1[0] + R1[1] * l1[1] + R1[2] * l1[2]) + c.xpos[3 * b1 + k];
+      double g2 = (R2[0] * l2[0] + R2[1] * l2[1] + R2[2] * l2[2]) + c.xpos[3 * b2 + k];
+      r = fabs(g1 - g2);
+    }
+    residual[o + e] = r;
+  }
+}
 // mjpc/tasks/humanoid/walk/walk.cc:44-166.  int_data = [body torso, pelvis, foot_right, foot_left, waist_lower]
 DEV void residual_humanoid_walk(Ctx &c, double *residual) {
   const DevModel &M = *c.M;
@@ -403,6 +455,8 @@ DEV void task_residual(Ctx &c, double *residual) {
     residual_humanoid_stand(c, residual);
   } else if (id == 6) {
     residual_humanoid_walk(c, residual);
+  } else if (id == 15) {
+    residual_humanoid_interact(c, residual);
   } else if (id == 7) {
     residual_shadow(c, residual);
   } else if (id == 8) {   // walker.cc:39-57: control, torso height - goal, torso z axis z - 1, subtree x velocity - goal

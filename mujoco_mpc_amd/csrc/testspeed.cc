@@ -389,7 +389,19 @@ static void SwimmerTransition(const MjpcHipModel& m, SimState& s, HostTask& t, c
   }
 }
 
+// Interact::TransitionLocked (interact.cc:191-197): a mode change installs that mode's row of default_weights (interact.h:40-45)
+static const double kInteractWeights[4][13] = {{10, 10, 5, 5, 0, 20, 30, 0, 0, 0, 0.01, .1, 80.}, {10, 0, 1, 1, 80, 0, 0, 100, 0, 0, 0.01, 0.025, 0.},
+                                               {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0.01, .8, 80.}, {0, 0, 0, 0, 0, 0, 0, 0, 0, 50, 20, .025, 80.}};
+
 TransitionFn TransitionForTask(int task_id, int mode, double mode_time) {
+  if (task_id == MJPC_TASK_HUMANOID_INTERACT) {
+    auto current = std::make_shared<int>(0);                 // residual_.current_task_mode_ starts as kSitting
+    return [current, mode, mode_time](const MjpcHipModel&, SimState& s, HostTask& t, const SimFrame&) {
+      int want = s.time >= mode_time ? mode : 0;
+      if (want < 0 || want > 3) want = 0;
+      if (*current != want) { *current = want; for (size_t k = 0; k < t.weight.size() && k < 13; k++) t.weight[k] = kInteractWeights[want][k]; }
+    };
+  }
   if (task_id == MJPC_TASK_SWIMMER) return SwimmerTransition;
   if (task_id == MJPC_TASK_QUADROTOR) return QuadrotorTransition;
   if (task_id == MJPC_TASK_PARTICLE_TIMEVARYING) return ParticleTransition;

@@ -535,6 +535,53 @@ def humanoid_walk(timestep=0.015):
     return m, task, dict(N=10, P=3, sigma=(0.05, 0.0), interp=0, horizon=24, state=state, mocap=np.zeros(0))
 
 
+TASK_HUMANOID_INTERACT = 15
+INTERACT_MODES = ("Sit Down", "Stand Up", "Relax", "Stay Still")
+# default_weights of interact.h:40-45 (one row per mode; Transition copies the row on a mode change, interact.cc:191-197)
+INTERACT_WEIGHTS = [[10, 10, 5, 5, 0, 20, 30, 0, 0, 0, 0.01, .1, 80.], [10, 0, 1, 1, 80, 0, 0, 100, 0, 0, 0.01, 0.025, 0.],
+                    [0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0.01, .8, 80.], [0, 0, 0, 0, 0, 0, 0, 0, 0, 50, 20, .025, 80.]]
+_INTERACT_HOME = [-0.3729, -0.0358, 0.9018, 0.99555, 0.05669, -0.05346, 0.05304, 0.070186, 0.28932, 0.04422, -0.07611, -0.40237, -1.80319, -1.75152,
+                  -0.02876, -0.02198, 0.179219, 0.093576, -1.67581, -1.49138, 0.01844, -0.06467, 0.677519, -0.82367, -0.94849, 0.859786, -0.88692, -1.14922]
+
+
+def humanoid_interact(timestep=0.015, contact_pairs=(), facing_target=None):
+    """mjpc/tasks/humanoid/interact (interact.cc:31-186, task.xml, scenes/armchair.xml): the modified dm_control humanoid next to an
+    armchair (a static body of five boxes, scenes/armchair.xml:3-9), 13 cost terms over 68 residuals: up-vectors of torso / pelvis /
+    feet, head and torso height goals, knee-feet and com-feet distances in the plane, facing direction, com velocity, joint
+    velocities, controls, and the distances of up to five user-chosen contact pairs (body, local point) x 2 - none by default, as in
+    the reference (ContactKeyframe() is empty until the GUI fills it); the `home` key of the scene (humanoid seated in front of
+    the chair... standing pose of armchair.xml:28-58) is the default state.  The XML's cost weights are the start-up weights; the
+    per-mode rows INTERACT_WEIGHTS are what the host Transition installs on a mode change."""
+    b, sites, torso = _humanoid_model(timestep, False)
+    chair = b.body("chair", 0, pos=(-0.35, 0, 0.2))
+    box = dict(condim=3, friction=(1, 0.005, 0.0001))
+    b.geom(chair, "seat", BOX, size=(.25, .35, .05), pos=(0, 0, 0.12), mass=10.0, **box)
+    b.geom(chair, "seat_base", BOX, size=(.30, .35, .15), pos=(-0.12, 0, -0.05), mass=10.0, **box)
+    b.geom(chair, "back", BOX, size=(.05, .35, .3), pos=(-0.35, 0, 0.35), quat=(0.984, 0, -0.178, 0), mass=10.0, **box)
+    b.geom(chair, "chair_leg_1", BOX, size=(.3, .05, .3), pos=(-0.12, 0.37, 0.1), mass=5.0, **box)
+    b.geom(chair, "chair_leg_2", BOX, size=(.3, .05, .3), pos=(-0.12, -0.37, 0.1), mass=5.0, **box)
+    b.key("home", _INTERACT_HOME)
+    m = b.compile()
+    bid = m["names"]["body"]
+    pairs = list(contact_pairs)[:5]
+    ints = [bid["torso"], bid["pelvis"], bid["foot_right"], bid["foot_left"], bid["head"], bid["shin_right"], bid["shin_left"],
+            1 if facing_target is not None else 0]
+    dbls = list(facing_target) if facing_target is not None else [0.0, 0.0]
+    for k in range(5):
+        if k < len(pairs):
+            b1, p1, b2, p2 = pairs[k]
+            ints += [bid[b1] if isinstance(b1, str) else int(b1), bid[b2] if isinstance(b2, str) else int(b2)]
+            dbls += list(p1) + list(p2)
+        else:
+            ints += [-1, -1]
+            dbls += [0.0] * 6
+    terms = [(1, 6, 10.0, [0.1]), (1, 6, 10.0, [0.1]), (1, 6, 5.0, [0.1]), (1, 6, 5.0, [0.1]), (1, 6, 0.0, [0.1]), (1, 6, 20.0, [0.1]),
+             (1, 6, 30.0, [0.1]), (1, 6, 0.0, [0.1]), (1, 6, 0.0, [0.1]), (2, 0, 10.0), (21, 0, 0.01), (21, 3, 0.8, [0.05]), (15, 6, 100.0, [0.1])]
+    task = make_task(TASK_HUMANOID_INTERACT, terms, parameters=[1.4, 1.3], traces=[(OBJ_BODY, torso)], int_data=ints, dbl_data=dbls)
+    state = np.concatenate([np.array(_INTERACT_HOME), np.zeros(m["nv"])])
+    return m, task, dict(N=10, P=3, sigma=(0.05, 0.0), interp=0, horizon=24, state=state, mocap=np.zeros(0))
+
+
 # ----------------------------------------------------------------------------------- Shadow hand + cube (BASELINE configs[4])
 # mjpc/tasks/shadow_reorient/task.xml is local (floor, goal body, cost table, planner numerics, the 35-value `grasp` key), so is
 # the cube (common_assets/reorientation_cube.xml + cube.xml.patch: half size 0.022, 0.126 kg, at 0.325 0 0.075,
@@ -850,4 +897,4 @@ def terrain_balls(timestep=0.004):
     return m, task, defaults
 
 
-REGISTRY = {"swimmer": swimmer, "quadrotor": quadrotor, "linkage": linkage, "servo_arm": servo_arm, "particle_timevarying": particle_task, "particle_fixed": lambda: particle_task(fixed=True), "filter_arm": filter_arm, "ball_chain_friction": lambda: ball_chain(tendon_frictionloss=0.3), "quadruped_hill": quadruped_hill, "terrain_balls": terrain_balls, "walker": walker, "acrobot": acrobot, "ball_chain": ball_chain, "cylinder_pile": cylinder_pile, "humanoid_stand": humanoid_stand, "humanoid_walk": humanoid_walk, "particle": particle, "cartpole": cartpole, "quadruped": quadruped, "humanoid_track": humanoid_track, "shadow_hand": shadow_hand}
+REGISTRY = {"humanoid_interact": humanoid_interact, "swimmer": swimmer, "quadrotor": quadrotor, "linkage": linkage, "servo_arm": servo_arm, "particle_timevarying": particle_task, "particle_fixed": lambda: particle_task(fixed=True), "filter_arm": filter_arm, "ball_chain_friction": lambda: ball_chain(tendon_frictionloss=0.3), "quadruped_hill": quadruped_hill, "terrain_balls": terrain_balls, "walker": walker, "acrobot": acrobot, "ball_chain": ball_chain, "cylinder_pile": cylinder_pile, "humanoid_stand": humanoid_stand, "humanoid_walk": humanoid_walk, "particle": particle, "cartpole": cartpole, "quadruped": quadruped, "humanoid_track": humanoid_track, "shadow_hand": shadow_hand}

@@ -417,6 +417,55 @@ static void residual_humanoid_stand(const OModel *om, OData *d, double *residual
   o_copy(residual + counter, d->ctrl, m->nu); counter += m->nu;
 }
 
+/* mjpc/tasks/humanoid/interact/interact.cc:31-186 (sensors of task.xml:52-68: framezaxis of the xbody frames = column 2 of xmat,
+ * framepos / framexaxis / framelinvel of a body = its inertial frame, subtreecom).  int_data = [body torso, pelvis, foot_right,
+ * foot_left, head, shin_right, shin_left, has facing target, (body1, body2) x 5]; dbl_data = [facing x, y, (local1, local2) x 5] */
+static void residual_humanoid_interact(const OModel *om, OData *d, double *residual) {
+  const MjpcHipModel *m = &om->m;
+  const int *I = om->t.int_data;
+  const double *P = om->t.parameters, *D = om->t.dbl_data;
+  int torso = I[0], pelvis = I[1], fr = I[2], fl = I[3], head = I[4], kr = I[5], kl = I[6];
+  int counter = 0;
+  residual[counter++] = fabs(d->xmat[9 * torso + 8] - 1.0);
+  residual[counter++] = fabs(d->xmat[9 * pelvis + 8] - 1.0);
+  residual[counter++] = fabs(d->xmat[9 * fr + 8] - 1.0);
+  residual[counter++] = fabs(d->xmat[9 * fl + 8] - 1.0);
+  residual[counter++] = fabs(d->xipos[3 * head + 2] - P[0]);
+  residual[counter++] = fabs(d->xipos[3 * torso + 2] - P[1]);
+  const double *knee_right = d->xipos + 3 * kr, *knee_left = d->xipos + 3 * kl, *foot_right = d->xipos + 3 * fr, *foot_left = d->xipos + 3 * fl;
+  double knee[2] = {0, 0}, foot[2] = {0, 0};
+  knee[0] += knee_left[0]; knee[1] += knee_left[1]; knee[0] += knee_right[0]; knee[1] += knee_right[1]; knee[0] *= 0.5; knee[1] *= 0.5;
+  foot[0] += foot_left[0]; foot[1] += foot_left[1]; foot[0] += foot_right[0]; foot[1] += foot_right[1]; foot[0] *= 0.5; foot[1] *= 0.5;
+  knee[0] -= foot[0]; knee[1] -= foot[1];
+  residual[counter++] = sqrt(knee[0] * knee[0] + knee[1] * knee[1]);
+  double com[2] = {d->subtree_com[3 * torso] - foot[0], d->subtree_com[3 * torso + 1] - foot[1]};
+  residual[counter++] = sqrt(com[0] * com[0] + com[1] * com[1]);
+  if (!I[7]) residual[counter++] = 0;
+  else {
+    const double *xi = d->ximat + 9 * torso, *tp = d->xipos + 3 * torso;
+    double target[2] = {D[0] - tp[0], D[1] - tp[1]};
+    double n = sqrt(target[0] * target[0] + target[1] * target[1]);
+    if (n < O_MINVAL) { target[0] = 1; target[1] = 0; } else { target[0] /= n; target[1] /= n; }      /* mju_normalize */
+    target[0] -= xi[0]; target[1] -= xi[3];
+    residual[counter++] = sqrt(target[0] * target[0] + target[1] * target[1]);
+  }
+  double tv[3];
+  body_linvel(om, d, torso, tv);                          /* the sensor named torso_subtreelinvel is a framelinvel of the torso body */
+  residual[counter++] = tv[0]; residual[counter++] = tv[1];
+  o_copy(residual + counter, d->qvel + 6, m->nv - 6); counter += m->nv - 6;
+  o_copy(residual + counter, d->ctrl, m->nu); counter += m->nu;
+  for (int i = 0; i < 5; i++) {
+    int b1 = I[8 + 2 * i], b2 = I[9 + 2 * i];
+    if (b1 >= 0 && b2 >= 0) {
+      const double *l1 = D + 2 + 6 * i, *l2 = l1 + 3;
+      double g1[3], g2[3];
+      o_mulmatvec3(g1, d->xmat + 9 * b1, l1); o_add3(g1, g1, d->xpos + 3 * b1);
+      o_mulmatvec3(g2, d->xmat + 9 * b2, l2); o_add3(g2, g2, d->xpos + 3 * b2);
+      for (int k = 0; k < 3; k++) residual[counter++] = fabs(g1[k] - g2[k]);
+    } else for (int k = 0; k < 3; k++) residual[counter++] = 0;
+  }
+}
+
 /* mjpc/tasks/humanoid/walk/walk.cc:44-166.  int_data = [body torso, pelvis, foot_right, foot_left, waist_lower] */
 static void residual_humanoid_walk(const OModel *om, OData *d, double *residual) {
   const MjpcHipModel *m = &om->m;
@@ -531,6 +580,9 @@ void oracle_residual(const OModel *om, OData *d, double *residual) {
       break;
     case MJPC_TASK_HUMANOID_WALK:
       residual_humanoid_walk(om, d, residual);
+      break;
+    case MJPC_TASK_HUMANOID_INTERACT:
+      residual_humanoid_interact(om, d, residual);
       break;
     case MJPC_TASK_SHADOW_REORIENT:
       residual_shadow(om, d, residual);

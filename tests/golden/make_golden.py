@@ -25,6 +25,7 @@ CONFIGS = {
     "particle_10x11": ("particle", 10, 11, 11, 2, 0.01, False),             # test fixture of rollout_test / sampling_planner_test
     "quadruped_8x30": ("quadruped", 8, 30, 3, 2, 0.04, False),              # configs[1]/[3] model, reduced size
     "humanoid_track_4x24": ("humanoid_track", 4, 24, 16, 2, 0.15, False),   # configs[2] model, reduced size
+    "humanoid_interact_4x24": ("humanoid_interact", 4, 24, 3, 0, 0.05, False),   # registry Humanoid Interact (task.xml:31-37: horizon 0.35 s, 3 zero-order points, exploration 0.05), from the scene's home key
     "shadow_hand_6x24": ("shadow_hand", 6, 24, 5, 0, 0.1, True),            # configs[4] model (synthetic hand), reduced size
     "walker_10x80": ("walker", 10, 80, 3, 2, 0.5, False),                   # mjpc/tasks/walker/task.xml:10-15 (horizon 0.8 s, 3 points, exploration 0.5)
     "acrobot_10x100": ("acrobot", 10, 100, 10, 2, 0.05, False),             # mjpc/tasks/acrobot/task.xml:9-17, half the horizon

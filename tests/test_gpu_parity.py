@@ -1124,6 +1124,34 @@ def test_full_implicit_integrator_matches_oracle(name, tol):
 
 
 @pytest.mark.gpu
+def test_humanoid_interact_task_and_its_mode_transition():
+    """mjpc/tasks/humanoid/interact (interact.cc:31-197): the humanoid at the armchair, 68 residuals; plan-step parity with the oracle
+    from the scene's home key, without and with contact pairs / a facing target in the frozen state; closed loop: the harness's
+    Transition installs the mode's weight row (interact.h:40-45), so 'Stand Up' (head-height weight 80) ends with the head higher
+    than 'Sit Down' does from the same start."""
+    from mujoco_mpc_amd import cplanner
+    from mujoco_mpc_amd.modelgen import humanoid_interact
+    m, task, d = humanoid_interact()
+    out, ref, allc = _compare(m, task, d, 3, 24, 8, (0.05, 0.0), 0, 1e-5, nominal_scale=0.2)
+    assert allc["residual"].shape[-1] == 68 and not out["failure"].any() and allc["diag"][:, 1].max() >= 1       # contacts (floor / chair)
+    pairs = [("hand_right", (0.0, 0.0, -0.05), "chair", (0.1, 0.3, 0.2)), ("pelvis", (0.0, 0.0, -0.1), 0, (-0.35, 0.0, 0.4))]
+    m2, task2, d2 = humanoid_interact(contact_pairs=pairs, facing_target=(1.0, 2.0))
+    _, _, allc2 = _compare(m2, task2, d2, 3, 24, 8, (0.05, 0.0), 0, 1e-5, nominal_scale=0.2)
+    assert np.abs(allc2["residual"][..., 53:59]).max() > 0.05 and np.abs(allc2["residual"][..., 8]).max() > 0.05
+    heights = {}
+    for mode in (0, 1):
+        num = dict(sampling_spline_points=3, sampling_exploration=0.05, sampling_trajectories=128, sampling_representation=0)
+        p = cplanner.SamplingPlanner()
+        p.Initialize(m, task, num, max_samples=128, max_horizon=24)
+        p.Reset(24)
+        res = cplanner.testspeed(p, d["state"], None, horizon=24, steps_per_planning_iteration=1, total_time=1.5, mode=mode, mode_time=0.0)
+        p.close()
+        assert not res["failure"]
+        heights[mode] = res["state"][2]
+    assert heights[1] > heights[0] + 0.05, heights
+
+
+@pytest.mark.gpu
 def test_quadrotor_task_site_transmissions_and_transition():
     """mjpc/tasks/quadrotor (quadrotor.cc:37-95): four thrust motors through site transmissions (moment = site Jacobian of the gear
     wrench).  Plan-step parity around the hover thrust; closed loop with the host Transition from a hover 0.8 m short of the first

@@ -33,7 +33,8 @@ def _rel(a, b):
                                                    ("filter_arm", 4, 80, 6, (0.4, 0.0), 1e-9),      # activation states: filter / filterexact / clamped integrator actuators
                                                    ("ball_chain", 4, 60, 6, (0.4, 0.0), 1e-5),      # limited ball joints, tendon spring / damper / cross-branch limit
                                                    ("humanoid_track", 16, 30, 4, (0.15, 0.0), 1e-5),
-                                                   ("humanoid_stand", 3, 24, 4, (0.05, 0.0), 1e-5), ("humanoid_walk", 3, 24, 4, (0.05, 0.0), 1e-5)])
+                                                   ("humanoid_stand", 3, 24, 4, (0.05, 0.0), 1e-5), ("humanoid_walk", 3, 24, 4, (0.05, 0.0), 1e-5),
+                                                   ("humanoid_interact", 3, 24, 4, (0.05, 0.0), 1e-5)])    # registry Humanoid Interact: humanoid + armchair (capsule-box contacts), 68 residuals
 def test_kernel_source_matches_oracle(name, P, H, N, sigma, tol):
     m, task, d = REGISTRY[name]()
     o = ol.Oracle(m, task)

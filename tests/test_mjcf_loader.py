@@ -225,6 +225,31 @@ def test_cost_tables_and_agent_numerics_of_the_late_registry_tasks(rel, missing,
         assert info["numeric"]["sampling_exploration"] == [d["sigma"][0]]
 
 
+def test_humanoid_interact_xml_matches_generator():
+    """tasks/humanoid/interact/task.xml + scenes/armchair.xml (both local; the humanoid itself is the patched dm_control file the
+    other humanoid tasks share): cost table, residual parameters, agent numerics, the chair's five boxes and the scene's home key"""
+    b, info = mjcf.parse_mjcf(os.path.join(REF, "tasks/humanoid/interact/task.xml"), missing_ok=("humanoid_modified.xml",))
+    m2, task, d = tasks.humanoid_interact()
+    assert _xml_terms(info) == _terms_of(task)
+    assert [info["numeric"]["residual_Head Height"][0], info["numeric"]["residual_Torso Height"][0]] == list(task["parameters"])
+    assert info["numeric"]["agent_timestep"] == [m2["timestep"]] and info["numeric"]["sampling_spline_points"] == [d["P"]]
+    assert info["numeric"]["sampling_exploration"] == [d["sigma"][0]] and round(info["numeric"]["agent_horizon"][0] / m2["timestep"]) + 1 >= d["horizon"] - 1
+    home = next(k for k in info["keys"] if k["name"] == "home")
+    assert np.allclose(home["qpos"], d["state"][:m2["nq"]], atol=0)
+    chair = next(bd for bd in b.bodies if bd.name == "chair")
+    cid = m2["names"]["body"]["chair"]
+    assert np.allclose(chair.pos, np.asarray(m2["body_pos"]).reshape(-1, 3)[cid])
+    mx = b.compile()
+    gx = [g for g in range(mx["ngeom"]) if mx["geom_bodyid"][g] == mx["names"]["body"]["chair"]]
+    g2 = [g for g in range(m2["ngeom"]) if m2["geom_bodyid"][g] == cid]
+    assert len(gx) == len(g2) == 5
+    for a, c in zip(gx, g2):
+        for k, w in (("geom_size", 3), ("geom_pos", 3), ("geom_quat", 4), ("geom_friction", 3)):
+            assert np.allclose(np.asarray(mx[k]).reshape(-1, w)[a], np.asarray(m2[k]).reshape(-1, w)[c], atol=1e-12), k
+        assert mx["geom_type"][a] == m2["geom_type"][c] and mx["geom_condim"][a] == m2["geom_condim"][c]
+    assert tasks.INTERACT_MODES == tuple(info["text"]["task_transition"].split("|")) if "text" in info else True
+
+
 def test_loader_attributes_of_the_late_features():
     """<option density / viscosity / wind / integrator>, body gravcomp, joint actuatorfrcrange, <velocity> actuators, filter dynamics and
     <equality> are outside the reference files above: a small inline document"""

@@ -926,3 +926,48 @@ def test_implicit_integrator_step_solves_its_linear_system():
         assert np.abs((v1 - qvel) / h - np.linalg.solve(A, rhs)).max() < 1e-9 * np.abs(rhs).max()
         steps[integ] = v1
     assert np.abs(steps[2] - steps[3]).max() > 1e-6 and np.abs(steps[3] - steps[0]).max() > 1e-6          # the three really differ
+
+
+def test_humanoid_interact_residual_against_closed_forms():
+    """interact.cc:31-186 on the oracle, in a tilted pose at rest and in motion: every term from the numpy kinematics of the model
+    generator (xmat columns, inertial-frame positions), independent of the oracle's own kinematics; contact pairs and the facing target
+    (empty in the reference's default key frame) are exercised through the frozen state."""
+    from mujoco_mpc_amd.modelgen import humanoid_interact, kinematics
+    pairs = [("hand_right", (0.0, 0.0, -0.05), "chair", (0.1, 0.3, 0.2)), ("pelvis", (0.0, 0.0, -0.1), 0, (-0.35, 0.0, 0.4))]
+    m, task, d = humanoid_interact(contact_pairs=pairs, facing_target=(1.0, 2.0))
+    assert task["num_residual"] == 68 and task["num_term"] == 13
+    o = ol.Oracle(m, task)
+    nq, nv, nu = m["nq"], m["nv"], m["nu"]
+    qpos = d["state"][:nq].copy()
+    rng = np.random.default_rng(0)
+    qvel = rng.normal(0, 0.3, nv); ctrl = rng.uniform(-0.5, 0.5, nu)
+    r = o.forward(qpos, qvel, ctrl)["sensordata"]
+    xpos, xquat, xmat, _, _ = kinematics(m, qpos)
+    xmat = np.asarray(xmat).reshape(-1, 3, 3); xpos = np.asarray(xpos).reshape(-1, 3)
+    xipos = xpos + np.einsum("bij,bj->bi", xmat, np.asarray(m["body_ipos"]).reshape(-1, 3))
+    b = m["names"]["body"]
+    for k, name in enumerate(("torso", "pelvis", "foot_right", "foot_left")):
+        assert abs(r[k] - abs(xmat[b[name]][2, 2] - 1.0)) < 1e-12
+    assert abs(r[4] - abs(xipos[b["head"]][2] - 1.4)) < 1e-12 and abs(r[5] - abs(xipos[b["torso"]][2] - 1.3)) < 1e-12
+    knee = 0.5 * (xipos[b["shin_left"]][:2] + xipos[b["shin_right"]][:2]); foot = 0.5 * (xipos[b["foot_left"]][:2] + xipos[b["foot_right"]][:2])
+    assert abs(r[6] - np.linalg.norm(knee - foot)) < 1e-12
+    f = o.forward(qpos, qvel, ctrl)
+    assert abs(r[7] - np.linalg.norm(f["subtree_com"][b["torso"]][:2] - foot)) < 1e-12
+    ximat_t = xmat[b["torso"]] @ _quat2mat(np.asarray(m["body_iquat"]).reshape(-1, 4)[b["torso"]])
+    tgt = np.array([1.0, 2.0]) - xipos[b["torso"]][:2]; tgt /= np.linalg.norm(tgt)
+    assert abs(r[8] - np.linalg.norm(tgt - ximat_t[:2, 0])) < 1e-12
+    assert np.allclose(r[11:32], qvel[6:], atol=0) and np.allclose(r[32:53], ctrl, atol=0)
+    g1 = xpos[b["hand_right"]] + xmat[b["hand_right"]] @ np.array(pairs[0][1]); g2 = xpos[b["chair"]] + xmat[b["chair"]] @ np.array(pairs[0][3])
+    assert np.allclose(r[53:56], np.abs(g1 - g2), atol=1e-12)
+    g1 = xpos[b["pelvis"]] + xmat[b["pelvis"]] @ np.array(pairs[1][1])
+    assert np.allclose(r[56:59], np.abs(g1 - np.array(pairs[1][3])), atol=1e-12) and np.all(r[59:68] == 0)
+    # the reference's default: no pairs, no facing target -> those terms vanish; at rest the velocity terms do too
+    m0, task0, d0 = humanoid_interact()
+    r0 = ol.Oracle(m0, task0).forward(qpos)["sensordata"]
+    assert r0[8] == 0 and np.all(r0[53:] == 0) and np.all(r0[9:53] == 0) and np.allclose(r0[:8], r[:8], atol=1e-12)
+
+
+def _quat2mat(q):
+    w, x, y, z = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)], [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                     [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])

@@ -264,7 +264,8 @@ DEV_NOINLINE void ph_init(KP Kc) {
   PFOR(i, nq) { c.qpos[i] = K->state[i]; R.states[i] = K->state[i]; }
   PFOR(i, nv) { c.qvel[i] = K->state[nq + i]; R.states[nq + i] = K->state[nq + i]; c.qacc_ws[i] = 0; }
   if (M.na) PFOR(i, M.na) { C_ACT(c)[i] = K->state[nq + nv + i]; R.states[nq + nv + i] = K->state[nq + nv + i]; C_ACTDOT(c)[i] = 0; }
-  PFOR(e, nv * M.nvp) { c.qM[e] = 0; c.qH[e] = 0; }
+  PFOR(e, nv * M.nvp) c.qM[e] = 0;
+  if (K->L.Linv - K->L.qH >= nv * M.nvp) PFOR(e, nv * M.nvp) c.qH[e] = 0;      // (no qH in the layout of a one-column-group register solve)
 #ifndef MJPC_LEAN_LDS
   PFOR(e, M.nhpair + nv) c.hpair[e] = MI(hpair_i)[e] | (MI(hpair_j)[e] << 8);
 #endif

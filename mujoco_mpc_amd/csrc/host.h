@@ -96,7 +96,9 @@ static inline void make_layout(const PackedModel &p, Lay &L, const MjpcHipModel 
   A_(subtree_com, 3 * nb); B_(cinert, 10 * nb); B_(crb, 10 * nb); A_(cdof, 6 * nv + 18); A_(cvel, 6 * nb); B_(cdof_dot, 6 * nv + 18);
   B_(cacc, 6 * nb); B_(cfrc, 6 * nb); B_(cfrc_sub, 6 * nb); A_(subtree_linvel, 3 * nb); A_(bodytmp, 3 * nb);
 #undef B_
-  A_(qM, nv * nvp + 1); A_(qL, nv * nvp + 1); A_(qH, nv * nvp + 1); A_(Linv, nv + 1); A_(Hinv, nv + 1);
+  A_(qM, nv * nvp + 1); A_(qL, nv * nvp + 1);
+  A_(qH, (lean && reg_solver && nv > 32) ? 1 : nv * nvp + 1);      // dense tier, one column group (64 / nv == 1): the register solve factors straight from its row registers, no Hessian in LDS
+  A_(Linv, nv + 1); A_(Hinv, nv + 1);
   // efc_JA holds the scaled rows of the Newton Hessian: the active contact rows (padded to 8) + one negative row per cone
   // contact (padded to 4)
   int ja_rows = ((ne - M.nfric + 7) & ~7) + (m->cone == MJPC_CONE_ELLIPTIC ? ((nc + 3) & ~3) : 0) + 4 + ((M.ntfric + 3) & ~3);

@@ -75,7 +75,7 @@ template <int N>
 struct LDLRegs { double lo[N], up[N], rinv; };
 // the matrix to factor may arrive as a sum: A plus up to three partial matrices of the same layout (the worker waves' partial
 // Hessians, solver_reg.h); they are added while the rows are loaded
-struct LDLExtra { const double *x[3]; int n; };
+struct LDLExtra { const double *x[3]; int n; const double *row; };      // row != nullptr: lane i already holds the full symmetric row i of A in registers (A itself is not read)
 
 template <int I, int E, class F>
 DEV void static_for(F &&f) {
@@ -88,8 +88,14 @@ template <int N>
 DEV void ldl_load_row(const double *A, int nvp, const LDLExtra *ex, double *a, double &dg) {
   const int i = LANE;
   const bool act = i < N;
-  static_for<0, N>([&](auto jc) { constexpr int j = decltype(jc)::value; a[j] = act ? A[(j <= i) ? i * nvp + j : j * nvp + i] : 0.0; });
-  dg = act ? A[i * nvp + i] : 1.0;
+  if (ex && ex->row) {
+    double d0 = 1.0;
+    static_for<0, N>([&](auto jc) { constexpr int j = decltype(jc)::value; a[j] = act ? ex->row[j] : 0.0; d0 = (j == i) ? ex->row[j] : d0; });
+    dg = act ? d0 : 1.0;
+  } else {
+    static_for<0, N>([&](auto jc) { constexpr int j = decltype(jc)::value; a[j] = act ? A[(j <= i) ? i * nvp + j : j * nvp + i] : 0.0; });
+    dg = act ? A[i * nvp + i] : 1.0;
+  }
   if (ex && ex->n > 0) {
     const int nx = ex->n;
     double t[3][N], td[3];

@@ -6,5 +6,5 @@
 #define MJPC_NO_MODEL_CACHE 1
 #define MJPC_MIN_BLOCKS 2
 #define MJPC_LEAN_LDS 1
-#define MJPC_TU_NVT_LIST(X) X(18) X(27)
+#define MJPC_TU_NVT_LIST(X) X(18) X(27) X(33)
 #include "rollout_tu.inc"

@@ -45,9 +45,25 @@ DEV void hblock_add_rows(const Ctx &c, double *h, unsigned long long mask, int r
 #pragma unroll
     for (int q = 0; q < CB; q++) { y0[q] = r0p[j0 + q]; y1[q] = r1p[j0 + q]; }
     __builtin_amdgcn_sched_barrier(0);
-    double s0 = w0 * x0, s1 = w1 * x1;
+#ifdef MJPC_LEAN_LDS
+    if constexpr (HLay<NVT>::G == 1) {
+      // one column group in the dense tier: the factorisation takes lane i's registers as row i, i.e. it reads entry (i, j), j > i,
+      // where the full-capacity kernel (through qH, lower triangle) reads lane j's entry (j, i) = (w x_j) x_i.  Same bits here, so
+      // that the capacity tiers stay bit-identical: above the diagonal the product is formed the way lane j forms it
+      double s0 = w0 * x0, s1 = w1 * x1;
 #pragma unroll
-    for (int q = 0; q < CB; q++) { h[q] += s0 * y0[q]; h[q] += s1 * y1[q]; }
+      for (int q = 0; q < CB; q++) {
+        const bool up = j0 + q > hi;
+        h[q] = __builtin_fma(up ? w0 * y0[q] : s0, up ? x0 : y0[q], h[q]);
+        h[q] = __builtin_fma(up ? w1 * y1[q] : s1, up ? x1 : y1[q], h[q]);
+      }
+    } else
+#endif
+    {
+      double s0 = w0 * x0, s1 = w1 * x1;
+#pragma unroll
+      for (int q = 0; q < CB; q++) { h[q] = __builtin_fma(s0, y0[q], h[q]); h[q] = __builtin_fma(s1, y1[q], h[q]); }
+    }
   }
 }
 
@@ -297,11 +313,30 @@ template <int NVT>
 DEV void newton_direction_np(Ctx &c, int np) {
   if (np > 0) {
     LDLExtra ex;
+    ex.row = nullptr;
     ex.n = np;
 #pragma unroll
     for (int w = 0; w < 3; w++) ex.x[w] = CONE_PARTIAL(c, w < np ? w : 0);
     newton_direction_sum<NVT>(c, ex);
   } else newton_direction<NVT>(c);
+}
+
+// One column group (nv > 32: the hand): lane i's Hessian block IS row i, the layout the register factorisation works in - the
+// Hessian never goes through LDS (no qH in such a kernel's layout): Mgrad <- (hq + diag + the workers' partials)^-1 grad
+template <int NVT>
+DEV void newton_direction_rows(Ctx &c, const double *hq, int hi, bool hact, int np) {
+  if constexpr (HLay<NVT>::G != 1) return;             // (only instantiated for one column group)
+  double row[NVT];
+  const double dg = c.sgl[NVT + hi] + c.sgl[3 * NVT + hi];
+#pragma unroll
+  for (int q = 0; q < NVT; q++) row[q] = hact ? hq[q] + ((q == hi) ? dg : 0.0) : 0.0;
+  LDLExtra ex;
+  ex.row = row;
+  ex.n = np;
+#pragma unroll
+  for (int w = 0; w < 3; w++) ex.x[w] = CONE_PARTIAL(c, w < np ? w : 0);
+  chol_factor_solve_reg<NVT>(c.qH, c.Mgrad, NVP_OF(NVT), c.M->tree_ok && !c.cross, &ex);
+  PROF(c, 17);
 }
 
 // line-search data of a lane plus what the commit needs (friction coefficients, first row / dim of the contact, the single-entry
@@ -598,6 +633,13 @@ DEV void solve_constraints_reg_d(Ctx &c) {
   const DevModel &M = *c.M;
   constexpr int nv = NVT, nvp = NVP_OF(NVT);
   constexpr int G = HLay<NVT>::G, CB = HLay<NVT>::CB;
+  // one column group in the dense tier's lean layout (the hand): factor straight from the row registers, no Hessian in LDS
+  // (with all 512 registers and room in LDS the round trip through qH is the faster form: measured on the hand, 6.94 vs 7.62 ms)
+#ifdef MJPC_LEAN_LDS
+  constexpr bool ROWS = G == 1 && MJPC_HELPER;
+#else
+  constexpr bool ROWS = false;
+#endif
   const int hg_ = LANE / NVT;
   const bool hact = hg_ < G;
   const int hg = hact ? hg_ : 0, hi = hact ? LANE - hg_ * NVT : 0, j0 = hg * CB;
@@ -642,12 +684,11 @@ DEV void solve_constraints_reg_d(Ctx &c) {
   PROF(c, 15);
   newton_grad_reg<NVT>(c, hi, hg, hact);
   PROF(c, 9);
-  newton_assemble<NVT, DIMT>(c, hq, hi, hg, j0, hact);
-  PROF(c, 19);
+  if constexpr (!ROWS) { newton_assemble<NVT, DIMT>(c, hq, hi, hg, j0, hact); PROF(c, 19); }
 #if MJPC_HELPER
   if (np) { job_wait(c, np); PROF(c, 16); }
 #endif
-  newton_direction_np<NVT>(c, np);
+  if constexpr (!ROWS) newton_direction_np<NVT>(c, np); else newton_direction_rows<NVT>(c, hq, hi, hact, np);
   PFOR(i, nv) c.search[i] = -c.Mgrad[i];
   SYNC();
   const double scale = 1.0 / (M.meaninertia * (nv > 1 ? nv : 1));
@@ -737,12 +778,12 @@ DEV void solve_constraints_reg_d(Ctx &c) {
     PFOR(i, nv) pg += c.grad[i] * c.grad[i];
     const double gradient = scale * sqrt(wave_sum(pg));
     const int done = stop || gradient < M.tolerance;
-    if (!done) { newton_assemble<NVT, DIMT>(c, hq, hi, hg, j0, hact); PROF(c, 19); }
+    if constexpr (!ROWS) { if (!done) { newton_assemble<NVT, DIMT>(c, hq, hi, hg, j0, hact); PROF(c, 19); } }
 #if MJPC_HELPER
     if (np) { job_wait(c, np); PROF(c, 16); }           // (also when the gradient says stop: no job is left behind unfinished)
 #endif
     if (done) break;
-    newton_direction_np<NVT>(c, np);
+    if constexpr (!ROWS) newton_direction_np<NVT>(c, np); else newton_direction_rows<NVT>(c, hq, hi, hact, np);
     PFOR(i, nv) c.search[i] = -c.Mgrad[i];
     SYNC();
   }

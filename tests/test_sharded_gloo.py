@@ -82,3 +82,17 @@ def test_single_rank_passthrough():
     res = s.plan(state=d["state"], mocap=None, time=0.0, knot_times=np.array([0.0, 0.1]), knot_values=np.zeros((2, 1)),
                  interpolation=1, horizon=10, sigma=(0.5, 0.0), seed=1, stream=0)
     assert res["owner"] == 0 and res["winner"] == res["local"]["winner"]
+
+
+def test_bench_with_gpus_flag_and_no_launcher_starts_its_own_ranks_or_fails():
+    """`python bench.py --gpus 2` without WORLD_SIZE must start 2 ranks itself (torch.distributed.run, 127.0.0.1) - on this GPU-less
+    box they fail, so the command exits non-zero; what it must never do is fall back to one rank and print an `n_gpus: 1` line"""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-secondary"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert '"n_gpus": 1' not in r.stdout
+    import torch
+    if not torch.cuda.is_available():
+        assert r.returncode != 0

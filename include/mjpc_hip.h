@@ -128,7 +128,7 @@ typedef struct MjpcHipModel {
                             * plus the velocity derivative of the bias forces, mjd_rne_vel, and an LU factorisation of the non-symmetric
                             * M - h dF/dv).  RK4 is refused */
   int noslip_iterations;   /* must be 0 */
-  int neq;                 /* number of equality constraints (eq_* below): connect, joint and (fixed-)tendon equalities; weld / flex are refused */
+  int neq;                 /* number of equality constraints (eq_* below): connect, weld, joint and (fixed-)tendon equalities; flex is refused */
   int unsupported;         /* MJPC_UNSUP_* bits found by whoever fills this view in parts of mjModel the view does not carry
                             * (integration/hip_sampling_planner.cc: FillModelView); non-zero is refused at create */
   /* mjStatistic */
@@ -166,7 +166,8 @@ typedef struct MjpcHipModel {
   /* <contact><exclude>: (body1 << 16) + body2, as mjModel.exclude_signature */
   const int *exclude_signature;
   /* equality constraints [neq] (mj_instantiateEquality): MJPC_EQ_CONNECT obj = the two bodies (obj2 may be the world 0), eq_data[0..2]
-   * / [3..5] = the anchor in either body frame; MJPC_EQ_JOINT obj = joint1 and joint2 (or -1), eq_data[0..4] = polycoef of
+   * / [3..5] = the anchor in either body frame; MJPC_EQ_WELD obj = the two bodies, eq_data[0..2] = anchor in body 2, [3..5] = the same point in
+   * body 1, [6..9] = quaternion of body 2 in body 1's frame (mj_setConst has filled both), [10] = torquescale; MJPC_EQ_JOINT obj = joint1 and joint2 (or -1), eq_data[0..4] = polycoef of
    * q1 - q1_0 = poly(q2 - q2_0); MJPC_EQ_TENDON the same with the lengths of two fixed tendons (relative to their length at qpos0).  eq_active0 = 0 rows are left out (no run-time activation).  All NULL when neq = 0 */
   const int *eq_type, *eq_obj1id, *eq_obj2id, *eq_active0;
   const double *eq_data;            /* 11 per equality (mjNEQDATA) */

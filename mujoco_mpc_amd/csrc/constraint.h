@@ -85,8 +85,20 @@ DEV void make_noncontact_rows(Ctx &c, int *nsingle_out, int *n_nc_out) {
       PFOR(k, M.neq) {
         const int *et = MI(eq_tab) + 4 * k; const double *ep = MD(eq_prm) + 18 * k;
         int r0 = nefc + et[3], nr = 1;
-        double pos[3] = {0, 0, 0}, diag;
-        if (et[0] == 2) {            // joint: (q1 - q1_0) - poly(q2 - q2_0)
+        double pos[6] = {0, 0, 0, 0, 0, 0}, diag, diag_rot = 0;
+        if (et[0] == 1) {            // weld: anchor offset (body 1 holds ep[3..5], body 2 the anchor ep[0..2]) and torquescale * vec(conj(q2) q1 relpose)
+          int b1 = et[1], b2 = et[2];
+          double p1[3], p2[3], quat[4], quat1[4], quat2[4];
+          d_mulmatvec3(p1, c.xmat + 9 * b1, ep + 3); d_mulmatvec3(p2, c.xmat + 9 * b2, ep);
+          for (int q = 0; q < 3; q++) pos[q] = (p1[q] + c.xpos[3 * b1 + q]) - (p2[q] + c.xpos[3 * b2 + q]);
+          d_mulquat(quat, c.xquat + 4 * b1, ep + 6);
+          quat1[0] = c.xquat[4 * b2]; for (int q = 1; q < 4; q++) quat1[q] = -c.xquat[4 * b2 + q];
+          d_mulquat(quat2, quat1, quat);
+          for (int q = 0; q < 3; q++) pos[3 + q] = ep[10] * quat2[1 + q];
+          diag = MDH(body_invweight0)[2 * b1] + MDH(body_invweight0)[2 * b2];
+          diag_rot = MDH(body_invweight0)[2 * b1 + 1] + MDH(body_invweight0)[2 * b2 + 1];
+          nr = 6;
+        } else if (et[0] == 2) {     // joint: (q1 - q1_0) - poly(q2 - q2_0)
           int q1 = MIH(jnt_qposadr)[et[1]];
           pos[0] = c.qpos[q1] - MDH(qpos0)[q1];
           diag = MD(dof_invweight0)[MIH(jnt_dofadr)[et[1]]];
@@ -117,7 +129,7 @@ DEV void make_noncontact_rows(Ctx &c, int *nsingle_out, int *n_nc_out) {
         for (int q = 0; q < nr; q++) {
           int r = r0 + q;
           c.efc_type[r] = CNSTR_EQUALITY; c.efc_id[r] = k; c.efc_dof[r] = r0;
-          c.efc_floss[r] = 1e300; c.efc_pos[r] = pos[q]; c.efc_margin[r] = 0; c.efc_diag[r] = diag;
+          c.efc_floss[r] = 1e300; c.efc_pos[r] = pos[q]; c.efc_margin[r] = 0; c.efc_diag[r] = q > 2 ? diag_rot : diag;
         }
       }
       nefc += M.neqrow;
@@ -213,11 +225,16 @@ DEV void make_noncontact_rows(Ctx &c, int *nsingle_out, int *n_nc_out) {
         double deriv = ep[1] + dif * (2 * ep[2] + dif * (3 * ep[3] + dif * 4 * ep[4]));
         for (int w = MI(tendon_adr)[t2]; w < MI(tendon_adr)[t2] + MI(tendon_num)[t2]; w++) c.efc_J[r0 * nvp + MI(wrap_dofadr)[w]] -= deriv * MD(wrap_prm)[w];
       }
-    } else {       // point Jacobians of the two anchors (cdof about the root's subtree com)
+    } else {       // point Jacobians of the two anchors (cdof about the root's subtree com); a weld adds the rotation rows
       int b1 = et[1], b2 = et[2];
-      double p1[3], p2[3];
-      d_mulmatvec3(p1, c.xmat + 9 * b1, ep); d_mulmatvec3(p2, c.xmat + 9 * b2, ep + 3);
+      const int weld = et[0] == 1;
+      double p1[3], p2[3], quat[4], quat1[4];
+      d_mulmatvec3(p1, c.xmat + 9 * b1, weld ? ep + 3 : ep); d_mulmatvec3(p2, c.xmat + 9 * b2, weld ? ep : ep + 3);
       for (int q = 0; q < 3; q++) { p1[q] += c.xpos[3 * b1 + q]; p2[q] += c.xpos[3 * b2 + q]; }
+      if (weld) {
+        d_mulquat(quat, c.xquat + 4 * b1, ep + 6);
+        quat1[0] = c.xquat[4 * b2]; for (int q = 1; q < 4; q++) quat1[q] = -c.xquat[4 * b2 + q];
+      }
       for (int d = 0; d < nv; d++) {
         unsigned long long bit = 1ull << d;
         int in1 = (MDM()[b1] & bit) != 0, in2 = (MDM()[b2] & bit) != 0;
@@ -227,6 +244,13 @@ DEV void make_noncontact_rows(Ctx &c, int *nsingle_out, int *n_nc_out) {
         if (in1) { d_sub3(off, p1, c.subtree_com + 3 * MIH(body_rootid)[b1]); d_cross(t, cd, off); for (int q = 0; q < 3; q++) jp[q] += cd[3 + q] + t[q]; }
         if (in2) { d_sub3(off, p2, c.subtree_com + 3 * MIH(body_rootid)[b2]); d_cross(t, cd, off); for (int q = 0; q < 3; q++) jp[q] -= cd[3 + q] + t[q]; }
         for (int q = 0; q < 3; q++) c.efc_J[(r0 + q) * nvp + d] = jp[q];
+        if (weld) {          // torquescale * 0.5 * vec(conj(q2) (0, w1 - w2) q1 relpose)
+          double ax[4] = {0, 0, 0, 0}, tq[4], q3[4];
+          if (in1) for (int q = 0; q < 3; q++) ax[1 + q] = cd[q];
+          if (in2) for (int q = 0; q < 3; q++) ax[1 + q] -= cd[q];
+          d_mulquat(tq, quat1, ax); d_mulquat(q3, tq, quat);
+          for (int q = 0; q < 3; q++) c.efc_J[(r0 + 3 + q) * nvp + d] = ep[10] * (0.5 * q3[1 + q]);
+        }
       }
     }
   }
@@ -393,6 +417,10 @@ DEV void make_impedance(Ctx &c, int r0, int r1, int with_contacts) {
     if (type == CNSTR_EQUALITY && MI(eq_tab)[4 * id] == 0) {      // connect: one impedance from the norm of its three residuals
       const double *ps = c.efc_pos + c.efc_dof[r];
       imp_pos = d_sqrt(ps[0] * ps[0] + ps[1] * ps[1] + ps[2] * ps[2]);
+    }
+    if (type == CNSTR_EQUALITY && MI(eq_tab)[4 * id] == 1) {      // weld: from the norm of all six
+      const double *ps = c.efc_pos + c.efc_dof[r];
+      imp_pos = d_sqrt(ps[0] * ps[0] + ps[1] * ps[1] + ps[2] * ps[2] + ps[3] * ps[3] + ps[4] * ps[4] + ps[5] * ps[5]);
     }
     double imp = impedance(solimp, imp_pos, c.efc_margin[r]);
     double dmax = d_clip(solimp[1], 0.0001, 0.9999);

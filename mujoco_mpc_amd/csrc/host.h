@@ -163,9 +163,9 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
     if (!m->eq_type || !m->eq_obj1id || !m->eq_obj2id || !m->eq_active0 || !m->eq_data || !m->eq_solref || !m->eq_solimp) { p.error = "neq > 0 but the eq_* tables are missing"; return false; }
     if (!m->eq_active0[e]) continue;
     int ty = m->eq_type[e], a = m->eq_obj1id[e], b = m->eq_obj2id[e];
-    if (ty != MJPC_EQ_CONNECT && ty != MJPC_EQ_JOINT && ty != MJPC_EQ_TENDON) { p.error = "equality " + std::to_string(e) + ": only connect, joint and tendon equalities are implemented (weld / flex refused)"; return false; }
+    if (ty != MJPC_EQ_CONNECT && ty != MJPC_EQ_WELD && ty != MJPC_EQ_JOINT && ty != MJPC_EQ_TENDON) { p.error = "equality " + std::to_string(e) + ": only connect, weld, joint and tendon equalities are implemented (flex refused)"; return false; }
     if (ty == MJPC_EQ_TENDON && (a < 0 || a >= m->ntendon || b >= m->ntendon)) { p.error = "equality " + std::to_string(e) + ": tendon id out of range"; return false; }
-    if (ty == MJPC_EQ_CONNECT && (a < 0 || a >= nb || b < 0 || b >= nb)) { p.error = "equality " + std::to_string(e) + ": body id out of range"; return false; }
+    if ((ty == MJPC_EQ_CONNECT || ty == MJPC_EQ_WELD) && (a < 0 || a >= nb || b < 0 || b >= nb)) { p.error = "equality " + std::to_string(e) + ": body id out of range"; return false; }
     if (ty == MJPC_EQ_JOINT) {
       if (a < 0 || a >= nj || b >= nj) { p.error = "equality " + std::to_string(e) + ": joint id out of range"; return false; }
       if ((m->jnt_type[a] != MJPC_JNT_HINGE && m->jnt_type[a] != MJPC_JNT_SLIDE) || (b >= 0 && m->jnt_type[b] != MJPC_JNT_HINGE && m->jnt_type[b] != MJPC_JNT_SLIDE)) {
@@ -449,10 +449,10 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
       for (int k = 0; k < 11; k++) prm.push_back(m->eq_data[11 * e + k]);
       for (int k = 0; k < 2; k++) prm.push_back(m->eq_solref[2 * e + k]);
       for (int k = 0; k < 5; k++) prm.push_back(m->eq_solimp[5 * e + k]);
-      rows += ty == MJPC_EQ_CONNECT ? 3 : 1; ncon += ty == MJPC_EQ_CONNECT;
+      rows += ty == MJPC_EQ_CONNECT ? 3 : ty == MJPC_EQ_WELD ? 6 : 1; ncon += ty == MJPC_EQ_CONNECT || ty == MJPC_EQ_WELD;      // ncon: equalities whose Jacobian needs subtree_com
       // dofs of the row(s): every pair must be ancestor-related in the elimination tree, else the pattern does not hold them
       std::vector<int> dofs;
-      if (ty == MJPC_EQ_CONNECT) { for (int bb : {a, b}) for (int x = bb; x > 0; x = m->body_parentid[x]) for (int k = 0; k < m->body_dofnum[x]; k++) dofs.push_back(m->body_dofadr[x] + k); }
+      if (ty == MJPC_EQ_CONNECT || ty == MJPC_EQ_WELD) { for (int bb : {a, b}) for (int x = bb; x > 0; x = m->body_parentid[x]) for (int k = 0; k < m->body_dofnum[x]; k++) dofs.push_back(m->body_dofadr[x] + k); }
       else if (ty == MJPC_EQ_TENDON) { for (int tt : {a, b}) if (tt >= 0) for (int w = m->tendon_adr[tt]; w < m->tendon_adr[tt] + m->tendon_num[tt]; w++) dofs.push_back(m->jnt_dofadr[m->wrap_objid[w]]); }
       else { dofs.push_back(m->jnt_dofadr[a]); if (b >= 0) dofs.push_back(m->jnt_dofadr[b]); }
       for (size_t x = 0; x < dofs.size(); x++) for (size_t y = 0; y < x; y++) {

@@ -240,6 +240,12 @@ class ModelBuilder:
         """MJCF <connect>: the point `anchor` (body1 frame) stays where it is relative to body2 (0 = the world) at qpos0"""
         self.equalities.append(dict(type=0, obj1=body1, obj2=body2, anchor=tuple(anchor), solref=tuple(solref), solimp=tuple(solimp), active=active))
 
+    def weld(self, body1, body2=0, anchor=(0, 0, 0), relpose=None, torquescale=1.0, solref=DEF_SOLREF, solimp=DEF_SOLIMP, active=True):
+        """MJCF <weld>: body1 keeps its pose relative to body2 (0 = the world); `anchor` (body2 frame) is the point the position rows
+        are taken at; relpose = (pos 3, quat 4) of body2 in body1's frame, None = the pose at qpos0 (mj_setConst)"""
+        self.equalities.append(dict(type=1, obj1=body1, obj2=body2, anchor=tuple(anchor), relpose=None if relpose is None else tuple(relpose),
+                                    torquescale=float(torquescale), solref=tuple(solref), solimp=tuple(solimp), active=active))
+
     def joint_equality(self, joint1, joint2=None, polycoef=(0, 1, 0, 0, 0), solref=DEF_SOLREF, solimp=DEF_SOLIMP, active=True):
         """MJCF <equality><joint>: q1 - q1_0 = poly(q2 - q2_0) (joint names; joint2 None: q1 - q1_0 = polycoef[0])"""
         self.equalities.append(dict(type=2, obj1=joint1, obj2=joint2, polycoef=tuple(polycoef), solref=tuple(solref), solimp=tuple(solimp), active=active))
@@ -575,13 +581,25 @@ class ModelBuilder:
         M["neq"] = len(E)
         M["eq_type"] = np.array([e["type"] for e in E], np.int32); M["eq_active0"] = np.array([int(e["active"]) for e in E], np.int32)
         o1, o2 = [], []; data = np.zeros((len(E), 11))
-        xpos0, _, xmat0, _, _ = kinematics(M, M["qpos0"])
+        xpos0, xquat0, xmat0, _, _ = kinematics(M, M["qpos0"])
         for k, e in enumerate(E):
             if e["type"] == 0:
                 b1, b2 = e["obj1"], e["obj2"]
                 o1.append(b1); o2.append(b2)
                 world = xpos0[b1] + xmat0[b1] @ np.array(e["anchor"], float)
                 data[k, :3] = e["anchor"]; data[k, 3:6] = xmat0[b2].T @ (world - xpos0[b2])
+            elif e["type"] == 1:
+                # [anchor in body2's frame, the same point in body1's frame, quat of body2 in body1's frame, torquescale]
+                b1, b2 = e["obj1"], e["obj2"]
+                o1.append(b1); o2.append(b2)
+                data[k, :3] = e["anchor"]; data[k, 10] = e["torquescale"]
+                rp = e["relpose"]
+                if rp is None or not np.any(np.asarray(rp[3:7], float)):
+                    world = xpos0[b2] + xmat0[b2] @ np.array(e["anchor"], float)
+                    data[k, 3:6] = xmat0[b1].T @ (world - xpos0[b1])
+                    data[k, 6:10] = quat_mul(xquat0[b1] * np.array([1.0, -1, -1, -1]), xquat0[b2])
+                else:
+                    data[k, 3:6] = rp[:3]; data[k, 6:10] = normq(np.asarray(rp[3:7], float))
             elif e["type"] == 3:
                 tn = [t["name"] for t in self.tendons]
                 o1.append(tn.index(e["obj1"])); o2.append(-1 if e["obj2"] is None else tn.index(e["obj2"]))

@@ -3,7 +3,7 @@
 Covers what the task files of the reference that are complete without MuJoCo's model zoo use
 (mjpc/test/testdata/particle*.xml, mjpc/tasks/humanoid/humanoid.xml.patch + task.xml files): <include>, <compiler angle>,
 <option> (+ <flag contact>), nested <default> classes with `childclass` / `class`, the body tree with <joint>/<freejoint>/
-<geom>/<site>/<inertial>, <actuator> motor / position / velocity / general (incl. filter dynamics), fixed <tendon>s, <equality> connect / joint / tendon, <contact><exclude>, <keyframe>,
+<geom>/<site>/<inertial>, <actuator> motor / position / velocity / general (incl. filter dynamics), fixed <tendon>s, <equality> connect / weld / joint / tendon, <contact><exclude>, <keyframe>,
 <custom><numeric>, and the MJPC cost table in <sensor><user> (mjpc/task.cc:203-238).  Anything visual is ignored.
 
 MuJoCo semantics restated here (compile-time only, no simulation): defaults inherit along the class tree and apply per
@@ -287,12 +287,16 @@ def parse_mjcf(path_or_text, base_dir=None, reader=None, missing_ok=()):
             poly = _floats(ch.get("polycoef", "0 1 0 0 0")); poly = tuple(poly + [0.0] * (5 - len(poly)))
             if ch.tag == "connect":
                 b.connect(b.body_id(ch.get("body1")), b.body_id(ch.get("body2")) if ch.get("body2") else 0, tuple(_floats(ch.get("anchor"))), **kw)
+            elif ch.tag == "weld":
+                rp = _floats(ch.get("relpose", "0 1 0 0 0 0 0"))
+                b.weld(b.body_id(ch.get("body1")), b.body_id(ch.get("body2")) if ch.get("body2") else 0, tuple(_floats(ch.get("anchor", "0 0 0"))),
+                       relpose=tuple(rp), torquescale=float(ch.get("torquescale", "1")), **kw)
             elif ch.tag == "joint":
                 b.joint_equality(ch.get("joint1"), ch.get("joint2"), polycoef=poly, **kw)
             elif ch.tag == "tendon":
                 b.tendon_equality(ch.get("tendon1"), ch.get("tendon2"), polycoef=poly, **kw)
             else:
-                raise ValueError(f"equality <{ch.tag}> not in the supported subset (connect, joint, tendon)")
+                raise ValueError(f"equality <{ch.tag}> not in the supported subset (connect, weld, joint, tendon)")
 
     for ct in root.findall("contact"):
         for ex in ct.findall("exclude"):

@@ -191,6 +191,37 @@ def linkage(timestep=0.004):
     return m, task, defaults
 
 
+def welded(timestep=0.004):
+    """Test model for weld equalities: a two-link arm (hinge + ball) whose hand is welded to a free tool with an off-centre anchor and
+    torquescale 0.7 (both sides move; cross-branch rows), a free lamp welded to the world with an explicit relpose it starts away
+    from (it is pulled in), and a free puck welded to a mocap body (the MJPC way of dragging an object); a box on the floor for
+    contacts next to them.  Residual = state (TASK_COPYSTATE)."""
+    b = ModelBuilder(timestep=timestep, gravity=(0, 0, -9.81), contact=True)
+    b.geom(0, "floor", PLANE, pos=(0, 0, -0.6), size=(2, 2, 0.1))
+    l1 = b.body("l1", 0, pos=(0, 0, 0.2)); b.joint(l1, "sh", HINGE, axis=(0, 1, 0), damping=0.05, armature=0.01)
+    b.geom(l1, "l1_g", CAPSULE, size=(0.02, 0), fromto=(0, 0, 0, 0.25, 0, 0), mass=0.4)
+    l2 = b.body("l2", l1, pos=(0.25, 0, 0)); b.joint(l2, "el", BALL, damping=0.03)
+    b.geom(l2, "l2_g", CAPSULE, size=(0.018, 0), fromto=(0, 0, 0, 0.2, 0, 0), mass=0.25)
+    tool = b.body("tool", 0, pos=(0.5, 0.01, 0.21), quat=(0.98, 0.05, -0.1, 0.15)); b.joint(tool, "tool_f", FREE)
+    b.geom(tool, "tool_g", BOX, size=(0.04, 0.02, 0.015), mass=0.15)
+    b.weld(l2, tool, anchor=(-0.03, 0.0, 0.01), torquescale=0.7, solref=(0.01, 1.0))
+    lamp = b.body("lamp", 0, pos=(-0.4, 0.3, 0.1)); b.joint(lamp, "lamp_f", FREE); b.geom(lamp, "lamp_g", SPHERE, size=(0.04,), pos=(0.05, 0, 0), mass=0.2)
+    b.weld(lamp, 0, relpose=(0.38, -0.3, -0.15, 0.96, 0.0, 0.28, 0.0), solref=(0.02, 1.0))
+    hold = b.body("hold", 0, pos=(-0.3, -0.4, -0.2), mocap=True)
+    puck = b.body("puck", 0, pos=(-0.3, -0.4, -0.2)); b.joint(puck, "puck_f", FREE); b.geom(puck, "puck_g", CYLINDER, size=(0.05, 0.02), mass=0.3)
+    b.weld(puck, hold, solref=(0.02, 1.0), solimp=(0.9, 0.95, 0.01, 0.5, 2))
+    box = b.body("box", 0, pos=(0.1, 0, -0.55)); b.joint(box, "box_f", FREE); b.geom(box, "box_g", BOX, size=(0.05, 0.05, 0.05), mass=0.3)
+    tip = b.site(tool, "tip", pos=(0.04, 0, 0))
+    b.actuator("sh_m", "sh", gear=1.5, ctrlrange=(-1, 1))
+    m = b.compile()
+    task = make_task(TASK_COPYSTATE, [(m["nq"], 0, 1.0), (m["nv"], 0, 0.1)], traces=[(OBJ_SITE, tip)])
+    q = m["qpos0"].copy(); v = np.zeros(m["nv"])
+    v[0] = 1.5; v[1:4] = [0.5, -1.0, 0.8]; v[4:7] = [0.2, 0.1, -0.3]; v[13:16] = [0.0, 0.0, 2.0]
+    mocap = np.array([-0.25, -0.35, -0.1, 0.92, 0.0, 0.0, 0.39])          # the hold has moved and turned: the puck follows
+    defaults = dict(N=6, P=4, sigma=(0.5, 0.0), interp=2, horizon=80, state=np.concatenate([q, v]), mocap=mocap)
+    return m, task, defaults
+
+
 def servo_arm(timestep=0.005, integrator=3):
     """Test model for mjINT_IMPLICITFAST: a three-link arm on position servos with velocity gains (kv: the bias' velocity term), one
     of them with a force range it saturates, a velocity servo through a fixed tendon along the chain, a damped tendon and gravity
@@ -897,4 +928,4 @@ def terrain_balls(timestep=0.004):
     return m, task, defaults
 
 
-REGISTRY = {"humanoid_interact": humanoid_interact, "swimmer": swimmer, "quadrotor": quadrotor, "linkage": linkage, "servo_arm": servo_arm, "particle_timevarying": particle_task, "particle_fixed": lambda: particle_task(fixed=True), "filter_arm": filter_arm, "ball_chain_friction": lambda: ball_chain(tendon_frictionloss=0.3), "quadruped_hill": quadruped_hill, "terrain_balls": terrain_balls, "walker": walker, "acrobot": acrobot, "ball_chain": ball_chain, "cylinder_pile": cylinder_pile, "humanoid_stand": humanoid_stand, "humanoid_walk": humanoid_walk, "particle": particle, "cartpole": cartpole, "quadruped": quadruped, "humanoid_track": humanoid_track, "shadow_hand": shadow_hand}
+REGISTRY = {"humanoid_interact": humanoid_interact, "welded": welded, "swimmer": swimmer, "quadrotor": quadrotor, "linkage": linkage, "servo_arm": servo_arm, "particle_timevarying": particle_task, "particle_fixed": lambda: particle_task(fixed=True), "filter_arm": filter_arm, "ball_chain_friction": lambda: ball_chain(tendon_frictionloss=0.3), "quadruped_hill": quadruped_hill, "terrain_balls": terrain_balls, "walker": walker, "acrobot": acrobot, "ball_chain": ball_chain, "cylinder_pile": cylinder_pile, "humanoid_stand": humanoid_stand, "humanoid_walk": humanoid_walk, "particle": particle, "cartpole": cartpole, "quadruped": quadruped, "humanoid_track": humanoid_track, "shadow_hand": shadow_hand}

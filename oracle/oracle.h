@@ -130,6 +130,8 @@ int oracle_debug_step(const OModel *om, double *qpos, double *qvel, const double
                       const double *mocap, double *time, int nstep, double *energy);
 int oracle_debug_vel_derivatives(const OModel *om, const double *qpos, const double *qvel, double *dbias, double *dfluid, double *bias,
                                  double *passive_out);
+int oracle_debug_constraints(const OModel *om, const double *qpos, const double *qvel, const double *mocap, int cap, double *J, double *pos,
+                             double *diag, double *R, double *aref);
 
 #ifdef __cplusplus
 }

@@ -409,6 +409,31 @@ static void make_constraint(const OModel *om, OData *d) {
         o_copy(d->efc_solref + 2 * r, m->eq_solref + 2 * e, 2); o_copy(d->efc_solimp + 5 * r, m->eq_solimp + 5 * e, 5);
         d->efc_diagApprox[r] = m->body_invweight0[2 * b1] + m->body_invweight0[2 * b2];
       }
+    } else if (m->eq_type[e] == MJPC_EQ_WELD) {
+      /* weld (body semantic): rows 0-2 = (x1 + R1 data[3:6]) - (x2 + R2 data[0:3]); rows 3-5 = torquescale * vec(conj(q2) q1 relpose),
+       * whose Jacobian is torquescale * 0.5 * vec(conj(q2) (0, w1 - w2) q1 relpose) per dof column; data[6:10] = relpose,
+       * data[10] = torquescale */
+      int b1 = m->eq_obj1id[e], b2 = m->eq_obj2id[e];
+      double p1[3], p2[3], *j1 = d->work, *j2 = d->work + 6 * nv, cpos[6], quat[4], quat1[4], quat2[4], ts = data[10];
+      o_mulmatvec3(p1, d->xmat + 9 * b1, data + 3); o_add3(p1, p1, d->xpos + 3 * b1);
+      o_mulmatvec3(p2, d->xmat + 9 * b2, data); o_add3(p2, p2, d->xpos + 3 * b2);
+      jac_point(om, d, j1, j1 + 3 * nv, p1, b1); jac_point(om, d, j2, j2 + 3 * nv, p2, b2);
+      o_mulquat(quat, d->xquat + 4 * b1, data + 6);
+      quat1[0] = d->xquat[4 * b2]; for (int k = 1; k < 4; k++) quat1[k] = -d->xquat[4 * b2 + k];
+      o_mulquat(quat2, quat1, quat);
+      for (int k = 0; k < 3; k++) { cpos[k] = p1[k] - p2[k]; cpos[3 + k] = ts * quat2[1 + k]; }
+      for (int i = 0; i < nv; i++) {
+        double ax[4] = {0, j1[3 * nv + i] - j2[3 * nv + i], j1[4 * nv + i] - j2[4 * nv + i], j1[5 * nv + i] - j2[5 * nv + i]}, t[4], q3[4];
+        o_mulquat(t, quat1, ax); o_mulquat(q3, t, quat);
+        for (int k = 0; k < 3; k++) { j1[k * nv + i] -= j2[k * nv + i]; j1[(3 + k) * nv + i] = ts * (0.5 * q3[1 + k]); }
+      }
+      for (int k = 0; k < 6; k++) {
+        int r = add_row(om, d, O_CNSTR_EQUALITY, e); if (r < 0) return;
+        o_copy(d->efc_J + r * nv, j1 + k * nv, nv);
+        d->efc_pos[r] = cpos[k];
+        o_copy(d->efc_solref + 2 * r, m->eq_solref + 2 * e, 2); o_copy(d->efc_solimp + 5 * r, m->eq_solimp + 5 * e, 5);
+        d->efc_diagApprox[r] = m->body_invweight0[2 * b1 + (k > 2)] + m->body_invweight0[2 * b2 + (k > 2)];
+      }
     } else if (m->eq_type[e] == MJPC_EQ_JOINT) {
       int j1 = m->eq_obj1id[e], j2 = m->eq_obj2id[e];
       int r = add_row(om, d, O_CNSTR_EQUALITY, e); if (r < 0) return;
@@ -580,6 +605,7 @@ static void make_impedance(const OModel *om, OData *d) {
     const int equality = d->efc_type[r] == O_CNSTR_EQUALITY;
     double imp_pos = d->efc_pos[r];
     if (equality && m->eq_type[d->efc_id[r]] == MJPC_EQ_CONNECT) { dim = 3; imp_pos = o_norm(d->efc_pos + r, 3); }    /* one impedance from |residual| */
+    if (equality && m->eq_type[d->efc_id[r]] == MJPC_EQ_WELD) { dim = 6; imp_pos = o_norm(d->efc_pos + r, 6); }
     double imp = impedance(solimp, imp_pos, d->efc_margin[r]);
     double dmax = o_clip(solimp[1], 0.0001, 0.9999);
     double K, B;
@@ -1212,6 +1238,23 @@ int oracle_debug_vel_derivatives(const OModel *om, const double *qpos, const dou
   if (passive_out) o_copy(passive_out, d->qfrc_passive, nv);
   oracle_free_data(d);
   return w;
+}
+
+/* the constraint rows at (qpos, qvel): efc_J [nefc x nv], efc_pos, efc_diagApprox, efc_R, efc_aref (each up to `cap` rows); returns
+ * nefc.  Test hook (finite-difference checks of the row Jacobians) */
+int oracle_debug_constraints(const OModel *om, const double *qpos, const double *qvel, const double *mocap, int cap, double *J, double *pos,
+                             double *diag, double *R, double *aref) {
+  const MjpcHipModel *m = &om->m;
+  int nv = m->nv;
+  OData *d = oracle_make_data(om);
+  o_copy(d->qpos, qpos, m->nq); o_copy(d->qvel, qvel, nv);
+  if (mocap) for (int i = 0; i < m->nmocap; i++) { o_copy3(d->mocap_pos + 3 * i, mocap + 7 * i); o_copy(d->mocap_quat + 4 * i, mocap + 7 * i + 3, 4); }
+  oracle_forward(om, d);
+  int n = d->nefc < cap ? d->nefc : cap;
+  o_copy(J, d->efc_J, n * nv); o_copy(pos, d->efc_pos, n); o_copy(diag, d->efc_diagApprox, n); o_copy(R, d->efc_R, n); o_copy(aref, d->efc_aref, n);
+  n = d->nefc;
+  oracle_free_data(d);
+  return n;
 }
 
 void oracle_step(const OModel *om, OData *d) {

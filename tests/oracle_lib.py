@@ -59,6 +59,7 @@ def lib():
     L.oracle_debug_forward.argtypes = [C.c_void_p] + [c_double_p] * 4 + [C.c_double] + [c_double_p] * 5 + [c_int_p, c_int_p, c_double_p, c_double_p, c_double_p]
     L.oracle_debug_step.argtypes = [C.c_void_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, C.c_int, c_double_p]
     L.oracle_debug_vel_derivatives.argtypes = [C.c_void_p] + [c_double_p] * 6
+    L.oracle_debug_constraints.argtypes = [C.c_void_p, c_double_p, c_double_p, c_double_p, C.c_int] + [c_double_p] * 5; L.oracle_debug_constraints.restype = C.c_int
     _lib = L
     return L
 
@@ -180,6 +181,16 @@ class Oracle:
         out["warning"] = lib().oracle_debug_vel_derivatives(self.h, _dp(qpos), _dp(qvel), _dp(out["dbias"]), _dp(out["dfluid"]),
                                                             _dp(out["qfrc_bias"]), _dp(out["qfrc_passive"]))
         return out
+
+    def constraints(self, qpos, qvel=None, mocap=None, cap=256):
+        """the constraint rows at (qpos, qvel): efc_J, efc_pos, efc_diagApprox, efc_R, efc_aref"""
+        nv = self.model["nv"]
+        qpos = np.ascontiguousarray(qpos, float); qvel = np.ascontiguousarray(qvel if qvel is not None else np.zeros(nv), float)
+        out = dict(J=np.zeros((cap, nv)), pos=np.zeros(cap), diag=np.zeros(cap), R=np.zeros(cap), aref=np.zeros(cap))
+        mocap_a = np.ascontiguousarray(mocap, float) if mocap is not None else None
+        n = lib().oracle_debug_constraints(self.h, _dp(qpos), _dp(qvel), _dp(mocap_a), cap, _dp(out["J"]), _dp(out["pos"]), _dp(out["diag"]), _dp(out["R"]), _dp(out["aref"]))
+        assert n <= cap
+        return {k: v[:n] for k, v in out.items()}
 
     def step(self, qpos, qvel, ctrl=None, mocap=None, time=0.0, nstep=1):
         m = self.model

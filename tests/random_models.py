@@ -1,6 +1,6 @@
 """Random articulated models for the fuzz parity tests (test infrastructure): random trees of bodies on free / ball / hinge /
 slide joints with limits, damping, armature, friction loss and springs, one or two primitive geoms of every supported type per
-body, motors and position servos, fixed tendons with limits / springs / dampers / friction loss (also across branches), joint and connect equalities, stateful
+body, motors and position servos, fixed tendons with limits / springs / dampers / friction loss (also across branches), joint, connect and weld equalities, stateful
 actuators, either integrator, either friction cone,
 contact dimensions 1 / 3 / 4 / 6.  The residual copies the state."""
 import numpy as np
@@ -123,6 +123,11 @@ def random_model(seed, portal_pairs=False):
         b.fluid = (float(rng_fr.choice([0.0, 50.0, 300.0])), float(rng_fr.choice([0.0, 0.05, 0.5])), (float(rng_fr.uniform(-1, 1)), 0.0, 0.0) if rng_fr.random() < 0.5 else (0.0, 0.0, 0.0))
     if b.tendons and rng_fr.random() < 0.25:       # a tendon equality: the first tendon held at (a multiple of) the second's length, or at its own
         b.tendon_equality("t0", "t1" if len(b.tendons) > 1 and rng_fr.random() < 0.6 else None, polycoef=(0.0, float(rng_fr.uniform(-1, 1)), 0, 0, 0))
+    rng_w = np.random.default_rng([seed, 2])       # welds came later still: a third stream
+    if rng_w.random() < 0.3:                        # the last loose object welded to the world or to a body of the tree (where it is at qpos0)
+        other = 0 if rng_w.random() < 0.4 else int(rng_w.choice(bodies))
+        b.weld(b.body_id(f"loose{nloose - 1}"), other, anchor=tuple(float(x) for x in rng_w.uniform(-0.05, 0.05, 3)),
+               torquescale=float(rng_w.choice([1.0, 0.5, 0.2])), solref=(float(rng_w.choice([0.02, 0.01])), 1.0))
     for jn in scalar_joints:                        # joint-level clamp of the total actuator force on some joints
         if rng_fr.random() < 0.15:
             lim = float(rng_fr.uniform(0.3, 1.5)); b.actfrc[jn] = (-lim, lim)

@@ -89,6 +89,21 @@ def test_equality_constraints():
     assert np.abs(s[:, :, 1] - (-s[:, :, 2] + 0.1 * s[:, :, 2] ** 2)).max() < 5e-3       # the fingers stay coupled
 
 
+def test_weld_equalities():
+    """mjEQ_WELD on the device: six rows per weld (anchor offset + torquescale * relative rotation, one impedance from the norm of all
+    six): an arm's hand welded to a free tool, a free body pulled to an explicit relpose at the world, a puck welded to a mocap body
+    that has moved and turned; same trajectories as the oracle, and the puck ends up where the mocap body is."""
+    from mujoco_mpc_amd.modelgen import welded
+    m, task, d = welded()
+    out, ref, allc = _compare(m, task, d, 4, 80, 12, (0.5, 0.0), 2, 1e-7)
+    assert not out["failure"].any() and allc["diag"][:, 2].max() >= 18                  # 3 x 6 equality rows always there
+    s = allc["states"]
+    nq0 = 1 + 4 + 7 + 7                                                                  # sh, el, tool, lamp; then the puck's free joint
+    assert np.abs(s[:, -1, nq0:nq0 + 3] - d["mocap"][:3]).max() < 5e-3
+    q = s[:, -1, nq0 + 3:nq0 + 7]
+    assert np.abs(np.abs(q @ d["mocap"][3:] / np.linalg.norm(d["mocap"][3:])) - 1).max() < 1e-3
+
+
 def test_implicitfast_integrator():
     """mjINT_IMPLICITFAST: the integration solve uses M - h dF/dv with the velocity terms of the servos (dropped while a force sits on
     its range) and the tendon damping; same trajectories as the oracle, and different from Euler's on this stiff arm."""

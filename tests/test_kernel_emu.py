@@ -29,6 +29,7 @@ def _rel(a, b):
                                                    ("swimmer", 10, 101, 6, (0.3, 0.0), 1e-9),       # registry Swimmer: inertia-box fluid forces, filter actuators, planar root, the XML's full implicit integrator
                                                    ("quadrotor", 5, 51, 6, (0.3, 0.0), 1e-9),       # registry Quadrotor: site transmissions (thrust + reaction torque), 15 declared / 13 written residuals
                                                    ("linkage", 4, 80, 6, (0.5, 0.0), 1e-9),         # equality constraints: joint coupling across branches, four-bar connect, pinned free body
+                                                   ("welded", 4, 80, 6, (0.5, 0.0), 1e-9),          # weld equalities: arm-to-free-body, explicit relpose, free body welded to a mocap body
                                                    ("servo_arm", 4, 80, 6, (0.5, 0.0), 1e-9),       # mjINT_IMPLICITFAST: velocity servos, saturating force range, damped tendon
                                                    ("filter_arm", 4, 80, 6, (0.4, 0.0), 1e-9),      # activation states: filter / filterexact / clamped integrator actuators
                                                    ("ball_chain", 4, 60, 6, (0.4, 0.0), 1e-5),      # limited ball joints, tendon spring / damper / cross-branch limit
@@ -227,13 +228,14 @@ def test_models_the_engine_cannot_roll_out_are_refused_at_create():
     option("unsupported", 1, "outside the engine's model view")
     option("na", 2, "stateful actuators")                   # activation states must belong to integrator / filter actuators
 
-    check(lambda b, body: b.connect(body, 0, (0, 0, 0.1)), None)          # connect / joint equalities have rows; a weld does not
+    check(lambda b, body: b.connect(body, 0, (0, 0, 0.1)), None)          # connect / weld / joint / tendon equalities have rows; a flex does not
+    check(lambda b, body: b.weld(body, 0), None)
     b = ModelBuilder()
     body = b.body("a", 0, pos=(0, 0, 1)); b.joint(body, "f", FREE); b.geom(body, "g", SPHERE, size=(0.1,))
     b.connect(body, 0, (0, 0, 0.1))
-    m = b.compile(); m["eq_type"][0] = 1
+    m = b.compile(); m["eq_type"][0] = 4
     cm = capi.CModel(m, task)
-    assert lib.mjpc_hip_layout_bytes(ctypes.byref(cm.c_model), ctypes.byref(cm.c_task), 1) < 0 and b"only connect, joint and tendon equalities" in lib.mjpc_hip_last_error()
+    assert lib.mjpc_hip_layout_bytes(ctypes.byref(cm.c_model), ctypes.byref(cm.c_task), 1) < 0 and b"only connect, weld, joint and tendon equalities" in lib.mjpc_hip_last_error()
 
     def bigcon(b, body):
         b.nconmax = 100

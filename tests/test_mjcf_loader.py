@@ -256,7 +256,8 @@ def test_loader_attributes_of_the_late_features():
     xml = """<mujoco><option timestep="0.004" density="12" viscosity="0.3" wind="1 0 0" integrator="implicitfast"/>
       <worldbody><body name="a" pos="0 0 1" gravcomp="0.5"><joint name="h" type="hinge" axis="0 1 0" actuatorfrcrange="-2 3"/>
         <geom type="sphere" size="0.1"/><body name="c" pos="0 0 -0.3"><joint name="h2" type="hinge" axis="0 1 0"/><geom type="sphere" size="0.05"/></body></body></worldbody>
-      <equality><joint joint1="h" joint2="h2" polycoef="0 -1 0.1"/><connect body1="c" anchor="0 0 -0.1" solref="0.01 1"/></equality>
+      <equality><joint joint1="h" joint2="h2" polycoef="0 -1 0.1"/><connect body1="c" anchor="0 0 -0.1" solref="0.01 1"/>
+        <weld body1="c" body2="a" anchor="0.01 0 0" torquescale="0.5"/><weld body1="c" relpose="0 0 -0.7 0 0 0 2"/></equality>
       <actuator><velocity name="v" joint="h" kv="7"/><general name="f" joint="h" gainprm="2" dyntype="filter" dynprm="0.4"/></actuator></mujoco>"""
     b, info = mjcf.parse_mjcf(xml)
     m = b.compile()
@@ -264,7 +265,9 @@ def test_loader_attributes_of_the_late_features():
     assert m["body_gravcomp"][1] == 0.5 and m["jnt_actfrclimited"][0] == 1 and tuple(m["jnt_actfrcrange"][0]) == (-2.0, 3.0)
     assert tuple(m["actuator_gainprm"][0]) == (7.0, 0, 0) and tuple(m["actuator_biasprm"][0]) == (0, 0, -7.0) and m["actuator_biastype"][0] == 1
     assert m["na"] == 1 and m["actuator_dyntype"][1] == 2 and m["actuator_dynprm"][1] == 0.4 and m["actuator_actadr"][1] == 0
-    assert m["neq"] == 2 and list(m["eq_type"]) == [2, 0] and tuple(m["eq_data"][0][:3]) == (0.0, -1.0, 0.1)
+    assert m["neq"] == 4 and list(m["eq_type"]) == [2, 0, 1, 1] and tuple(m["eq_data"][0][:3]) == (0.0, -1.0, 0.1)
+    # weld without relpose: the anchor (body2 frame) seen from body1 and the orientation of body2 in body1 at qpos0; with one: as given, quat normalised
+    assert np.allclose(m["eq_data"][2], [0.01, 0, 0, 0.01, 0, 0.3, 1, 0, 0, 0, 0.5]) and np.allclose(m["eq_data"][3], [0, 0, 0, 0, 0, -0.7, 0, 0, 0, 1, 1])
     assert np.allclose(m["eq_data"][1][:6], [0, 0, -0.1, 0, 0, 0.6]) and tuple(m["eq_solref"][1]) == (0.01, 1.0)      # second anchor: the point in the world frame
     with pytest.raises(ValueError):
         mjcf.parse_mjcf('<mujoco><option integrator="RK4"/><worldbody/></mujoco>')

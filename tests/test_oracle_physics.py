@@ -634,6 +634,78 @@ def test_equality_constraints_against_equivalent_joints():
     assert abs(qc[0] - qc[1]) < 2e-3 and abs(qc[0] - q1[0]) < 5e-3 and abs(vc[0] - v1[0]) < 2e-2
 
 
+def _nudge(m, qpos, dof, eps):
+    """qpos moved by eps along one dof (mj_integratePos: free / ball rotations are body-frame)"""
+    from mujoco_mpc_amd.modelgen.builder import BALL, quat_mul
+    q = np.array(qpos, float)
+    for j in range(m["njnt"]):
+        da, qa, ty = m["jnt_dofadr"][j], m["jnt_qposadr"][j], m["jnt_type"][j]
+        n = {FREE: 6, BALL: 3}.get(ty, 1)
+        if not da <= dof < da + n:
+            continue
+        k = dof - da
+        if ty in (HINGE, SLIDE) or (ty == FREE and k < 3):
+            q[qa + k] += eps
+        else:
+            o = qa + 3 if ty == FREE else qa
+            ax = np.zeros(3); ax[k - 3 if ty == FREE else k] = 1.0
+            dq = np.concatenate([[math.cos(eps / 2)], math.sin(eps / 2) * ax])
+            q[o:o + 4] = quat_mul(q[o:o + 4], dq)
+    return q
+
+
+def test_weld_equality_rows():
+    """mjEQ_WELD in mj_instantiateEquality: six rows (anchor offset, torquescale * vec of the relative rotation) that vanish at the
+    reference pose; the Jacobian rows are the derivatives of the residuals along every dof (central differences); one impedance from
+    the norm of all six; diagApprox translational / rotational; a welded free body sags under gravity by the soft-constraint closed
+    form  m g R / (K imp)  and holds its orientation against its off-centre weight."""
+    from mujoco_mpc_amd.modelgen.builder import BALL
+    h = 0.002
+    b = ModelBuilder(timestep=h, contact=False)
+    l1 = b.body("l1", 0, pos=(0, 0, 1)); b.joint(l1, "h1", HINGE, axis=(0, 1, 0)); b.geom(l1, "g1", CAPSULE, size=(0.03, 0.2), pos=(0.2, 0, 0), euler=(0, 90, 0), mass=0.5)
+    l2 = b.body("l2", l1, pos=(0.4, 0, 0)); b.joint(l2, "b2", BALL); b.geom(l2, "g2", CAPSULE, size=(0.03, 0.15), pos=(0.15, 0, 0), euler=(0, 90, 0), mass=0.3)
+    f = b.body("f", 0, pos=(0.75, 0.05, 1.02), quat=(0.9, 0.1, -0.3, 0.2)); b.joint(f, "ff", FREE); b.geom(f, "gf", BOX, size=(0.05, 0.04, 0.03), mass=0.4)
+    b.weld(l2, f, anchor=(0.02, -0.01, 0.03), torquescale=0.7, solref=(0.01, 1.0))
+    w = b.body("w", 0, pos=(-1, 0, 1)); b.joint(w, "fw", FREE); b.geom(w, "gw", SPHERE, size=(0.05,), pos=(0.1, 0, 0), mass=0.25)
+    b.weld(w, 0, relpose=(0.3, 0.2, -1.1, 0.8, 0.0, 0.6, 0.0), solref=(0.006, 1.0))          # explicit relpose, not the qpos0 one
+    m = b.compile()
+    assert list(m["eq_type"]) == [1, 1] and m["eq_data"][0, 10] == 0.7 and m["eq_data"][1, 10] == 1.0
+    assert np.allclose(m["eq_data"][1, 3:10], [0.3, 0.2, -1.1, 0.8, 0, 0.6, 0])
+    o = ol.Oracle(m, _copy_task(m))
+    c0 = o.constraints(m["qpos0"])
+    assert len(c0["pos"]) == 12 and np.abs(c0["pos"][:6]).max() < 1e-15 and np.abs(c0["pos"][6:]).max() > 0.1      # the first weld holds at qpos0
+    rng = np.random.default_rng(5)
+    q = np.array(m["qpos0"], float)
+    for d in range(m["nv"]):
+        q = _nudge(m, q, d, rng.uniform(-0.4, 0.4))
+    c = o.constraints(q, rng.normal(size=m["nv"]))
+    eps = 1e-6
+    for d in range(m["nv"]):
+        fd = (o.constraints(_nudge(m, q, d, eps))["pos"] - o.constraints(_nudge(m, q, d, -eps))["pos"]) / (2 * eps)
+        assert np.abs(fd - c["J"][:, d]).max() < 2e-8, (d, fd, c["J"][:, d])
+    iw = m["body_invweight0"].reshape(-1, 2)
+    assert np.allclose(c["diag"][:3], iw[l2, 0] + iw[f, 0]) and np.allclose(c["diag"][3:6], iw[l2, 1] + iw[f, 1])
+    assert np.allclose(c["diag"][6:9], iw[w, 0]) and np.allclose(c["diag"][9:], iw[w, 1])
+    for k in (0, 6):                                                                  # one impedance for the six rows
+        ratio = c["R"][k:k + 6] / c["diag"][k:k + 6]
+        assert np.allclose(ratio, ratio[0], rtol=1e-12)
+    # a free body welded to the world where it is, its mass off the body origin: static sag of the soft constraint
+    bb = ModelBuilder(timestep=h, contact=False)
+    s = bb.body("s", 0, pos=(0, 0, 1)); bb.joint(s, "fs", FREE); bb.geom(s, "gs", SPHERE, size=(0.05,), pos=(0.1, 0, 0), mass=0.25)
+    bb.weld(s, 0, solref=(0.006, 1.0))
+    ms = bb.compile()
+    os_ = ol.Oracle(ms, _copy_task(ms))
+    qs, vs = np.array(ms["qpos0"], float), np.zeros(6)
+    qs, vs, *_ = os_.step(qs, vs, nstep=8000)          # the tilt mode is slow
+    assert np.abs(vs).max() < 1e-6
+    cs = os_.constraints(qs)
+    tc, dmax = 0.006, 0.95
+    K = 1 / (dmax * dmax * tc * tc)
+    imp = 1 / (1 + cs["R"][2] / cs["diag"][2])
+    assert cs["pos"][2] == pytest.approx(-0.25 * 9.81 * cs["R"][2] / (K * imp), rel=1e-5)          # D K imp pos = - m g
+    assert abs(cs["pos"][2]) < 1e-3 and 1e-5 < np.abs(cs["pos"][3:]).max() < 5e-3                    # small tilt from the off-centre weight
+
+
 def test_implicitfast_integrator_closed_form():
     """mjINT_IMPLICITFAST on one hinge with a position servo (kp, kv) and joint damping b:  v' = v + h tau / (I + h (b + g^2 kv)),
     tau = g (kp (u - g q) - kv g v) - b v;  Euler keeps only b in the denominator; with the servo force on its range the velocity

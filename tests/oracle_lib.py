@@ -37,8 +37,15 @@ def lib():
     if FAST:
         so = os.path.join(ORACLE_DIR, "_build", "liboracle_fast.so")
         subprocess.check_call(["make", "-B", "-C", ORACLE_DIR, "fast"], stdout=subprocess.DEVNULL)   # -march=native: build where it runs
-    elif (not os.path.exists(ORACLE_SO)) or any(os.path.getmtime(s) > os.path.getmtime(ORACLE_SO) for s in srcs):
-        subprocess.check_call(["make", "-C", ORACLE_DIR], stdout=subprocess.DEVNULL)
+    else:
+        # parallel test workers: one of them rebuilds, the others wait for the lock and find the library fresh (the Makefile renames
+        # the finished file into place, so a reader never sees a half-written one)
+        import fcntl
+        os.makedirs(os.path.join(ORACLE_DIR, "_build"), exist_ok=True)
+        with open(os.path.join(ORACLE_DIR, "_build", ".lock"), "w") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            if (not os.path.exists(ORACLE_SO)) or any(os.path.getmtime(s) > os.path.getmtime(ORACLE_SO) for s in srcs):
+                subprocess.check_call(["make", "-C", ORACLE_DIR], stdout=subprocess.DEVNULL)
     L = C.CDLL(so)
     L.oracle_create.restype = C.c_void_p
     L.oracle_create.argtypes = [C.POINTER(capi.MjpcHipModel), C.POINTER(capi.MjpcHipTask)]

@@ -77,6 +77,8 @@ enum {
   MJPC_TASK_HUMANOID_INTERACT = 15, /* mjpc/tasks/humanoid/interact/interact.cc:31-186: int_data = [body torso, pelvis, foot_right, foot_left, head,
                                   * shin_right, shin_left, has facing target, (body1, body2) x 5 (-1: pair not selected)]; dbl_data = [facing target
                                   * x, y, (local_pos1[3], local_pos2[3]) x 5]; parameters = [head height goal, torso height goal] */
+  MJPC_TASK_FINGERS = 16,        /* mjpc/tasks/fingers/fingers.cc:31-62: finger_a - object, finger_b - object (framepos of the bodies), distance of the three
+                                  * object sites to their targets, control; int_data = [body finger_a, finger_b, object, sites 0 1 2, sites 0t 1t 2t] */
   MJPC_TASK_QUADROTOR = 13       /* mjpc/tasks/quadrotor/quadrotor.cc:37-60: position - goal, linear / angular velocity, control - hover thrust (13 of
                                  * the 15 declared residuals are written); int_data = [body, stage]; dbl_data = stage goals [nstage][7] */
 };
@@ -102,7 +104,7 @@ enum {
    with `struct_size` (= sizeof of the struct as the CALLER compiled it): mjpc_hip_create / mjpc_hip_set_task refuse a view whose
    size differs from the library's, so a stale .so paired with a newer header (or ctypes layout) fails loudly instead of reading
    garbage pointers.  Bindings without the header: mjpc_hip_sizeof_model() / _task() / _plan_input() / _plan_output(). */
-#define MJPC_HIP_ABI_VERSION 3
+#define MJPC_HIP_ABI_VERSION 4
 
 typedef struct MjpcHipModel {
   int struct_size;                  /* sizeof(MjpcHipModel) */
@@ -127,7 +129,8 @@ typedef struct MjpcHipModel {
                             * the inertia-box fluid forces; no Coriolis derivative; symmetric factorisation) or MJPC_INT_IMPLICIT (2: the same
                             * plus the velocity derivative of the bias forces, mjd_rne_vel, and an LU factorisation of the non-symmetric
                             * M - h dF/dv).  RK4 is refused */
-  int noslip_iterations;   /* must be 0 */
+  int noslip_iterations;   /* mjOption.noslip_iterations: > 0 runs mj_solNoSlip after the Newton solve (friction-loss rows and the friction
+                            * dimensions of the contacts re-solved without regularisation; noslip_tolerance at the end of this struct) */
   int neq;                 /* number of equality constraints (eq_* below): connect, weld, joint and (fixed-)tendon equalities; flex is refused */
   int unsupported;         /* MJPC_UNSUP_* bits found by whoever fills this view in parts of mjModel the view does not carry
                             * (integration/hip_sampling_planner.cc: FillModelView); non-zero is refused at create */
@@ -176,8 +179,8 @@ typedef struct MjpcHipModel {
   const int *site_bodyid;
   const double *site_pos, *site_quat;
   /* actuators (joint or fixed-tendon transmission; gain fixed; bias none/affine: motor, general, position servos) */
-  const int *actuator_trntype;      /* MJPC_TRN_JOINT / MJPC_TRN_TENDON / MJPC_TRN_SITE (no refsite: the wrench actuator_gear6 in the site frame,
-                                     * motors only - biastype none) */
+  const int *actuator_trntype;      /* MJPC_TRN_JOINT / MJPC_TRN_TENDON / MJPC_TRN_SITE (without a reference site: the wrench actuator_gear6 in the
+                                     * site frame, motors only - biastype none; with one: actuator_refsite at the end of this struct) */
   const int *actuator_trnid;        /* joint, tendon or site id (first of the 2 mjModel ints) */
   const int *actuator_ctrllimited, *actuator_forcelimited, *actuator_biastype;
   const double *actuator_gainprm;   /* 3 per actuator (first 3 of mjNGAIN) */
@@ -212,6 +215,13 @@ typedef struct MjpcHipModel {
   /* keyframes */
   const double *key_qpos;           /* nkey * nq */
   const double *key_mpos;           /* nkey * 3*nmocap */
+  /* added with ABI revision 4 */
+  const int *actuator_refsite;      /* second mjModel.actuator_trnid int of a MJPC_TRN_SITE actuator: the reference site, -1 = none; NULL = none at
+                                     * all.  With a reference site the transmission has a length (site position in the reference site's frame
+                                     * dotted with gear[0:3]) and the moment (Jp_site - Jp_ref)^T R_ref gear[0:3], zero on the dofs both sites
+                                     * share (mj_transmission); any gain / affine bias / activation state may ride it; a rotational gear
+                                     * (gear[3:6] != 0) with a reference site is refused */
+  double noslip_tolerance;          /* mjOption.noslip_tolerance (1e-6) */
 } MjpcHipModel;
 
 /* ---- task: cost table (mjpc/task.cc:147-245) + frozen ResidualFn state --------------- */

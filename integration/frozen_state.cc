@@ -117,6 +117,11 @@ struct HipFrozenState {
   static void Swimmer(const mjModel* m, std::vector<int>& I) { I = {SensorObject(m, "nose"), 0}; }             // swimmer.cc:41-43: the nose geom
   static void Walker(const mjModel* m, std::vector<int>& I) { I = {SensorObject(m, "torso_position")}; }      // walker.cc:39-57
   static void Particle(const mjModel* m, std::vector<int>& I) { I = {SensorObject(m, "position")}; }          // particle.cc:33-38: the tip site
+  // fingers.cc:36-52: the framepos sensors' objects (bodies finger_a, finger_b, object; sites 0 1 2 and 0t 1t 2t)
+  static void Fingers(const mjModel* m, std::vector<int>& I) {
+    I = {SensorObject(m, "finger_a"), SensorObject(m, "finger_b"), SensorObject(m, "object"), SensorObject(m, "0"), SensorObject(m, "1"), SensorObject(m, "2"),
+         SensorObject(m, "0t"), SensorObject(m, "1t"), SensorObject(m, "2t")};
+  }
   static void Acrobot(std::vector<int>& I) { I = {0, 1}; }                                                   // acrobot.cc:38-39: sites 0 and 1
 };
 
@@ -149,6 +154,7 @@ void FillFrozenState(const Task& task, const ResidualFn* residual, const mjModel
     case MJPC_TASK_SWIMMER: HipFrozenState::Swimmer(m, ints); break;
     case MJPC_TASK_WALKER: HipFrozenState::Walker(m, ints); break;
     case MJPC_TASK_ACROBOT: HipFrozenState::Acrobot(ints); break;
+    case MJPC_TASK_FINGERS: HipFrozenState::Fingers(m, ints); break;
     case MJPC_TASK_PARTICLE_TIMEVARYING: case MJPC_TASK_PARTICLE_FIXED: HipFrozenState::Particle(m, ints); break;
     default: break;                                                      // cartpole: nothing frozen
   }

@@ -40,6 +40,7 @@ int DeviceResidual(const Task& task) {
   if (name == "Quadrotor") return MJPC_TASK_QUADROTOR;
   if (name == "Swimmer") return MJPC_TASK_SWIMMER;
   if (name == "Acrobot") return MJPC_TASK_ACROBOT;
+  if (name == "FreeFingers") return MJPC_TASK_FINGERS;
   return -1;
 }
 
@@ -68,7 +69,7 @@ static void FillModelView(const mjModel* m, MjpcHipModel& v, std::vector<int>& j
   v.impratio = m->opt.impratio; v.tolerance = m->opt.tolerance; v.ls_tolerance = m->opt.ls_tolerance;
   v.cone = m->opt.cone; v.iterations = m->opt.iterations; v.ls_iterations = m->opt.ls_iterations;
   v.disableflags = m->opt.disableflags; v.enableflags = m->opt.enableflags; v.solver = m->opt.solver; v.integrator = m->opt.integrator;
-  v.noslip_iterations = m->opt.noslip_iterations; v.neq = m->neq; v.meaninertia = m->stat.meaninertia;
+  v.noslip_iterations = m->opt.noslip_iterations; v.noslip_tolerance = m->opt.noslip_tolerance; v.neq = m->neq; v.meaninertia = m->stat.meaninertia;
   // what this view does not carry: found here, refused by mjpc_hip_create
   v.unsupported = 0;
   v.density = m->opt.density; v.viscosity = m->opt.viscosity; mju_copy3(v.wind, m->opt.wind);
@@ -126,13 +127,14 @@ static void FillModelView(const mjModel* m, MjpcHipModel& v, std::vector<int>& j
   v.actuator_ctrllimited = ctrllimited.data(); v.actuator_forcelimited = forcelimited.data(); v.actuator_biastype = biastype.data();
   v.actuator_gainprm = gainprm.data(); v.actuator_biasprm = biasprm.data(); v.actuator_gear = gear.data(); v.actuator_gear6 = m->actuator_gear;
   v.actuator_ctrlrange = m->actuator_ctrlrange; v.actuator_forcerange = m->actuator_forcerange;
-  act_i.assign(3 * m->nu, 0); dynprm.assign(m->nu, 0.0);
+  act_i.assign(4 * m->nu, 0); dynprm.assign(m->nu, 0.0);
   for (int i = 0; i < m->nu; i++) {
     act_i[i] = m->actuator_dyntype[i]; act_i[m->nu + i] = m->actuator_actadr[i]; act_i[2 * m->nu + i] = m->actuator_actlimited[i];
     dynprm[i] = m->actuator_dynprm[mjNDYN * i];
+    act_i[3 * m->nu + i] = m->actuator_trntype[i] == mjTRN_SITE ? m->actuator_trnid[2 * i + 1] : -1;      // reference site
   }
   v.actuator_dyntype = act_i.data(); v.actuator_actadr = act_i.data() + m->nu; v.actuator_actlimited = act_i.data() + 2 * m->nu;
-  v.actuator_dynprm = dynprm.data(); v.actuator_actrange = m->actuator_actrange;
+  v.actuator_dynprm = dynprm.data(); v.actuator_actrange = m->actuator_actrange; v.actuator_refsite = act_i.data() + 3 * m->nu;
   // fixed tendons: wrap objects are joints, wrap_prm the coefficient (spatial tendons are refused by mjpc_hip_create)
   tendon_limited = Widen(m->tendon_limited, m->ntendon);
   wrap_objid.assign(m->wrap_objid, m->wrap_objid + m->nwrap); wrap_prm.assign(m->wrap_prm, m->wrap_prm + m->nwrap);

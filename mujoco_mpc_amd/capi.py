@@ -66,6 +66,7 @@ class MjpcHipModel(C.Structure):
         + [(n, c_int_p) for n in ["geom_dataid", "mesh_vertadr", "mesh_vertnum"]] + [("mesh_vert", c_double_p)]
         + [(n, c_int_p) for n in ["hfield_nrow", "hfield_ncol", "hfield_adr"]] + [("hfield_size", c_double_p), ("hfield_data", c_double_p)]
         + [("key_qpos", c_double_p), ("key_mpos", c_double_p)]
+        + [("actuator_refsite", c_int_p), ("noslip_tolerance", C.c_double)]
     )
 
 
@@ -135,6 +136,10 @@ class CModel:
                 v = np.zeros(int(model["nbody"]))
             elif name == "actuator_gear6" and name not in model:      # models built before site transmissions existed
                 v = np.zeros(6 * int(model["nu"]))
+            elif name == "actuator_refsite" and name not in model:    # models built before reference sites existed: none
+                v = -np.ones(int(model["nu"]))
+            elif name == "noslip_tolerance" and name not in model:
+                v = 1e-6
             elif name in _OPTIONAL_EQ and name not in model:            # models built before equality constraints existed: none
                 v = np.zeros(0)
             elif name in _OPTIONAL_ACT and name not in model:           # models built before activation states existed: none
@@ -289,7 +294,7 @@ def debug_set(name: str, value=None):
     load_engine().mjpc_hip_debug_set(name.encode(), None if value is None else str(value).encode())
 
 
-ABI_VERSION = 3            # MJPC_HIP_ABI_VERSION of include/mjpc_hip.h
+ABI_VERSION = 4            # MJPC_HIP_ABI_VERSION of include/mjpc_hip.h
 
 EXPORTED_SYMBOLS = [
     "mjpc_hip_sizeof_model", "mjpc_hip_sizeof_task", "mjpc_hip_sizeof_plan_input", "mjpc_hip_sizeof_plan_output", "mjpc_hip_debug_set",

@@ -203,6 +203,7 @@ DEV double spline_sample(const double *times, const double *values, int P, int d
 #include "constraint.h"
 #include "dynamics.h"
 #include "residuals.h"
+#include "noslip.h"
 // ======================================================================================
 // phases of one step (mj_step = position, velocity, solve, [residual], integrate) — all __noinline__
 // ======================================================================================
@@ -412,6 +413,7 @@ DEV_SOLVE_PHASE void ph_solve(KP Kc, int last, int t) {
   Ctx c; ctx_open(c, Kc);
   c.hseq = t * 256;
   solve_constraints<NVT>(c); PROF(c, 8);
+  const int noslip = c.M->noslip_iterations > 0 && !(c.warning & (WARN_CONTACTFULL | WARN_CNSTRFULL | WARN_SYNC));
 #if MJPC_HELPER
   // release the waves that wait for jobs: the workers of elliptic models (one packed word, solver_reg.h) / the Hessian builders of
   // the generic path
@@ -421,6 +423,7 @@ DEV_SOLVE_PHASE void ph_solve(KP Kc, int last, int t) {
     flag_set(c.misc + HX_JOB, ++c.hseq);
   }
 #endif
+  if (noslip) noslip_pass<NVT>(c);       // (after the job waves have been released: the pass is the owner's alone)
   // (a step that already overflowed a buffer fails with that code alone: what the solver made of the truncated rows does not matter)
   if (!last && !(c.warning & (WARN_CONTACTFULL | WARN_CNSTRFULL)) && bad_values(c.qacc, c.M->nv)) c.warning |= WARN_BADQACC;
   ctx_close(c);
@@ -470,10 +473,9 @@ DEV_NOINLINE CostOut ph_residual_cost(KP Kc, int t, int last) {        // role 1
 // role 1, after the residual and still under the solver's shadow: factor M + h*diag(damping) for the implicit-damping
 // Euler step into qL / Linv (M's own factor is no longer needed once qacc_smooth exists)
 template <int NVT>
-DEV_NOINLINE void ph_prefactor(KP Kc) {
-  Ctx c; ctx_open(c, Kc, 1);
+DEV void prefactor_body(Ctx &c) {
   const DevModel &M = *c.M;
-  if (M.any_damping && !M.int_dense) {
+  {
     int nv = M.nv, nvp = M.nvp;
     double h = M.timestep;
     PFOR(e, nv * nvp) { int i = e / nvp, j = e - i * nvp; c.qL[e] = c.qM[e] + ((i == j) ? h * MD(dof_damping)[i] : 0.0); }
@@ -494,6 +496,13 @@ DEV_NOINLINE void ph_prefactor(KP Kc) {
     }
     chol_factor<NVT>(c.qL, c.Linv, c.scr_a, nv, nvp, c.M->tree_ok);
   }
+}
+// (a model with a noslip pass keeps M's own factor until the pass is over: its prefactor is the first thing of ph_integrate)
+template <int NVT>
+DEV_NOINLINE void ph_prefactor(KP Kc) {
+  Ctx c; ctx_open(c, Kc, 1);
+  const DevModel &M = *c.M;
+  if (M.any_damping && !M.int_dense && M.noslip_iterations <= 0) prefactor_body<NVT>(c);
   PROFW(c, 11);
   ctx_close(c);
 }
@@ -678,7 +687,8 @@ DEV_NOINLINE void ph_integrate(KP Kc, int t) {
   Rows R = out_rows(K);
   int nq = M.nq, nv = M.nv, nvp = M.nvp;
   double h = M.timestep;
-  PFOR(i, nv) c.qacc_ws[i] = c.qacc[i];
+  if (M.noslip_iterations <= 0) { PFOR(i, nv) c.qacc_ws[i] = c.qacc[i]; }      // (with a noslip pass the warm start is the Newton solution it saved)
+  else if (M.any_damping && !M.int_dense) { prefactor_body<NVT>(c); SYNC(); }
   if (M.int_dense) {
     PFOR(i, nv) c.Mgrad[i] = c.qfrc_smooth[i] + c.qfrc_constraint[i];
     SYNC();

@@ -125,6 +125,20 @@ DEV void subtree_sums(Ctx &c, int part) {
 #ifndef MJPC_CHAIN33
 #define MJPC_CHAIN33 1      // the per-lane chain walk of the velocity sweep also for the 33-dof hand (-0.5 %; 0 = level sweep)
 #endif
+// site transmission with a reference site (mj_transmission): entry d of the moment (Jp_site - Jp_ref)^T w, w = the gear in the world
+// frame; zero on the dofs both sites hang from
+DEV double rs_moment(Ctx &c, const int *ri, const double *w, int d) {
+  const DevModel &M = *c.M;
+  const int s = ri[1], r = ri[2], bs = ri[3], br = ri[4];
+  const unsigned long long common = (unsigned long long)(unsigned)ri[5] | ((unsigned long long)(unsigned)ri[6] << 32);
+  const int in_s = (int)((MDM()[bs] >> d) & 1ull), in_r = (int)((MDM()[br] >> d) & 1ull);
+  if ((!in_s && !in_r) || ((common >> d) & 1ull)) return 0.0;
+  const double *cd = c.cdof + 6 * d;
+  double jp[3] = {0, 0, 0}, off[3], t[3];
+  if (in_s) { d_sub3(off, c.site_xpos + 3 * s, c.subtree_com + 3 * MIH(body_rootid)[bs]); d_cross(t, cd, off); for (int q = 0; q < 3; q++) jp[q] += cd[3 + q] + t[q]; }
+  if (in_r) { d_sub3(off, c.site_xpos + 3 * r, c.subtree_com + 3 * MIH(body_rootid)[br]); d_cross(t, cd, off); for (int q = 0; q < 3; q++) jp[q] -= cd[3 + q] + t[q]; }
+  return jp[0] * w[0] + jp[1] * w[1] + jp[2] * w[2];
+}
 // force of actuator i for the input u (control, or activation of a stateful actuator): gain * u + affine bias, force range
 DEV double actuator_force_of(Ctx &c, int i, double u) {
   double force = MD(actuator_gainprm)[3 * i] * u;
@@ -134,6 +148,15 @@ DEV double actuator_force_of(Ctx &c, int i, double u) {
     for (int e = MI(act_adr)[i]; e < MI(act_adr)[i + 1]; e++) {
       double cf = MD(act_coef)[e];
       length += cf * c.qpos[MI(act_qpos)[e]]; velocity += cf * c.qvel[MI(act_dof)[e]];
+    }
+    if (c.M->nrsact > 0 && MI(rsact_of)[i] >= 0) {      // site relative to a reference site: length = w . (x_site - x_ref), velocity = moment . qvel
+      const int k = MI(rsact_of)[i];
+      const int *ri = MI(rsact_i) + 7 * k;
+      double w[3], vec[3];
+      d_mulmatvec3(w, c.xmat + 9 * ri[4], MD(rsact_g) + 3 * k);
+      d_sub3(vec, c.site_xpos + 3 * ri[1], c.site_xpos + 3 * ri[2]);
+      length = w[0] * vec[0] + w[1] * vec[1] + w[2] * vec[2];
+      for (int d = 0; d < c.M->nv; d++) velocity += rs_moment(c, ri, w, d) * c.qvel[d];
     }
     force += MD(actuator_biasprm)[3 * i] + MD(actuator_biasprm)[3 * i + 1] * length + MD(actuator_biasprm)[3 * i + 2] * velocity;
   }
@@ -237,6 +260,20 @@ DEV_NOINLINE void ph_smooth_extras(KP Kc) {
         d_sub3(off, c.site_xpos + 3 * s, c.subtree_com + 3 * MIH(body_rootid)[b]);
         d_cross(t, cd, off);
         acc += c.actuator_force[a] * ((cd[3] + t[0]) * f[0] + (cd[4] + t[1]) * f[1] + (cd[5] + t[2]) * f[2] + cd[0] * tq[0] + cd[1] * tq[1] + cd[2] * tq[2]);
+      }
+      c.qfrc_smooth[d] = acc;
+    }
+    SYNC();
+  }
+  if (M.nrsact > 0) {
+    // site transmissions with a reference site: qfrc += moment^T force
+    PFOR(d, nv) {
+      double acc = c.qfrc_smooth[d];
+      for (int k = 0; k < M.nrsact; k++) {
+        const int *ri = MI(rsact_i) + 7 * k;
+        double w[3];
+        d_mulmatvec3(w, c.xmat + 9 * ri[4], MD(rsact_g) + 3 * k);
+        acc += rs_moment(c, ri, w, d) * c.actuator_force[ri[0]];
       }
       c.qfrc_smooth[d] = acc;
     }

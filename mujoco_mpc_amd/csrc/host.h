@@ -128,6 +128,7 @@ static inline void make_layout(const PackedModel &p, Lay &L, const MjpcHipModel 
   A_(residual, nr + 1); A_(terms, t->num_term + 1); A_(red, 8); A_(prof, 26);
   A_(scr_a, nv + 1); A_(scr_b, nv + 1);                       // solve-phase scratch of the side wave / of the helper's cost at qacc_smooth
   if (lean) L.xfrc = 0; else { A_(xfrc, 6 * nb); }             // no force noise on the dense tier (engine.hip)
+  if (m->noslip_iterations > 0) { A_(noslip, ne * nvp + nc * 36 + 2 * ne + 1); } else L.noslip = 0;
   A_(mc_d, cache_d + 1); A_(mc_i, (cache_i + 2) / 2);
   L.ints = o;
 #undef A_
@@ -158,7 +159,7 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
     if (cnt != m->na) { p.error = "na = " + std::to_string(m->na) + " but " + std::to_string(cnt) + " stateful actuators (one activation each)"; return false; } }
   if (m->solver != MJPC_SOL_NEWTON) { p.error = "only the Newton solver (mjSOL_NEWTON) is implemented"; return false; }
   if (m->integrator != MJPC_INT_EULER && m->integrator != MJPC_INT_IMPLICITFAST && m->integrator != MJPC_INT_IMPLICIT) { p.error = "only the Euler (with implicit joint damping), implicitfast and implicit integrators are implemented (not RK4)"; return false; }
-  if (m->noslip_iterations != 0) { p.error = "noslip_iterations > 0 not supported"; return false; }
+  if (m->noslip_iterations < 0) { p.error = "noslip_iterations < 0"; return false; }
   for (int e = 0; e < m->neq; e++) {
     if (!m->eq_type || !m->eq_obj1id || !m->eq_obj2id || !m->eq_active0 || !m->eq_data || !m->eq_solref || !m->eq_solimp) { p.error = "neq > 0 but the eq_* tables are missing"; return false; }
     if (!m->eq_active0[e]) continue;
@@ -183,7 +184,13 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
   for (int i = 0; i < nu; i++)
     if (m->actuator_trntype[i] == MJPC_TRN_SITE) {
       if (!m->actuator_gear6 || m->actuator_trnid[i] < 0 || m->actuator_trnid[i] >= ns) { p.error = "actuator " + std::to_string(i) + ": site transmission without actuator_gear6 or with a site id out of range"; return false; }
-      if (m->actuator_biastype[i] != MJPC_BIAS_NONE || (m->actuator_dyntype && m->actuator_dyntype[i] != MJPC_DYN_NONE)) { p.error = "actuator " + std::to_string(i) + ": site transmissions are implemented for plain motors (no bias, no activation)"; return false; }
+      const int rs = m->actuator_refsite ? m->actuator_refsite[i] : -1;
+      if (rs >= ns) { p.error = "actuator " + std::to_string(i) + ": reference site out of range"; return false; }
+      if (rs >= 0) {
+        const double *g = m->actuator_gear6 + 6 * i;
+        if (g[3] != 0 || g[4] != 0 || g[5] != 0) { p.error = "actuator " + std::to_string(i) + ": a rotational gear together with a reference site is not implemented"; return false; }
+        if (m->actuator_biastype[i] == MJPC_BIAS_AFFINE && m->actuator_biasprm[3 * i + 2] != 0 && m->integrator != MJPC_INT_EULER) { p.error = "actuator " + std::to_string(i) + ": a velocity bias on a site transmission under an implicit integrator is not implemented"; return false; }
+      } else if (m->actuator_biastype[i] != MJPC_BIAS_NONE || (m->actuator_dyntype && m->actuator_dyntype[i] != MJPC_DYN_NONE)) { p.error = "actuator " + std::to_string(i) + ": site transmissions without a reference site are implemented for plain motors (no bias, no activation)"; return false; }
     } else if (m->actuator_trntype[i] != MJPC_TRN_JOINT && m->actuator_trntype[i] != MJPC_TRN_TENDON) {
       p.error = "actuator " + std::to_string(i) + ": only joint, fixed-tendon and site transmissions are supported"; return false; }
   M.na = m->na;
@@ -313,9 +320,32 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
     }
     M.ngravcomp = (int)gb.size();
     M.gc_body = as_off<int>(put_i(p, gb.data(), gb.size())); M.gc_force = as_off<double>(put_d(p, gf.data(), gf.size())); }
+  // site transmissions with a reference site (mj_transmission): the translational gear in the reference body's frame and the
+  // dofs both sites hang from (their moment entries are cleared)
+  { std::vector<int> ri, rof(nu, -1); std::vector<double> rg;
+    for (int i = 0; i < nu; i++) if (m->actuator_trntype[i] == MJPC_TRN_SITE && m->actuator_refsite && m->actuator_refsite[i] >= 0) {
+      int s = m->actuator_trnid[i], r = m->actuator_refsite[i], bs = m->site_bodyid[s], br = m->site_bodyid[r];
+      rof[i] = (int)ri.size() / 7;
+      unsigned long long mask = 0;
+      int b0 = m->body_weldid[bs], b1 = m->body_weldid[br];
+      int d0 = m->body_dofnum[b0] ? m->body_dofadr[b0] + m->body_dofnum[b0] - 1 : -1, d1 = m->body_dofnum[b1] ? m->body_dofadr[b1] + m->body_dofnum[b1] - 1 : -1;
+      if (d0 >= 0 && d1 >= 0) {
+        while (d0 != d1) { if (d0 < d1) d1 = m->dof_parentid[d1]; else d0 = m->dof_parentid[d0]; if (d0 == -1 || d1 == -1) break; }
+        if (d0 == d1) for (int d = d0; d >= 0; d = m->dof_parentid[d]) mask |= 1ull << d;
+      }
+      ri.push_back(i); ri.push_back(s); ri.push_back(r); ri.push_back(bs); ri.push_back(br); ri.push_back((int)(mask & 0xffffffffu)); ri.push_back((int)(mask >> 32));
+      const double *q = m->site_quat + 4 * r, *g = m->actuator_gear6 + 6 * i;
+      double R[9] = {1 - 2 * (q[2] * q[2] + q[3] * q[3]), 2 * (q[1] * q[2] - q[0] * q[3]), 2 * (q[1] * q[3] + q[0] * q[2]),
+                     2 * (q[1] * q[2] + q[0] * q[3]), 1 - 2 * (q[1] * q[1] + q[3] * q[3]), 2 * (q[2] * q[3] - q[0] * q[1]),
+                     2 * (q[1] * q[3] - q[0] * q[2]), 2 * (q[2] * q[3] + q[0] * q[1]), 1 - 2 * (q[1] * q[1] + q[2] * q[2])};
+      for (int k = 0; k < 3; k++) rg.push_back(R[3 * k] * g[0] + R[3 * k + 1] * g[1] + R[3 * k + 2] * g[2]);
+    }
+    M.nrsact = (int)ri.size() / 7;
+    M.rsact_i = as_off<int>(put_i(p, ri.data(), ri.size())); M.rsact_of = as_off<int>(put_i(p, rof.data(), rof.size())); M.rsact_g = as_off<double>(put_d(p, rg.data(), rg.size())); }
+  M.noslip_iterations = m->noslip_iterations; M.noslip_tolerance = m->noslip_tolerance;
   // site transmissions (mjTRN_SITE, no refsite): [actuator, site, body] and the gear wrench rotated into the body frame
   { std::vector<int> si; std::vector<double> sg;
-    for (int i = 0; i < nu; i++) if (m->actuator_trntype[i] == MJPC_TRN_SITE) {
+    for (int i = 0; i < nu; i++) if (m->actuator_trntype[i] == MJPC_TRN_SITE && !(m->actuator_refsite && m->actuator_refsite[i] >= 0)) {
       int s = m->actuator_trnid[i];
       si.push_back(i); si.push_back(s); si.push_back(m->site_bodyid[s]);
       const double *q = m->site_quat + 4 * s;
@@ -486,7 +516,7 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
     }
     M.ntendon_passive = (int)ids.size();
     M.tpass_id = as_off<int>(put_i(p, ids.data(), ids.size())); M.tpass_prm = as_off<double>(put_d(p, prm.data(), prm.size())); }
-  M.smooth_extras = M.ntendon_passive + M.nsiteact + M.ngravcomp + M.fluid + M.nactfrc;
+  M.smooth_extras = M.ntendon_passive + M.nsiteact + M.nrsact + M.ngravcomp + M.fluid + M.nactfrc;
   M.any_damping = 0;
   for (int i = 0; i < nv; i++) if (m->dof_damping[i] > 0) M.any_damping = 1;
   // implicitfast: velocity derivatives of the smooth forces beyond joint damping, as entries (i >= j, coefficient, actuator or -1) of
@@ -582,7 +612,7 @@ static inline DevModel relocate(const PackedModel &p, const int *ibase, const do
   fi(M.level_adr); fi(M.level_body); fi(M.subtree_adr); fi(M.subtree_list); fi(M.chain_adr); fi(M.chain_list); fi(M.mpair_i); fi(M.mpair_j); fi(M.hpair_i); fi(M.hpair_j); fi(M.zpair_i); fi(M.zpair_j);
   { const double *q = reinterpret_cast<const double *>(M.body_dofmask); fd(q); M.body_dofmask = reinterpret_cast<const unsigned long long *>(q); }
   { const double *q = reinterpret_cast<const double *>(M.body_patmask); fd(q); M.body_patmask = reinterpret_cast<const unsigned long long *>(q); }
-  fi(M.pair_g1); fi(M.pair_g2); fi(M.fric_dof); fi(M.limit_jnt); fi(M.limit_ball); fi(M.ray_geom); fi(M.tpass_id); fd(M.tpass_prm); fi(M.tfric_id); fd(M.tfric_prm); fi(M.idrv_e); fd(M.idrv_c); fi(M.eq_tab); fd(M.eq_prm); fi(M.sact_i); fd(M.sact_g); fi(M.gc_body); fd(M.gc_force); fi(M.actfrc_dof); fd(M.actfrc_range);
+  fi(M.pair_g1); fi(M.pair_g2); fi(M.fric_dof); fi(M.limit_jnt); fi(M.limit_ball); fi(M.ray_geom); fi(M.tpass_id); fd(M.tpass_prm); fi(M.tfric_id); fd(M.tfric_prm); fi(M.idrv_e); fd(M.idrv_c); fi(M.eq_tab); fd(M.eq_prm); fi(M.sact_i); fd(M.sact_g); fi(M.rsact_i); fi(M.rsact_of); fd(M.rsact_g); fi(M.gc_body); fd(M.gc_force); fi(M.actfrc_dof); fd(M.actfrc_range);
   DevTask &T = M.task;
   fi(T.dim_norm_residual); fi(T.norm); fi(T.num_norm_parameter); fi(T.trace_objtype); fi(T.trace_objid); fi(T.int_data);
   fd(T.weight); fd(T.norm_parameter); fd(T.parameters); fd(T.dbl_data);

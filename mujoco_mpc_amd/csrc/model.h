@@ -119,6 +119,10 @@ struct DevModel {
   const int *gc_body; const double *gc_force;
   int nsiteact;                             // site transmissions: sact_i [actuator, site, body], sact_g [force 3, torque 3 in the body frame]
   const int *sact_i; const double *sact_g;
+  int nrsact;                               // site transmissions with a reference site: rsact_i [actuator, site, refsite, body, refbody, common-dof mask lo, hi],
+  const int *rsact_i, *rsact_of;            // rsact_g [the translational gear in the reference BODY's frame], rsact_of[actuator] = entry or -1
+  const double *rsact_g;
+  int noslip_iterations; double noslip_tolerance;      // mj_solNoSlip after the Newton solve (noslip.h)
   int na;                                   // activation states (one per stateful actuator); tables below only when na > 0
   const int *actuator_dyntype, *actuator_actadr, *actuator_actlimited;
   const double *actuator_dynprm, *actuator_actrange;
@@ -167,6 +171,7 @@ struct Lay {
   int Ma, grad, Mgrad, search, Mv, vtmp, sgl;
   int knot_times, knot_values, residual, terms, red, prof, scr_a, scr_b;
   int xfrc;            // external body forces (NoisyRollout of the robust planner), 6 per body
+  int noslip;          // noslip pass: M^-1 J^T rows [nefcmax x nvp], contact blocks [nconmax x 36], b and diagonal [2 x nefcmax] (0 without noslip)
   int mc_d, mc_i;      // LDS copy of the model tables: fp64 part, int part (both offsets in doubles)
   int ints;            // start of the int region (in doubles)
   int i_efc_type, i_efc_id, i_efc_state, i_efc_dof, i_con, i_active, i_misc, i_hpair;

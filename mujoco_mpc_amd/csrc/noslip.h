@@ -1,0 +1,289 @@
+// noslip.h — mj_solNoSlip (MuJoCo engine_solver.c) on the owner wave, after the Newton solve of a model with noslip_iterations > 0:
+// the friction-loss rows and the friction dimensions of the contacts are re-solved in the dual WITHOUT the regulariser R by
+// projected Gauss-Seidel over efc_force (limits, equalities and the contacts' normal forces stay as the Newton solve left them),
+// then qacc = qacc_smooth + M^-1 J^T force.  (part of core.h)
+//
+// MuJoCo works on the dense dual matrix AR = J M^-1 J^T + diag(R).  Here the rows B_r = M^-1 J_r^T are kept instead (same size
+// as J) together with w = M^-1 J^T force, one entry per lane: the residual of a block is J_blk w + b_blk, a force change d updates
+// w += sum_k d_k B_k, the small diagonal blocks J_blk B_blk^T are formed once per step.  Same sweeps, same block updates and
+// the same stopping rule as the CPU restatement (oracle/physics.c: noslip).
+#pragma once
+#define NS_BT(c) (lds_base() + (c).K->L.noslip)
+
+// entry i of constraint row r (a friction-loss row is the unit vector of its dof and has no stored row)
+DEV double ns_jent(Ctx &c, int r, int i) { return r < c.M->nfric ? (c.efc_dof[r] == i ? 1.0 : 0.0) : c.efc_J[r * c.M->nvp + i]; }
+
+// min 0.5 x'Ax + x'b  s.t.  sum (x_i / d_i)^2 <= r^2  (mju_QCQP2 / QCQP3 / QCQP): scaled to a ball, Newton on the multiplier.
+// Uniform scalar code: every lane computes the same values.
+DEV void ns_qcqp2(double *res, const double *Ain, const double *bin, const double *d, double r) {
+  double b1 = bin[0] * d[0], b2 = bin[1] * d[1];
+  double A11 = Ain[0] * d[0] * d[0], A22 = Ain[3] * d[1] * d[1], A12 = Ain[1] * d[0] * d[1];
+  double la = 0, v1 = 0, v2 = 0;
+  for (int iter = 0; iter < 20; iter++) {
+    double det = (A11 + la) * (A22 + la) - A12 * A12;
+    if (det < 1e-10) { res[0] = 0; res[1] = 0; return; }
+    double detinv = 1 / det;
+    double P11 = (A22 + la) * detinv, P22 = (A11 + la) * detinv, P12 = -A12 * detinv;
+    v1 = -P11 * b1 - P12 * b2; v2 = -P12 * b1 - P22 * b2;
+    double val = v1 * v1 + v2 * v2 - r * r;
+    if (val < 1e-10) break;
+    double deriv = -2 * (P11 * v1 * v1 + 2 * P12 * v1 * v2 + P22 * v2 * v2);
+    double delta = -val / deriv;
+    if (delta < 1e-10) break;
+    la += delta;
+  }
+  res[0] = v1 * d[0]; res[1] = v2 * d[1];
+}
+DEV void ns_qcqp3(double *res, const double *Ain, const double *bin, const double *d, double r) {
+  double b1 = bin[0] * d[0], b2 = bin[1] * d[1], b3 = bin[2] * d[2];
+  double A11 = Ain[0] * d[0] * d[0], A22 = Ain[4] * d[1] * d[1], A33 = Ain[8] * d[2] * d[2];
+  double A12 = Ain[1] * d[0] * d[1], A13 = Ain[2] * d[0] * d[2], A23 = Ain[5] * d[1] * d[2];
+  double la = 0, v1 = 0, v2 = 0, v3 = 0;
+  for (int iter = 0; iter < 20; iter++) {
+    double P11 = (A22 + la) * (A33 + la) - A23 * A23, P22 = (A11 + la) * (A33 + la) - A13 * A13, P33 = (A11 + la) * (A22 + la) - A12 * A12;
+    double P12 = A13 * A23 - A12 * (A33 + la), P13 = A12 * A23 - A13 * (A22 + la), P23 = A12 * A13 - A23 * (A11 + la);
+    double det = (A11 + la) * P11 + A12 * P12 + A13 * P13;
+    if (det < 1e-10) { res[0] = res[1] = res[2] = 0; return; }
+    double detinv = 1 / det;
+    P11 *= detinv; P22 *= detinv; P33 *= detinv; P12 *= detinv; P13 *= detinv; P23 *= detinv;
+    v1 = -P11 * b1 - P12 * b2 - P13 * b3; v2 = -P12 * b1 - P22 * b2 - P23 * b3; v3 = -P13 * b1 - P23 * b2 - P33 * b3;
+    double val = v1 * v1 + v2 * v2 + v3 * v3 - r * r;
+    if (val < 1e-10) break;
+    double deriv = -2 * (P11 * v1 * v1 + P22 * v2 * v2 + P33 * v3 * v3) - 4 * (P12 * v1 * v2 + P13 * v1 * v3 + P23 * v2 * v3);
+    double delta = -val / deriv;
+    if (delta < 1e-10) break;
+    la += delta;
+  }
+  res[0] = v1 * d[0]; res[1] = v2 * d[1]; res[2] = v3 * d[2];
+}
+// mju_cholFactor with a rank threshold / mju_cholSolve, n <= 5
+DEV int ns_small_chol(double *A, int n, double mindiag) {
+  int rank = n;
+  for (int j = 0; j < n; j++) {
+    double t = A[j * n + j];
+    for (int k = 0; k < j; k++) t -= A[j * n + k] * A[j * n + k];
+    if (t < mindiag) { t = mindiag; rank--; }
+    A[j * n + j] = sqrt(t);
+    double inv = 1 / A[j * n + j];
+    for (int i = j + 1; i < n; i++) {
+      double s = A[i * n + j];
+      for (int k = 0; k < j; k++) s -= A[i * n + k] * A[j * n + k];
+      A[i * n + j] = s * inv;
+    }
+  }
+  return rank;
+}
+DEV void ns_small_chol_solve(double *x, const double *L, const double *b, int n) {
+  for (int i = 0; i < n; i++) { double s = b[i]; for (int k = 0; k < i; k++) s -= L[i * n + k] * x[k]; x[i] = s / L[i * n + i]; }
+  for (int i = n - 1; i >= 0; i--) { double s = x[i]; for (int k = i + 1; k < n; k++) s -= L[k * n + i] * x[k]; x[i] = s / L[i * n + i]; }
+}
+DEV void ns_qcqpn(double *res, const double *Ain, const double *bin, const double *d, double r, int n) {
+  double A[25], Ala[25], b[5], tmp[5], la = 0;
+  for (int i = 0; i < n; i++) { b[i] = bin[i] * d[i]; for (int j = 0; j < n; j++) A[j + i * n] = Ain[j + i * n] * d[i] * d[j]; }
+  for (int iter = 0; iter < 20; iter++) {
+    for (int i = 0; i < n * n; i++) Ala[i] = A[i];
+    for (int i = 0; i < n; i++) Ala[i * (n + 1)] += la;
+    if (ns_small_chol(Ala, n, 1e-10) < n) { for (int i = 0; i < n; i++) res[i] = 0; return; }
+    ns_small_chol_solve(res, Ala, b, n);
+    double val = 0;
+    for (int i = 0; i < n; i++) { res[i] = -res[i]; val += res[i] * res[i]; }
+    val -= r * r;
+    if (val < 1e-10) break;
+    ns_small_chol_solve(tmp, Ala, res, n);
+    double deriv = 0;
+    for (int i = 0; i < n; i++) deriv += res[i] * tmp[i];
+    deriv *= -2;
+    double delta = -val / deriv;
+    if (delta < 1e-10) break;
+    la += delta;
+  }
+  for (int i = 0; i < n; i++) res[i] = res[i] * d[i];
+}
+// cost change of a block update; an update that raises the cost is taken back (costChange)
+DEV double ns_cost_change(const double *A, double *force, const double *oldforce, const double *res, int dim) {
+  double delta[6], change = 0;
+  for (int j = 0; j < dim; j++) delta[j] = force[j] - oldforce[j];
+  for (int j = 0; j < dim; j++) { double t = 0; for (int k = 0; k < dim; k++) t += A[j * dim + k] * delta[k]; change += 0.5 * delta[j] * t; }
+  for (int j = 0; j < dim; j++) change += delta[j] * res[j];
+  if (change > 1e-10) { for (int j = 0; j < dim; j++) force[j] = oldforce[j]; change = 0; }
+  return change;
+}
+
+// B_r = M^-1 J_r^T for every row, from the factor of M in qL / Linv
+template <int NVT>
+DEV void ns_minv_rows(Ctx &c, double *Bt) {
+  const DevModel &M = *c.M;
+  const int nv = M.nv, nvp = M.nvp, nefc = c.nefc;
+#ifndef MJPC_EMU
+  if constexpr (NVT > 0) {
+    // the factor is loaded into registers once; each row then costs one pair of substitutions
+    SYNC();
+    const int i = LANE;
+    const bool act = i < NVT;
+    LDLRegs<NVT> f;
+    f.rinv = act ? c.Linv[i] : 0.0;
+    static_for<0, NVT>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      f.lo[k] = (act && k < i) ? c.qL[i * NVP_OF(NVT) + k] : 0.0;
+      f.up[k] = (act && k > i) ? c.qL[k * NVP_OF(NVT) + i] : 0.0;
+    });
+    for (int r = 0; r < nefc; r++) {
+      double xi = ldl_solve_any<NVT>(f, act ? ns_jent(c, r, i) : 0.0, M.tree_ok);
+      if (act) Bt[r * nvp + i] = xi;
+    }
+    SYNC();
+    return;
+  }
+#endif
+  for (int r = 0; r < nefc; r++) {
+    PFOR(i, nv) c.Mv[i] = ns_jent(c, r, i);
+    SYNC();
+    chol_solve<NVT>(c.qL, c.Linv, c.Mv, nv, nvp, M.tree_ok);
+    SYNC();
+    PFOR(i, nv) Bt[r * nvp + i] = c.Mv[i];
+    SYNC();
+  }
+}
+
+template <int NVT>
+DEV void noslip_pass(Ctx &c) {
+  const DevModel &M = *c.M;
+  const int nv = M.nv, nvp = M.nvp, nefc = c.nefc, ncon = c.ncon;
+  // the next step's warm start is the Newton solution (mj_fwdConstraint saves it before the noslip pass)
+  PFOR(i, nv) c.qacc_ws[i] = c.qacc[i];
+  SYNC();
+  if (nefc == 0) return;
+  double *Bt = NS_BT(c), *Acs = Bt + M.nefcmax * nvp, *bb = Acs + M.nconmax * 36, *dg = bb + M.nefcmax;
+  double *force = c.efc_force;
+  ns_minv_rows<NVT>(c, Bt);
+  // b = J qacc_smooth - aref;  diagonal J_r B_r of the friction-loss rows
+  PFOR(r, nefc) {
+    double s = 0, t = 0;
+    for (int i = 0; i < nv; i++) { double j = ns_jent(c, r, i); s += j * c.qacc_smooth[i]; t += j * Bt[r * nvp + i]; }
+    bb[r] = s - c.efc_aref[r]; dg[r] = t;
+  }
+  // diagonal blocks of the contacts (elliptic: dim x dim; pyramidal: one 2 x 2 per pair of opposing edges), R not included
+  for (int ci = 0; ci < ncon; ci++) {
+    const int dim = c.con_i[ci * CONI_STRIDE], r0 = c.con_i[ci * CONI_STRIDE + 3], type = c.efc_type[r0];
+    if (dim == 1) continue;
+    if (type == CNSTR_CONTACT_ELLIPTIC) {
+      PFOR(e, dim * dim) {
+        int k = e / dim, l = e - k * dim;
+        double s = 0;
+        for (int i = 0; i < nv; i++) s += c.efc_J[(r0 + k) * nvp + i] * Bt[(r0 + l) * nvp + i];
+        Acs[ci * 36 + e] = s;
+      }
+    } else {
+      PFOR(e, 4 * (dim - 1)) {
+        int pr = e / 4, k = (e & 3) >> 1, l = e & 1;
+        double s = 0;
+        for (int i = 0; i < nv; i++) s += c.efc_J[(r0 + 2 * pr + k) * nvp + i] * Bt[(r0 + 2 * pr + l) * nvp + i];
+        Acs[ci * 36 + e] = s;
+      }
+    }
+  }
+  SYNC();
+  // w = M^-1 J^T force (in LDS: the one-lane emulation build runs the same source)
+  double *w = c.search;
+  PFOR(i, nv) { double s = 0; for (int r = 0; r < nefc; r++) s += force[r] * Bt[r * nvp + i]; w[i] = s; }
+  SYNC();
+  const double scale = 1.0 / (M.meaninertia * (nv > 1 ? nv : 1));
+  int iter = 0;
+  while (iter < M.noslip_iterations) {
+    double improvement = 0;
+    if (iter == 0) {
+      double p = 0;
+      PFOR(r, nefc) p += 0.5 * force[r] * force[r] * c.efc_R[r];
+      improvement = wave_sum(p);
+    }
+    // dry friction: dof rows, then tendon rows (MuJoCo's row order)
+    for (int pass = 0; pass < 2; pass++) {
+      const int want = pass == 0 ? CNSTR_FRICTION_DOF : CNSTR_FRICTION_TENDON;
+      for (int r = 0; r < nefc; r++) {
+        if (uniform_i(c.efc_type[r]) != want) continue;
+        double p = 0;
+        PFOR(i, nv) p += ns_jent(c, r, i) * w[i];
+        const double res = wave_sum(p) + bb[r];
+        const double old = force[r], arinv = 1 / dg[r], fl = c.efc_floss[r];
+        double f = old - res * arinv;
+        if (f < -fl) f = -fl; else if (f > fl) f = fl;
+        const double delta = f - old;
+        improvement -= 0.5 * delta * delta / arinv + delta * res;
+        SYNC();
+        if (LANE == 0) force[r] = f;
+        PFOR(i, nv) w[i] += delta * Bt[r * nvp + i];
+        SYNC();
+      }
+    }
+    // contact friction
+    for (int ci = 0; ci < ncon; ci++) {
+      const int dim = uniform_i(c.con_i[ci * CONI_STRIDE]), r0 = uniform_i(c.con_i[ci * CONI_STRIDE + 3]), type = uniform_i(c.efc_type[r0]);
+      if (dim == 1) continue;
+      const double *cc = c.contact + ci * M.con_stride;
+      if (type == CNSTR_CONTACT_PYRAMIDAL) {
+        for (int pr = 0; pr < dim - 1; pr++) {
+          const int j = r0 + 2 * pr;
+          double p0 = 0, p1 = 0, pz = 0;
+          PFOR(i, nv) { p0 += c.efc_J[j * nvp + i] * w[i]; p1 += c.efc_J[(j + 1) * nvp + i] * w[i]; }
+          wave_sum3(p0, p1, pz);
+          double res[2] = {p0 + bb[j], p1 + bb[j + 1]}, old[2] = {force[j], force[j + 1]}, f[2], Ac[4];
+          for (int e = 0; e < 4; e++) Ac[e] = Acs[ci * 36 + 4 * pr + e];
+          Ac[0] = fmax(1e-10, Ac[0]); Ac[3] = fmax(1e-10, Ac[3]);
+          const double mid = 0.5 * (old[0] + old[1]);
+          const double bc0 = res[0] - Ac[0] * old[0] - Ac[1] * old[1], bc1 = res[1] - Ac[2] * old[0] - Ac[3] * old[1];
+          const double K1 = Ac[0] + Ac[3] - Ac[1] - Ac[2], K0 = mid * (Ac[0] - Ac[3]) + bc0 - bc1;
+          if (K1 < D_MINVAL) f[0] = f[1] = mid;
+          else {
+            double y = -K0 / K1;
+            if (y < -mid) { f[0] = 0; f[1] = 2 * mid; }
+            else if (y > mid) { f[0] = 2 * mid; f[1] = 0; }
+            else { f[0] = mid + y; f[1] = mid - y; }
+          }
+          improvement -= ns_cost_change(Ac, f, old, res, 2);
+          SYNC();
+          if (LANE == 0) { force[j] = f[0]; force[j + 1] = f[1]; }
+          PFOR(i, nv) w[i] += (f[0] - old[0]) * Bt[j * nvp + i] + (f[1] - old[1]) * Bt[(j + 1) * nvp + i];
+          SYNC();
+        }
+      } else if (type == CNSTR_CONTACT_ELLIPTIC) {
+        double pk[6] = {0, 0, 0, 0, 0, 0};
+        PFOR(i, nv) for (int k = 0; k < 6; k++) if (k < dim) pk[k] += c.efc_J[(r0 + k) * nvp + i] * w[i];
+        wave_sum3(pk[0], pk[1], pk[2]);
+        if (dim > 3) wave_sum3(pk[3], pk[4], pk[5]);
+        double res[6], old[6], f[6], Ac[36];
+        for (int k = 0; k < dim; k++) { res[k] = pk[k] + bb[r0 + k]; old[k] = force[r0 + k]; f[k] = old[k]; }
+        for (int e = 0; e < dim * dim; e++) Ac[e] = Acs[ci * 36 + e];
+        for (int k = 0; k < dim; k++) Ac[k * (dim + 1)] = fmax(1e-10, Ac[k * (dim + 1)]);
+        if (old[0] < D_MINVAL) { for (int k = 1; k < dim; k++) f[k] = 0; }
+        else {
+          double bc[5], Af[25], v[5], mu[5];
+          for (int k = 0; k < 5; k++) mu[k] = cc[CON_FRICTION + k];
+          for (int j = 0; j < dim - 1; j++) {
+            bc[j] = res[j + 1];
+            for (int k = 0; k < dim - 1; k++) { Af[j * (dim - 1) + k] = Ac[(j + 1) * dim + (k + 1)]; bc[j] -= Ac[(j + 1) * dim + (k + 1)] * old[k + 1]; }
+          }
+          if (dim == 3) ns_qcqp2(v, Af, bc, mu, old[0]);
+          else if (dim == 4) ns_qcqp3(v, Af, bc, mu, old[0]);
+          else ns_qcqpn(v, Af, bc, mu, old[0], dim - 1);
+          for (int j = 0; j < dim - 1; j++) f[1 + j] = v[j];
+        }
+        improvement -= ns_cost_change(Ac, f, old, res, dim);
+        SYNC();
+        if (LANE == 0) for (int k = 1; k < dim; k++) force[r0 + k] = f[k];
+        PFOR(i, nv) for (int k = 1; k < dim; k++) w[i] += (f[k] - old[k]) * Bt[(r0 + k) * nvp + i];
+        SYNC();
+      }
+    }
+    improvement *= scale;
+    iter++;
+    if (improvement < M.noslip_tolerance) break;
+  }
+  // dualFinish: qfrc_constraint = J^T force, qacc = qacc_smooth + M^-1 J^T force (= w)
+  PFOR(i, nv) {
+    double s = 0;
+    for (int r = 0; r < nefc; r++) { double f = force[r]; if (f != 0) s += ns_jent(c, r, i) * f; }
+    c.qfrc_constraint[i] = s;
+    c.qacc[i] = c.qacc_smooth[i] + w[i];
+  }
+  SYNC();
+}

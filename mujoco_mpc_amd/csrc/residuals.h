@@ -508,6 +508,18 @@ DEV void task_residual(Ctx &c, double *residual) {
       for (int i = 0; i < M.nu; i++) residual[9 + i] = c.ctrl[i] - thrust;
       for (int i = 9 + M.nu; i < M.task.num_residual; i++) residual[i] = 0;
     }
+  } else if (id == 16) {  // fingers.cc:31-62: finger - object (framepos of a body = its inertial frame origin), object sites - target sites, control
+    const int *I = MI(task.int_data);
+    if (LANE == 0) {
+      d_sub3(residual, c.xipos + 3 * I[0], c.xipos + 3 * I[2]);
+      d_sub3(residual + 3, c.xipos + 3 * I[1], c.xipos + 3 * I[2]);
+      for (int i = 0; i < 3; i++) {
+        double df[3];
+        d_sub3(df, c.site_xpos + 3 * I[3 + i], c.site_xpos + 3 * I[6 + i]);
+        residual[6 + i] = d_sqrt(df[0] * df[0] + df[1] * df[1] + df[2] * df[2]);
+      }
+    }
+    PFOR(i, M.nu) residual[9 + i] = c.ctrl[i];
   } else if (id == 9) {   // acrobot.cc:34-49: goal - tip (z, x), joint velocities, control
     if (LANE == 0) {
       int g = MI(task.int_data)[0], t = MI(task.int_data)[1];

@@ -210,14 +210,16 @@ class ModelBuilder:
 
     def actuator(self, name, joint=None, gainprm=(1, 0, 0), biastype=0, biasprm=(0, 0, 0), gear=1.0,
                  ctrllimited=True, ctrlrange=(-1, 1), forcelimited=False, forcerange=(0, 0), tendon=None,
-                 dyntype=0, dynprm=1.0, actlimited=False, actrange=(0, 0), site=None, gear6=None):
+                 dyntype=0, dynprm=1.0, actlimited=False, actrange=(0, 0), site=None, gear6=None, refsite=None):
         """joint transmission (joint=name) or fixed-tendon transmission (tendon=name); dyntype 1 integrator / 2 filter / 3 filterexact
         gives the actuator one activation state (time constant dynprm)"""
+        if gear6 is not None:
+            gear = float(gear6[0])             # (mjModel.actuator_gear[6 * i]; site transmissions read all six)
         self.actuators.append(dict(name=name, joint=joint, tendon=tendon, gainprm=tuple(gainprm), biastype=biastype,
                                    biasprm=tuple(biasprm), gear=gear, ctrllimited=ctrllimited,
                                    ctrlrange=tuple(ctrlrange), forcelimited=forcelimited, forcerange=tuple(forcerange),
                                    dyntype=int(dyntype), dynprm=float(dynprm), actlimited=bool(actlimited), actrange=tuple(actrange),
-                                   site=site, gear6=None if gear6 is None else tuple(gear6)))
+                                   site=site, gear6=None if gear6 is None else tuple(gear6), refsite=refsite))
 
     def position(self, name, joint=None, tendon=None, kp=1.0, ctrlrange=(-1, 1), forcerange=None, gear=1.0):
         """MJCF <position>: gain kp, affine bias (0, -kp, 0)."""
@@ -494,6 +496,7 @@ class ModelBuilder:
         M["actuator_gear"] = np.array([a["gear"] for a in A], float)
         M["actuator_ctrlrange"] = np.array([a["ctrlrange"] for a in A], float).reshape(nu, 2)
         M["actuator_forcerange"] = np.array([a["forcerange"] for a in A], float).reshape(nu, 2)
+        M["actuator_refsite"] = np.array([-1 if a.get("refsite") is None else int(a["refsite"]) for a in A], np.int32)
         M["actuator_gear6"] = np.array([a["gear6"] if a.get("gear6") is not None else (a["gear"], 0, 0, 0, 0, 0) for a in A], float).reshape(nu, 6)
         M["jnt_actfrclimited"] = np.array([int(j.name in self.actfrc) for j in joints], np.int32)
         M["jnt_actfrcrange"] = np.array([self.actfrc.get(j.name, (0.0, 0.0)) for j in joints], float).reshape(len(joints), 2)
@@ -548,7 +551,8 @@ class ModelBuilder:
         M.update(timestep=o["timestep"], gravity=o["gravity"], impratio=o["impratio"], tolerance=o["tolerance"],
                  ls_tolerance=o["ls_tolerance"], cone=o["cone"], iterations=o["iterations"],
                  ls_iterations=o["ls_iterations"], disableflags=(0 if o["contact"] else (1 << 4)) | int(getattr(self, "disableflags", 0)),
-                 enableflags=0, solver=2, integrator=int(getattr(self, "integrator", 0)), noslip_iterations=0, neq=0, unsupported=0,
+                 enableflags=0, solver=2, integrator=int(getattr(self, "integrator", 0)), noslip_iterations=int(getattr(self, "noslip_iterations", 0)),
+                 noslip_tolerance=float(getattr(self, "noslip_tolerance", 1e-6)), neq=0, unsupported=0,
                  nconmax=self.nconmax, nefcmax=self.nefcmax, density=self.fluid[0], viscosity=self.fluid[1], wind=np.array(self.fluid[2]))
         # ---- quantities evaluated at qpos0 (mjModel "set0")
         Mq, Jp, Jr = mass_matrix(M, M["qpos0"])

@@ -3,7 +3,7 @@
 Covers what the task files of the reference that are complete without MuJoCo's model zoo use
 (mjpc/test/testdata/particle*.xml, mjpc/tasks/humanoid/humanoid.xml.patch + task.xml files): <include>, <compiler angle>,
 <option> (+ <flag contact>), nested <default> classes with `childclass` / `class`, the body tree with <joint>/<freejoint>/
-<geom>/<site>/<inertial>, <actuator> motor / position / velocity / general (incl. filter dynamics), fixed <tendon>s, <equality> connect / weld / joint / tendon, <contact><exclude>, <keyframe>,
+<geom>/<site>/<inertial>, <actuator> motor / position / velocity / intvelocity / general (incl. filter dynamics; joint or site transmission with an optional reference site), fixed <tendon>s, <equality> connect / weld / joint / tendon, <contact><exclude>, <keyframe>,
 <custom><numeric>, and the MJPC cost table in <sensor><user> (mjpc/task.cc:203-238).  Anything visual is ignored.
 
 MuJoCo semantics restated here (compile-time only, no simulation): defaults inherit along the class tree and apply per
@@ -25,7 +25,7 @@ from .builder import BALL, BOX, CAPSULE, CYLINDER, FREE, HINGE, PLANE, SLIDE, SP
 
 _GEOM_TYPES = {"plane": PLANE, "sphere": SPHERE, "capsule": CAPSULE, "cylinder": CYLINDER, "box": BOX}
 _JNT_TYPES = {"free": FREE, "ball": BALL, "slide": SLIDE, "hinge": HINGE}
-_ELEMENT_DEFAULT_KINDS = ("joint", "geom", "site", "motor", "position", "general", "velocity", "tendon")
+_ELEMENT_DEFAULT_KINDS = ("joint", "geom", "site", "motor", "position", "general", "velocity", "intvelocity", "tendon")
 
 
 def _floats(s):
@@ -109,6 +109,7 @@ def parse_mjcf(path_or_text, base_dir=None, reader=None, missing_ok=()):
 
     opt = dict(timestep=0.002, cone=0, impratio=1.0, contact=True, tolerance=1e-8, iterations=100, ls_iterations=50, ls_tolerance=0.01,
                gravity=(0, 0, -9.81))
+    noslip = {}
     for o in root.iter("option"):
         for k in ("timestep", "impratio", "tolerance", "ls_tolerance"):
             if o.get(k) is not None:
@@ -116,6 +117,10 @@ def parse_mjcf(path_or_text, base_dir=None, reader=None, missing_ok=()):
         for k in ("iterations", "ls_iterations"):
             if o.get(k) is not None:
                 opt[k] = int(o.get(k))
+        if o.get("noslip_iterations") is not None:
+            noslip["iterations"] = int(o.get("noslip_iterations"))
+        if o.get("noslip_tolerance") is not None:
+            noslip["tolerance"] = float(o.get("noslip_tolerance"))
         if o.get("cone") is not None:
             opt["cone"] = 1 if o.get("cone") == "elliptic" else 0
         if o.get("gravity") is not None:
@@ -134,6 +139,10 @@ def parse_mjcf(path_or_text, base_dir=None, reader=None, missing_ok=()):
             if fl.get("contact") == "disable":
                 opt["contact"] = False
     b = ModelBuilder(**opt)
+    if "iterations" in noslip:
+        b.noslip_iterations = noslip["iterations"]
+    if "tolerance" in noslip:
+        b.noslip_tolerance = noslip["tolerance"]
 
     defaults = _Defaults()
     for dnode in root.findall("default"):
@@ -218,12 +227,17 @@ def parse_mjcf(path_or_text, base_dir=None, reader=None, missing_ok=()):
     for act in root.findall("actuator"):
         for ch in act:
             kind = ch.tag
-            if kind not in ("motor", "position", "velocity", "general"):
+            if kind not in ("motor", "position", "velocity", "intvelocity", "general"):
                 raise ValueError(f"actuator <{kind}> not in the supported subset")
             cls = ch.get("class")
             a = dict(defaults.get(cls, kind)); a.update(ch.attrib)
             gear = _floats(a.get("gear", "1"))[0]
             kw = dict(gear=gear)
+            if "site" in a:                      # site transmission: the whole 6-vector gear, an optional reference site
+                g6 = _floats(a.get("gear", "1")); site_names = [sv[0] for sv in b.sites]
+                kw.update(site=site_names.index(a["site"]), gear6=tuple(g6 + [0.0] * (6 - len(g6))))
+                if "refsite" in a:
+                    kw["refsite"] = site_names.index(a["refsite"])
             if "ctrlrange" in a:
                 kw["ctrlrange"] = tuple(_floats(a["ctrlrange"]))
             cl = a.get("ctrllimited", "auto")
@@ -237,6 +251,9 @@ def parse_mjcf(path_or_text, base_dir=None, reader=None, missing_ok=()):
             elif kind == "position":
                 kp = float(a.get("kp", 1)); kv = float(a.get("kv", 0))
                 kw.update(gainprm=(kp, 0, 0), biastype=1, biasprm=(0, -kp, -kv))
+            elif kind == "intvelocity":          # MJCF <intvelocity kp kv actrange>: a position servo on the integral of the control
+                kp = float(a.get("kp", 1)); kv = float(a.get("kv", 0))
+                kw.update(gainprm=(kp, 0, 0), biastype=1, biasprm=(0, -kp, -kv), dyntype=1, actlimited=True, actrange=tuple(_floats(a["actrange"])))
             elif kind == "general":
                 g = _floats(a.get("gainprm", "1")); kw["gainprm"] = tuple(g + [0, 0, 0][len(g):3])[:3]
                 if a.get("biastype", "none") == "affine":
@@ -248,7 +265,7 @@ def parse_mjcf(path_or_text, base_dir=None, reader=None, missing_ok=()):
                     kw.update(dyntype=("none", "integrator", "filter", "filterexact").index(dyn), dynprm=_floats(a.get("dynprm", "1"))[0])
                     if "actrange" in a:
                         kw.update(actrange=tuple(_floats(a["actrange"])), actlimited=a.get("actlimited", "auto") in ("true", "auto"))
-            b.actuator(a.get("name", f"actuator{len(b.actuators)}"), a["joint"], **kw)
+            b.actuator(a.get("name", f"actuator{len(b.actuators)}"), a.get("joint"), **kw)
 
     for tn in root.findall("tendon"):
         for fx in tn.findall("fixed"):

@@ -155,6 +155,105 @@ def quadrotor(timestep=0.01, stage=0):
     return m, task, defaults
 
 
+TASK_FINGERS = 16
+
+
+def fingers(timestep=0.005, noslip_iterations=5, integrator=2, grasp=False):
+    """mjpc/tasks/fingers (fingers.cc:31-62, task.xml): two free-floating spherical fingers on three slide joints each, driven by
+    integrated-velocity servos (intvelocity: integrator activation, kp 1000, site transmission relative to a world reference site),
+    a thin box (condim 6) to bring to a gravity-compensated target pose; elliptic cones, `noslip_iterations` 5, the implicit
+    integrator at the agent's 5 ms step.  Residual: finger - object (2 x 3), distance of three object sites to the target's, control."""
+    b = ModelBuilder(timestep=timestep, cone=1, contact=True, integrator=integrator)
+    b.noslip_iterations = int(noslip_iterations)
+    world = b.site(0, "world")
+    b.geom(0, "floor", PLANE, size=(0, 0, 0.05))
+    obj = b.body("object", 0); b.joint(obj, "red_rgb_object/", FREE)
+    b.geom(obj, "object", BOX, size=(0.05, 0.01, 0.1), condim=6, friction=(0.2, 0.005, 0.0001), mass=0.2, solref=(0.004, 1.0))
+    s_obj = [b.site(obj, str(k), pos=p) for k, p in enumerate(((0.12, 0, 0), (0, 0.08, 0), (0, 0, 0.08)))]
+    tgt = b.body("target", 0, gravcomp=1.0); b.joint(tgt, "joint1", FREE)          # (unnamed in the XML)
+    b.geom(tgt, "target", BOX, size=(0.039, 0.008, 0.09), contype=0, conaffinity=0)
+    s_tgt = [b.site(tgt, f"{k}t", pos=p) for k, p in enumerate(((0.12, 0, 0), (0, 0.08, 0), (0, 0, 0.08)))]
+    fb, fs = [], []
+    for name in ("a", "b"):
+        f = b.body(f"finger_{name}", 0, gravcomp=1.0)
+        for ax, v in (("x", (1, 0, 0)), ("y", (0, 1, 0)), ("z", (0, 0, 1))):
+            b.joint(f, f"{name.upper()}_{ax}", SLIDE, axis=v)
+        b.geom(f, f"finger_{name}", SPHERE, size=(0.02,), condim=6)
+        fb.append(f); fs.append(b.site(f, f"finger_{name}"))
+    b.exclude(obj, tgt)
+    for name, s in zip(("A", "B"), fs):
+        for k, ax in enumerate("xyz"):
+            g6 = [0.0] * 6; g6[k] = 1.0
+            b.actuator(f"{name}_{ax}", site=s, refsite=world, gear6=g6, gainprm=(1000, 0, 0), biastype=1, biasprm=(0, -1000, 0), ctrlrange=(-0.99, 0.99),
+                       dyntype=1, actlimited=True, actrange=(0, 1.4) if ax == "z" else (-1, 1))
+    home = [0, 0, 0.3, 1, 0, 0, 0, 0, 0, 0.12, 1, 0, 1, 0, 0, 0.1, 0.3, 0, -0.1, 0.3]
+    home = np.array(home, float); home[10:14] /= np.linalg.norm(home[10:14])
+    b.key("home", home)
+    m = b.compile()
+    task = make_task(TASK_FINGERS, [(6, 2, 0.35, [0.02]), (3, 6, 1.0, [0.05]), (6, 6, 0.05, [0.01])], traces=[(OBJ_SITE, fs[0]), (OBJ_SITE, fs[1])],
+                     int_data=[fb[0], fb[1], obj] + s_obj + s_tgt)
+    # the "home" key puts the OBJECT up at 0.3 and the target on the floor in the XML's body order (object first): [object 7, target 7, A 3, B 3]
+    q = home.copy()
+    act = np.array([0, 0.1, 0.3, 0, -0.1, 0.3], float)
+    if grasp:       # test state: the object stands on the floor, pinched on its thin sides by the fingers, whose servo targets squeeze and lift
+        q[0:7] = [0, 0, 0.1, 1, 0, 0, 0]; q[7:14] = [0.3, 0, 0.3, 1, 0, 0, 0]
+        q[14:17] = [0, 0.0295, 0.1]; q[17:20] = [0, -0.0295, 0.1]
+        act = np.array([0, 0.022, 0.16, 0, -0.022, 0.16], float)
+    defaults = dict(N=60, P=5, sigma=(0.04, 0.0), interp=2, horizon=101, state=np.concatenate([q, np.zeros(m["nv"]), act]), mocap=np.zeros(0))
+    return m, task, defaults
+
+
+def noslip_mix(cone=1, condim=3, noslip_iterations=5, timestep=0.005):
+    """Test model for the noslip pass: gravity with a tangential component; a box and a capsule on the floor (contacts of the given
+    cone / condim), a hinged arm with joint friction loss under its own weight, two sliders tied by a tendon with friction loss and
+    a motor pushing one of them against it, a limited joint at its stop.  Residual = state (TASK_COPYSTATE)."""
+    b = ModelBuilder(timestep=timestep, gravity=(1.2, 0.5, -9.81), cone=cone, contact=True)
+    b.noslip_iterations = int(noslip_iterations)
+    b.geom(0, "floor", PLANE, size=(0, 0, 0.05), condim=condim)
+    box = b.body("box", 0, pos=(0, 0, 0.05)); b.joint(box, "box_f", FREE)
+    b.geom(box, "box_g", BOX, size=(0.05, 0.04, 0.05), condim=condim, friction=(0.5, 0.005, 0.0001), mass=0.2)
+    cap = b.body("cap", 0, pos=(0.4, 0, 0.03), quat=(0.92, 0, 0, 0.39)); b.joint(cap, "cap_f", FREE)
+    b.geom(cap, "cap_g", CAPSULE, size=(0.03, 0.08), euler=(0, 90, 0), condim=condim, friction=(0.7, 0.01, 0.001), mass=0.15)
+    arm = b.body("arm", 0, pos=(-0.5, 0, 0.5)); b.joint(arm, "arm_h", HINGE, axis=(0, 1, 0), frictionloss=0.5, limited=True, range=(-0.4, 0.4))
+    b.geom(arm, "arm_g", CAPSULE, size=(0.02, 0), fromto=(0, 0, 0, 0.3, 0, 0), mass=0.2, contype=0, conaffinity=0)
+    for k in range(2):
+        sl = b.body(f"sl{k}", 0, pos=(-0.5, 0.3 + 0.2 * k, 0.3)); b.joint(sl, f"sl{k}_j", SLIDE, axis=(0, 0, 1), damping=0.2)
+        b.geom(sl, f"sl{k}_g", SPHERE, size=(0.03,), mass=0.1, contype=0, conaffinity=0)
+    b.tendon("t", ["sl0_j", "sl1_j"], [1.0, -0.5], frictionloss=0.8)
+    b.actuator("push", "sl0_j", gear=1.0, ctrlrange=(-1, 1))
+    tip = b.site(arm, "tip", pos=(0.3, 0, 0))
+    m = b.compile()
+    task = make_task(TASK_COPYSTATE, [(m["nq"], 0, 1.0), (m["nv"], 0, 0.1)], traces=[(OBJ_SITE, tip)])
+    q = m["qpos0"].copy(); v = np.zeros(m["nv"])
+    q[14] = 0.39; v[0] = 0.2; v[6] = -0.1; v[13] = 0.5
+    defaults = dict(N=6, P=4, sigma=(0.5, 0.0), interp=2, horizon=60, state=np.concatenate([q, v]), mocap=np.zeros(0))
+    return m, task, defaults
+
+
+def site_servo(timestep=0.005, integrator=0):
+    """Test model for site transmissions with a reference site: the tip of a two-link arm servoed (position gains, one with an
+    integrator activation) along three axes of a tilted reference site that rides a sliding cart, and along one axis of a reference
+    site on the arm's own first link (moment cleared on the shared hinge).  Residual = state (TASK_COPYSTATE)."""
+    b = ModelBuilder(timestep=timestep, contact=False, integrator=integrator)
+    cart = b.body("cart", 0, pos=(0.5, 0.2, 0)); b.joint(cart, "cx", SLIDE, axis=(1, 0, 0), damping=0.5); b.geom(cart, "gc", BOX, size=(0.05, 0.05, 0.05), mass=1.0)
+    ref = b.site(cart, "ref", pos=(0.02, 0.0, 0.05), quat=(0.9, 0.1, -0.3, 0.2))
+    l1 = b.body("l1", 0, pos=(0, 0, 0.4)); b.joint(l1, "h1", HINGE, axis=(0, 1, 0), damping=0.05); b.geom(l1, "g1", CAPSULE, size=(0.02, 0), fromto=(0, 0, 0, 0.3, 0, 0), mass=0.3)
+    ref1 = b.site(l1, "ref1", pos=(0.1, 0, 0.02))
+    l2 = b.body("l2", l1, pos=(0.3, 0, 0)); b.joint(l2, "h2", HINGE, axis=(0, 0, 1), damping=0.05); b.geom(l2, "g2", CAPSULE, size=(0.02, 0), fromto=(0, 0, 0, 0.2, 0, 0), mass=0.2)
+    tip = b.site(l2, "tip", pos=(0.2, 0.01, 0))
+    for k, ax in enumerate("xyz"):
+        g6 = [0.0] * 6; g6[k] = 1.0
+        b.actuator(f"ref_{ax}", site=tip, refsite=ref, gear6=g6, gainprm=(8, 0, 0), biastype=1, biasprm=(0.1, -8, -0.5 if integrator == 0 else 0.0), ctrlrange=(-0.5, 0.5),
+                   dyntype=1 if k == 2 else 0, actlimited=k == 2, actrange=(-0.3, 0.3))
+    b.actuator("link_y", site=tip, refsite=ref1, gear6=(0.2, 1.0, 0, 0, 0, 0), gainprm=(5, 0, 0), biastype=1, biasprm=(0, -5, 0), ctrlrange=(-0.5, 0.5), forcelimited=True, forcerange=(-0.6, 0.6))
+    b.actuator("cart_m", "cx", gear=2.0, ctrlrange=(-1, 1))
+    m = b.compile()
+    task = make_task(TASK_COPYSTATE, [(m["nq"], 0, 1.0), (m["nv"], 0, 0.1), (m["na"], 0, 0.1)], traces=[(OBJ_SITE, tip)])
+    q = np.array([0.13, 0.4, -0.7]); v = np.array([0.2, -0.5, 1.0])
+    defaults = dict(N=6, P=4, sigma=(0.3, 0.0), interp=2, horizon=80, state=np.concatenate([q, v, [0.05]]), mocap=np.zeros(0))
+    return m, task, defaults
+
+
 def linkage(timestep=0.004):
     """Test model for equality constraints: a gripper-like pair of fingers on one palm whose hinge angles are coupled by a joint
     equality (different branches: dense Hessian builds), a four-bar loop closed by a connect constraint between two chain ends, a
@@ -928,4 +1027,4 @@ def terrain_balls(timestep=0.004):
     return m, task, defaults
 
 
-REGISTRY = {"humanoid_interact": humanoid_interact, "welded": welded, "swimmer": swimmer, "quadrotor": quadrotor, "linkage": linkage, "servo_arm": servo_arm, "particle_timevarying": particle_task, "particle_fixed": lambda: particle_task(fixed=True), "filter_arm": filter_arm, "ball_chain_friction": lambda: ball_chain(tendon_frictionloss=0.3), "quadruped_hill": quadruped_hill, "terrain_balls": terrain_balls, "walker": walker, "acrobot": acrobot, "ball_chain": ball_chain, "cylinder_pile": cylinder_pile, "humanoid_stand": humanoid_stand, "humanoid_walk": humanoid_walk, "particle": particle, "cartpole": cartpole, "quadruped": quadruped, "humanoid_track": humanoid_track, "shadow_hand": shadow_hand}
+REGISTRY = {"humanoid_interact": humanoid_interact, "fingers": fingers, "site_servo": site_servo, "noslip_elliptic3": lambda: noslip_mix(1, 3), "noslip_elliptic4": lambda: noslip_mix(1, 4), "noslip_elliptic6": lambda: noslip_mix(1, 6), "noslip_pyramidal3": lambda: noslip_mix(0, 3), "noslip_pyramidal6": lambda: noslip_mix(0, 6), "fingers_grasp": lambda: fingers(grasp=True), "welded": welded, "swimmer": swimmer, "quadrotor": quadrotor, "linkage": linkage, "servo_arm": servo_arm, "particle_timevarying": particle_task, "particle_fixed": lambda: particle_task(fixed=True), "filter_arm": filter_arm, "ball_chain_friction": lambda: ball_chain(tendon_frictionloss=0.3), "quadruped_hill": quadruped_hill, "terrain_balls": terrain_balls, "walker": walker, "acrobot": acrobot, "ball_chain": ball_chain, "cylinder_pile": cylinder_pile, "humanoid_stand": humanoid_stand, "humanoid_walk": humanoid_walk, "particle": particle, "cartpole": cartpole, "quadruped": quadruped, "humanoid_track": humanoid_track, "shadow_hand": shadow_hand}

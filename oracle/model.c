@@ -60,6 +60,7 @@ OModel *oracle_create(const MjpcHipModel *src, const MjpcHipTask *task) {
   CI(actuator_trntype, nu); CI(actuator_trnid, nu); CI(actuator_ctrllimited, nu); CI(actuator_forcelimited, nu); CI(actuator_biastype, nu);
   CD(actuator_gainprm, 3 * nu); CD(actuator_biasprm, 3 * nu); CD(actuator_gear, nu);
   if (src->actuator_gear6) CD(actuator_gear6, 6 * nu);
+  if (src->actuator_refsite) CI(actuator_refsite, nu);
   CD(actuator_ctrlrange, 2 * nu); CD(actuator_forcerange, 2 * nu);
   if (src->actuator_dyntype) { CI(actuator_dyntype, nu); CI(actuator_actadr, nu); CI(actuator_actlimited, nu); CD(actuator_dynprm, nu); CD(actuator_actrange, 2 * nu); }
   CI(tendon_adr, src->ntendon); CI(tendon_num, src->ntendon); CI(tendon_limited, src->ntendon); CI(wrap_objid, src->nwrap);

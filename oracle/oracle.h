@@ -59,6 +59,9 @@ typedef struct OData {
   int *efc_type, *efc_id, *efc_state;
   double *efc_J, *efc_pos, *efc_margin, *efc_frictionloss, *efc_diagApprox, *efc_D, *efc_R,
          *efc_vel, *efc_aref, *efc_force, *efc_jar, *efc_jv, *efc_KBIP;
+  double *efc_AR, *efc_b, *efc_MiJT;     /* noslip only: J M^-1 J^T + diag(R), J qacc_smooth - aref, M^-1 J^T (row r = M^-1 J_r^T) */
+  int noslip_iter;
+  double *qacc_newton;                   /* the Newton solve's qacc (the next step's warm start; mj_solNoSlip runs after it is saved) */
   double *efc_solref, *efc_solimp;
   /* solver scratch */
   double *Ma, *grad, *Mgrad, *search, *Mv, *work;
@@ -130,6 +133,7 @@ int oracle_debug_step(const OModel *om, double *qpos, double *qvel, const double
                       const double *mocap, double *time, int nstep, double *energy);
 int oracle_debug_vel_derivatives(const OModel *om, const double *qpos, const double *qvel, double *dbias, double *dfluid, double *bias,
                                  double *passive_out);
+int oracle_debug_actuation(const OModel *om, const double *qpos, const double *qvel, const double *ctrl, const double *act, double *force, double *qfrc);
 int oracle_debug_constraints(const OModel *om, const double *qpos, const double *qvel, const double *mocap, int cap, double *J, double *pos,
                              double *diag, double *R, double *aref);
 

@@ -34,7 +34,7 @@ OData *oracle_make_data(const OModel *om) {
   int nv = m->nv, nb = m->nbody, ne = om->nefcmax;
   DD(qpos, m->nq); DD(qvel, nv); DD(ctrl, m->nu); DD(mocap_pos, 3 * m->nmocap + 3);
   DD(mocap_quat, 4 * m->nmocap + 4); DD(userdata, m->nuserdata + 1);
-  DD(qacc, nv); DD(qacc_warmstart, nv); DD(qacc_smooth, nv); DD(qfrc_smooth, nv);
+  DD(qacc, nv); DD(qacc_newton, nv); DD(qacc_warmstart, nv); DD(qacc_smooth, nv); DD(qfrc_smooth, nv);
   DD(qfrc_bias, nv); DD(qfrc_passive, nv); DD(qfrc_actuator, nv); DD(qfrc_constraint, nv);
   DD(actuator_force, m->nu + 1); DD(act, m->na + 1); DD(act_dot, m->na + 1);
   DD(xpos, 3 * nb); DD(xquat, 4 * nb); DD(xmat, 9 * nb); DD(xipos, 3 * nb); DD(ximat, 9 * nb);
@@ -50,6 +50,7 @@ OData *oracle_make_data(const OModel *om) {
   DD(efc_diagApprox, ne); DD(efc_D, ne); DD(efc_R, ne); DD(efc_vel, ne); DD(efc_aref, ne);
   DD(efc_force, ne); DD(efc_jar, ne); DD(efc_jv, ne); DD(efc_KBIP, 4 * ne);
   DD(efc_solref, 2 * ne); DD(efc_solimp, 5 * ne);
+  if (m->noslip_iterations > 0) { DD(efc_AR, ne * ne + 1); DD(efc_b, ne); DD(efc_MiJT, ne * nv + 1); }
   DD(Ma, nv); DD(grad, nv); DD(Mgrad, nv); DD(search, nv); DD(Mv, nv); DD(work, 16 * nv + 64);
   DD(sensordata, om->t.num_residual + 1);
   /* defaults: qpos0, mocap at body pose */
@@ -796,6 +797,48 @@ static void actuation(const OModel *om, OData *d) {
     if (m->actuator_ctrllimited[i]) ctrl = o_clip(ctrl, m->actuator_ctrlrange[2 * i], m->actuator_ctrlrange[2 * i + 1]);
     double gear = m->actuator_gear[i];
     int id = m->actuator_trnid[i];
+    const int refsite = (m->actuator_trntype[i] == MJPC_TRN_SITE && m->actuator_refsite) ? m->actuator_refsite[i] : -1;
+    if (refsite >= 0) {
+      /* mjTRN_SITE with a reference site (mj_transmission): length = gear[0:3] . R_ref^T (x_site - x_ref), moment = (Jp_site - Jp_ref)^T R_ref
+       * gear[0:3], cleared on the dofs the two sites' bodies share; gain / affine bias / activation as for the other transmissions */
+      const double *g6 = m->actuator_gear6 + 6 * i;
+      if (g6[3] != 0 || g6[4] != 0 || g6[5] != 0) { d->unsupported++; d->warning |= MJPC_WARN_UNSUPPORTED; }
+      double *jp = d->work, *jq = d->work + 3 * nv, *mom = d->work + 6 * nv, vec[3], loc[3], w[3];
+      int bs = m->site_bodyid[id], br = m->site_bodyid[refsite];
+      jac_point(om, d, jp, NULL, d->site_xpos + 3 * id, bs); jac_point(om, d, jq, NULL, d->site_xpos + 3 * refsite, br);
+      o_sub3(vec, d->site_xpos + 3 * id, d->site_xpos + 3 * refsite);
+      const double *R = d->site_xmat + 9 * refsite;
+      for (int k = 0; k < 3; k++) loc[k] = R[k] * vec[0] + R[3 + k] * vec[1] + R[6 + k] * vec[2];      /* R^T vec */
+      double length = loc[0] * g6[0] + loc[1] * g6[1] + loc[2] * g6[2], velocity = 0;
+      o_mulmatvec3(w, R, g6);
+      for (int k = 0; k < nv; k++) mom[k] = (jp[k] - jq[k]) * w[0] + (jp[nv + k] - jq[nv + k]) * w[1] + (jp[2 * nv + k] - jq[2 * nv + k]) * w[2];
+      {      /* dofs above both bodies: the common ancestors of the two weld bodies' last dofs */
+        int b0 = m->body_weldid[bs], b1 = m->body_weldid[br];
+        int d0 = m->body_dofadr[b0] + m->body_dofnum[b0] - 1, d1 = m->body_dofadr[b1] + m->body_dofnum[b1] - 1;
+        if (m->body_dofnum[b0] == 0) d0 = -1;
+        if (m->body_dofnum[b1] == 0) d1 = -1;
+        int common = -1;
+        if (d0 >= 0 && d1 >= 0) {
+          while (d0 != d1) { if (d0 < d1) d1 = m->dof_parentid[d1]; else d0 = m->dof_parentid[d0]; if (d0 == -1 || d1 == -1) break; }
+          if (d0 == d1) common = d0;
+        }
+        for (; common >= 0; common = m->dof_parentid[common]) mom[common] = 0;
+      }
+      for (int k = 0; k < nv; k++) velocity += mom[k] * d->qvel[k];
+      double input = ctrl;
+      if (m->na > 0 && m->actuator_dyntype && m->actuator_dyntype[i] != MJPC_DYN_NONE) {
+        int a = m->actuator_actadr[i];
+        input = d->act[a];
+        d->act_dot[a] = m->actuator_dyntype[i] == MJPC_DYN_INTEGRATOR ? ctrl : (ctrl - input) / fmax(O_MINVAL, m->actuator_dynprm[i]);
+      }
+      double force = m->actuator_gainprm[3 * i] * input;
+      if (m->actuator_biastype[i] == MJPC_BIAS_AFFINE)
+        force += m->actuator_biasprm[3 * i] + m->actuator_biasprm[3 * i + 1] * length + m->actuator_biasprm[3 * i + 2] * velocity;
+      if (m->actuator_forcelimited[i]) force = o_clip(force, m->actuator_forcerange[2 * i], m->actuator_forcerange[2 * i + 1]);
+      d->actuator_force[i] = force;
+      for (int k = 0; k < nv; k++) d->qfrc_actuator[k] += mom[k] * force;
+      continue;
+    }
     if (m->actuator_trntype[i] == MJPC_TRN_SITE) {
       /* mjTRN_SITE without refsite: length 0, moment = J_site^T (R_site gear[0:3]; R_site gear[3:6]); motors only */
       double *jp = d->work, *jr = d->work + 3 * nv, f[3], tq[3];
@@ -1080,6 +1123,196 @@ static void solve_constraints(const OModel *om, OData *d) {
   }
 }
 
+/* ---- mj_solNoSlip: friction-loss rows and the friction dimensions of the contacts re-solved in the dual without the
+ * regulariser R (projected Gauss-Seidel over efc_force; limits, equalities and the contacts' normal forces stay as the Newton
+ * solve left them), then qacc = qacc_smooth + M^-1 J^T force ------------------------------------------------------------- */
+/* min 0.5 x'Ax + x'b  s.t.  sum (x_i / d_i)^2 <= r^2  (mju_QCQP2 / QCQP3 / QCQP): scaled to a ball, Newton on the multiplier */
+static int qcqp2(double *res, const double *Ain, const double *bin, const double *d, double r) {
+  double b1 = bin[0] * d[0], b2 = bin[1] * d[1];
+  double A11 = Ain[0] * d[0] * d[0], A22 = Ain[3] * d[1] * d[1], A12 = Ain[1] * d[0] * d[1];
+  double la = 0, v1 = 0, v2 = 0;
+  for (int iter = 0; iter < 20; iter++) {
+    double det = (A11 + la) * (A22 + la) - A12 * A12;
+    if (det < 1e-10) { res[0] = 0; res[1] = 0; return 0; }
+    double detinv = 1 / det;
+    double P11 = (A22 + la) * detinv, P22 = (A11 + la) * detinv, P12 = -A12 * detinv;
+    v1 = -P11 * b1 - P12 * b2; v2 = -P12 * b1 - P22 * b2;
+    double val = v1 * v1 + v2 * v2 - r * r;
+    if (val < 1e-10) break;
+    double deriv = -2 * (P11 * v1 * v1 + 2 * P12 * v1 * v2 + P22 * v2 * v2);
+    double delta = -val / deriv;
+    if (delta < 1e-10) break;
+    la += delta;
+  }
+  res[0] = v1 * d[0]; res[1] = v2 * d[1];
+  return la != 0;
+}
+static int qcqp3(double *res, const double *Ain, const double *bin, const double *d, double r) {
+  double b1 = bin[0] * d[0], b2 = bin[1] * d[1], b3 = bin[2] * d[2];
+  double A11 = Ain[0] * d[0] * d[0], A22 = Ain[4] * d[1] * d[1], A33 = Ain[8] * d[2] * d[2];
+  double A12 = Ain[1] * d[0] * d[1], A13 = Ain[2] * d[0] * d[2], A23 = Ain[5] * d[1] * d[2];
+  double la = 0, v1 = 0, v2 = 0, v3 = 0;
+  for (int iter = 0; iter < 20; iter++) {
+    double P11 = (A22 + la) * (A33 + la) - A23 * A23, P22 = (A11 + la) * (A33 + la) - A13 * A13, P33 = (A11 + la) * (A22 + la) - A12 * A12;
+    double P12 = A13 * A23 - A12 * (A33 + la), P13 = A12 * A23 - A13 * (A22 + la), P23 = A12 * A13 - A23 * (A11 + la);
+    double det = (A11 + la) * P11 + A12 * P12 + A13 * P13;
+    if (det < 1e-10) { res[0] = res[1] = res[2] = 0; return 0; }
+    double detinv = 1 / det;
+    P11 *= detinv; P22 *= detinv; P33 *= detinv; P12 *= detinv; P13 *= detinv; P23 *= detinv;
+    v1 = -P11 * b1 - P12 * b2 - P13 * b3; v2 = -P12 * b1 - P22 * b2 - P23 * b3; v3 = -P13 * b1 - P23 * b2 - P33 * b3;
+    double val = v1 * v1 + v2 * v2 + v3 * v3 - r * r;
+    if (val < 1e-10) break;
+    double deriv = -2 * (P11 * v1 * v1 + P22 * v2 * v2 + P33 * v3 * v3) - 4 * (P12 * v1 * v2 + P13 * v1 * v3 + P23 * v2 * v3);
+    double delta = -val / deriv;
+    if (delta < 1e-10) break;
+    la += delta;
+  }
+  res[0] = v1 * d[0]; res[1] = v2 * d[1]; res[2] = v3 * d[2];
+  return la != 0;
+}
+/* mju_cholFactor with a rank threshold (diagonal below mindiag: set to it, rank - 1) / mju_cholSolve, n <= 5 */
+static int small_chol(double *A, int n, double mindiag) {
+  int rank = n;
+  for (int j = 0; j < n; j++) {
+    double t = A[j * n + j];
+    for (int k = 0; k < j; k++) t -= A[j * n + k] * A[j * n + k];
+    if (t < mindiag) { t = mindiag; rank--; }
+    A[j * n + j] = sqrt(t);
+    double inv = 1 / A[j * n + j];
+    for (int i = j + 1; i < n; i++) {
+      double s = A[i * n + j];
+      for (int k = 0; k < j; k++) s -= A[i * n + k] * A[j * n + k];
+      A[i * n + j] = s * inv;
+    }
+  }
+  return rank;
+}
+static void small_chol_solve(double *x, const double *L, const double *b, int n) {
+  for (int i = 0; i < n; i++) { double s = b[i]; for (int k = 0; k < i; k++) s -= L[i * n + k] * x[k]; x[i] = s / L[i * n + i]; }
+  for (int i = n - 1; i >= 0; i--) { double s = x[i]; for (int k = i + 1; k < n; k++) s -= L[k * n + i] * x[k]; x[i] = s / L[i * n + i]; }
+}
+static int qcqpn(double *res, const double *Ain, const double *bin, const double *d, double r, int n) {
+  double A[25], Ala[25], b[5], tmp[5], la = 0;
+  for (int i = 0; i < n; i++) { b[i] = bin[i] * d[i]; for (int j = 0; j < n; j++) A[j + i * n] = Ain[j + i * n] * d[i] * d[j]; }
+  for (int iter = 0; iter < 20; iter++) {
+    for (int i = 0; i < n * n; i++) Ala[i] = A[i];
+    for (int i = 0; i < n; i++) Ala[i * (n + 1)] += la;
+    if (small_chol(Ala, n, 1e-10) < n) { for (int i = 0; i < n; i++) res[i] = 0; return 0; }
+    small_chol_solve(res, Ala, b, n);
+    for (int i = 0; i < n; i++) res[i] = -res[i];
+    double val = o_dot(res, res, n) - r * r;
+    if (val < 1e-10) break;
+    small_chol_solve(tmp, Ala, res, n);
+    double deriv = -2 * o_dot(res, tmp, n);
+    double delta = -val / deriv;
+    if (delta < 1e-10) break;
+    la += delta;
+  }
+  for (int i = 0; i < n; i++) res[i] = res[i] * d[i];
+  return la != 0;
+}
+/* cost change of a block update; an update that raises the cost is taken back (costChange) */
+static double noslip_cost_change(const double *A, double *force, const double *oldforce, const double *res, int dim) {
+  double delta[6], change = 0;
+  for (int j = 0; j < dim; j++) delta[j] = force[j] - oldforce[j];
+  for (int j = 0; j < dim; j++) { double t = 0; for (int k = 0; k < dim; k++) t += A[j * dim + k] * delta[k]; change += 0.5 * delta[j] * t; }
+  for (int j = 0; j < dim; j++) change += delta[j] * res[j];
+  if (change > 1e-10) { for (int j = 0; j < dim; j++) force[j] = oldforce[j]; change = 0; }
+  return change;
+}
+static void noslip(const OModel *om, OData *d) {
+  const MjpcHipModel *m = &om->m;
+  const int nv = m->nv, nefc = d->nefc;
+  double *AR = d->efc_AR, *b = d->efc_b, *force = d->efc_force;
+  d->noslip_iter = 0;
+  if (nefc == 0) return;
+  /* mj_projectConstraint: AR = J M^-1 J^T + diag(R);  b = J qacc_smooth - aref */
+  for (int r = 0; r < nefc; r++) chol_solve(d->efc_MiJT + r * nv, d->qL, d->efc_J + r * nv, nv);
+  for (int r = 0; r < nefc; r++) {
+    for (int q = 0; q < nefc; q++) AR[r * nefc + q] = o_dot(d->efc_J + r * nv, d->efc_MiJT + q * nv, nv);
+    AR[r * nefc + r] += d->efc_R[r];
+    b[r] = o_dot(d->efc_J + r * nv, d->qacc_smooth, nv) - d->efc_aref[r];
+  }
+  const double scale = 1.0 / (m->meaninertia * (nv > 1 ? nv : 1));
+#define NS_RES(res_, i_, dim_) for (int j_ = 0; j_ < (dim_); j_++) (res_)[j_] = o_dot(AR + ((i_) + j_) * nefc, force, nefc) + b[(i_) + j_] - d->efc_R[(i_) + j_] * force[(i_) + j_]
+#define NS_BLOCK(Ac_, i_, dim_) do { for (int j_ = 0; j_ < (dim_); j_++) for (int k_ = 0; k_ < (dim_); k_++) (Ac_)[j_ * (dim_) + k_] = AR[((i_) + j_) * nefc + (i_) + k_]; \
+    for (int j_ = 0; j_ < (dim_); j_++) { (Ac_)[j_ * ((dim_) + 1)] -= d->efc_R[(i_) + j_]; (Ac_)[j_ * ((dim_) + 1)] = fmax(1e-10, (Ac_)[j_ * ((dim_) + 1)]); } } while (0)
+  int iter = 0;
+  while (iter < m->noslip_iterations) {
+    double improvement = 0;
+    if (iter == 0) for (int i = 0; i < nefc; i++) improvement += 0.5 * force[i] * force[i] * d->efc_R[i];
+    /* dry friction (dof rows, then tendon rows: MuJoCo's row order) */
+    for (int pass = 0; pass < 2; pass++)
+      for (int i = 0; i < nefc; i++) {
+        if (d->efc_type[i] != (pass == 0 ? O_CNSTR_FRICTION_DOF : O_CNSTR_FRICTION_TENDON)) continue;
+        double res[1], old = force[i], arinv = 1 / (AR[i * (nefc + 1)] - d->efc_R[i]), fl = d->efc_frictionloss[i];
+        NS_RES(res, i, 1);
+        force[i] -= res[0] * arinv;
+        if (force[i] < -fl) force[i] = -fl; else if (force[i] > fl) force[i] = fl;
+        double delta = force[i] - old;
+        improvement -= 0.5 * delta * delta / arinv + delta * res[0];
+      }
+    /* contact friction */
+    for (int i = 0; i < nefc; i++) {
+      if (d->efc_type[i] == O_CNSTR_CONTACT_PYRAMIDAL) {
+        const OContact *con = d->contact + d->efc_id[i];
+        int dim = con->dim;
+        for (int j = i; j < i + 2 * (dim - 1); j += 2) {
+          double res[2], old[2] = {force[j], force[j + 1]}, Ac[4];
+          NS_RES(res, j, 2);
+          double mid = 0.5 * (force[j] + force[j + 1]);
+          NS_BLOCK(Ac, j, 2);
+          /* along f = (mid + y, mid - y) the cost is 0.5 K1 y^2 + K0 y + const, with bc = res - Ac f_old the part of the residual that does not move */
+          double bc0 = res[0] - Ac[0] * old[0] - Ac[1] * old[1], bc1 = res[1] - Ac[2] * old[0] - Ac[3] * old[1];
+          double K1 = Ac[0] + Ac[3] - Ac[1] - Ac[2], K0 = mid * (Ac[0] - Ac[3]) + bc0 - bc1;
+          if (K1 < O_MINVAL) force[j] = force[j + 1] = mid;
+          else {
+            double y = -K0 / K1;
+            if (y < -mid) { force[j] = 0; force[j + 1] = 2 * mid; }
+            else if (y > mid) { force[j] = 2 * mid; force[j + 1] = 0; }
+            else { force[j] = mid + y; force[j + 1] = mid - y; }
+          }
+          improvement -= noslip_cost_change(Ac, force + j, old, res, 2);
+        }
+        i += 2 * (dim - 1) - 1;
+      } else if (d->efc_type[i] == O_CNSTR_CONTACT_ELLIPTIC) {
+        const OContact *con = d->contact + d->efc_id[i];
+        int dim = con->dim;
+        if (dim == 1) continue;
+        double res[6], old[6], Ac[36];
+        NS_RES(res, i, dim);
+        for (int j = 0; j < dim; j++) old[j] = force[i + j];
+        NS_BLOCK(Ac, i, dim);
+        if (force[i] < O_MINVAL) { for (int j = 1; j < dim; j++) force[i + j] = 0; }
+        else {
+          double bc[5], Af[25], v[5];
+          for (int j = 0; j < dim - 1; j++) {
+            bc[j] = res[j + 1];
+            for (int k = 0; k < dim - 1; k++) { Af[j * (dim - 1) + k] = Ac[(j + 1) * dim + (k + 1)]; bc[j] -= Ac[(j + 1) * dim + (k + 1)] * old[k + 1]; }
+          }
+          if (dim == 3) qcqp2(v, Af, bc, con->friction, force[i]);
+          else if (dim == 4) qcqp3(v, Af, bc, con->friction, force[i]);
+          else qcqpn(v, Af, bc, con->friction, force[i], dim - 1);
+          for (int j = 0; j < dim - 1; j++) force[i + 1 + j] = v[j];
+        }
+        improvement -= noslip_cost_change(Ac, force + i, old, res, dim);
+        i += dim - 1;
+      }
+    }
+    improvement *= scale;
+    iter++;
+    if (improvement < m->noslip_tolerance) break;
+  }
+#undef NS_RES
+#undef NS_BLOCK
+  d->noslip_iter = iter;
+  /* dualFinish: qfrc_constraint = J^T force, qacc = qacc_smooth + M^-1 qfrc_constraint */
+  o_zero(d->qfrc_constraint, nv);
+  for (int r = 0; r < nefc; r++) { double f = force[r]; if (f == 0) continue; for (int i = 0; i < nv; i++) d->qfrc_constraint[i] += d->efc_J[r * nv + i] * f; }
+  chol_solve(d->qacc, d->qL, d->qfrc_constraint, nv);
+  for (int i = 0; i < nv; i++) d->qacc[i] += d->qacc_smooth[i];
+}
+
 /* ---- pipeline ------------------------------------------------------------------------ */
 static int bad(const double *x, int n) {
   for (int i = 0; i < n; i++) if (!(x[i] == x[i]) || x[i] > 1e10 || x[i] < -1e10) return 1;
@@ -1120,6 +1353,8 @@ void oracle_forward(const OModel *om, OData *d) {
   }
   chol_solve(d->qacc_smooth, d->qL, d->qfrc_smooth, nv);
   solve_constraints(om, d);
+  o_copy(d->qacc_newton, d->qacc, nv);           /* mj_fwdConstraint saves the warm start before the noslip pass */
+  if (m->noslip_iterations > 0) noslip(om, d);
   oracle_residual(om, d, d->sensordata);
 }
 
@@ -1240,6 +1475,19 @@ int oracle_debug_vel_derivatives(const OModel *om, const double *qpos, const dou
   return w;
 }
 
+/* actuator forces and their generalized force at (qpos, qvel, ctrl, act).  Test hook (transmission lengths / moments) */
+int oracle_debug_actuation(const OModel *om, const double *qpos, const double *qvel, const double *ctrl, const double *act, double *force, double *qfrc) {
+  const MjpcHipModel *m = &om->m;
+  OData *d = oracle_make_data(om);
+  o_copy(d->qpos, qpos, m->nq); o_copy(d->qvel, qvel, m->nv); o_copy(d->ctrl, ctrl, m->nu);
+  if (act && m->na > 0) o_copy(d->act, act, m->na);
+  oracle_forward(om, d);
+  o_copy(force, d->actuator_force, m->nu); o_copy(qfrc, d->qfrc_actuator, m->nv);
+  int w = d->warning;
+  oracle_free_data(d);
+  return w;
+}
+
 /* the constraint rows at (qpos, qvel): efc_J [nefc x nv], efc_pos, efc_diagApprox, efc_R, efc_aref (each up to `cap` rows); returns
  * nefc.  Test hook (finite-difference checks of the row Jacobians) */
 int oracle_debug_constraints(const OModel *om, const double *qpos, const double *qvel, const double *mocap, int cap, double *J, double *pos,
@@ -1295,6 +1543,7 @@ void oracle_step(const OModel *om, OData *d) {
       for (int a = 0; a < m->nu; a++) {
         double kv = m->actuator_biastype[a] == MJPC_BIAS_AFFINE ? m->actuator_biasprm[3 * a + 2] : 0;
         if (kv == 0) continue;
+        if (m->actuator_trntype[a] == MJPC_TRN_SITE) { d->unsupported++; d->warning |= MJPC_WARN_UNSUPPORTED; continue; }      /* (refused at create by the engine) */
         if (m->actuator_forcelimited[a] && (d->actuator_force[a] <= m->actuator_forcerange[2 * a] || d->actuator_force[a] >= m->actuator_forcerange[2 * a + 1])) continue;
         double gear = m->actuator_gear[a];
         o_zero(row, nv);
@@ -1333,7 +1582,7 @@ void oracle_step(const OModel *om, OData *d) {
   for (int i = 0; i < nv; i++) d->qvel[i] += h * qacc[i];
   integrate_pos(om, d, h);
   d->time += h;
-  o_copy(d->qacc_warmstart, d->qacc, nv);
+  o_copy(d->qacc_warmstart, d->qacc_newton, nv);
 }
 
 /* ---- debug accessors for unit tests --------------------------------------------------- */

@@ -639,6 +639,18 @@ void oracle_residual(const OModel *om, OData *d, double *residual) {
       for (int i = 9 + m->nu; i < om->t.num_residual; i++) residual[i] = 0;
       break;
     }
+    case MJPC_TASK_FINGERS: {  /* fingers.cc:31-62 (framepos of a body = its inertial frame origin) */
+      const int *id = om->t.int_data;
+      o_sub3(residual, d->xipos + 3 * id[0], d->xipos + 3 * id[2]);
+      o_sub3(residual + 3, d->xipos + 3 * id[1], d->xipos + 3 * id[2]);
+      for (int i = 0; i < 3; i++) {
+        double df[3];
+        o_sub3(df, d->site_xpos + 3 * id[3 + i], d->site_xpos + 3 * id[6 + i]);
+        residual[6 + i] = o_norm3(df);
+      }
+      o_copy(residual + 9, d->ctrl, m->nu);
+      break;
+    }
     case MJPC_TASK_ACROBOT: {  /* acrobot.cc:34-49 */
       int g = om->t.int_data[0], t = om->t.int_data[1];
       residual[0] = d->site_xpos[3 * g + 2] - d->site_xpos[3 * t + 2];

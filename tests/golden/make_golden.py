@@ -33,6 +33,8 @@ CONFIGS = {
     "ball_chain_friction_6x80": ("ball_chain_friction", 6, 80, 4, 2, 0.4, False),   # tendon friction loss rows (cross-branch and in-pattern)
     "swimmer_6x101": ("swimmer", 6, 101, 10, 2, 0.3, False),                # mjpc/tasks/swimmer/task.xml:9-16 (10 spline points), half the horizon; agent_integrator 2 (the full implicit integrator), as the XML asks
     "quadrotor_8x51": ("quadrotor", 8, 51, 5, 2, 0.3, True),                # mjpc/tasks/quadrotor/task.xml:13-19 (horizon 0.5 s, 5 points, exploration 0.3), hover nominal
+    "fingers_8x60": ("fingers_grasp", 8, 60, 5, 2, 0.04, False),             # registry Fingers (task.xml:9-19: 5 spline points, exploration 0.04, implicit 5 ms steps, noslip 5), from a pinch grasp
+    "welded_6x80": ("welded", 6, 80, 4, 2, 0.5, False),                     # weld equalities (arm-to-free-body, explicit relpose, puck welded to a mocap body)
     "linkage_6x80": ("linkage", 6, 80, 4, 2, 0.5, False),                   # equality constraints (joint coupling, four-bar connect, pinned free body) next to contacts
     "servo_arm_6x80": ("servo_arm", 6, 80, 4, 2, 0.5, False),               # implicitfast integrator (velocity servos, saturating force range, damped tendon)
     "filter_arm_6x80": ("filter_arm", 6, 80, 4, 2, 0.4, False),             # activation states (filter / filterexact / clamped integrator)

@@ -66,6 +66,7 @@ def lib():
     L.oracle_debug_forward.argtypes = [C.c_void_p] + [c_double_p] * 4 + [C.c_double] + [c_double_p] * 5 + [c_int_p, c_int_p, c_double_p, c_double_p, c_double_p]
     L.oracle_debug_step.argtypes = [C.c_void_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, C.c_int, c_double_p]
     L.oracle_debug_vel_derivatives.argtypes = [C.c_void_p] + [c_double_p] * 6
+    L.oracle_debug_actuation.argtypes = [C.c_void_p] + [c_double_p] * 6
     L.oracle_debug_constraints.argtypes = [C.c_void_p, c_double_p, c_double_p, c_double_p, C.c_int] + [c_double_p] * 5; L.oracle_debug_constraints.restype = C.c_int
     _lib = L
     return L
@@ -188,6 +189,16 @@ class Oracle:
         out["warning"] = lib().oracle_debug_vel_derivatives(self.h, _dp(qpos), _dp(qvel), _dp(out["dbias"]), _dp(out["dfluid"]),
                                                             _dp(out["qfrc_bias"]), _dp(out["qfrc_passive"]))
         return out
+
+    def actuation(self, qpos, qvel=None, ctrl=None, act=None):
+        """actuator_force [nu] and qfrc_actuator [nv] at the given state"""
+        m = self.model
+        qpos = np.ascontiguousarray(qpos, float); qvel = np.ascontiguousarray(qvel if qvel is not None else np.zeros(m["nv"]), float)
+        ctrl = np.ascontiguousarray(ctrl if ctrl is not None else np.zeros(max(m["nu"], 1)), float)
+        act_a = np.ascontiguousarray(act, float) if act is not None else None
+        force, qfrc = np.zeros(max(m["nu"], 1)), np.zeros(m["nv"])
+        lib().oracle_debug_actuation(self.h, _dp(qpos), _dp(qvel), _dp(ctrl), _dp(act_a), _dp(force), _dp(qfrc))
+        return force[:m["nu"]], qfrc
 
     def constraints(self, qpos, qvel=None, mocap=None, cap=256):
         """the constraint rows at (qpos, qvel): efc_J, efc_pos, efc_diagApprox, efc_R, efc_aref"""

@@ -37,6 +37,7 @@ typedef enum { mjGAIN_FIXED = 0, mjGAIN_AFFINE, mjGAIN_MUSCLE, mjGAIN_USER } mjt
 typedef enum { mjBIAS_NONE = 0, mjBIAS_AFFINE, mjBIAS_MUSCLE, mjBIAS_USER } mjtBias;
 typedef enum { mjDYN_NONE = 0, mjDYN_INTEGRATOR, mjDYN_FILTER, mjDYN_FILTEREXACT, mjDYN_MUSCLE, mjDYN_USER } mjtDyn;
 typedef enum { mjWRAP_NONE = 0, mjWRAP_JOINT, mjWRAP_PULLEY, mjWRAP_SITE, mjWRAP_SPHERE, mjWRAP_CYLINDER } mjtWrap;
+typedef enum { mjTRN_JOINT = 0, mjTRN_JOINTINPARENT, mjTRN_SLIDERCRANK, mjTRN_TENDON, mjTRN_SITE, mjTRN_BODY } mjtTrn;
 typedef enum { mjGEOM_PLANE = 0, mjGEOM_HFIELD, mjGEOM_SPHERE, mjGEOM_CAPSULE, mjGEOM_ELLIPSOID, mjGEOM_CYLINDER, mjGEOM_BOX,
                mjGEOM_MESH, mjGEOM_SDF, mjNGEOMTYPES, mjGEOM_ARROW = 100, mjGEOM_ARROW1, mjGEOM_ARROW2, mjGEOM_LINE, mjGEOM_SKIN,
                mjGEOM_LABEL, mjGEOM_TRIANGLE, mjGEOM_NONE = 1001 } mjtGeom;

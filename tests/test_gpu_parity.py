@@ -104,6 +104,46 @@ def test_weld_equalities():
     assert np.abs(np.abs(q @ d["mocap"][3:] / np.linalg.norm(d["mocap"][3:])) - 1).max() < 1e-3
 
 
+@pytest.mark.parametrize("name, tol", [("noslip_elliptic3", 1e-6), ("noslip_elliptic4", 1e-6), ("noslip_elliptic6", 1e-6), ("noslip_pyramidal3", 1e-6), ("noslip_pyramidal6", 1e-6)])
+def test_noslip_pass(name, tol):
+    """mj_solNoSlip on the device (csrc/noslip.h): friction-loss rows of a joint and of a tendon, contact friction of either cone and
+    every condim, next to a joint at its limit; same trajectories as the oracle, and the box the tilted gravity would let creep stays put."""
+    from mujoco_mpc_amd.modelgen import REGISTRY
+    m, task, d = REGISTRY[name]()
+    out, ref, allc = _compare(m, task, d, 4, 60, 12, (0.5, 0.0), 2, tol)
+    assert not out["failure"].any() and allc["diag"][:, 1].max() >= 4
+    assert np.abs(allc["states"][:, -1, m["nq"]:m["nq"] + 2]).max() < 2e-5            # the box does not slide
+
+
+def test_site_transmissions_with_reference_sites():
+    """mj_transmission for mjTRN_SITE with a refsite on the device: tilted reference site on another kinematic tree, one on the
+    actuated site's own branch (moment cleared on the shared hinge), affine bias with a velocity term, an integrator activation, a force range."""
+    from mujoco_mpc_amd.modelgen import site_servo
+    m, task, d = site_servo()
+    out, ref, allc = _compare(m, task, d, 4, 80, 12, (0.3, 0.0), 2, 1e-9)
+    assert not out["failure"].any()
+    m2, task2, d2 = site_servo(integrator=2)                     # the dense implicit path carries them too (no velocity bias there)
+    _compare(m2, task2, d2, 4, 80, 8, (0.3, 0.0), 2, 1e-9)
+
+
+@pytest.mark.parametrize("grasp", [False, True])
+def test_fingers_task(grasp):
+    """mjpc/tasks/fingers (fingers.cc:31-62, task.xml): engine vs oracle with the task's agent settings (5 ms implicit steps, 5 cubic
+    knots, noslip_iterations 5, condim-6 elliptic contacts, integrated-velocity servos on site transmissions); from the home key
+    (the object drops onto the floor) and from a pinch grasp that lifts it, where the noslip pass decides whether it slips."""
+    from mujoco_mpc_amd.modelgen import fingers
+    m, task, d = fingers(grasp=grasp)
+    out, ref, allc = _compare(m, task, d, 5, 60 if grasp else 101, 16, (0.04, 0.0), 2, 1e-5, nominal_scale=0.3)
+    assert not out["failure"].any() and allc["diag"][:, 1].max() >= (2 if grasp else 4)
+    if grasp:
+        m0, task0, _ = fingers(grasp=True, noslip_iterations=0)
+        o0 = ol.Oracle(m0, task0)
+        kt = np.linspace(0, 59 * m["timestep"], 5); kv = np.random.default_rng(1).uniform(-0.3, 0.3, (5, m["nu"]))
+        eps, sel = ol.noise(1, 0, 0, 16, 5, m["nu"])
+        r0 = o0.plan(d["state"], None, 0.0, kt, kv, 2, 16, 60, sigma=(0.04, 0.0), noise_eps=eps, noise_sel=sel, nthreads=8)
+        assert _rel(r0["states"], ref["states"]) > 1e-3          # without the pass the object slips differently: the test sees the pass
+
+
 def test_implicitfast_integrator():
     """mjINT_IMPLICITFAST: the integration solve uses M - h dF/dv with the velocity terms of the servos (dropped while a force sits on
     its range) and the tendon damping; same trajectories as the oracle, and different from Euler's on this stiff arm."""

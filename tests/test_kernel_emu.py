@@ -30,6 +30,11 @@ def _rel(a, b):
                                                    ("quadrotor", 5, 51, 6, (0.3, 0.0), 1e-9),       # registry Quadrotor: site transmissions (thrust + reaction torque), 15 declared / 13 written residuals
                                                    ("linkage", 4, 80, 6, (0.5, 0.0), 1e-9),         # equality constraints: joint coupling across branches, four-bar connect, pinned free body
                                                    ("welded", 4, 80, 6, (0.5, 0.0), 1e-9),          # weld equalities: arm-to-free-body, explicit relpose, free body welded to a mocap body
+                                                   ("fingers", 5, 60, 6, (0.3, 0.0), 1e-6),         # registry Fingers: noslip pass, site transmissions against a reference site with integrated-velocity servos, condim 6
+                                                   ("fingers_grasp", 5, 40, 6, (0.05, 0.0), 1e-5),  # the same with the object pinched between the fingers and lifted: the noslip pass at work on condim-6 contacts
+                                                   ("site_servo", 4, 80, 6, (0.3, 0.0), 1e-9),      # site transmissions against reference sites (tilted, on another tree / on the same branch), affine bias, activation, force range
+                                                   ("noslip_elliptic3", 4, 60, 6, (0.5, 0.0), 1e-6), ("noslip_elliptic4", 4, 60, 6, (0.5, 0.0), 1e-6), ("noslip_elliptic6", 4, 60, 6, (0.5, 0.0), 1e-6),
+                                                   ("noslip_pyramidal3", 4, 60, 6, (0.5, 0.0), 1e-6), ("noslip_pyramidal6", 4, 60, 6, (0.5, 0.0), 1e-6),      # noslip pass: joint / tendon friction loss, contact friction of either cone
                                                    ("servo_arm", 4, 80, 6, (0.5, 0.0), 1e-9),       # mjINT_IMPLICITFAST: velocity servos, saturating force range, damped tendon
                                                    ("filter_arm", 4, 80, 6, (0.4, 0.0), 1e-9),      # activation states: filter / filterexact / clamped integrator actuators
                                                    ("ball_chain", 4, 60, 6, (0.4, 0.0), 1e-5),      # limited ball joints, tendon spring / damper / cross-branch limit
@@ -221,7 +226,7 @@ def test_models_the_engine_cannot_roll_out_are_refused_at_create():
         cmf = capi.CModel(bf.compile(), task)
         assert lib.mjpc_hip_layout_bytes(ctypes.byref(cmf.c_model), ctypes.byref(cmf.c_task), 1) > 0, lib.mjpc_hip_last_error()
         assert lib.mjpc_hip_layout_bytes(ctypes.byref(cmf.c_model), ctypes.byref(cmf.c_task), 2) < 0 and b"dense-tier" in lib.mjpc_hip_last_error()
-    option("noslip_iterations", 3, "noslip")
+    option("noslip_iterations", 3, None); option("noslip_iterations", -1, "noslip")           # the noslip pass is built (csrc/noslip.h)
     option("disableflags", 1 << 6, "disableflags"); option("disableflags", 1 << 14, "disableflags")          # gravity, eulerdamp
     option("disableflags", (1 << 0) | (1 << 2) | (1 << 3) | (1 << 4) | (1 << 12), None)
     option("enableflags", 1 << 0, "override"); option("enableflags", 1 << 1, None)

@@ -250,6 +250,29 @@ def test_humanoid_interact_xml_matches_generator():
     assert tasks.INTERACT_MODES == tuple(info["text"]["task_transition"].split("|")) if "text" in info else True
 
 
+def test_fingers_xml_matches_generator():
+    """tasks/fingers/task.xml is complete and local: the generator's model (bodies, joints, geoms, sites, the six integrated-velocity
+    servos on site transmissions against the world site, gravity compensation, the exclude), options (elliptic cones, noslip 5, the
+    agent's implicit integrator and 5 ms step), cost terms, agent settings and home key are the file's."""
+    b, info = _load("tasks/fingers/task.xml")
+    m = b.compile()
+    m2, task, d = tasks.fingers()
+    assert _compare_named(m, m2) == []
+    for k in ("actuator_trntype", "actuator_gear6", "actuator_dyntype", "actuator_actlimited", "actuator_actrange", "actuator_ctrllimited", "actuator_biastype", "body_gravcomp"):
+        assert np.array_equal(np.asarray(m[k]), np.asarray(m2[k])), k
+    site_name = lambda mm, i: {v: k for k, v in mm["names"]["site"].items()}[int(i)]
+    assert [site_name(m, i) for i in m["actuator_trnid"]] == [site_name(m2, i) for i in m2["actuator_trnid"]] == ["finger_a"] * 3 + ["finger_b"] * 3
+    assert [site_name(m, i) for i in m["actuator_refsite"]] == [site_name(m2, i) for i in m2["actuator_refsite"]] == ["world"] * 6
+    assert (m["cone"], m["noslip_iterations"], m["nexclude"]) == (m2["cone"], m2["noslip_iterations"], m2["nexclude"]) == (1, 5, 1)
+    assert info["numeric"]["agent_timestep"] == [m2["timestep"]] and info["numeric"]["agent_integrator"] == [m2["integrator"]] and m["integrator"] == 2
+    assert _xml_terms(info) == _terms_of(task)
+    assert info["numeric"]["sampling_trajectories"] == [d["N"]] and info["numeric"]["sampling_spline_points"] == [d["P"]] and info["numeric"]["sampling_exploration"] == [d["sigma"][0]]
+    assert round(info["numeric"]["agent_horizon"][0] / m2["timestep"]) + 1 == d["horizon"]
+    home = next(k for k in info["keys"] if k["name"] == "home")
+    q = np.array(home["qpos"]); q[10:14] /= np.linalg.norm(q[10:14])
+    assert np.allclose(q, d["state"][:20], atol=1e-15) and np.array_equal(home["act"], d["state"][38:])
+
+
 def test_loader_attributes_of_the_late_features():
     """<option density / viscosity / wind / integrator>, body gravcomp, joint actuatorfrcrange, <velocity> actuators, filter dynamics and
     <equality> are outside the reference files above: a small inline document"""

@@ -706,6 +706,114 @@ def test_weld_equality_rows():
     assert abs(cs["pos"][2]) < 1e-3 and 1e-5 < np.abs(cs["pos"][3:]).max() < 5e-3                    # small tilt from the off-centre weight
 
 
+@pytest.mark.parametrize("cone, condim", [(0, 3), (0, 4), (0, 6), (1, 3), (1, 4), (1, 6)])
+def test_noslip_pass_removes_the_creep_of_soft_contacts(cone, condim):
+    """mj_solNoSlip (opt.noslip_iterations): a box resting under gravity with a tangential component below the friction limit.  The
+    soft friction rows let it creep (velocity ~ R * force); re-solving the friction dimensions without the regulariser stops it."""
+    def drift(ns):
+        b = ModelBuilder(timestep=0.005, gravity=(1.5, 0.4, -9.81), cone=cone, contact=True)
+        b.noslip_iterations = ns
+        b.geom(0, "floor", PLANE, size=(0, 0, 0.05))
+        o = b.body("box", 0, pos=(0, 0, 0.05)); b.joint(o, "f", FREE)
+        b.geom(o, "g", BOX, size=(0.05, 0.04, 0.05), condim=condim, friction=(0.5, 0.005, 0.0001), mass=0.2)
+        m = b.compile()
+        q, v, *_ = ol.Oracle(m, _copy_task(m)).step(np.array(m["qpos0"], float), np.zeros(6), nstep=200)
+        return np.hypot(*v[:2])
+    creep, held = drift(0), drift(5)
+    assert creep > 3e-4 and held < creep / 100
+
+
+def test_noslip_leaves_normal_forces_and_limits_alone():
+    """the pass only touches friction-loss rows and friction dimensions: a frictionless (condim 1) contact and a joint at its limit
+    give the same step with and without it; a joint with friction loss held by it against a load below the loss does not move at all"""
+    def build(ns, condim=1, floss=0.0):
+        b = ModelBuilder(timestep=0.004, contact=True)
+        b.noslip_iterations = ns
+        b.geom(0, "floor", PLANE, size=(0, 0, 0.05), condim=condim)
+        ball = b.body("ball", 0, pos=(0, 0, 0.049)); b.joint(ball, "f", FREE); b.geom(ball, "g", SPHERE, size=(0.05,), condim=condim, mass=0.3)
+        arm = b.body("arm", 0, pos=(1, 0, 0.5)); b.joint(arm, "h", HINGE, axis=(0, 1, 0), limited=True, range=(-0.2, 0.2), frictionloss=floss)
+        b.geom(arm, "ga", CAPSULE, size=(0.02, 0), fromto=(0, 0, 0, 0.3, 0, 0), mass=0.2)
+        m = b.compile()
+        return m, ol.Oracle(m, _copy_task(m))
+    m, o5 = build(5); _, o0 = build(0)
+    q = np.array(m["qpos0"], float); q[7] = 0.21; v = np.zeros(7); v[0] = 0.3
+    a, b_ = o5.step(q, v, nstep=20), o0.step(q, v, nstep=20)
+    assert np.abs(a[0] - b_[0]).max() < 1e-13 and np.abs(a[1] - b_[1]).max() < 1e-12
+    # gravity torque on the arm 0.2 * 9.81 * 0.15 = 0.29 < frictionloss 0.5: soft row -> slow creep; noslip -> none
+    m, o5 = build(5, floss=0.5); _, o0 = build(0, floss=0.5)
+    q = np.array(m["qpos0"], float); v = np.zeros(7)
+    a, b_ = o5.step(q, v, nstep=50), o0.step(q, v, nstep=50)
+    assert abs(b_[1][6]) > 1e-4 and abs(a[1][6]) < 1e-9
+
+
+def test_site_transmission_with_a_reference_site():
+    """mj_transmission, mjTRN_SITE with refsite: (i) the Fingers arrangement - a body on three slide joints, servos on its site
+    relative to a world site - is the same system as position servos on the joints themselves; (ii) in general the length is the
+    site's position in the reference site's frame dotted with the gear, and the moment is its derivative along the dofs that do
+    not turn the reference frame (central differences), cleared on the dofs both sites hang from."""
+    def finger(site_servo):
+        b = ModelBuilder(timestep=0.005, contact=False)
+        world = b.site(0, "world")
+        f = b.body("f", 0, pos=(0.1, -0.2, 0.3))
+        for ax, v in (("x", (1, 0, 0)), ("y", (0, 1, 0)), ("z", (0, 0, 1))):
+            b.joint(f, ax, SLIDE, axis=v, damping=0.3)
+        b.geom(f, "g", SPHERE, size=(0.02,), mass=0.05)
+        s = b.site(f, "s")
+        for k, ax in enumerate("xyz"):
+            g6 = [0.0] * 6; g6[k] = 1.0
+            kw = dict(gainprm=(200, 0, 0), biastype=1, biasprm=(0, -200, 0), ctrlrange=(-0.99, 0.99), dyntype=1, actlimited=True, actrange=(-1, 1))
+            if site_servo:
+                b.actuator(f"a{ax}", site=s, refsite=world, gear6=g6, **kw)
+            else:
+                b.actuator(f"a{ax}", ax, **kw)
+        m = b.compile()
+        return m, ol.Oracle(m, _copy_task(m))
+    ms, os_ = finger(True); mj, oj = finger(False)
+    assert list(ms["actuator_refsite"]) == [0, 0, 0] and list(mj["actuator_refsite"]) == [-1, -1, -1]
+    # joint transmissions measure qpos, the site one the world position: start the activations accordingly
+    qs, vs = np.zeros(3), np.array([0.2, -0.1, 0.3])
+    act_site, act_joint = np.array([0.15, -0.25, 0.4]), np.array([0.05, -0.05, 0.1])
+    def run(o, m, act):
+        P, H, N = 3, 40, 2
+        kt = np.linspace(0, (H - 1) * m["timestep"], P); kv = np.array([[0.5, -0.3, 0.2]] * P)
+        eps, sel = ol.noise(1, 0, 0, N, P, m["nu"])
+        return o.plan(np.concatenate([qs, vs, act]), None, 0.0, kt, kv, 0, N, H, sigma=(0.0, 0.0), noise_eps=eps, noise_sel=sel, nthreads=2)["states"][0]
+    a, b_ = run(os_, ms, act_site), run(oj, mj, act_joint)
+    assert np.abs(a[:, :6] - b_[:, :6]).max() < 1e-12 and np.abs(a[-1, :3]).max() > 0.01
+    # (ii) a site on a two-link arm against a tilted reference site on a sliding cart (another tree) and against one on the first link
+    b = ModelBuilder(timestep=0.005, contact=False)
+    cart = b.body("cart", 0, pos=(0.5, 0.2, 0)); b.joint(cart, "cx", SLIDE, axis=(1, 0, 0)); b.geom(cart, "gc", BOX, size=(0.05, 0.05, 0.05), mass=1.0)
+    ref = b.site(cart, "ref", pos=(0.02, 0.0, 0.05), quat=(0.9, 0.1, -0.3, 0.2))
+    l1 = b.body("l1", 0, pos=(0, 0, 0.4)); b.joint(l1, "h1", HINGE, axis=(0, 1, 0)); b.geom(l1, "g1", CAPSULE, size=(0.02, 0), fromto=(0, 0, 0, 0.3, 0, 0), mass=0.3)
+    ref1 = b.site(l1, "ref1", pos=(0.1, 0, 0.02))
+    l2 = b.body("l2", l1, pos=(0.3, 0, 0)); b.joint(l2, "h2", HINGE, axis=(0, 0, 1)); b.geom(l2, "g2", CAPSULE, size=(0.02, 0), fromto=(0, 0, 0, 0.2, 0, 0), mass=0.2)
+    tip = b.site(l2, "tip", pos=(0.2, 0.01, 0))
+    gear = (0.3, -1.0, 0.5)
+    b.actuator("cartref", site=tip, refsite=ref, gear6=gear + (0, 0, 0), gainprm=(0, 0, 0), biastype=1, biasprm=(0, -1, 0))     # force = -length
+    b.actuator("linkref", site=tip, refsite=ref1, gear6=gear + (0, 0, 0), gainprm=(0, 0, 0), biastype=1, biasprm=(0, -1, 0))
+    m = b.compile()
+    o = ol.Oracle(m, _copy_task(m))
+    q = np.array([0.13, 0.4, -0.7])
+    f0, qf = o.actuation(q)
+    eps = 1e-6
+    grad = np.array([(o.actuation(q + eps * np.eye(3)[d])[0] - o.actuation(q - eps * np.eye(3)[d])[0]) / (2 * eps) for d in range(3)])   # d(-length)/dq
+    # both actuators at once: qfrc = sum_a moment_a * force_a; separate them by switching one bias off
+    def moment(a):
+        mm = dict(m); bp = np.array(m["actuator_biasprm"], float).copy(); bp[1 - a] = 0; mm["actuator_biasprm"] = bp
+        fa, qa = ol.Oracle(mm, _copy_task(mm)).actuation(q)
+        return qa / fa[a]
+    m0, m1 = moment(0), moment(1)
+    assert np.allclose(m0, -grad[:, 0], atol=1e-8)                        # nothing turns the cart's frame: the moment is the full derivative
+    assert m1[0] == 0 and m1[1] == 0                                      # h1 carries both sites: cleared (and the cart does not move either)
+    assert m1[2] == pytest.approx(-grad[2, 1], abs=1e-8)                  # h2 moves the tip only
+    # the length itself: R_ref^T (x_tip - x_ref) . gear
+    from mujoco_mpc_amd.modelgen.builder import kinematics, quat2mat, quat_mul
+    xpos, xquat, xmat, *_ = kinematics(m, q)
+    x_tip = xpos[l2] + xmat[l2] @ np.array([0.2, 0.01, 0]); x_ref = xpos[cart] + xmat[cart] @ np.array([0.02, 0.0, 0.05])
+    R_ref = xmat[cart] @ quat2mat(np.array([0.9, 0.1, -0.3, 0.2]) / np.linalg.norm([0.9, 0.1, -0.3, 0.2]))
+    assert -f0[0] == pytest.approx(np.array(gear) @ (R_ref.T @ (x_tip - x_ref)), rel=1e-12)
+
+
 def test_implicitfast_integrator_closed_form():
     """mjINT_IMPLICITFAST on one hinge with a position servo (kp, kv) and joint damping b:  v' = v + h tau / (I + h (b + g^2 kv)),
     tau = g (kp (u - g q) - kv g v) - b v;  Euler keeps only b in the denominator; with the servo force on its range the velocity

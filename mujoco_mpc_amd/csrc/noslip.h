@@ -6,7 +6,7 @@
 // MuJoCo works on the dense dual matrix AR = J M^-1 J^T + diag(R).  Here the rows B_r = M^-1 J_r^T are kept instead (same size
 // as J) together with w = M^-1 J^T force, one entry per lane: the residual of a block is J_blk w + b_blk, a force change d updates
 // w += sum_k d_k B_k, the small diagonal blocks J_blk B_blk^T are formed once per step.  Same sweeps, same block updates and
-// the same stopping rule as the CPU restatement (oracle/physics.c: noslip).
+// the same stopping rule as the CPU restatement the tests check it against.
 #pragma once
 #define NS_BT(c) (lds_base() + (c).K->L.noslip)
 

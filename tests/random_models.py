@@ -1,6 +1,6 @@
 """Random articulated models for the fuzz parity tests (test infrastructure): random trees of bodies on free / ball / hinge /
 slide joints with limits, damping, armature, friction loss and springs, one or two primitive geoms of every supported type per
-body, motors and position servos, fixed tendons with limits / springs / dampers / friction loss (also across branches), joint, connect and weld equalities, stateful
+body, motors and position servos, fixed tendons with limits / springs / dampers / friction loss (also across branches), joint, connect and weld equalities, the noslip pass, stateful
 actuators, either integrator, either friction cone,
 contact dimensions 1 / 3 / 4 / 6.  The residual copies the state."""
 import numpy as np
@@ -128,6 +128,8 @@ def random_model(seed, portal_pairs=False):
         other = 0 if rng_w.random() < 0.4 else int(rng_w.choice(bodies))
         b.weld(b.body_id(f"loose{nloose - 1}"), other, anchor=tuple(float(x) for x in rng_w.uniform(-0.05, 0.05, 3)),
                torquescale=float(rng_w.choice([1.0, 0.5, 0.2])), solref=(float(rng_w.choice([0.02, 0.01])), 1.0))
+    if rng_w.random() < 0.25:                       # the noslip pass on some models (friction-loss rows and contact friction of whatever cone / condim came up)
+        b.noslip_iterations = int(rng_w.choice([2, 5]))
     for jn in scalar_joints:                        # joint-level clamp of the total actuator force on some joints
         if rng_fr.random() < 0.15:
             lim = float(rng_fr.uniform(0.3, 1.5)); b.actfrc[jn] = (-lim, lim)

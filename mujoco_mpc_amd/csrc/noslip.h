@@ -22,13 +22,13 @@ DEV void ns_qcqp2(double *res, const double *Ain, const double *bin, const doubl
   for (int iter = 0; iter < 20; iter++) {
     double det = (A11 + la) * (A22 + la) - A12 * A12;
     if (det < 1e-10) { res[0] = 0; res[1] = 0; return; }
-    double detinv = 1 / det;
+    double detinv = fast_rcp(det);
     double P11 = (A22 + la) * detinv, P22 = (A11 + la) * detinv, P12 = -A12 * detinv;
     v1 = -P11 * b1 - P12 * b2; v2 = -P12 * b1 - P22 * b2;
     double val = v1 * v1 + v2 * v2 - r * r;
     if (val < 1e-10) break;
     double deriv = -2 * (P11 * v1 * v1 + 2 * P12 * v1 * v2 + P22 * v2 * v2);
-    double delta = -val / deriv;
+    double delta = d_div(-val, deriv);
     if (delta < 1e-10) break;
     la += delta;
   }
@@ -44,68 +44,170 @@ DEV void ns_qcqp3(double *res, const double *Ain, const double *bin, const doubl
     double P12 = A13 * A23 - A12 * (A33 + la), P13 = A12 * A23 - A13 * (A22 + la), P23 = A12 * A13 - A23 * (A11 + la);
     double det = (A11 + la) * P11 + A12 * P12 + A13 * P13;
     if (det < 1e-10) { res[0] = res[1] = res[2] = 0; return; }
-    double detinv = 1 / det;
+    double detinv = fast_rcp(det);
     P11 *= detinv; P22 *= detinv; P33 *= detinv; P12 *= detinv; P13 *= detinv; P23 *= detinv;
     v1 = -P11 * b1 - P12 * b2 - P13 * b3; v2 = -P12 * b1 - P22 * b2 - P23 * b3; v3 = -P13 * b1 - P23 * b2 - P33 * b3;
     double val = v1 * v1 + v2 * v2 + v3 * v3 - r * r;
     if (val < 1e-10) break;
     double deriv = -2 * (P11 * v1 * v1 + P22 * v2 * v2 + P33 * v3 * v3) - 4 * (P12 * v1 * v2 + P13 * v1 * v3 + P23 * v2 * v3);
-    double delta = -val / deriv;
+    double delta = d_div(-val, deriv);
     if (delta < 1e-10) break;
     la += delta;
   }
   res[0] = v1 * d[0]; res[1] = v2 * d[1]; res[2] = v3 * d[2];
 }
-// mju_cholFactor with a rank threshold / mju_cholSolve, n <= 5
-DEV int ns_small_chol(double *A, int n, double mindiag) {
-  int rank = n;
-  for (int j = 0; j < n; j++) {
-    double t = A[j * n + j];
-    for (int k = 0; k < j; k++) t -= A[j * n + k] * A[j * n + k];
+// mju_cholFactor with a rank threshold / mju_cholSolve.  The size is a compile-time constant and every loop unrolls: the small
+// matrices live in registers (with run-time sizes they sit in scratch memory and a pass costs milliseconds - measured)
+template <int N>
+DEV int ns_small_chol(double *A, double *dinv, double mindiag) {      // dinv[j] = 1 / L[j][j]: the substitutions multiply
+  int rank = N;
+#pragma unroll
+  for (int j = 0; j < N; j++) {
+    double t = A[j * N + j];
+#pragma unroll
+    for (int k = 0; k < j; k++) t -= A[j * N + k] * A[j * N + k];
     if (t < mindiag) { t = mindiag; rank--; }
-    A[j * n + j] = sqrt(t);
-    double inv = 1 / A[j * n + j];
-    for (int i = j + 1; i < n; i++) {
-      double s = A[i * n + j];
-      for (int k = 0; k < j; k++) s -= A[i * n + k] * A[j * n + k];
-      A[i * n + j] = s * inv;
+    const double inv = fast_rsqrt(t);
+    A[j * N + j] = t * inv; dinv[j] = inv;
+#pragma unroll
+    for (int i = j + 1; i < N; i++) {
+      double s = A[i * N + j];
+#pragma unroll
+      for (int k = 0; k < j; k++) s -= A[i * N + k] * A[j * N + k];
+      A[i * N + j] = s * inv;
     }
   }
   return rank;
 }
-DEV void ns_small_chol_solve(double *x, const double *L, const double *b, int n) {
-  for (int i = 0; i < n; i++) { double s = b[i]; for (int k = 0; k < i; k++) s -= L[i * n + k] * x[k]; x[i] = s / L[i * n + i]; }
-  for (int i = n - 1; i >= 0; i--) { double s = x[i]; for (int k = i + 1; k < n; k++) s -= L[k * n + i] * x[k]; x[i] = s / L[i * n + i]; }
+template <int N>
+DEV void ns_small_chol_solve(double *x, const double *L, const double *dinv, const double *b) {
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    double s = b[i];
+#pragma unroll
+    for (int k = 0; k < i; k++) s -= L[i * N + k] * x[k];
+    x[i] = s * dinv[i];
+  }
+#pragma unroll
+  for (int i = N - 1; i >= 0; i--) {
+    double s = x[i];
+#pragma unroll
+    for (int k = i + 1; k < N; k++) s -= L[k * N + i] * x[k];
+    x[i] = s * dinv[i];
+  }
 }
-DEV void ns_qcqpn(double *res, const double *Ain, const double *bin, const double *d, double r, int n) {
-  double A[25], Ala[25], b[5], tmp[5], la = 0;
-  for (int i = 0; i < n; i++) { b[i] = bin[i] * d[i]; for (int j = 0; j < n; j++) A[j + i * n] = Ain[j + i * n] * d[i] * d[j]; }
+template <int N>
+DEV void ns_qcqpn(double *res, const double *Ain, const double *bin, const double *d, double r) {
+  double A[N * N], Ala[N * N], b[N], tmp[N], dinv[N], la = 0;
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    b[i] = bin[i] * d[i];
+#pragma unroll
+    for (int j = 0; j < N; j++) A[j + i * N] = Ain[j + i * N] * d[i] * d[j];
+  }
   for (int iter = 0; iter < 20; iter++) {
-    for (int i = 0; i < n * n; i++) Ala[i] = A[i];
-    for (int i = 0; i < n; i++) Ala[i * (n + 1)] += la;
-    if (ns_small_chol(Ala, n, 1e-10) < n) { for (int i = 0; i < n; i++) res[i] = 0; return; }
-    ns_small_chol_solve(res, Ala, b, n);
+#pragma unroll
+    for (int i = 0; i < N * N; i++) Ala[i] = A[i];
+#pragma unroll
+    for (int i = 0; i < N; i++) Ala[i * (N + 1)] += la;
+    if (ns_small_chol<N>(Ala, dinv, 1e-10) < N) {
+#pragma unroll
+      for (int i = 0; i < N; i++) res[i] = 0;
+      return;
+    }
+    ns_small_chol_solve<N>(res, Ala, dinv, b);
     double val = 0;
-    for (int i = 0; i < n; i++) { res[i] = -res[i]; val += res[i] * res[i]; }
+#pragma unroll
+    for (int i = 0; i < N; i++) { res[i] = -res[i]; val += res[i] * res[i]; }
     val -= r * r;
     if (val < 1e-10) break;
-    ns_small_chol_solve(tmp, Ala, res, n);
+    ns_small_chol_solve<N>(tmp, Ala, dinv, res);
     double deriv = 0;
-    for (int i = 0; i < n; i++) deriv += res[i] * tmp[i];
+#pragma unroll
+    for (int i = 0; i < N; i++) deriv += res[i] * tmp[i];
     deriv *= -2;
-    double delta = -val / deriv;
+    double delta = d_div(-val, deriv);
     if (delta < 1e-10) break;
     la += delta;
   }
-  for (int i = 0; i < n; i++) res[i] = res[i] * d[i];
+#pragma unroll
+  for (int i = 0; i < N; i++) res[i] = res[i] * d[i];
 }
 // cost change of a block update; an update that raises the cost is taken back (costChange)
-DEV double ns_cost_change(const double *A, double *force, const double *oldforce, const double *res, int dim) {
-  double delta[6], change = 0;
-  for (int j = 0; j < dim; j++) delta[j] = force[j] - oldforce[j];
-  for (int j = 0; j < dim; j++) { double t = 0; for (int k = 0; k < dim; k++) t += A[j * dim + k] * delta[k]; change += 0.5 * delta[j] * t; }
-  for (int j = 0; j < dim; j++) change += delta[j] * res[j];
-  if (change > 1e-10) { for (int j = 0; j < dim; j++) force[j] = oldforce[j]; change = 0; }
+template <int DIM>
+DEV double ns_cost_change(const double *A, double *force, const double *oldforce, const double *res) {
+  double delta[DIM], change = 0;
+#pragma unroll
+  for (int j = 0; j < DIM; j++) delta[j] = force[j] - oldforce[j];
+#pragma unroll
+  for (int j = 0; j < DIM; j++) {
+    double t = 0;
+#pragma unroll
+    for (int k = 0; k < DIM; k++) t += A[j * DIM + k] * delta[k];
+    change += 0.5 * delta[j] * t;
+  }
+#pragma unroll
+  for (int j = 0; j < DIM; j++) change += delta[j] * res[j];
+  if (change > 1e-10) {
+#pragma unroll
+    for (int j = 0; j < DIM; j++) force[j] = oldforce[j];
+    change = 0;
+  }
+  return change;
+}
+// one elliptic contact of dimension DIM (rows r0 .. r0 + DIM - 1): residual J_blk w + b_blk, the friction forces from the QCQP over
+// the cone of the (unchanged) normal force, w updated by the change.  Returns the block's cost change.
+template <int DIM>
+DEV double ns_elliptic_block(Ctx &c, int r0, const double *Acs_c, const double *cc, const double *Bt, const double *bb, double *w) {
+  const int nv = c.M->nv, nvp = c.M->nvp;
+  double *force = c.efc_force;
+  double pk[6] = {0, 0, 0, 0, 0, 0};
+  PFOR(i, nv) {
+    const double wi = w[i];
+#pragma unroll
+    for (int k = 0; k < DIM; k++) pk[k] += c.efc_J[(r0 + k) * nvp + i] * wi;
+  }
+  wave_sum3(pk[0], pk[1], pk[2]);
+  if (DIM > 3) wave_sum3(pk[3], pk[4], pk[5]);
+  double res[DIM], old[DIM], f[DIM], Ac[DIM * DIM];
+#pragma unroll
+  for (int k = 0; k < DIM; k++) { res[k] = pk[k] + bb[r0 + k]; old[k] = force[r0 + k]; f[k] = old[k]; }
+#pragma unroll
+  for (int e = 0; e < DIM * DIM; e++) Ac[e] = Acs_c[e];
+#pragma unroll
+  for (int k = 0; k < DIM; k++) Ac[k * (DIM + 1)] = fmax(1e-10, Ac[k * (DIM + 1)]);
+  if (old[0] < D_MINVAL) {
+#pragma unroll
+    for (int k = 1; k < DIM; k++) f[k] = 0;
+  } else {
+    double bc[DIM - 1], Af[(DIM - 1) * (DIM - 1)], v[DIM - 1], mu[DIM - 1];
+#pragma unroll
+    for (int k = 0; k < DIM - 1; k++) mu[k] = cc[CON_FRICTION + k];
+#pragma unroll
+    for (int j = 0; j < DIM - 1; j++) {
+      bc[j] = res[j + 1];
+#pragma unroll
+      for (int k = 0; k < DIM - 1; k++) { Af[j * (DIM - 1) + k] = Ac[(j + 1) * DIM + (k + 1)]; bc[j] -= Ac[(j + 1) * DIM + (k + 1)] * old[k + 1]; }
+    }
+    if constexpr (DIM == 3) ns_qcqp2(v, Af, bc, mu, old[0]);
+    else if constexpr (DIM == 4) ns_qcqp3(v, Af, bc, mu, old[0]);
+    else ns_qcqpn<DIM - 1>(v, Af, bc, mu, old[0]);
+#pragma unroll
+    for (int j = 0; j < DIM - 1; j++) f[1 + j] = v[j];
+  }
+  const double change = ns_cost_change<DIM>(Ac, f, old, res);
+  SYNC();
+  if (LANE == 0) {
+#pragma unroll
+    for (int k = 1; k < DIM; k++) force[r0 + k] = f[k];
+  }
+  PFOR(i, nv) {
+    double acc = w[i];
+#pragma unroll
+    for (int k = 1; k < DIM; k++) acc += (f[k] - old[k]) * Bt[(r0 + k) * nvp + i];
+    w[i] = acc;
+  }
+  SYNC();
   return change;
 }
 
@@ -204,11 +306,11 @@ DEV void noslip_pass(Ctx &c) {
         double p = 0;
         PFOR(i, nv) p += ns_jent(c, r, i) * w[i];
         const double res = wave_sum(p) + bb[r];
-        const double old = force[r], arinv = 1 / dg[r], fl = c.efc_floss[r];
+        const double old = force[r], arinv = fast_rcp(dg[r]), fl = c.efc_floss[r];
         double f = old - res * arinv;
         if (f < -fl) f = -fl; else if (f > fl) f = fl;
         const double delta = f - old;
-        improvement -= 0.5 * delta * delta / arinv + delta * res;
+        improvement -= 0.5 * delta * delta * dg[r] + delta * res;
         SYNC();
         if (LANE == 0) force[r] = f;
         PFOR(i, nv) w[i] += delta * Bt[r * nvp + i];
@@ -234,44 +336,22 @@ DEV void noslip_pass(Ctx &c) {
           const double K1 = Ac[0] + Ac[3] - Ac[1] - Ac[2], K0 = mid * (Ac[0] - Ac[3]) + bc0 - bc1;
           if (K1 < D_MINVAL) f[0] = f[1] = mid;
           else {
-            double y = -K0 / K1;
+            double y = d_div(-K0, K1);
             if (y < -mid) { f[0] = 0; f[1] = 2 * mid; }
             else if (y > mid) { f[0] = 2 * mid; f[1] = 0; }
             else { f[0] = mid + y; f[1] = mid - y; }
           }
-          improvement -= ns_cost_change(Ac, f, old, res, 2);
+          improvement -= ns_cost_change<2>(Ac, f, old, res);
           SYNC();
           if (LANE == 0) { force[j] = f[0]; force[j + 1] = f[1]; }
           PFOR(i, nv) w[i] += (f[0] - old[0]) * Bt[j * nvp + i] + (f[1] - old[1]) * Bt[(j + 1) * nvp + i];
           SYNC();
         }
       } else if (type == CNSTR_CONTACT_ELLIPTIC) {
-        double pk[6] = {0, 0, 0, 0, 0, 0};
-        PFOR(i, nv) for (int k = 0; k < 6; k++) if (k < dim) pk[k] += c.efc_J[(r0 + k) * nvp + i] * w[i];
-        wave_sum3(pk[0], pk[1], pk[2]);
-        if (dim > 3) wave_sum3(pk[3], pk[4], pk[5]);
-        double res[6], old[6], f[6], Ac[36];
-        for (int k = 0; k < dim; k++) { res[k] = pk[k] + bb[r0 + k]; old[k] = force[r0 + k]; f[k] = old[k]; }
-        for (int e = 0; e < dim * dim; e++) Ac[e] = Acs[ci * 36 + e];
-        for (int k = 0; k < dim; k++) Ac[k * (dim + 1)] = fmax(1e-10, Ac[k * (dim + 1)]);
-        if (old[0] < D_MINVAL) { for (int k = 1; k < dim; k++) f[k] = 0; }
-        else {
-          double bc[5], Af[25], v[5], mu[5];
-          for (int k = 0; k < 5; k++) mu[k] = cc[CON_FRICTION + k];
-          for (int j = 0; j < dim - 1; j++) {
-            bc[j] = res[j + 1];
-            for (int k = 0; k < dim - 1; k++) { Af[j * (dim - 1) + k] = Ac[(j + 1) * dim + (k + 1)]; bc[j] -= Ac[(j + 1) * dim + (k + 1)] * old[k + 1]; }
-          }
-          if (dim == 3) ns_qcqp2(v, Af, bc, mu, old[0]);
-          else if (dim == 4) ns_qcqp3(v, Af, bc, mu, old[0]);
-          else ns_qcqpn(v, Af, bc, mu, old[0], dim - 1);
-          for (int j = 0; j < dim - 1; j++) f[1 + j] = v[j];
-        }
-        improvement -= ns_cost_change(Ac, f, old, res, dim);
-        SYNC();
-        if (LANE == 0) for (int k = 1; k < dim; k++) force[r0 + k] = f[k];
-        PFOR(i, nv) for (int k = 1; k < dim; k++) w[i] += (f[k] - old[k]) * Bt[(r0 + k) * nvp + i];
-        SYNC();
+        const double *Ab = Acs + ci * 36;
+        if (dim == 3) improvement -= ns_elliptic_block<3>(c, r0, Ab, cc, Bt, bb, w);
+        else if (dim == 4) improvement -= ns_elliptic_block<4>(c, r0, Ab, cc, Bt, bb, w);
+        else improvement -= ns_elliptic_block<6>(c, r0, Ab, cc, Bt, bb, w);
       }
     }
     improvement *= scale;

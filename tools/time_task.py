@@ -6,10 +6,8 @@ from mujoco_mpc_amd.modelgen import REGISTRY
 from mujoco_mpc_amd.planner import HipBackend
 name, N = sys.argv[1], int(sys.argv[2])
 kw = {k: (int(v) if v.lstrip("-").isdigit() else v == "True" if v in ("True", "False") else float(v)) for k, v in (a.split("=") for a in sys.argv[3:])}
-gen = REGISTRY[name]
 import mujoco_mpc_amd.modelgen.tasks as T
-if kw:
-    gen = lambda: getattr(T, name)(**kw)
+gen = (lambda: getattr(T, name)(**kw)) if (kw or name not in REGISTRY) else REGISTRY[name]
 m, task, d = gen()
 H, P = d["horizon"], d["P"]
 kt = np.linspace(0, (H - 1) * m["timestep"], P); kv = np.tile(d["ctrl0"], (P, 1)) if "ctrl0" in d else np.zeros((P, m["nu"]))

@@ -1,6 +1,6 @@
 // Diagnostic: where do the wavefronts of 256-thread workgroups land?  Prints, for a launch with two workgroups per CU (80 KB of LDS
 // each), the SIMD of every wave index and the hardware workgroup slots (TG_ID) of the workgroups sharing a CU.
-// build: hipcc --offload-arch=gfx950 -O2 -o gpurun_out/hwid_probe tools/probes/hwid_probe.hip
+// build: hipcc --offload-arch=gfx950 -O2 -o gpurun_out/hwid_probe tools/hwid_pairs_probe.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <map>

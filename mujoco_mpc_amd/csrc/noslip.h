@@ -105,7 +105,10 @@ DEV void ns_qcqpn(double *res, const double *Ain, const double *bin, const doubl
 #pragma unroll
     for (int j = 0; j < N; j++) A[j + i * N] = Ain[j + i * N] * d[i] * d[j];
   }
-  for (int iter = 0; iter < 20; iter++) {
+#ifndef NS_EXP_ITERS
+#define NS_EXP_ITERS 20
+#endif
+  for (int iter = 0; iter < NS_EXP_ITERS; iter++) {
 #pragma unroll
     for (int i = 0; i < N * N; i++) Ala[i] = A[i];
 #pragma unroll

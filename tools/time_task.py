@@ -2,6 +2,9 @@
 import sys, os
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+from mujoco_mpc_amd import capi
+if os.environ.get("ENGINE_LIB"):      # a variant built by tools/mkvariant.sh
+    capi.ENGINE_PATH = os.path.abspath(os.environ["ENGINE_LIB"])
 from mujoco_mpc_amd.modelgen import REGISTRY
 from mujoco_mpc_amd.planner import HipBackend
 name, N = sys.argv[1], int(sys.argv[2])

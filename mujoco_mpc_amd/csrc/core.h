@@ -413,7 +413,6 @@ DEV_SOLVE_PHASE void ph_solve(KP Kc, int last, int t) {
   Ctx c; ctx_open(c, Kc);
   c.hseq = t * 256;
   solve_constraints<NVT>(c); PROF(c, 8);
-  const int noslip = c.M->noslip_iterations > 0 && !(c.warning & (WARN_CONTACTFULL | WARN_CNSTRFULL | WARN_SYNC));
 #if MJPC_HELPER
   // release the waves that wait for jobs: the workers of elliptic models (one packed word, solver_reg.h) / the Hessian builders of
   // the generic path
@@ -423,9 +422,19 @@ DEV_SOLVE_PHASE void ph_solve(KP Kc, int last, int t) {
     flag_set(c.misc + HX_JOB, ++c.hseq);
   }
 #endif
-  if (noslip) noslip_pass<NVT>(c);       // (after the job waves have been released: the pass is the owner's alone)
   // (a step that already overflowed a buffer fails with that code alone: what the solver made of the truncated rows does not matter)
   if (!last && !(c.warning & (WARN_CONTACTFULL | WARN_CNSTRFULL)) && bad_values(c.qacc, c.M->nv)) c.warning |= WARN_BADQACC;
+  ctx_close(c);
+}
+// role 0, models with noslip_iterations > 0: the noslip pass behind the Newton solve, a phase of its own (the solve phase keeps its
+// register allocation; the job waves have been released by then, the pass is the owner's alone)
+template <int NVT>
+DEV_NOINLINE void ph_noslip(KP Kc, int last) {
+  Ctx c; ctx_open(c, Kc);
+  if (!(c.warning & (WARN_CONTACTFULL | WARN_CNSTRFULL | WARN_SYNC | WARN_BADQACC))) {
+    noslip_pass<NVT>(c);
+    if (!last && bad_values(c.qacc, c.M->nv)) c.warning |= WARN_BADQACC;
+  }
   ctx_close(c);
 }
 #if MJPC_HELPER
@@ -822,7 +831,7 @@ DEV void rollout(KP Kc) {
     if (ROLEH && WAVE_ID() == MJPC_WAVES - 2) ph_noncontact(Kc, t);
 #endif
     XBAR(); RPROF(3);
-    if (r0) ph_solve<NVT>(Kc, last, t);
+    if (r0) { ph_solve<NVT>(Kc, last, t); if (Kc->M.noslip_iterations > 0) ph_noslip<NVT>(Kc, last); }
 #if MJPC_HELPER
     if (ROLEH) ph_solve_helper<NVT>(Kc, t);
 #endif

@@ -1110,6 +1110,24 @@ def test_closed_loop_shadow_hand_and_its_transition():
 
 
 @pytest.mark.gpu
+def test_closed_loop_fingers_reach_the_object():
+    """testspeed loop (testspeed.cc:44-129) on the Fingers task with the task file's agent settings (5 spline points, exploration
+    0.04, 0.5 s horizon; 128 rollouts): from the home key the object drops onto the floor and both fingers, 10 cm to either side,
+    close in on it; the cost halves within three seconds and no step of the noslip / implicit pipeline fails."""
+    from mujoco_mpc_amd import cplanner
+    from mujoco_mpc_amd.modelgen import fingers
+    m, task, d = fingers()
+    num = dict(sampling_spline_points=5, sampling_exploration=0.04, sampling_trajectories=128, sampling_representation=2)
+    p = cplanner.SamplingPlanner()
+    p.Initialize(m, task, num, max_samples=128, max_horizon=101)
+    p.Reset(101)
+    res = cplanner.testspeed(p, d["state"], None, horizon=101, steps_per_planning_iteration=1, total_time=3.0)
+    c, s = res["cost_per_step"], res["state"]
+    assert not res["failure"] and c[-50:].mean() < 0.6 * c[:50].mean(), (c[:50].mean(), c[-50:].mean())
+    assert np.linalg.norm(s[14:17] - s[:3]) < 0.06 and np.linalg.norm(s[17:20] - s[:3]) < 0.06, s[:20]
+    p.close()
+
+
 def test_closed_loop_walker_walks_and_acrobot_swings_up():
     """testspeed loop (testspeed.cc:44-129) on the two registry tasks with the reference's agent settings: with a speed goal of
     1 m/s the walker stays up and moves forward (a passive walker is on the floor within the same time); the acrobot's tip,

@@ -895,19 +895,21 @@ DEV void contact_param(Ctx &c, int g1, int g2, double *cc, int *dim) {
 
 // one batch of (at most) NLANE active pairs: narrow phase per lane, ordered compaction, contact records.
 // returns 0: done; 1 (HEAVY == false only): some pair needs narrow_heavy(), nothing was written; 2: contact buffer full
+#define HX_HEAVY 46      // the previous step's first batch needed an out-of-line collider: this step starts with that flavour
 template <bool HEAVY>
-DEV int narrow_batch(Ctx &c, int base, int nactive) {
+DEV int narrow_batch(Ctx &c, int base, int nactive, int *used_heavy = nullptr) {
   const DevModel &M = *c.M;
   int a = base + LANE, n = 0, g1 = 0, g2 = 0;
   double margin = 0, gap = 0;
   NPCon con[4] = {};
   if (a < nactive) {
-    int p = c.active[a];
-    g1 = MI(pair_g1)[p]; g2 = MI(pair_g2)[p];
+    const int gg = c.active[a];           // (the broad phase leaves the pair's two geoms in the list, not its index)
+    g1 = gg & 0xffff; g2 = (int)((unsigned)gg >> 16);
     margin = fmax(MD(geom_margin)[g1], MD(geom_margin)[g2]);
     gap = fmax(MD(geom_gap)[g1], MD(geom_gap)[g2]);
     n = narrow_phase(c, g1, g2, margin, con);
     if constexpr (HEAVY) {
+      if (n == -2 && used_heavy) *used_heavy = 1;
       if (n == -2) {
         NPOut h = narrow_heavy(c, g1, g2, margin);
         n = h.n; con[0] = h.c[0]; con[1] = h.c[1]; con[2] = h.c[2]; con[3] = h.c[3];
@@ -944,14 +946,20 @@ DEV int narrow_batch(Ctx &c, int base, int nactive) {
   return full ? 2 : 0;
 }
 // the batches from `base` on with every collider available (out of line: own registers, called from outside collision()'s loop)
-struct BatchOut { int ncon, warning; };
+struct BatchOut { int ncon, warning, first_heavy; };
 DEV_NOINLINE BatchOut narrow_rest_heavy(const KParams *Kg, int base, int nactive, int ncon, int warning) {
   Ctx c;
   ctx_init(c, Kg, lds_base());
   c.ncon = ncon; c.warning = warning;
-  for (; base < nactive; base += NLANE) if (narrow_batch<true>(c, base, nactive) == 2) break;
+  int first = 0, used = 0;
+  for (int b = base; b < nactive; b += NLANE) {
+    used = 0;
+    int st = narrow_batch<true>(c, b, nactive, &used);
+    if (b == base) first = wave_any(used);
+    if (st == 2) break;
+  }
   BatchOut o;
-  o.ncon = c.ncon; o.warning = c.warning;
+  o.ncon = c.ncon; o.warning = c.warning; o.first_heavy = first;
   return o;
 }
 
@@ -959,18 +967,25 @@ DEV void collision(Ctx &c) {
   const DevModel &M = *c.M;
   c.ncon = 0;
   if (M.disableflags & (1 << 4)) return;
-  // (1) broad phase: ordered compaction of the pairs whose bounding volumes overlap
+  // (1) broad phase: ordered compaction of the pairs whose bounding volumes overlap.  One packed record per pair (host.h) and
+  // the next batch's records requested before this batch is tested: where the tables live in HBM / L2 (no room for the LDS copy)
+  // a batch no longer waits two dependent round trips
   int nactive = 0;
-  for (int base = 0; base < M.npair; base += NLANE) {
-    int p = base + LANE, pass = 0;
-    if (p < M.npair) {
-      int g1 = MI(pair_g1)[p], g2 = MI(pair_g2)[p];
-      double margin = fmax(MD(geom_margin)[g1], MD(geom_margin)[g2]);
-      double r1 = MD(geom_rbound)[g1], r2 = MD(geom_rbound)[g2];
+  const int npair = M.npair;
+  int gg_n = 0; double mg_n = 0, r1_n = 0, r2_n = 0;
+  if (LANE < npair) { gg_n = MI(pair_gg)[LANE]; const double *pp = MD(pair_bp) + 3 * LANE; mg_n = pp[0]; r1_n = pp[1]; r2_n = pp[2]; }
+  for (int base = 0; base < npair; base += NLANE) {
+    const int p = base + LANE, pn = p + NLANE;
+    int pass = 0;
+    const int gg = gg_n;
+    const double margin = mg_n, r1 = r1_n, r2 = r2_n;
+    if (pn < npair) { gg_n = MI(pair_gg)[pn]; const double *pp = MD(pair_bp) + 3 * pn; mg_n = pp[0]; r1_n = pp[1]; r2_n = pp[2]; }
+    if (p < npair) {
+      const int g1 = gg & 0xffff, g2 = (int)((unsigned)gg >> 16);
       double dif[3];
       d_sub3(dif, c.geom_xpos + 3 * g2, c.geom_xpos + 3 * g1);
       pass = 1;
-      if (MI(geom_type)[g1] == 0) {
+      if (r1 < 0) {
         const double *mat = c.geom_xmat + 9 * g1;
         double n[3] = {mat[2], mat[5], mat[8]};
         if (d_dot3(dif, n) > margin + r2) pass = 0;
@@ -980,24 +995,39 @@ DEV void collision(Ctx &c) {
       }
     }
     int tot, off = wave_excl_scan(pass, &tot);
-    if (pass && nactive + off < MAX_ACTIVE_PAIRS) c.active[nactive + off] = p;
+    if (pass && nactive + off < MAX_ACTIVE_PAIRS) c.active[nactive + off] = gg;
     nactive += tot;
   }
   if (nactive > MAX_ACTIVE_PAIRS) { c.warning |= WARN_CONTACTFULL; nactive = MAX_ACTIVE_PAIRS; }
   SYNC();
+#ifdef MJPC_PROFILE_COLLISION      // (diagnostic build: broad phase / cheap batches / out-of-line batches in the slots a pyramidal model leaves empty)
+  PROF(c, 10);
+#endif
   // (2) narrow phase, one lane per active pair, contacts appended in pair order.  The loop only knows the cheap colliders; at
   // the first batch in which some pair needs an expensive one it stops (nothing of that batch is kept) and the out-of-line
   // flavour finishes the list from there.  The call sits behind the loop, so the loop's registers are not shaped by it.
-  int heavy_from = -1;
-  for (int base = 0; base < nactive; base += NLANE) {
-    int st = narrow_batch<false>(c, base, nactive);
-    if (st == 1) heavy_from = base;
-    if (st != 0) break;
-  }
+  // (a candidate whose first batch went out of line in the previous step - a cube lying in the hand - starts there: the cheap
+  // pass would only be thrown away again.  Both flavours write the same contacts.)
+  int heavy_from = (nactive > 0 && uniform_i(c.misc[HX_HEAVY])) ? 0 : -1;
+  if (heavy_from < 0)
+    for (int base = 0; base < nactive; base += NLANE) {
+      int st = narrow_batch<false>(c, base, nactive);
+      if (st == 1) heavy_from = base;
+      if (st != 0) break;
+    }
+  int again = 0;
+#ifdef MJPC_PROFILE_COLLISION
+  PROF(c, 16);
+#endif
   if (heavy_from >= 0) {
     BatchOut o = narrow_rest_heavy(c.K, heavy_from, nactive, c.ncon, c.warning);
     c.ncon = o.ncon; c.warning = o.warning;
+    again = heavy_from == 0 && o.first_heavy;
   }
+  if (LANE == 0) c.misc[HX_HEAVY] = again;
+#ifdef MJPC_PROFILE_COLLISION
+  PROF(c, 18);
+#endif
   SYNC();
 }
 

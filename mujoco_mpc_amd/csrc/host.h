@@ -439,7 +439,18 @@ static inline bool build(PackedModel &p, const MjpcHipModel *m, const MjpcHipTas
       g1s.push_back(g1); g2s.push_back(g2);
     }
     M.npair = (int)g1s.size();
-    M.pair_g1 = as_off<int>(put_i(p, g1s.data(), g1s.size())); M.pair_g2 = as_off<int>(put_i(p, g2s.data(), g2s.size())); }
+    if (ng > 65535) { p.error = "more than 65535 geoms"; return false; }
+    // one record per pair for the broad phase: both geoms in one word, the pair's margin and the two bounding radii (-1 marks a
+    // plane as the first geom): a single round of loads per batch, whatever memory the tables live in
+    std::vector<int> gg(g1s.size()); std::vector<double> bp(3 * g1s.size());
+    for (size_t k = 0; k < g1s.size(); k++) {
+      int a = g1s[k], b = g2s[k];
+      gg[k] = a | (b << 16);
+      bp[3 * k] = std::max(m->geom_margin[a], m->geom_margin[b]);
+      bp[3 * k + 1] = m->geom_type[a] == MJPC_GEOM_PLANE ? -1.0 : m->geom_rbound[a];
+      bp[3 * k + 2] = m->geom_rbound[b];
+    }
+    M.pair_gg = as_off<int>(put_i(p, gg.data(), gg.size())); M.pair_bp = as_off<double>(put_d(p, bp.data(), bp.size())); }
   { std::vector<int> fr, lim, limb, ray;
     for (int i = 0; i < nv; i++) if (!no_fric && m->dof_frictionloss[i] > 0) fr.push_back(i);
     for (int j = 0; j < nj; j++) if (!no_limit && m->jnt_limited[j] && (m->jnt_type[j] == MJPC_JNT_SLIDE || m->jnt_type[j] == MJPC_JNT_HINGE)) lim.push_back(j);
@@ -612,7 +623,7 @@ static inline DevModel relocate(const PackedModel &p, const int *ibase, const do
   fi(M.level_adr); fi(M.level_body); fi(M.subtree_adr); fi(M.subtree_list); fi(M.chain_adr); fi(M.chain_list); fi(M.mpair_i); fi(M.mpair_j); fi(M.hpair_i); fi(M.hpair_j); fi(M.zpair_i); fi(M.zpair_j);
   { const double *q = reinterpret_cast<const double *>(M.body_dofmask); fd(q); M.body_dofmask = reinterpret_cast<const unsigned long long *>(q); }
   { const double *q = reinterpret_cast<const double *>(M.body_patmask); fd(q); M.body_patmask = reinterpret_cast<const unsigned long long *>(q); }
-  fi(M.pair_g1); fi(M.pair_g2); fi(M.fric_dof); fi(M.limit_jnt); fi(M.limit_ball); fi(M.ray_geom); fi(M.tpass_id); fd(M.tpass_prm); fi(M.tfric_id); fd(M.tfric_prm); fi(M.idrv_e); fd(M.idrv_c); fi(M.eq_tab); fd(M.eq_prm); fi(M.sact_i); fd(M.sact_g); fi(M.rsact_i); fi(M.rsact_of); fd(M.rsact_g); fi(M.gc_body); fd(M.gc_force); fi(M.actfrc_dof); fd(M.actfrc_range);
+  fi(M.pair_gg); fd(M.pair_bp); fi(M.fric_dof); fi(M.limit_jnt); fi(M.limit_ball); fi(M.ray_geom); fi(M.tpass_id); fd(M.tpass_prm); fi(M.tfric_id); fd(M.tfric_prm); fi(M.idrv_e); fd(M.idrv_c); fi(M.eq_tab); fd(M.eq_prm); fi(M.sact_i); fd(M.sact_g); fi(M.rsact_i); fi(M.rsact_of); fd(M.rsact_g); fi(M.gc_body); fd(M.gc_force); fi(M.actfrc_dof); fd(M.actfrc_range);
   DevTask &T = M.task;
   fi(T.dim_norm_residual); fi(T.norm); fi(T.num_norm_parameter); fi(T.trace_objtype); fi(T.trace_objid); fi(T.int_data);
   fd(T.weight); fd(T.norm_parameter); fd(T.parameters); fd(T.dbl_data);

@@ -153,7 +153,7 @@ struct DevModel {
   const int *zpair_i, *zpair_j;             // the rest of the lower triangle (structural zeros of that pattern)
   const unsigned long long *body_dofmask;   // bit d set <=> dof d moves body
   const unsigned long long *body_patmask;   // the same along the elimination tree (hub dofs included): cross-branch test of a contact
-  const int *pair_g1, *pair_g2;             // statically filtered geom pairs (type1 <= type2)
+  const int *pair_gg; const double *pair_bp; // statically filtered geom pairs (type1 <= type2): geom1 | geom2 << 16; [margin, rbound1 (-1: plane), rbound2]
   const int *fric_dof, *limit_jnt, *limit_ball, *ray_geom;
   DevTask task;
 };

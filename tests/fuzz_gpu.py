@@ -9,12 +9,17 @@ from random_models import random_model
 from test_random_models import _plan_inputs, _check
 from mujoco_mpc_amd.planner import HipBackend
 lo, hi = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (24, 224)
-bad = []
+bad, refused = [], []
 for seed in range(lo, hi):
     m, task, d = random_model(seed)
     P, H, N, kt, kv, eps, sel = _plan_inputs(m, seed)
     a = ol.Oracle(m, task).plan(d["state"], None, 0.0, kt, kv, 2, N, H, sigma=(0.3, 0.0), noise_eps=eps, noise_sel=sel, nthreads=8)
-    be = HipBackend(m, task, max_samples=N, max_horizon=H)
+    try:
+        be = HipBackend(m, task, max_samples=N, max_horizon=H)
+    except RuntimeError as e:          # a model larger than one CU's LDS is refused at create (loudly): not a parity case
+        if "exceeds 160 KiB" in str(e):
+            refused.append(seed); continue
+        raise
     out = be.plan(state=d["state"], mocap=None, time=0.0, knot_times=kt, knot_values=kv, interpolation=2, num_trajectory=N, horizon=H,
                   sigma=(0.3, 0.0), noise_eps=eps, noise_sel=sel)
     b = be.fetch_all(N, H, P); b["returns"] = out["returns"]; b["failure"] = out["failure"]
@@ -24,4 +29,4 @@ for seed in range(lo, hi):
         assert out["winner"] == a["winner"]
     except AssertionError as e:
         bad.append((seed, str(e)[:60]))
-print("seeds", lo, hi, "failed:", bad)
+print("seeds", lo, hi, "refused for size:", refused, "failed:", bad)

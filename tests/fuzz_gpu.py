@@ -6,10 +6,10 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import oracle_lib as ol
 from random_models import random_model
-from test_random_models import _plan_inputs, _check
+from test_random_models import _plan_inputs, _check, _oracle_is_reproducible
 from mujoco_mpc_amd.planner import HipBackend
 lo, hi = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (24, 224)
-bad, refused = [], []
+bad, refused, loose = [], [], []
 for seed in range(lo, hi):
     m, task, d = random_model(seed)
     P, H, N, kt, kv, eps, sel = _plan_inputs(m, seed)
@@ -28,5 +28,13 @@ for seed in range(lo, hi):
         _check(a, b)
         assert out["winner"] == a["winner"]
     except AssertionError as e:
-        bad.append((seed, str(e)[:60]))
-print("seeds", lo, hi, "refused for size:", refused, "failed:", bad)
+        # the same self-measured bar as the test: where the oracle does not reproduce ITSELF under a one-ulp change of qpos (a
+        # rollout that blows up, an ill-conditioned contact), the first 20 steps are compared at 1e-2 instead
+        if _oracle_is_reproducible(m, task, d, a, kt, kv, N, H, eps, sel, nthreads=8):
+            bad.append((seed, str(e)[:60]))
+        else:
+            try:
+                _check(a, b, 1e-2, 20); loose.append(seed)
+            except AssertionError as e2:
+                bad.append((seed, "loose bar: " + str(e2)[:60]))
+print("seeds", lo, hi, "refused for size:", refused, "held to the loose bar (oracle irreproducible):", loose, "failed:", bad)

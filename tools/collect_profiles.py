@@ -41,7 +41,7 @@ for d, name in (("stats", "kernel_stats"), ("stats512", "kernel_stats_512"), ("s
                 ("stats_humanoid", "kernel_stats_humanoid")):
     for f in glob.glob(os.path.join(src, d, "**", "*kernel_stats.csv"), recursive=True):
         shutil.copy(f, os.path.join(dst, f"{tag}_{name}.csv"))
-for f in glob.glob(os.path.join(src, "bench_*.json")):
+for f in glob.glob(os.path.join(src, "bench_*.json")) + glob.glob(os.path.join(src, "fingers_time.log")):
     shutil.copy(f, os.path.join(dst, f"{tag}_" + os.path.basename(f)))
 print(json.dumps(traffic, indent=1))
 print(sorted(os.listdir(dst)))

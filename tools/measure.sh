@@ -26,5 +26,9 @@ python3 $R/bench.py --workload hand --samples 2048 --steps 5 --warmup 2 --no-sec
 rocprofv3 --kernel-trace --stats -d $O/stats_hand -o s --output-format csv -- python3 $R/bench.py --workload hand --samples 256 --steps 10 --warmup 2 --no-cpu-baseline --no-secondary > /dev/null 2> $O/stats_hand.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_fetch_hand -o p --output-format csv -- python3 $R/bench.py --workload hand --samples 256 --steps 4 --warmup 1 --no-cpu-baseline --no-secondary > /dev/null 2> $O/pmc_fetch_hand.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pmc_write_hand -o p --output-format csv -- python3 $R/bench.py --workload hand --samples 256 --steps 4 --warmup 1 --no-cpu-baseline --no-secondary > /dev/null 2> $O/pmc_write_hand.err
+python3 $R/tools/time_task.py fingers 60 > $O/fingers_time.log 2>&1
+python3 $R/tools/time_task.py fingers 60 grasp=True >> $O/fingers_time.log 2>&1
+python3 $R/tools/time_task.py fingers 256 grasp=True >> $O/fingers_time.log 2>&1
+echo "fingers done"
 find $O -name "*.csv" | head -40
 tail -c 400 $O/bench_default.json

@@ -296,8 +296,12 @@ DEV BBSel bb_candidate(const BBFace &f, int q) {
   }
   return o;
 }
+// the face case of a box pair, set up by the pair's lane and finished by the whole wave (bb_face_select): the 24 candidate points
+// are independent, one lane each; only the (order-dependent) selection among them is serial
+struct BBPend { BBFace f; double pr[3], ru[3], rv[3], n[3], hn; int refA; };
+// returns the number of contacts, or -3: face case, `pend` filled (bb_face_select / bb_face_finish complete it)
 DEV int np_box_box(NPCon *con, double margin, const double *pa, const double *ma, const double *sa,
-                   const double *pb, const double *mb, const double *sb) {
+                   const double *pb, const double *mb, const double *sb, BBPend &pend) {
   double R[9], AR[9], t[3], tb[3], dif[3];
   d_sub3(dif, pb, pa);
   d_mulmattvec3(t, ma, dif);
@@ -402,20 +406,37 @@ DEV int np_box_box(NPCon *con, double margin, const double *pa, const double *ma
   f.e1[0] = sq1 * d_dot3(q1, ru); f.e1[1] = sq1 * d_dot3(q1, rv); f.e1[2] = sq1 * d_dot3(q1, n);
   f.e2[0] = sq2 * d_dot3(q2, ru); f.e2[1] = sq2 * d_dot3(q2, rv); f.e2[2] = sq2 * d_dot3(q2, n);
   f.det = f.e1[0] * f.e2[1] - f.e1[1] * f.e2[0];
-  // selection passes regenerate the candidates instead of storing 24 of them: deepest, farthest from it, extreme on either side
-  BBSel s0, s1, s2, s3; s0.ok = s1.ok = s2.ok = s3.ok = 0;
+  pend.f = f; pend.hn = hn; pend.refA = refA;
+  d_copy3(pend.pr, pr); d_copy3(pend.ru, ru); d_copy3(pend.rv, rv); d_copy3(pend.n, n);
+  return -3;
+}
+// the wave's part of a face case: every lane below 24 evaluates one candidate point of the (wave-uniform) face problem, then the
+// selection - deepest, farthest from it, extreme on either side, each with its tie rule, so in candidate order - reads them lane
+// by lane.  All lanes return the same four picks.  (One-lane emulation build: the candidates in a local array.)
+DEV void bb_face_select(const BBFace &f, double margin, BBSel &s0, BBSel &s1, BBSel &s2, BBSel &s3) {
+#ifdef MJPC_EMU
+  BBSel cand[24];
+  for (int q = 0; q < 24; q++) cand[q] = bb_candidate(f, q);
+#define BB_CAND(q) cand[q]
+#else
+  const BBSel mine = bb_candidate(f, LANE < 24 ? LANE : 0);
+  auto bb_pick = [&](int q) { BBSel o; o.ok = __builtin_amdgcn_readlane(mine.ok, q); o.x = readlane_d(mine.x, q); o.y = readlane_d(mine.y, q); o.d = readlane_d(mine.d, q); return o; };
+#define BB_CAND(q) bb_pick(q)
+#endif
+  s0.ok = s1.ok = s2.ok = s3.ok = 0;
+  s0.x = s0.y = s0.d = 0; s1 = s0; s2 = s0; s3 = s0;
   double bd = 1e300;
-  for (int q = 0; q < 24; q++) { BBSel cd = bb_candidate(f, q); if (cd.ok && cd.d <= margin && cd.d < bd - BB_TIE_D) { bd = cd.d; s0 = cd; } }
-  if (!s0.ok) return 0;
+  for (int q = 0; q < 24; q++) { BBSel cd = BB_CAND(q); if (cd.ok && cd.d <= margin && cd.d < bd - BB_TIE_D) { bd = cd.d; s0 = cd; } }
+  if (!s0.ok) return;
   double far = 1e-16;
   for (int q = 0; q < 24; q++) {
-    BBSel cd = bb_candidate(f, q);
+    BBSel cd = BB_CAND(q);
     if (cd.ok && cd.d <= margin) { double r2 = (cd.x - s0.x) * (cd.x - s0.x) + (cd.y - s0.y) * (cd.y - s0.y); if (r2 > far + BB_TIE_A) { far = r2; s1 = cd; } }
   }
   if (s1.ok) {
     double lx = s1.x - s0.x, ly = s1.y - s0.y, amx = 1e-12, amn = -1e-12;
     for (int q = 0; q < 24; q++) {
-      BBSel cd = bb_candidate(f, q);
+      BBSel cd = BB_CAND(q);
       if (cd.ok && cd.d <= margin) {
         double ar = lx * (cd.y - s0.y) - ly * (cd.x - s0.x);
         if (ar > amx + BB_TIE_A) { amx = ar; s2 = cd; }
@@ -423,19 +444,23 @@ DEV int np_box_box(NPCon *con, double margin, const double *pa, const double *ma
       }
     }
   }
+#undef BB_CAND
+}
+// the pair's lane again: contacts from the picks
+DEV int bb_face_finish(NPCon *con, const BBPend &pd, const BBSel &s0, const BBSel &s1, const BBSel &s2, const BBSel &s3) {
   int cnt = 0;
 #pragma unroll
   for (int q = 0; q < 4; q++) {
     BBSel cd = q == 0 ? s0 : (q == 1 ? s1 : (q == 2 ? s2 : s3));
     if (!cd.ok) continue;
     NPCon o;
-    double hgt = hn + cd.d - 0.5 * cd.d;
-    o.pos[0] = pr[0] + cd.x * ru[0] + cd.y * rv[0] + hgt * n[0];
-    o.pos[1] = pr[1] + cd.x * ru[1] + cd.y * rv[1] + hgt * n[1];
-    o.pos[2] = pr[2] + cd.x * ru[2] + cd.y * rv[2] + hgt * n[2];
+    double hgt = pd.hn + cd.d - 0.5 * cd.d;
+    o.pos[0] = pd.pr[0] + cd.x * pd.ru[0] + cd.y * pd.rv[0] + hgt * pd.n[0];
+    o.pos[1] = pd.pr[1] + cd.x * pd.ru[1] + cd.y * pd.rv[1] + hgt * pd.n[1];
+    o.pos[2] = pd.pr[2] + cd.x * pd.ru[2] + cd.y * pd.rv[2] + hgt * pd.n[2];
     o.dist = cd.d;
     for (int e = 0; e < 6; e++) o.frame[e] = 0;
-    if (refA) d_copy3(o.frame, n); else d_scl3(o.frame, n, -1);
+    if (pd.refA) d_copy3(o.frame, pd.n); else d_scl3(o.frame, pd.n, -1);
     np_put(con, cnt, o);
     cnt++;
   }
@@ -751,7 +776,7 @@ DEV int np_plane_convex(NPCon *con, double margin, const double *pp, const doubl
 // Only the out-of-line flavour of the narrow-phase batch (narrow_batch<true>) contains this code: the batch loop of
 // collision() itself stays free of it and of any call inside the loop body's live ranges.
 struct NPOut { NPCon c[4]; int n; };
-DEV NPOut narrow_heavy(Ctx &c, int g1, int g2, double margin) {
+DEV NPOut narrow_heavy(Ctx &c, int g1, int g2, double margin, BBPend &pend) {
   const DevModel &M = *c.M;
   NPOut o;
   int t1 = MI(geom_type)[g1], t2 = MI(geom_type)[g2];
@@ -761,7 +786,7 @@ DEV NPOut narrow_heavy(Ctx &c, int g1, int g2, double margin) {
   d_copy3(s1, MD(geom_size) + 3 * g1); d_copy3(s2, MD(geom_size) + 3 * g2);
   o.n = -1;
   if (t1 == 3 && t2 == 6) o.n = np_capsule_box(o.c, margin, p1, m1, s1, p2, m2, s2);
-  else if (t1 == 6 && t2 == 6) o.n = np_box_box(o.c, margin, p1, m1, s1, p2, m2, s2);
+  else if (t1 == 6 && t2 == 6) o.n = np_box_box(o.c, margin, p1, m1, s1, p2, m2, s2, pend);
   else if (t1 == 2 && t2 == 5) o.n = np_sphere_cylinder(o.c, margin, p1, s1[0], p2, m2, s2);
   else if (t1 == 3 && t2 == 5) o.n = np_capsule_cylinder(o.c, margin, p1, m1, s1, p2, m2, s2);
   else if (t1 == 1 && t2 >= 2) {
@@ -863,15 +888,16 @@ DEV int narrow_phase(Ctx &c, int g1, int g2, double margin, NPCon *con) {
   return (cyl && n > 0) ? -2 : n;
 }
 
-DEV void contact_param(Ctx &c, int g1, int g2, double *cc, int *dim) {
+// contact parameters of a geom pair (mj_contactParam): prm = [friction 5, solref 2, solimp 5]; once per pair, not per contact
+DEV void contact_param(Ctx &c, int g1, int g2, double *prm, int *dim) {
   const DevModel &M = *c.M; (void)M;
   int p1 = MI(geom_priority)[g1], p2 = MI(geom_priority)[g2];
   double fri[3];
   if (p1 != p2) {
     int g = p1 > p2 ? g1 : g2;
     *dim = MI(geom_condim)[g];
-    for (int i = 0; i < 2; i++) cc[CON_SOLREF + i] = MD(geom_solref)[2 * g + i];
-    for (int i = 0; i < 5; i++) cc[CON_SOLIMP + i] = MD(geom_solimp)[5 * g + i];
+    for (int i = 0; i < 2; i++) prm[5 + i] = MD(geom_solref)[2 * g + i];
+    for (int i = 0; i < 5; i++) prm[7 + i] = MD(geom_solimp)[5 * g + i];
     d_copy3(fri, MD(geom_friction) + 3 * g);
   } else {
     int d1 = MI(geom_condim)[g1], d2 = MI(geom_condim)[g2];
@@ -884,13 +910,12 @@ DEV void contact_param(Ctx &c, int g1, int g2, double *cc, int *dim) {
     double r10 = MD(geom_solref)[2 * g1], r20 = MD(geom_solref)[2 * g2];
     for (int i = 0; i < 2; i++) {
       double a = MD(geom_solref)[2 * g1 + i], b = MD(geom_solref)[2 * g2 + i];
-      cc[CON_SOLREF + i] = (r10 > 0 && r20 > 0) ? mix * a + (1 - mix) * b : fmin(a, b);
+      prm[5 + i] = (r10 > 0 && r20 > 0) ? mix * a + (1 - mix) * b : fmin(a, b);
     }
-    for (int i = 0; i < 5; i++) cc[CON_SOLIMP + i] = mix * MD(geom_solimp)[5 * g1 + i] + (1 - mix) * MD(geom_solimp)[5 * g2 + i];
+    for (int i = 0; i < 5; i++) prm[7 + i] = mix * MD(geom_solimp)[5 * g1 + i] + (1 - mix) * MD(geom_solimp)[5 * g2 + i];
     for (int i = 0; i < 3; i++) fri[i] = fmax(MD(geom_friction)[3 * g1 + i], MD(geom_friction)[3 * g2 + i]);
   }
-  cc[CON_FRICTION] = fri[0]; cc[CON_FRICTION + 1] = fri[0]; cc[CON_FRICTION + 2] = fri[1];
-  cc[CON_FRICTION + 3] = fri[2]; cc[CON_FRICTION + 4] = fri[2];
+  prm[0] = fri[0]; prm[1] = fri[0]; prm[2] = fri[1]; prm[3] = fri[2]; prm[4] = fri[2];
 }
 
 // one batch of (at most) NLANE active pairs: narrow phase per lane, ordered compaction, contact records.
@@ -902,19 +927,49 @@ DEV int narrow_batch(Ctx &c, int base, int nactive, int *used_heavy = nullptr) {
   int a = base + LANE, n = 0, g1 = 0, g2 = 0;
   double margin = 0, gap = 0;
   NPCon con[4] = {};
+  BBPend pend; pend.refA = 0;
   if (a < nactive) {
     const int gg = c.active[a];           // (the broad phase leaves the pair's two geoms in the list, not its index)
     g1 = gg & 0xffff; g2 = (int)((unsigned)gg >> 16);
     margin = fmax(MD(geom_margin)[g1], MD(geom_margin)[g2]);
     gap = fmax(MD(geom_gap)[g1], MD(geom_gap)[g2]);
     n = narrow_phase(c, g1, g2, margin, con);
+#if defined(MJPC_PROFILE_COLLISION) && MJPC_PROFILE_COLLISION == 2
+    if constexpr (HEAVY) PROF(c, 10);
+#endif
     if constexpr (HEAVY) {
       if (n == -2 && used_heavy) *used_heavy = 1;
       if (n == -2) {
-        NPOut h = narrow_heavy(c, g1, g2, margin);
+        NPOut h = narrow_heavy(c, g1, g2, margin, pend);
         n = h.n; con[0] = h.c[0]; con[1] = h.c[1]; con[2] = h.c[2]; con[3] = h.c[3];
       }
-      if (n < 0) { c.warning |= WARN_UNSUPPORTED; n = 0; }      // lane-local here; made wave-uniform below
+      if (n < 0 && n != -3) { c.warning |= WARN_UNSUPPORTED; n = 0; }      // lane-local here; made wave-uniform below
+    }
+  }
+#if defined(MJPC_PROFILE_COLLISION) && MJPC_PROFILE_COLLISION == 2
+  if constexpr (HEAVY) PROF(c, 16);
+#endif
+  if constexpr (HEAVY) {
+    // box pairs in their face case, one after the other with the whole wave (bb_face_select): the pair's lane hands its face
+    // problem round, takes the picks back
+#ifdef MJPC_EMU
+    unsigned long long todo = n == -3 ? 1ull : 0ull;
+#else
+    unsigned long long todo = __builtin_amdgcn_ballot_w64(n == -3);
+#endif
+    while (todo) {
+      const int L = __builtin_ctzll(todo);
+      todo &= todo - 1;
+      BBFace f; double mg;
+#ifdef MJPC_EMU
+      f = pend.f; mg = margin;
+#else
+      for (int k = 0; k < 3; k++) { f.c0[k] = readlane_d(pend.f.c0[k], L); f.e1[k] = readlane_d(pend.f.e1[k], L); f.e2[k] = readlane_d(pend.f.e2[k], L); }
+      f.hu = readlane_d(pend.f.hu, L); f.hv = readlane_d(pend.f.hv, L); f.det = readlane_d(pend.f.det, L); mg = readlane_d(margin, L);
+#endif
+      BBSel s0, s1, s2, s3;
+      bb_face_select(f, mg, s0, s1, s2, s3);
+      if (LANE == L) n = bb_face_finish(con, pend, s0, s1, s2, s3);
     }
   }
   if constexpr (HEAVY) c.warning = wave_or_i(c.warning);
@@ -924,12 +979,17 @@ DEV int narrow_batch(Ctx &c, int base, int nactive, int *used_heavy = nullptr) {
   // with them (the candidate fails at the end of the step, but its constraint stage sees what the CPU path sees)
   const int full = c.ncon + tot > M.nconmax;
   if (full) c.warning |= WARN_CONTACTFULL;
+  double prm[12]; int dim = 0;
+  if (n > 0) contact_param(c, g1, g2, prm, &dim);
   for (int k = 0; k < n; k++) {
     int ci = c.ncon + off + k;
     if (ci >= M.nconmax) break;
     double *cc = c.contact + ci * c.M->con_stride;
-    int dim;
-    contact_param(c, g1, g2, cc, &dim);
+#pragma unroll
+    for (int q = 0; q < 5; q++) cc[CON_FRICTION + q] = prm[q];
+    cc[CON_SOLREF] = prm[5]; cc[CON_SOLREF + 1] = prm[6];
+#pragma unroll
+    for (int q = 0; q < 5; q++) cc[CON_SOLIMP + q] = prm[7 + q];
     const NPCon cur = np_get(con, k);
     double fr[9];
     for (int q = 0; q < 6; q++) fr[q] = cur.frame[q];
@@ -1000,7 +1060,7 @@ DEV void collision(Ctx &c) {
   }
   if (nactive > MAX_ACTIVE_PAIRS) { c.warning |= WARN_CONTACTFULL; nactive = MAX_ACTIVE_PAIRS; }
   SYNC();
-#ifdef MJPC_PROFILE_COLLISION      // (diagnostic build: broad phase / cheap batches / out-of-line batches in the slots a pyramidal model leaves empty)
+#if defined(MJPC_PROFILE_COLLISION) && MJPC_PROFILE_COLLISION == 1      // (diagnostic build: broad phase / cheap batches / out-of-line batches in the slots a pyramidal model leaves empty; level 2: inside the out-of-line batch - cheap colliders / out-of-line colliders / the rest)
   PROF(c, 10);
 #endif
   // (2) narrow phase, one lane per active pair, contacts appended in pair order.  The loop only knows the cheap colliders; at
@@ -1016,8 +1076,10 @@ DEV void collision(Ctx &c) {
       if (st != 0) break;
     }
   int again = 0;
-#ifdef MJPC_PROFILE_COLLISION
+#if defined(MJPC_PROFILE_COLLISION) && MJPC_PROFILE_COLLISION == 1
   PROF(c, 16);
+#else
+  PROF(c, 4);
 #endif
   if (heavy_from >= 0) {
     BatchOut o = narrow_rest_heavy(c.K, heavy_from, nactive, c.ncon, c.warning);

@@ -96,45 +96,145 @@ DEV void ns_small_chol_solve(double *x, const double *L, const double *dinv, con
     x[i] = s * dinv[i];
   }
 }
+// mju_QCQP for N > 3.  The reference factors A + la I afresh in each of its (up to 20) Newton iterations on the multiplier - on a
+// pinch grasp it runs 17 of them per call, its absolute tolerance 1e-10 is rarely met earlier - and a 5 x 5 Cholesky with two
+// solves is one dependent chain of ~300 operations.  Here only the first iteration (la = 0: the rank test, the "already inside
+// the cone" exit) is done that way; then A = Q T Q' is reduced to tridiagonal form once (three Householder reflections) and
+// every further iteration solves with T + la I in O(N): the same function of la, so the same iterates up to rounding, at an
+// eighth of the chain.  (|v| = |Q'v|: the norm and the derivative are taken in the rotated frame, v = Q y at the end.)
 template <int N>
 DEV void ns_qcqpn(double *res, const double *Ain, const double *bin, const double *d, double r) {
-  double A[N * N], Ala[N * N], b[N], tmp[N], dinv[N], la = 0;
+  double A[N * N], L[N * N], b[N], v[N], tmp[N], dinv[N], la = 0;
 #pragma unroll
   for (int i = 0; i < N; i++) {
     b[i] = bin[i] * d[i];
 #pragma unroll
     for (int j = 0; j < N; j++) A[j + i * N] = Ain[j + i * N] * d[i] * d[j];
   }
-#ifndef NS_EXP_ITERS
-#define NS_EXP_ITERS 20
-#endif
-  for (int iter = 0; iter < NS_EXP_ITERS; iter++) {
+  // ---- iteration 0, as the reference does it
 #pragma unroll
-    for (int i = 0; i < N * N; i++) Ala[i] = A[i];
+  for (int i = 0; i < N * N; i++) L[i] = A[i];
+  if (ns_small_chol<N>(L, dinv, 1e-10) < N) {
 #pragma unroll
-    for (int i = 0; i < N; i++) Ala[i * (N + 1)] += la;
-    if (ns_small_chol<N>(Ala, dinv, 1e-10) < N) {
+    for (int i = 0; i < N; i++) res[i] = 0;
+    return;
+  }
+  ns_small_chol_solve<N>(v, L, dinv, b);
+  double val = 0;
 #pragma unroll
-      for (int i = 0; i < N; i++) res[i] = 0;
-      return;
-    }
-    ns_small_chol_solve<N>(res, Ala, dinv, b);
-    double val = 0;
-#pragma unroll
-    for (int i = 0; i < N; i++) { res[i] = -res[i]; val += res[i] * res[i]; }
-    val -= r * r;
-    if (val < 1e-10) break;
-    ns_small_chol_solve<N>(tmp, Ala, dinv, res);
+  for (int i = 0; i < N; i++) { v[i] = -v[i]; val += v[i] * v[i]; }
+  val -= r * r;
+  int go = !(val < 1e-10);
+  if (go) {
+    ns_small_chol_solve<N>(tmp, L, dinv, v);
     double deriv = 0;
 #pragma unroll
-    for (int i = 0; i < N; i++) deriv += res[i] * tmp[i];
+    for (int i = 0; i < N; i++) deriv += v[i] * tmp[i];
     deriv *= -2;
     double delta = d_div(-val, deriv);
-    if (delta < 1e-10) break;
-    la += delta;
+    if (delta < 1e-10) go = 0; else la = delta;
+  }
+  if (go) {
+    // ---- A = Q T Q' (Householder, lower triangle), c = Q' b
+    double hv[(N - 2) * N], hb[N - 2], c[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) c[i] = b[i];
+#pragma unroll
+    for (int k = 0; k < N - 2; k++) {
+      double x2 = 0;
+#pragma unroll
+      for (int i = k + 2; i < N; i++) x2 += A[i * N + k] * A[i * N + k];
+      const double x0 = A[(k + 1) * N + k];
+      const double nrm2 = x0 * x0 + x2;
+      const double nrm = nrm2 * fast_rsqrt(nrm2);
+      const double alpha = x0 > 0 ? -nrm : nrm;
+      const int skip = !(x2 > 0);                 // already tridiagonal in this column
+#pragma unroll
+      for (int i = 0; i < N; i++) hv[k * N + i] = (i > k && !skip) ? A[i * N + k] : 0.0;
+      if (!skip) hv[k * N + k + 1] = x0 - alpha;
+      double vv = 0;
+#pragma unroll
+      for (int i = k + 1; i < N; i++) vv += hv[k * N + i] * hv[k * N + i];
+      const double beta = skip ? 0.0 : 2.0 * fast_rcp(vv);
+      hb[k] = beta;
+      // p = beta A v, K = beta/2 v'p, w = p - K v, A -= v w' + w v'   (trailing block; symmetric storage kept full)
+      double pw[N];
+      double vp = 0;
+#pragma unroll
+      for (int i = k + 1; i < N; i++) {
+        double t = 0;
+#pragma unroll
+        for (int j = k + 1; j < N; j++) t += A[i * N + j] * hv[k * N + j];
+        pw[i] = beta * t; vp += hv[k * N + i] * pw[i];
+      }
+      const double K = 0.5 * beta * vp;
+#pragma unroll
+      for (int i = k + 1; i < N; i++) pw[i] -= K * hv[k * N + i];
+#pragma unroll
+      for (int i = k + 1; i < N; i++)
+#pragma unroll
+        for (int j = k + 1; j < N; j++) A[i * N + j] -= hv[k * N + i] * pw[j] + pw[i] * hv[k * N + j];
+      if (!skip) {
+        A[(k + 1) * N + k] = alpha; A[k * N + k + 1] = alpha;
+#pragma unroll
+        for (int i = k + 2; i < N; i++) { A[i * N + k] = 0; A[k * N + i] = 0; }
+      }
+      double vc = 0;
+#pragma unroll
+      for (int i = k + 1; i < N; i++) vc += hv[k * N + i] * c[i];
+#pragma unroll
+      for (int i = k + 1; i < N; i++) c[i] -= beta * vc * hv[k * N + i];
+    }
+    double td[N], te[N], y[N], z[N], rp[N], lf[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) { td[i] = A[i * N + i]; te[i] = i + 1 < N ? A[(i + 1) * N + i] : 0.0; }
+    // ---- iterations 1 .. 19 in the rotated frame
+    for (int iter = 1; iter < 20; iter++) {
+      // T + la I = L D L': pivots and their reciprocals
+      double piv = td[0] + la;
+      rp[0] = fast_rcp(piv); lf[0] = 0;
+#pragma unroll
+      for (int i = 1; i < N; i++) { lf[i] = te[i - 1] * rp[i - 1]; piv = td[i] + la - lf[i] * te[i - 1]; rp[i] = fast_rcp(piv); }
+      // y = -(T + la)^-1 c
+      y[0] = -c[0];
+#pragma unroll
+      for (int i = 1; i < N; i++) y[i] = -c[i] - lf[i] * y[i - 1];
+      y[N - 1] *= rp[N - 1];
+#pragma unroll
+      for (int i = N - 2; i >= 0; i--) y[i] = (y[i] - te[i] * y[i + 1]) * rp[i];
+      val = 0;
+#pragma unroll
+      for (int i = 0; i < N; i++) val += y[i] * y[i];
+      val -= r * r;
+      if (val < 1e-10) break;
+      z[0] = y[0];
+#pragma unroll
+      for (int i = 1; i < N; i++) z[i] = y[i] - lf[i] * z[i - 1];
+      z[N - 1] *= rp[N - 1];
+#pragma unroll
+      for (int i = N - 2; i >= 0; i--) z[i] = (z[i] - te[i] * z[i + 1]) * rp[i];
+      double deriv = 0;
+#pragma unroll
+      for (int i = 0; i < N; i++) deriv += y[i] * z[i];
+      deriv *= -2;
+      double delta = d_div(-val, deriv);
+      if (delta < 1e-10) break;
+      la += delta;
+    }
+    // v = Q y: the reflections in reverse order
+#pragma unroll
+    for (int i = 0; i < N; i++) v[i] = y[i];
+#pragma unroll
+    for (int k = N - 3; k >= 0; k--) {
+      double vy = 0;
+#pragma unroll
+      for (int i = k + 1; i < N; i++) vy += hv[k * N + i] * v[i];
+#pragma unroll
+      for (int i = k + 1; i < N; i++) v[i] -= hb[k] * vy * hv[k * N + i];
+    }
   }
 #pragma unroll
-  for (int i = 0; i < N; i++) res[i] = res[i] * d[i];
+  for (int i = 0; i < N; i++) res[i] = v[i] * d[i];
 }
 // cost change of a block update; an update that raises the cost is taken back (costChange)
 template <int DIM>

@@ -28,20 +28,16 @@ def lib():
     if _lib is None:
         csrc = os.path.join(ROOT, "mujoco_mpc_amd", "csrc")
         srcs = [os.path.join(EMU_DIR, "emu.cpp")] + [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".h")]
-        so = EMU_SO
-        if os.environ.get("MJPC_EMU_ASAN"):       # memory-checked build of the kernel source: LD_PRELOAD=$(gcc -print-file-name=libasan.so) MJPC_EMU_ASAN=1 pytest ...
-            so = EMU_SO[:-3] + "_asan.so"
-            subprocess.check_call(["g++", "-O1", "-g", "-fsanitize=address", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=off", "-o", so,
-                                   os.path.join(EMU_DIR, "emu.cpp")])
-        else:
-            import fcntl
-            with open(os.path.join(EMU_DIR, ".build.lock"), "w") as lock:      # pytest-xdist workers: one builds, the others wait
-                fcntl.flock(lock, fcntl.LOCK_EX)
-                if (not os.path.exists(EMU_SO)) or any(os.path.getmtime(s) > os.path.getmtime(EMU_SO) for s in srcs):
-                    tmp = EMU_SO + f".{os.getpid()}.tmp"
-                    subprocess.check_call(["g++", "-O2", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=off", "-o", tmp,
-                                           os.path.join(EMU_DIR, "emu.cpp")])
-                    os.replace(tmp, EMU_SO)
+        asan = bool(os.environ.get("MJPC_EMU_ASAN"))      # memory-checked build of the kernel source: LD_PRELOAD=$(gcc -print-file-name=libasan.so) MJPC_EMU_ASAN=1 pytest ...
+        so = EMU_SO[:-3] + "_asan.so" if asan else EMU_SO
+        flags = ["-O1", "-g", "-fsanitize=address"] if asan else ["-O2"]
+        import fcntl
+        with open(os.path.join(EMU_DIR, ".build.lock"), "w") as lock:      # pytest-xdist workers: one builds, the others wait
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            if (not os.path.exists(so)) or any(os.path.getmtime(s_) > os.path.getmtime(so) for s_ in srcs):
+                tmp = so + f".{os.getpid()}.tmp"
+                subprocess.check_call(["g++"] + flags + ["-fPIC", "-shared", "-std=c++17", "-ffp-contract=off", "-o", tmp, os.path.join(EMU_DIR, "emu.cpp")])
+                os.replace(tmp, so)
         _lib = C.CDLL(so)
         _lib.emu_plan.argtypes = [C.POINTER(capi.MjpcHipModel), C.POINTER(capi.MjpcHipTask),
                                   C.POINTER(capi.MjpcHipPlanInput), C.POINTER(EmuOut)]

@@ -27,6 +27,7 @@ typedef void (*RolloutFn)(const KParams);
 extern "C" RolloutFn mjpc_pick_rollout_cached(int nv, int *exact);
 extern "C" RolloutFn mjpc_pick_rollout_direct(int nv, int *exact);
 extern "C" RolloutFn mjpc_pick_rollout_dense2(int nv, int *exact);
+extern "C" RolloutFn mjpc_pick_rollout_dense2h(int nv, int *exact);
 extern "C" int mjpc_rollout_threads_cached(void);
 
 // Capacity tiers.  One candidate per CU leaves every SIMD with a single, mostly stalled wave; two resident workgroups per CU
@@ -38,6 +39,7 @@ extern "C" int mjpc_rollout_threads_cached(void);
 #define TIERB_NEFCMAX 128    // first capacity tried for the dense tier (rows); contacts = rows / 4 + 2
 #define TIERB_NEFCMIN 40
 #define TIERB_LDS_LIMIT (80 * 1024)
+#define TIERB_HOT_KEEP 75       // per cent of the plain dense tier's rows the hot-cached variant must still hold to be preferred
 
 // eps[r, e] for global candidate (offset + r), element e = p*nu + k; sel[r] = second-std choice
 extern "C" __global__ void noise_kernel(double *eps, int *sel, unsigned long long seed, unsigned long long stream,
@@ -141,7 +143,7 @@ struct MjpcHipEngine {
   int summary_only = 0, last_summary = 0;      // mjpc_hip_set_fetch_mode
   int last_dense = 0;
   // dense tier (two workgroups per CU), see "Capacity tiers" above
-  RolloutFn kernelB = nullptr; Lay layB; int nefcB = 0, nconB = 0; size_t ldsB = 0; int num_cu = 256, force_tier = 0;
+  RolloutFn kernelB = nullptr; Lay layB; int nefcB = 0, nconB = 0, cacheB_i = 0, cacheB_d = 0; size_t ldsB = 0; int num_cu = 256, force_tier = 0;
 };
 
 static int upload_model(MjpcHipEngine *e) {
@@ -208,16 +210,28 @@ MjpcHipEngine *mjpc_hip_create(const MjpcHipModel *model, const MjpcHipTask *tas
         if (sscanf(cap.c_str(), "%d,%d", &a, &b) == 2 && a > 0 && b > 0 && a <= e->pm.M.nefcmax && b <= e->pm.M.nconmax) { cap_e = a; cap_c = b; }
       }
       int first = e->pm.M.nefcmax < TIERB_NEFCMAX ? e->pm.M.nefcmax : TIERB_NEFCMAX;
-      for (int ne = cap_e ? cap_e : first; ne >= (cap_e ? cap_e : TIERB_NEFCMIN) && !e->kernelB; ne -= 4) {
-        MjpcHipModel mb = *model;
-        mb.nefcmax = ne; mb.nconmax = cap_e ? cap_c : ne / 4 + 2;
-        if (mb.nconmax > e->pm.M.nconmax) mb.nconmax = e->pm.M.nconmax;
-        PackedModel pmB;
-        if (mjpc_host::build(pmB, &mb, task, e->P_max, false, true, false, true) && (size_t)pmB.L.total_doubles * sizeof(double) <= TIERB_LDS_LIMIT) {
-          e->kernelB = kb; e->layB = pmB.L; e->nefcB = pmB.M.nefcmax; e->nconB = pmB.M.nconmax;
-          e->ldsB = (size_t)pmB.L.total_doubles * sizeof(double);
+      // two variants of the flavour: with the hot prefix of the tables in LDS (rollout_dense2h.hip; costs capacity) and without.
+      // The hot-cached one is taken when it exists for this dof count and still holds TIERB_HOT_KEEP of the plain one's rows
+      int exact_h = 0;
+      RolloutFn kh = mjpc_pick_rollout_dense2h(model->nv, &exact_h);
+      struct Cand { RolloutFn k = nullptr; Lay lay; int nefc = 0, ncon = 0, ci = 0, cd = 0; size_t lds = 0; } plain, hot;
+      for (int variant = 0; variant < 2; variant++) {
+        Cand &cd = variant ? hot : plain;
+        if (variant && (!exact_h || cap_e)) break;          // (a forced tiny tier is the plain flavour's test case)
+        for (int ne = cap_e ? cap_e : first; ne >= (cap_e ? cap_e : TIERB_NEFCMIN) && !cd.k; ne -= 4) {
+          MjpcHipModel mb = *model;
+          mb.nefcmax = ne; mb.nconmax = cap_e ? cap_c : ne / 4 + 2;
+          if (mb.nconmax > e->pm.M.nconmax) mb.nconmax = e->pm.M.nconmax;
+          PackedModel pmB;
+          if (mjpc_host::build(pmB, &mb, task, e->P_max, false, true, variant == 1, true) && (size_t)pmB.L.total_doubles * sizeof(double) <= TIERB_LDS_LIMIT) {
+            cd.k = variant ? kh : kb; cd.lay = pmB.L; cd.nefc = pmB.M.nefcmax; cd.ncon = pmB.M.nconmax;
+            cd.ci = (int)pmB.cache_i; cd.cd = (int)pmB.cache_d;
+            cd.lds = (size_t)pmB.L.total_doubles * sizeof(double);
+          }
         }
       }
+      const Cand &use = (hot.k && plain.k && hot.nefc * 100 >= plain.nefc * TIERB_HOT_KEEP) ? hot : plain;
+      if (use.k) { e->kernelB = use.k; e->layB = use.lay; e->nefcB = use.nefc; e->nconB = use.ncon; e->cacheB_i = use.ci; e->cacheB_d = use.cd; e->ldsB = use.lds; }
     }
     std::string tier, fi;                                 // diagnostics knobs: "A" = never the dense tier, "B" = always (when it exists)
     e->force_tier = mjpc_host::debug_knob("tier", &tier) ? (tier[0] == 'B' ? 2 : 1) : 0;
@@ -392,7 +406,7 @@ int mjpc_hip_plan_async(MjpcHipEngine *e, const MjpcHipPlanInput *in) {
   const bool dense = e->kernelB && e->force_tier != 1 && (nl > e->num_cu || e->force_tier == 2) && !(in->xfrc_std > 0);   // (the lean layout has no body-force block)
   if (dense) {
     KParams KB = K;
-    KB.M.nefcmax = e->nefcB; KB.M.nconmax = e->nconB; KB.L = e->layB; KB.cache_i = 0; KB.cache_d = 0; KB.tier = 1;
+    KB.M.nefcmax = e->nefcB; KB.M.nconmax = e->nconB; KB.L = e->layB; KB.cache_i = e->cacheB_i; KB.cache_d = e->cacheB_d; KB.tier = 1;
     hipLaunchKernelGGL(e->kernelB, dim3(nl), dim3(mjpc_rollout_threads_cached()), e->ldsB, e->stream, KB);
     K.retry = 1;                       // full capacity for whoever overflowed the dense tier (usually nobody: the launch drains at once)
   }

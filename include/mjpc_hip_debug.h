@@ -17,6 +17,9 @@
 extern "C" {
 #endif
 void mjpc_hip_debug_set(const char *name, const char *value);
+/* Capacity of the engine's dense tier (rows, contacts; 0, 0 without one); *hot = 1 when it is the variant with the hot tables in
+   LDS (rollout_dense2h.hip).  Diagnostics / tests only. */
+void mjpc_hip_debug_dense_capacity(struct MjpcHipEngine *e, int *nefc, int *ncon, int *hot);
 #ifdef __cplusplus
 }
 #endif

@@ -262,6 +262,7 @@ def load_engine():
     lib.mjpc_hip_layout_bytes.argtypes = [C.POINTER(MjpcHipModel), C.POINTER(MjpcHipTask), C.c_int]
     lib.mjpc_hip_set_fetch_mode.argtypes = [C.c_void_p, C.c_int]
     lib.mjpc_hip_dense_tier.argtypes = [C.c_void_p, c_int_p]
+    lib.mjpc_hip_debug_dense_capacity.argtypes = [C.c_void_p, c_int_p, c_int_p, c_int_p]; lib.mjpc_hip_debug_dense_capacity.restype = None
     lib.mjpc_hip_multi_create.restype = C.c_void_p
     lib.mjpc_hip_multi_create.argtypes = [C.POINTER(MjpcHipModel), C.POINTER(MjpcHipTask), C.c_int, C.c_int, C.c_int, c_int_p]
     lib.mjpc_hip_multi_destroy.argtypes = [C.c_void_p]
@@ -301,7 +302,7 @@ EXPORTED_SYMBOLS = [
     "mjpc_hip_create", "mjpc_hip_destroy", "mjpc_hip_set_task", "mjpc_hip_plan", "mjpc_hip_plan_async",
     "mjpc_hip_plan_fetch", "mjpc_hip_get_candidate", "mjpc_hip_kernel_time", "mjpc_hip_device_ptrs",
     "mjpc_hip_last_error", "mjpc_hip_version", "mjpc_hip_get_knots", "mjpc_hip_get_frame",
-    "mjpc_hip_get_traces", "mjpc_hip_get_all_candidates", "mjpc_hip_lds_bytes", "mjpc_hip_layout_bytes", "mjpc_hip_set_fetch_mode", "mjpc_hip_dense_tier",
+    "mjpc_hip_get_traces", "mjpc_hip_get_all_candidates", "mjpc_hip_lds_bytes", "mjpc_hip_layout_bytes", "mjpc_hip_set_fetch_mode", "mjpc_hip_dense_tier", "mjpc_hip_debug_dense_capacity",
     "mjpc_hip_multi_create", "mjpc_hip_multi_destroy", "mjpc_hip_multi_set_task", "mjpc_hip_multi_plan", "mjpc_hip_multi_get_candidate",
     "mjpc_hip_multi_get_knots", "mjpc_hip_multi_get_traces", "mjpc_hip_multi_num_devices", "mjpc_hip_multi_engine",
 ]

@@ -575,6 +575,11 @@ int mjpc_hip_get_all_candidates(MjpcHipEngine *e, double *states, double *action
 }
 
 int mjpc_hip_lds_bytes(MjpcHipEngine *e) { return e ? (int)e->lds_bytes : 0; }
+void mjpc_hip_debug_dense_capacity(MjpcHipEngine *e, int *nefc, int *ncon, int *hot) {
+  if (nefc) *nefc = (e && e->kernelB) ? e->nefcB : 0;
+  if (ncon) *ncon = (e && e->kernelB) ? e->nconB : 0;
+  if (hot) *hot = (e && e->kernelB && e->cacheB_d > 0) ? 1 : 0;
+}
 // LDS bytes of the dense (two workgroups per CU) tier, 0 when the model has none; *used_last = 1 when the last plan ran on it
 int mjpc_hip_dense_tier(MjpcHipEngine *e, int *used_last) {
   if (!e) return 0;

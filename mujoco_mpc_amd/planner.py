@@ -126,6 +126,12 @@ class HipBackend:
         n = self.lib.mjpc_hip_dense_tier(self.h, C.byref(used))
         return n, bool(used.value)
 
+    def dense_capacity(self):
+        """(rows, contacts, hot tables in LDS) of the dense tier; (0, 0, False) without one.  Diagnostics."""
+        a = C.c_int(0); b = C.c_int(0); h = C.c_int(0)
+        self.lib.mjpc_hip_debug_dense_capacity(self.h, C.byref(a), C.byref(b), C.byref(h))
+        return a.value, b.value, bool(h.value)
+
     def kernel_time(self):
         a = C.c_double(0); b = C.c_double(0)
         n = self.lib.mjpc_hip_kernel_time(self.h, C.byref(a), C.byref(b))

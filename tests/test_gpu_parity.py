@@ -1110,6 +1110,20 @@ def test_closed_loop_shadow_hand_and_its_transition():
 
 
 @pytest.mark.gpu
+def test_dense_tier_variant_is_picked_by_capacity():
+    """engine.hip: the dense tier comes with the hot tables in LDS (rollout_dense2h) where that still leaves 75 % of the plain
+    variant's rows - the A1 - and without them where it does not (humanoid) or where no such kernel exists (hand)."""
+    from mujoco_mpc_amd.modelgen import humanoid_track, shadow_hand
+    caps = {}
+    for name, gen in (("quadruped", quadruped), ("humanoid", humanoid_track), ("hand", shadow_hand)):
+        m, task, d = gen()
+        be = HipBackend(m, task, max_samples=8, max_horizon=8)
+        caps[name] = be.dense_capacity()
+        be.close()
+    assert caps["quadruped"][2] and caps["quadruped"][0] >= 80, caps                  # the bench workload peaks at 66 rows / 14 contacts
+    assert not caps["humanoid"][2] and caps["humanoid"][0] >= 40 and not caps["hand"][2] and caps["hand"][0] >= 80, caps
+
+
 def test_closed_loop_fingers_reach_the_object():
     """testspeed loop (testspeed.cc:44-129) on the Fingers task with the task file's agent settings (5 spline points, exploration
     0.04, 0.5 s horizon; 128 rollouts): from the home key the object drops onto the floor and both fingers, 10 cm to either side,

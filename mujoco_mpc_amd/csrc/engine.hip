@@ -200,7 +200,9 @@ MjpcHipEngine *mjpc_hip_create(const MjpcHipModel *model, const MjpcHipTask *tas
     // layout of <= 80 KiB
     int exact_b = 0;
     RolloutFn kb = mjpc_pick_rollout_dense2(model->nv, &exact_b);
-    if (exact_b) {
+    // (a model with a noslip pass runs at full capacity only: the pass recomputes qacc from efc_force, and the last commit's
+    // force bits - unlike the iterate - are not pinned across kernel flavours, so the tiers would agree to rounding, not bit for bit)
+    if (exact_b && model->noslip_iterations <= 0) {
       // capacity of the dense tier: the largest (rows, contacts = rows / 4 + 2) not above the model's own whose lean layout fits
       // 80 KiB; below 40 rows the retry pass would be the rule, not the exception
       int cap_e = 0, cap_c = 0;

@@ -1051,16 +1051,18 @@ def test_cpp_sampling_planner_sharded_over_engines_matches_the_unsharded_planner
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("workload", ["quadruped", "humanoid"])
+@pytest.mark.parametrize("workload", ["quadruped", "humanoid", "quadruped_noslip"])
 def test_dense_tier_is_bit_identical_to_full_capacity_and_retries_what_overflows(debug_knobs, workload):
     """Capacity tiers (engine.hip): more candidates than CUs -> the two-workgroups-per-CU flavour (<= 80 KiB of LDS, smaller
     contact / row buffers) runs first and the full-capacity kernel re-runs whatever overflowed.  Returns, failure flags, winner
     and every trajectory must equal the full-capacity-only plan bit for bit - also when the dense tier is made so small
     (test knob) that most candidates overflow it and take the retry pass."""
     # (the lean layout overlays the inertia / RNE intermediates with the solver's scaled rows: any lifetime overlap would show here)
-    m, task, d = quadruped() if workload == "quadruped" else humanoid_track()
-    N, H, P = (300, 40, 3) if workload == "quadruped" else (280, 48, 6)
-    sigma, tiny, rows = (0.04, "40,8", 40) if workload == "quadruped" else (0.15, "24,8", 24)
+    m, task, d = humanoid_track() if workload == "humanoid" else quadruped()
+    if workload == "quadruped_noslip":          # a noslip pass keeps the model off the dense tier
+        m = dict(m, noslip_iterations=3)
+    N, H, P = (280, 48, 6) if workload == "humanoid" else (300, 40, 3)
+    sigma, tiny, rows = (0.15, "24,8", 24) if workload == "humanoid" else (0.04, "40,8", 40)
     kt = np.linspace(0, (H - 1) * m["timestep"], P); kv = np.zeros((P, m["nu"]))
     kw = dict(state=d["state"], mocap=d["mocap"], time=0.0, knot_times=kt, knot_values=kv, interpolation=2, num_trajectory=N,
               horizon=H, sigma=(sigma, 0.0), seed=0x5EED, stream=7)
@@ -1075,6 +1077,11 @@ def test_dense_tier_is_bit_identical_to_full_capacity_and_retries_what_overflows
         lds, used = be.dense_tier()
         res[name] = (out, be.fetch_all(N, H, P), lds, used)
         be.close()
+    if workload == "quadruped_noslip":
+        # no dense tier for a model with a noslip pass (engine.hip): every variant above ran the full-capacity kernel
+        assert all(r[2] == 0 and r[3] is False for r in res.values())
+        assert np.array_equal(res["full"][1]["states"], res["auto"][1]["states"]) and np.array_equal(res["full"][1]["states"], res["tiny"][1]["states"])
+        return
     assert res["full"][3] is False and res["auto"][3] is True and res["tiny"][3] is True
     assert 0 < res["auto"][2] <= 80 * 1024
     assert not res["full"][0]["failure"].any()
